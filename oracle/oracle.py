@@ -1,0 +1,241 @@
+"""ctypes front end of the CPU oracle (oracle/mdapy_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py — never by the mdapy_amd product package.
+
+The functions mirror the Python-visible signatures of the reference's nanobind
+modules so parity tests read like the reference's own tests:
+caller-allocated, caller-initialised numpy outputs and a trailing ``num_t``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmdapy_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "mdapy_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a, dtype):
+    """pointer to a C-contiguous array of the exact dtype (writable outputs must not be copied)."""
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous, (a.dtype, dtype)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ro(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _boxargs(box, origin, boundary):
+    b = _ro(box, np.float64).reshape(9)
+    o = _ro(origin, np.float64)
+    p = _ro(boundary, np.int32)
+    return b, o, p
+
+
+def _chk(rc):
+    if rc == -1:
+        raise RuntimeError("The volume of the box is zero.")
+    if rc != 0:
+        raise RuntimeError(f"oracle error {rc}")
+
+
+i64 = C.c_int64
+dbl = C.c_double
+cint = C.c_int
+
+
+# ---------------------------------------------------------------- _neighbor
+def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_list, neighbor_number, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    M = 0 if verlet_list is None else verlet_list.shape[1]
+    _chk(lib().orc_build_neighbor(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                                  _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), dbl(rc),
+                                  _p(verlet_list, np.int32), _p(distance_list, np.float64),
+                                  _p(neighbor_number, np.int32), i64(M), cint(num_t)))
+
+
+def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1):
+    N = len(x)
+    nn = np.zeros(N, np.int32)
+    build_neighbor(x, y, z, box, origin, boundary, rc, None, None, nn, num_t)
+    M = max(int(nn.max(initial=0)), 1)
+    v = np.full((N, M), -1, np.int32)
+    d = np.full((N, M), rc + 1.0, np.float64)
+    build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t)
+    return v, d, nn
+
+
+def sort_verlet_by_distance(verlet_list, distance_list, sortNum, num_t=1):
+    N, M = verlet_list.shape
+    lib().orc_sort_verlet_by_distance(_p(verlet_list, np.int32), _p(distance_list, np.float64), i64(N), i64(M),
+                                      cint(sortNum), cint(num_t))
+
+
+def wrap_positions(x, y, z, box, origin, boundary, num_t=1):
+    b, o, p = _boxargs(box, origin, boundary)
+    _chk(lib().orc_wrap_positions(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                                  _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), cint(num_t)))
+
+
+def average_by_neighbor(rc, verlet_list, distance_list, neighbor_number, value, value_ave, include_self, num_t=1):
+    N, M = verlet_list.shape
+    value = _ro(value, np.float64)
+    lib().orc_average_by_neighbor(dbl(rc), _p(_ro(verlet_list, np.int32), np.int32),
+                                  _p(_ro(distance_list, np.float64), np.float64),
+                                  _p(_ro(neighbor_number, np.int32), np.int32), i64(N), i64(M),
+                                  _p(value, np.float64), _p(value_ave, np.float64), cint(bool(include_self)),
+                                  cint(num_t))
+
+
+# --------------------------------------------------------------------- _cna
+def fcna(x, y, z, box, origin, boundary, verlet_list, neighbor_number, pattern, rc, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v = _ro(verlet_list, np.int32)
+    nn = _ro(neighbor_number, np.int32)
+    _chk(lib().orc_fcna(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                        _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), i64(v.shape[1]),
+                        _p(nn, np.int32), _p(pattern, np.int32), dbl(rc), cint(num_t)))
+
+
+def acna(x, y, z, box, origin, boundary, verlet_list, pattern, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v = _ro(verlet_list, np.int32)
+    assert v.shape[1] >= 14
+    _chk(lib().orc_acna(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                        _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), i64(v.shape[1]),
+                        _p(pattern, np.int32), cint(num_t)))
+
+
+def ids(x, y, z, box, origin, boundary, verlet_list, new_verlet_list, pattern, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v = _ro(verlet_list, np.int32)
+    _chk(lib().orc_ids(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                       _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), i64(v.shape[1]),
+                       _p(new_verlet_list, np.int32), _p(pattern, np.int32), cint(num_t)))
+
+
+# --------------------------------------------------------------------- _csp
+def get_csp(x, y, z, box, origin, boundary, verlet_list, N, csp, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v = _ro(verlet_list, np.int32)
+    _chk(lib().orc_csp(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                       _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), i64(v.shape[1]),
+                       cint(N), _p(csp, np.float64), cint(num_t)))
+
+
+# --------------------------------------------------------------------- _sbo
+def get_sq(x, y, z, box, origin, boundary, verlet_list, distance_list, neighbor_number, weight, llist, nnn, lmax,
+           wl, wlhat, average, use_voronoi, rc, use_weight, qlm_r, qlm_i, qnarray, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v = _ro(verlet_list, np.int32)
+    d = _ro(distance_list, np.float64)
+    nn = _ro(neighbor_number, np.int32)
+    w = _ro(weight, np.float64) if use_weight else None
+    ll = _ro(llist, np.int32)
+    _chk(lib().orc_get_sq(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                          _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(v, np.int32),
+                          _p(d, np.float64), i64(v.shape[1]), _p(nn, np.int32), _p(w, np.float64),
+                          _p(ll, np.int32), cint(len(ll)), cint(nnn), cint(lmax), cint(bool(wl)), cint(bool(wlhat)),
+                          cint(bool(average)), cint(bool(use_voronoi)), dbl(rc), cint(bool(use_weight)),
+                          _p(qlm_r, np.float64), _p(qlm_i, np.float64), _p(qnarray, np.float64), cint(num_t)))
+
+
+def identifySolidLiquid(Q6index, Q6, verlet_list, distance_list, neighbor_number, qlm_r, qlm_i, threshold, n_bond,
+                        solidliquid, nbond, use_voronoi, nnn, rc, num_t=1):
+    v = _ro(verlet_list, np.int32)
+    d = _ro(distance_list, np.float64)
+    nn = _ro(neighbor_number, np.int32)
+    q6 = _ro(Q6, np.float64)
+    qr, qi = _ro(qlm_r, np.float64), _ro(qlm_i, np.float64)
+    lib().orc_identify_solid_liquid(cint(Q6index), _p(q6, np.float64), _p(v, np.int32), _p(d, np.float64),
+                                    _p(nn, np.int32), i64(v.shape[0]), i64(v.shape[1]), _p(qr, np.float64),
+                                    _p(qi, np.float64), cint(qr.shape[1]), cint(qr.shape[2]), dbl(threshold),
+                                    cint(n_bond), _p(solidliquid, np.int32), _p(nbond, np.int32),
+                                    cint(bool(use_voronoi)), cint(nnn), dbl(rc), cint(num_t))
+
+
+# --------------------------------------------------------------------- _rdf
+def _rdf(verlet_list, distance_list, neighbor_number, type_list, g, rc, nbin):
+    v = _ro(verlet_list, np.int32)
+    d = _ro(distance_list, np.float64)
+    nn = _ro(neighbor_number, np.int32)
+    t = _ro(type_list, np.int32)
+    lib().orc_rdf(_p(v, np.int32), _p(d, np.float64), _p(nn, np.int32), _p(t, np.int32), i64(v.shape[0]),
+                  i64(v.shape[1]), _p(g, np.float64), cint(g.shape[0]), dbl(rc), cint(nbin))
+
+
+def _rdf_single_species(verlet_list, distance_list, neighbor_number, g, rc, nbin):
+    v = _ro(verlet_list, np.int32)
+    d = _ro(distance_list, np.float64)
+    nn = _ro(neighbor_number, np.int32)
+    lib().orc_rdf_single(_p(v, np.int32), _p(d, np.float64), _p(nn, np.int32), i64(v.shape[0]), i64(v.shape[1]),
+                         _p(g, np.float64), dbl(rc), cint(nbin))
+
+
+def _rdf_streaming(x, y, z, type_list, box, origin, boundary, g, rc, nbin, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    t = _ro(type_list, np.int32)
+    _chk(lib().orc_rdf_streaming(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), _p(t, np.int32),
+                                 i64(x.shape[0]), _p(b, np.float64), _p(o, np.float64), _p(p, np.int32),
+                                 _p(g, np.float64), cint(g.shape[0]), dbl(rc), cint(nbin), cint(num_t)))
+
+
+# --------------------------------------------------------------------- _wcp
+def get_wcp(verlet_list, neighbor_number, type_list, Ntype, WCP, num_t=1):
+    v = _ro(verlet_list, np.int32)
+    nn = _ro(neighbor_number, np.int32)
+    t = _ro(type_list, np.int32)
+    lib().orc_wcp(_p(v, np.int32), _p(nn, np.int32), _p(t, np.int32), i64(v.shape[0]), i64(v.shape[1]), cint(Ntype),
+                  _p(WCP, np.float64))
+
+
+# ---------------------------------------------------------------- _fast_knn
+def knn(x, y, z, box, origin, boundary, k, indices, distances, num_t=1):
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    _chk(lib().orc_knn(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]),
+                       _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), cint(k), _p(indices, np.int32),
+                       _p(distances, np.float64), cint(num_t)))
+
+
+# ------------------------------------------------------------- _repeat_cell
+def repeat_cell(new_pos, old_box, old_pos, nx, ny, nz, num_t=1):
+    ob = _ro(old_box, np.float64).reshape(9)
+    op = _ro(old_pos, np.float64)
+    lib().orc_repeat_cell(_p(new_pos, np.float64), _p(ob, np.float64), _p(op, np.float64), i64(op.shape[0]),
+                          cint(nx), cint(ny), cint(nz))
+
+
+def num_procs() -> int:
+    return int(lib().orc_num_procs())
