@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py — headline metric of BASELINE.json: atoms/sec for neighbor-build + CNA on FCC Cu.
+
+A "step" is one pass of the hot path over the whole (synthetic) system, positions already resident
+in HBM: cell-list neighbor build (rc = 0.854 a, max_neigh = 16: the `System.cal_common_neighbor_analysis(rc)`
+configuration the reference's own CNA tests and SURVEY.md §6 use) followed by fixed-cutoff CNA, all through
+the C ABI of libmdapy_amd.so with device pointers.  At N GPUs every rank owns a 136^3-cell slab of a
+(136 N) x 136 x 136-cell box (weak scaling) and exchanges a one-cutoff ghost halo with its two ring
+neighbours over RCCL each step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_neighbor), timed with HIP events
+recorded inside the library on the launch stream; `cpu_baseline` is the CPU oracle (a parity-checked port of
+the reference's OpenMP C++, oracle/mdapy_oracle.c) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+A_CU = 3.615
+RC = 0.854 * A_CU
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--cells", type=int, default=136, help="FCC cells per axis per GPU (136 -> 10 061 824 atoms)")
+    p.add_argument("--max-neigh", type=int, default=16)
+    p.add_argument("--sigma", type=float, default=0.0, help="optional thermal rattle (A) of the lattice")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-cells", type=int, default=63, help="cells per axis of the CPU-baseline sample (63 -> 1 000 188 atoms)")
+    return p.parse_args()
+
+
+def slab_positions(torch, dev, cells, rank, sigma):
+    """FCC Cu slab of rank `rank`: cells ix in [cells*rank, cells*(rank+1)), cell-major order, basis innermost —
+    same expression as build_crystal / repeat_cell (basis@cell + (ix*a1 + iy*a2 + iz*a3))."""
+    a = A_CU
+    basis = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]], dtype=torch.float64, device=dev) * a
+    ix = torch.arange(cells * rank, cells * (rank + 1), dtype=torch.float64, device=dev) * a
+    iy = torch.arange(cells, dtype=torch.float64, device=dev) * a
+    out = []
+    for k, (sx, sy, sz) in enumerate(((ix, None, None), (None, iy, None), (None, None, iy))):
+        s = sx if sx is not None else (sy if sy is not None else sz)
+        shape = [1, 1, 1, 1]
+        shape[k] = cells
+        comp = basis[:, k].view(1, 1, 1, 4) + s.view(shape)
+        out.append(comp.expand(cells, cells, cells, 4).reshape(-1).contiguous())
+    if sigma > 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        out = [c + torch.randn(c.shape, generator=g, dtype=torch.float64, device=dev) * sigma for c in out]
+    n = cells ** 3 * 4
+    gid = torch.arange(n * rank, n * (rank + 1), dtype=torch.int64, device=dev)
+    return out[0], out[1], out[2], gid
+
+
+def cpu_baseline(args):
+    from mdapy_amd.build_lattice import lattice_positions
+    from oracle import oracle as O
+
+    n = args.cpu_cells
+    pos, box = lattice_positions("fcc", A_CU, n, n, n)
+    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+    N, M = len(x), args.max_neigh
+    org, bnd = np.zeros(3), np.array([1, 1, 1], np.int32)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best = float("inf")
+    t_all = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 12):
+        v = np.full((N, M), -1, np.int32); d = np.full((N, M), RC + 1.0); nn = np.zeros(N, np.int32); pat = np.zeros(N, np.int32)
+        t0 = time.perf_counter()
+        O.build_neighbor(x, y, z, box, org, bnd, RC, v, d, nn, cores)
+        O.fcna(x, y, z, box, org, bnd, v, nn, pat, RC, cores)
+        dt = time.perf_counter() - t0
+        best = min(best, dt)
+        reps += 1
+        if time.perf_counter() - t_all > 40.0:
+            break
+    assert int((pat == 1).sum()) == N
+    return {"value": N / best, "unit": "atoms/s", "cores": cores, "kind": "port",
+            "sample": f"{N}-atom FCC Cu ({n}^3 cells), neighbor(rc={RC:.5f}, max_neigh={M}) + fixed CNA, OpenMP oracle port, best of {reps}"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import mdapy_amd as mp
+    from mdapy_amd import _cna, _lib, _neighbor
+    from mdapy_amd.distributed import SlabDecomposition, neighbor_cna_step
+
+    L = _lib.lib()
+    _lib.check(L.mdh_set_device(local_rank))
+    cells, M = args.cells, args.max_neigh
+    x, y, z, gid = slab_positions(torch, dev, cells, rank, args.sigma)
+    n_local = int(x.shape[0])
+    box = mp.Box(np.diag([A_CU * cells * world, A_CU * cells, A_CU * cells]))
+    dec = SlabDecomposition(box, rank, world, axis=0)
+
+    if world == 1:
+        verlet = torch.empty((n_local, M), dtype=torch.int32, device=dev)
+        distl = torch.empty((n_local, M), dtype=torch.float64, device=dev)
+        nn = torch.empty((n_local,), dtype=torch.int32, device=dev)
+        pattern = torch.empty((n_local,), dtype=torch.int32, device=dev)
+
+        def step():
+            pattern.zero_()  # the kernels rely on the caller's pre-zeroing (common_neighbor_analysis.py:128)
+            _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, RC, verlet, distl, nn, 1, fill_pads=True)
+            _cna.fcna(x, y, z, box.box, box.origin, box.boundary, verlet, nn, pattern, RC, 1)
+            return nn, pattern, None
+    else:
+        def step():
+            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M)
+            return nn_, pat_, dom
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    L.mdh_prof_reset()
+    L.mdh_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.mdh_prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # correctness of what was timed: perfect FCC -> every owned atom has 12 neighbours and label 1
+    nn_o, pat_o, dom = out
+    if dom is not None:
+        nn_o, pat_o = nn_o[dom.owned], pat_o[dom.owned]
+    ok = True
+    if args.sigma == 0.0:
+        ok = bool((nn_o == 12).all().item()) and bool((pat_o == 1).all().item()) and int(nn_o.shape[0]) == n_local
+    if not ok:
+        raise SystemExit(f"rank {rank}: timed result is wrong (expected 12 neighbours / FCC label everywhere)")
+
+    buf = ctypes.create_string_buffer(1 << 16)
+    nbytes = L.mdh_prof_report(buf, len(buf))
+    prof = {}
+    if nbytes > 0:
+        for line in buf.value.decode().strip().splitlines():
+            name, cnt, tot = line.split()
+            prof[name] = (int(cnt), float(tot))
+
+    if rank == 0:
+        n_total = n_local * world
+        ms_per_step = elapsed / args.steps * 1e3
+        n_rows = n_local if dom is None else int(dom.x.shape[0])  # rows the kernel actually processed on rank 0
+        res = {
+            "metric": "atoms/sec for neighbor+CNA on 10M-atom FCC Cu; 1/2/4/8-GPU scaling",
+            "value": n_total / (elapsed / args.steps),
+            "unit": "atoms/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"FCC Cu a={A_CU}, {cells}^3 cells per GPU ({n_local} atoms/GPU, {n_total} total), "
+                                   f"build_neighbor(rc=0.854a={RC:.5f}, max_neigh={M}) + fixed-cutoff CNA, positions resident in HBM",
+                       "atoms_per_gpu": n_local, "rc": RC, "max_neigh": M, "sigma": args.sigma,
+                       "parallelism": f"slab{world}" if world > 1 else "single"},
+        }
+        if "k_neighbor" in prof:
+            cnt, tot = prof["k_neighbor"]
+            avg_ms = tot / cnt
+            alg_bytes = (28 + 12 * M) * n_rows  # read x,y,z (24 B) + write nn (4 B) + rows (12 M B) per atom
+            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms, "launches": cnt,
+                               "algorithmic_bytes_per_launch": alg_bytes}
+            res["kernels_ms"] = {k: v[1] / v[0] for k, v in prof.items()}
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/*
+ * mdapy_amd.h — C ABI of libmdapy_amd.so: MI355X (gfx950) HIP implementation of
+ * mdapy's neighbor-list + per-atom structural-analysis hot path.
+ *
+ * This is the drop-in boundary: each entry point replaces one
+ * function of one of the reference's nanobind extension modules
+ * (mushroomfire/mdapy, CMakeLists.txt:71-100).  The reference interface that
+ * each one replaces is cited as  file:line  relative to the reference tree.
+ *
+ * Conventions (mirroring SURVEY.md §8b):
+ *   - plain pointers + sizes, no torch / numpy types;
+ *   - `int` is int32, `double` is IEEE binary64, index products are 64-bit;
+ *   - box9 = 3x3 row-major box matrix (rows a,b,c), origin3, boundary3 (0/1) are
+ *     ALWAYS host pointers (they are 15 numbers);
+ *   - every other array pointer of one call lives in the SAME memory space,
+ *     given by `space`: MDH_HOST (pageable/pinned host memory: the library
+ *     stages through HBM and returns when the results are back on the host) or
+ *     MDH_DEVICE (HBM of the current HIP device, e.g. torch tensor.data_ptr():
+ *     the call is enqueued on `stream` and returns without synchronising unless
+ *     it has to hand a scalar back to the host);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - outputs are caller-allocated and, unless stated otherwise, caller
+ *     initialised exactly as the reference's Python layer initialises them;
+ *   - return value 0 = success; <0 = error, text via mdh_last_error().
+ *     MDH_ERR_BOX corresponds to the reference's only C++ throw on this path
+ *     (src/box.h:185-186 "The volume of the box is zero.") and is surfaced as
+ *     RuntimeError by the Python layer, like nanobind does.
+ */
+#ifndef MDAPY_AMD_H
+#define MDAPY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDH_HOST 0
+#define MDH_DEVICE 1
+
+#define MDH_OK 0
+#define MDH_ERR_BOX (-1)   /* singular triclinic box                       */
+#define MDH_ERR_HIP (-2)   /* a HIP runtime call failed / no gfx950 device */
+#define MDH_ERR_ARG (-3)   /* invalid argument                             */
+#define MDH_ERR_NOMEM (-4) /* device allocation failed                     */
+
+/* ---- runtime ---------------------------------------------------------- */
+const char *mdh_last_error(void);
+int mdh_version(void);
+/* number of visible HIP devices (0 when there is no GPU; never an error) */
+int mdh_device_count(void);
+int mdh_set_device(int device);
+/* free the cached per-device scratch buffers */
+int mdh_release_workspace(void);
+/* bytes currently held by the scratch cache of the current device */
+int64_t mdh_workspace_bytes(void);
+/*
+ * Per-kernel timing with HIP events recorded on the stream each kernel is launched on
+ * (used by bench.py for the roofline figure).  mdh_prof_enable(1) starts collecting,
+ * mdh_prof_reset() drops what was collected, mdh_prof_report() synchronises the recorded
+ * events and writes lines "name count total_ms\n" into buf (returns bytes written, <0 on error).
+ */
+int mdh_prof_enable(int on);
+int mdh_prof_reset(void);
+int mdh_prof_report(char *buf, int buflen);
+
+/* ---- _neighbor -------------------------------------------------------- */
+/*
+ * replaces _neighbor.build_neighbor                       src/neighbor.cpp:351-388
+ * (cell build :64-100 + build_verlet_list :102-187).
+ * verlet (N,max_neigh) int32, dist (N,max_neigh) f64, nn (N) int32.
+ * fill_pads == 0: reference semantics — only the first min(nn[i],max_neigh)
+ *   slots of a row are written; the caller has pre-filled -1 / rc+1
+ *   (src/mdapy/neighbor.py:125-129).
+ * fill_pads != 0: the kernel also writes the pads (-1, rc+1.0) so that the
+ *   caller may hand over uninitialised memory (saves one full pass over HBM).
+ * nn[i] keeps counting past max_neigh (neighbor.cpp:172-177).
+ */
+int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                       const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
+                       int64_t max_neigh, int fill_pads, int space, void *stream);
+
+/*
+ * first half of _neighbor.build_neighbor_without_max_neigh  src/neighbor.cpp:189-349:
+ * counts only; *max_count (host int) receives max(nn) (0 when N == 0).  The
+ * caller then allocates (N, max(max_count,1)) arrays and calls
+ * mdh_build_neighbor(..., fill_pads=1).  Synchronises `stream`.
+ */
+int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                       const double *origin3, const int *boundary3, double rc, int *nn, int *max_count, int space,
+                       void *stream);
+
+/* replaces _neighbor.sort_verlet_by_distance               src/neighbor.cpp:745-775 */
+int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M, int sort_num, int space,
+                                void *stream);
+
+/* replaces _neighbor.wrap_positions                        src/neighbor.cpp:675-702 */
+int mdh_wrap_positions(double *x, double *y, double *z, int64_t N, const double *box9, const double *origin3,
+                       const int *boundary3, int space, void *stream);
+
+/* replaces _neighbor.average_by_neighbor                   src/neighbor.cpp:704-743 */
+int mdh_average_by_neighbor(double rc, const int *verlet, const double *dist, const int *nn, int64_t N, int64_t M,
+                            const double *value, double *value_ave, int include_self, int space, void *stream);
+
+/* ---- _cna ------------------------------------------------------------- */
+/* replaces _cna.fcna (FixedCNA)                            src/cna.cpp:429-506; pattern pre-zeroed */
+int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+             const double *origin3, const int *boundary3, const int *verlet, int64_t M, const int *nn, int *pattern,
+             double rc, int space, void *stream);
+
+/* replaces _cna.acna (AdaptiveCNA)                         src/cna.cpp:289-427; rows distance sorted, M >= 14 */
+int mdh_acna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+             const double *origin3, const int *boundary3, const int *verlet, int64_t M, int *pattern, int space,
+             void *stream);
+
+/* replaces _cna.ids (IdentifyDiamond)                      src/cna.cpp:163-287; new_verlet (N,12) */
+int mdh_ids(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+            const int *boundary3, const int *verlet, int64_t M, int *new_verlet, int *pattern, int space,
+            void *stream);
+
+/* ---- _csp ------------------------------------------------------------- */
+/* replaces _csp.get_csp                                    src/centro_symmetry_parameter.cpp:12-94 */
+int mdh_csp(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+            const int *boundary3, const int *verlet, int64_t M, int num_neigh, double *csp, int space,
+            void *stream);
+
+/* ---- _sbo ------------------------------------------------------------- */
+/* replaces _sbo.get_sq                                     src/steinhardt_bond_orientation.cpp:677-784
+ * qlm_r/qlm_i (N,nl,2*lmax+1) pre-zeroed, qnarray (N,ncol); weight may be NULL when !use_weight.
+ * llist is a HOST pointer (nl small ints). */
+int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+               const double *origin3, const int *boundary3, const int *verlet, const double *dist, int64_t M,
+               const int *nn, const double *weight, const int *llist_host, int nl, int nnn, int lmax, int wl,
+               int wlhat, int average, int use_voronoi, double rc, int use_weight, double *qlm_r, double *qlm_i,
+               double *qnarray, int space, void *stream);
+
+/* replaces _sbo.identifySolidLiquid                        src/steinhardt_bond_orientation.cpp:578-675 */
+int mdh_identify_solid_liquid(int q6index, const double *Q6, const int *verlet, const double *dist, const int *nn,
+                              int64_t N, int64_t M, const double *qlm_r, const double *qlm_i, int nl, int nz,
+                              double threshold, int n_bond, int *solidliquid, int *nbond, int use_voronoi, int nnn,
+                              double rc, int space, void *stream);
+
+/* ---- _rdf ------------------------------------------------------------- */
+/* replaces _rdf._rdf                                       src/radial_distribution_function.cpp:22-54 */
+int mdh_rdf(const int *verlet, const double *dist, const int *nn, const int *type, int64_t N, int64_t M, double *g,
+            int ntype, double rc, int nbin, int space, void *stream);
+/* replaces _rdf._rdf_single_species                        src/radial_distribution_function.cpp:56-85 */
+int mdh_rdf_single_species(const int *verlet, const double *dist, const int *nn, int64_t N, int64_t M, double *g,
+                           double rc, int nbin, int space, void *stream);
+/* replaces _rdf._rdf_streaming                             src/radial_distribution_function.cpp:143-317 */
+int mdh_rdf_streaming(const double *x, const double *y, const double *z, const int *type, int64_t N,
+                      const double *box9, const double *origin3, const int *boundary3, double *g, int ntype,
+                      double rc, int nbin, int space, void *stream);
+
+/* ---- _wcp ------------------------------------------------------------- */
+/* replaces _wcp.get_wcp                                    src/warren_cowley_parameter.cpp:9-80; wcp (ntype,ntype) */
+int mdh_wcp(const int *verlet, const int *nn, const int *type, int64_t N, int64_t M, int ntype, double *wcp,
+            int space, void *stream);
+
+/* ---- _fast_knn -------------------------------------------------------- */
+/* replaces _fast_knn.knn                                   src/fast_knn.cpp:846-916 */
+int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+            const int *boundary3, int k, int *indices, double *distances, int space, void *stream);
+
+/* ---- _repeat_cell ----------------------------------------------------- */
+/* replaces _repeat_cell.repeat_cell                        src/repeat_cell.cpp:19-61; new_pos flat (n_old*nx*ny*nz*3) */
+int mdh_repeat_cell(double *new_pos, const double *old_box9_host, const double *old_pos, int64_t n_old, int nx,
+                    int ny, int nz, int space, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDAPY_AMD_H */

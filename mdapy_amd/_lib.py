@@ -1,0 +1,102 @@
+"""ctypes binding of libmdapy_amd.so (the C ABI declared in include/mdapy_amd.h).
+
+The reference binds its C++ with nanobind (CMakeLists.txt:71-100); nanobind is
+not available in this image, so the same entry points are reached through
+ctypes.  There is NO CPU fallback: if the shared library is missing, or no HIP
+device is visible when a kernel is requested, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmdapy_amd.so")
+
+HOST, DEVICE = 0, 1
+ERR_BOX, ERR_HIP, ERR_ARG, ERR_NOMEM = -1, -2, -3, -4
+
+_lib = None
+
+i64, dbl, cint, vp = C.c_int64, C.c_double, C.c_int, C.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mdapy_amd.h
+_SIGNATURES = {
+    "mdh_last_error": [],
+    "mdh_version": [],
+    "mdh_device_count": [],
+    "mdh_set_device": [cint],
+    "mdh_release_workspace": [],
+    "mdh_workspace_bytes": [],
+    "mdh_prof_enable": [cint],
+    "mdh_prof_reset": [],
+    "mdh_prof_report": [vp, cint],
+    "mdh_build_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, cint, vp],
+    "mdh_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, cint, vp],
+    "mdh_sort_verlet_by_distance": [vp, vp, i64, i64, cint, cint, vp],
+    "mdh_wrap_positions": [vp, vp, vp, i64, vp, vp, vp, cint, vp],
+    "mdh_average_by_neighbor": [dbl, vp, vp, vp, i64, i64, vp, vp, cint, cint, vp],
+    "mdh_fcna": [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, dbl, cint, vp],
+    "mdh_acna": [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, cint, vp],
+    "mdh_ids": [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, cint, vp],
+    "mdh_csp": [vp, vp, vp, i64, vp, vp, vp, vp, i64, cint, vp, cint, vp],
+    "mdh_get_sq": [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, cint, cint, cint, cint, cint, cint, cint,
+                   dbl, cint, vp, vp, vp, cint, vp],
+    "mdh_identify_solid_liquid": [cint, vp, vp, vp, vp, i64, i64, vp, vp, cint, cint, dbl, cint, vp, vp, cint, cint,
+                                  dbl, cint, vp],
+    "mdh_rdf": [vp, vp, vp, vp, i64, i64, vp, cint, dbl, cint, cint, vp],
+    "mdh_rdf_single_species": [vp, vp, vp, i64, i64, vp, dbl, cint, cint, vp],
+    "mdh_rdf_streaming": [vp, vp, vp, vp, i64, vp, vp, vp, vp, cint, dbl, cint, cint, vp],
+    "mdh_wcp": [vp, vp, vp, i64, i64, cint, vp, cint, vp],
+    "mdh_knn": [vp, vp, vp, i64, vp, vp, vp, cint, vp, vp, cint, vp],
+    "mdh_repeat_cell": [vp, vp, vp, i64, cint, cint, cint, cint, vp],
+}
+_RESTYPES = {"mdh_last_error": C.c_char_p, "mdh_workspace_bytes": C.c_int64}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C mdapy_amd/csrc`).  mdapy_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, argt in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argt
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().mdh_device_count())
+
+
+def check(rc: int) -> None:
+    """Translate a C-ABI return code into the exception the reference would raise."""
+    if rc == 0:
+        return
+    msg = lib().mdh_last_error().decode("utf-8", "replace")
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    # ERR_BOX mirrors the C++ throw in src/box.h:185-186, which nanobind turns into RuntimeError
+    raise RuntimeError(msg)
+
+
+def host_box(box, origin, boundary):
+    """(box9, origin3, boundary3) as C-contiguous host arrays + their pointers (kept alive by the caller)."""
+    b = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3, 3))
+    o = np.ascontiguousarray(np.asarray(origin, dtype=np.float64).reshape(3))
+    # the reference accepts int64 boundary through nanobind's implicit conversion
+    p = np.ascontiguousarray(np.asarray(boundary).astype(np.int32).reshape(3))
+    return (b, o, p), (b.ctypes.data, o.ctypes.data, p.ctypes.data)

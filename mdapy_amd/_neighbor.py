@@ -1,0 +1,79 @@
+"""Drop-in for the reference's ``mdapy._neighbor`` nanobind module
+(src/neighbor.cpp:841-859): same function names, argument order and
+caller-allocated outputs, executed by the HIP kernels in csrc/neighbor.hip.
+Arrays may be numpy (host; staged by the library) or HBM resident
+(:class:`mdapy_amd.devarray.HArray`, frame columns, torch ROCm tensors)."""
+import numpy as np
+
+from . import _lib
+from .devarray import Call, HArray, have_gpu
+
+f64, i32 = np.float64, np.int32
+
+
+def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_list, neighbor_number, num_t=1,
+                   fill_pads=False):
+    """src/neighbor.cpp:351.  ``fill_pads`` (extension): let the kernel write the -1 / rc+1 pads so the
+    caller may pass uninitialised buffers."""
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    c = Call(x, y, z, verlet_list, distance_list, neighbor_number)
+    N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
+    rc_ = _lib.lib().mdh_build_neighbor(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
+                                        c.out(verlet_list, i32, upload=not fill_pads),
+                                        c.out(distance_list, f64, upload=not fill_pads),
+                                        c.out(neighbor_number, i32, upload=False), M, int(bool(fill_pads)), c.space,
+                                        c.stream)
+    c.done(rc_)
+
+
+def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1):
+    """src/neighbor.cpp:189: exact row width = max neighbour count (>= 1); returns (verlet, dist, nn).
+    The arrays are HBM resident when the inputs are (or when a GPU is present and inputs are frame columns)."""
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    N = int(len(x))
+    on_dev = not all(isinstance(a, np.ndarray) for a in (x, y, z))
+    nn = HArray.empty((N,), i32) if on_dev else np.zeros(N, i32)
+    import ctypes
+
+    mx = ctypes.c_int(0)
+    c = Call(x, y, z, nn)
+    px, py, pz = c.inp(x, f64), c.inp(y, f64), c.inp(z, f64)
+    rc_ = _lib.lib().mdh_neighbor_count(px, py, pz, N, pb, po, pp, float(rc), c.out(nn, i32, upload=False),
+                                        ctypes.addressof(mx), c.space, c.stream)
+    c.done(rc_)
+    M = max(int(mx.value), 1)  # :301-304
+    if on_dev:
+        verlet, dist = HArray.empty((N, M), i32), HArray.empty((N, M), f64)
+    else:
+        verlet, dist = np.empty((N, M), i32), np.empty((N, M), f64)
+    build_neighbor(x, y, z, box, origin, boundary, rc, verlet, dist, nn, num_t, fill_pads=True)
+    return verlet, dist, nn
+
+
+def sort_verlet_by_distance(verlet_list, distance_list, sortNum, num_t=1):
+    """src/neighbor.cpp:745"""
+    c = Call(verlet_list, distance_list)
+    N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
+    rc_ = _lib.lib().mdh_sort_verlet_by_distance(c.out(verlet_list, i32), c.out(distance_list, f64), N, M,
+                                                 int(sortNum), c.space, c.stream)
+    c.done(rc_)
+
+
+def wrap_positions(x, y, z, box, origin, boundary, num_t=1):
+    """src/neighbor.cpp:675 (in place)"""
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    c = Call(x, y, z)
+    rc_ = _lib.lib().mdh_wrap_positions(c.out(x, f64), c.out(y, f64), c.out(z, f64), int(x.shape[0]), pb, po, pp,
+                                        c.space, c.stream)
+    c.done(rc_)
+
+
+def average_by_neighbor(rc, verlet_list, distance_list, neighbor_number, value, value_ave, include_self, num_t=1):
+    """src/neighbor.cpp:704"""
+    c = Call(verlet_list, distance_list, neighbor_number, value, value_ave)
+    N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
+    rc_ = _lib.lib().mdh_average_by_neighbor(float(rc), c.inp(verlet_list, i32), c.inp(distance_list, f64),
+                                             c.inp(neighbor_number, i32), N, M, c.inp(value, f64),
+                                             c.out(value_ave, f64, upload=False), int(bool(include_self)), c.space,
+                                             c.stream)
+    c.done(rc_)

@@ -1,0 +1,180 @@
+// common.hpp — shared host/device definitions of libmdapy_amd (gfx950 only).
+//
+// Numerical contract: every kernel whose output is compared
+// bit-exactly with the reference is compiled with -ffp-contract=off and uses
+// IEEE '/', sqrt and floor; the operation ORDER of each formula follows the
+// reference line cited next to it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/mdapy_amd.h"
+
+namespace mdh {
+
+// ----------------------------------------------------------------------------
+// Simulation box as the kernels see it (reference: struct Box, src/box.h:8-17).
+// Passed by value as a kernel argument (lands in SGPRs / the kernarg segment).
+// ----------------------------------------------------------------------------
+struct DBox {
+    double h[9];      // rows a,b,c
+    double hi[9];     // inverse (triclinic: adjugate/det, box.h:182-203; ortho: 1/L on the diagonal)
+    double o[3];      // origin
+    double thick[3];  // perpendicular thickness, box.h:54-89
+    // Orthogonal minimum image n(d) = floor(d/L + 0.5) is a monotone step
+    // function of d.  tn[a][k] is the smallest double d with n(d) >= k-1
+    // (k = 0..3, i.e. n >= -1, 0, 1, 2), found on the host by bisection with
+    // the very same IEEE expression, so `d >= tn` reproduces the reference's
+    // floor(d/L+0.5) bit for bit without a division (see pbc_axis()).
+    double tn[3][4];
+    int pbc[3];
+    int tri;
+    int anypbc;
+};
+
+// host: build DBox from the C-ABI box arguments; returns MDH_OK / MDH_ERR_BOX
+int make_box(DBox &b, const double *box9, const double *origin3, const int *boundary3);
+
+// ----------------------------------------------------------------------------
+// device-side geometry
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ double pbc_axis(double d, double L, const double *t)
+{
+    // reference: xij -= L * floor(xij / L + 0.5)   (box.h:120-124)
+    double n;
+    if (d >= t[0] && d < t[3])
+        n = (d >= t[2]) ? 1.0 : ((d >= t[1]) ? 0.0 : -1.0);
+    else
+        n = floor(d / L + 0.5);
+    return d - L * n;
+}
+
+template <bool TRI>
+__device__ __forceinline__ void pbc(const DBox &b, double &dx, double &dy, double &dz)
+{
+    if (TRI) { // box.h:99-114
+        double fx = dx * b.hi[0] + dy * b.hi[3] + dz * b.hi[6];
+        double fy = dx * b.hi[1] + dy * b.hi[4] + dz * b.hi[7];
+        double fz = dx * b.hi[2] + dy * b.hi[5] + dz * b.hi[8];
+        if (b.pbc[0]) fx -= floor(fx + 0.5);
+        if (b.pbc[1]) fy -= floor(fy + 0.5);
+        if (b.pbc[2]) fz -= floor(fz + 0.5);
+        dx = fx * b.h[0] + fy * b.h[3] + fz * b.h[6];
+        dy = fx * b.h[1] + fy * b.h[4] + fz * b.h[7];
+        dz = fx * b.h[2] + fy * b.h[5] + fz * b.h[8];
+    } else {
+        if (b.pbc[0]) dx = pbc_axis(dx, b.h[0], b.tn[0]);
+        if (b.pbc[1]) dy = pbc_axis(dy, b.h[4], b.tn[1]);
+        if (b.pbc[2]) dz = pbc_axis(dz, b.h[8], b.tn[2]);
+    }
+}
+
+template <bool TRI>
+__device__ __forceinline__ void wrap(const DBox &b, double &x, double &y, double &z)
+{
+    if (TRI) { // box.h:133-156
+        double dx = x - b.o[0], dy = y - b.o[1], dz = z - b.o[2];
+        double fx = dx * b.hi[0] + dy * b.hi[3] + dz * b.hi[6];
+        double fy = dx * b.hi[1] + dy * b.hi[4] + dz * b.hi[7];
+        double fz = dx * b.hi[2] + dy * b.hi[5] + dz * b.hi[8];
+        if (b.pbc[0]) fx -= floor(fx);
+        if (b.pbc[1]) fy -= floor(fy);
+        if (b.pbc[2]) fz -= floor(fz);
+        x = b.o[0] + fx * b.h[0] + fy * b.h[3] + fz * b.h[6];
+        y = b.o[1] + fx * b.h[1] + fy * b.h[4] + fz * b.h[7];
+        z = b.o[2] + fx * b.h[2] + fy * b.h[5] + fz * b.h[8];
+    } else { // box.h:158-176
+        if (b.pbc[0]) { double d = x - b.o[0]; x = b.o[0] + d - b.h[0] * floor(d / b.h[0]); }
+        if (b.pbc[1]) { double d = y - b.o[1]; y = b.o[1] + d - b.h[4] * floor(d / b.h[4]); }
+        if (b.pbc[2]) { double d = z - b.o[2]; z = b.o[2] + d - b.h[8] * floor(d / b.h[8]); }
+    }
+}
+
+// squared minimum-image distance between two RAW positions (src/cna.cpp:149-161)
+template <bool TRI>
+__device__ __forceinline__ double pair_d2(const DBox &b, double xi, double yi, double zi, double xj, double yj,
+                                          double zj)
+{
+    double dx = xj - xi, dy = yj - yi, dz = zj - zi;
+    pbc<TRI>(b, dx, dy, dz);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// ----------------------------------------------------------------------------
+// host runtime: errors, per-device scratch cache, host<->HBM staging
+// ----------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define MDH_HIP(call)                                                         \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess)                                                \
+            return ::mdh::hip_fail(e__, #call, __FILE__, __LINE__);           \
+    } while (0)
+
+#define MDH_TRY(expr)                                                         \
+    do {                                                                      \
+        int rc__ = (expr);                                                    \
+        if (rc__ != MDH_OK)                                                   \
+            return rc__;                                                      \
+    } while (0)
+
+// A call-scoped view of the scratch cache.  Buffers handed out live until the
+// Scope is destroyed; they go back to the per-device cache (not to the driver),
+// so steady-state calls perform no hipMalloc/hipFree at all.
+class Scope {
+  public:
+    explicit Scope(void *stream);
+    ~Scope();
+    hipStream_t stream() const { return stream_; }
+    // device scratch, 256-byte aligned; nullptr + error set on failure
+    void *alloc(size_t bytes);
+    template <class T> T *alloc_n(size_t n) { return static_cast<T *>(alloc((n ? n : 1) * sizeof(T))); }
+
+    // Stage a caller array.  space==MDH_DEVICE: returns the pointer itself.
+    // space==MDH_HOST: returns a device copy (uploaded when `in`), and remembers
+    // to download it at finish() when `out`.
+    template <class T> T *stage(T *p, size_t n, int space, bool in, bool out)
+    {
+        return static_cast<T *>(stage_raw(const_cast<void *>(static_cast<const void *>(p)), n * sizeof(T), space, in, out));
+    }
+    template <class T> const T *stage_in(const T *p, size_t n, int space)
+    {
+        return static_cast<const T *>(stage_raw(const_cast<T *>(p), n * sizeof(T), space, true, false));
+    }
+    // download staged outputs (host space) and, for host space, synchronise.
+    int finish(int space);
+    bool failed() const { return failed_; }
+    int error() const { return err_; } // MDH_ERR_HIP (no device / HIP failure) or MDH_ERR_NOMEM
+
+  private:
+    void *stage_raw(void *p, size_t bytes, int space, bool in, bool out);
+    struct Out { void *host; void *dev; size_t bytes; };
+    hipStream_t stream_;
+    int device_;
+    bool failed_ = false;
+    int err_ = MDH_ERR_NOMEM;
+    static const int kMaxHeld = 64;
+    void *held_[kMaxHeld];
+    size_t held_bytes_[kMaxHeld];
+    int nheld_ = 0;
+    Out outs_[16];
+    int nouts_ = 0;
+};
+
+inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
+
+// Scoped HIP-event pair around a kernel launch (no-op unless mdh_prof_enable(1)); prof.hip
+class ProfRange {
+  public:
+    ProfRange(const char *name, hipStream_t st);
+    ~ProfRange();
+
+  private:
+    const char *name_;
+    hipStream_t st_;
+    hipEvent_t a_;
+};
+
+} // namespace mdh

@@ -1,0 +1,135 @@
+// csp.hip — centro-symmetry parameter on gfx950.
+//
+// Replaces src/centro_symmetry_parameter.cpp:12-94 (get_csp): for every atom the
+// K(K-1)/2 values |r_j + r_k|^2 over its first K listed neighbours, of which the
+// K/2 smallest are summed in ascending order (partial_sort + sequential sum,
+// :79-91).
+//
+// One thread per atom.  r_j (minimum-image vector to neighbour j) is evaluated
+// once per neighbour — the reference re-evaluates it for every pair but from
+// identical operands, so the values are bit-identical — and the K/2 smallest
+// pair values are kept in a sorted register array.
+#include "common.hpp"
+
+namespace mdh {
+
+template <bool TRI, int K>
+__device__ __forceinline__ double csp_atom_static(const DBox &b, const double *__restrict__ x,
+                                                  const double *__restrict__ y, const double *__restrict__ z,
+                                                  int64_t i, const int *__restrict__ row)
+{
+    constexpr int H = K / 2;
+    const double xi = x[i], yi = y[i], zi = z[i]; // RAW centre (:46-48)
+    double rx[K], ry[K], rz[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+        const int j = row[a];
+        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+        pbc<TRI>(b, dx, dy, dz);
+        rx[a] = dx; ry[a] = dy; rz[a] = dz;
+    }
+    double top[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q)
+        top[q] = __builtin_huge_val();
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int c = a + 1; c < K; ++c) {
+            const double sx = rx[a] + rx[c], sy = ry[a] + ry[c], sz = rz[a] + rz[c];
+            double v = sx * sx + sy * sy + sz * sz; // :73
+            if (v < top[H - 1]) {
+#pragma unroll
+                for (int q = 0; q < H; ++q) { // sorted insert by compare-exchange
+                    const double lo = v < top[q] ? v : top[q];
+                    const double hi = v < top[q] ? top[q] : v;
+                    top[q] = lo;
+                    v = hi;
+                }
+            }
+        }
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < H; ++q)
+        s += top[q];
+    return s;
+}
+
+static constexpr int CSP_MAXK = 64;
+
+template <bool TRI>
+__device__ double csp_atom_dynamic(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
+                                   const double *__restrict__ z, int64_t i, const int *__restrict__ row, int K)
+{
+    const int H = K / 2;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    double rx[CSP_MAXK], ry[CSP_MAXK], rz[CSP_MAXK], top[CSP_MAXK / 2];
+    for (int a = 0; a < K; ++a) {
+        const int j = row[a];
+        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+        pbc<TRI>(b, dx, dy, dz);
+        rx[a] = dx; ry[a] = dy; rz[a] = dz;
+    }
+    for (int q = 0; q < H; ++q)
+        top[q] = __builtin_huge_val();
+    for (int a = 0; a < K; ++a)
+        for (int c = a + 1; c < K; ++c) {
+            const double sx = rx[a] + rx[c], sy = ry[a] + ry[c], sz = rz[a] + rz[c];
+            double v = sx * sx + sy * sy + sz * sz;
+            if (H > 0 && v < top[H - 1]) {
+                int q = H - 1;
+                while (q > 0 && top[q - 1] > v) { top[q] = top[q - 1]; --q; }
+                top[q] = v;
+            }
+        }
+    double s = 0.0;
+    for (int q = 0; q < H; ++q)
+        s += top[q];
+    return s;
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_csp(const double *__restrict__ x, const double *__restrict__ y,
+                                             const double *__restrict__ z, int64_t N, DBox b,
+                                             const int *__restrict__ verlet, int64_t M, int K,
+                                             double *__restrict__ csp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int *row = verlet + i * M;
+    double v;
+    if (K == 12) v = csp_atom_static<TRI, 12>(b, x, y, z, i, row);
+    else if (K == 8) v = csp_atom_static<TRI, 8>(b, x, y, z, i, row);
+    else v = csp_atom_dynamic<TRI>(b, x, y, z, i, row, K);
+    csp[i] = v;
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" int mdh_csp(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                       const double *origin3, const int *boundary3, const int *verlet, int64_t M, int num_neigh,
+                       double *csp, int space, void *stream)
+{
+    if (N < 0 || num_neigh <= 0 || (num_neigh & 1) || num_neigh > M || num_neigh > CSP_MAXK) {
+        set_error("mdh_csp: num_neigh must be a positive even number <= min(verlet columns, 64)");
+        return MDH_ERR_ARG;
+    }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    double *dc = sc.stage(csp, (size_t)N, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    if (b.tri)
+        hipLaunchKernelGGL(k_csp<true>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc);
+    else
+        hipLaunchKernelGGL(k_csp<false>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc);
+    return sc.finish(space);
+}

@@ -1,0 +1,80 @@
+// grid.hpp — the rc-wide cell grid shared by the neighbor build, kNN and RDF kernels.
+#pragma once
+#include "common.hpp"
+#include <cmath>
+
+namespace mdh {
+
+// mode 0: cells of width rc anchored at the origin, last cell absorbs the remainder (neighbor.cpp:29-62)
+// mode 1: nc equal cells across the box, floor((x-o)/L*nc)  (radial_distribution_function.cpp:109-141; also kNN)
+struct Grid {
+    int nc[3];
+    int64_t ncell;
+    double rc_inv;
+    int mode;
+};
+
+// device buffers produced by build_cell_grid (owned by the Scope that built them)
+struct CellGrid {
+    Grid g;
+    int *cell_start; // [ncell+1] exclusive prefix of the per-cell populations
+    int *order;      // [N] atom ids, cell-major, DESCENDING id inside a cell
+    double *xs, *ys, *zs; // [N] raw positions in `order`
+};
+
+__host__ __device__ __forceinline__ int pmod(int a, int n) // neighbor.cpp:18-22
+{
+    int r = a % n;
+    return r < 0 ? r + n : r;
+}
+
+// cell coordinates of an already wrapped position (neighbor.cpp:29-62)
+template <bool TRI>
+__device__ __forceinline__ void cell_coords(const DBox &b, const Grid &g, double x, double y, double z, int &c0,
+                                            int &c1, int &c2)
+{
+    double f0, f1, f2;
+    if (TRI) {
+        double dx = x - b.o[0], dy = y - b.o[1], dz = z - b.o[2];
+        double nx = dx * b.hi[0] + dy * b.hi[3] + dz * b.hi[6];
+        double ny = dx * b.hi[1] + dy * b.hi[4] + dz * b.hi[7];
+        double nz = dx * b.hi[2] + dy * b.hi[5] + dz * b.hi[8];
+        if (g.mode == 0) {
+            f0 = floor(nx * b.thick[0] * g.rc_inv);
+            f1 = floor(ny * b.thick[1] * g.rc_inv);
+            f2 = floor(nz * b.thick[2] * g.rc_inv);
+        } else {
+            f0 = floor(nx * g.nc[0]);
+            f1 = floor(ny * g.nc[1]);
+            f2 = floor(nz * g.nc[2]);
+        }
+    } else if (g.mode == 0) {
+        f0 = floor((x - b.o[0]) * g.rc_inv);
+        f1 = floor((y - b.o[1]) * g.rc_inv);
+        f2 = floor((z - b.o[2]) * g.rc_inv);
+    } else {
+        f0 = floor((x - b.o[0]) / b.h[0] * g.nc[0]);
+        f1 = floor((y - b.o[1]) / b.h[4] * g.nc[1]);
+        f2 = floor((z - b.o[2]) / b.h[8] * g.nc[2]);
+    }
+    // static_cast<int> then clamp to [0, nc-1] (neighbor.cpp:58-61); done in
+    // floating point first so that huge values saturate instead of wrapping.
+    f0 = fmin(fmax(f0, 0.0), (double)(g.nc[0] - 1));
+    f1 = fmin(fmax(f1, 0.0), (double)(g.nc[1] - 1));
+    f2 = fmin(fmax(f2, 0.0), (double)(g.nc[2] - 1));
+    c0 = (int)f0; // NaN -> fmax(NaN,0)=0
+    c1 = (int)f1;
+    c2 = (int)f2;
+}
+
+// fills cg.g for the cutoff neighbor search: nc = max(floor(thickness/rc), 3) (neighbor.cpp:203-206)
+int neighbor_grid_dims(const DBox &b, double rc, Grid &g);
+
+// Bins the atoms into cg.g (dims/mode set by the caller) and produces cell_start/order/xs,ys,zs.
+//   wrap_first : wrap a position into the primary cell before binning when any axis is periodic
+//   sort_desc  : order every cell's atoms by descending id (reference row order); otherwise the
+//                order inside a cell is whatever the atomic counters produced
+int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
+                    bool wrap_first, bool sort_desc, CellGrid &cg);
+
+} // namespace mdh

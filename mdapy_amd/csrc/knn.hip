@@ -1,0 +1,240 @@
+// knn.hip — exact k nearest neighbours (periodic images are distinct candidates) on gfx950.
+//
+// Replaces src/fast_knn.cpp:846-916 (knn) with its kd-trees (:208-568, :588-794).
+// Exact kNN is defined by its result; the candidate set and the distance
+// arithmetic are the reference's:
+//   wrap    orthogonal  s = floor((p-O)*(1/L)); if (s != 0) p -= s*L            (:688-703, :743-757)
+//           triclinic   r = p.inv (NO origin shift); s = floor(r_d); p -= s*row_d (:86-99)
+//   images  +-nimages per periodic axis, nimages = 200/clamp(N,50,200), >= 2 if triclinic (:801-841)
+//   d2      q = q_wrapped - shift;  d = a - q;  d2 = dx*dx + dy*dy + dz*dz     (:598-603, :421-425, :759-770)
+//   self    skipped only when idx == self && d2 == 0.0                          (:641, :525)
+// Order under EXACT ties in d2 is traversal dependent in the reference; here ties
+// are ordered by atom index.
+//
+// Search structure: a uniform grid over the (wrapped) atoms; each query walks
+// Chebyshev rings of cells around its own cell — image cells beyond the box map
+// to (cell, shift) — and stops once the k-th best distance is no larger than
+// the distance to anything outside the rings visited so far.
+#include "common.hpp"
+#include "grid.hpp"
+
+namespace mdh {
+
+struct KnnGeom {
+    int nim[3];    // images per axis (0 on open axes)
+    double wmin;   // smallest perpendicular cell width
+    int rmax;      // ring index after which every (cell, image) has been visited
+};
+
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_knn_wrap(const double *__restrict__ x, const double *__restrict__ y,
+                                                  const double *__restrict__ z, int64_t N, DBox b,
+                                                  double *__restrict__ wx, double *__restrict__ wy,
+                                                  double *__restrict__ wz)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double px = x[i], py = y[i], pz = z[i];
+    if (TRI) {
+        const double r0 = px * b.hi[0] + py * b.hi[3] + pz * b.hi[6];
+        const double r1 = px * b.hi[1] + py * b.hi[4] + pz * b.hi[7];
+        const double r2 = px * b.hi[2] + py * b.hi[5] + pz * b.hi[8];
+        const double r[3] = {r0, r1, r2};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (b.pbc[d]) {
+                const double s = floor(r[d]);
+                if (s != 0.0) { px -= s * b.h[d * 3 + 0]; py -= s * b.h[d * 3 + 1]; pz -= s * b.h[d * 3 + 2]; }
+            }
+    } else {
+        if (b.pbc[0]) { const double s = floor((px - b.o[0]) * (1.0 / b.h[0])); if (s != 0.0) px -= s * b.h[0]; }
+        if (b.pbc[1]) { const double s = floor((py - b.o[1]) * (1.0 / b.h[4])); if (s != 0.0) py -= s * b.h[4]; }
+        if (b.pbc[2]) { const double s = floor((pz - b.o[2]) * (1.0 / b.h[8])); if (s != 0.0) pz -= s * b.h[8]; }
+    }
+    wx[i] = px; wy[i] = py; wz[i] = pz;
+}
+
+__device__ __forceinline__ int floordiv(int a, int n) { int q = a / n; return (a % n < 0) ? q - 1 : q; }
+
+// top-k lists live in LDS: entry s of thread t at [s * blockDim + t]
+template <bool TRI>
+__global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
+                      const int *__restrict__ order, const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg,
+                      Grid g, KnnGeom kg, int k, int *__restrict__ indices, double *__restrict__ distances)
+{
+    extern __shared__ unsigned char smem[];
+    const int bd = blockDim.x, t = threadIdx.x;
+    double *td = reinterpret_cast<double *>(smem);                      // [k][bd]
+    int *ti = reinterpret_cast<int *>(smem + sizeof(double) * (size_t)k * bd); // [k][bd]
+    const int64_t p = (int64_t)blockIdx.x * bd + t;
+    if (p >= N)
+        return;
+    const int i = order[p];
+    const double qx = xs[p], qy = ys[p], qz = zs[p]; // wrapped query == stored wrapped self (bitwise)
+    int c0, c1, c2;
+    cell_coords<TRI>(bg, g, qx, qy, qz, c0, c1, c2);
+    int n = 0;
+    double worst = __builtin_huge_val();
+    int worst_id = 0x7fffffff;
+    for (int R = 0; R <= kg.rmax; ++R) {
+        for (int da = -R; da <= R; ++da) {
+            const int e0 = c0 + da;
+            int m0 = 0, a0 = e0;
+            if (b.pbc[0]) { m0 = floordiv(e0, g.nc[0]); a0 = e0 - m0 * g.nc[0]; if (m0 > kg.nim[0] || m0 < -kg.nim[0]) continue; }
+            else if (e0 < 0 || e0 >= g.nc[0]) continue;
+            const int ada = da < 0 ? -da : da;
+            for (int db = -R; db <= R; ++db) {
+                const int e1 = c1 + db;
+                int m1 = 0, a1 = e1;
+                if (b.pbc[1]) { m1 = floordiv(e1, g.nc[1]); a1 = e1 - m1 * g.nc[1]; if (m1 > kg.nim[1] || m1 < -kg.nim[1]) continue; }
+                else if (e1 < 0 || e1 >= g.nc[1]) continue;
+                const int adb = db < 0 ? -db : db;
+                const bool shell_ab = (ada == R) || (adb == R);
+                for (int dc = -R; dc <= R; dc += (shell_ab || R == 0) ? 1 : 2 * R) { // interior of the cube was done by earlier rings
+                    const int e2 = c2 + dc;
+                    int m2 = 0, a2 = e2;
+                    if (b.pbc[2]) { m2 = floordiv(e2, g.nc[2]); a2 = e2 - m2 * g.nc[2]; if (m2 > kg.nim[2] || m2 < -kg.nim[2]) continue; }
+                    else if (e2 < 0 || e2 >= g.nc[2]) continue;
+                    // image shift, fast_knn.cpp:822-833
+                    double s0, s1, s2;
+                    if (TRI) {
+                        s0 = m0 * b.h[0] + m1 * b.h[3] + m2 * b.h[6];
+                        s1 = m0 * b.h[1] + m1 * b.h[4] + m2 * b.h[7];
+                        s2 = m0 * b.h[2] + m1 * b.h[5] + m2 * b.h[8];
+                    } else {
+                        s0 = m0 * b.h[0]; s1 = m1 * b.h[4]; s2 = m2 * b.h[8];
+                    }
+                    // An atom stored in cell (a0,a1,a2), seen through the extended cell e = a + m*nc, is the image
+                    // a + m*L.  Its distance to the query is |a - (q - m*L)|: the reference's shifted query with
+                    // shift = m*L (:759-763).
+                    const double w0 = qx - s0, w1 = qy - s1, w2 = qz - s2;
+                    const int64_t cell = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
+                    const int sb = cell_start[cell], se = cell_start[cell + 1];
+                    for (int q = sb; q < se; ++q) {
+                        const int j = order[q];
+                        const double dx = xs[q] - w0, dy = ys[q] - w1, dz = zs[q] - w2;
+                        const double d2 = dx * dx + dy * dy + dz * dz;
+                        if (j == i && d2 == 0.0)
+                            continue;
+                        if (n == k && !(d2 < worst || (d2 == worst && j < worst_id)))
+                            continue;
+                        int pos = n < k ? n : k - 1;
+                        while (pos > 0) {
+                            const double pd = td[(pos - 1) * bd + t];
+                            const int pi = ti[(pos - 1) * bd + t];
+                            if (!(pd > d2 || (pd == d2 && pi > j)))
+                                break;
+                            td[pos * bd + t] = pd;
+                            ti[pos * bd + t] = pi;
+                            --pos;
+                        }
+                        td[pos * bd + t] = d2;
+                        ti[pos * bd + t] = j;
+                        if (n < k) ++n;
+                        if (n == k) { worst = td[(k - 1) * bd + t]; worst_id = ti[(k - 1) * bd + t]; }
+                    }
+                }
+            }
+        }
+        // everything not yet visited lies at Chebyshev cell distance >= R+1, i.e. at least R cell widths away
+        if (n == k) {
+            const double reach = (double)R * kg.wmin * (1.0 - 1e-9);
+            if (worst <= reach * reach)
+                break;
+        }
+    }
+    for (int q = 0; q < n; ++q) {
+        indices[(int64_t)i * k + q] = ti[q * bd + t];
+        distances[(int64_t)i * k + q] = sqrt(td[q * bd + t]); // :883
+    }
+    for (int q = n; q < k; ++q) { // :885-888
+        indices[(int64_t)i * k + q] = -1;
+        distances[(int64_t)i * k + q] = -1.0;
+    }
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                       const double *origin3, const int *boundary3, int k, int *indices, double *distances, int space,
+                       void *stream)
+{
+    if (N < 0 || N >= 2147483647LL || k <= 0 || k > 64) { set_error("mdh_knn: need 1 <= k <= 64"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    int *di = sc.stage(indices, (size_t)(N * k), space, false, true);
+    double *dd = sc.stage(distances, (size_t)(N * k), space, false, true);
+    double *wx = sc.alloc_n<double>((size_t)N), *wy = sc.alloc_n<double>((size_t)N), *wz = sc.alloc_n<double>((size_t)N);
+    if (sc.failed())
+        return sc.error();
+    if (b.tri)
+        hipLaunchKernelGGL(k_knn_wrap<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, dx, dy, dz, N, b, wx, wy, wz);
+    else
+        hipLaunchKernelGGL(k_knn_wrap<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, dx, dy, dz, N, b, wx, wy, wz);
+
+    // images per periodic axis (fast_knn.cpp:806-816)
+    KnnGeom kg;
+    int nim = 1;
+    if (b.anypbc) {
+        int64_t cl = N < 50 ? 50 : (N > 200 ? 200 : N);
+        nim = (int)(200 / cl);
+        if (nim < 1) nim = 1;
+        if (nim < 2 && b.tri) nim = 2;
+    }
+    for (int d = 0; d < 3; ++d) kg.nim[d] = b.pbc[d] ? nim : 0;
+
+    // grid: aim at ~k/3+1 atoms per cell so that ring 1 usually holds the k nearest
+    DBox bg = b;
+    if (b.tri) bg.o[0] = bg.o[1] = bg.o[2] = 0.0; // the triclinic wrap above is anchored at 0, not at the origin
+    CellGrid cg;
+    const double vol = std::fabs(b.tri ? (b.h[0] * (b.h[4] * b.h[8] - b.h[5] * b.h[7]) - b.h[1] * (b.h[3] * b.h[8] - b.h[5] * b.h[6]) + b.h[2] * (b.h[3] * b.h[7] - b.h[4] * b.h[6])) : b.h[0] * b.h[4] * b.h[8]);
+    const double per_cell = (double)k / 3.0 + 1.0;
+    double wtarget = std::cbrt(vol * per_cell / (double)N);
+    if (!(wtarget > 0) || !std::isfinite(wtarget)) wtarget = 1.0;
+    double tot = 1.0;
+    kg.wmin = __builtin_huge_val();
+    kg.rmax = 0;
+    for (int d = 0; d < 3; ++d) {
+        const double th = std::fabs(b.thick[d]);
+        double f = std::floor(th / wtarget);
+        int n = (f < 1.0 || !(f == f)) ? 1 : (f > 1024.0 ? 1024 : (int)f);
+        cg.g.nc[d] = n;
+        tot *= n;
+    }
+    // keep the grid below ~4 cells per atom (sparse / slab-like systems)
+    while (tot > 4.0 * (double)N + 64.0) {
+        int dmax = 0;
+        for (int d = 1; d < 3; ++d) if (cg.g.nc[d] > cg.g.nc[dmax]) dmax = d;
+        if (cg.g.nc[dmax] <= 1) break;
+        tot /= cg.g.nc[dmax];
+        cg.g.nc[dmax] = (cg.g.nc[dmax] + 1) / 2;
+        tot *= cg.g.nc[dmax];
+    }
+    for (int d = 0; d < 3; ++d) {
+        const double w = std::fabs(b.thick[d]) / cg.g.nc[d];
+        if (w < kg.wmin) kg.wmin = w;
+        const int r = b.pbc[d] ? (kg.nim[d] + 1) * cg.g.nc[d] : cg.g.nc[d] - 1;
+        if (r > kg.rmax) kg.rmax = r;
+    }
+    cg.g.ncell = (int64_t)cg.g.nc[0] * cg.g.nc[1] * cg.g.nc[2];
+    cg.g.rc_inv = 0.0;
+    cg.g.mode = 1;
+    MDH_TRY(build_cell_grid(sc, wx, wy, wz, N, bg, false, false, cg));
+
+    int bd = 256;
+    while (bd > 64 && (size_t)bd * k * 12 > 65536) bd -= 64;
+    const size_t lds = (size_t)bd * k * 12;
+    if (b.tri)
+        hipLaunchKernelGGL(k_knn<true>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd);
+    else
+        hipLaunchKernelGGL(k_knn<false>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd);
+    return sc.finish(space);
+}

@@ -1,0 +1,486 @@
+// neighbor.hip — cell-list cutoff neighbor search on gfx950.
+//
+// Replaces src/neighbor.cpp of the reference (build_cell :64-100,
+// build_verlet_list :102-187, build_neighbor :351-388, the exact-width variant
+// :189-349, sort_verlet_by_distance :745-775, wrap_positions :675-702,
+// average_by_neighbor :704-743).
+//
+// Data layout in HBM:
+//   caller:  x,y,z f64[N] (SoA, original atom order); verlet int32[N][M],
+//            dist f64[N][M], nn int32[N]   — rows in ORIGINAL atom order.
+//   scratch: cell_count u32[ncell] -> cell_start i32[ncell+1] (exclusive scan),
+//            rank i32[N] (slot handed out by the atomic bin counter),
+//            order i32[N]  (atom ids sorted by cell; inside a cell DESCENDING id,
+//                           the order in which the reference's head-inserted
+//                           linked list is walked),
+//            xs,ys,zs f64[N] (raw positions gathered into cell order, so a
+//                           cell's atoms — and the 3 cells of a z-run — are
+//                           contiguous and loads are coalesced).
+#include "common.hpp"
+#include "grid.hpp"
+
+namespace mdh {
+
+// ----------------------------------------------------------------------------
+// cell assignment: wrap, bin, take a slot from the cell's atomic counter
+// ----------------------------------------------------------------------------
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, const double *__restrict__ y,
+                                                const double *__restrict__ z, int64_t N, DBox b, Grid g,
+                                                int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
+                                                unsigned *__restrict__ cell_count)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double xi = x[i], yi = y[i], zi = z[i];
+    if (wrap_first && b.anypbc) // neighbor.cpp:88-91
+        wrap<TRI>(b, xi, yi, zi);
+    int c0, c1, c2;
+    cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+    int c = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
+    cell_id[i] = c;
+    rank[i] = (int)atomicAdd(&cell_count[c], 1u);
+}
+
+// ----------------------------------------------------------------------------
+// exclusive prefix sum of the bin counters (three small kernels)
+// ----------------------------------------------------------------------------
+static constexpr int SCAN_BLOCK = 256;
+static constexpr int SCAN_ITEMS = 4; // per thread -> 1024 per block
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns exclusive prefix, total via *tot
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *tot)
+{
+    __shared__ unsigned wsum[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned off = 0, t = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < w) off += wsum[k];
+        t += wsum[k];
+    }
+    __syncthreads();
+    *tot = t;
+    return off + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(const unsigned *__restrict__ in, int *__restrict__ out,
+                                                           unsigned *__restrict__ block_sum, int64_t n)
+{
+    const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    unsigned v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        s += v[k];
+    }
+    unsigned tot;
+    unsigned ex = block_excl_scan(s, &tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = (int)ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = tot;
+}
+
+// one block scans the per-block totals in place (exclusive)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(unsigned *__restrict__ block_sum, int64_t nb)
+{
+    unsigned carry = 0;
+    for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
+        int64_t idx = base + threadIdx.x;
+        unsigned v = idx < nb ? block_sum[idx] : 0u;
+        unsigned tot;
+        unsigned ex = block_excl_scan(v, &tot);
+        if (idx < nb) block_sum[idx] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int *__restrict__ out, const unsigned *__restrict__ block_sum,
+                                                         int64_t n, int total)
+{
+    const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    const unsigned off = block_sum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) out[base + k] += (int)off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total;
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const int *__restrict__ cell_id, const int *__restrict__ rank,
+                                                 const int *__restrict__ cell_start, int *__restrict__ order,
+                                                 int64_t N)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    order[cell_start[cell_id[i]] + rank[i]] = (int)i;
+}
+
+// The atomic counters hand out slots in arbitrary order; put every cell's
+// atoms into DESCENDING id order (what a walk of the reference's linked list
+// sees, neighbor.cpp:97-98) so that rows come out in reference order and the
+// result is deterministic.  One thread per cell; cells hold a handful of atoms.
+__global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell_start, int *__restrict__ order,
+                                                    int64_t ncell)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell)
+        return;
+    const int s = cell_start[c], e = cell_start[c + 1];
+    for (int a = s + 1; a < e; ++a) {
+        int v = order[a], q = a - 1;
+        while (q >= s && order[q] < v) {
+            order[q + 1] = order[q];
+            --q;
+        }
+        order[q + 1] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, const double *__restrict__ y,
+                                                const double *__restrict__ z, const int *__restrict__ order,
+                                                double *__restrict__ xs, double *__restrict__ ys,
+                                                double *__restrict__ zs, int64_t N)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N)
+        return;
+    const int i = order[p];
+    xs[p] = x[i];
+    ys[p] = y[i];
+    zs[p] = z[i];
+}
+
+int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
+{
+    double nc_total = 1.0;
+    for (int d = 0; d < 3; ++d) { // neighbor.cpp:203-206
+        double f = std::floor(b.thick[d] / rc);
+        if (!(f < 2147483647.0)) { set_error("cell grid too large (box thickness / rc overflows int)"); return MDH_ERR_ARG; }
+        int n = (int)f;
+        g.nc[d] = n > 3 ? n : 3;
+        nc_total *= (double)g.nc[d];
+    }
+    if (nc_total > 2147483000.0) {
+        set_error("cell grid too large: " + std::to_string(nc_total) + " cells (the reference indexes cells with int32)");
+        return MDH_ERR_ARG;
+    }
+    g.ncell = (int64_t)g.nc[0] * g.nc[1] * g.nc[2];
+    g.rc_inv = 1.0 / rc; // neighbor.cpp:78
+    g.mode = 0;
+    return MDH_OK;
+}
+
+int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
+                    bool wrap_first, bool sort_desc, CellGrid &cg)
+{
+    const Grid &g = cg.g;
+    hipStream_t st = sc.stream();
+
+    unsigned *cell_count = sc.alloc_n<unsigned>((size_t)g.ncell);
+    cg.cell_start = sc.alloc_n<int>((size_t)g.ncell + 1);
+    int *cell_id = sc.alloc_n<int>((size_t)N);
+    int *rank = sc.alloc_n<int>((size_t)N);
+    cg.order = sc.alloc_n<int>((size_t)N);
+    cg.xs = sc.alloc_n<double>((size_t)N);
+    cg.ys = sc.alloc_n<double>((size_t)N);
+    cg.zs = sc.alloc_n<double>((size_t)N);
+    const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+    unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk);
+    if (sc.failed())
+        return sc.error();
+
+    MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * (size_t)g.ncell, st));
+    if (b.tri)
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count);
+    else
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
+    hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
+    if (sort_desc)
+        hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell);
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
+
+// ----------------------------------------------------------------------------
+// 27-cell scan, one thread per centre atom (centres taken in cell order so the
+// lanes of a wave share their candidate cells through L1/L2).
+//   MODE 0: count only            (first pass of the exact-width variant)
+//   MODE 1: reference semantics   (write valid slots only, caller pre-filled pads)
+//   MODE 2: also write the pads   (-1, rc+1)
+// ----------------------------------------------------------------------------
+template <bool TRI, int MODE>
+__global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                  const double *__restrict__ zs, const int *__restrict__ order,
+                                                  const int *__restrict__ cell_start, int64_t N, DBox b, Grid g,
+                                                  double rc, int *__restrict__ verlet, double *__restrict__ dist,
+                                                  int *__restrict__ nn, int64_t M, int *__restrict__ max_count)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int cnt = 0;
+    if (p < N) {
+        const int i = order[p];
+        double xi = xs[p], yi = ys[p], zi = zs[p];
+        if (b.anypbc) // neighbor.cpp:139-142
+            wrap<TRI>(b, xi, yi, zi);
+        int c0, c1, c2;
+        cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+        const double rcsq = rc * rc; // neighbor.cpp:127
+        const int64_t row = (int64_t)i * M;
+        const bool zrun = (c2 >= 1) && (c2 + 1 < g.nc[2]); // the three z-cells are one contiguous run
+        for (int a = c0 - 1; a <= c0 + 1; ++a) {            // neighbor.cpp:147-151
+            const int ca = pmod(a, g.nc[0]);
+            for (int bb = c1 - 1; bb <= c1 + 1; ++bb) {
+                const int64_t base = ((int64_t)ca * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2];
+                for (int seg = 0; seg < (zrun ? 1 : 3); ++seg) {
+                    int s, e;
+                    if (zrun) {
+                        s = cell_start[base + c2 - 1];
+                        e = cell_start[base + c2 + 2];
+                    } else {
+                        const int cc = pmod(c2 - 1 + seg, g.nc[2]);
+                        s = cell_start[base + cc];
+                        e = cell_start[base + cc + 1];
+                    }
+                    for (int q = s; q < e; ++q) {
+                        const int j = order[q];
+                        if (j == i)
+                            continue;
+                        double dx = xs[q] - xi, dy = ys[q] - yi, dz = zs[q] - zi; // raw x[j] - wrapped centre, :164-166
+                        pbc<TRI>(b, dx, dy, dz);
+                        const double d2 = dx * dx + dy * dy + dz * dz;
+                        if (d2 <= rcsq) {
+                            if (MODE != 0 && cnt < M) {
+                                verlet[row + cnt] = j;
+                                dist[row + cnt] = sqrt(d2);
+                            }
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+        }
+        nn[i] = cnt;
+        if (MODE == 2) {
+            const double pad = rc + 1.0;
+            for (int64_t n = cnt; n < M; ++n) {
+                verlet[row + n] = -1;
+                dist[row + n] = pad;
+            }
+        }
+    }
+    if (MODE == 0) {
+        int m = cnt;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            int t = __shfl_xor(m, d, 64);
+            m = t > m ? t : m;
+        }
+        if ((threadIdx.x & 63) == 0 && m > 0)
+            atomicMax(max_count, m);
+    }
+}
+
+template <int MODE>
+static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const DBox &b, double rc, int *verlet,
+                            double *dist, int *nn, int64_t M, int *max_count)
+{
+    dim3 grid(grid_for(N, 256)), block(256);
+    if (b.tri)
+        hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count);
+    else
+        hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count);
+}
+
+// ----------------------------------------------------------------------------
+// small row-wise helpers
+// ----------------------------------------------------------------------------
+// neighbor.cpp:745-775: selection of the first k entries by strict '<' over all M columns
+__global__ __launch_bounds__(256) void k_sort_rows(int *__restrict__ verlet, double *__restrict__ dist, int64_t N,
+                                                   int64_t M, int k)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    int *v = verlet + i * M;
+    double *d = dist + i * M;
+    for (int a = 0; a < k; ++a) {
+        int best = a;
+        double db = d[a];
+        for (int c = a + 1; c < M; ++c) {
+            double t = d[c];
+            if (t < db) { db = t; best = c; }
+        }
+        if (best != a) {
+            double td = d[a]; d[a] = db; d[best] = td;
+            int tv = v[a]; v[a] = v[best]; v[best] = tv;
+        }
+    }
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_wrap(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                              int64_t N, DBox b)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double xi = x[i], yi = y[i], zi = z[i];
+    wrap<TRI>(b, xi, yi, zi); // neighbor.cpp:695 (unconditional)
+    x[i] = xi; y[i] = yi; z[i] = zi;
+}
+
+__global__ __launch_bounds__(256) void k_average(double rc, const int *__restrict__ verlet,
+                                                 const double *__restrict__ dist, const int *__restrict__ nn,
+                                                 int64_t N, int64_t M, const double *__restrict__ value,
+                                                 double *__restrict__ out, int include_self)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double s = 0.0;
+    int cnt = 0;
+    if (include_self) { s += value[i]; ++cnt; }
+    const int n = nn[i];
+    for (int j = 0; j < n; ++j) // neighbor.cpp:729-736 (sequential sum in list order)
+        if (dist[i * M + j] <= rc) { s += value[verlet[i * M + j]]; ++cnt; }
+    out[i] = cnt > 0 ? s / cnt : 0.0;
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" {
+
+int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                       const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
+                       int64_t max_neigh, int fill_pads, int space, void *stream)
+{
+    if (N < 0 || N >= 2147483647LL || !(rc > 0) || max_neigh <= 0) { set_error("mdh_build_neighbor: invalid N, rc or max_neigh"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    // host space + reference semantics: pads come from the caller's buffers, so they are uploaded too
+    int *dv = sc.stage(verlet, (size_t)(N * max_neigh), space, !fill_pads, true);
+    double *dd = sc.stage(dist, (size_t)(N * max_neigh), space, !fill_pads, true);
+    int *dn = sc.stage(nn, (size_t)N, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    CellGrid cg;
+    MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    {
+        ProfRange pr("cell_grid", sc.stream());
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
+    }
+    {
+        ProfRange pr("k_neighbor", sc.stream());
+        if (fill_pads)
+            launch_neighbor<2>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr);
+        else
+            launch_neighbor<1>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr);
+    }
+    return sc.finish(space);
+}
+
+int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                       const double *origin3, const int *boundary3, double rc, int *nn, int *max_count, int space,
+                       void *stream)
+{
+    if (N < 0 || N >= 2147483647LL || !(rc > 0) || !max_count) { set_error("mdh_neighbor_count: invalid N or rc"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    *max_count = 0;
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    int *dn = sc.stage(nn, (size_t)N, space, false, true);
+    int *dmax = sc.alloc_n<int>(1);
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), sc.stream()));
+    CellGrid cg;
+    MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
+    launch_neighbor<0>(sc.stream(), cg, N, b, rc, nullptr, nullptr, dn, 1, dmax);
+    MDH_HIP(hipMemcpyAsync(max_count, dmax, sizeof(int), hipMemcpyDeviceToHost, sc.stream()));
+    MDH_TRY(sc.finish(space));
+    MDH_HIP(hipStreamSynchronize(sc.stream()));
+    return MDH_OK;
+}
+
+int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M, int sort_num, int space, void *stream)
+{
+    if (N < 0 || M <= 0) { set_error("mdh_sort_verlet_by_distance: invalid shape"); return MDH_ERR_ARG; }
+    if (N == 0 || sort_num <= 0)
+        return MDH_OK;
+    Scope sc(stream);
+    int *dv = sc.stage(verlet, (size_t)(N * M), space, true, true);
+    double *dd = sc.stage(dist, (size_t)(N * M), space, true, true);
+    if (sc.failed())
+        return sc.error();
+    const int k = (int)(sort_num < M ? sort_num : M);
+    hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, k);
+    return sc.finish(space);
+}
+
+int mdh_wrap_positions(double *x, double *y, double *z, int64_t N, const double *box9, const double *origin3,
+                       const int *boundary3, int space, void *stream)
+{
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N <= 0)
+        return MDH_OK;
+    Scope sc(stream);
+    double *dx = sc.stage(x, (size_t)N, space, true, true), *dy = sc.stage(y, (size_t)N, space, true, true), *dz = sc.stage(z, (size_t)N, space, true, true);
+    if (sc.failed())
+        return sc.error();
+    if (b.tri)
+        hipLaunchKernelGGL(k_wrap<true>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b);
+    else
+        hipLaunchKernelGGL(k_wrap<false>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b);
+    return sc.finish(space);
+}
+
+int mdh_average_by_neighbor(double rc, const int *verlet, const double *dist, const int *nn, int64_t N, int64_t M,
+                            const double *value, double *value_ave, int include_self, int space, void *stream)
+{
+    if (N <= 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const double *dd = sc.stage_in(dist, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    const double *dval = sc.stage_in(value, (size_t)N, space);
+    double *dout = sc.stage(value_ave, (size_t)N, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    hipLaunchKernelGGL(k_average, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), rc, dv, dd, dn, N, M, dval, dout, include_self);
+    return sc.finish(space);
+}
+}

@@ -1,0 +1,267 @@
+// runtime.hip — error reporting, per-device scratch cache, host<->HBM staging,
+// and the host-side construction of the kernel-visible box.
+#include "common.hpp"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace mdh {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string &msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
+    return MDH_ERR_HIP;
+}
+
+// ----------------------------------------------------------------------------
+// scratch cache: blocks are handed out best-fit and returned at Scope exit
+// ----------------------------------------------------------------------------
+struct Block { void *p; size_t bytes; bool busy; int device; };
+static std::mutex g_mu;
+static std::vector<Block> g_blocks;
+
+Scope::Scope(void *stream) : stream_(static_cast<hipStream_t>(stream))
+{
+    device_ = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) { // no CPU fallback: fail loudly
+        set_error(std::string("HIP error: no ROCm device available (") + hipGetErrorString(e) + "); mdapy_amd needs an AMD GPU (gfx950)");
+        failed_ = true;
+        err_ = MDH_ERR_HIP;
+        return;
+    }
+    (void)hipGetDevice(&device_);
+}
+
+Scope::~Scope()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < nheld_; ++i)
+        for (auto &b : g_blocks)
+            if (b.p == held_[i]) { b.busy = false; break; }
+}
+
+void *Scope::alloc(size_t bytes)
+{
+    if (failed_)
+        return nullptr;
+    if (nheld_ >= kMaxHeld) { set_error("internal: too many scratch buffers in one call"); failed_ = true; return nullptr; }
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_blocks.size(); ++i) {
+        const Block &b = g_blocks[i];
+        if (!b.busy && b.device == device_ && b.bytes >= bytes && (best < 0 || b.bytes < g_blocks[best].bytes))
+            best = (int)i;
+    }
+    // reuse only if the block is not grossly oversized (keeps big list buffers from being pinned by tiny requests)
+    if (best >= 0 && g_blocks[best].bytes <= 2 * bytes + (1u << 20)) {
+        g_blocks[best].busy = true;
+        held_[nheld_] = g_blocks[best].p;
+        held_bytes_[nheld_++] = g_blocks[best].bytes;
+        return g_blocks[best].p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop idle cached blocks of this device and retry once
+        for (size_t i = 0; i < g_blocks.size();) {
+            if (!g_blocks[i].busy && g_blocks[i].device == device_) { (void)hipFree(g_blocks[i].p); g_blocks.erase(g_blocks.begin() + i); }
+            else ++i;
+        }
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("device allocation of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+        failed_ = true;
+        return nullptr;
+    }
+    g_blocks.push_back(Block{p, bytes, true, device_});
+    held_[nheld_] = p;
+    held_bytes_[nheld_++] = bytes;
+    return p;
+}
+
+void *Scope::stage_raw(void *p, size_t bytes, int space, bool in, bool out)
+{
+    if (space == MDH_DEVICE || p == nullptr)
+        return p;
+    void *d = alloc(bytes);
+    if (!d)
+        return nullptr;
+    if (in && bytes) {
+        hipError_t e = hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, stream_);
+        if (e != hipSuccess) { hip_fail(e, "hipMemcpyAsync(H2D)", __FILE__, __LINE__); failed_ = true; err_ = MDH_ERR_HIP; return nullptr; }
+    }
+    if (out) {
+        if (nouts_ >= 16) { set_error("internal: too many staged outputs"); failed_ = true; return nullptr; }
+        outs_[nouts_++] = Out{p, d, bytes};
+    }
+    return d;
+}
+
+int Scope::finish(int space)
+{
+    if (failed_)
+        return err_;
+    MDH_HIP(hipGetLastError());
+    if (space == MDH_HOST) {
+        for (int i = 0; i < nouts_; ++i)
+            if (outs_[i].bytes)
+                MDH_HIP(hipMemcpyAsync(outs_[i].host, outs_[i].dev, outs_[i].bytes, hipMemcpyDeviceToHost, stream_));
+        MDH_HIP(hipStreamSynchronize(stream_));
+    }
+    return MDH_OK;
+}
+
+// ----------------------------------------------------------------------------
+// box
+// ----------------------------------------------------------------------------
+static double det3(const double *d, bool tri) // box.h:22-35
+{
+    if (tri)
+        return d[0] * (d[4] * d[8] - d[5] * d[7]) - d[1] * (d[3] * d[8] - d[5] * d[6]) + d[2] * (d[3] * d[7] - d[4] * d[6]);
+    return d[0] * d[4] * d[8];
+}
+
+// total order preserving map double <-> int64 (for bisection over representable doubles)
+static int64_t to_key(double v)
+{
+    int64_t k;
+    std::memcpy(&k, &v, 8);
+    return k < 0 ? (int64_t)(0x8000000000000000ull - (uint64_t)k) : k;
+}
+static double from_key(int64_t k)
+{
+    if (k < 0) k = (int64_t)(0x8000000000000000ull - (uint64_t)k);
+    double v;
+    std::memcpy(&v, &k, 8);
+    return v;
+}
+
+// smallest double d with floor(d / L + 0.5) >= n   (L > 0)
+static double image_threshold(double L, double n)
+{
+    auto f = [L](double d) { return std::floor(d / L + 0.5); };
+    int64_t lo = to_key(-8.0 * L), hi = to_key(8.0 * L); // f(lo) < n <= f(hi) for n in [-1,2]
+    while (hi - lo > 1) {
+        int64_t mid = lo + (hi - lo) / 2;
+        if (f(from_key(mid)) >= n) hi = mid; else lo = mid;
+    }
+    return from_key(hi);
+}
+
+int make_box(DBox &b, const double *box9, const double *origin3, const int *boundary3)
+{
+    std::memset(&b, 0, sizeof(b));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            b.h[i * 3 + j] = box9[i * 3 + j];
+            if (i != j && std::fabs(box9[i * 3 + j]) > 1e-10) // box.h:216-218
+                b.tri = 1;
+        }
+    if (b.h[0] < 0 || b.h[4] < 0 || b.h[8] < 0) // box.h:221-222
+        b.tri = 1;
+    if (b.tri) {
+        double det = det3(b.h, true);
+        if (std::fabs(det) < 1e-12) { // box.h:185-186
+            set_error("The volume of the box is zero.");
+            return MDH_ERR_BOX;
+        }
+        const double id = 1.0 / det;
+        const double *m = b.h;
+        b.hi[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+        b.hi[1] = -(m[1] * m[8] - m[2] * m[7]) * id;
+        b.hi[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+        b.hi[3] = -(m[3] * m[8] - m[5] * m[6]) * id;
+        b.hi[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+        b.hi[5] = -(m[0] * m[5] - m[2] * m[3]) * id;
+        b.hi[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+        b.hi[7] = -(m[0] * m[7] - m[1] * m[6]) * id;
+        b.hi[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    } else {
+        b.hi[0] = 1.0 / b.h[0];
+        b.hi[4] = 1.0 / b.h[4];
+        b.hi[8] = 1.0 / b.h[8];
+    }
+    for (int i = 0; i < 3; ++i) {
+        b.o[i] = origin3[i];
+        b.pbc[i] = boundary3[i] ? 1 : 0;
+    }
+    b.anypbc = b.pbc[0] || b.pbc[1] || b.pbc[2];
+    for (int dir = 0; dir < 3; ++dir) { // box.h:54-89
+        if (!b.tri) { b.thick[dir] = b.h[dir * 4]; continue; }
+        const double V = det3(b.h, true);
+        const double *A = b.h, *B = b.h + 3, *C = b.h + 6;
+        const double *p = dir == 0 ? B : A;
+        const double *q = dir == 2 ? B : C;
+        const double mm = p[1] * q[2] - p[2] * q[1];
+        const double nn = p[2] * q[0] - p[0] * q[2];
+        const double kk = p[0] * q[1] - p[1] * q[0];
+        b.thick[dir] = V / std::sqrt(mm * mm + nn * nn + kk * kk);
+    }
+    for (int a = 0; a < 3; ++a) {
+        const double L = b.h[a * 4];
+        if (!b.tri && b.pbc[a] && L > 0 && std::isfinite(L)) {
+            for (int k = 0; k < 4; ++k)
+                b.tn[a][k] = image_threshold(L, (double)(k - 1));
+        } else { // empty fast range => kernels always take the exact division path
+            b.tn[a][0] = 1.0; b.tn[a][1] = 0.0; b.tn[a][2] = 0.0; b.tn[a][3] = 0.0;
+        }
+    }
+    return MDH_OK;
+}
+
+} // namespace mdh
+
+// ----------------------------------------------------------------------------
+// C ABI: runtime
+// ----------------------------------------------------------------------------
+extern "C" {
+
+const char *mdh_last_error(void) { return mdh::g_err.c_str(); }
+
+int mdh_version(void) { return 100; }
+
+int mdh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int mdh_set_device(int device)
+{
+    MDH_HIP(hipSetDevice(device));
+    return MDH_OK;
+}
+
+int mdh_release_workspace(void)
+{
+    std::lock_guard<std::mutex> lk(mdh::g_mu);
+    for (size_t i = 0; i < mdh::g_blocks.size();) {
+        if (!mdh::g_blocks[i].busy) { (void)hipFree(mdh::g_blocks[i].p); mdh::g_blocks.erase(mdh::g_blocks.begin() + i); }
+        else ++i;
+    }
+    return MDH_OK;
+}
+
+int64_t mdh_workspace_bytes(void)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mdh::g_mu);
+    int64_t s = 0;
+    for (auto &b : mdh::g_blocks)
+        if (b.device == dev) s += (int64_t)b.bytes;
+    return s;
+}
+}

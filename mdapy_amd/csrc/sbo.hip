@@ -1,0 +1,414 @@
+// sbo.hip — Steinhardt bond-orientational order parameters on gfx950.
+//
+// Replaces src/steinhardt_bond_orientation.cpp: get_sq :677-784 over _compute_ql
+// :288-576 (stage 1 q_lm, stage 2 Lechner-Dellago neighbour average, stage 3
+// q_l / w_l / w_l-hat) and identifySolidLiquid :578-675.
+//
+// Stage 1: one thread per atom; the 2*nl*(2lmax+1) running sums of an atom live
+// in LDS (lane-strided, conflict free) while its neighbours are visited in list
+// order — the same sequence of += as the reference, so sums agree to the last
+// bit wherever the spherical-harmonic factors do.  The (l,m) normalisation
+// sqrt((2l+1)/(4 pi prod)) (:270-279) does not depend on the bond and is
+// tabulated once on the host with the reference's expression.
+#include "common.hpp"
+#include <vector>
+
+namespace mdh {
+
+static constexpr int SBO_MAXL = 16;  // entries of llist
+static constexpr int SBO_LMAX = 40;  // largest degree (3l+1 must index the 168-entry factorial table)
+static constexpr double MY_PI = 3.14159265358979323846;
+
+struct LList { int l[SBO_MAXL]; int n; };
+
+__device__ __forceinline__ double assoc_legendre(int l, int m, double x) // :243-268
+{
+    double p = 1.0, pm1 = 0.0, pm2 = 0.0;
+    if (m != 0) {
+        const double sqx = sqrt(1.0 - x * x);
+        for (int i = 1; i < m + 1; ++i)
+            p *= (2 * i - 1) * sqx;
+    }
+    for (int i = m + 1; i < l + 1; ++i) {
+        pm2 = pm1;
+        pm1 = p;
+        p = ((2 * i - 1) * x * pm1 - (i + m - 1) * pm2) / (i - m);
+    }
+    return p;
+}
+
+// LDS accumulators: component c of thread t at acc[c * blockDim.x + t]
+template <bool TRI, bool LDSACC>
+__global__ void k_sq_stage1(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                            int64_t N, DBox b, const int *__restrict__ NL, const double *__restrict__ DL, int64_t M,
+                            const int *__restrict__ NN, const double *__restrict__ weight, LList ll, int nnn, int lmax,
+                            int use_voronoi, double rc, int use_weight, const double *__restrict__ norm /* [nl][lmax+1] */,
+                            double *__restrict__ qlm_r, double *__restrict__ qlm_i)
+{
+    extern __shared__ double acc[];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int nz = 2 * lmax + 1, nl = ll.n;
+    const int stride = nl * nz;
+    const int bd = blockDim.x, t = threadIdx.x;
+    double *gr = qlm_r + i * stride, *gi = qlm_i + i * stride;
+    if (LDSACC) // start from the caller's (pre-zeroed) content, like the reference's '+=' on the output arrays
+        for (int c = 0; c < stride; ++c) {
+            acc[c * bd + t] = gr[c];
+            acc[(stride + c) * bd + t] = gi[c];
+        }
+#define QR(c) (LDSACC ? acc[(c) * bd + t] : gr[c])
+#define QI(c) (LDSACC ? acc[(stride + (c)) * bd + t] : gi[c])
+    const double EPS = 1e-15;
+    const double x1 = x[i], y1 = y[i], z1 = z[i];
+    int cnt = NN[i];
+    if (!use_voronoi && nnn > 0) // :329-333
+        cnt = nnn;
+    double wsum = 0.0;
+    for (int jj = 0; jj < cnt; ++jj) {
+        const int64_t idx = i * M + jj;
+        const int j = NL[idx];
+        if (j < 0)
+            continue;
+        double dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1; // :346-350
+        pbc<TRI>(b, dx, dy, dz);
+        const double r = DL[idx];
+        if (!((r > EPS) && (r <= rc)))
+            continue;
+        const double w = use_weight ? weight[idx] : 1.0;
+        wsum += w;
+        const double rinv = 1.0 / r;
+        const double ct = dz * rinv;
+        double er = dx, ei = dy;
+        const double rxy2 = er * er + ei * ei;
+        if (rxy2 < EPS * EPS) { er = 1.0; ei = 0.0; }
+        else { const double s = 1.0 / sqrt(rxy2); er *= s; ei *= s; }
+        for (int il = 0; il < nl; ++il) {
+            const int l = ll.l[il];
+            const int o = il * nz;
+            const double *nrm = norm + il * (lmax + 1);
+            QR(o + l) += w * (nrm[0] * assoc_legendre(l, 0, ct));
+            double mr = er, mi = ei;
+            for (int m = 1; m < l + 1; ++m) {
+                const double pf = nrm[m] * assoc_legendre(l, m, ct);
+                const double cr = pf * mr, ci = pf * mi;
+                const double wr = w * cr, wi = w * ci;
+                QR(o + l + m) += wr;
+                QI(o + l + m) += wi;
+                if (m & 1) { QR(o + l - m) -= wr; QI(o + l - m) += wi; }
+                else { QR(o + l - m) += wr; QI(o + l - m) -= wi; }
+                const double tr = mr * er - mi * ei, ti = mr * ei + mi * er;
+                mr = tr; mi = ti;
+            }
+        }
+    }
+    const double f = 1.0 / wsum; // :422 (no guard: NaN/inf for an atom without neighbours)
+    for (int il = 0; il < nl; ++il) {
+        const int l = ll.l[il];
+        for (int m = 0; m < 2 * l + 1; ++m) {
+            const int c = il * nz + m;
+            QR(c) *= f;
+            QI(c) *= f;
+        }
+    }
+    if (LDSACC)
+        for (int c = 0; c < stride; ++c) {
+            gr[c] = acc[c * bd + t];
+            gi[c] = acc[(stride + c) * bd + t];
+        }
+#undef QR
+#undef QI
+}
+
+// stage 2 (:439-503): one thread per (atom, component); neighbours added in list order
+__global__ __launch_bounds__(256) void k_sq_average(int64_t N, const int *__restrict__ NL, int64_t M,
+                                                    const int *__restrict__ NN, LList ll, int nnn, int lmax,
+                                                    int use_voronoi, const double *__restrict__ ar,
+                                                    const double *__restrict__ ai, double *__restrict__ qlm_r,
+                                                    double *__restrict__ qlm_i)
+{
+    const int nz = 2 * lmax + 1, stride = ll.n * nz;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N * stride)
+        return;
+    const int64_t i = g / stride;
+    const int c = (int)(g % stride);
+    const int il = c / nz, m = c % nz;
+    if (m >= 2 * ll.l[il] + 1)
+        return;
+    int cnt = NN[i];
+    if (!use_voronoi && nnn > 0)
+        cnt = nnn;
+    double sr = qlm_r[g], si = qlm_i[g];
+    int nb = 1;
+    for (int jj = 0; jj < cnt; ++jj) {
+        const int j = NL[i * M + jj];
+        if (j < 0)
+            continue;
+        sr += ar[(int64_t)j * stride + c];
+        si += ai[(int64_t)j * stride + c];
+        ++nb;
+    }
+    const double inv = 1.0 / nb;
+    qlm_r[g] = sr * inv;
+    qlm_i[g] = si * inv;
+}
+
+// stage 3 (:506-575)
+__global__ __launch_bounds__(256) void k_sq_final(int64_t N, LList ll, int lmax, int wl, int wlhat,
+                                                  const double *__restrict__ cg, const double *__restrict__ qlm_r,
+                                                  const double *__restrict__ qlm_i, double *__restrict__ qn, int ncol)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int nz = 2 * lmax + 1, nl = ll.n;
+    const double *qr = qlm_r + i * nl * nz, *qi = qlm_i + i * nl * nz;
+    double *out = qn + i * ncol;
+    const double EPS = 1e-15;
+    for (int il = 0; il < nl; ++il) {
+        const int l = ll.l[il];
+        const double nf = sqrt(4 * MY_PI / (2 * l + 1));
+        double s = 0.0;
+        for (int m = 0; m < 2 * l + 1; ++m)
+            s += qr[il * nz + m] * qr[il * nz + m] + qi[il * nz + m] * qi[il * nz + m];
+        out[il] = nf * sqrt(s);
+    }
+    if (wl | wlhat) {
+        int c = 0;
+        for (int il = 0; il < nl; ++il) {
+            const int l = ll.l[il];
+            const double *pr = qr + il * nz, *pi = qi + il * nz;
+            double ws = 0.0;
+            for (int m1 = 0; m1 < 2 * l + 1; ++m1) {
+                const int lo = (l - m1) > 0 ? (l - m1) : 0;
+                const int hi = (2 * l + 1) < (3 * l - m1 + 1) ? (2 * l + 1) : (3 * l - m1 + 1);
+                for (int m2 = lo; m2 < hi; ++m2) {
+                    const int m = m1 + m2 - l;
+                    const double a_r = pr[m1] * pr[m2] - pi[m1] * pi[m2];
+                    const double a_i = pr[m1] * pi[m2] + pi[m1] * pr[m2];
+                    ws += (a_r * pr[m] + a_i * pi[m]) * cg[c];
+                    ++c;
+                }
+            }
+            const double wf = ws / sqrt(2 * l + 1.0);
+            if (wl)
+                out[il + nl] = wf;
+            if (wlhat) {
+                const double q = out[il];
+                if (q > EPS) {
+                    const double nf = sqrt(4 * MY_PI / (2 * l + 1));
+                    const double gfac = nf / q;
+                    out[il + (wl ? nl : 0) + nl] = wf * (gfac * gfac * gfac);
+                }
+            }
+        }
+    }
+}
+
+// identifySolidLiquid pass 1 (:605-643)
+__global__ __launch_bounds__(256) void k_solid_bonds(int q6index, const double *__restrict__ Q6,
+                                                     const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                     const int *__restrict__ nn, int64_t N, int64_t M,
+                                                     const double *__restrict__ qlm_r, const double *__restrict__ qlm_i,
+                                                     int nl, int nz, double threshold, int n_bond,
+                                                     int *__restrict__ solid, int *__restrict__ nbond, int use_voronoi,
+                                                     int nnn, double rc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int64_t stride = (int64_t)nl * nz;
+    int cnt = nn[i], nsb = 0;
+    if (!use_voronoi && nnn > 0)
+        cnt = nnn;
+    const double *ar = qlm_r + i * stride + q6index * nz, *ai = qlm_i + i * stride + q6index * nz;
+    for (int jj = 0; jj < cnt; ++jj) {
+        const int j = verlet[i * M + jj];
+        if (j < 0) continue;
+        if (dist[i * M + jj] > rc) continue;
+        const double *br = qlm_r + (int64_t)j * stride + q6index * nz, *bi = qlm_i + (int64_t)j * stride + q6index * nz;
+        double s = 0.0;
+        for (int m = 0; m < 13; ++m)
+            s += ar[m] * br[m] + ai[m] * bi[m];
+        s = s / Q6[i] / Q6[j] * 4 * MY_PI / 13;
+        if (s > threshold) ++nsb;
+    }
+    if (nsb >= n_bond) solid[i] = 1;
+    nbond[i] = nsb;
+}
+
+// pass 2 (:645-674): a solid atom without any solid neighbour becomes liquid.  The reference updates
+// the labels in place from concurrent threads; here every atom is judged against the pass-1 labels.
+__global__ __launch_bounds__(256) void k_solid_cleanup(const int *__restrict__ verlet, const int *__restrict__ nn,
+                                                       int64_t N, int64_t M, const int *__restrict__ snap,
+                                                       int *__restrict__ solid, int use_voronoi, int nnn)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || snap[i] != 1)
+        return;
+    int cnt = nn[i];
+    if (!use_voronoi && nnn > 0)
+        cnt = nnn;
+    for (int jj = 0; jj < cnt; ++jj) {
+        const int j = verlet[i * M + jj];
+        if (j < 0) continue;
+        if (snap[j] == 1) return;
+    }
+    solid[i] = 0;
+}
+
+// host tables ------------------------------------------------------------------
+static void factorials(double *f) // h_factorial, :12-181 (n! rounded to double)
+{
+    long double v = 1.0L;
+    f[0] = 1.0;
+    for (int n = 1; n < 168; ++n) { v *= (long double)n; f[n] = (double)v; }
+}
+
+static void clebsch_gordan(std::vector<double> &cg, const LList &ll) // :188-224
+{
+    double F[168];
+    factorials(F);
+    cg.clear();
+    for (int il = 0; il < ll.n; ++il) {
+        const int l = ll.l[il];
+        for (int m1 = 0; m1 < 2 * l + 1; ++m1) {
+            const int aa2 = m1 - l;
+            for (int m2 = std::max(0, l - m1); m2 < std::min(2 * l + 1, 3 * l - m1 + 1); ++m2) {
+                const int bb2 = m2 - l, m = aa2 + bb2 + l;
+                double sums = 0.0;
+                for (int zz = std::max(0, std::max(-aa2, bb2)); zz < std::min(l, std::min(l - aa2, l + bb2)) + 1; ++zz) {
+                    const int ifac = (zz % 2) ? -1 : 1;
+                    sums += ifac / (F[zz] * F[l - zz] * F[l - aa2 - zz] * F[l + bb2 - zz] * F[aa2 + zz] * F[-bb2 + zz]);
+                }
+                const int cc2 = m - l;
+                const double sfaccg = std::sqrt(F[l + aa2] * F[l - aa2] * F[l + bb2] * F[l - bb2] * F[l + cc2] * F[l - cc2] * (2 * l + 1));
+                const double sfac1 = F[3 * l + 1], sfac2 = F[l];
+                const double dcg = std::sqrt(sfac2 * sfac2 * sfac2 / sfac1);
+                cg.push_back(sums * dcg * sfaccg);
+            }
+        }
+    }
+    if (cg.empty()) cg.push_back(0.0);
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" {
+
+int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+               const double *origin3, const int *boundary3, const int *verlet, const double *dist, int64_t M,
+               const int *nn, const double *weight, const int *llist_host, int nl, int nnn, int lmax, int wl,
+               int wlhat, int average, int use_voronoi, double rc, int use_weight, double *qlm_r, double *qlm_i,
+               double *qnarray, int space, void *stream)
+{
+    if (N < 0 || M <= 0 || nl <= 0 || nl > SBO_MAXL || lmax < 0 || lmax > SBO_LMAX) {
+        set_error("mdh_get_sq: need 1 <= len(llist) <= 16 and lmax <= 40");
+        return MDH_ERR_ARG;
+    }
+    LList ll;
+    ll.n = nl;
+    for (int k = 0; k < SBO_MAXL; ++k) ll.l[k] = 0;
+    for (int k = 0; k < nl; ++k) {
+        ll.l[k] = llist_host[k];
+        if (ll.l[k] < 0 || ll.l[k] > lmax) { set_error("mdh_get_sq: every degree must satisfy 0 <= l <= lmax"); return MDH_ERR_ARG; }
+    }
+    if (use_weight && !weight) { set_error("mdh_get_sq: use_weight without weight array"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    const int nz = 2 * lmax + 1;
+    const int64_t stride = (int64_t)nl * nz;
+    const int ncol = nl + (wl ? nl : 0) + (wlhat ? nl : 0);
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const double *dd = sc.stage_in(dist, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    const double *dw = use_weight ? sc.stage_in(weight, (size_t)(N * M), space) : nullptr;
+    double *dqr = sc.stage(qlm_r, (size_t)(N * stride), space, true, true);
+    double *dqi = sc.stage(qlm_i, (size_t)(N * stride), space, true, true);
+    // stage 3 leaves some w-hat entries untouched (q <= eps), so the caller's content is kept
+    double *dqn = sc.stage(qnarray, (size_t)(N * ncol), space, true, true);
+
+    // (l,m) normalisation  sqrt((2l+1)/(4 pi prod_{i=l-m+1}^{l+m} i))   (:270-279)
+    std::vector<double> norm((size_t)nl * (lmax + 1), 0.0);
+    for (int il = 0; il < nl; ++il)
+        for (int m = 0; m <= ll.l[il]; ++m) {
+            const int l = ll.l[il];
+            double pf = 1.0;
+            for (int i = l - m + 1; i < l + m + 1; ++i)
+                pf *= i;
+            norm[(size_t)il * (lmax + 1) + m] = std::sqrt((2 * l + 1) / (4 * MY_PI * pf));
+        }
+    std::vector<double> cg;
+    if (wl || wlhat) clebsch_gordan(cg, ll);
+    else cg.push_back(0.0);
+    double *dnorm = sc.alloc_n<double>(norm.size());
+    double *dcg = sc.alloc_n<double>(cg.size());
+    double *ar = average ? sc.alloc_n<double>((size_t)(N * stride)) : nullptr;
+    double *ai = average ? sc.alloc_n<double>((size_t)(N * stride)) : nullptr;
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemcpyAsync(dnorm, norm.data(), norm.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    MDH_HIP(hipMemcpyAsync(dcg, cg.data(), cg.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    MDH_HIP(hipStreamSynchronize(st)); // norm/cg are host temporaries
+
+    // block size so that 2*stride doubles per thread fit in 64 KiB of LDS
+    int bd = (int)(65536 / (16 * stride)) / 64 * 64;
+    if (bd > 256) bd = 256;
+    if (bd >= 64) {
+        const size_t lds = (size_t)bd * 16 * (size_t)stride;
+        if (b.tri)
+            hipLaunchKernelGGL((k_sq_stage1<true, true>), dim3(grid_for(N, bd)), dim3(bd), lds, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+        else
+            hipLaunchKernelGGL((k_sq_stage1<false, true>), dim3(grid_for(N, bd)), dim3(bd), lds, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+    } else {
+        if (b.tri)
+            hipLaunchKernelGGL((k_sq_stage1<true, false>), dim3(grid_for(N, 64)), dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+        else
+            hipLaunchKernelGGL((k_sq_stage1<false, false>), dim3(grid_for(N, 64)), dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+    }
+    if (average) {
+        MDH_HIP(hipMemcpyAsync(ar, dqr, sizeof(double) * (size_t)(N * stride), hipMemcpyDeviceToDevice, st));
+        MDH_HIP(hipMemcpyAsync(ai, dqi, sizeof(double) * (size_t)(N * stride), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_sq_average, dim3(grid_for(N * stride, 256)), dim3(256), 0, st, N, dv, M, dn, ll, nnn, lmax, use_voronoi, ar, ai, dqr, dqi);
+    }
+    hipLaunchKernelGGL(k_sq_final, dim3(grid_for(N, 256)), dim3(256), 0, st, N, ll, lmax, wl, wlhat, dcg, dqr, dqi, dqn, ncol);
+    return sc.finish(space);
+}
+
+int mdh_identify_solid_liquid(int q6index, const double *Q6, const int *verlet, const double *dist, const int *nn,
+                              int64_t N, int64_t M, const double *qlm_r, const double *qlm_i, int nl, int nz,
+                              double threshold, int n_bond, int *solidliquid, int *nbond, int use_voronoi, int nnn,
+                              double rc, int space, void *stream)
+{
+    if (N < 0 || M <= 0 || nl <= 0 || nz < 13 || q6index < 0 || q6index >= nl) { set_error("mdh_identify_solid_liquid: invalid argument"); return MDH_ERR_ARG; }
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    const int64_t stride = (int64_t)nl * nz;
+    const double *dq6 = sc.stage_in(Q6, (size_t)N, space);
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const double *dd = sc.stage_in(dist, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    const double *dqr = sc.stage_in(qlm_r, (size_t)(N * stride), space);
+    const double *dqi = sc.stage_in(qlm_i, (size_t)(N * stride), space);
+    int *ds = sc.stage(solidliquid, (size_t)N, space, true, true);
+    int *db = sc.stage(nbond, (size_t)N, space, false, true);
+    int *snap = sc.alloc_n<int>((size_t)N);
+    if (sc.failed())
+        return sc.error();
+    hipLaunchKernelGGL(k_solid_bonds, dim3(grid_for(N, 256)), dim3(256), 0, st, q6index, dq6, dv, dd, dn, N, M, dqr, dqi, nl, nz, threshold, n_bond, ds, db, use_voronoi, nnn, rc);
+    MDH_HIP(hipMemcpyAsync(snap, ds, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_solid_cleanup, dim3(grid_for(N, 256)), dim3(256), 0, st, dv, dn, N, M, snap, ds, use_voronoi, nnn);
+    return sc.finish(space);
+}
+}

@@ -1,0 +1,69 @@
+// wcp.hip — Warren-Cowley short-range-order parameter on gfx950.
+//
+// Replaces src/warren_cowley_parameter.cpp:9-80 (get_wcp).  Z_mn, Z_m and the
+// per-type atom counts are integer reductions: u32 partials in LDS per
+// workgroup, u64 totals in HBM (the reference uses int32 totals, which agree
+// whenever they do not overflow), then alpha_ab = 1 - Z_ab / (c_b * Z_a).
+#include "common.hpp"
+
+namespace mdh {
+
+static constexpr int WCP_MAXT = 64; // LDS budget: (T*T + 2T) u32
+
+__global__ __launch_bounds__(256) void k_wcp_count(const int *__restrict__ verlet, const int *__restrict__ nn,
+                                                   const int *__restrict__ type, int64_t N, int64_t M, int T,
+                                                   unsigned long long *__restrict__ tot)
+{
+    extern __shared__ unsigned lds[]; // [T*T] Zmn, [T] Zm, [T] count
+    const int words = T * T + 2 * T;
+    for (int q = threadIdx.x; q < words; q += blockDim.x) lds[q] = 0u;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        const int ti = type[i], n = nn[i];
+        atomicAdd(&lds[T * T + T + ti], 1u);
+        atomicAdd(&lds[T * T + ti], (unsigned)n);
+        for (int q = 0; q < n; ++q)
+            atomicAdd(&lds[ti * T + type[verlet[i * M + q]]], 1u);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < words; q += blockDim.x) {
+        const unsigned v = lds[q];
+        if (v) atomicAdd(&tot[q], (unsigned long long)v);
+    }
+}
+
+__global__ void k_wcp_final(const unsigned long long *__restrict__ tot, int64_t N, int T, double *__restrict__ wcp)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= T * T)
+        return;
+    const int a = q / T, c = q % T;
+    const double conc = (double)tot[T * T + T + c] / (double)N; // :57-59
+    const unsigned long long zm = tot[T * T + a];
+    wcp[q] = (conc > 0 && zm > 0) ? 1.0 - (double)tot[q] / (conc * (double)zm) : 0.0; // :66-75
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" int mdh_wcp(const int *verlet, const int *nn, const int *type, int64_t N, int64_t M, int ntype,
+                       double *wcp, int space, void *stream)
+{
+    if (N <= 0 || M <= 0 || ntype <= 0 || ntype > WCP_MAXT) { set_error("mdh_wcp: need N>0, M>0 and 1 <= ntype <= 64"); return MDH_ERR_ARG; }
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    const int *dt = sc.stage_in(type, (size_t)N, space);
+    double *dw = sc.stage(wcp, (size_t)ntype * ntype, space, false, true);
+    const int words = ntype * ntype + 2 * ntype;
+    unsigned long long *tot = sc.alloc_n<unsigned long long>((size_t)words);
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemsetAsync(tot, 0, sizeof(unsigned long long) * (size_t)words, st));
+    hipLaunchKernelGGL(k_wcp_count, dim3(grid_for(N, 256)), dim3(256), sizeof(unsigned) * (size_t)words, st, dv, dn, dt, N, M, ntype, tot);
+    hipLaunchKernelGGL(k_wcp_final, dim3(grid_for(ntype * ntype, 64)), dim3(64), 0, st, tot, N, ntype, dw);
+    return sc.finish(space);
+}

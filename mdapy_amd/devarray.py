@@ -1,0 +1,294 @@
+"""HBM-resident arrays and argument marshalling for the C ABI.
+
+The reference hands numpy arrays to its extension modules.  On an MI355X the
+neighbor arrays of a 10 M-atom system are ~2 GB; bouncing them over PCIe
+between `build_neighbor` and every `cal_*` would dominate the run time, so the
+host layer keeps them in HBM as :class:`HArray` (a torch ROCm tensor with a lazy,
+read-only numpy mirror).  `HArray` quacks like the ndarray the reference exposes
+(`shape`, indexing, `min`/`max`, ``np.asarray``), so user code and the parity
+tests read `system.verlet_list[i, :n]` unchanged.
+
+torch is used for device memory and streams only (plumbing); every kernel is in
+mdapy_amd/csrc.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+_torch = None
+_gpu = None
+
+_NP2T = {}
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as t  # deferred: `import torch` costs seconds and is not needed for host-only use
+
+        _torch = t
+        _NP2T.update({np.dtype(np.float64): t.float64, np.dtype(np.int32): t.int32, np.dtype(np.int64): t.int64,
+                      np.dtype(np.float32): t.float32})
+    return _torch
+
+
+def have_gpu() -> bool:
+    """True when a HIP device is visible to both the library and torch."""
+    global _gpu
+    if _gpu is None:
+        try:
+            _gpu = _lib.device_count() > 0 and torch().cuda.is_available()
+        except Exception:
+            _gpu = False
+    return _gpu
+
+
+def current_stream_ptr() -> int:
+    return int(torch().cuda.current_stream().cuda_stream)
+
+
+class HArray:
+    """An array that lives in HBM; the host copy is made on demand and is read-only."""
+
+    __slots__ = ("_dev", "_host")
+    __array_priority__ = 100
+
+    def __init__(self, dev):
+        self._dev = dev
+        self._host = None
+
+    # ---- construction
+    @staticmethod
+    def empty(shape, dtype):
+        t = torch()
+        return HArray(t.empty(tuple(int(s) for s in np.atleast_1d(shape)), dtype=_NP2T[np.dtype(dtype)], device="cuda"))
+
+    @staticmethod
+    def full(shape, value, dtype):
+        t = torch()
+        return HArray(t.full(tuple(int(s) for s in np.atleast_1d(shape)), value, dtype=_NP2T[np.dtype(dtype)], device="cuda"))
+
+    @staticmethod
+    def from_numpy(a):
+        t = torch()
+        a = np.ascontiguousarray(a)
+        return HArray(t.from_numpy(a).to("cuda"))
+
+    # ---- device side
+    def dev(self):
+        return self._dev
+
+    def data_ptr(self) -> int:
+        return int(self._dev.data_ptr())
+
+    def invalidate_host(self):
+        """call after a kernel changed the HBM content"""
+        self._host = None
+
+    # ---- host side
+    def numpy(self) -> np.ndarray:
+        if self._host is None:
+            h = self._dev.cpu().numpy()
+            h.setflags(write=False)
+            self._host = h
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    @property
+    def shape(self):
+        return tuple(self._dev.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(str(self._dev.dtype).replace("torch.", ""))
+
+    @property
+    def ndim(self):
+        return self._dev.dim()
+
+    @property
+    def size(self):
+        return int(self._dev.numel())
+
+    def __len__(self):
+        return self._dev.shape[0]
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __repr__(self):
+        return f"HArray(shape={self.shape}, dtype={self.dtype}, device='hbm')"
+
+    def min(self, *a, **k):
+        if not a and not k and self.size:
+            return self.dtype.type(self._dev.min().item())
+        return self.numpy().min(*a, **k)
+
+    def max(self, *a, **k):
+        if self.size and not a and set(k) <= {"initial"}:
+            m = self._dev.max().item()
+            if "initial" in k:
+                m = max(m, k["initial"])
+            return self.dtype.type(m)
+        return self.numpy().max(*a, **k)
+
+    def sum(self, *a, **k):
+        return self.numpy().sum(*a, **k)
+
+    def copy(self):
+        return self.numpy().copy()
+
+    def astype(self, dtype, **k):
+        return self.numpy().astype(dtype, **k)
+
+    def tolist(self):
+        return self.numpy().tolist()
+
+    def _cmp(self, other, op):
+        return op(self.numpy(), np.asarray(other))
+
+    def __eq__(self, other):
+        return self._cmp(other, np.equal)
+
+    def __ne__(self, other):
+        return self._cmp(other, np.not_equal)
+
+    def __lt__(self, other):
+        return self._cmp(other, np.less)
+
+    def __le__(self, other):
+        return self._cmp(other, np.less_equal)
+
+    def __gt__(self, other):
+        return self._cmp(other, np.greater)
+
+    def __ge__(self, other):
+        return self._cmp(other, np.greater_equal)
+
+    __hash__ = None
+
+
+def as_numpy(a):
+    """host ndarray view of numpy / HArray / Column input"""
+    if isinstance(a, np.ndarray):
+        return a
+    if isinstance(a, HArray):
+        return a.numpy()
+    if hasattr(a, "to_numpy"):
+        return a.to_numpy()
+    return np.asarray(a)
+
+
+def zeros(shape, dtype):
+    """output buffer: HBM when a GPU is there, numpy otherwise (host-logic tests with a patched backend)"""
+    if have_gpu():
+        return HArray.full(shape, 0, dtype)
+    return np.zeros(shape, dtype)
+
+
+def full(shape, value, dtype):
+    if have_gpu():
+        return HArray.full(shape, value, dtype)
+    return np.full(shape, value, dtype)
+
+
+def empty(shape, dtype):
+    if have_gpu():
+        return HArray.empty(shape, dtype)
+    return np.empty(shape, dtype)
+
+
+# ---------------------------------------------------------------------------
+# marshalling
+# ---------------------------------------------------------------------------
+class Call:
+    """Collects the array arguments of one C-ABI call and decides the memory space.
+
+    space = HOST  iff every array argument is a plain numpy array (the library
+                  stages through HBM itself);
+    space = DEVICE otherwise: numpy inputs are uploaded, numpy outputs are
+                  written back after the call.
+    """
+
+    def __init__(self, *arrays):
+        self._keep = []
+        self._writeback = []
+        dev = False
+        for a in arrays:
+            if a is None or isinstance(a, np.ndarray):
+                continue
+            dev = True
+        self.space = _lib.DEVICE if dev else _lib.HOST
+        self.stream = current_stream_ptr() if dev else None
+
+    def _is_dev(self):
+        return self.space == _lib.DEVICE
+
+    def inp(self, a, dtype):
+        """read-only array argument -> pointer"""
+        if a is None:
+            return None
+        dtype = np.dtype(dtype)
+        if isinstance(a, HArray) or hasattr(a, "device_array"):
+            h = a if isinstance(a, HArray) else a.device_array()
+            if h.dtype != dtype:
+                raise TypeError(f"expected {dtype}, got {h.dtype}")
+            if not h.dev().is_contiguous():
+                h = HArray(h.dev().contiguous())
+            self._keep.append(h)
+            return h.data_ptr()
+        if _torch is not None and isinstance(a, _torch.Tensor):
+            if not a.is_cuda:
+                a = a.cuda()
+            a = a.contiguous()
+            if a.dtype != _NP2T[dtype]:
+                a = a.to(_NP2T[dtype])
+            self._keep.append(a)
+            return int(a.data_ptr())
+        arr = np.ascontiguousarray(as_numpy(a), dtype=dtype)  # read-only params accept convertible input (src/type.h:9-15)
+        if self._is_dev():
+            h = HArray.from_numpy(arr)
+            self._keep.append(h)
+            return h.data_ptr()
+        self._keep.append(arr)
+        return arr.ctypes.data
+
+    def out(self, a, dtype, upload=True):
+        """writable array argument (exact dtype, C-contiguous, no implicit copy: src/type.h:16-21) -> pointer"""
+        dtype = np.dtype(dtype)
+        if isinstance(a, HArray):
+            if a.dtype != dtype or not a.dev().is_contiguous():
+                raise TypeError(f"writable argument must be C-contiguous {dtype}")
+            a.invalidate_host()
+            self._keep.append(a)
+            return a.data_ptr()
+        if _torch is not None and isinstance(a, _torch.Tensor):
+            if not a.is_cuda or not a.is_contiguous() or a.dtype != _NP2T[dtype]:
+                raise TypeError(f"writable tensor must be a contiguous ROCm tensor of {dtype}")
+            self._keep.append(a)
+            return int(a.data_ptr())
+        if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags.c_contiguous or not a.flags.writeable:
+            raise TypeError(f"writable argument must be a writable C-contiguous numpy array of {dtype}")
+        if self._is_dev():
+            h = HArray.from_numpy(a) if upload else HArray.empty(a.shape, dtype)
+            self._keep.append(h)
+            self._writeback.append((a, h))
+            return h.data_ptr()
+        self._keep.append(a)
+        return a.ctypes.data
+
+    def done(self, rc):
+        _lib.check(rc)
+        for host, h in self._writeback:
+            host[...] = h.dev().cpu().numpy()
+        self._keep.clear()

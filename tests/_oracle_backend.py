@@ -1,0 +1,90 @@
+"""Adapters that give the CPU oracle the call surface of mdapy_amd's backend shim modules.
+TEST INFRASTRUCTURE: used by the CPU ("not gpu") tests to run the host-side policy layer of
+mdapy_amd against the golden vectors, and by the GPU tests as the checker."""
+import types
+
+import numpy as np
+
+from oracle import oracle as O
+from mdapy_amd.devarray import as_numpy
+
+NT = 4
+
+
+def _np(a):
+    return None if a is None else as_numpy(a)
+
+
+def _mod(**fns):
+    return types.SimpleNamespace(**fns)
+
+
+def _build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_pads=False):
+    if fill_pads:
+        v.fill(-1)
+        d.fill(rc + 1.0)
+    O.build_neighbor(_np(x), _np(y), _np(z), box, origin, boundary, rc, v, d, nn, NT)
+
+
+neighbor = _mod(
+    build_neighbor=_build_neighbor,
+    build_neighbor_without_max_neigh=lambda x, y, z, box, origin, boundary, rc, num_t=1:
+        O.build_neighbor_without_max_neigh(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT),
+    sort_verlet_by_distance=lambda v, d, k, num_t=1: O.sort_verlet_by_distance(v, d, k, NT),
+    wrap_positions=lambda x, y, z, box, origin, boundary, num_t=1: O.wrap_positions(x, y, z, box, origin, boundary, NT),
+    average_by_neighbor=lambda rc, v, d, nn, value, out, inc, num_t=1:
+        O.average_by_neighbor(rc, _np(v), _np(d), _np(nn), _np(value), out, inc, NT),
+)
+cna = _mod(
+    fcna=lambda x, y, z, box, origin, boundary, v, nn, pat, rc, num_t=1:
+        O.fcna(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(nn), pat, rc, NT),
+    acna=lambda x, y, z, box, origin, boundary, v, pat, num_t=1:
+        O.acna(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), pat, NT),
+    ids=lambda x, y, z, box, origin, boundary, v, nv, pat, num_t=1:
+        O.ids(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), nv, pat, NT),
+)
+csp = _mod(get_csp=lambda x, y, z, box, origin, boundary, v, N, out, num_t=1:
+           O.get_csp(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), N, out, NT))
+sbo = _mod(
+    get_sq=lambda x, y, z, box, origin, boundary, v, d, nn, w, ll, nnn, lmax, wl, wlhat, avg, uv, rc, uw, qr, qi, qn,
+    num_t=1: O.get_sq(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(d), _np(nn), _np(w), ll, nnn, lmax,
+                      wl, wlhat, avg, uv, rc, uw, qr, qi, qn, NT),
+    identifySolidLiquid=lambda qi_, Q6, v, d, nn, qr, qi, thr, nb, sl, nbond, uv, nnn, rc, num_t=1:
+        O.identifySolidLiquid(qi_, _np(Q6), _np(v), _np(d), _np(nn), _np(qr), _np(qi), thr, nb, sl, nbond, uv, nnn,
+                              rc, NT),
+)
+rdf = _mod(
+    _rdf=lambda v, d, nn, t, g, rc, nbin: O._rdf(_np(v), _np(d), _np(nn), _np(t), g, rc, nbin),
+    _rdf_single_species=lambda v, d, nn, g, rc, nbin: O._rdf_single_species(_np(v), _np(d), _np(nn), g, rc, nbin),
+    _rdf_streaming=lambda x, y, z, t, box, origin, boundary, g, rc, nbin, num_t=1:
+        O._rdf_streaming(_np(x), _np(y), _np(z), _np(t), box, origin, boundary, g, rc, nbin, NT),
+)
+wcp = _mod(get_wcp=lambda v, nn, t, Nt, W, num_t=1: O.get_wcp(_np(v), _np(nn), _np(t), Nt, W, NT))
+fast_knn = _mod(knn=lambda x, y, z, box, origin, boundary, k, idx, dist, num_t=1:
+                O.knn(_np(x), _np(y), _np(z), box, origin, boundary, k, idx, dist, NT))
+repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
+
+
+def install(monkeypatch):
+    import mdapy_amd.build_lattice as bl
+    import mdapy_amd.centro_symmetry_parameter as m_csp
+    import mdapy_amd.common_neighbor_analysis as m_cna
+    import mdapy_amd.identify_diamond_structure as m_ids
+    import mdapy_amd.knn as m_knn
+    import mdapy_amd.neighbor as m_nb
+    import mdapy_amd.radial_distribution_function as m_rdf
+    import mdapy_amd.steinhardt_bond_orientation as m_sbo
+    import mdapy_amd.tool_function as m_tool
+    import mdapy_amd.warren_cowley_parameter as m_wcp
+
+    monkeypatch.setattr(m_nb, "_neighbor", neighbor)
+    monkeypatch.setattr(m_tool, "_neighbor", neighbor)
+    monkeypatch.setattr(m_tool, "_repeat_cell", repeat_cell)
+    monkeypatch.setattr(bl, "_repeat_cell", repeat_cell)
+    monkeypatch.setattr(m_knn, "_fast_knn", fast_knn)
+    monkeypatch.setattr(m_cna, "_cna", cna)
+    monkeypatch.setattr(m_ids, "_cna", cna)
+    monkeypatch.setattr(m_csp, "_csp", csp)
+    monkeypatch.setattr(m_sbo, "_sbo", sbo)
+    monkeypatch.setattr(m_rdf, "_rdf", rdf)
+    monkeypatch.setattr(m_wcp, "_wcp", wcp)

@@ -1,0 +1,353 @@
+"""GPU suite (-m gpu): the HIP kernels, called through the C ABI (mdapy_amd._<module> shims ->
+libmdapy_amd.so), against (1) the CPU oracle on the same seeded inputs, (2) the golden vectors of the
+reference's test-suite, (3) size-independent properties at large N.
+
+Bars: bit-exact for integer outputs (neighbor ids, counts, labels, histogram counts) and — where the
+arithmetic is IEEE-exact — for distances; 1e-6 relative for floating-point outputs (CSP, q_l, g(r)).
+"""
+import json
+
+import numpy as np
+import pytest
+
+import mdapy_amd as mp
+from _golden import GOLDEN, fixtures_with, ids_of, input_path, misc, system_from_fixture
+from mdapy_amd import _cna, _csp, _fast_knn, _neighbor, _rdf, _repeat_cell, _sbo, _wcp
+from mdapy_amd.build_lattice import lattice_positions
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PBC = np.array([1, 1, 1], np.int32)
+ORG0 = np.zeros(3)
+
+
+def _xyz(pos):
+    return tuple(np.ascontiguousarray(pos[:, k]) for k in range(3))
+
+
+def _fcc(n, sigma=0.0, seed=0, a=3.615):
+    pos, box = lattice_positions("fcc", a, n, n, n)
+    if sigma > 0:
+        pos = pos + np.random.default_rng(seed).normal(0.0, sigma, pos.shape)
+    return pos, box
+
+
+def _cases():
+    """(name, pos, box, origin, boundary) — ortho / triclinic, periodic / open, in-box / out-of-box atoms"""
+    rng = np.random.default_rng(11)
+    out = []
+    p, b = _fcc(8, 0.05, 1)
+    out.append(("fcc_rattled", p, b, ORG0, PBC))
+    p, b = _fcc(7, 0.2, 2)
+    out.append(("fcc_hot_shifted_origin", p + np.array([-3.0, 5.0, 1.5]), b, np.array([-3.0, 5.0, 1.5]), PBC))
+    p, b = _fcc(6, 0.1, 3)
+    p2 = p + rng.integers(-2, 3, p.shape) * np.diag(b)  # unwrapped input: atoms whole box lengths away
+    out.append(("fcc_unwrapped", p2, b, ORG0, PBC))
+    out.append(("slab_open_z", p, b, ORG0, np.array([1, 1, 0], np.int32)))
+    out.append(("cluster_open", p, b * 1.0, ORG0, np.array([0, 0, 0], np.int32)))
+    tri = np.array([[22.0, 0.0, 0.0], [4.0, 21.0, 0.0], [-3.0, 5.0, 20.0]])
+    frac = rng.random((3000, 3))
+    out.append(("triclinic_random", frac @ tri + np.array([1.0, -2.0, 0.5]), tri, np.array([1.0, -2.0, 0.5]), PBC))
+    out.append(("triclinic_open_y", frac @ tri, tri, ORG0, np.array([1, 0, 1], np.int32)))
+    out.append(("random_gas", rng.random((4000, 3)) * 30.0, np.eye(3) * 30.0, ORG0, PBC))
+    out.append(("thin_box_3cells", rng.random((600, 3)) * np.array([9.1, 30.0, 30.0]), np.diag([9.1, 30.0, 30.0]), ORG0, PBC))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("rc", [3.0, 4.4])
+def test_neighbor_bit_exact_vs_oracle(case, rc):
+    """ids, order inside a row, counts and distances are identical to the oracle (host-space C ABI)."""
+    _, pos, box, org, bnd = case
+    x, y, z = _xyz(pos)
+    v0, d0, n0 = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    v1, d1, n1 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1)
+    assert np.array_equal(n1, n0)
+    assert v1.shape == v0.shape and np.array_equal(v1, v0)
+    assert np.array_equal(d1, d0)  # bitwise: IEEE sqrt / div / floor, no FMA contraction
+    # fixed width, reference semantics (caller pads), with overflow: count keeps running past M
+    M = max(int(n0.max()) - 2, 1)
+    va = np.full((len(x), M), -1, np.int32); da = np.full((len(x), M), rc + 1.0); na = np.zeros(len(x), np.int32)
+    vb = va.copy(); db = da.copy(); nb = na.copy()
+    O.build_neighbor(x, y, z, box, org, bnd, rc, va, da, na, 4)
+    _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vb, db, nb, 1)
+    assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+
+
+def test_neighbor_device_space_and_pads():
+    """HBM-resident path (torch tensors in, HArray out) == host-space path; kernel-written pads == -1 / rc+1."""
+    import torch
+
+    pos, box = _fcc(10, 0.05, 4)
+    x, y, z = _xyz(pos)
+    rc = 3.615
+    v0, d0, n0 = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 4)
+    tx, ty, tz = (torch.from_numpy(a).cuda() for a in (x, y, z))
+    v1, d1, n1 = _neighbor.build_neighbor_without_max_neigh(tx, ty, tz, box, ORG0, PBC, rc, 1)
+    assert type(v1).__name__ == "HArray"
+    assert np.array_equal(np.asarray(v1), v0) and np.array_equal(np.asarray(d1), d0) and np.array_equal(np.asarray(n1), n0)
+    assert (np.asarray(v1) == -1).sum() == (v0 == -1).sum() and np.all(np.asarray(d1)[v0 == -1] == rc + 1.0)
+
+
+def test_neighbor_knife_edge_counts():
+    ref = json.load(open(GOLDEN / "knife_edge_counts.json"))["counts"]
+    s = mp.build_crystal("Cu", "fcc", 3.615, nx=10, ny=10, nz=10)
+    s.build_neighbor(3.615)
+    got = np.bincount(np.asarray(s.neighbor_number))
+    assert {str(k): int(v) for k, v in enumerate(got) if v} == ref
+    assert s.verlet_list.shape == (4000, 18)
+
+
+def test_neighbor_determinism_and_large_properties():
+    """1M atoms: run twice (bitwise identical), symmetric pairs, sorted-ness of nothing assumed; counts vs closed form."""
+    pos, box = _fcc(63)  # 1 000 188 atoms
+    x, y, z = _xyz(pos)
+    rc = 0.854 * 3.615
+    v1, d1, n1 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 1)
+    v2, d2, n2 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 1)
+    assert np.array_equal(v1, v2) and np.array_equal(d1, d2) and np.array_equal(n1, n2)
+    assert np.all(n1 == 12) and v1.shape[1] == 12
+    assert np.allclose(d1, 3.615 / np.sqrt(2), rtol=1e-12)
+    # symmetry: j in row(i)  <=>  i in row(j)   (checked through a hash of unordered pairs)
+    i = np.repeat(np.arange(len(x), dtype=np.int64), 12)
+    j = v1.reshape(-1).astype(np.int64)
+    assert np.array_equal(np.sort(i * len(x) + j), np.sort(j * len(x) + i))
+
+
+@pytest.mark.parametrize("case", CASES[:7], ids=[c[0] for c in CASES[:7]])
+def test_sort_and_cna_vs_oracle(case):
+    _, pos, box, org, bnd = case
+    x, y, z = _xyz(pos)
+    rc = 3.2
+    v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    p0 = np.zeros(len(x), np.int32); p1 = np.zeros(len(x), np.int32)
+    O.fcna(x, y, z, box, org, bnd, v, n, p0, rc, 4)
+    _cna.fcna(x, y, z, box, org, bnd, v, n, p1, rc, 1)
+    assert np.array_equal(p1, p0)
+    # partial selection sort (ties: first minimum wins)
+    k = min(6, v.shape[1])
+    va, da = v.copy(), d.copy(); vb, db = v.copy(), d.copy()
+    O.sort_verlet_by_distance(va, da, k, 4)
+    _neighbor.sort_verlet_by_distance(vb, db, k, 1)
+    assert np.array_equal(vb, va) and np.array_equal(db, da)
+
+
+@pytest.mark.parametrize("name", ["fcc", "bcc", "hcp", "diamond"])
+@pytest.mark.parametrize("sigma", [0.0, 0.08])
+def test_knn_acna_csp_ids_vs_oracle(name, sigma):
+    a = {"fcc": 3.615, "bcc": 2.86, "hcp": 3.21, "diamond": 3.57}[name]
+    n = {"fcc": 6, "bcc": 8, "hcp": 8, "diamond": 5}[name]
+    pos, box = lattice_positions(name, a, n, n, n)
+    if sigma:
+        pos = pos + np.random.default_rng(5).normal(0, sigma, pos.shape)
+    x, y, z = _xyz(pos)
+    N = len(x)
+    k = 14
+    i0 = np.zeros((N, k), np.int32); q0 = np.zeros((N, k)); i1 = np.zeros((N, k), np.int32); q1 = np.zeros((N, k))
+    O.knn(x, y, z, box, ORG0, PBC, k, i0, q0, 4)
+    _fast_knn.knn(x, y, z, box, ORG0, PBC, k, i1, q1, 1)
+    assert np.array_equal(q1, q0)  # sorted distances are bit-identical; ids may permute inside exact ties
+    if sigma:  # no exact ties: ids must agree too (on perfect lattices ids may permute inside a tie group)
+        assert np.array_equal(i1, i0)
+    p0 = np.zeros(N, np.int32); p1 = np.zeros(N, np.int32)
+    O.acna(x, y, z, box, ORG0, PBC, i1, p0, 4)
+    _cna.acna(x, y, z, box, ORG0, PBC, i1, p1, 1)
+    assert np.array_equal(p1, p0)
+    c0 = np.zeros(N); c1 = np.zeros(N)
+    O.get_csp(x, y, z, box, ORG0, PBC, i1, 12, c0, 4)
+    _csp.get_csp(x, y, z, box, ORG0, PBC, i1, 12, c1, 1)
+    assert np.allclose(c1, c0, rtol=1e-6, atol=1e-12)
+    O.get_csp(x, y, z, box, ORG0, PBC, i1, 6, c0, 4)  # generic-K path
+    _csp.get_csp(x, y, z, box, ORG0, PBC, i1, 6, c1, 1)
+    assert np.allclose(c1, c0, rtol=1e-6, atol=1e-12)
+    s0 = np.zeros((N, 12), np.int32); s1 = np.zeros((N, 12), np.int32); p0 = np.zeros(N, np.int32); p1 = np.zeros(N, np.int32)
+    O.ids(x, y, z, box, ORG0, PBC, i1, s0, p0, 4)
+    _cna.ids(x, y, z, box, ORG0, PBC, i1, s1, p1, 1)
+    assert np.array_equal(s1, s0) and np.array_equal(p1, p0)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[5], CASES[7]], ids=[CASES[0][0], CASES[5][0], CASES[7][0]])
+def test_knn_general_vs_oracle(case):
+    _, pos, box, org, bnd = case
+    x, y, z = _xyz(pos[:1500])
+    N = len(x)
+    for k in (1, 12, 18):
+        i0 = np.zeros((N, k), np.int32); q0 = np.zeros((N, k)); i1 = np.zeros((N, k), np.int32); q1 = np.zeros((N, k))
+        O.knn(x, y, z, box, org, bnd, k, i0, q0, 4)
+        _fast_knn.knn(x, y, z, box, org, bnd, k, i1, q1, 1)
+        assert np.array_equal(q1, q0)
+        assert np.array_equal(i1, i0)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[5]], ids=[CASES[0][0], CASES[5][0]])
+@pytest.mark.parametrize("mode", ["rc", "nnn"])
+def test_steinhardt_vs_oracle(case, mode):
+    _, pos, box, org, bnd = case
+    x, y, z = _xyz(pos)
+    N = len(x)
+    if mode == "rc":
+        rc = 3.4
+        v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+        nnn = 0
+    else:
+        nnn = 12
+        v = np.zeros((N, nnn), np.int32); d = np.zeros((N, nnn))
+        O.knn(x, y, z, box, org, bnd, nnn, v, d, 4)
+        n = np.full(N, nnn, np.int32)
+        rc = 1e9
+    ll = np.array([4, 6, 8], np.int32)
+    lmax = 8
+    for avg in (False, True):
+        outs = []
+        for be in (O, _sbo):
+            qr = np.zeros((N, 3, 2 * lmax + 1)); qi = np.zeros_like(qr); qn = np.zeros((N, 9))
+            be.get_sq(x, y, z, box, org, bnd, v, d, n, np.zeros((2, 2)), ll, nnn, lmax, True, True, avg, False, rc,
+                      False, qr, qi, qn, 4)
+            outs.append((qr, qi, qn))
+        ok = np.isfinite(outs[0][2]).all(axis=1)
+        assert np.array_equal(ok, np.isfinite(outs[1][2]).all(axis=1))
+        for a, b in zip(outs[0], outs[1]):
+            assert np.allclose(b[ok], a[ok], rtol=1e-6, atol=1e-12)
+    # solid / liquid bond counting on the averaged-off q6m
+    qr, qi, qn = outs[1]
+    Q6 = np.ascontiguousarray(qn[:, 1])
+    res = []
+    for be in (O, _sbo):
+        sl = np.zeros(N, np.int32); nb = np.zeros(N, np.int32)
+        be.identifySolidLiquid(1, Q6, v, d, n, qr, qi, 0.7, 7, sl, nb, False, nnn, rc, 4)
+        res.append((sl, nb))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+
+
+def test_rdf_and_wcp_vs_oracle():
+    rng = np.random.default_rng(21)
+    pos, box = lattice_positions("fcc", 4.0, 9, 9, 9)
+    pos = pos + rng.normal(0, 0.35, pos.shape)
+    typ = (rng.random(len(pos)) < 0.36).astype(np.int32)
+    x, y, z = _xyz(pos)
+    for bnd in (PBC, np.array([1, 0, 1], np.int32)):
+        for rc, nbin in ((8.0, 200), (13.0, 50)):  # 13 A > L/3: all-pairs branch
+            g0 = np.zeros((2, 2, nbin)); g1 = np.zeros((2, 2, nbin))
+            O._rdf_streaming(x, y, z, typ, box, ORG0, bnd, g0, rc, nbin, 4)
+            _rdf._rdf_streaming(x, y, z, typ, box, ORG0, bnd, g1, rc, nbin, 1)
+            assert np.array_equal(g1, g0)  # integer counts
+    v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, 5.0, 4)
+    g0 = np.zeros((2, 2, 60)); g1 = np.zeros((2, 2, 60))
+    O._rdf(v, d, n, typ, g0, 5.0, 60); _rdf._rdf(v, d, n, typ, g1, 5.0, 60)
+    assert np.array_equal(g1, g0)
+    h0 = np.zeros(60); h1 = np.zeros(60)
+    O._rdf_single_species(v, d, n, h0, 5.0, 60); _rdf._rdf_single_species(v, d, n, h1, 5.0, 60)
+    assert np.array_equal(h1, h0)
+    w0 = np.zeros((2, 2)); w1 = np.zeros((2, 2))
+    O.get_wcp(v, n, typ, 2, w0); _wcp.get_wcp(v, n, typ, 2, w1, 1)
+    assert np.array_equal(w1, w0)
+
+
+def test_small_helpers_vs_oracle():
+    rng = np.random.default_rng(3)
+    tri = np.array([[12.0, 0.0, 0.0], [3.0, 11.0, 0.0], [-2.0, 1.0, 10.0]])
+    for box in (np.diag([9.0, 10.0, 11.0]), tri):
+        p = rng.normal(0, 25, (2000, 3))
+        a = [np.ascontiguousarray(p[:, k]) for k in range(3)]
+        b = [c.copy() for c in a]
+        O.wrap_positions(*a, box, np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1], np.int32), 4)
+        _neighbor.wrap_positions(*b, box, np.array([1.0, 2.0, 3.0]), np.array([1, 0, 1], np.int32), 1)
+        assert all(np.array_equal(u, w) for u, w in zip(a, b))
+        old = rng.random((7, 3)) @ box
+        n0 = np.zeros(7 * 24 * 3); n1 = np.zeros(7 * 24 * 3)
+        O.repeat_cell(n0, box, old, 2, 3, 4); _repeat_cell.repeat_cell(n1, box, old, 2, 3, 4, 1)
+        assert np.array_equal(n1, n0)
+    pos, bx = _fcc(5, 0.1, 9)
+    x, y, z = _xyz(pos)
+    v, d, n = O.build_neighbor_without_max_neigh(x, y, z, bx, ORG0, PBC, 4.0, 4)
+    o0 = np.zeros(len(x)); o1 = np.zeros(len(x))
+    O.average_by_neighbor(3.0, v, d, n, x, o0, True, 4)
+    _neighbor.average_by_neighbor(3.0, v, d, n, x, o1, True, 1)
+    assert np.array_equal(o1, o0)
+
+
+# ------------------------------------------------------------------ golden vectors, full System flow on the GPU
+CNA_PATHS, CSP_PATHS, QL_PATHS, IDS_PATHS = (fixtures_with(k) for k in ("cna", "csp", "q4", "ids"))
+
+
+@pytest.mark.parametrize("path", CNA_PATHS, ids=ids_of(CNA_PATHS))
+def test_golden_cna(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_common_neighbor_analysis(rc=float(d["cna_cutoff"]))
+    assert np.array_equal(s.data["cna"].to_numpy(), d["cna"])
+
+
+@pytest.mark.parametrize("path", CSP_PATHS, ids=ids_of(CSP_PATHS))
+def test_golden_csp(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_centro_symmetry_parameter(int(d["csp_num_neighbors"]))
+    assert np.allclose(s.data["csp"].to_numpy(), d["csp"], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("path", QL_PATHS, ids=ids_of(QL_PATHS))
+def test_golden_ql(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    rc = float(d["ql_cutoff"])
+    s.cal_steinhardt_bond_orientation([4, 6], rc=rc)
+    for l in (4, 6):
+        assert np.allclose(s.data[f"ql{l}"].to_numpy(), d[f"q{l}"], atol=1e-6, rtol=1e-6)
+    s.cal_steinhardt_bond_orientation([4, 6], rc=rc, average=True)
+    for l in (4, 6):
+        assert np.allclose(s.data[f"ql{l}"].to_numpy(), d[f"q{l}_avg"], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("path", IDS_PATHS, ids=ids_of(IDS_PATHS))
+def test_golden_ids(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_identify_diamond_structure()
+    assert np.array_equal(s.data["ids"].to_numpy(), d["ids"])
+
+
+def test_golden_rdf_wcp_average():
+    d = misc("rdf")
+    s = mp.System(input_path("AlCrNi.xyz"))
+    rdf = s.cal_radial_distribution_function(float(d["cutoff"]), int(d["nbins"]))
+    el = list(d["elements"])
+    for i in range(len(el)):
+        for j in range(i, len(el)):
+            assert np.allclose(rdf.g_partial[(el[i], el[j])], d["g"][i, j], atol=1e-6)
+    s = mp.System(input_path("CoCuFeNiPd-4M.dump"))
+    wcp = s.cal_warren_cowley_parameter(rc=3.0)
+    ref = np.array([[-1.39, 0.64, 0.39, -0.3, 0.66], [0.64, -1.94, 0.58, 0.51, 0.2], [0.39, 0.58, -0.56, 0.63, -1.04],
+                    [-0.3, 0.51, 0.63, -1.69, 0.85], [0.66, 0.2, -1.04, 0.85, -0.67]])
+    assert np.allclose(wcp.WCP.round(2), ref)
+    d = misc("average_neighbor")
+    for name in ("rec_box_big", "tri_box_big"):
+        s = mp.System(input_path(f"{name}.xyz"))
+        s.average_by_neighbor(float(d[f"{name}__cutoff"]), "x", include_self=True)
+        assert np.allclose(s.data["x_ave"].to_numpy(), d[f"{name}__x_ave"], atol=1e-6)
+
+
+def test_system_flow_perfect_crystals_and_errors():
+    a = 4.05
+    fcc = mp.build_crystal("Al", "fcc", a, nx=4, ny=4, nz=4)
+    fcc.cal_common_neighbor_analysis(rc=0.854 * a)
+    assert np.all(fcc.data["cna"].to_numpy() == 1)
+    fcc.cal_common_neighbor_analysis()
+    assert np.all(fcc.data["cna"].to_numpy() == 1)
+    fcc.cal_centro_symmetry_parameter(12)
+    assert np.allclose(fcc.data["csp"].to_numpy(), 0.0, atol=1e-10)
+    fcc.cal_steinhardt_bond_orientation([4, 6], rc=0.95 * a)
+    assert np.allclose(fcc.data["ql4"].to_numpy(), 0.190941, atol=1e-5)
+    assert np.allclose(fcc.data["ql6"].to_numpy(), 0.574524, atol=1e-5)
+    bcc = mp.build_crystal("Fe", "bcc", 2.86, nx=6, ny=6, nz=6)
+    bcc.cal_common_neighbor_analysis(rc=1.21 * 2.86)
+    assert np.all(bcc.data["cna"].to_numpy() == 3)
+    with pytest.raises(ValueError, match="max_neigh=5 is too small"):
+        bcc.build_neighbor(3.0, max_neigh=5)
+    with pytest.raises(RuntimeError, match="volume of the box is zero"):
+        x = np.zeros(4); v = np.full((4, 2), -1, np.int32); dd = np.zeros((4, 2)); nn = np.zeros(4, np.int32)
+        _neighbor.build_neighbor(x, x, x, np.array([[1.0, 1, 0], [2, 2, 0], [0, 0, 1]]), ORG0, PBC, 1.0, v, dd, nn, 1)
