@@ -67,6 +67,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C mdapy_amd/csrc`).  mdapy_amd has no CPU fallback."
             )
+        # torch ships its own libamdhip64.so.7; a process must not end up with two HIP runtimes (the second
+        # one to initialise reports "No HIP GPUs are available").  Importing torch first makes the dynamic
+        # linker resolve our library's libamdhip64.so.7 to the copy torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is only plumbing (device memory, streams); the C ABI also works without it
+            pass
         L = C.CDLL(LIB_PATH)
         for name, argt in _SIGNATURES.items():
             fn = getattr(L, name)

@@ -74,7 +74,12 @@ class HArray:
     def from_numpy(a):
         t = torch()
         a = np.ascontiguousarray(a)
-        return HArray(t.from_numpy(a).to("cuda"))
+        import warnings
+
+        with warnings.catch_warnings():  # frame columns are read-only numpy views; the tensor is only read
+            warnings.simplefilter("ignore")
+            src = t.from_numpy(a)
+        return HArray(src.to("cuda"))
 
     # ---- device side
     def dev(self):
