@@ -63,6 +63,9 @@ int64_t mdh_workspace_bytes(void);
 int mdh_prof_enable(int on);
 int mdh_prof_reset(void);
 int mdh_prof_report(char *buf, int buflen);
+/* A/B switch for measurements and tests: 0 = automatic kernel choice (default), 1 = force the
+ * thread-per-atom neighbor kernel even where the LDS-tiled one applies.  Results are identical. */
+int mdh_debug_set_neighbor_variant(int variant);
 
 /* ---- _neighbor -------------------------------------------------------- */
 /*

@@ -20,7 +20,29 @@ struct CellGrid {
     int *cell_start; // [ncell+1] exclusive prefix of the per-cell populations
     int *order;      // [N] atom ids, cell-major, DESCENDING id inside a cell
     double *xs, *ys, *zs; // [N] raw positions in `order`
+    // device flags written while binning:
+    //   flags[0] != 0 : some atom's raw coordinate differs from its wrapped one by more than `slack` on a
+    //                   periodic axis (unwrapped input) -> per-cell image shifts are not valid
+    //   flags[1]      : largest cell population
+    int *flags;
 };
+
+// neighbor_tiled.hip: LDS-tiled 27-cell scan for orthogonal boxes (see the file header)
+struct TiledPlan {
+    int tile;        // cells per tile edge (4 or 2); 0 = not applicable
+    bool cellshift;  // every periodic axis has >= 7 cells: per-cell image shifts may replace the minimum-image search
+};
+// what the LDS-tiled kernel leaves to the thread-per-atom kernel: tiles whose halo did not fit in LDS
+// (flag[t] != 0; *any counts them).  flag == nullptr: no filtering (the thread-per-atom kernel does everything).
+struct TileFilter {
+    const unsigned char *flag = nullptr;
+    const int *any = nullptr;
+    int tile = 1;
+    int nt[3] = {1, 1, 1};
+};
+TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M);
+int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
+                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, TileFilter &tf);
 
 __host__ __device__ __forceinline__ int pmod(int a, int n) // neighbor.cpp:18-22
 {

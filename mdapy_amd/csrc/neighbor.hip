@@ -21,6 +21,8 @@
 
 namespace mdh {
 
+int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel (A/B measurements, tests)
+
 // ----------------------------------------------------------------------------
 // cell assignment: wrap, bin, take a slot from the cell's atomic counter
 // ----------------------------------------------------------------------------
@@ -28,19 +30,28 @@ template <bool TRI>
 __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
-                                                unsigned *__restrict__ cell_count)
+                                                unsigned *__restrict__ cell_count, int *__restrict__ flags,
+                                                double slack)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    double xi = x[i], yi = y[i], zi = z[i];
-    if (wrap_first && b.anypbc) // neighbor.cpp:88-91
-        wrap<TRI>(b, xi, yi, zi);
-    int c0, c1, c2;
-    cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
-    int c = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
-    cell_id[i] = c;
-    rank[i] = (int)atomicAdd(&cell_count[c], 1u);
+    bool moved = false;
+    if (i < N) {
+        const double xr = x[i], yr = y[i], zr = z[i];
+        double xi = xr, yi = yr, zi = zr;
+        if (wrap_first && b.anypbc) { // neighbor.cpp:88-91
+            wrap<TRI>(b, xi, yi, zi);
+            // an atom whose raw position is not (to within `slack`) its wrapped one was handed over unwrapped
+            moved = (b.pbc[0] && !(fabs(xi - xr) <= slack)) || (b.pbc[1] && !(fabs(yi - yr) <= slack)) ||
+                    (b.pbc[2] && !(fabs(zi - zr) <= slack));
+        }
+        int c0, c1, c2;
+        cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+        int c = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
+        cell_id[i] = c;
+        rank[i] = (int)atomicAdd(&cell_count[c], 1u);
+    }
+    if (__any(moved) && (threadIdx.x & 63) == 0)
+        flags[0] = 1;
 }
 
 // ----------------------------------------------------------------------------
@@ -204,14 +215,18 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     cg.zs = sc.alloc_n<double>((size_t)N);
     const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
     unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk);
+    cg.flags = sc.alloc_n<int>(4);
     if (sc.failed())
         return sc.error();
 
     MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * (size_t)g.ncell, st));
+    MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 4, st));
+    // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
+    const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
     if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack);
     else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count);
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack);
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
@@ -235,17 +250,28 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
                                                   const double *__restrict__ zs, const int *__restrict__ order,
                                                   const int *__restrict__ cell_start, int64_t N, DBox b, Grid g,
                                                   double rc, int *__restrict__ verlet, double *__restrict__ dist,
-                                                  int *__restrict__ nn, int64_t M, int *__restrict__ max_count)
+                                                  int *__restrict__ nn, int64_t M, int *__restrict__ max_count,
+                                                  TileFilter tf)
 {
+    if (tf.flag && *tf.any == 0) // mop-up pass with nothing to mop up
+        return;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cnt = 0;
-    if (p < N) {
-        const int i = order[p];
-        double xi = xs[p], yi = ys[p], zi = zs[p];
+    bool mine = p < N;
+    int c0 = 0, c1 = 0, c2 = 0;
+    double xi = 0, yi = 0, zi = 0;
+    if (mine) {
+        xi = xs[p]; yi = ys[p]; zi = zs[p];
         if (b.anypbc) // neighbor.cpp:139-142
             wrap<TRI>(b, xi, yi, zi);
-        int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+        if (tf.flag) { // fallback pass: only atoms of tiles the LDS-tiled kernel could not hold (or all of them when it stood down)
+            const int t = ((c0 / tf.tile) * tf.nt[1] + (c1 / tf.tile)) * tf.nt[2] + (c2 / tf.tile);
+            mine = tf.flag[t] != 0;
+        }
+    }
+    if (mine) {
+        const int i = order[p];
         const double rcsq = rc * rc; // neighbor.cpp:127
         const int64_t row = (int64_t)i * M;
         const bool zrun = (c2 >= 1) && (c2 + 1 < g.nc[2]); // the three z-cells are one contiguous run
@@ -304,13 +330,13 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
 
 template <int MODE>
 static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const DBox &b, double rc, int *verlet,
-                            double *dist, int *nn, int64_t M, int *max_count)
+                            double *dist, int *nn, int64_t M, int *max_count, TileFilter tf = TileFilter{})
 {
     dim3 grid(grid_for(N, 256)), block(256);
     if (b.tri)
-        hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count);
+        hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else
-        hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count);
+        hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
 }
 
 // ----------------------------------------------------------------------------
@@ -399,12 +425,22 @@ int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_
     }
     {
         ProfRange pr("k_neighbor", sc.stream());
+        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, false} : plan_tiled(b, cg.g, N, max_neigh);
+        TileFilter tf{};
+        if (plan.tile) // LDS-tiled kernel; the thread-per-atom kernel below then only mops up what it left
+            MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));
         if (fill_pads)
-            launch_neighbor<2>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr);
+            launch_neighbor<2>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr, tf);
         else
-            launch_neighbor<1>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr);
+            launch_neighbor<1>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr, tf);
     }
     return sc.finish(space);
+}
+
+int mdh_debug_set_neighbor_variant(int v)
+{
+    g_neighbor_variant = v;
+    return MDH_OK;
 }
 
 int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_t N, const double *box9,

@@ -1,0 +1,311 @@
+// neighbor_tiled.hip — LDS-tiled 27-cell neighbor scan for orthogonal boxes (gfx950).
+//
+// Same result, bit for bit, as the thread-per-atom kernel in neighbor.hip (and therefore as
+// src/neighbor.cpp:102-187 of the reference); this is the fast path for the common case.
+//
+// One workgroup owns a tile of T x T x T cells.  It stages the atoms of the (T+2)^3 halo cells
+// (raw x,y,z + atom id) from the cell-sorted arrays into LDS with coalesced loads — every cell of
+// the grid is read from HBM/L2 once per neighbouring tile instead of once per neighbouring ATOM —
+// then each thread takes one centre atom of the tile and walks its 27 cells out of LDS in the
+// reference's order (cells (i,j,k)-lexicographic, atoms of a cell by descending id).
+//
+// Minimum image.  With all atoms handed over inside the box and >= 7 cells on every periodic axis
+// the image number n = floor(d/L + 0.5) of a (centre, candidate) pair is decided by the pair of
+// CELLS: candidates of an adjacent cell are < 3 rc <= 3L/7 away after the right shift, so n is 0
+// inside the box and +-1 across the periodic seam — far from the +-L/2 decision points.  The kernel
+// then evaluates the reference's  d - L*n  with that n (same operands, same two roundings), which
+// removes 3 divisions / 3 floors per candidate.  When the precondition does not hold (flag from the
+// binning pass, or < 7 cells) the exact threshold search of common.hpp::pbc_axis is used instead.
+//
+// Output.  A hit is first recorded in LDS as a 4-byte ticket (LDS index of the candidate + its image
+// code).  After the scan the workgroup turns tickets into rows cooperatively: consecutive lanes
+// write consecutive slots of a row, so a wave store covers whole 64 B / 128 B row segments instead
+// of 64 scattered rows; the distance is recomputed from the same operands (identical bits).  With
+// fill_pads the same pass writes the -1 / rc+1 pads.
+#include "common.hpp"
+#include "grid.hpp"
+
+namespace mdh {
+
+static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (28 B each)
+
+template <int T> struct TileGeom {
+    static constexpr int H = T + 2;            // halo cells per edge
+    static constexpr int NH = H * H * H;       // halo cells
+    static constexpr int NT = (T == 4) ? 256 : 128; // threads (>= NH required)
+};
+
+__device__ __forceinline__ int excl_scan_block(int v, int *scratch, int nthreads, int *total)
+{
+    // small block scan (nthreads = 128 or 256) built from wave scans
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) scratch[w] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < (nthreads >> 6); ++k) {
+        if (k < w) off += scratch[k];
+        tot += scratch[k];
+    }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
+}
+
+// d2 of one (centre, candidate) pair; CELLSHIFT: sx,sy,sz = L*n for the pair's cells
+template <bool CELLSHIFT>
+__device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double yj, double zj, double xi, double yi,
+                                                double zi, double sx, double sy, double sz)
+{
+    double dx = xj - xi, dy = yj - yi, dz = zj - zi; // raw x[j] - wrapped centre (neighbor.cpp:164-166)
+    if (CELLSHIFT) {
+        dx = dx - sx; // == xij - L*floor(xij/L+0.5)   (box.h:120-124) with n known from the cells
+        dy = dy - sy;
+        dz = dz - sz;
+    } else {
+        pbc<false>(b, dx, dy, dz);
+    }
+    return dx * dx + dy * dy + dz * dz;
+}
+
+template <int T, bool CELLSHIFT, int MODE>
+__global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
+    const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
+    const int *__restrict__ order, const int *__restrict__ cell_start, DBox b, Grid g, double rc,
+    int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int *__restrict__ flags,
+    unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved)
+{
+    using G = TileGeom<T>;
+    constexpr int H = G::H, NH = G::NH, NT = G::NT;
+    // which of the two minimum-image variants serves this call is decided on the device (no host sync)
+    // want_moved: 0 = run only if every atom came in wrapped, 1 = run only if not, -1 = always run
+    if (want_moved >= 0 && (flags[0] != 0) != (want_moved != 0))
+        return;
+
+    extern __shared__ unsigned char smem[];
+    double *lx = reinterpret_cast<double *>(smem);
+    double *ly = lx + HALO_CAP;
+    double *lz = ly + HALO_CAP;
+    double *cxi = lz + HALO_CAP; // wrapped centre coordinates of this pass [NT]
+    double *cyi = cxi + NT;
+    double *czi = cyi + NT;
+    int *lid = reinterpret_cast<int *>(czi + NT); // [HALO_CAP]
+    int *crow = lid + HALO_CAP;                   // global atom id of the centre [NT]
+    int *ccnt = crow + NT;                        // min(count, M) [NT]
+    unsigned *tick = reinterpret_cast<unsigned *>(ccnt + NT); // [NT][M]
+    __shared__ int h_off[NH + 1];
+    __shared__ int h_img[NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
+    __shared__ int c_off[T * T + 1];
+    __shared__ int scan_tmp[4];
+
+    // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of tiles so that
+    // neighbouring tiles (which share halo cells) meet in the same L2.
+    const int ntiles = nt0 * nt1 * nt2;
+    const int per = (ntiles + 7) / 8;
+    const int tile_id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile_id >= ntiles)
+        return;
+    const int t2 = tile_id % nt2, t1 = (tile_id / nt2) % nt1, t0 = tile_id / (nt2 * nt1);
+    const int T0 = t0 * T, T1 = t1 * T, T2 = t2 * T;
+    const int tid = threadIdx.x;
+
+    // ---- halo cell table: source range, LDS offset, image code
+    int cnt = 0, src = 0;
+    if (tid < NH) {
+        const int hz = tid % H, hy = (tid / H) % H, hx = tid / (H * H);
+        const int g0 = T0 + hx - 1, g1 = T1 + hy - 1, g2 = T2 + hz - 1;
+        int img = 1 | (1 << 2) | (1 << 4);
+        if (g0 >= -1 && g0 <= g.nc[0] && g1 >= -1 && g1 <= g.nc[1] && g2 >= -1 && g2 <= g.nc[2]) {
+            const int a0 = pmod(g0, g.nc[0]), a1 = pmod(g1, g.nc[1]), a2 = pmod(g2, g.nc[2]);
+            const int64_t c = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
+            src = cell_start[c];
+            cnt = cell_start[c + 1] - src;
+            // image of the candidate cell seen from an in-grid centre cell: below the box -> raw coordinates are
+            // ~+L away (n = +1); above -> n = -1.  Open axes are never folded (box.h:120-124).
+            const int n0 = b.pbc[0] ? (g0 < 0 ? 1 : (g0 >= g.nc[0] ? -1 : 0)) : 0;
+            const int n1 = b.pbc[1] ? (g1 < 0 ? 1 : (g1 >= g.nc[1] ? -1 : 0)) : 0;
+            const int n2 = b.pbc[2] ? (g2 < 0 ? 1 : (g2 >= g.nc[2] ? -1 : 0)) : 0;
+            img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
+        }
+        h_img[tid] = img;
+    }
+    int total;
+    const int off = excl_scan_block(cnt, scan_tmp, NT, &total);
+    if (tid < NH) h_off[tid] = off;
+    if (tid == 0) h_off[NH] = total;
+    if (total > HALO_CAP) { // leave this tile to the thread-per-atom kernel
+        if (tid == 0) {
+            tile_flag[tile_id] = 1;
+            atomicAdd(&flags[2], 1);
+        }
+        return;
+    }
+    // ---- stage the halo atoms (each thread copies its cell: neighbouring threads read neighbouring memory)
+    if (tid < NH)
+        for (int k = 0; k < cnt; ++k) {
+            lx[off + k] = xs[src + k];
+            ly[off + k] = ys[src + k];
+            lz[off + k] = zs[src + k];
+            lid[off + k] = order[src + k];
+        }
+    // ---- centre runs: one contiguous LDS run per (x,y) column of the tile, clipped to the grid
+    const int zlo = 1, zhi = min(T, g.nc[2] - T2); // interior hz in [1, zhi]
+    if (tid < T * T) {
+        const int hx = tid / T + 1, hy = tid % T + 1;
+        const bool ok = (T0 + hx - 1 < g.nc[0]) && (T1 + hy - 1 < g.nc[1]) && zhi >= 1;
+        c_off[tid + 1] = ok ? (h_off[(hx * H + hy) * H + zhi + 1] - h_off[(hx * H + hy) * H + zlo]) : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        c_off[0] = 0;
+        for (int k = 0; k < T * T; ++k) c_off[k + 1] += c_off[k];
+    }
+    __syncthreads();
+    const int ncentres = c_off[T * T];
+    const double rcsq = rc * rc; // neighbor.cpp:127
+    const double pad = rc + 1.0;
+
+    for (int base = 0; base < ncentres; base += NT) {
+        const int q = base + tid;
+        int hits = 0;
+        if (q < ncentres) {
+            int col = 0;
+#pragma unroll
+            for (int k = 1; k < T * T; ++k)
+                col += (q >= c_off[k]) ? 1 : 0;
+            const int hx = col / T + 1, hy = col % T + 1;
+            const int colbase = (hx * H + hy) * H;
+            const int li = h_off[colbase + zlo] + (q - c_off[col]); // LDS index of the centre atom
+            int hz = zlo;
+            while (hz < zhi && li >= h_off[colbase + hz + 1]) ++hz;
+            double xi = lx[li], yi = ly[li], zi = lz[li];
+            if (b.anypbc) // neighbor.cpp:139-142
+                wrap<false>(b, xi, yi, zi);
+            unsigned *my = tick + (size_t)tid * M;
+            for (int da = -1; da <= 1; ++da)       // neighbor.cpp:147-151
+                for (int db = -1; db <= 1; ++db) {
+                    const int cb = ((hx + da) * H + (hy + db)) * H + hz;
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const int h = cb + dc;
+                        const int img = h_img[h];
+                        const double sx = b.h[0] * (double)((img & 3) - 1);
+                        const double sy = b.h[4] * (double)(((img >> 2) & 3) - 1);
+                        const double sz = b.h[8] * (double)(((img >> 4) & 3) - 1);
+                        const int e = h_off[h + 1];
+                        for (int k = h_off[h]; k < e; ++k) {
+                            if (k == li)
+                                continue;
+                            const double d2 = pair_d2_tiled<CELLSHIFT>(b, lx[k], ly[k], lz[k], xi, yi, zi, sx, sy, sz);
+                            if (d2 <= rcsq) {
+                                if (hits < M) my[hits] = (unsigned)k | ((unsigned)img << 16);
+                                ++hits;
+                            }
+                        }
+                    }
+                }
+            const int i = lid[li];
+            nn[i] = hits; // keeps counting past M (neighbor.cpp:172-177)
+            crow[tid] = i;
+            ccnt[tid] = hits < M ? hits : M;
+            cxi[tid] = xi; cyi[tid] = yi; czi[tid] = zi;
+        }
+        __syncthreads();
+        // ---- tickets -> rows: lane f handles slot (f % M) of centre (f / M)
+        const int nrows = min(NT, ncentres - base);
+        for (int f = tid; f < nrows * M; f += NT) {
+            const int c = f / M, e = f - c * M;
+            const int64_t o = (int64_t)crow[c] * M + e;
+            if (e < ccnt[c]) {
+                const unsigned tk = tick[f];
+                const int k = (int)(tk & 0xffffu), img = (int)(tk >> 16);
+                const double sx = b.h[0] * (double)((img & 3) - 1);
+                const double sy = b.h[4] * (double)(((img >> 2) & 3) - 1);
+                const double sz = b.h[8] * (double)(((img >> 4) & 3) - 1);
+                const double d2 = pair_d2_tiled<CELLSHIFT>(b, lx[k], ly[k], lz[k], cxi[c], cyi[c], czi[c], sx, sy, sz);
+                verlet[o] = lid[k];
+                dist[o] = sqrt(d2);
+            } else if (MODE == 2) {
+                verlet[o] = -1;
+                dist[o] = pad;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t tiled_lds_bytes(int nt, int64_t M)
+{
+    return (size_t)HALO_CAP * 28 + (size_t)nt * (24 + 4 + 4) + (size_t)nt * (size_t)M * 4;
+}
+
+TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
+{
+    TiledPlan p{0, false};
+    if (b.tri || g.mode != 0 || N <= 0 || M <= 0)
+        return p;
+    const double pop = (double)N / (double)g.ncell; // mean atoms per cell
+    int tile = 0;
+    if (pop * 216.0 <= 0.93 * HALO_CAP) tile = 4;
+    else if (pop * 64.0 <= 0.80 * HALO_CAP) tile = 2;
+    if (!tile)
+        return p;
+    const int nt = tile == 4 ? 256 : 128;
+    if (tiled_lds_bytes(nt, M) > 62 * 1024) // ticket rows must fit next to the halo (<= 64 KiB: two workgroups per CU)
+        return p;
+    p.tile = tile;
+    p.cellshift = true;
+    for (int d = 0; d < 3; ++d)
+        if (b.pbc[d] && g.nc[d] < 7)
+            p.cellshift = false;
+    return p;
+}
+
+template <int T, bool CS>
+static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double rc, int *verlet, double *dist, int *nn,
+                       int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved)
+{
+    const int ntiles = nt[0] * nt[1] * nt[2];
+    const int per = (ntiles + 7) / 8;
+    dim3 grid((unsigned)(per * 8)), block(TileGeom<T>::NT);
+    const size_t lds = tiled_lds_bytes(TileGeom<T>::NT, M);
+    if (fill_pads)
+        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
+    else
+        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
+}
+
+int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
+                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, TileFilter &tf)
+{
+    const int T = plan.tile;
+    int nt[3];
+    for (int d = 0; d < 3; ++d) nt[d] = (cg.g.nc[d] + T - 1) / T;
+    const int64_t ntiles = (int64_t)nt[0] * nt[1] * nt[2];
+    unsigned char *tile_flag = sc.alloc_n<unsigned char>((size_t)ntiles);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    MDH_HIP(hipMemsetAsync(tile_flag, 0, (size_t)ntiles, st));
+    // Two launches, one of which returns at once on the device flag: per-cell image shifts when every atom
+    // came in wrapped (and the grid allows it), the exact threshold search otherwise.
+    if (T == 4) {
+        if (plan.cellshift) launch_one<4, true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0);
+        launch_one<4, false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1);
+    } else {
+        if (plan.cellshift) launch_one<2, true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0);
+        launch_one<2, false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1);
+    }
+    MDH_HIP(hipGetLastError());
+    tf.flag = tile_flag;
+    tf.any = cg.flags + 2;
+    tf.tile = T;
+    tf.nt[0] = nt[0]; tf.nt[1] = nt[1]; tf.nt[2] = nt[2];
+    return MDH_OK;
+}
+
+} // namespace mdh

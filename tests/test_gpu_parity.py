@@ -52,6 +52,11 @@ def _cases():
     out.append(("triclinic_open_y", frac @ tri, tri, ORG0, np.array([1, 0, 1], np.int32)))
     out.append(("random_gas", rng.random((4000, 3)) * 30.0, np.eye(3) * 30.0, ORG0, PBC))
     out.append(("thin_box_3cells", rng.random((600, 3)) * np.array([9.1, 30.0, 30.0]), np.diag([9.1, 30.0, 30.0]), ORG0, PBC))
+    # a dense blob in a dilute box: the blob's tiles overflow the LDS halo of the tiled kernel (mop-up path)
+    blob = np.concatenate([rng.random((2500, 3)) * 9.0 + 20.0, rng.random((1500, 3)) * 60.0])
+    out.append(("dense_blob", blob, np.eye(3) * 60.0, ORG0, PBC))
+    p, b = _fcc(9, 0.03, 8)
+    out.append(("fcc_partial_tiles", p, b, ORG0, PBC))  # 9..10 cells per axis: clipped tiles, periodic seam inside a tile
     return out
 
 
@@ -76,6 +81,43 @@ def test_neighbor_bit_exact_vs_oracle(case, rc):
     O.build_neighbor(x, y, z, box, org, bnd, rc, va, da, na, 4)
     _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vb, db, nb, 1)
     assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+
+
+def test_neighbor_tile_overflow_and_variants():
+    """fixed narrow rows (max_neigh=20, heavy overflow) on the dense-blob case: blob tiles exceed the LDS halo of
+    the tiled kernel and are finished by the thread-per-atom kernel; forcing that kernel everywhere gives the same bits."""
+    from mdapy_amd import _lib
+
+    _, pos, box, org, bnd = [c for c in CASES if c[0] == "dense_blob"][0]
+    x, y, z = _xyz(pos)
+    rc, M = 3.0, 20
+    va = np.full((len(x), M), -1, np.int32); da = np.full((len(x), M), rc + 1.0); na = np.zeros(len(x), np.int32)
+    O.build_neighbor(x, y, z, box, org, bnd, rc, va, da, na, 4)
+    assert na.max() > M  # rows overflow: counts keep running
+    res = []
+    for variant in (0, 1):
+        _lib.lib().mdh_debug_set_neighbor_variant(variant)
+        try:
+            vb = np.full((len(x), M), -1, np.int32); db = np.full((len(x), M), rc + 1.0); nb = np.zeros(len(x), np.int32)
+            _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vb, db, nb, 1)
+            vc = np.empty((len(x), M), np.int32); dc = np.empty((len(x), M)); nc = np.empty(len(x), np.int32)
+            _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vc, dc, nc, 1, fill_pads=True)
+        finally:
+            _lib.lib().mdh_debug_set_neighbor_variant(0)
+        assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+        assert np.array_equal(nc, na) and np.array_equal(vc, va) and np.array_equal(dc, da)
+        res.append((vb, db, nb))
+    for case in CASES[:4]:
+        _, pos, box, org, bnd = case
+        x, y, z = _xyz(pos)
+        outs = []
+        for variant in (0, 1):
+            _lib.lib().mdh_debug_set_neighbor_variant(variant)
+            try:
+                outs.append(_neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, 3.3, 1))
+            finally:
+                _lib.lib().mdh_debug_set_neighbor_variant(0)
+        assert all(np.array_equal(a, b) for a, b in zip(*outs))
 
 
 def test_neighbor_device_space_and_pads():
