@@ -7,7 +7,9 @@
 // (raw x,y,z + atom id) from the cell-sorted arrays into LDS with coalesced loads — every cell of
 // the grid is read from HBM/L2 once per neighbouring tile instead of once per neighbouring ATOM —
 // then each thread takes one centre atom of the tile and walks its 27 cells out of LDS in the
-// reference's order (cells (i,j,k)-lexicographic, atoms of a cell by descending id).
+// reference's order (cells (i,j,k)-lexicographic, atoms of a cell by descending id).  The three
+// z-cells of one (i,j) column are contiguous in LDS, so the walk is 9 runs of candidates, each
+// processed four at a time (independent f64 chains, predicated; no per-candidate branch).
 //
 // Minimum image.  With all atoms handed over inside the box and >= 7 cells on every periodic axis
 // the image number n = floor(d/L + 0.5) of a (centre, candidate) pair is decided by the pair of
@@ -17,17 +19,17 @@
 // removes 3 divisions / 3 floors per candidate.  When the precondition does not hold (flag from the
 // binning pass, or < 7 cells) the exact threshold search of common.hpp::pbc_axis is used instead.
 //
-// Output.  A hit is first recorded in LDS as a 4-byte ticket (LDS index of the candidate + its image
-// code).  After the scan the workgroup turns tickets into rows cooperatively: consecutive lanes
-// write consecutive slots of a row, so a wave store covers whole 64 B / 128 B row segments instead
-// of 64 scattered rows; the distance is recomputed from the same operands (identical bits).  With
-// fill_pads the same pass writes the -1 / rc+1 pads.
+// Output.  A hit is first recorded in LDS as a 2-byte ticket (LDS index of the candidate + which of
+// the run's three z-cells it sits in).  After the scan the workgroup turns tickets into rows
+// cooperatively: consecutive lanes write consecutive slots of a row, so a wave store covers whole
+// 64 B / 128 B row segments instead of 64 scattered rows; the distance is recomputed from the same
+// operands (identical bits).  With fill_pads the same pass writes the -1 / rc+1 pads.
 #include "common.hpp"
 #include "grid.hpp"
 
 namespace mdh {
 
-static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (28 B each)
+static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (28 B each); ticket index is 10 bits
 
 template <int T> struct TileGeom {
     static constexpr int H = T + 2;            // halo cells per edge
@@ -37,7 +39,6 @@ template <int T> struct TileGeom {
 
 __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int nthreads, int *total)
 {
-    // small block scan (nthreads = 128 or 256) built from wave scans
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = v;
 #pragma unroll
@@ -73,12 +74,15 @@ __device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double
     return dx * dx + dy * dy + dz * dz;
 }
 
+// L * n for the 2-bit image code (n+1)
+__device__ __forceinline__ double img_shift(double L, int code) { return L * (double)(code - 1); }
+
 template <int T, bool CELLSHIFT, int MODE>
 __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const int *__restrict__ cell_start, DBox b, Grid g, double rc,
-    int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int *__restrict__ flags,
-    unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved)
+    int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int mp_shift,
+    int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved)
 {
     using G = TileGeom<T>;
     constexpr int H = G::H, NH = G::NH, NT = G::NT;
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
     double *czi = cyi + NT;
     int *lid = reinterpret_cast<int *>(czi + NT); // [HALO_CAP]
     int *crow = lid + HALO_CAP;                   // global atom id of the centre [NT]
-    int *ccnt = crow + NT;                        // min(count, M) [NT]
-    unsigned *tick = reinterpret_cast<unsigned *>(ccnt + NT); // [NT][M]
+    int *cinfo = crow + NT;                       // min(count, M) | xy image code << 8 | (z codes) << 12  [NT]
+    unsigned short *tick = reinterpret_cast<unsigned short *>(cinfo + NT); // [NT][M]
     __shared__ int h_off[NH + 1];
     __shared__ int h_img[NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
     __shared__ int c_off[T * T + 1];
@@ -146,13 +150,23 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
         return;
     }
     // ---- stage the halo atoms (each thread copies its cell: neighbouring threads read neighbouring memory)
-    if (tid < NH)
-        for (int k = 0; k < cnt; ++k) {
+    if (tid < NH) {
+        int k = 0;
+        for (; k + 4 <= cnt; k += 4) { // four independent loads in flight per array
+            double a[4], bb[4], c[4];
+            int d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = xs[src + k + u]; bb[u] = ys[src + k + u]; c[u] = zs[src + k + u]; d[u] = order[src + k + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { lx[off + k + u] = a[u]; ly[off + k + u] = bb[u]; lz[off + k + u] = c[u]; lid[off + k + u] = d[u]; }
+        }
+        for (; k < cnt; ++k) {
             lx[off + k] = xs[src + k];
             ly[off + k] = ys[src + k];
             lz[off + k] = zs[src + k];
             lid[off + k] = order[src + k];
         }
+    }
     // ---- centre runs: one contiguous LDS run per (x,y) column of the tile, clipped to the grid
     const int zlo = 1, zhi = min(T, g.nc[2] - T2); // interior hz in [1, zhi]
     if (tid < T * T) {
@@ -169,10 +183,10 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
     const int ncentres = c_off[T * T];
     const double rcsq = rc * rc; // neighbor.cpp:127
     const double pad = rc + 1.0;
+    const int MP = 1 << mp_shift; // smallest power of two >= M: slots of a row handled by MP adjacent lanes
 
     for (int base = 0; base < ncentres; base += NT) {
         const int q = base + tid;
-        int hits = 0;
         if (q < ncentres) {
             int col = 0;
 #pragma unroll
@@ -186,23 +200,32 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
             double xi = lx[li], yi = ly[li], zi = lz[li];
             if (b.anypbc) // neighbor.cpp:139-142
                 wrap<false>(b, xi, yi, zi);
-            unsigned *my = tick + (size_t)tid * M;
+            // z image codes of the three cells of every run of this centre (only the seam cells differ from 0)
+            const int zc_m = (h_img[colbase + hz - 1] >> 4) & 3, zc_p = (h_img[colbase + hz + 1] >> 4) & 3;
+            const double sz_m = img_shift(b.h[8], zc_m), sz_p = img_shift(b.h[8], zc_p);
+            unsigned short *my = tick + (size_t)tid * M;
+            int hits = 0;
             for (int da = -1; da <= 1; ++da)       // neighbor.cpp:147-151
                 for (int db = -1; db <= 1; ++db) {
                     const int cb = ((hx + da) * H + (hy + db)) * H + hz;
-                    for (int dc = -1; dc <= 1; ++dc) {
-                        const int h = cb + dc;
-                        const int img = h_img[h];
-                        const double sx = b.h[0] * (double)((img & 3) - 1);
-                        const double sy = b.h[4] * (double)(((img >> 2) & 3) - 1);
-                        const double sz = b.h[8] * (double)(((img >> 4) & 3) - 1);
-                        const int e = h_off[h + 1];
-                        for (int k = h_off[h]; k < e; ++k) {
-                            if (k == li)
-                                continue;
-                            const double d2 = pair_d2_tiled<CELLSHIFT>(b, lx[k], ly[k], lz[k], xi, yi, zi, sx, sy, sz);
-                            if (d2 <= rcsq) {
-                                if (hits < M) my[hits] = (unsigned)k | ((unsigned)img << 16);
+                    const int xy = h_img[cb] & 15;
+                    const double sx = img_shift(b.h[0], xy & 3), sy = img_shift(b.h[4], xy >> 2);
+                    const int k0 = h_off[cb - 1], k1 = h_off[cb], k2 = h_off[cb + 1], k3 = h_off[cb + 2];
+                    for (int k = k0; k < k3; k += 4) {
+                        double d2[4];
+                        int kk[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            kk[u] = min(k + u, k3 - 1); // clamped: the tail re-reads the last candidate, masked below
+                            const double sz = CELLSHIFT ? (kk[u] < k1 ? sz_m : (kk[u] < k2 ? 0.0 : sz_p)) : 0.0;
+                            d2[u] = pair_d2_tiled<CELLSHIFT>(b, lx[kk[u]], ly[kk[u]], lz[kk[u]], xi, yi, zi, sx, sy, sz);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool hit = (k + u < k3) && (kk[u] != li) && (d2[u] <= rcsq);
+                            if (hit) {
+                                if (hits < M) // 10 bits LDS index | 2 bits z-cell of the run | 4 bits xy image code
+                                    my[hits] = (unsigned short)(kk[u] | ((kk[u] < k1 ? 0 : (kk[u] < k2 ? 1 : 2)) << 10) | (xy << 12));
                                 ++hits;
                             }
                         }
@@ -211,22 +234,25 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
             const int i = lid[li];
             nn[i] = hits; // keeps counting past M (neighbor.cpp:172-177)
             crow[tid] = i;
-            ccnt[tid] = hits < M ? hits : M;
+            cinfo[tid] = (hits < M ? hits : M) | (zc_m << 16) | (zc_p << 18);
             cxi[tid] = xi; cyi[tid] = yi; czi[tid] = zi;
         }
         __syncthreads();
-        // ---- tickets -> rows: lane f handles slot (f % M) of centre (f / M)
+        // ---- tickets -> rows: MP adjacent lanes serve the slots of one centre
         const int nrows = min(NT, ncentres - base);
-        for (int f = tid; f < nrows * M; f += NT) {
-            const int c = f / M, e = f - c * M;
+        const int e = tid & (MP - 1);
+        for (int c = tid >> mp_shift; c < nrows; c += (NT >> mp_shift)) {
+            if (e >= M)
+                continue;
+            const int info = cinfo[c];
             const int64_t o = (int64_t)crow[c] * M + e;
-            if (e < ccnt[c]) {
-                const unsigned tk = tick[f];
-                const int k = (int)(tk & 0xffffu), img = (int)(tk >> 16);
-                const double sx = b.h[0] * (double)((img & 3) - 1);
-                const double sy = b.h[4] * (double)(((img >> 2) & 3) - 1);
-                const double sz = b.h[8] * (double)(((img >> 4) & 3) - 1);
-                const double d2 = pair_d2_tiled<CELLSHIFT>(b, lx[k], ly[k], lz[k], cxi[c], cyi[c], czi[c], sx, sy, sz);
+            if (e < (info & 0xffff)) {
+                const unsigned tk = tick[c * M + e];
+                const int k = (int)(tk & 1023u), zsel = (int)((tk >> 10) & 3u), xy = (int)(tk >> 12);
+                const int zc = zsel == 0 ? ((info >> 16) & 3) : (zsel == 1 ? 1 : ((info >> 18) & 3));
+                const double d2 = pair_d2_tiled<CELLSHIFT>(b, lx[k], ly[k], lz[k], cxi[c], cyi[c], czi[c],
+                                                           img_shift(b.h[0], xy & 3), img_shift(b.h[4], xy >> 2),
+                                                           CELLSHIFT ? (zsel == 1 ? 0.0 : img_shift(b.h[8], zc)) : 0.0);
                 verlet[o] = lid[k];
                 dist[o] = sqrt(d2);
             } else if (MODE == 2) {
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
 
 static size_t tiled_lds_bytes(int nt, int64_t M)
 {
-    return (size_t)HALO_CAP * 28 + (size_t)nt * (24 + 4 + 4) + (size_t)nt * (size_t)M * 4;
+    return (size_t)HALO_CAP * 28 + (size_t)nt * (24 + 4 + 4) + (size_t)nt * (size_t)M * 2;
 }
 
 TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
@@ -256,6 +282,10 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
         return p;
     const int nt = tile == 4 ? 256 : 128;
     if (tiled_lds_bytes(nt, M) > 62 * 1024) // ticket rows must fit next to the halo (<= 64 KiB: two workgroups per CU)
+        return p;
+    int mp = 1;
+    while (mp < M) mp <<= 1;
+    if (mp > nt)
         return p;
     p.tile = tile;
     p.cellshift = true;
@@ -273,10 +303,12 @@ static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double
     const int per = (ntiles + 7) / 8;
     dim3 grid((unsigned)(per * 8)), block(TileGeom<T>::NT);
     const size_t lds = tiled_lds_bytes(TileGeom<T>::NT, M);
+    int mp_shift = 0;
+    while ((1 << mp_shift) < M) ++mp_shift;
     if (fill_pads)
-        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
+        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
     else
-        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
+        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
 }
 
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
