@@ -29,7 +29,8 @@ struct CellGrid {
 
 // neighbor_tiled.hip: LDS-tiled 27-cell scan for orthogonal boxes (see the file header)
 struct TiledPlan {
-    int tile;        // cells per tile edge (4 or 2); 0 = not applicable
+    int tile;        // cells per tile edge in x and y; 0 = not applicable
+    int tile_z;      // cells per tile edge in z
     bool cellshift;  // every periodic axis has >= 7 cells: per-cell image shifts may replace the minimum-image search
 };
 // what the LDS-tiled kernel leaves to the thread-per-atom kernel: tiles whose halo did not fit in LDS
@@ -37,7 +38,7 @@ struct TiledPlan {
 struct TileFilter {
     const unsigned char *flag = nullptr;
     const int *any = nullptr;
-    int tile = 1;
+    int tile = 1, tile_z = 1;
     int nt[3] = {1, 1, 1};
 };
 TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
             wrap<TRI>(b, xi, yi, zi);
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         if (tf.flag) { // fallback pass: only atoms of tiles the LDS-tiled kernel could not hold (or all of them when it stood down)
-            const int t = ((c0 / tf.tile) * tf.nt[1] + (c1 / tf.tile)) * tf.nt[2] + (c2 / tf.tile);
+            const int t = ((c0 / tf.tile) * tf.nt[1] + (c1 / tf.tile)) * tf.nt[2] + (c2 / tf.tile_z);
             mine = tf.flag[t] != 0;
         }
     }
@@ -425,7 +425,7 @@ int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_
     }
     {
         ProfRange pr("k_neighbor", sc.stream());
-        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, false} : plan_tiled(b, cg.g, N, max_neigh);
+        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, 0, false} : plan_tiled(b, cg.g, N, max_neigh);
         TileFilter tf{};
         if (plan.tile) // LDS-tiled kernel; the thread-per-atom kernel below then only mops up what it left
             MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));

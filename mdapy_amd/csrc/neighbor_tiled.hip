@@ -31,11 +31,13 @@ namespace mdh {
 
 static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (28 B each); ticket index is 10 bits
 
-template <int T> struct TileGeom {
-    static constexpr int H = T + 2;            // halo cells per edge
-    static constexpr int NH = H * H * H;       // halo cells
-    static constexpr int NT = (T == 4) ? 256 : 128; // threads (>= NH required)
-};
+static constexpr int NT = 256;       // threads per workgroup
+static constexpr int MAX_NH = 512;   // halo cells a tile may have
+static constexpr int MAX_COLS = 64;  // (x,y) columns of centre cells a tile may have
+
+// Tile shape (cells): TXY x TXY x TZ, chosen on the host from the mean cell population so that the halo fills
+// (but does not overflow) the LDS budget and the number of centre atoms is close to a multiple of NT.
+struct TileShape { int txy, tz; };
 
 __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int nthreads, int *total)
 {
@@ -77,15 +79,16 @@ __device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double
 // L * n for the 2-bit image code (n+1)
 __device__ __forceinline__ double img_shift(double L, int code) { return L * (double)(code - 1); }
 
-template <int T, bool CELLSHIFT, int MODE>
-__global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
+template <bool CELLSHIFT, int MODE>
+__global__ __launch_bounds__(NT) void k_neighbor_tiled(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const int *__restrict__ cell_start, DBox b, Grid g, double rc,
     int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int mp_shift,
-    int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved)
+    int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved,
+    TileShape ts)
 {
-    using G = TileGeom<T>;
-    constexpr int H = G::H, NH = G::NH, NT = G::NT;
+    const int TXY = ts.txy, TZ = ts.tz;
+    const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ, NCOL = TXY * TXY;
     // which of the two minimum-image variants serves this call is decided on the device (no host sync)
     // want_moved: 0 = run only if every atom came in wrapped, 1 = run only if not, -1 = always run
     if (want_moved >= 0 && (flags[0] != 0) != (want_moved != 0))
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
     int *crow = lid + HALO_CAP;                   // global atom id of the centre [NT]
     int *cinfo = crow + NT;                       // min(count, M) | xy image code << 8 | (z codes) << 12  [NT]
     unsigned short *tick = reinterpret_cast<unsigned short *>(cinfo + NT); // [NT][M]
-    __shared__ int h_off[NH + 1];
-    __shared__ int h_img[NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
-    __shared__ int c_off[T * T + 1];
+    __shared__ int h_off[MAX_NH + 1];
+    __shared__ int h_img[MAX_NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
+    __shared__ int c_off[MAX_COLS + 1];
     __shared__ int scan_tmp[4];
 
     // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of tiles so that
@@ -115,13 +118,19 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
     if (tile_id >= ntiles)
         return;
     const int t2 = tile_id % nt2, t1 = (tile_id / nt2) % nt1, t0 = tile_id / (nt2 * nt1);
-    const int T0 = t0 * T, T1 = t1 * T, T2 = t2 * T;
+    const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
     const int tid = threadIdx.x;
 
-    // ---- halo cell table: source range, LDS offset, image code
-    int cnt = 0, src = 0;
-    if (tid < NH) {
-        const int hz = tid % H, hy = (tid / H) % H, hx = tid / (H * H);
+    // ---- halo cell table: source range, LDS offset, image code.  Thread t owns halo cells 2t and 2t+1
+    // (adjacent in z, hence adjacent in memory).
+    int cnt2[2] = {0, 0}, src2[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int h = 2 * tid + u;
+        if (h >= NH)
+            continue;
+        int cnt = 0, src = 0;
+        const int hz = h % HZ, hy = (h / HZ) % HXY, hx = h / (HZ * HXY);
         const int g0 = T0 + hx - 1, g1 = T1 + hy - 1, g2 = T2 + hz - 1;
         int img = 1 | (1 << 2) | (1 << 4);
         if (g0 >= -1 && g0 <= g.nc[0] && g1 >= -1 && g1 <= g.nc[1] && g2 >= -1 && g2 <= g.nc[2]) {
@@ -136,11 +145,14 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
             const int n2 = b.pbc[2] ? (g2 < 0 ? 1 : (g2 >= g.nc[2] ? -1 : 0)) : 0;
             img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
         }
-        h_img[tid] = img;
+        h_img[h] = img;
+        cnt2[u] = cnt;
+        src2[u] = src;
     }
     int total;
-    const int off = excl_scan_block(cnt, scan_tmp, NT, &total);
-    if (tid < NH) h_off[tid] = off;
+    const int off0 = excl_scan_block(cnt2[0] + cnt2[1], scan_tmp, NT, &total);
+    if (2 * tid < NH) h_off[2 * tid] = off0;
+    if (2 * tid + 1 < NH) h_off[2 * tid + 1] = off0 + cnt2[0];
     if (tid == 0) h_off[NH] = total;
     if (total > HALO_CAP) { // leave this tile to the thread-per-atom kernel
         if (tid == 0) {
@@ -150,7 +162,9 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
         return;
     }
     // ---- stage the halo atoms (each thread copies its cell: neighbouring threads read neighbouring memory)
-    if (tid < NH) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int cnt = cnt2[u], src = src2[u], off = off0 + (u ? cnt2[0] : 0);
         int k = 0;
         for (; k + 4 <= cnt; k += 4) { // four independent loads in flight per array
             double a[4], bb[4], c[4];
@@ -168,19 +182,26 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
         }
     }
     // ---- centre runs: one contiguous LDS run per (x,y) column of the tile, clipped to the grid
-    const int zlo = 1, zhi = min(T, g.nc[2] - T2); // interior hz in [1, zhi]
-    if (tid < T * T) {
-        const int hx = tid / T + 1, hy = tid % T + 1;
-        const bool ok = (T0 + hx - 1 < g.nc[0]) && (T1 + hy - 1 < g.nc[1]) && zhi >= 1;
-        c_off[tid + 1] = ok ? (h_off[(hx * H + hy) * H + zhi + 1] - h_off[(hx * H + hy) * H + zlo]) : 0;
+    const int zlo = 1, zhi = min(TZ, g.nc[2] - T2); // interior hz in [1, zhi]
+    __syncthreads();                                  // h_off complete
+    if (tid < 64) { // one wave: per-column centre counts -> exclusive prefix
+        int v = 0;
+        if (tid < NCOL) {
+            const int hx = tid / TXY + 1, hy = tid % TXY + 1;
+            const bool ok = (T0 + hx - 1 < g.nc[0]) && (T1 + hy - 1 < g.nc[1]) && zhi >= 1;
+            v = ok ? (h_off[(hx * HXY + hy) * HZ + zhi + 1] - h_off[(hx * HXY + hy) * HZ + zlo]) : 0;
+        }
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(inc, d, 64);
+            if (tid >= d) inc += t;
+        }
+        if (tid < NCOL) c_off[tid + 1] = inc;
+        if (tid == 0) c_off[0] = 0;
     }
     __syncthreads();
-    if (tid == 0) {
-        c_off[0] = 0;
-        for (int k = 0; k < T * T; ++k) c_off[k + 1] += c_off[k];
-    }
-    __syncthreads();
-    const int ncentres = c_off[T * T];
+    const int ncentres = c_off[NCOL];
     const double rcsq = rc * rc; // neighbor.cpp:127
     const double pad = rc + 1.0;
     const int MP = 1 << mp_shift; // smallest power of two >= M: slots of a row handled by MP adjacent lanes
@@ -189,11 +210,10 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
         const int q = base + tid;
         if (q < ncentres) {
             int col = 0;
-#pragma unroll
-            for (int k = 1; k < T * T; ++k)
+            for (int k = 1; k < NCOL; ++k)
                 col += (q >= c_off[k]) ? 1 : 0;
-            const int hx = col / T + 1, hy = col % T + 1;
-            const int colbase = (hx * H + hy) * H;
+            const int hx = col / TXY + 1, hy = col % TXY + 1;
+            const int colbase = (hx * HXY + hy) * HZ;
             const int li = h_off[colbase + zlo] + (q - c_off[col]); // LDS index of the centre atom
             int hz = zlo;
             while (hz < zhi && li >= h_off[colbase + hz + 1]) ++hz;
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
             int hits = 0;
             for (int da = -1; da <= 1; ++da)       // neighbor.cpp:147-151
                 for (int db = -1; db <= 1; ++db) {
-                    const int cb = ((hx + da) * H + (hy + db)) * H + hz;
+                    const int cb = ((hx + da) * HXY + (hy + db)) * HZ + hz;
                     const int xy = h_img[cb] & 15;
                     const double sx = img_shift(b.h[0], xy & 3), sy = img_shift(b.h[4], xy >> 2);
                     const int k0 = h_off[cb - 1], k1 = h_off[cb], k2 = h_off[cb + 1], k3 = h_off[cb + 2];
@@ -264,30 +284,50 @@ __global__ __launch_bounds__(TileGeom<T>::NT) void k_neighbor_tiled(
     }
 }
 
-static size_t tiled_lds_bytes(int nt, int64_t M)
+static size_t tiled_lds_bytes(int64_t M)
 {
-    return (size_t)HALO_CAP * 28 + (size_t)nt * (24 + 4 + 4) + (size_t)nt * (size_t)M * 2;
+    return (size_t)HALO_CAP * 28 + (size_t)NT * (24 + 4 + 4) + (size_t)NT * (size_t)M * 2;
+}
+
+// pick the tile shape for a mean cell population `pop`
+static TileShape choose_shape(double pop, const Grid &g)
+{
+    TileShape best{0, 0};
+    double best_score = -1.0;
+    for (int txy = 2; txy <= 8; ++txy)
+        for (int tz = 2; tz <= 16; ++tz) {
+            const int nh = (txy + 2) * (txy + 2) * (tz + 2);
+            if (nh > MAX_NH || txy * txy > MAX_COLS)
+                continue;
+            if (nh * pop > 0.86 * HALO_CAP) // head-room for density fluctuations; overflowing tiles fall back
+                continue;
+            const double c = txy * txy * tz * pop;                       // centre atoms per tile
+            const double util = c / (std::ceil(c / NT) * NT);           // lane utilisation of the scan
+            const double reuse = (double)(txy * txy * tz) / (double)nh; // centre cells per staged cell
+            const double score = util * (0.35 + reuse);
+            if (score > best_score) { best_score = score; best = TileShape{txy, tz}; }
+        }
+    (void)g;
+    return best;
 }
 
 TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
 {
-    TiledPlan p{0, false};
+    TiledPlan p{0, 0, false};
     if (b.tri || g.mode != 0 || N <= 0 || M <= 0)
         return p;
     const double pop = (double)N / (double)g.ncell; // mean atoms per cell
-    int tile = 0;
-    if (pop * 216.0 <= 0.93 * HALO_CAP) tile = 4;
-    else if (pop * 64.0 <= 0.80 * HALO_CAP) tile = 2;
-    if (!tile)
+    const TileShape sh = choose_shape(pop, g);
+    if (!sh.txy)
         return p;
-    const int nt = tile == 4 ? 256 : 128;
-    if (tiled_lds_bytes(nt, M) > 62 * 1024) // ticket rows must fit next to the halo (<= 64 KiB: two workgroups per CU)
+    if (tiled_lds_bytes(M) > 62 * 1024) // ticket rows must fit next to the halo (<= 64 KiB: two workgroups per CU)
         return p;
     int mp = 1;
     while (mp < M) mp <<= 1;
-    if (mp > nt)
+    if (mp > NT)
         return p;
-    p.tile = tile;
+    p.tile = sh.txy;
+    p.tile_z = sh.tz;
     p.cellshift = true;
     for (int d = 0; d < 3; ++d)
         if (b.pbc[d] && g.nc[d] < 7)
@@ -295,28 +335,31 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
     return p;
 }
 
-template <int T, bool CS>
+template <bool CS>
 static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double rc, int *verlet, double *dist, int *nn,
-                       int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved)
+                       int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved, TileShape ts)
 {
     const int ntiles = nt[0] * nt[1] * nt[2];
     const int per = (ntiles + 7) / 8;
-    dim3 grid((unsigned)(per * 8)), block(TileGeom<T>::NT);
-    const size_t lds = tiled_lds_bytes(TileGeom<T>::NT, M);
+    dim3 grid((unsigned)(per * 8)), block(NT);
+    const size_t lds = tiled_lds_bytes(M);
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
     if (fill_pads)
-        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
+        hipLaunchKernelGGL((k_neighbor_tiled<CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
     else
-        hipLaunchKernelGGL((k_neighbor_tiled<T, CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved);
+        hipLaunchKernelGGL((k_neighbor_tiled<CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
 }
 
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
                           int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, TileFilter &tf)
 {
-    const int T = plan.tile;
+    const TileShape ts{plan.tile, plan.tile_z};
     int nt[3];
-    for (int d = 0; d < 3; ++d) nt[d] = (cg.g.nc[d] + T - 1) / T;
+    for (int d = 0; d < 3; ++d) {
+        const int T = d == 2 ? ts.tz : ts.txy;
+        nt[d] = (cg.g.nc[d] + T - 1) / T;
+    }
     const int64_t ntiles = (int64_t)nt[0] * nt[1] * nt[2];
     unsigned char *tile_flag = sc.alloc_n<unsigned char>((size_t)ntiles);
     if (sc.failed())
@@ -325,17 +368,13 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
     MDH_HIP(hipMemsetAsync(tile_flag, 0, (size_t)ntiles, st));
     // Two launches, one of which returns at once on the device flag: per-cell image shifts when every atom
     // came in wrapped (and the grid allows it), the exact threshold search otherwise.
-    if (T == 4) {
-        if (plan.cellshift) launch_one<4, true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0);
-        launch_one<4, false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1);
-    } else {
-        if (plan.cellshift) launch_one<2, true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0);
-        launch_one<2, false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1);
-    }
+    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts);
+    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts);
     MDH_HIP(hipGetLastError());
     tf.flag = tile_flag;
     tf.any = cg.flags + 2;
-    tf.tile = T;
+    tf.tile = ts.txy;
+    tf.tile_z = ts.tz;
     tf.nt[0] = nt[0]; tf.nt[1] = nt[1]; tf.nt[2] = nt[2];
     return MDH_OK;
 }
