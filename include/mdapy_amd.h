@@ -66,6 +66,9 @@ int mdh_prof_report(char *buf, int buflen);
 /* A/B switch for measurements and tests: 0 = automatic kernel choice (default), 1 = force the
  * thread-per-atom neighbor kernel even where the LDS-tiled one applies.  Results are identical. */
 int mdh_debug_set_neighbor_variant(int variant);
+/* test hook: out4[k] = smallest double d with floor(d/L + 0.5) >= k-1 (k = 0..3) for a periodic orthogonal
+ * axis of length L — the exact decision points that let the kernels replace floor(d/L+0.5) by compares. */
+int mdh_debug_image_thresholds(double L, double *out4);
 
 /* ---- _neighbor -------------------------------------------------------- */
 /*

@@ -151,8 +151,8 @@ static double image_threshold(double L, double n)
 {
     auto f = [L](double d) { return std::floor(d / L + 0.5); };
     int64_t lo = to_key(-8.0 * L), hi = to_key(8.0 * L); // f(lo) < n <= f(hi) for n in [-1,2]
-    while (hi - lo > 1) {
-        int64_t mid = lo + (hi - lo) / 2;
+    while (lo + 1 < hi) { // keys of opposite sign: hi - lo would overflow int64
+        const int64_t mid = (lo >> 1) + (hi >> 1) + (lo & hi & 1);
         if (f(from_key(mid)) >= n) hi = mid; else lo = mid;
     }
     return from_key(hi);
@@ -251,6 +251,17 @@ int mdh_release_workspace(void)
         if (!mdh::g_blocks[i].busy) { (void)hipFree(mdh::g_blocks[i].p); mdh::g_blocks.erase(mdh::g_blocks.begin() + i); }
         else ++i;
     }
+    return MDH_OK;
+}
+
+// test hook: the four minimum-image decision thresholds of an orthogonal periodic axis of length L
+int mdh_debug_image_thresholds(double L, double *out4)
+{
+    mdh::DBox b;
+    const double box9[9] = {L, 0, 0, 0, L, 0, 0, 0, L}, o[3] = {0, 0, 0};
+    const int p[3] = {1, 1, 1};
+    MDH_TRY(mdh::make_box(b, box9, o, p));
+    for (int k = 0; k < 4; ++k) out4[k] = b.tn[0][k];
     return MDH_OK;
 }
 

@@ -54,3 +54,19 @@ def test_argument_errors_map_to_python_exceptions():
     sing = np.array([[1.0, 1.0, 0.0], [2.0, 2.0, 0.0], [0.0, 0.0, 1.0]])  # singular triclinic box: src/box.h:185-186
     with pytest.raises(RuntimeError, match="volume of the box is zero"):
         _neighbor.build_neighbor(x, x, x, sing, np.zeros(3), np.ones(3, np.int32), 1.0, v, d, nn, 1)
+
+
+def test_minimum_image_thresholds_are_exact():
+    """DBox::tn — the kernels pick floor(d/L+0.5) by comparing d with these; each must be the exact step point."""
+    from mdapy_amd import _lib
+
+    L = _lib.lib()
+    for length in (491.64, 36.15, 1.0, 7.3e-3, 123456.789):
+        out = np.zeros(4)
+        assert L.mdh_debug_image_thresholds(float(length), out.ctypes.data) == 0
+        for k, t in enumerate(out):
+            n = k - 1
+            assert np.floor(t / length + 0.5) >= n
+            assert np.floor(np.nextafter(t, -np.inf) / length + 0.5) < n
+        assert out[0] < out[1] < out[2] < out[3]
+        assert abs(out[1] + 0.5 * length) < 1e-9 * length and abs(out[2] - 0.5 * length) < 1e-9 * length
