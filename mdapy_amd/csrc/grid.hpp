@@ -25,6 +25,7 @@ struct CellGrid {
     //                   periodic axis (unwrapped input) -> per-cell image shifts are not valid
     //   flags[1]      : largest cell population
     int *flags;
+    unsigned char *mvs; // [N] per-atom image code (raw vs wrapped coordinate), in `order`
 };
 
 // neighbor_tiled.hip: LDS-tiled 27-cell scan for orthogonal boxes (see the file header)

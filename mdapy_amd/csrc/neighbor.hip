@@ -31,19 +31,33 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
                                                 unsigned *__restrict__ cell_count, int *__restrict__ flags,
-                                                double slack)
+                                                double slack, unsigned char *__restrict__ mv)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false;
     if (i < N) {
         const double xr = x[i], yr = y[i], zr = z[i];
         double xi = xr, yi = yr, zi = zr;
+        int code = 1 | (1 << 2) | (1 << 4); // (m+1) per axis: raw = wrapped + m*L
         if (wrap_first && b.anypbc) { // neighbor.cpp:88-91
             wrap<TRI>(b, xi, yi, zi);
-            // an atom whose raw position is not (to within `slack`) its wrapped one was handed over unwrapped
-            moved = (b.pbc[0] && !(fabs(xi - xr) <= slack)) || (b.pbc[1] && !(fabs(yi - yr) <= slack)) ||
-                    (b.pbc[2] && !(fabs(zi - zr) <= slack));
+            if (!TRI) {
+                // whole box lengths between the raw and the wrapped coordinate; anything that is not a clean
+                // -1/0/+1 (far-unwrapped input) invalidates the image codes for this call (flags[0])
+                const double raw[3] = {xr, yr, zr}, wrp[3] = {xi, yi, zi};
+                code = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    double m = 0.0;
+                    if (b.pbc[d]) {
+                        m = rint((raw[d] - wrp[d]) / b.h[d * 4]);
+                        if (!(fabs(m) <= 1.0) || !(fabs(raw[d] - m * b.h[d * 4] - wrp[d]) <= slack)) { moved = true; m = 0.0; }
+                    }
+                    code |= ((int)m + 1) << (2 * d);
+                }
+            }
         }
+        if (mv) mv[i] = (unsigned char)code;
         int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         int c = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
@@ -168,7 +182,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell
 __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, const int *__restrict__ order,
                                                 double *__restrict__ xs, double *__restrict__ ys,
-                                                double *__restrict__ zs, int64_t N)
+                                                double *__restrict__ zs, int64_t N,
+                                                const unsigned char *__restrict__ mv, unsigned char *__restrict__ mvs)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N)
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
     xs[p] = x[i];
     ys[p] = y[i];
     zs[p] = z[i];
+    mvs[p] = mv[i];
 }
 
 int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
@@ -213,6 +229,8 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     cg.xs = sc.alloc_n<double>((size_t)N);
     cg.ys = sc.alloc_n<double>((size_t)N);
     cg.zs = sc.alloc_n<double>((size_t)N);
+    unsigned char *mv = sc.alloc_n<unsigned char>((size_t)N);
+    cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
     const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
     unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk);
     cg.flags = sc.alloc_n<int>(4);
@@ -224,16 +242,16 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
     if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv);
     else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack);
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv);
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc)
         hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell);
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N);
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }

@@ -3,43 +3,48 @@
 // Same result, bit for bit, as the thread-per-atom kernel in neighbor.hip (and therefore as
 // src/neighbor.cpp:102-187 of the reference); this is the fast path for the common case.
 //
-// One workgroup owns a tile of T x T x T cells.  It stages the atoms of the (T+2)^3 halo cells
-// (raw x,y,z + atom id) from the cell-sorted arrays into LDS with coalesced loads — every cell of
-// the grid is read from HBM/L2 once per neighbouring tile instead of once per neighbouring ATOM —
-// then each thread takes one centre atom of the tile and walks its 27 cells out of LDS in the
-// reference's order (cells (i,j,k)-lexicographic, atoms of a cell by descending id).  The three
-// z-cells of one (i,j) column are contiguous in LDS, so the walk is 9 runs of candidates, each
-// processed four at a time (independent f64 chains, predicated; no per-candidate branch).
+// One workgroup owns a tile of TXY x TXY x TZ cells (shape chosen on the host from the mean cell
+// population).  It stages the atoms of the halo cells (raw x,y,z + atom id) from the cell-sorted
+// arrays into LDS with coalesced loads — every cell of the grid is read from HBM/L2 once per
+// neighbouring tile instead of once per neighbouring ATOM — then each thread takes one centre atom
+// of the tile and walks its 27 cells out of LDS in the reference's order (cells (i,j,k)-
+// lexicographic, atoms of a cell by descending id).  The three z-cells of one (i,j) column are
+// contiguous in LDS, so the walk is 9 runs of candidates, each processed four at a time
+// (independent f64 chains).
 //
-// Minimum image.  With all atoms handed over inside the box and >= 7 cells on every periodic axis
-// the image number n = floor(d/L + 0.5) of a (centre, candidate) pair is decided by the pair of
-// CELLS: candidates of an adjacent cell are < 3 rc <= 3L/7 away after the right shift, so n is 0
-// inside the box and +-1 across the periodic seam — far from the +-L/2 decision points.  The kernel
-// then evaluates the reference's  d - L*n  with that n (same operands, same two roundings), which
-// removes 3 divisions / 3 floors per candidate.  When the precondition does not hold (flag from the
-// binning pass, or < 7 cells) the exact threshold search of common.hpp::pbc_axis is used instead.
+// Minimum image.  n = floor(d/L + 0.5) of a (centre, candidate) pair is known without evaluating it
+// when there are >= 7 cells on every periodic axis: candidates of an adjacent cell are < 3 rc <= 3L/7
+// away after the right shift, far from the +-L/2 decision points, so
+//        n = n_cell + m_atom
+// where n_cell in {-1,0,1} says whether the candidate's cell was reached across the periodic seam and
+// m_atom in {-1,0,1} is the whole number of box lengths by which the candidate's RAW coordinate differs
+// from its wrapped one (0 for input that is already wrapped; recorded by the binning pass).  The
+// kernel then evaluates the reference's  d - L*n  with that n (same operands, same roundings; L*n is
+// exact for |n| <= 2), removing 3 divisions and 3 floors per candidate.  Tiles away from the seam
+// whose atoms all have m = 0 (almost all of them) skip the shift altogether: d - L*0 == d.  When the
+// precondition fails (flag from the binning pass, or < 7 cells) the exact threshold search of
+// common.hpp::pbc_axis is used instead.
 //
-// Output.  A hit is first recorded in LDS as a 2-byte ticket (LDS index of the candidate + which of
-// the run's three z-cells it sits in).  After the scan the workgroup turns tickets into rows
-// cooperatively: consecutive lanes write consecutive slots of a row, so a wave store covers whole
-// 64 B / 128 B row segments instead of 64 scattered rows; the distance is recomputed from the same
-// operands (identical bits).  With fill_pads the same pass writes the -1 / rc+1 pads.
+// Output.  A hit is first recorded in LDS as a 2-byte ticket (LDS index of the candidate).  After the
+// scan the workgroup turns tickets into rows cooperatively: consecutive lanes write consecutive
+// slots of a row, so a wave store covers whole 64 B / 128 B row segments instead of 64 scattered
+// rows; the distance is recomputed from the same operands (identical bits).  With fill_pads the
+// same pass writes the -1 / rc+1 pads.
 #include "common.hpp"
 #include "grid.hpp"
 
 namespace mdh {
 
-static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (28 B each); ticket index is 10 bits
+static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (31 B each)
+static constexpr int NT = 256;        // threads per workgroup
+static constexpr int MAX_NH = 512;    // halo cells a tile may have
+static constexpr int MAX_COLS = 64;   // (x,y) columns of centre cells a tile may have
+static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4); // image code of "no shift": (n+1) per axis, 2 bits each
 
-static constexpr int NT = 256;       // threads per workgroup
-static constexpr int MAX_NH = 512;   // halo cells a tile may have
-static constexpr int MAX_COLS = 64;  // (x,y) columns of centre cells a tile may have
-
-// Tile shape (cells): TXY x TXY x TZ, chosen on the host from the mean cell population so that the halo fills
-// (but does not overflow) the LDS budget and the number of centre atoms is close to a multiple of NT.
+// Tile shape (cells): TXY x TXY x TZ
 struct TileShape { int txy, tz; };
 
-__device__ __forceinline__ int excl_scan_block(int v, int *scratch, int nthreads, int *total)
+__device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = v;
@@ -51,7 +56,8 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int nthreads
     if (lane == 63) scratch[w] = inc;
     __syncthreads();
     int off = 0, tot = 0;
-    for (int k = 0; k < (nthreads >> 6); ++k) {
+#pragma unroll
+    for (int k = 0; k < (NT >> 6); ++k) {
         if (k < w) off += scratch[k];
         tot += scratch[k];
     }
@@ -60,55 +66,124 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int nthreads
     return off + inc - v;
 }
 
-// d2 of one (centre, candidate) pair; CELLSHIFT: sx,sy,sz = L*n for the pair's cells
-template <bool CELLSHIFT>
+// L * n for cell code cc and atom code ca (each (n+1) in 2 bits): n = n_cell + m_atom in [-2, 2]
+__device__ __forceinline__ double img_shift(double L, int cc, int ca) { return L * (double)(cc + ca - 2); }
+
+// squared distance of one (centre, candidate) pair.
+//   PBCMODE 0: no shift at all (tile away from the seam, all atoms wrapped): d - L*0 == d
+//   PBCMODE 1: d - L*n with n from the image codes
+//   PBCMODE 2: exact threshold / division search (common.hpp)
+template <int PBCMODE>
 __device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double yj, double zj, double xi, double yi,
-                                                double zi, double sx, double sy, double sz)
+                                                double zi, int cc, int ca)
 {
     double dx = xj - xi, dy = yj - yi, dz = zj - zi; // raw x[j] - wrapped centre (neighbor.cpp:164-166)
-    if (CELLSHIFT) {
-        dx = dx - sx; // == xij - L*floor(xij/L+0.5)   (box.h:120-124) with n known from the cells
-        dy = dy - sy;
-        dz = dz - sz;
-    } else {
+    if (PBCMODE == 1) {
+        dx = dx - img_shift(b.h[0], cc & 3, ca & 3); // == xij - L*floor(xij/L+0.5)   (box.h:120-124)
+        dy = dy - img_shift(b.h[4], (cc >> 2) & 3, (ca >> 2) & 3);
+        dz = dz - img_shift(b.h[8], (cc >> 4) & 3, (ca >> 4) & 3);
+    } else if (PBCMODE == 2) {
         pbc<false>(b, dx, dy, dz);
     }
     return dx * dx + dy * dy + dz * dz;
 }
 
-// L * n for the 2-bit image code (n+1)
-__device__ __forceinline__ double img_shift(double L, int code) { return L * (double)(code - 1); }
+struct TileLds {
+    double *lx, *ly, *lz;        // staged raw positions [HALO_CAP]
+    int *lid;                    // staged atom ids [HALO_CAP]
+    unsigned short *lcell;       // halo cell of a staged atom [HALO_CAP]
+    unsigned char *lmv;          // atom image code (raw vs wrapped) [HALO_CAP]
+    const unsigned char *h_img;  // cell image code [MAX_NH]
+};
 
+// one run of candidates [k0, k3) for centre li; tickets (LDS indices) appended to my[]
+template <int PBCMODE, bool SELF>
+__device__ __forceinline__ void scan_run(const DBox &b, const TileLds &L, int k0, int k3, int li, double xi, double yi,
+                                         double zi, double rcsq, unsigned short *__restrict__ my, int M, int &hits)
+{
+    int k = k0;
+    for (; k + 4 <= k3; k += 4) { // four independent chains, no bounds checks
+        double d2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = k + u;
+            int cc = NEUTRAL, ca = NEUTRAL;
+            if (PBCMODE == 1) { cc = L.h_img[L.lcell[q]]; ca = L.lmv[q]; }
+            d2[u] = pair_d2_tiled<PBCMODE>(b, L.lx[q], L.ly[q], L.lz[q], xi, yi, zi, cc, ca);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool hit = (d2[u] <= rcsq) && (!SELF || (k + u != li));
+            if (hit) {
+                if (hits < M) my[hits] = (unsigned short)(k + u);
+                ++hits;
+            }
+        }
+    }
+    for (; k < k3; ++k) { // tail (< 4 candidates)
+        int cc = NEUTRAL, ca = NEUTRAL;
+        if (PBCMODE == 1) { cc = L.h_img[L.lcell[k]]; ca = L.lmv[k]; }
+        const double d2 = pair_d2_tiled<PBCMODE>(b, L.lx[k], L.ly[k], L.lz[k], xi, yi, zi, cc, ca);
+        if ((d2 <= rcsq) && (!SELF || (k != li))) {
+            if (hits < M) my[hits] = (unsigned short)k;
+            ++hits;
+        }
+    }
+}
+
+template <int PBCMODE>
+__device__ __forceinline__ int scan_centre(const DBox &b, const TileLds &L, const unsigned short *__restrict__ h_off,
+                                           int HXY, int HZ, int hx, int hy, int hz, int li, double xi, double yi,
+                                           double zi, double rcsq, unsigned short *__restrict__ my, int M)
+{
+    int hits = 0;
+    for (int da = -1; da <= 1; ++da)       // neighbor.cpp:147-151
+        for (int db = -1; db <= 1; ++db) {
+            const int cb = ((hx + da) * HXY + (hy + db)) * HZ + hz;
+            const int k0 = h_off[cb - 1], k3 = h_off[cb + 2]; // cells hz-1, hz, hz+1 of this column
+            if (da == 0 && db == 0)
+                scan_run<PBCMODE, true>(b, L, k0, k3, li, xi, yi, zi, rcsq, my, M, hits);
+            else
+                scan_run<PBCMODE, false>(b, L, k0, k3, li, xi, yi, zi, rcsq, my, M, hits);
+        }
+    return hits;
+}
+
+// CELLSHIFT: image numbers from codes (PBCMODE 0/1 chosen per tile); otherwise the exact search (PBCMODE 2)
 template <bool CELLSHIFT, int MODE>
 __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
-    const int *__restrict__ order, const int *__restrict__ cell_start, DBox b, Grid g, double rc,
-    int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int mp_shift,
+    const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
+    Grid g, double rc, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int mp_shift,
     int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved,
     TileShape ts)
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ, NCOL = TXY * TXY;
     // which of the two minimum-image variants serves this call is decided on the device (no host sync)
-    // want_moved: 0 = run only if every atom came in wrapped, 1 = run only if not, -1 = always run
+    // want_moved: 0 = run only if the image codes are valid, 1 = run only if not, -1 = always run
     if (want_moved >= 0 && (flags[0] != 0) != (want_moved != 0))
         return;
 
     extern __shared__ unsigned char smem[];
-    double *lx = reinterpret_cast<double *>(smem);
-    double *ly = lx + HALO_CAP;
-    double *lz = ly + HALO_CAP;
-    double *cxi = lz + HALO_CAP; // wrapped centre coordinates of this pass [NT]
+    TileLds L;
+    L.lx = reinterpret_cast<double *>(smem);
+    L.ly = L.lx + HALO_CAP;
+    L.lz = L.ly + HALO_CAP;
+    double *cxi = L.lz + HALO_CAP; // wrapped centre coordinates of this pass [NT]
     double *cyi = cxi + NT;
     double *czi = cyi + NT;
-    int *lid = reinterpret_cast<int *>(czi + NT); // [HALO_CAP]
-    int *crow = lid + HALO_CAP;                   // global atom id of the centre [NT]
-    int *cinfo = crow + NT;                       // min(count, M) | xy image code << 8 | (z codes) << 12  [NT]
-    unsigned short *tick = reinterpret_cast<unsigned short *>(cinfo + NT); // [NT][M]
-    __shared__ int h_off[MAX_NH + 1];
-    __shared__ int h_img[MAX_NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
+    L.lid = reinterpret_cast<int *>(czi + NT);
+    int *crow = L.lid + HALO_CAP;                 // global atom id of the centre [NT]
+    int *ccnt = crow + NT;                        // min(count, M) [NT]
+    L.lcell = reinterpret_cast<unsigned short *>(ccnt + NT);
+    unsigned short *tick = L.lcell + HALO_CAP;    // [NT][M]
+    L.lmv = reinterpret_cast<unsigned char *>(tick + (size_t)NT * M);
+    __shared__ unsigned short h_off[MAX_NH + 2];
+    __shared__ unsigned char h_img[MAX_NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
     __shared__ int c_off[MAX_COLS + 1];
     __shared__ int scan_tmp[4];
+    L.h_img = h_img;
 
     // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of tiles so that
     // neighbouring tiles (which share halo cells) meet in the same L2.
@@ -124,6 +199,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     // ---- halo cell table: source range, LDS offset, image code.  Thread t owns halo cells 2t and 2t+1
     // (adjacent in z, hence adjacent in memory).
     int cnt2[2] = {0, 0}, src2[2] = {0, 0};
+    bool general = false; // does this tile need image shifts at all?
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int h = 2 * tid + u;
@@ -132,7 +208,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         int cnt = 0, src = 0;
         const int hz = h % HZ, hy = (h / HZ) % HXY, hx = h / (HZ * HXY);
         const int g0 = T0 + hx - 1, g1 = T1 + hy - 1, g2 = T2 + hz - 1;
-        int img = 1 | (1 << 2) | (1 << 4);
+        int img = NEUTRAL;
         if (g0 >= -1 && g0 <= g.nc[0] && g1 >= -1 && g1 <= g.nc[1] && g2 >= -1 && g2 <= g.nc[2]) {
             const int a0 = pmod(g0, g.nc[0]), a1 = pmod(g1, g.nc[1]), a2 = pmod(g2, g.nc[2]);
             const int64_t c = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
@@ -145,15 +221,13 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
             const int n2 = b.pbc[2] ? (g2 < 0 ? 1 : (g2 >= g.nc[2] ? -1 : 0)) : 0;
             img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
         }
-        h_img[h] = img;
+        h_img[h] = (unsigned char)img;
+        general = general || (img != NEUTRAL && cnt > 0);
         cnt2[u] = cnt;
         src2[u] = src;
     }
     int total;
-    const int off0 = excl_scan_block(cnt2[0] + cnt2[1], scan_tmp, NT, &total);
-    if (2 * tid < NH) h_off[2 * tid] = off0;
-    if (2 * tid + 1 < NH) h_off[2 * tid + 1] = off0 + cnt2[0];
-    if (tid == 0) h_off[NH] = total;
+    const int off0 = excl_scan_block(cnt2[0] + cnt2[1], scan_tmp, &total);
     if (total > HALO_CAP) { // leave this tile to the thread-per-atom kernel
         if (tid == 0) {
             tile_flag[tile_id] = 1;
@@ -161,35 +235,44 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         }
         return;
     }
-    // ---- stage the halo atoms (each thread copies its cell: neighbouring threads read neighbouring memory)
+    if (2 * tid < NH) h_off[2 * tid] = (unsigned short)off0;
+    if (2 * tid + 1 < NH) h_off[2 * tid + 1] = (unsigned short)(off0 + cnt2[0]);
+    if (tid == 0) { h_off[NH] = (unsigned short)total; h_off[NH + 1] = (unsigned short)total; }
+    // ---- stage the halo atoms (each thread copies its two cells: neighbouring threads read neighbouring memory)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int cnt = cnt2[u], src = src2[u], off = off0 + (u ? cnt2[0] : 0);
+        const unsigned short hcell = (unsigned short)(2 * tid + u);
         int k = 0;
         for (; k + 4 <= cnt; k += 4) { // four independent loads in flight per array
             double a[4], bb[4], c[4];
             int d[4];
+            unsigned char m[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = xs[src + k + u]; bb[u] = ys[src + k + u]; c[u] = zs[src + k + u]; d[u] = order[src + k + u]; }
+            for (int v = 0; v < 4; ++v) { a[v] = xs[src + k + v]; bb[v] = ys[src + k + v]; c[v] = zs[src + k + v]; d[v] = order[src + k + v]; m[v] = mvs[src + k + v]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { lx[off + k + u] = a[u]; ly[off + k + u] = bb[u]; lz[off + k + u] = c[u]; lid[off + k + u] = d[u]; }
+            for (int v = 0; v < 4; ++v) {
+                L.lx[off + k + v] = a[v]; L.ly[off + k + v] = bb[v]; L.lz[off + k + v] = c[v]; L.lid[off + k + v] = d[v];
+                L.lcell[off + k + v] = hcell; L.lmv[off + k + v] = m[v];
+                general = general || (m[v] != NEUTRAL);
+            }
         }
         for (; k < cnt; ++k) {
-            lx[off + k] = xs[src + k];
-            ly[off + k] = ys[src + k];
-            lz[off + k] = zs[src + k];
-            lid[off + k] = order[src + k];
+            const unsigned char m = mvs[src + k];
+            L.lx[off + k] = xs[src + k]; L.ly[off + k] = ys[src + k]; L.lz[off + k] = zs[src + k]; L.lid[off + k] = order[src + k];
+            L.lcell[off + k] = hcell; L.lmv[off + k] = m;
+            general = general || (m != NEUTRAL);
         }
     }
+    const int tile_general = __syncthreads_or(general ? 1 : 0); // also publishes h_off / staged atoms
     // ---- centre runs: one contiguous LDS run per (x,y) column of the tile, clipped to the grid
     const int zlo = 1, zhi = min(TZ, g.nc[2] - T2); // interior hz in [1, zhi]
-    __syncthreads();                                  // h_off complete
     if (tid < 64) { // one wave: per-column centre counts -> exclusive prefix
         int v = 0;
         if (tid < NCOL) {
             const int hx = tid / TXY + 1, hy = tid % TXY + 1;
             const bool ok = (T0 + hx - 1 < g.nc[0]) && (T1 + hy - 1 < g.nc[1]) && zhi >= 1;
-            v = ok ? (h_off[(hx * HXY + hy) * HZ + zhi + 1] - h_off[(hx * HXY + hy) * HZ + zlo]) : 0;
+            v = ok ? ((int)h_off[(hx * HXY + hy) * HZ + zhi + 1] - (int)h_off[(hx * HXY + hy) * HZ + zlo]) : 0;
         }
         int inc = v;
 #pragma unroll
@@ -214,47 +297,21 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
                 col += (q >= c_off[k]) ? 1 : 0;
             const int hx = col / TXY + 1, hy = col % TXY + 1;
             const int colbase = (hx * HXY + hy) * HZ;
-            const int li = h_off[colbase + zlo] + (q - c_off[col]); // LDS index of the centre atom
+            const int li = (int)h_off[colbase + zlo] + (q - c_off[col]); // LDS index of the centre atom
             int hz = zlo;
-            while (hz < zhi && li >= h_off[colbase + hz + 1]) ++hz;
-            double xi = lx[li], yi = ly[li], zi = lz[li];
+            while (hz < zhi && li >= (int)h_off[colbase + hz + 1]) ++hz;
+            double xi = L.lx[li], yi = L.ly[li], zi = L.lz[li];
             if (b.anypbc) // neighbor.cpp:139-142
                 wrap<false>(b, xi, yi, zi);
-            // z image codes of the three cells of every run of this centre (only the seam cells differ from 0)
-            const int zc_m = (h_img[colbase + hz - 1] >> 4) & 3, zc_p = (h_img[colbase + hz + 1] >> 4) & 3;
-            const double sz_m = img_shift(b.h[8], zc_m), sz_p = img_shift(b.h[8], zc_p);
             unsigned short *my = tick + (size_t)tid * M;
-            int hits = 0;
-            for (int da = -1; da <= 1; ++da)       // neighbor.cpp:147-151
-                for (int db = -1; db <= 1; ++db) {
-                    const int cb = ((hx + da) * HXY + (hy + db)) * HZ + hz;
-                    const int xy = h_img[cb] & 15;
-                    const double sx = img_shift(b.h[0], xy & 3), sy = img_shift(b.h[4], xy >> 2);
-                    const int k0 = h_off[cb - 1], k1 = h_off[cb], k2 = h_off[cb + 1], k3 = h_off[cb + 2];
-                    for (int k = k0; k < k3; k += 4) {
-                        double d2[4];
-                        int kk[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            kk[u] = min(k + u, k3 - 1); // clamped: the tail re-reads the last candidate, masked below
-                            const double sz = CELLSHIFT ? (kk[u] < k1 ? sz_m : (kk[u] < k2 ? 0.0 : sz_p)) : 0.0;
-                            d2[u] = pair_d2_tiled<CELLSHIFT>(b, lx[kk[u]], ly[kk[u]], lz[kk[u]], xi, yi, zi, sx, sy, sz);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const bool hit = (k + u < k3) && (kk[u] != li) && (d2[u] <= rcsq);
-                            if (hit) {
-                                if (hits < M) // 10 bits LDS index | 2 bits z-cell of the run | 4 bits xy image code
-                                    my[hits] = (unsigned short)(kk[u] | ((kk[u] < k1 ? 0 : (kk[u] < k2 ? 1 : 2)) << 10) | (xy << 12));
-                                ++hits;
-                            }
-                        }
-                    }
-                }
-            const int i = lid[li];
+            int hits;
+            if (!CELLSHIFT) hits = scan_centre<2>(b, L, h_off, HXY, HZ, hx, hy, hz, li, xi, yi, zi, rcsq, my, M);
+            else if (tile_general) hits = scan_centre<1>(b, L, h_off, HXY, HZ, hx, hy, hz, li, xi, yi, zi, rcsq, my, M);
+            else hits = scan_centre<0>(b, L, h_off, HXY, HZ, hx, hy, hz, li, xi, yi, zi, rcsq, my, M);
+            const int i = L.lid[li];
             nn[i] = hits; // keeps counting past M (neighbor.cpp:172-177)
             crow[tid] = i;
-            cinfo[tid] = (hits < M ? hits : M) | (zc_m << 16) | (zc_p << 18);
+            ccnt[tid] = hits < M ? hits : M;
             cxi[tid] = xi; cyi[tid] = yi; czi[tid] = zi;
         }
         __syncthreads();
@@ -264,16 +321,14 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         for (int c = tid >> mp_shift; c < nrows; c += (NT >> mp_shift)) {
             if (e >= M)
                 continue;
-            const int info = cinfo[c];
             const int64_t o = (int64_t)crow[c] * M + e;
-            if (e < (info & 0xffff)) {
-                const unsigned tk = tick[c * M + e];
-                const int k = (int)(tk & 1023u), zsel = (int)((tk >> 10) & 3u), xy = (int)(tk >> 12);
-                const int zc = zsel == 0 ? ((info >> 16) & 3) : (zsel == 1 ? 1 : ((info >> 18) & 3));
-                const double d2 = pair_d2_tiled<CELLSHIFT>(b, lx[k], ly[k], lz[k], cxi[c], cyi[c], czi[c],
-                                                           img_shift(b.h[0], xy & 3), img_shift(b.h[4], xy >> 2),
-                                                           CELLSHIFT ? (zsel == 1 ? 0.0 : img_shift(b.h[8], zc)) : 0.0);
-                verlet[o] = lid[k];
+            if (e < ccnt[c]) {
+                const int k = tick[c * M + e];
+                double d2;
+                if (!CELLSHIFT) d2 = pair_d2_tiled<2>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], NEUTRAL, NEUTRAL);
+                else if (tile_general) d2 = pair_d2_tiled<1>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], h_img[L.lcell[k]], L.lmv[k]);
+                else d2 = pair_d2_tiled<0>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], NEUTRAL, NEUTRAL);
+                verlet[o] = L.lid[k];
                 dist[o] = sqrt(d2);
             } else if (MODE == 2) {
                 verlet[o] = -1;
@@ -286,11 +341,11 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
 
 static size_t tiled_lds_bytes(int64_t M)
 {
-    return (size_t)HALO_CAP * 28 + (size_t)NT * (24 + 4 + 4) + (size_t)NT * (size_t)M * 2;
+    return (size_t)HALO_CAP * (24 + 4 + 2 + 1) + (size_t)NT * (24 + 4 + 4) + (size_t)NT * (size_t)M * 2;
 }
 
 // pick the tile shape for a mean cell population `pop`
-static TileShape choose_shape(double pop, const Grid &g)
+static TileShape choose_shape(double pop)
 {
     TileShape best{0, 0};
     double best_score = -1.0;
@@ -307,7 +362,6 @@ static TileShape choose_shape(double pop, const Grid &g)
             const double score = util * (0.35 + reuse);
             if (score > best_score) { best_score = score; best = TileShape{txy, tz}; }
         }
-    (void)g;
     return best;
 }
 
@@ -317,7 +371,7 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
     if (b.tri || g.mode != 0 || N <= 0 || M <= 0)
         return p;
     const double pop = (double)N / (double)g.ncell; // mean atoms per cell
-    const TileShape sh = choose_shape(pop, g);
+    const TileShape sh = choose_shape(pop);
     if (!sh.txy)
         return p;
     if (tiled_lds_bytes(M) > 62 * 1024) // ticket rows must fit next to the halo (<= 64 KiB: two workgroups per CU)
@@ -346,9 +400,9 @@ static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
     if (fill_pads)
-        hipLaunchKernelGGL((k_neighbor_tiled<CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
+        hipLaunchKernelGGL((k_neighbor_tiled<CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
     else
-        hipLaunchKernelGGL((k_neighbor_tiled<CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
+        hipLaunchKernelGGL((k_neighbor_tiled<CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
 }
 
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
@@ -366,8 +420,8 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
         return sc.error();
     hipStream_t st = sc.stream();
     MDH_HIP(hipMemsetAsync(tile_flag, 0, (size_t)ntiles, st));
-    // Two launches, one of which returns at once on the device flag: per-cell image shifts when every atom
-    // came in wrapped (and the grid allows it), the exact threshold search otherwise.
+    // Two launches, one of which returns at once on the device flag: image numbers from the cell / atom codes when
+    // the binning pass found them valid (and the grid allows it), the exact threshold search otherwise.
     if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts);
     launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts);
     MDH_HIP(hipGetLastError());
