@@ -39,6 +39,7 @@ static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (31
 static constexpr int NT = 256;        // threads per workgroup
 static constexpr int MAX_NH = 512;    // halo cells a tile may have
 static constexpr int MAX_COLS = 64;   // (x,y) columns of centre cells a tile may have
+static constexpr int TICK_STRIDE = NT + 2; // ticket slot stride (u16 units): 516 B -> consecutive slots shift by one bank
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4); // image code of "no shift": (n+1) per axis, 2 bits each
 
 // Tile shape (cells): TXY x TXY x TZ
@@ -101,32 +102,26 @@ template <int PBCMODE, bool SELF>
 __device__ __forceinline__ void scan_run(const DBox &b, const TileLds &L, int k0, int k3, int li, double xi, double yi,
                                          double zi, double rcsq, unsigned short *__restrict__ my, int M, int &hits)
 {
-    int k = k0;
-    for (; k + 4 <= k3; k += 4) { // four independent chains, no bounds checks
+    // four independent chains per step; the last step re-reads the run's last candidate for the lanes past the
+    // end (clamped index) and masks them out.  Tickets are stored slot-major with a padded stride
+    // (my[slot * TICK_STRIDE]) so that the lanes of a wave hit different LDS banks.
+    for (int k = k0; k < k3; k += 4) {
         double d2[4];
+        int q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int q = k + u;
+            q[u] = min(k + u, k3 - 1);
             int cc = NEUTRAL, ca = NEUTRAL;
-            if (PBCMODE == 1) { cc = L.h_img[L.lcell[q]]; ca = L.lmv[q]; }
-            d2[u] = pair_d2_tiled<PBCMODE>(b, L.lx[q], L.ly[q], L.lz[q], xi, yi, zi, cc, ca);
+            if (PBCMODE == 1) { cc = L.h_img[L.lcell[q[u]]]; ca = L.lmv[q[u]]; }
+            d2[u] = pair_d2_tiled<PBCMODE>(b, L.lx[q[u]], L.ly[q[u]], L.lz[q[u]], xi, yi, zi, cc, ca);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool hit = (d2[u] <= rcsq) && (!SELF || (k + u != li));
+            const bool hit = (d2[u] <= rcsq) && (k + u < k3) && (!SELF || (q[u] != li));
             if (hit) {
-                if (hits < M) my[hits] = (unsigned short)(k + u);
+                if (hits < M) my[hits * TICK_STRIDE] = (unsigned short)q[u];
                 ++hits;
             }
-        }
-    }
-    for (; k < k3; ++k) { // tail (< 4 candidates)
-        int cc = NEUTRAL, ca = NEUTRAL;
-        if (PBCMODE == 1) { cc = L.h_img[L.lcell[k]]; ca = L.lmv[k]; }
-        const double d2 = pair_d2_tiled<PBCMODE>(b, L.lx[k], L.ly[k], L.lz[k], xi, yi, zi, cc, ca);
-        if ((d2 <= rcsq) && (!SELF || (k != li))) {
-            if (hits < M) my[hits] = (unsigned short)k;
-            ++hits;
         }
     }
 }
@@ -136,16 +131,22 @@ __device__ __forceinline__ int scan_centre(const DBox &b, const TileLds &L, cons
                                            int HXY, int HZ, int hx, int hy, int hz, int li, double xi, double yi,
                                            double zi, double rcsq, unsigned short *__restrict__ my, int M)
 {
+    // bounds of the nine runs first (18 independent LDS reads, one wait), then the runs in reference order
+    int k0s[9], k3s[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { // r = (da+1)*3 + (db+1): neighbor.cpp:147-151
+        const int cb = ((hx + r / 3 - 1) * HXY + (hy + r % 3 - 1)) * HZ + hz;
+        k0s[r] = h_off[cb - 1]; // cells hz-1, hz, hz+1 of this column are contiguous
+        k3s[r] = h_off[cb + 2];
+    }
     int hits = 0;
-    for (int da = -1; da <= 1; ++da)       // neighbor.cpp:147-151
-        for (int db = -1; db <= 1; ++db) {
-            const int cb = ((hx + da) * HXY + (hy + db)) * HZ + hz;
-            const int k0 = h_off[cb - 1], k3 = h_off[cb + 2]; // cells hz-1, hz, hz+1 of this column
-            if (da == 0 && db == 0)
-                scan_run<PBCMODE, true>(b, L, k0, k3, li, xi, yi, zi, rcsq, my, M, hits);
-            else
-                scan_run<PBCMODE, false>(b, L, k0, k3, li, xi, yi, zi, rcsq, my, M, hits);
-        }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        if (r == 4)
+            scan_run<PBCMODE, true>(b, L, k0s[r], k3s[r], li, xi, yi, zi, rcsq, my, M, hits);
+        else
+            scan_run<PBCMODE, false>(b, L, k0s[r], k3s[r], li, xi, yi, zi, rcsq, my, M, hits);
+    }
     return hits;
 }
 
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     int *crow = L.lid + HALO_CAP;                 // global atom id of the centre [NT]
     int *ccnt = crow + NT;                        // min(count, M) [NT]
     L.lcell = reinterpret_cast<unsigned short *>(ccnt + NT);
-    unsigned short *tick = L.lcell + HALO_CAP;    // [NT][M]
-    L.lmv = reinterpret_cast<unsigned char *>(tick + (size_t)NT * M);
+    unsigned short *tick = L.lcell + HALO_CAP;    // [M][TICK_STRIDE]
+    L.lmv = reinterpret_cast<unsigned char *>(tick + (size_t)TICK_STRIDE * M);
     __shared__ unsigned short h_off[MAX_NH + 2];
     __shared__ unsigned char h_img[MAX_NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
     __shared__ int c_off[MAX_COLS + 1];
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
             double xi = L.lx[li], yi = L.ly[li], zi = L.lz[li];
             if (b.anypbc) // neighbor.cpp:139-142
                 wrap<false>(b, xi, yi, zi);
-            unsigned short *my = tick + (size_t)tid * M;
+            unsigned short *my = tick + tid; // slot s of this centre at my[s * TICK_STRIDE]
             int hits;
             if (!CELLSHIFT) hits = scan_centre<2>(b, L, h_off, HXY, HZ, hx, hy, hz, li, xi, yi, zi, rcsq, my, M);
             else if (tile_general) hits = scan_centre<1>(b, L, h_off, HXY, HZ, hx, hy, hz, li, xi, yi, zi, rcsq, my, M);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
                 continue;
             const int64_t o = (int64_t)crow[c] * M + e;
             if (e < ccnt[c]) {
-                const int k = tick[c * M + e];
+                const int k = tick[e * TICK_STRIDE + c];
                 double d2;
                 if (!CELLSHIFT) d2 = pair_d2_tiled<2>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], NEUTRAL, NEUTRAL);
                 else if (tile_general) d2 = pair_d2_tiled<1>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], h_img[L.lcell[k]], L.lmv[k]);
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
 
 static size_t tiled_lds_bytes(int64_t M)
 {
-    return (size_t)HALO_CAP * (24 + 4 + 2 + 1) + (size_t)NT * (24 + 4 + 4) + (size_t)NT * (size_t)M * 2;
+    return (size_t)HALO_CAP * (24 + 4 + 2 + 1) + (size_t)NT * (24 + 4 + 4) + (size_t)TICK_STRIDE * (size_t)M * 2;
 }
 
 // pick the tile shape for a mean cell population `pop`
