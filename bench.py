@@ -199,8 +199,15 @@ def main():
             avg_ms = tot / cnt
             alg_bytes = (28 + 12 * M) * n_rows  # read x,y,z (24 B) + write nn (4 B) + rows (12 M B) per atom
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            # HBM traffic of this kernel comes from separate rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot share
+            # a pass); the committed measurement applies to the default workload only
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath) and cells == 136 and M == 16 and world == 1 and args.sigma == 0.0:
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("traffic_bytes_per_launch_raw")
             res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_ms": avg_ms, "launches": cnt,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": avg_ms, "launches": cnt,
                                "algorithmic_bytes_per_launch": alg_bytes}
             res["kernels_ms"] = {k: v[1] / v[0] for k, v in prof.items()}
         if not args.no_cpu_baseline and world == 1:
