@@ -12,6 +12,7 @@ from .common_neighbor_analysis import CommonNeighborAnalysis
 from .centro_symmetry_parameter import CentroSymmetryParameter
 from .identify_diamond_structure import IdentifyDiamondStructure
 from .steinhardt_bond_orientation import SteinhardtBondOrientation
+from .polyhedral_template_matching import PolyhedralTemplateMatching
 from .radial_distribution_function import RadialDistributionFunction
 from .warren_cowley_parameter import WarrenCowleyParameter
 from .build_lattice import build_crystal
@@ -19,6 +20,6 @@ from .parallel import get_num_threads
 
 __all__ = [
     "Box", "Frame", "System", "Neighbor", "NearestNeighbor", "CommonNeighborAnalysis", "CentroSymmetryParameter",
-    "IdentifyDiamondStructure", "SteinhardtBondOrientation", "RadialDistributionFunction", "WarrenCowleyParameter",
+    "IdentifyDiamondStructure", "SteinhardtBondOrientation", "PolyhedralTemplateMatching", "RadialDistributionFunction", "WarrenCowleyParameter",
     "build_crystal", "get_num_threads",
 ]

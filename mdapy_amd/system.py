@@ -27,6 +27,7 @@ from .frame import Frame
 from .identify_diamond_structure import IdentifyDiamondStructure
 from .knn import NearestNeighbor
 from .neighbor import Neighbor
+from .polyhedral_template_matching import PolyhedralTemplateMatching
 from .radial_distribution_function import RadialDistributionFunction
 from .steinhardt_bond_orientation import SteinhardtBondOrientation
 from .warren_cowley_parameter import WarrenCowleyParameter
@@ -158,6 +159,32 @@ class System:
         cna = CommonNeighborAnalysis(data, box, verlet_list, neighbor_number, rc)
         cna.compute()
         self.update_data(self.__data.with_columns(cna=as_numpy(cna.pattern)[: self.N]))
+
+    def cal_polyhedral_template_matching(self, structure="fcc-hcp-bcc", rmsd_threshold=0.1, return_ordering=False,
+                                         return_rmsd=False, return_atomic_distance=False, return_orientation=False):
+        """column ``ptm`` (+ ``ordering``, ``rmsd``, ``interatomic_distance``, ``qx,qy,qz,qw``) (system.py:1863-1970);
+        the FCC planar-fault post-processing (``identify_fcc_planar_faults``) is outside the hot path."""
+        verlet_list = None
+        if sum(self._safe_repeat()) == 3:
+            if hasattr(self, "neighbor_number"):
+                if self.neighbor_number.min() >= 18:
+                    tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, 18)
+                    verlet_list = self.verlet_list
+        box, data = self._get_compute_view()
+        ptm = PolyhedralTemplateMatching(structure, data, box, rmsd_threshold, verlet_list)
+        ptm.compute()
+        output = as_numpy(ptm.output)[: self.N]
+        new = {"ptm": output[:, 0].astype(np.int32)}
+        if return_ordering:
+            new["ordering"] = output[:, 1]
+        if return_rmsd:
+            new["rmsd"] = output[:, 2]
+        if return_atomic_distance:
+            new["interatomic_distance"] = output[:, 3]
+        if return_orientation:
+            new.update(qx=output[:, 5], qy=output[:, 6], qz=output[:, 7], qw=output[:, 4])
+        self.ptm_indices = ptm.ptm_indices
+        self.update_data(self.__data.with_columns(**new))
 
     def cal_centro_symmetry_parameter(self, N: int):
         """column ``csp`` (system.py:1972-2003)"""

@@ -239,3 +239,42 @@ def repeat_cell(new_pos, old_box, old_pos, nx, ny, nz, num_t=1):
 
 def num_procs() -> int:
     return int(lib().orc_num_procs())
+
+
+# --------------------------------------------------------------------- _ptm  (oracle/_ref: the reference's own PTM library)
+_REF_SO = os.path.join(_HERE, "_ref", "libptm_ref.so")
+_ref = None
+
+
+def build_ref(force: bool = False) -> str:
+    """Build oracle/_ref/libptm_ref.so from /root/reference/extern/ptm (only possible where the reference is present;
+    the GPU box uses the prebuilt file that travels with the snapshot)."""
+    if (force or not os.path.exists(_REF_SO)) and os.path.isdir("/root/reference/extern/ptm"):
+        subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.ref", "-s", "-j", "8"])
+    return _REF_SO
+
+
+def have_ref() -> bool:
+    return os.path.exists(build_ref())
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(build_ref())
+    return _ref
+
+
+def get_ptm(structure, x, y, z, box, origin, boundary, verlet_list, atom_types, rmsd_threshold, output, ptm_indices,
+            num_t=1, cached=None):
+    """mdapy._ptm.get_ptm (src/polyhedral_template_matching.cpp:135) through the reference PTM library."""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v = _ro(verlet_list, np.int32)
+    t = None if atom_types is None or len(atom_types) != len(x) else _ro(atom_types, np.int32)
+    rc = ref_lib().ref_get_ptm(structure.encode(), _p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)),
+                               _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), i64(v.shape[1]),
+                               _p(t, np.int32), dbl(rmsd_threshold), _p(output, np.float64), cint(output.shape[1]),
+                               _p(ptm_indices, np.int32), cint(ptm_indices.shape[1]),
+                               None if cached is None else cached.ctypes.data_as(C.c_void_p))
+    _chk(rc)

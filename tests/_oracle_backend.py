@@ -62,6 +62,8 @@ rdf = _mod(
 wcp = _mod(get_wcp=lambda v, nn, t, Nt, W, num_t=1: O.get_wcp(_np(v), _np(nn), _np(t), Nt, W, NT))
 fast_knn = _mod(knn=lambda x, y, z, box, origin, boundary, k, idx, dist, num_t=1:
                 O.knn(_np(x), _np(y), _np(z), box, origin, boundary, k, idx, dist, NT))
+ptm = _mod(get_ptm=lambda st, x, y, z, box, origin, boundary, v, t, thr, out, ind, num_t=1:
+           O.get_ptm(st, _np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(t), thr, out, ind, NT))
 repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
 
 
@@ -72,6 +74,7 @@ def install(monkeypatch):
     import mdapy_amd.identify_diamond_structure as m_ids
     import mdapy_amd.knn as m_knn
     import mdapy_amd.neighbor as m_nb
+    import mdapy_amd.polyhedral_template_matching as m_ptm
     import mdapy_amd.radial_distribution_function as m_rdf
     import mdapy_amd.steinhardt_bond_orientation as m_sbo
     import mdapy_amd.tool_function as m_tool
@@ -86,5 +89,6 @@ def install(monkeypatch):
     monkeypatch.setattr(m_ids, "_cna", cna)
     monkeypatch.setattr(m_csp, "_csp", csp)
     monkeypatch.setattr(m_sbo, "_sbo", sbo)
+    monkeypatch.setattr(m_ptm, "_ptm", ptm)
     monkeypatch.setattr(m_rdf, "_rdf", rdf)
     monkeypatch.setattr(m_wcp, "_wcp", wcp)

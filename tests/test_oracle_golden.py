@@ -210,3 +210,37 @@ def test_system_cache_invalidation(oracle_backend):
     s.build_neighbor(3.0)
     s.update_data(s.data, reset_neighbor=True)
     assert not hasattr(s, "neighbor_number")
+
+
+# ---------------------------------------------------------------- PTM: oracle/_ref = the reference's own PTM library
+from oracle import oracle as _O
+
+PTM_PATHS = fixtures_with("ptm")
+needs_ref = pytest.mark.skipif(not _O.have_ref(), reason="oracle/_ref/libptm_ref.so not built (needs /root/reference)")
+
+
+# reference: tests/test_polyhedral_template_matching.py:21-31
+@needs_ref
+@pytest.mark.parametrize("path", PTM_PATHS, ids=ids_of(PTM_PATHS))
+def test_ptm_against_fixture(path, oracle_backend):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_polyhedral_template_matching()
+    assert int(np.sum(s.data["ptm"].to_numpy() != d["ptm"])) == 0
+
+
+# reference: tests/test_polyhedral_template_matching.py:34-58
+@needs_ref
+def test_ptm_perfect_crystals(oracle_backend):
+    fcc = mp.build_crystal("Al", "fcc", 4.05, nx=4, ny=4, nz=4)
+    fcc.cal_polyhedral_template_matching()
+    assert np.all(fcc.data["ptm"].to_numpy() == 1)
+    bcc = mp.build_crystal("Fe", "bcc", 2.86, nx=4, ny=4, nz=4)
+    bcc.cal_polyhedral_template_matching()
+    assert np.all(bcc.data["ptm"].to_numpy() == 3)
+    hcp = mp.build_crystal("Mg", "hcp", 3.21, nx=4, ny=4, nz=3)
+    hcp.cal_polyhedral_template_matching()
+    assert np.all(hcp.data["ptm"].to_numpy() == 2)
+    dia = mp.build_crystal("C", "diamond", 3.5, nx=3, ny=3, nz=3)
+    dia.cal_polyhedral_template_matching(structure="all")
+    assert np.all(dia.data["ptm"].to_numpy() == 6)
