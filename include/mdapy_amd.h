@@ -173,6 +173,20 @@ int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const 
 int mdh_repeat_cell(double *new_pos, const double *old_box9_host, const double *old_pos, int64_t n_old, int nx,
                     int ny, int nz, int space, void *stream);
 
+/* ---- _ptm --------------------------------------------------------------- */
+/* replaces _ptm.get_ptm                                     src/polyhedral_template_matching.cpp:135-318
+ * (both passes: ptm_preorder_neighbours :215-255 and ptm_index :258-318 of extern/ptm).
+ * structure: the reference's structure string ("fcc-hcp-bcc", "default", ...; separators " ,-_|", :168-206).
+ * verlet (N,M) int32 rows sorted by distance (the caller passes the 18 nearest neighbours); types may be NULL.
+ * output (N,ncol>=8) f64: type, alloy ordering, rmsd, interatomic distance, orientation quaternion w x y z;
+ * ptm_indices (N,nind) i32: matched atoms in template order, -1 padded (:296-305).
+ * Built: sc, fcc, hcp, ico, bcc.  Requesting dcub / dhex / graphene returns MDH_ERR_ARG (not built yet). */
+int mdh_ptm(const char *structure, const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+            const double *origin3_host, const int *boundary3_host, const int *verlet, int64_t M, const int *types,
+            double rmsd_threshold, double *output, int ncol, int *ptm_indices, int nind, int space, void *stream);
+/* the PTM_CHECK_* bit mask the structure string selects (:168-206) */
+int mdh_ptm_flags(const char *structure);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "mdh_wcp": [vp, vp, vp, i64, i64, cint, vp, cint, vp],
     "mdh_knn": [vp, vp, vp, i64, vp, vp, vp, cint, vp, vp, cint, vp],
     "mdh_repeat_cell": [vp, vp, vp, i64, cint, cint, cint, cint, vp],
+    "mdh_ptm": [C.c_char_p, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp, cint, vp, cint, cint, vp],
+    "mdh_ptm_flags": [C.c_char_p],
 }
 _RESTYPES = {"mdh_last_error": C.c_char_p, "mdh_workspace_bytes": C.c_int64}
 

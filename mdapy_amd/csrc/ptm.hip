@@ -1,0 +1,190 @@
+// ptm.hip — polyhedral template matching on gfx950 (SC / FCC / HCP / ICO / BCC).
+//
+// Replaces src/polyhedral_template_matching.cpp:135-318 (get_ptm) together with the part of extern/ptm it drives
+// (ptm_preorder_neighbours + ptm_index, see ptm_core.hpp for the per-function map).  The reference runs two
+// passes — a serial pre-ordering of every atom's 18 nearest neighbours by Voronoi-face solid angle (:215-255)
+// and the OpenMP matching pass (:258-318).  Both depend on the atom's own neighbour row only, so here they are
+// one kernel: a thread gathers its row, folds the separations (bit-identical minimum image, common.hpp), orders
+// them, matches the templates and writes the (N,8) result row and the (N,18) matched-neighbour row.
+//
+// Work per atom is ~1e5 f64 operations on ~4 KB of private state, no HBM traffic to speak of besides the row
+// gather (18 x 28 B) and 136 B of output: the kernel is bound by VALU issue / scratch latency, not HBM.  The
+// tables (51 KB, generated on the host by ptm_tables.hpp) live in HBM and are read through the scalar/L2 caches.
+#include "common.hpp"
+#include "ptm_tables.hpp"
+#include <mutex>
+
+namespace mdh {
+
+using ptmc::Tables;
+
+static constexpr int PTM_BLOCK = 64;
+
+template <bool TRI>
+__global__ __launch_bounds__(PTM_BLOCK) void k_ptm(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, int64_t N, DBox b,
+                                                   const int *__restrict__ verlet, int64_t M,
+                                                   const int *__restrict__ types, const Tables *__restrict__ tables,
+                                                   int flags, double rmsd_threshold, double *__restrict__ output,
+                                                   int ncol, int *__restrict__ ptm_indices, int nind)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int *row = verlet + i * M;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    double pts[ptmc::MAX_IN][3];
+    int ids[ptmc::MAX_IN];
+    int cnt = 0;
+    const int scan = M < 18 ? (int)M : 18; // get_neighbours, :60-66
+    for (int a = 0; a < scan; ++a) {
+        const int j = row[a];
+        if (j < 0 || j >= N)
+            break;
+        if (j == i)
+            continue;
+        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+        pbc<TRI>(b, dx, dy, dz);
+        pts[cnt][0] = dx; pts[cnt][1] = dy; pts[cnt][2] = dz;
+        ids[cnt++] = j;
+    }
+    int8_t order[ptmc::MAX_IN];
+    ptmc::order_neighbours(cnt, pts, order);
+    double env[ptmc::MAX_IN][3];
+    int numbers[ptmc::MAX_IN], atom_ids[ptmc::MAX_IN];
+    env[0][0] = env[0][1] = env[0][2] = 0;
+    numbers[0] = types ? types[i] : 0;
+    atom_ids[0] = (int)i;
+    for (int k = 0; k < cnt; ++k) {
+        const int p = order[k];
+        env[k + 1][0] = pts[p][0]; env[k + 1][1] = pts[p][1]; env[k + 1][2] = pts[p][2];
+        numbers[k + 1] = types ? types[ids[p]] : 0;
+        atom_ids[k + 1] = ids[p];
+    }
+    ptmc::Result r;
+    ptmc::index_atom(*tables, flags, cnt + 1, env, numbers, r);
+    int type = r.type, ordering = r.ordering;
+    if (r.rmsd > rmsd_threshold || type == ptmc::T_NONE) { // :287-291
+        type = 0;
+        ordering = 0;
+    }
+    double *o = output + i * ncol;
+    const double vals[8] = {(double)type, (double)ordering, r.rmsd, r.interatomic, r.q[0], r.q[1], r.q[2], r.q[3]};
+    for (int k = 0; k < ncol; ++k)
+        o[k] = k < 8 ? vals[k] : 0.0;
+    int *pi = ptm_indices + (int64_t)i * nind;
+    for (int k = 0; k < nind; ++k)
+        pi[k] = k < r.num_out ? atom_ids[r.mapping[k]] : -1;
+}
+
+// device copy of the tables, one per device, created on first use
+static int device_tables(const Tables **out)
+{
+    static std::mutex mu;
+    static const Tables *dev[64] = {nullptr};
+    static Tables *host = nullptr;
+    int d = 0;
+    MDH_HIP(hipGetDevice(&d));
+    std::lock_guard<std::mutex> lk(mu);
+    if (d < 0 || d >= 64) {
+        set_error("mdh_ptm: device ordinal out of range");
+        return MDH_ERR_HIP;
+    }
+    if (!dev[d]) {
+        if (!host) {
+            Tables *t = new Tables;
+            const std::string err = ptmc::tables_generate(*t);
+            if (!err.empty()) {
+                delete t;
+                set_error(err);
+                return MDH_ERR_ARG;
+            }
+            host = t;
+        }
+        void *p = nullptr;
+        MDH_HIP(hipMalloc(&p, sizeof(Tables)));
+        MDH_HIP(hipMemcpy(p, host, sizeof(Tables), hipMemcpyHostToDevice));
+        dev[d] = static_cast<const Tables *>(p);
+    }
+    *out = dev[d];
+    return MDH_OK;
+}
+
+// structure string -> PTM_CHECK_* flags, src/polyhedral_template_matching.cpp:168-206
+static int parse_structures(const char *s)
+{
+    static const char *names[] = {"fcc", "hcp", "bcc", "ico", "sc", "dcub", "dhex", "graphene", "all", "default"};
+    static const int bits[] = {ptmc::CHECK_FCC, ptmc::CHECK_HCP, ptmc::CHECK_BCC, ptmc::CHECK_ICO, ptmc::CHECK_SC,
+                               ptmc::CHECK_DCUB, ptmc::CHECK_DHEX, ptmc::CHECK_GRAPHENE, 255,
+                               ptmc::CHECK_FCC | ptmc::CHECK_HCP | ptmc::CHECK_BCC | ptmc::CHECK_ICO};
+    auto sep = [](char c) { return c == ' ' || c == ',' || c == '-' || c == '_' || c == '|'; };
+    int out = 0;
+    while (s && *s) {
+        if (sep(*s)) { ++s; continue; }
+        bool found = false;
+        for (int k = 0; k < 10 && !found; ++k) {
+            const size_t len = strlen(names[k]);
+            if (strncmp(s, names[k], len) == 0 && (s[len] == 0 || sep(s[len]))) {
+                out |= bits[k];
+                s += len;
+                found = true;
+            }
+        }
+        if (!found)
+            ++s;
+    }
+    return out ? out : (ptmc::CHECK_FCC | ptmc::CHECK_HCP | ptmc::CHECK_BCC | ptmc::CHECK_ICO);
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" int mdh_ptm_flags(const char *structure) { return parse_structures(structure); }
+
+extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, const double *z, int64_t N,
+                       const double *box9, const double *origin3, const int *boundary3, const int *verlet, int64_t M,
+                       const int *types, double rmsd_threshold, double *output, int ncol, int *ptm_indices, int nind,
+                       int space, void *stream)
+{
+    if (N < 0 || M < 0 || ncol < 8 || nind < 0) {
+        set_error("mdh_ptm: output needs >= 8 columns and the neighbour list a non-negative width");
+        return MDH_ERR_ARG;
+    }
+    if (N > 2147483647LL) {
+        set_error("mdh_ptm: atom ids are 32-bit (verlet_list is int32)");
+        return MDH_ERR_ARG;
+    }
+    const int flags = parse_structures(structure);
+    if (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) {
+        set_error("mdh_ptm: the two-shell structure types (dcub, dhex, graphene) are not built yet; "
+                  "request a combination of fcc, hcp, bcc, ico, sc");
+        return MDH_ERR_ARG;
+    }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    if (sc.failed())
+        return sc.error();
+    const Tables *dt = nullptr;
+    MDH_TRY(device_tables(&dt));
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const int *dtp = types ? sc.stage_in(types, (size_t)N, space) : nullptr;
+    double *dout = sc.stage(output, (size_t)N * (size_t)ncol, space, false, true);
+    int *dind = sc.stage(ptm_indices, (size_t)N * (size_t)nind, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    {
+        ProfRange pr("k_ptm", sc.stream());
+        if (b.tri)
+            hipLaunchKernelGGL(k_ptm<true>, dim3(grid_for(N, PTM_BLOCK)), dim3(PTM_BLOCK), 0, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dt,
+                               flags, rmsd_threshold, dout, ncol, dind, nind);
+        else
+            hipLaunchKernelGGL(k_ptm<false>, dim3(grid_for(N, PTM_BLOCK)), dim3(PTM_BLOCK), 0, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dt,
+                               flags, rmsd_threshold, dout, ncol, dind, nind);
+    }
+    return sc.finish(space);
+}

@@ -11,6 +11,7 @@
 #include <ptm_constants.h>
 #include <ptm_functions.h>
 #include <ptm_initialize_data.h>
+#include <ptm_quat.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -191,5 +192,61 @@ __attribute__((visibility("default"))) int ref_get_ptm(const char *structure, co
     ptm_uninitialize_local(lh);
     if (cached_out) std::memcpy(cached_out, cached.data(), sizeof(uint64_t) * (size_t)N);
     return 0;
+}
+
+// ---- read-only views of the reference's literal tables (used by tests to validate GENERATED tables) ----------
+static const ptm::refdata_t *ref_struct(int type)
+{
+    switch (type) {
+    case PTM_MATCH_FCC: return &ptm::structure_fcc;
+    case PTM_MATCH_HCP: return &ptm::structure_hcp;
+    case PTM_MATCH_BCC: return &ptm::structure_bcc;
+    case PTM_MATCH_ICO: return &ptm::structure_ico;
+    case PTM_MATCH_SC: return &ptm::structure_sc;
+    case PTM_MATCH_DCUB: return &ptm::structure_dcub;
+    case PTM_MATCH_DHEX: return &ptm::structure_dhex;
+    case PTM_MATCH_GRAPHENE: return &ptm::structure_graphene;
+    }
+    return nullptr;
+}
+// info[0..5] = num_nbrs, num_facets, max_degree, num_graphs, num_mappings, num_conventional_mappings
+__attribute__((visibility("default"))) int ref_ptm_struct_info(int type, int *info)
+{
+    ptm_initialize_global();
+    const ptm::refdata_t *s = ref_struct(type);
+    if (!s) return -1;
+    info[0] = s->num_nbrs; info[1] = s->num_facets; info[2] = s->max_degree; info[3] = s->num_graphs; info[4] = s->num_mappings;
+    info[5] = s->num_conventional_mappings;
+    return 0;
+}
+__attribute__((visibility("default"))) int ref_ptm_graphs(int type, uint64_t *hashes, int *nauts, int8_t *canon, int8_t *facets)
+{
+    ptm_initialize_global();
+    const ptm::refdata_t *s = ref_struct(type);
+    if (!s) return -1;
+    for (int g = 0; g < s->num_graphs; ++g) {
+        hashes[g] = s->graphs[g].hash;
+        nauts[g] = s->graphs[g].num_automorphisms;
+        std::memcpy(canon + g * PTM_MAX_POINTS, s->graphs[g].canonical_labelling, PTM_MAX_POINTS);
+        std::memcpy(facets + g * PTM_MAX_FACETS * 3, s->graphs[g].facets, PTM_MAX_FACETS * 3);
+    }
+    return 0;
+}
+// which: 0 = mapping (num_mappings rows), 1 = mapping_conventional; quats: qconventional rows (may be NULL)
+__attribute__((visibility("default"))) int ref_ptm_symmetry(int type, int which, int8_t *maps, double *quats, double *points)
+{
+    const ptm::refdata_t *s = ref_struct(type);
+    if (!s) return -1;
+    const int n = (which && s->num_conventional_mappings) ? s->num_conventional_mappings : s->num_mappings;
+    const int8_t (*m)[PTM_MAX_POINTS] = which ? s->mapping_conventional : s->mapping;
+    for (int i = 0; i < n; ++i) std::memcpy(maps + i * PTM_MAX_POINTS, m[i], PTM_MAX_POINTS);
+    if (quats && which) { // the generator list map_quaternion_onto_target pairs with mapping_conventional (ptm_map_templates.cpp:21-68)
+        const double (*g)[4] = s->qconventional;
+        if (type == PTM_MATCH_SC || type == PTM_MATCH_FCC || type == PTM_MATCH_BCC || type == PTM_MATCH_DCUB) g = ptm::generator_cubic;
+        if (type == PTM_MATCH_ICO) g = ptm::generator_icosahedral;
+        if (g) std::memcpy(quats, g, sizeof(double) * 4 * n);
+    }
+    if (points) std::memcpy(points, s->points[0], sizeof(double) * 3 * PTM_MAX_POINTS);
+    return n;
 }
 }

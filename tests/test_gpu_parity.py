@@ -393,3 +393,69 @@ def test_system_flow_perfect_crystals_and_errors():
     with pytest.raises(RuntimeError, match="volume of the box is zero"):
         x = np.zeros(4); v = np.full((4, 2), -1, np.int32); dd = np.zeros((4, 2)); nn = np.zeros(4, np.int32)
         _neighbor.build_neighbor(x, x, x, np.array([[1.0, 1, 0], [2, 2, 0], [0, 0, 1]]), ORG0, PBC, 1.0, v, dd, nn, 1)
+
+
+# ------------------------------------------------------------------ PTM (a13): HIP kernel vs oracle/_ref, the reference's own library
+from _ptm_cases import compare_ptm, ptm_cases
+from mdapy_amd import _ptm
+
+PTM_CASES = ptm_cases()
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/libptm_ref.so missing")
+
+
+@needs_ref
+@pytest.mark.parametrize("case", PTM_CASES, ids=[c[0] for c in PTM_CASES])
+def test_ptm_vs_reference_library(case):
+    name, pos, box, boundary, structure, types, thr = case
+    N = len(pos)
+    x, y, z = _xyz(pos)
+    bd = np.array(boundary, np.int32)
+    k = min(18, N - 1)
+    idx, dist = np.zeros((N, k), np.int32), np.zeros((N, k))
+    O.knn(x, y, z, box, ORG0, bd, k, idx, dist, 4)
+    out_r, ind_r = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
+    O.get_ptm(structure, x, y, z, box, ORG0, bd, idx, types, thr, out_r, ind_r)
+    out_g, ind_g = np.full((N, 8), 7.0), np.full((N, 18), 7, np.int32)
+    _ptm.get_ptm(structure, x, y, z, box, ORG0, bd, idx, types, thr, out_g, ind_g)
+    compare_ptm(out_g, ind_g, out_r, ind_r)
+
+
+PTM_PATHS = fixtures_with("ptm")
+
+
+# reference: tests/test_polyhedral_template_matching.py:21-31
+@pytest.mark.parametrize("path", PTM_PATHS, ids=ids_of(PTM_PATHS))
+def test_golden_ptm(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_polyhedral_template_matching()
+    assert np.array_equal(s.data["ptm"].to_numpy(), d["ptm"])
+
+
+def test_ptm_system_flow_and_errors():
+    fcc = mp.build_crystal("Al", "fcc", 4.05, nx=4, ny=4, nz=4)
+    fcc.cal_polyhedral_template_matching(return_rmsd=True, return_atomic_distance=True, return_orientation=True)
+    assert np.all(fcc.data["ptm"].to_numpy() == 1)
+    assert np.allclose(fcc.data["interatomic_distance"].to_numpy(), 4.05 / 2 ** 0.5, rtol=1e-9)
+    assert np.allclose(np.abs(fcc.data["qw"].to_numpy()), 1.0, atol=1e-6)
+    bcc = mp.build_crystal("Fe", "bcc", 2.86, nx=4, ny=4, nz=4)
+    bcc.cal_polyhedral_template_matching()
+    assert np.all(bcc.data["ptm"].to_numpy() == 3)
+    hcp = mp.build_crystal("Mg", "hcp", 3.21, nx=4, ny=4, nz=3)
+    hcp.cal_polyhedral_template_matching()
+    assert np.all(hcp.data["ptm"].to_numpy() == 2)
+    with pytest.raises(ValueError):  # two-shell types: refused loudly, never silently skipped
+        fcc.cal_polyhedral_template_matching(structure="all")
+    # device-resident call: same answer with HBM-resident inputs
+    import torch
+    pos, box = _fcc(6, 0.05, 4)
+    x, y, z = _xyz(pos)
+    idx, dist = np.zeros((len(pos), 18), np.int32), np.zeros((len(pos), 18))
+    O.knn(x, y, z, box, ORG0, PBC, 18, idx, dist, 4)
+    out_h, ind_h = np.zeros((len(pos), 8)), np.zeros((len(pos), 18), np.int32)
+    _ptm.get_ptm("default", x, y, z, box, ORG0, PBC, idx, None, 0.1, out_h, ind_h)
+    dev = [torch.from_numpy(a).cuda() for a in (x, y, z, idx)]
+    out_d = torch.zeros((len(pos), 8), dtype=torch.float64, device="cuda")
+    ind_d = torch.zeros((len(pos), 18), dtype=torch.int32, device="cuda")
+    _ptm.get_ptm("default", dev[0], dev[1], dev[2], box, ORG0, PBC, dev[3], None, 0.1, out_d, ind_d)
+    assert np.array_equal(out_d.cpu().numpy(), out_h) and np.array_equal(ind_d.cpu().numpy(), ind_h)

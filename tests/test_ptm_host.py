@@ -1,0 +1,110 @@
+"""CPU checks of the PTM product sources (mdapy_amd/csrc/ptm_core.hpp + ptm_tables.hpp) compiled for the host by
+tests/native/ptm_host.cpp, against oracle/_ref (the reference's own PTM library):
+  * every GENERATED table equals the reference's literal one as a set (graph hashes + automorphism counts,
+    symmetry permutations paired with their generator quaternions, template coordinates);
+  * the per-atom algorithm gives the reference's outputs on seeded crystals, alloys, surfaces and gases.
+The GPU build of the same sources is checked in test_gpu_parity.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _ptm_cases import compare_ptm, ptm_cases
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "native", "_build", "libptm_host.so")
+pytestmark = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/libptm_ref.so not built (needs /root/reference)")
+P = 17
+TYPES = {"sc": 5, "fcc": 1, "hcp": 2, "ico": 4, "bcc": 3}
+BITS = {"fcc": 1, "hcp": 2, "bcc": 4, "ico": 8, "sc": 16}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def host():
+    src = os.path.join(HERE, "native", "ptm_host.cpp")
+    hdrs = [os.path.join(HERE, "..", "mdapy_amd", "csrc", h) for h in ("ptm_core.hpp", "ptm_tables.hpp")]
+    if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
+        os.makedirs(os.path.dirname(SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, src])
+    lib = C.CDLL(SO)
+    lib.ptmh_init.restype = C.c_char_p
+    assert lib.ptmh_init() == b""
+    return lib
+
+
+def _flags(structure):
+    f = 0
+    for tok in structure.replace("default", "fcc-hcp-bcc-ico").replace(",", "-").split("-"):
+        f |= BITS[tok]
+    return f
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_generated_tables_equal_reference_tables(host, name):
+    t, R = TYPES[name], O.ref_lib()
+    info, mine = np.zeros(6, np.int32), np.zeros(6, np.int32)
+    assert R.ref_ptm_struct_info(t, _ptr(info)) == 0
+    host.ptmh_type_info(t, _ptr(mine))
+    nn, nf, maxdeg, ng, nmap, nconv = (int(v) for v in info)
+    assert (mine[0], mine[1], mine[2], mine[3]) == (nn, nf, ng, nmap)
+    # graph classes: same multiset of (hash, number of automorphisms)
+    h, na = np.zeros(ng, np.uint64), np.zeros(ng, np.int32)
+    R.ref_ptm_graphs(t, _ptr(h), _ptr(na), _ptr(np.zeros((ng, P), np.int8)), _ptr(np.zeros((ng, 84), np.int8)))
+    mh, mna = np.zeros(ng, np.uint64), np.zeros(ng, np.int32)
+    host.ptmh_graph_hashes(t, _ptr(mh), _ptr(mna))
+    assert sorted(zip(h.tolist(), na.tolist())) == sorted(zip(mh.tolist(), mna.tolist()))
+    # templates and symmetry tables
+    npnt = nn + 1
+    for which in (0, 1):
+        n = nmap if (which == 0 or nconv == 0) else nconv
+        maps, q, pts = np.zeros((n, P), np.int8), np.zeros((n, 4)), np.zeros((P, 3))
+        assert R.ref_ptm_symmetry(t, which, _ptr(maps), _ptr(q), _ptr(pts)) == n
+        mp_ = np.zeros((int(mine[3] if which == 0 else mine[4]), P), np.int8)
+        host.ptmh_mappings(t, which, _ptr(mp_))
+        tp = np.zeros((P, 3))
+        host.ptmh_template(t, _ptr(tp))
+        assert np.abs(tp - pts).max() < 1e-15
+        assert len(mp_) == n
+        if which == 0:
+            assert set(map(tuple, maps[:, :npnt].tolist())) == set(map(tuple, mp_[:, :npnt].tolist()))
+        else:  # the remap pairs generator i with permutation i: compare the PAIRS (quaternion up to sign)
+            g = np.zeros((n, 4))
+            host.ptmh_generators(t, _ptr(g))
+
+            def key(qq, m):
+                qq = np.array(qq)
+                lead = qq[np.flatnonzero(np.abs(qq) > 1e-9)[0]]
+                qq = np.round(qq * np.sign(lead), 9) + 0.0
+                return tuple(qq.tolist()) + tuple(m)
+
+            assert {key(q[i], maps[i, :npnt].tolist()) for i in range(n)} == {key(g[i], mp_[i, :npnt].tolist()) for i in range(n)}
+
+
+CASES = ptm_cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_host_build_matches_reference_library(host, case):
+    name, pos, box, boundary, structure, types, thr = case
+    N = len(pos)
+    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+    bd, origin = np.array(boundary, np.int32), np.zeros(3)
+    k = min(18, N - 1)
+    idx, dist = np.zeros((N, k), np.int32), np.zeros((N, k))
+    O.knn(x, y, z, box, origin, bd, k, idx, dist, 4)
+    out_r, ind_r = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
+    O.get_ptm(structure, x, y, z, box, origin, bd, idx, types, thr, out_r, ind_r)
+    out_m, ind_m = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
+    b9 = np.ascontiguousarray(box, dtype=np.float64).reshape(9)
+    assert host.ptmh_run(_ptr(x), _ptr(y), _ptr(z), C.c_int64(N), _ptr(b9), _ptr(bd), _ptr(idx), C.c_int64(k), _ptr(types),
+                         _flags(structure), C.c_double(thr), _ptr(out_m), _ptr(ind_m), None) == 0
+    compare_ptm(out_m, ind_m, out_r, ind_r)
+    if name in ("fcc_L12", "fcc_L12_au", "fcc_L10", "bcc_B2"):  # the alloy branches are really exercised
+        assert set(np.unique(out_r[:, 1]).tolist()) - {0.0, 1.0}
