@@ -1,11 +1,12 @@
-// ptm.hip — polyhedral template matching on gfx950 (SC / FCC / HCP / ICO / BCC).
+// ptm.hip — polyhedral template matching on gfx950 (SC, FCC, HCP, ICO, BCC, DCUB, DHEX, graphene).
 //
 // Replaces src/polyhedral_template_matching.cpp:135-318 (get_ptm) together with the part of extern/ptm it drives
 // (ptm_preorder_neighbours + ptm_index, see ptm_core.hpp for the per-function map).  The reference runs two
 // passes — a serial pre-ordering of every atom's 18 nearest neighbours by Voronoi-face solid angle (:215-255)
-// and the OpenMP matching pass (:258-318).  Both depend on the atom's own neighbour row only, so here they are
-// one kernel: a thread gathers its row, folds the separations (bit-identical minimum image, common.hpp), orders
-// them, matches the templates and writes the (N,8) result row and the (N,18) matched-neighbour row.
+// and the OpenMP matching pass (:258-318) — and so do the kernels: k_ptm_order (a thread gathers its row, folds
+// the separations with the bit-identical minimum image of common.hpp, orders them, stores 18 bytes) and
+// k_ptm_index (templates, (N,8) result row, (N,18) matched-neighbour row).  The split is needed because the
+// diamond and graphene templates use the ordered rows of the atom's nearest neighbours as well.
 //
 // Work per atom is ~1e5 f64 operations on ~4 KB of private state, no HBM traffic to speak of besides the row
 // gather (18 x 28 B) and 136 B of output: the kernel is bound by VALU issue / scratch latency, not HBM.  The
@@ -20,49 +21,58 @@ using ptmc::Tables;
 
 static constexpr int PTM_BLOCK = 64;
 
+template <bool TRI> struct DevFold {
+    const DBox &b;
+    __device__ __forceinline__ void operator()(double &dx, double &dy, double &dz) const { pbc<TRI>(b, dx, dy, dz); }
+};
+
+// pass 1 (src/polyhedral_template_matching.cpp:215-255): the Voronoi order of every atom's row, 18 bytes per atom
 template <bool TRI>
-__global__ __launch_bounds__(PTM_BLOCK) void k_ptm(const double *__restrict__ x, const double *__restrict__ y,
-                                                   const double *__restrict__ z, int64_t N, DBox b,
-                                                   const int *__restrict__ verlet, int64_t M,
-                                                   const int *__restrict__ types, const Tables *__restrict__ tables,
-                                                   int flags, double rmsd_threshold, double *__restrict__ output,
-                                                   int ncol, int *__restrict__ ptm_indices, int nind)
+__global__ __launch_bounds__(PTM_BLOCK) void k_ptm_order(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, int64_t N, DBox b,
+                                                         const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    const int *row = verlet + i * M;
-    const double xi = x[i], yi = y[i], zi = z[i];
-    double pts[ptmc::MAX_IN][3];
-    int ids[ptmc::MAX_IN];
-    int cnt = 0;
-    const int scan = M < 18 ? (int)M : 18; // get_neighbours, :60-66
-    for (int a = 0; a < scan; ++a) {
-        const int j = row[a];
-        if (j < 0 || j >= N)
-            break;
-        if (j == i)
-            continue;
-        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
-        pbc<TRI>(b, dx, dy, dz);
-        pts[cnt][0] = dx; pts[cnt][1] = dy; pts[cnt][2] = dz;
-        ids[cnt++] = j;
+    const DevFold<TRI> fold{b};
+    ptmc::Env env;
+    ptmc::build_env(x, y, z, N, verlet + i * M, (int)M, nullptr, (int)i, fold, nullptr, env);
+    int8_t *o = orders + i * 18;
+    for (int k = 0; k < 18; ++k)
+        o[k] = k + 1 < env.num ? (int8_t)(env.corr[k + 1] - 1) : (int8_t)-1;
+}
+
+template <bool TRI> struct DevSrc {
+    const double *x, *y, *z;
+    int64_t N, M;
+    const int *verlet, *types;
+    const int8_t *orders;
+    const DBox &b;
+    __device__ void get(int atom, ptmc::Env &env)
+    {
+        const DevFold<TRI> fold{b};
+        ptmc::build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, fold, orders + (int64_t)atom * 18, env);
     }
-    int8_t order[ptmc::MAX_IN];
-    ptmc::order_neighbours(cnt, pts, order);
-    double env[ptmc::MAX_IN][3];
-    int numbers[ptmc::MAX_IN], atom_ids[ptmc::MAX_IN];
-    env[0][0] = env[0][1] = env[0][2] = 0;
-    numbers[0] = types ? types[i] : 0;
-    atom_ids[0] = (int)i;
-    for (int k = 0; k < cnt; ++k) {
-        const int p = order[k];
-        env[k + 1][0] = pts[p][0]; env[k + 1][1] = pts[p][1]; env[k + 1][2] = pts[p][2];
-        numbers[k + 1] = types ? types[ids[p]] : 0;
-        atom_ids[k + 1] = ids[p];
-    }
+};
+
+// pass 2 (:258-318): match the templates, write the result row and the matched-neighbour row.  SHELL = diamond /
+// graphene stages compiled in (9 KB more private memory per lane; the common fcc-hcp-bcc call does without)
+template <bool TRI, bool SHELL>
+__global__ __launch_bounds__(PTM_BLOCK) void k_ptm_index(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ z, int64_t N, DBox b,
+                                                         const int *__restrict__ verlet, int64_t M,
+                                                         const int *__restrict__ types, const int8_t *__restrict__ orders,
+                                                         const Tables *__restrict__ tables, int flags, double rmsd_threshold,
+                                                         double *__restrict__ output, int ncol, int *__restrict__ ptm_indices,
+                                                         int nind)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    DevSrc<TRI> src{x, y, z, N, M, verlet, types, orders, b};
     ptmc::Result r;
-    ptmc::index_atom(*tables, flags, cnt + 1, env, numbers, r);
+    ptmc::index_atom<SHELL>(*tables, flags, src, (int)i, r);
     int type = r.type, ordering = r.ordering;
     if (r.rmsd > rmsd_threshold || type == ptmc::T_NONE) { // :287-291
         type = 0;
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(PTM_BLOCK) void k_ptm(const double *__restrict__ x,
         o[k] = k < 8 ? vals[k] : 0.0;
     int *pi = ptm_indices + (int64_t)i * nind;
     for (int k = 0; k < nind; ++k)
-        pi[k] = k < r.num_out ? atom_ids[r.mapping[k]] : -1;
+        pi[k] = k < r.num_out && k < ptmc::MAX_PTS ? r.ids[k] : -1;
 }
 
 // device copy of the tables, one per device, created on first use
@@ -156,11 +166,6 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
         return MDH_ERR_ARG;
     }
     const int flags = parse_structures(structure);
-    if (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) {
-        set_error("mdh_ptm: the two-shell structure types (dcub, dhex, graphene) are not built yet; "
-                  "request a combination of fcc, hcp, bcc, ico, sc");
-        return MDH_ERR_ARG;
-    }
     DBox b;
     MDH_TRY(make_box(b, box9, origin3, boundary3));
     if (N == 0)
@@ -177,14 +182,28 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     int *dind = sc.stage(ptm_indices, (size_t)N * (size_t)nind, space, false, true);
     if (sc.failed())
         return sc.error();
+    int8_t *dord = sc.alloc_n<int8_t>((size_t)N * 18);
+    if (sc.failed())
+        return sc.error();
+    const dim3 grid(grid_for(N, PTM_BLOCK)), block(PTM_BLOCK);
     {
-        ProfRange pr("k_ptm", sc.stream());
+        ProfRange pr("k_ptm_order", sc.stream());
         if (b.tri)
-            hipLaunchKernelGGL(k_ptm<true>, dim3(grid_for(N, PTM_BLOCK)), dim3(PTM_BLOCK), 0, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dt,
-                               flags, rmsd_threshold, dout, ncol, dind, nind);
+            hipLaunchKernelGGL(k_ptm_order<true>, grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
         else
-            hipLaunchKernelGGL(k_ptm<false>, dim3(grid_for(N, PTM_BLOCK)), dim3(PTM_BLOCK), 0, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dt,
-                               flags, rmsd_threshold, dout, ncol, dind, nind);
+            hipLaunchKernelGGL(k_ptm_order<false>, grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
+    }
+    {
+        ProfRange pr("k_ptm_index", sc.stream());
+        const bool shell = (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) != 0;
+#define MDH_PTM_LAUNCH(TRI, SHELL)                                                                                              \
+    hipLaunchKernelGGL((k_ptm_index<TRI, SHELL>), grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dord, dt, flags,   \
+                       rmsd_threshold, dout, ncol, dind, nind)
+        if (b.tri && shell) MDH_PTM_LAUNCH(true, true);
+        else if (b.tri) MDH_PTM_LAUNCH(true, false);
+        else if (shell) MDH_PTM_LAUNCH(false, true);
+        else MDH_PTM_LAUNCH(false, false);
+#undef MDH_PTM_LAUNCH
     }
     return sc.finish(space);
 }

@@ -25,7 +25,7 @@ namespace ptmc {
 
 struct TemplateDef {
     int type, num_nbrs, max_degree, num_variants;
-    double pts[2][MAX_PTS][3];
+    double pts[4][MAX_PTS][3];
 };
 
 inline void tables_fill_templates(std::vector<TemplateDef> &defs)
@@ -80,6 +80,55 @@ inline void tables_fill_templates(std::vector<TemplateDef> &defs)
             put(d, 0, 9 + 2 * a, p[0], p[1], p[2]);
             put(d, 0, 10 + 2 * a, m[0], m[1], m[2]);
         }
+        defs.push_back(d);
+    }
+    { // diamond cubic: 4 x <111>*u then, per inner atom, its three further bonds = 12 x <220>*u; variant 1 = the other sublattice
+        TemplateDef d{};
+        d.type = T_DCUB; d.num_nbrs = 16; d.max_degree = 8; d.num_variants = 2;
+        const double u = 4 / (s3 + 6 * std::sqrt(2.0));
+        const int in0[4][3] = {{1, 1, 1}, {1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}};
+        const int out0[12][3] = {{2, 2, 0}, {0, 2, 2}, {2, 0, 2}, {0, -2, -2}, {2, -2, 0}, {2, 0, -2},
+                                 {-2, -2, 0}, {0, -2, 2}, {-2, 0, 2}, {-2, 0, -2}, {-2, 2, 0}, {0, 2, -2}};
+        const int in1[4][3] = {{1, -1, 1}, {1, 1, -1}, {-1, -1, -1}, {-1, 1, 1}};
+        const int out1[12][3] = {{2, 0, 2}, {0, -2, 2}, {2, -2, 0}, {0, 2, -2}, {2, 0, -2}, {2, 2, 0},
+                                 {-2, 0, -2}, {0, -2, -2}, {-2, -2, 0}, {-2, 2, 0}, {-2, 0, 2}, {0, 2, 2}};
+        for (int i = 0; i < 4; ++i) { put(d, 0, 1 + i, in0[i][0] * u, in0[i][1] * u, in0[i][2] * u); put(d, 1, 1 + i, in1[i][0] * u, in1[i][1] * u, in1[i][2] * u); }
+        for (int i = 0; i < 12; ++i) { put(d, 0, 5 + i, out0[i][0] * u, out0[i][1] * u, out0[i][2] * u); put(d, 1, 5 + i, out1[i][0] * u, out1[i][1] * u, out1[i][2] * u); }
+        defs.push_back(d);
+    }
+    { // diamond hexagonal (lonsdaleite), c along z: bond length L, three bonds at z = -/+ L/3, one along +/- z.
+      // Coordinates in units (a, b, c, e, f) = (L sqrt(2/3), L sqrt(2)/3, L/3, L, 4L/3): x multiples of a, y of b, z of c|e|f.
+        TemplateDef d{};
+        d.type = T_DHEX; d.num_nbrs = 16; d.max_degree = 8; d.num_variants = 4;
+        const double L = 16 / (4 + 12 * std::sqrt(8.0 / 3.0));
+        const double a = L * std::sqrt(2.0 / 3.0), b = L * std::sqrt(2.0) / 3, c = L / 3, f = 4 * L / 3;
+        // each row: x/a, y/b, z-code (0: 0, 1: c, 2: L, 3: f; sign carried by the code's sign)
+        static const int tab[4][16][3] = {
+            {{-1, 1, -1}, {0, -2, -1}, {1, 1, -1}, {0, 0, 2}, {-2, 0, 0}, {-1, 1, -3}, {-1, 3, 0}, {1, -3, 0}, {0, -2, -3}, {-1, -3, 0},
+             {1, 1, -3}, {1, 3, 0}, {2, 0, 0}, {0, -2, 3}, {1, 1, 3}, {-1, 1, 3}},
+            {{-1, -1, -1}, {1, -1, -1}, {0, 2, -1}, {0, 0, 2}, {-1, -3, 0}, {-1, -1, -3}, {-2, 0, 0}, {2, 0, 0}, {1, -1, -3}, {1, -3, 0},
+             {0, 2, -3}, {-1, 3, 0}, {1, 3, 0}, {1, -1, 3}, {0, 2, 3}, {-1, -1, 3}},
+            {{0, -2, 1}, {-1, 1, 1}, {1, 1, 1}, {0, 0, -2}, {-1, -3, 0}, {0, -2, 3}, {1, -3, 0}, {-1, 3, 0}, {-1, 1, 3}, {-2, 0, 0},
+             {1, 1, 3}, {2, 0, 0}, {1, 3, 0}, {-1, 1, -3}, {1, 1, -3}, {0, -2, -3}},
+            {{1, -1, 1}, {-1, -1, 1}, {0, 2, 1}, {0, 0, -2}, {1, -3, 0}, {1, -1, 3}, {2, 0, 0}, {-2, 0, 0}, {-1, -1, 3}, {-1, -3, 0},
+             {0, 2, 3}, {1, 3, 0}, {-1, 3, 0}, {-1, -1, -3}, {0, 2, -3}, {1, -1, -3}}};
+        for (int v = 0; v < 4; ++v)
+            for (int i = 0; i < 16; ++i) {
+                const int zc = tab[v][i][2];
+                const double zz = (zc < 0 ? -1 : 1) * (std::abs(zc) == 1 ? c : std::abs(zc) == 2 ? L : std::abs(zc) == 3 ? f : 0.0);
+                put(d, v, 1 + i, tab[v][i][0] * a, tab[v][i][1] * b, zz);
+            }
+        defs.push_back(d);
+    }
+    { // graphene, in the xy plane: three bonds of length L, then the two further bonds of each
+        TemplateDef d{};
+        d.type = T_GRAPHENE; d.num_nbrs = 9; d.max_degree = -1; d.num_variants = 2;
+        const double L = 3 / (1 + 2 * s3), hx = L * s3 / 2, hy = L / 2;
+        // x in units of hx, y in units of hy
+        static const int tab[2][9][2] = {{{0, 2}, {1, -1}, {-1, -1}, {-1, 3}, {1, 3}, {2, 0}, {1, -3}, {-1, -3}, {-2, 0}},
+                                         {{-1, 1}, {1, 1}, {0, -2}, {-2, 0}, {-1, 3}, {1, 3}, {2, 0}, {1, -3}, {-1, -3}}};
+        for (int v = 0; v < 2; ++v)
+            for (int i = 0; i < 9; ++i) put(d, v, 1 + i, tab[v][i][0] * hx, tab[v][i][1] * hy, 0.0);
         defs.push_back(d);
     }
 }
@@ -140,11 +189,10 @@ inline void orient_facet(const double (*p)[3], int a, int b, int c, int8_t *out)
 
 // all traversals reproducing the best code -> automorphisms (as template-index permutations, aut[0] = 0)
 inline void graph_automorphisms(int nf, const int8_t (*f)[3], int nn, const int8_t *best_code, const int8_t *canon,
-                                std::vector<std::array<int8_t, MAX_PTS>> &auts)
+                                const int8_t *colours, std::vector<std::array<int8_t, MAX_PTS>> &auts)
 {
     auts.clear();
     const int ne = 3 * nf / 2;
-    int8_t colours[MAX_PTS] = {0};
     std::set<std::array<int8_t, MAX_PTS>> uniq;
     for (int i = 0; i < nf; ++i)
         for (int e = 0; e < 3; ++e) {
@@ -298,8 +346,23 @@ inline std::string tables_generate(Tables &T)
             std::memcpy(T.gens[T.num_gens++], o.g, sizeof(o.g));
         }
         // --- graph classes ------------------------------------------------------------------------------
+        if (d.type == T_GRAPHENE) { // matched by direct trial (match_graphene), no graphs
+            ti.num_facets = 0;
+            ti.graph_begin = T.num_graphs;
+            ti.num_graphs = 0;
+            continue;
+        }
+        // diamond types: the graph is the hull of the 12 outer atoms in which the facet spanned by an inner atom's three
+        // outer atoms is replaced by the three facets through that inner atom (what match_dcub_dhex builds); inner
+        // atoms carry colour 1
+        const bool two_shell = d.type == T_DCUB || d.type == T_DHEX;
+        const int first = two_shell ? 4 : 0; // neighbour index of the first hull vertex
+        int8_t colours[MAX_PTS] = {0};
+        if (two_shell) colours[0] = colours[1] = colours[2] = colours[3] = 1;
         std::vector<Face> faces;
-        template_faces(nn, d.pts[0] + 1, faces);
+        template_faces(nn - first, d.pts[0] + 1 + first, faces);
+        for (Face &fc : faces)
+            for (int &v : fc.v) v += first;
         std::vector<int> quads;
         int ntri = 0;
         for (size_t i = 0; i < faces.size(); ++i) {
@@ -307,6 +370,7 @@ inline std::string tables_generate(Tables &T)
             else if (faces[i].v.size() != 3) return "ptm tables: template face is neither triangle nor quadrilateral";
             ntri += (int)faces[i].v.size() - 2;
         }
+        if (two_shell) ntri += 8; // four facets become twelve
         ti.num_facets = ntri;
         if (ntri > MAX_FACETS || quads.size() > 20) return "ptm tables: template too large";
         ti.graph_begin = T.num_graphs;
@@ -331,7 +395,17 @@ inline std::string tables_generate(Tables &T)
             for (size_t i = 0; i < faces.size(); ++i) {
                 const std::vector<int> &v = faces[i].v;
                 if (v.size() == 3) {
-                    orient_facet(d.pts[0] + 1, v[0], v[1], v[2], f[nf++]);
+                    int8_t t[3];
+                    orient_facet(d.pts[0] + 1, v[0], v[1], v[2], t);
+                    const int i0 = (t[0] - 4) / 3, i1 = (t[1] - 4) / 3, i2 = (t[2] - 4) / 3;
+                    if (two_shell && i0 == i1 && i0 == i2) {
+                        const int8_t in = (int8_t)i0;
+                        const int8_t add[3][3] = {{in, t[1], t[2]}, {t[0], in, t[2]}, {t[0], t[1], in}};
+                        for (int q = 0; q < 3; ++q) { f[nf][0] = add[q][0]; f[nf][1] = add[q][1]; f[nf][2] = add[q][2]; ++nf; }
+                    } else {
+                        f[nf][0] = t[0]; f[nf][1] = t[1]; f[nf][2] = t[2];
+                        ++nf;
+                    }
                 } else {
                     const bool alt = (mask >> qi++) & 1;
                     if (!alt) { orient_facet(d.pts[0] + 1, v[0], v[1], v[2], f[nf]); ++nf; orient_facet(d.pts[0] + 1, v[0], v[2], v[3], f[nf]); ++nf; }
@@ -340,7 +414,7 @@ inline std::string tables_generate(Tables &T)
             }
             if (seen_orbits.count(normalised(nf, f, nullptr))) continue;
             for (const SymOp &o : self) seen_orbits.insert(normalised(nf, f, o.perm.data()));
-            int8_t deg[MAX_NBR], colours[MAX_PTS] = {0};
+            int8_t deg[MAX_NBR];
             if (graph_degree(nf, f, nn, deg) > d.max_degree) continue;
             Canon C;
             uint64_t hash = 0;
@@ -350,7 +424,7 @@ inline std::string tables_generate(Tables &T)
             g.hash = hash;
             std::memcpy(g.canon, C.label, MAX_PTS);
             std::vector<std::array<int8_t, MAX_PTS>> auts;
-            graph_automorphisms(nf, f, nn, C.best, C.label, auts);
+            graph_automorphisms(nf, f, nn, C.best, C.label, colours, auts);
             { // automorphisms that differ by a rotation of the template give the same rmsd: keep one per coset
                 std::set<std::array<int8_t, MAX_PTS>> kept;
                 std::vector<std::array<int8_t, MAX_PTS>> out;

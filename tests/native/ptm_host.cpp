@@ -54,72 +54,79 @@ void ptmh_template(int type, double *out)
 }
 
 // both passes on the host.  box9 row-major cell vectors; only orthogonal/triclinic minimum image as box.h does.
+namespace {
+struct HostFold {
+    bool tri;
+    const double *h;
+    double hi[9];
+    int pbc[3];
+    void operator()(double &dx, double &dy, double &dz) const
+    {
+        if (tri) {
+            double fx = dx * hi[0] + dy * hi[3] + dz * hi[6], fy = dx * hi[1] + dy * hi[4] + dz * hi[7], fz = dx * hi[2] + dy * hi[5] + dz * hi[8];
+            if (pbc[0]) fx -= std::floor(fx + 0.5);
+            if (pbc[1]) fy -= std::floor(fy + 0.5);
+            if (pbc[2]) fz -= std::floor(fz + 0.5);
+            dx = fx * h[0] + fy * h[3] + fz * h[6];
+            dy = fx * h[1] + fy * h[4] + fz * h[7];
+            dz = fx * h[2] + fy * h[5] + fz * h[8];
+        } else {
+            if (pbc[0]) dx -= h[0] * std::floor(dx / h[0] + 0.5);
+            if (pbc[1]) dy -= h[4] * std::floor(dy / h[4] + 0.5);
+            if (pbc[2]) dz -= h[8] * std::floor(dz / h[8] + 0.5);
+        }
+    }
+};
+struct HostSrc {
+    const double *x, *y, *z;
+    int64_t N, M;
+    const int *verlet, *types;
+    const HostFold *fold;
+    const int8_t *orders; // (N,18) from pass 1
+    void get(int atom, Env &env) { build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, *fold, orders + (int64_t)atom * 18, env); }
+};
+} // namespace
+
 int ptmh_run(const double *x, const double *y, const double *z, int64_t N, const double *box9, const int *boundary, const int *verlet,
              int64_t M, const int *types, int flags, double rmsd_threshold, double *output, int *ptm_indices, int8_t *order_out)
 {
     if (!g_ready) return -1;
-    bool tri = false;
-    for (int i = 0; i < 3; ++i)
+    HostFold fold;
+    fold.tri = false;
+    fold.h = box9;
+    for (int i = 0; i < 3; ++i) {
+        fold.pbc[i] = boundary[i];
         for (int j = 0; j < 3; ++j)
-            if (i != j && std::fabs(box9[i * 3 + j]) > 1e-10) tri = true;
-    double hi[9] = {0};
-    if (tri) {
+            if (i != j && std::fabs(box9[i * 3 + j]) > 1e-10) fold.tri = true;
+    }
+    std::memset(fold.hi, 0, sizeof(fold.hi));
+    if (fold.tri) {
         const double *m = box9;
+        double *hi = fold.hi;
         const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
         const double id = 1.0 / det;
         hi[0] = (m[4] * m[8] - m[5] * m[7]) * id;  hi[1] = -(m[1] * m[8] - m[2] * m[7]) * id; hi[2] = (m[1] * m[5] - m[2] * m[4]) * id;
         hi[3] = -(m[3] * m[8] - m[5] * m[6]) * id; hi[4] = (m[0] * m[8] - m[2] * m[6]) * id;  hi[5] = -(m[0] * m[5] - m[2] * m[3]) * id;
         hi[6] = (m[3] * m[7] - m[4] * m[6]) * id;  hi[7] = -(m[0] * m[7] - m[1] * m[6]) * id; hi[8] = (m[0] * m[4] - m[1] * m[3]) * id;
     }
+    std::vector<int8_t> orders((size_t)N * 18, (int8_t)-1);
+    for (int64_t i = 0; i < N; ++i) { // pass 1: the Voronoi order of every atom's row
+        Env env;
+        int8_t *orow = orders.data() + i * 18;
+        build_env(x, y, z, N, verlet + i * M, (int)M, types, (int)i, fold, nullptr, env);
+        for (int k = 1; k < env.num; ++k) orow[k - 1] = (int8_t)(env.corr[k] - 1);
+    }
+    if (order_out) std::memcpy(order_out, orders.data(), orders.size());
+    HostSrc src{x, y, z, N, M, verlet, types, &fold, orders.data()};
     for (int64_t i = 0; i < N; ++i) {
-        const int *row = verlet + i * M;
-        double pts[MAX_IN][3];
-        int ids[MAX_IN];
-        int cnt = 0;
-        for (int j = 0; j < (int)M && j < 18; ++j) {
-            const int k = row[j];
-            if (k < 0 || k >= N) break;
-            if (k == i) continue;
-            double dx = x[k] - x[i], dy = y[k] - y[i], dz = z[k] - z[i];
-            if (tri) {
-                double fx = dx * hi[0] + dy * hi[3] + dz * hi[6], fy = dx * hi[1] + dy * hi[4] + dz * hi[7], fz = dx * hi[2] + dy * hi[5] + dz * hi[8];
-                if (boundary[0]) fx -= std::floor(fx + 0.5);
-                if (boundary[1]) fy -= std::floor(fy + 0.5);
-                if (boundary[2]) fz -= std::floor(fz + 0.5);
-                dx = fx * box9[0] + fy * box9[3] + fz * box9[6];
-                dy = fx * box9[1] + fy * box9[4] + fz * box9[7];
-                dz = fx * box9[2] + fy * box9[5] + fz * box9[8];
-            } else {
-                if (boundary[0]) dx -= box9[0] * std::floor(dx / box9[0] + 0.5);
-                if (boundary[1]) dy -= box9[4] * std::floor(dy / box9[4] + 0.5);
-                if (boundary[2]) dz -= box9[8] * std::floor(dz / box9[8] + 0.5);
-            }
-            pts[cnt][0] = dx; pts[cnt][1] = dy; pts[cnt][2] = dz;
-            ids[cnt++] = k;
-        }
-        int8_t order[MAX_IN];
-        order_neighbours(cnt, pts, order);
-        if (order_out)
-            for (int k = 0; k < 18; ++k) order_out[i * 18 + k] = k < cnt ? order[k] : (int8_t)-1;
-        double env[MAX_IN][3];
-        int numbers[MAX_IN], atom_ids[MAX_IN];
-        env[0][0] = env[0][1] = env[0][2] = 0;
-        numbers[0] = types ? types[i] : 0;
-        atom_ids[0] = (int)i;
-        for (int k = 0; k < cnt; ++k) {
-            const int p = order[k];
-            env[k + 1][0] = pts[p][0]; env[k + 1][1] = pts[p][1]; env[k + 1][2] = pts[p][2];
-            numbers[k + 1] = types ? types[ids[p]] : 0;
-            atom_ids[k + 1] = ids[p];
-        }
         Result r;
-        index_atom(g_tables, flags, cnt + 1, env, numbers, r);
+        index_atom<true>(g_tables, flags, src, (int)i, r);
         double *o = output + i * 8;
         int type = r.type, ordering = r.ordering;
         if (r.rmsd > rmsd_threshold || type == T_NONE) { type = 0; ordering = 0; }
         o[0] = type; o[1] = ordering; o[2] = r.rmsd; o[3] = r.interatomic;
         o[4] = r.q[0]; o[5] = r.q[1]; o[6] = r.q[2]; o[7] = r.q[3];
-        for (int k = 0; k < 18; ++k) ptm_indices[i * 18 + k] = k < r.num_out ? atom_ids[r.mapping[k]] : -1;
+        for (int k = 0; k < 18; ++k) ptm_indices[i * 18 + k] = k < r.num_out ? r.ids[k] : -1;
     }
     return 0;
 }

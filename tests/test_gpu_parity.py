@@ -444,8 +444,9 @@ def test_ptm_system_flow_and_errors():
     hcp = mp.build_crystal("Mg", "hcp", 3.21, nx=4, ny=4, nz=3)
     hcp.cal_polyhedral_template_matching()
     assert np.all(hcp.data["ptm"].to_numpy() == 2)
-    with pytest.raises(ValueError):  # two-shell types: refused loudly, never silently skipped
-        fcc.cal_polyhedral_template_matching(structure="all")
+    dia = mp.build_crystal("C", "diamond", 3.5, nx=3, ny=3, nz=3)  # reference: tests/test_polyhedral_template_matching.py:53-58
+    dia.cal_polyhedral_template_matching(structure="all")
+    assert np.all(dia.data["ptm"].to_numpy() == 6)
     # device-resident call: same answer with HBM-resident inputs
     import torch
     pos, box = _fcc(6, 0.05, 4)

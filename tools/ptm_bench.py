@@ -1,0 +1,26 @@
+"""Time mdh_ptm on device-resident inputs: python tools/ptm_bench.py [cells]  (fcc cells per axis, default 64 -> 1.05 M atoms)"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+import mdapy_amd as mp
+from mdapy_amd import _ptm, _lib
+from mdapy_amd.build_lattice import lattice_positions
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+pos, box = lattice_positions("fcc", 3.615, n, n, n)
+pos = pos + np.random.default_rng(0).normal(0, 0.08, pos.shape)
+s = mp.System(pos=pos, box=box)
+t0 = time.time(); s.build_nearest_neighbor(18) if hasattr(s, "build_nearest_neighbor") else None
+torch.cuda.synchronize(); print("knn s", time.time() - t0)
+N = len(pos)
+x, y, z = (torch.from_numpy(np.ascontiguousarray(pos[:, k])).cuda() for k in range(3))
+v = s.verlet_list
+v = v.dev() if hasattr(v, "dev") else torch.from_numpy(np.asarray(v)).cuda()
+out = torch.zeros((N, 8), dtype=torch.float64, device="cuda"); ind = torch.zeros((N, 18), dtype=torch.int32, device="cuda")
+b = np.asarray(box, float); b = b if b.shape == (3, 3) else np.diag(b)
+for structure in ("fcc-hcp-bcc", "fcc-hcp-bcc-ico-sc"):
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        _ptm.get_ptm(structure, x, y, z, b, np.zeros(3), np.array([1, 1, 1], np.int32), v, None, 0.1, out, ind)
+        torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"{structure}: N={N} {dt*1e3:.1f} ms  {N/dt/1e6:.2f} M atoms/s  types {np.bincount(out[:,0].cpu().numpy().astype(int), minlength=6)}")
