@@ -18,9 +18,16 @@ v = s.verlet_list
 v = v.dev() if hasattr(v, "dev") else torch.from_numpy(np.asarray(v)).cuda()
 out = torch.zeros((N, 8), dtype=torch.float64, device="cuda"); ind = torch.zeros((N, 18), dtype=torch.int32, device="cuda")
 b = np.asarray(box, float); b = b if b.shape == (3, 3) else np.diag(b)
-for structure in ("fcc-hcp-bcc", "fcc-hcp-bcc-ico-sc"):
+import ctypes
+L = _lib.lib()
+structures = sys.argv[2].split("+") if len(sys.argv) > 2 else ["fcc-hcp-bcc", "all"]
+for structure in structures:
+    L.mdh_prof_reset(); L.mdh_prof_enable(1)
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.time()
         _ptm.get_ptm(structure, x, y, z, b, np.zeros(3), np.array([1, 1, 1], np.int32), v, None, 0.1, out, ind)
         torch.cuda.synchronize(); dt = time.time() - t0
+    L.mdh_prof_enable(0)
+    buf = ctypes.create_string_buffer(4096); L.mdh_prof_report(buf, 4096)
+    print(buf.value.decode().strip().replace("\n", " | "))
     print(f"{structure}: N={N} {dt*1e3:.1f} ms  {N/dt/1e6:.2f} M atoms/s  types {np.bincount(out[:,0].cpu().numpy().astype(int), minlength=6)}")
