@@ -163,6 +163,11 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
 int mdh_wcp(const int *verlet, const int *nn, const int *type, int64_t N, int64_t M, int ntype, double *wcp,
             int space, void *stream);
 
+/* extension (multi-GPU): the integer reductions of get_wcp (:26-55) over the rows with rows[i] != 0 (NULL = all rows);
+ * counts (ntype*ntype + 2*ntype) u64 = Z_mn | Z_m | atoms per type.  Ranks all-reduce them, then apply :57-75. */
+int mdh_wcp_counts(const int *verlet, const int *nn, const int *type, const unsigned char *rows, int64_t N, int64_t M,
+                   int ntype, unsigned long long *counts, int space, void *stream);
+
 /* ---- _fast_knn -------------------------------------------------------- */
 /* replaces _fast_knn.knn                                   src/fast_knn.cpp:846-916 */
 int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "mdh_rdf_single_species": [vp, vp, vp, i64, i64, vp, dbl, cint, cint, vp],
     "mdh_rdf_streaming": [vp, vp, vp, vp, i64, vp, vp, vp, vp, cint, dbl, cint, cint, vp],
     "mdh_wcp": [vp, vp, vp, i64, i64, cint, vp, cint, vp],
+    "mdh_wcp_counts": [vp, vp, vp, vp, i64, i64, cint, vp, cint, vp],
     "mdh_knn": [vp, vp, vp, i64, vp, vp, vp, cint, vp, vp, cint, vp],
     "mdh_repeat_cell": [vp, vp, vp, i64, cint, cint, cint, cint, vp],
     "mdh_ptm": [C.c_char_p, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp, cint, vp, cint, cint, vp],

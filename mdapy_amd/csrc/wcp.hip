@@ -11,15 +11,15 @@ namespace mdh {
 static constexpr int WCP_MAXT = 64; // LDS budget: (T*T + 2T) u32
 
 __global__ __launch_bounds__(256) void k_wcp_count(const int *__restrict__ verlet, const int *__restrict__ nn,
-                                                   const int *__restrict__ type, int64_t N, int64_t M, int T,
-                                                   unsigned long long *__restrict__ tot)
+                                                   const int *__restrict__ type, const unsigned char *__restrict__ rows,
+                                                   int64_t N, int64_t M, int T, unsigned long long *__restrict__ tot)
 {
     extern __shared__ unsigned lds[]; // [T*T] Zmn, [T] Zm, [T] count
     const int words = T * T + 2 * T;
     for (int q = threadIdx.x; q < words; q += blockDim.x) lds[q] = 0u;
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) {
+    if (i < N && (!rows || rows[i])) { // rows: optional mask of the rows to count (owned atoms of a multi-GPU slab)
         const int ti = type[i], n = nn[i];
         atomicAdd(&lds[T * T + T + ti], 1u);
         atomicAdd(&lds[T * T + ti], (unsigned)n);
@@ -63,7 +63,32 @@ extern "C" int mdh_wcp(const int *verlet, const int *nn, const int *type, int64_
     if (sc.failed())
         return sc.error();
     MDH_HIP(hipMemsetAsync(tot, 0, sizeof(unsigned long long) * (size_t)words, st));
-    hipLaunchKernelGGL(k_wcp_count, dim3(grid_for(N, 256)), dim3(256), sizeof(unsigned) * (size_t)words, st, dv, dn, dt, N, M, ntype, tot);
+    hipLaunchKernelGGL(k_wcp_count, dim3(grid_for(N, 256)), dim3(256), sizeof(unsigned) * (size_t)words, st, dv, dn, dt, nullptr, N, M, ntype, tot);
     hipLaunchKernelGGL(k_wcp_final, dim3(grid_for(ntype * ntype, 64)), dim3(64), 0, st, tot, N, ntype, dw);
+    return sc.finish(space);
+}
+
+// Extension for the multi-GPU path (no counterpart in the reference): the raw integer reductions of get_wcp
+// (src/warren_cowley_parameter.cpp:26-55) over the rows selected by `rows` (NULL = all): counts[0..T*T) = Z_mn,
+// [T*T..T*T+T) = Z_m, [T*T+T..T*T+2T) = atoms per type.  Ranks all-reduce these and apply :57-75 once.
+extern "C" int mdh_wcp_counts(const int *verlet, const int *nn, const int *type, const unsigned char *rows, int64_t N,
+                              int64_t M, int ntype, unsigned long long *counts, int space, void *stream)
+{
+    if (N < 0 || M <= 0 || ntype <= 0 || ntype > WCP_MAXT) { set_error("mdh_wcp_counts: need N>=0, M>0 and 1 <= ntype <= 64"); return MDH_ERR_ARG; }
+    Scope sc(stream);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    const int words = ntype * ntype + 2 * ntype;
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    const int *dt = sc.stage_in(type, (size_t)N, space);
+    const unsigned char *dr = rows ? sc.stage_in(rows, (size_t)N, space) : nullptr;
+    unsigned long long *dc = sc.stage(counts, (size_t)words, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemsetAsync(dc, 0, sizeof(unsigned long long) * (size_t)words, st));
+    if (N > 0)
+        hipLaunchKernelGGL(k_wcp_count, dim3(grid_for(N, 256)), dim3(256), sizeof(unsigned) * (size_t)words, st, dv, dn, dt, dr, N, M, ntype, dc);
     return sc.finish(space);
 }

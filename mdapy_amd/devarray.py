@@ -30,7 +30,7 @@ def torch():
 
         _torch = t
         _NP2T.update({np.dtype(np.float64): t.float64, np.dtype(np.int32): t.int32, np.dtype(np.int64): t.int64,
-                      np.dtype(np.float32): t.float32})
+                      np.dtype(np.float32): t.float32, np.dtype(np.uint8): t.uint8, np.dtype(np.int8): t.int8})
     return _torch
 
 

@@ -21,7 +21,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from . import _cna, _neighbor
+from . import _cna, _csp, _fast_knn, _neighbor, _ptm, _rdf, _wcp
 from .box import Box
 
 
@@ -155,3 +155,176 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     _neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True)
     _cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
     return dom, verlet, dist, nn, pattern
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# k-nearest-neighbour analyses (adaptive CNA, CSP, PTM, ...): the halo is not known in advance
+# ------------------------------------------------------------------------------------------------------------------
+def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo: Optional[float] = None, neighbor_rows: int = 0,
+             max_tries: int = 6):
+    """k nearest neighbours of every owned atom, bit-identical to a single-GPU search of the whole system.
+
+    A slab knows the atoms within `halo` of its faces.  The k-th neighbour distance r_k(i) of an atom proves its own row
+    complete iff r_k(i) is smaller than the distance from i to the edge of the known region; the halo is doubled (all
+    ranks together, one 1-element all-reduce per try) until that holds for every owned atom — and, when
+    ``neighbor_rows = m > 0``, also for the first m neighbours of every owned atom (analyses that read their
+    neighbours' rows: identify-diamond m=4, the two-shell PTM templates m=13).
+
+    Returns (dom, idx, dist, valid): rows in ``dom`` order; ``idx`` holds local indices (``dom.gid[idx]`` = global ids);
+    ``valid`` marks the rows proven complete (all owned rows are).
+    """
+    t = _torch()
+    import torch.distributed as dist_
+
+    b = dec.box
+    thick = float(b.get_thickness()[dec.axis])
+    if halo is None:  # about the k-th neighbour distance of a uniform system of the local density, with head-room
+        n_loc = max(int(x.shape[0]), 1)
+        vol = float(b.volume) / dec.world
+        halo = 1.5 * (3.0 * (k + 1) / (4.0 * np.pi) * vol / n_loc) ** (1.0 / 3.0)
+    for _ in range(max_tries):
+        if dec.world > 1:
+            halo = min(halo, thick / dec.world * (1.0 - 1e-6))
+        dom = dec.exchange_halo(x, y, z, gid, halo)
+        n = int(dom.x.shape[0])
+        idx = t.empty((n, k), dtype=t.int32, device=dom.x.device)
+        dst = t.empty((n, k), dtype=t.float64, device=dom.x.device)
+        _fast_knn.knn(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, k, idx, dst, 1)
+        if dec.world == 1:
+            return dom, idx, dst, t.ones(n, dtype=t.bool, device=dom.x.device)
+        h = dec.halo_fraction(halo)
+        f = dec.frac(dom.x, dom.y, dom.z)
+        lo, hi = dec.rank / dec.world, (dec.rank + 1) / dec.world
+        # fractional distance to the nearer edge of the known region [lo - h, hi + h), measured around the ring
+        centre = 0.5 * (lo + hi)
+        off = f - centre
+        off = off - t.round(off)
+        room = (0.5 * (hi - lo) + h - off.abs()) * thick
+        if (hi - lo) + 2 * h >= 1.0 - 1e-12:
+            room = t.full_like(room, float("inf"))  # own slab + both halos cover the whole ring
+        valid = dst[:, k - 1] < room * (1.0 - 1e-12)
+        ok = valid[dom.owned]
+        if neighbor_rows > 0:
+            m = min(neighbor_rows, k)
+            nb = idx[dom.owned][:, :m].long()
+            ok = ok & valid[nb.clamp(min=0)].all(dim=1)
+        bad = t.tensor([int((~ok).sum().item())], dtype=t.int64, device=dom.x.device)
+        dist_.all_reduce(bad, group=dec.group)
+        if int(bad.item()) == 0:
+            return dom, idx, dst, valid
+        if halo >= thick / dec.world * (1.0 - 1e-6):
+            raise RuntimeError(f"knn_step: slab of thickness {thick / dec.world:.3f} cannot prove {k} neighbours complete; "
+                               "use fewer ranks along this axis")
+        halo *= 2.0
+    raise RuntimeError("knn_step: halo did not converge")
+
+
+def knn_analysis_step(dec: SlabDecomposition, x, y, z, gid, what=("acna", "csp", "ptm"), csp_neighbors: int = 12,
+                      ptm_structure: str = "fcc-hcp-bcc", ptm_threshold: float = 0.1, types=None):
+    """Adaptive CNA / CSP / PTM of the owned atoms from one verified 18-neighbour search (rows sorted by distance, as the
+    reference's classes build them: common_neighbor_analysis.py:125-140, centro_symmetry_parameter.py:79-100,
+    polyhedral_template_matching.py:110-150).  ``types``: optional int32 per OWNED atom (PTM alloy ordering) — it
+    travels with the halo as a fifth packed column.  Returns (dom, results) with results[name] in ``dom`` order;
+    only rows with ``dom.owned`` are meaningful."""
+    t = _torch()
+    flags = ptm_structure.replace("all", "dcub-dhex-graphene")
+    two_shell = "ptm" in what and any(s in flags for s in ("dcub", "dhex", "graphene"))
+    k = 18 if "ptm" in what else max(14 if "acna" in what else 0, csp_neighbors if "csp" in what else 0)
+    tdom = None
+    if types is not None:  # ghosts need their types: ship them as an extra coordinate-like payload keyed by gid
+        tdom = _gather_by_gid(dec, gid, types)
+    dom, idx, dst, valid = knn_step(dec, x, y, z, gid, k, neighbor_rows=13 if two_shell else 0)
+    n = int(dom.x.shape[0])
+    b = dec.box
+    out = {}
+    if "acna" in what:
+        pat = t.zeros((n,), dtype=t.int32, device=dom.x.device)
+        _cna.acna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, idx, pat, 1)
+        out["acna"] = pat
+    if "csp" in what:
+        csp = t.zeros((n,), dtype=t.float64, device=dom.x.device)
+        _csp.get_csp(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, idx, csp_neighbors, csp, 1)
+        out["csp"] = csp
+    if "ptm" in what:
+        res = t.zeros((n, 8), dtype=t.float64, device=dom.x.device)
+        ind = t.zeros((n, 18), dtype=t.int32, device=dom.x.device)
+        ty = None
+        if tdom is not None:
+            ty = tdom(dom.gid)
+        _ptm.get_ptm(ptm_structure, dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, idx, ty, ptm_threshold, res, ind, 1)
+        out["ptm"] = res
+        out["ptm_indices"] = ind
+    out["knn_idx"], out["knn_dist"], out["valid"] = idx, dst, valid
+    return dom, out
+
+
+def _gather_by_gid(dec: SlabDecomposition, gid, values):
+    """all-gather a per-owned-atom int32 column so that any rank can look it up by global id (types are 4 B/atom:
+    one all-gather of N x 12 B in total; used for PTM alloy ordering only)"""
+    t = _torch()
+    import torch.distributed as dist_
+
+    if dec.world == 1:
+        g, v = gid, values
+    else:
+        n = t.tensor([int(gid.shape[0])], dtype=t.int64, device=gid.device)
+        sizes = [t.zeros(1, dtype=t.int64, device=gid.device) for _ in range(dec.world)]
+        dist_.all_gather(sizes, n, group=dec.group)
+        mx = int(max(int(s.item()) for s in sizes))
+        pad_g = t.full((mx,), -1, dtype=t.int64, device=gid.device); pad_g[: gid.shape[0]] = gid
+        pad_v = t.zeros((mx,), dtype=t.int64, device=gid.device); pad_v[: gid.shape[0]] = values.to(t.int64)
+        gs = [t.empty_like(pad_g) for _ in range(dec.world)]
+        vs = [t.empty_like(pad_v) for _ in range(dec.world)]
+        dist_.all_gather(gs, pad_g, group=dec.group)
+        dist_.all_gather(vs, pad_v, group=dec.group)
+        g = t.cat([a[: int(s.item())] for a, s in zip(gs, sizes)])
+        v = t.cat([a[: int(s.item())] for a, s in zip(vs, sizes)])
+    order = t.argsort(g)
+    g, v = g[order], v[order]
+
+    def lookup(q):
+        pos = t.searchsorted(g, q)
+        return v[pos].to(t.int32).contiguous()
+
+    return lookup
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# reductions over the neighbor list: g(r) and the Warren-Cowley matrix (integer counts, one all-reduce each)
+# ------------------------------------------------------------------------------------------------------------------
+def rdf_counts_step(dec: SlabDecomposition, dom: LocalDomain, verlet, dist, nn, types, ntype: int, rc: float, nbin: int):
+    """Pair counts (Nt,Nt,nbin) of the WHOLE system from every rank's owned rows (`_rdf._rdf`,
+    radial_distribution_function.cpp:22-54): ghost rows are switched off through their neighbour count, the integer
+    counts (exact in f64 below 2^53) are summed over the ranks.  `types` int32 0-based in ``dom`` order."""
+    t = _torch()
+    import torch.distributed as dist_
+
+    nn_own = t.where(dom.owned, nn, t.zeros_like(nn)).contiguous()
+    g = t.zeros((ntype, ntype, nbin), dtype=t.float64, device=dom.x.device)
+    _rdf._rdf(verlet, dist, nn_own, types, g, rc, nbin)
+    if dec.world > 1:
+        dist_.all_reduce(g, group=dec.group)
+    return g
+
+
+def wcp_step(dec: SlabDecomposition, dom: LocalDomain, verlet, nn, types, ntype: int):
+    """Warren-Cowley matrix of the whole system: Z_mn / Z_m / atoms-per-type counted over owned rows
+    (`mdh_wcp_counts`), one int64 all-reduce, then warren_cowley_parameter.cpp:57-75."""
+    t = _torch()
+    import torch.distributed as dist_
+
+    counts = t.zeros((ntype * ntype + 2 * ntype,), dtype=t.int64, device=dom.x.device)
+    _wcp.get_wcp_counts(verlet, nn, types, ntype, counts, rows=dom.owned.to(t.uint8).contiguous())
+    if dec.world > 1:
+        dist_.all_reduce(counts, group=dec.group)
+    c = counts.cpu().numpy().astype(np.int64)
+    T = ntype
+    zmn, zm, cnt = c[: T * T].reshape(T, T), c[T * T: T * T + T], c[T * T + T:]
+    ntot = float(cnt.sum())
+    wcp = np.zeros((T, T))
+    for a in range(T):
+        for bb in range(T):
+            conc = float(cnt[bb]) / ntot
+            if conc > 0 and zm[a] > 0:
+                wcp[a, bb] = 1.0 - float(zmn[a, bb]) / (conc * float(zm[a]))
+    return wcp

@@ -102,3 +102,133 @@ def test_slab_halo_exchange_matches_single_process(world):
         assert ok is True, f"rank {rank}: {n_own}"
         assert n_own > 0 and n_ghost > 0
     assert sum(r[2] for r in res) == 12 * 6 * 6 * 4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# kNN analyses (verified halo) and list reductions (RDF counts, Warren-Cowley) across ranks
+# ------------------------------------------------------------------------------------------------------------------
+def _worker_analyses(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types as _types
+
+        import mdapy_amd as mp
+        import mdapy_amd.distributed as D
+        from mdapy_amd.build_lattice import lattice_positions
+        from oracle import oracle as O
+
+        def npv(a):  # torch CPU tensor -> numpy view sharing its memory
+            return a.numpy() if isinstance(a, torch.Tensor) else a
+
+        def wrap(fn):
+            return staticmethod(lambda *a, **k: fn(*[npv(v) for v in a], **{kk: npv(v) for kk, v in k.items()}))
+
+        def build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_pads=False):
+            if fill_pads:
+                v.fill(-1); d.fill(rc + 1.0); nn.fill(0)
+            O.build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, 2)
+
+        def wcp_counts(v, nn, t, Nt, counts, rows=None):  # numpy statement of warren_cowley_parameter.cpp:26-55
+            counts[:] = 0
+            sel = np.ones(len(nn), bool) if rows is None else rows.astype(bool)
+            for i in np.nonzero(sel)[0]:
+                counts[Nt * Nt + Nt + t[i]] += 1
+                counts[Nt * Nt + t[i]] += nn[i]
+                for j in v[i, : nn[i]]:
+                    counts[t[i] * Nt + t[j]] += 1
+
+        D._neighbor = _types.SimpleNamespace(build_neighbor=wrap(build_neighbor).__func__)
+        D._fast_knn = _types.SimpleNamespace(knn=wrap(lambda x, y, z, b, o, p, k, i, d, nt=1: O.knn(x, y, z, b, o, p, k, i, d, 2)).__func__)
+        D._cna = _types.SimpleNamespace(acna=wrap(lambda x, y, z, b, o, p, v, pat, nt=1: O.acna(x, y, z, b, o, p, v, pat, 2)).__func__)
+        D._csp = _types.SimpleNamespace(get_csp=wrap(lambda x, y, z, b, o, p, v, n, out, nt=1: O.get_csp(x, y, z, b, o, p, v, n, out, 2)).__func__)
+        D._ptm = _types.SimpleNamespace(get_ptm=wrap(lambda st, x, y, z, b, o, p, v, ty, thr, out, ind, nt=1:
+                                                     O.get_ptm(st, x, y, z, b, o, p, v, ty, thr, out, ind)).__func__)
+        D._rdf = _types.SimpleNamespace(_rdf=wrap(lambda v, d, nn, ty, g, rc, nbin: O._rdf(v, d, nn, ty, g, rc, nbin)).__func__)
+        D._wcp = _types.SimpleNamespace(get_wcp_counts=wrap(wcp_counts).__func__)
+
+        a = 3.6
+        pos, boxm = lattice_positions("fcc", a, 10, 5, 5)
+        rng = np.random.default_rng(9)
+        pos = pos + rng.normal(0, 0.06, pos.shape)
+        pos[rng.random(len(pos)) < 0.04] += rng.normal(0, 0.6, 3)    # a few strongly displaced atoms: non-fcc labels
+        types_all = rng.integers(0, 2, len(pos)).astype(np.int32)
+        perm = rng.permutation(len(pos))
+        pos, types_all = pos[perm], types_all[perm]
+        box = mp.Box(boxm)
+        N = len(pos)
+        x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+        org, bnd = np.zeros(3), np.array([1, 1, 1], np.int32)
+        owned_ids = D.partition_atoms(pos, box, world, axis=0)[rank]
+        t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr))
+        dec = D.SlabDecomposition(box, rank, world, axis=0)
+        own_args = (t(pos[owned_ids, 0]), t(pos[owned_ids, 1]), t(pos[owned_ids, 2]), t(owned_ids))
+        msgs = []
+
+        # ---- kNN analyses; a deliberately small first halo forces at least one growth step
+        dom, res = D.knn_analysis_step(dec, *own_args, what=("acna", "csp", "ptm"), types=t(types_all[owned_ids] + 1))
+        own, gid = dom.owned.numpy(), dom.gid.numpy()
+        I = np.zeros((N, 18), np.int32); Dk = np.zeros((N, 18))
+        O.knn(x, y, z, boxm, org, bnd, 18, I, Dk, 2)
+        P = np.zeros(N, np.int32); O.acna(x, y, z, boxm, org, bnd, I, P, 2)
+        C = np.zeros(N); O.get_csp(x, y, z, boxm, org, bnd, I, 12, C, 2)
+        R = np.zeros((N, 8)); RI = np.zeros((N, 18), np.int32)
+        O.get_ptm("fcc-hcp-bcc", x, y, z, boxm, org, bnd, I, types_all + 1, 0.1, R, RI)
+        g_own = gid[own]
+        msgs.append(("knn_dist", np.array_equal(res["knn_dist"].numpy()[own], Dk[g_own])))
+        msgs.append(("knn_ids", np.array_equal(gid[res["knn_idx"].numpy()[own]], I[g_own])))
+        msgs.append(("acna", np.array_equal(res["acna"].numpy()[own], P[g_own])))
+        msgs.append(("csp", np.array_equal(res["csp"].numpy()[own], C[g_own])))
+        msgs.append(("ptm", np.array_equal(res["ptm"].numpy()[own], R[g_own])))
+        pi = res["ptm_indices"].numpy()[own]
+        msgs.append(("ptm_indices", np.array_equal(np.where(pi >= 0, gid[np.clip(pi, 0, None)], -1), RI[g_own])))
+        msgs.append(("labels_nontrivial", len(np.unique(P)) > 1 and len(np.unique(R[:, 0])) > 1))
+        dom2, _, _, valid = D.knn_step(dec, *own_args, 18, halo=1.0, neighbor_rows=13)   # must grow from 1.0 A
+        msgs.append(("neighbor_rows_valid", bool(valid[dom2.owned].all())))
+
+        # ---- list reductions
+        rc, M, nbin = 0.854 * a, 16, 40
+        dom = dec.exchange_halo(*own_args, rc)
+        n = int(dom.x.shape[0])
+        v = torch.empty((n, M), dtype=torch.int32); d = torch.empty((n, M), dtype=torch.float64); nn = torch.empty(n, dtype=torch.int32)
+        D._neighbor.build_neighbor(dom.x, dom.y, dom.z, boxm, org, bnd, rc, v, d, nn, 1, fill_pads=True)
+        ty = t(types_all[dom.gid.numpy()])
+        g = D.rdf_counts_step(dec, dom, v, d, nn, ty, 2, rc, nbin)
+        w = D.wcp_step(dec, dom, v, nn, ty, 2)
+        V = np.full((N, M), -1, np.int32); Dd = np.full((N, M), rc + 1.0); NN = np.zeros(N, np.int32)
+        O.build_neighbor(x, y, z, boxm, org, bnd, rc, V, Dd, NN, 2)
+        G = np.zeros((2, 2, nbin)); O._rdf(V, Dd, NN, types_all, G, rc, nbin)
+        W = np.zeros((2, 2)); O.get_wcp(V, NN, types_all, 2, W, 2)
+        msgs.append(("rdf_counts", np.array_equal(g.numpy(), G) and G.sum() > 0))
+        msgs.append(("wcp", np.array_equal(w, W)))
+        q.put((rank, all(ok for _, ok in msgs), [m for m, ok in msgs if not ok], int(dom.owned.sum())))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, repr(e) + traceback.format_exc()[-1500:], 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_knn_analyses_and_reductions_match_single_process(world):
+    import torch.multiprocessing as tmp
+
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_analyses, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, failed, n_own in sorted(res):
+        assert ok is True, f"rank {rank}: {failed}"
+    assert sum(r[3] for r in res) == 10 * 5 * 5 * 4

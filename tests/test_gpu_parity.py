@@ -460,3 +460,33 @@ def test_ptm_system_flow_and_errors():
     ind_d = torch.zeros((len(pos), 18), dtype=torch.int32, device="cuda")
     _ptm.get_ptm("default", dev[0], dev[1], dev[2], box, ORG0, PBC, dev[3], None, 0.1, out_d, ind_d)
     assert np.array_equal(out_d.cpu().numpy(), out_h) and np.array_equal(ind_d.cpu().numpy(), ind_h)
+
+
+def test_wcp_counts_extension():
+    """mdh_wcp_counts (multi-GPU building block): integer reductions over a row mask vs numpy, and consistency with get_wcp"""
+    rng = np.random.default_rng(3)
+    pos, box = _fcc(7, 0.05, 6)
+    x, y, z = _xyz(pos)
+    N, M, rc, T = len(pos), 16, 0.854 * 3.615, 3
+    v, d, nn = np.full((N, M), -1, np.int32), np.full((N, M), rc + 1.0), np.zeros(N, np.int32)
+    _neighbor.build_neighbor(x, y, z, box, ORG0, PBC, rc, v, d, nn, 1)
+    ty = rng.integers(0, T, N).astype(np.int32)
+    rows = (rng.random(N) < 0.6).astype(np.uint8)
+    for mask in (None, rows):
+        got = np.zeros(T * T + 2 * T, np.int64)
+        _wcp.get_wcp_counts(v, nn, ty, T, got, rows=mask)
+        exp = np.zeros_like(got)
+        for i in range(N):
+            if mask is not None and not mask[i]:
+                continue
+            exp[T * T + T + ty[i]] += 1
+            exp[T * T + ty[i]] += nn[i]
+            np.add.at(exp, ty[i] * T + ty[v[i, : nn[i]]], 1)
+        assert np.array_equal(got, exp)
+    w = np.zeros((T, T))
+    _wcp.get_wcp(v, nn, ty, T, w, 1)
+    full = np.zeros(T * T + 2 * T, np.int64)
+    _wcp.get_wcp_counts(v, nn, ty, T, full)
+    zmn, zm, cnt = full[: T * T].reshape(T, T), full[T * T: T * T + T], full[T * T + T:]
+    w2 = 1.0 - zmn / ((cnt / N)[None, :] * zm[:, None])
+    assert np.allclose(w, w2, rtol=0, atol=1e-15)
