@@ -192,6 +192,20 @@ int mdh_ptm(const char *structure, const double *x, const double *y, const doubl
 /* the PTM_CHECK_* bit mask the structure string selects (:168-206) */
 int mdh_ptm_flags(const char *structure);
 
+/* ---- list consumers ---------------------------------------- */
+/* replaces _aja.compute_aja                                 src/ackland_jones_analysis.cpp:9-172
+ * rows: >= 14 neighbours sorted by distance; aja (N) i32: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico */
+int mdh_aja(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+            const double *origin3_host, const int *boundary3_host, const int *verlet, const double *dist, int64_t M,
+            int *aja, int space, void *stream);
+/* replaces _cnp.compute_cnp                                 src/common_neighbor_parameter.cpp:10-137; cnp (N) f64 */
+int mdh_cnp(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+            const double *origin3_host, const int *boundary3_host, const int *verlet, const double *dist, const int *nn,
+            int64_t M, double *cnp, double rc, int space, void *stream);
+/* replaces _structure_entropy.calculate_structure_entropy   src/structure_entropy.cpp:9-108; entropy (N) f64 */
+int mdh_structure_entropy(double rc, double sigma, int use_local_density, double volume, const double *dist,
+                          const int *nn, int64_t N, int64_t M, double *entropy, int space, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,9 @@ _SIGNATURES = {
     "mdh_repeat_cell": [vp, vp, vp, i64, cint, cint, cint, cint, vp],
     "mdh_ptm": [C.c_char_p, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp, cint, vp, cint, cint, vp],
     "mdh_ptm_flags": [C.c_char_p],
+    "mdh_aja": [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, cint, vp],
+    "mdh_cnp": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, dbl, cint, vp],
+    "mdh_structure_entropy": [dbl, dbl, cint, dbl, vp, vp, i64, i64, vp, cint, vp],
 }
 _RESTYPES = {"mdh_last_error": C.c_char_p, "mdh_workspace_bytes": C.c_int64}
 

@@ -19,9 +19,11 @@ from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
 import numpy as np
 
 from . import tool_function as tool
+from .ackland_jones_analysis import AcklandJonesAnalysis
 from .box import Box
 from .centro_symmetry_parameter import CentroSymmetryParameter
 from .common_neighbor_analysis import CommonNeighborAnalysis
+from .common_neighbor_parameter import CommonNeighborParameter
 from .devarray import as_numpy
 from .frame import Frame
 from .identify_diamond_structure import IdentifyDiamondStructure
@@ -30,6 +32,7 @@ from .neighbor import Neighbor
 from .polyhedral_template_matching import PolyhedralTemplateMatching
 from .radial_distribution_function import RadialDistributionFunction
 from .steinhardt_bond_orientation import SteinhardtBondOrientation
+from .structure_entropy import StructureEntropy
 from .warren_cowley_parameter import WarrenCowleyParameter
 
 _NEIGH_ATTRS = ("verlet_list", "neighbor_number", "distance_list", "rc", "_enlarge_box", "_enlarge_data")
@@ -185,6 +188,48 @@ class System:
             new.update(qx=output[:, 5], qy=output[:, 6], qz=output[:, 7], qw=output[:, 4])
         self.ptm_indices = ptm.ptm_indices
         self.update_data(self.__data.with_columns(**new))
+
+    def cal_common_neighbor_parameter(self, rc: float, max_neigh: Optional[int] = None) -> None:
+        """column ``cnp`` (system.py:1572-1603)"""
+        has_neigh = hasattr(self, "rc") and self.rc >= rc
+        if not has_neigh:
+            self.build_neighbor(rc, max_neigh)
+        box, data = self._get_compute_view()
+        cnp = CommonNeighborParameter(data, box, rc, self.verlet_list, self.distance_list, self.neighbor_number)
+        cnp.compute()
+        self.update_data(self.__data.with_columns(cnp=as_numpy(cnp.cnp)[: self.N]))
+
+    def cal_ackland_jones_analysis(self) -> None:
+        """column ``aja``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico (system.py:1605-1636)"""
+        n_neigh = 14
+        if self.data.shape[0] < n_neigh and sum(self.box.boundary) == 0:
+            self.update_data(self.__data.with_columns(aja=np.zeros(self.N, np.int32)))
+            return
+        if hasattr(self, "neighbor_number") and self.neighbor_number.min() >= n_neigh:
+            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, n_neigh)
+        else:
+            self.build_nearest_neighbor(n_neigh)
+        box, data = self._get_compute_view()
+        aja = AcklandJonesAnalysis(data, box, self.verlet_list, self.distance_list)
+        aja.compute()
+        self.update_data(self.__data.with_columns(aja=as_numpy(aja.aja)[: self.N]))
+
+    def cal_structure_entropy(self, rc: float, sigma: float, use_local_density: bool = False, average_rc: float = 0.0,
+                              max_neigh: Optional[int] = None) -> None:
+        """columns ``entropy`` (+ ``entropy_ave`` when average_rc > 0) (system.py:2481-2542)"""
+        if hasattr(self, "rc"):
+            if self.rc < rc:
+                self.build_neighbor(rc, max_neigh)
+        else:
+            self.build_neighbor(rc, max_neigh)
+        box, _ = self._get_compute_view()
+        se = StructureEntropy(box, self.verlet_list, self.distance_list, self.neighbor_number, rc, sigma, use_local_density,
+                              average_rc)
+        se.compute()
+        data = self.data.with_columns(entropy=as_numpy(se.entropy)[: self.N])
+        if average_rc > 0:
+            data = data.with_columns(entropy_ave=as_numpy(se.entropy_ave)[: self.N])
+        self.update_data(data)
 
     def cal_centro_symmetry_parameter(self, N: int):
         """column ``csp`` (system.py:1972-2003)"""

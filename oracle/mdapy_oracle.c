@@ -1195,3 +1195,153 @@ ORC_API int orc_num_procs(void)
     return 1;
 #endif
 }
+
+/* ====================================================================== list consumers
+ * Ackland-Jones analysis                                  src/ackland_jones_analysis.cpp:9-172
+ * rows must hold >= 14 neighbours sorted by distance (system.py:1620-1636) */
+ORC_API int orc_aja(const double *x, const double *y, const double *z, int64_t n_atoms, const double *box9,
+                    const double *origin, const int *boundary, const int *verlet, const double *dist, int64_t M,
+                    int *aja, int num_t)
+{
+    obox b;
+    if (obox_init(&b, box9, origin, boundary))
+        return -1;
+#pragma omp parallel for num_threads(num_t > 0 ? num_t : 1) schedule(static)
+    for (int64_t i = 0; i < n_atoms; ++i) {
+        const double *di = dist + i * M;
+        const int *vi = verlet + i * M;
+        double r0 = 0.0;
+        for (int j = 0; j < 6; ++j) r0 += di[j] * di[j];               /* :44-52 */
+        r0 /= 6.0;
+        const double c145 = 1.45 * r0, c155 = 1.55 * r0;
+        int n0 = 0, n1 = 0;
+        for (int j = 0; j < 14; ++j) {                                   /* :55-72 */
+            const double r2 = di[j] * di[j];
+            if (r2 < c155) { ++n1; if (r2 < c145) ++n0; }
+        }
+        int al[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const double xi = x[i], yi = y[i], zi = z[i];
+        for (int j = 0; j < n0; ++j) {                                   /* :80-126: bond-angle histogram */
+            double ax = x[vi[j]] - xi, ay = y[vi[j]] - yi, az = z[vi[j]] - zi;
+            obox_pbc(&b, &ax, &ay, &az);
+            for (int k = j + 1; k < n0; ++k) {
+                double bx = x[vi[k]] - xi, by = y[vi[k]] - yi, bz = z[vi[k]] - zi;
+                obox_pbc(&b, &bx, &by, &bz);
+                const double c = (ax * bx + ay * by + az * bz) / (di[j] * di[k]);
+                if (c < -0.945) al[0]++; else if (c < -0.915) al[1]++; else if (c < -0.755) al[2]++;
+                else if (c < -0.195) al[3]++; else if (c < 0.195) al[4]++; else if (c < 0.245) al[5]++;
+                else if (c < 0.795) al[6]++; else al[7]++;
+            }
+        }
+        const double s_cp = fabs(1.0 - al[6] / 24.0);                    /* :129-150 */
+        const int s56m4 = al[5] + al[6] - al[4];
+        double s_bcc = s_cp + 1.0;
+        if (s56m4 != 0) s_bcc = 0.35 * al[4] / (double)s56m4;
+        double s_fcc = 0.61 * (abs(al[0] + al[1] - 6) + al[2]) / 6.0;
+        double s_hcp = (fabs(al[0] - 3.0) + abs(al[0] + al[1] + al[2] + al[3] - 9)) / 12.0;
+        if (al[0] == 7) s_bcc = 0.0; else if (al[0] == 6) s_fcc = 0.0; else if (al[0] <= 3) s_hcp = 0.0;
+        int t;                                                           /* :152-170 */
+        if (al[7] > 0) t = 0;
+        else if (al[4] < 3) t = (n1 > 13 || n1 < 11) ? 0 : 4;
+        else if (s_bcc <= s_cp) t = n1 < 11 ? 0 : 3;
+        else if (n1 > 12 || n1 < 11) t = 0;
+        else t = s_fcc < s_hcp ? 1 : 2;
+        aja[i] = t;
+    }
+    return 0;
+}
+
+/* common neighbour parameter                                 src/common_neighbor_parameter.cpp:10-137 */
+ORC_API int orc_cnp(const double *x, const double *y, const double *z, int64_t n_atoms, const double *box9,
+                    const double *origin, const int *boundary, const int *verlet, const double *dist, const int *nn,
+                    int64_t M, double *cnp, double rc, int num_t)
+{
+    obox b;
+    if (obox_init(&b, box9, origin, boundary))
+        return -1;
+#pragma omp parallel for num_threads(num_t > 0 ? num_t : 1) schedule(dynamic, 64)
+    for (int64_t i = 0; i < n_atoms; ++i) {
+        int cnt = 0;
+        double acc = 0.0;
+        const int ni = nn[i];
+        const int *vi = verlet + i * M;
+        const double *di = dist + i * M;
+        for (int m = 0; m < ni; ++m) {
+            if (!(di[m] <= rc)) continue;                                /* :59 */
+            const int j = vi[m];
+            ++cnt;
+            double rx = 0, ry = 0, rz = 0;
+            const int nj = nn[j];
+            const int *vj = verlet + (int64_t)j * M;
+            const double *dj = dist + (int64_t)j * M;
+            for (int s = 0; s < nj; ++s)
+                for (int h = 0; h < ni; ++h)
+                    if (vj[s] == vi[h]) {                                /* first match only, :83-120 */
+                        if (dj[s] <= rc && di[h] <= rc) {
+                            const int k = vj[s];
+                            double ax = x[i] - x[k], ay = y[i] - y[k], az = z[i] - z[k];
+                            double bx = x[j] - x[k], by = y[j] - y[k], bz = z[j] - z[k];
+                            obox_pbc(&b, &ax, &ay, &az);
+                            obox_pbc(&b, &bx, &by, &bz);
+                            rx += ax + bx; ry += ay + by; rz += az + bz;
+                        }
+                        break;
+                    }
+            acc += rx * rx + ry * ry + rz * rz;
+        }
+        cnp[i] = cnt > 0 ? acc / cnt : 1000.0;                           /* :127-134 */
+    }
+    return 0;
+}
+
+/* structural (pair) entropy fingerprint                      src/structure_entropy.cpp:9-108 */
+ORC_API int orc_structure_entropy(double rc, double sigma, int use_local_density, double volume, const double *dist,
+                                  const int *nn, int64_t n_atoms, int64_t M, double *entropy, int num_t)
+{
+    const double PI = 3.14159265358979323846;
+    const int nbins = (int)floor(rc / sigma) + 1;
+    const double gd = n_atoms / volume;
+    double *rl = (double *)malloc(sizeof(double) * (size_t)nbins), *rl2 = (double *)malloc(sizeof(double) * (size_t)nbins),
+           *pre = (double *)malloc(sizeof(double) * (size_t)nbins);
+    const double step = rc / (nbins - 1);
+    const double factor = 4. * PI * gd * sqrt(2. * PI * sigma * sigma);
+    for (int j = 0; j < nbins; ++j) { rl[j] = j * step; rl2[j] = rl[j] * rl[j]; pre[j] = rl2[j] * factor; }
+    pre[0] = pre[1];
+    const double s2 = sigma * sigma, lvol = 4. / 3. * PI * rc * rc * rc;
+#pragma omp parallel num_threads(num_t > 0 ? num_t : 1)
+    {
+        double *g = (double *)malloc(sizeof(double) * (size_t)nbins);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n_atoms; ++i) {
+            int nin = 0;
+            for (int j = 0; j < nbins; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < nn[i]; ++k) {
+                    const double d = dist[i * M + k];
+                    if (d <= rc) {
+                        const double dl = rl[j] - d;
+                        a += exp(-(dl * dl) / (2.0 * s2)) / pre[j];
+                        if (j == 0) ++nin;
+                    }
+                }
+                g[j] = a;
+            }
+            double density = gd;
+            if (use_local_density) {
+                density = nin / lvol;
+                const double fac = gd / density;
+                for (int j = 0; j < nbins; ++j) g[j] *= fac;
+            }
+            double prev = 0.0, sum = 0.0;
+            for (int j = 0; j < nbins; ++j) {
+                const double v = g[j] >= 1e-10 ? (g[j] * log(g[j]) - g[j] + 1.0) * rl2[j] : rl2[j];
+                if (j > 0) sum += prev + v;
+                prev = v;
+            }
+            entropy[i] = -PI * density * sum * sigma;
+        }
+        free(g);
+    }
+    free(rl); free(rl2); free(pre);
+    return 0;
+}

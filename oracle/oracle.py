@@ -278,3 +278,32 @@ def get_ptm(structure, x, y, z, box, origin, boundary, verlet_list, atom_types, 
                                _p(ptm_indices, np.int32), cint(ptm_indices.shape[1]),
                                None if cached is None else cached.ctypes.data_as(C.c_void_p))
     _chk(rc)
+
+
+# --------------------------------------------------------------------- list consumers
+def compute_aja(x, y, z, box, origin, boundary, verlet_list, distance_list, aja, num_t=1):
+    """mdapy._aja.compute_aja (src/ackland_jones_analysis.cpp:9)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v, d = _ro(verlet_list, np.int32), _ro(distance_list, np.float64)
+    _chk(lib().orc_aja(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]), _p(b, np.float64),
+                       _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), _p(d, np.float64), i64(v.shape[1]),
+                       _p(aja, np.int32), cint(num_t)))
+
+
+def compute_cnp(x, y, z, box, origin, boundary, verlet_list, distance_list, neighbor_number, cnp, rc, num_t=1):
+    """mdapy._cnp.compute_cnp (src/common_neighbor_parameter.cpp:10)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    v, d, n = _ro(verlet_list, np.int32), _ro(distance_list, np.float64), _ro(neighbor_number, np.int32)
+    _chk(lib().orc_cnp(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(x.shape[0]), _p(b, np.float64),
+                       _p(o, np.float64), _p(p, np.int32), _p(v, np.int32), _p(d, np.float64), _p(n, np.int32),
+                       i64(v.shape[1]), _p(cnp, np.float64), dbl(rc), cint(num_t)))
+
+
+def calculate_structure_entropy(rc, sigma, use_local_density, volume, distance_list, neighbor_number, entropy, num_t=1):
+    """mdapy._structure_entropy.calculate_structure_entropy (src/structure_entropy.cpp:9)"""
+    d, n = _ro(distance_list, np.float64), _ro(neighbor_number, np.int32)
+    _chk(lib().orc_structure_entropy(dbl(rc), dbl(sigma), cint(bool(use_local_density)), dbl(volume), _p(d, np.float64),
+                                     _p(n, np.int32), i64(d.shape[0]), i64(d.shape[1]), _p(entropy, np.float64),
+                                     cint(num_t)))

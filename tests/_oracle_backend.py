@@ -64,11 +64,20 @@ fast_knn = _mod(knn=lambda x, y, z, box, origin, boundary, k, idx, dist, num_t=1
                 O.knn(_np(x), _np(y), _np(z), box, origin, boundary, k, idx, dist, NT))
 ptm = _mod(get_ptm=lambda st, x, y, z, box, origin, boundary, v, t, thr, out, ind, num_t=1:
            O.get_ptm(st, _np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(t), thr, out, ind, NT))
+aja = _mod(compute_aja=lambda x, y, z, box, origin, boundary, v, d, out, num_t=1:
+           O.compute_aja(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(d), out, NT))
+cnp = _mod(compute_cnp=lambda x, y, z, box, origin, boundary, v, d, nn, out, rc, num_t=1:
+           O.compute_cnp(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(d), _np(nn), out, rc, NT))
+structure_entropy = _mod(calculate_structure_entropy=lambda rc, sigma, loc, vol, d, nn, out, num_t=1:
+                         O.calculate_structure_entropy(rc, sigma, loc, vol, _np(d), _np(nn), out, NT))
 repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
 
 
 def install(monkeypatch):
+    import mdapy_amd.ackland_jones_analysis as m_aja
     import mdapy_amd.build_lattice as bl
+    import mdapy_amd.common_neighbor_parameter as m_cnp
+    import mdapy_amd.structure_entropy as m_se
     import mdapy_amd.centro_symmetry_parameter as m_csp
     import mdapy_amd.common_neighbor_analysis as m_cna
     import mdapy_amd.identify_diamond_structure as m_ids
@@ -92,3 +101,7 @@ def install(monkeypatch):
     monkeypatch.setattr(m_ptm, "_ptm", ptm)
     monkeypatch.setattr(m_rdf, "_rdf", rdf)
     monkeypatch.setattr(m_wcp, "_wcp", wcp)
+    monkeypatch.setattr(m_aja, "_aja", aja)
+    monkeypatch.setattr(m_cnp, "_cnp", cnp)
+    monkeypatch.setattr(m_se, "_structure_entropy", structure_entropy)
+    monkeypatch.setattr(m_se, "_neighbor", neighbor)

@@ -490,3 +490,69 @@ def test_wcp_counts_extension():
     zmn, zm, cnt = full[: T * T].reshape(T, T), full[T * T: T * T + T], full[T * T + T:]
     w2 = 1.0 - zmn / ((cnt / N)[None, :] * zm[:, None])
     assert np.allclose(w, w2, rtol=0, atol=1e-15)
+
+
+# ------------------------------------------------------------------ list consumers: AJA, CNP, structure entropy
+from mdapy_amd import _aja, _cnp, _structure_entropy
+
+
+@pytest.mark.parametrize("case", ["fcc_rattled", "fcc_hot_shifted_origin", "triclinic_random", "random_gas", "slab_open_z"])
+def test_aja_cnp_entropy_vs_oracle(case):
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    x, y, z = _xyz(pos)
+    N = len(pos)
+    # AJA on 14 nearest neighbours
+    idx, dk = np.zeros((N, 14), np.int32), np.zeros((N, 14))
+    O.knn(x, y, z, box, origin, bd, 14, idx, dk, 4)
+    a0, a1 = np.zeros(N, np.int32), np.full(N, 9, np.int32)
+    O.compute_aja(x, y, z, box, origin, bd, idx, dk, a0, 4)
+    _aja.compute_aja(x, y, z, box, origin, bd, idx, dk, a1, 1)
+    assert np.array_equal(a1, a0)
+    # CNP + entropy on a cutoff list
+    rc = 3.2
+    v, d, nn = O.build_neighbor_without_max_neigh(x, y, z, box, origin, bd, rc, 4)
+    c0, c1 = np.zeros(N), np.full(N, -1.0)
+    O.compute_cnp(x, y, z, box, origin, bd, v, d, nn, c0, rc, 4)
+    _cnp.compute_cnp(x, y, z, box, origin, bd, v, d, nn, c1, rc, 1)
+    assert np.allclose(c1, c0, rtol=1e-6, atol=1e-9)
+    vol = abs(np.linalg.det(np.asarray(box, float) if np.ndim(box) == 2 else np.diag(box)))
+    for local in (False, True):
+        e0, e1 = np.zeros(N), np.full(N, -1.0)
+        O.calculate_structure_entropy(rc, 0.2, local, vol, d, nn, e0, 4)
+        _structure_entropy.calculate_structure_entropy(rc, 0.2, local, vol, d, nn, e1, 1)
+        ok = np.isfinite(e0)
+        assert np.array_equal(np.isfinite(e1), ok)
+        assert np.allclose(e1[ok], e0[ok], rtol=1e-6, atol=1e-9)
+
+
+AJA_PATHS, CNP_PATHS = fixtures_with("aja"), fixtures_with("cnp")
+
+
+@pytest.mark.parametrize("path", AJA_PATHS, ids=ids_of(AJA_PATHS))
+def test_golden_aja(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_ackland_jones_analysis()
+    assert np.array_equal(s.data["aja"].to_numpy(), d["aja"])
+
+
+@pytest.mark.parametrize("path", CNP_PATHS, ids=ids_of(CNP_PATHS))
+def test_golden_cnp(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_common_neighbor_parameter(float(d["cnp_cutoff"]))
+    assert np.allclose(s.data["cnp"].to_numpy(), d["cnp"], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["rec_box_big", "tri_box_small"])
+@pytest.mark.parametrize("mode", ["default", "use_local_density", "compute_average"])
+def test_golden_structure_entropy(name, mode):
+    expected = misc("structure_entropy")[f"{name}__{mode}"]
+    s = mp.System(input_path(f"{name}.xyz"))
+    if mode == "compute_average":
+        s.cal_structure_entropy(5.0, 0.2, False, average_rc=4.0)
+        got = s.data["entropy_ave"].to_numpy()
+    else:
+        s.cal_structure_entropy(5.0, 0.2, mode == "use_local_density")
+        got = s.data["entropy"].to_numpy()
+    assert np.allclose(got, expected, atol=1e-6)

@@ -244,3 +244,53 @@ def test_ptm_perfect_crystals(oracle_backend):
     dia = mp.build_crystal("C", "diamond", 3.5, nx=3, ny=3, nz=3)
     dia.cal_polyhedral_template_matching(structure="all")
     assert np.all(dia.data["ptm"].to_numpy() == 6)
+
+
+# ---------------------------------------------------------------- list consumers: AJA, CNP, structure entropy
+AJA_PATHS, CNP_PATHS = fixtures_with("aja"), fixtures_with("cnp")
+
+
+# reference: tests/test_ackland_jones_analysis.py (fixture-driven, OVITO labels)
+@pytest.mark.parametrize("path", AJA_PATHS, ids=ids_of(AJA_PATHS))
+def test_aja_against_fixture(path, oracle_backend):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_ackland_jones_analysis()
+    assert np.array_equal(s.data["aja"].to_numpy(), d["aja"])
+
+
+# reference: tests/test_common_neighbor_parameter.py:19-52
+@pytest.mark.parametrize("path", CNP_PATHS, ids=ids_of(CNP_PATHS))
+def test_cnp_against_fixture(path, oracle_backend):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_common_neighbor_parameter(float(d["cnp_cutoff"]))
+    assert np.allclose(s.data["cnp"].to_numpy(), d["cnp"], atol=1e-6, rtol=1e-6)
+
+
+def test_cnp_perfect_crystals(oracle_backend):
+    a = 3.615
+    s = mp.build_crystal("Cu", "fcc", a, nx=4, ny=4, nz=4)
+    s.cal_common_neighbor_parameter(0.86 * a)
+    assert np.allclose(s.data["cnp"].to_numpy().max(), 0.0)
+    s = mp.build_crystal("Cu", "bcc", a, nx=4, ny=4, nz=4)
+    s.cal_common_neighbor_parameter(1.21 * a)
+    assert np.allclose(s.data["cnp"].to_numpy().max(), 0.0)
+    s = mp.build_crystal("Cu", "hcp", a, c=a * 1.633)
+    s.cal_common_neighbor_parameter(1.21 * a)
+    assert np.allclose(s.data["cnp"].to_numpy().max(), 8.71215)
+
+
+# reference: tests/test_structure_entropy.py:11-33
+@pytest.mark.parametrize("name", ["rec_box_big", "rec_box_small", "tri_box_big", "tri_box_small"])
+@pytest.mark.parametrize("mode", ["default", "use_local_density", "compute_average"])
+def test_structure_entropy_against_fixture(name, mode, oracle_backend):
+    expected = misc("structure_entropy")[f"{name}__{mode}"]
+    s = mp.System(input_path(f"{name}.xyz"))
+    if mode == "compute_average":
+        s.cal_structure_entropy(5.0, 0.2, False, average_rc=4.0)
+        got = s.data["entropy_ave"].to_numpy()
+    else:
+        s.cal_structure_entropy(5.0, 0.2, mode == "use_local_density")
+        got = s.data["entropy"].to_numpy()
+    assert np.allclose(got, expected, atol=1e-6)
