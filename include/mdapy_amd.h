@@ -206,6 +206,18 @@ int mdh_cnp(const double *x, const double *y, const double *z, int64_t N, const 
 int mdh_structure_entropy(double rc, double sigma, int use_local_density, double volume, const double *dist,
                           const int *nn, int64_t N, int64_t M, double *entropy, int space, void *stream);
 
+/* replaces _atomtemp.compute_temp                           src/atomic_temperature.cpp:9-112; velocities in m/s, mass g/mol */
+int mdh_atomic_temperature(const int *verlet, const double *dist, int64_t N, int64_t M, const double *vx, const double *vy,
+                           const double *vz, const double *mass, double *T, double rc, int space, void *stream);
+/* replaces _cluster.get_cluster (by_bond=0, :9-56) and _cluster.get_cluster_by_bond (by_bond=1, :58-106).
+ * cluster (N) i32 receives ids 1..n numbered by smallest member index; *n_clusters_host = n (the functions' return value).
+ * Connected components of the (symmetric) bond graph by min-index union-find instead of the serial flood fill. */
+int mdh_cluster(const int *verlet, const double *dist, const int *nn, int64_t N, int64_t M, double rc, int by_bond,
+                int *cluster, int *n_clusters_host, int space, void *stream);
+/* replaces _cluster.filter_by_type                           src/cluster.cpp:108-148; t1/t2/r host arrays of length ntype */
+int mdh_filter_by_type(int *verlet, const double *dist, const int *nn, const int *type, int64_t N, int64_t M,
+                       const int *t1_host, const int *t2_host, const double *r_host, int ntype, int space, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

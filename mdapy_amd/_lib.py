@@ -60,6 +60,9 @@ _SIGNATURES = {
     "mdh_aja": [vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, cint, vp],
     "mdh_cnp": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, dbl, cint, vp],
     "mdh_structure_entropy": [dbl, dbl, cint, dbl, vp, vp, i64, i64, vp, cint, vp],
+    "mdh_atomic_temperature": [vp, vp, i64, i64, vp, vp, vp, vp, vp, dbl, cint, vp],
+    "mdh_cluster": [vp, vp, vp, i64, i64, dbl, cint, vp, vp, cint, vp],
+    "mdh_filter_by_type": [vp, vp, vp, vp, i64, i64, vp, vp, vp, cint, cint, vp],
 }
 _RESTYPES = {"mdh_last_error": C.c_char_p, "mdh_workspace_bytes": C.c_int64}
 

@@ -248,3 +248,237 @@ extern "C" int mdh_structure_entropy(double rc, double sigma, int use_local_dens
                        gd, nbins, step, factor, de);
     return sc.finish(space);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// atomic temperature                                          src/atomic_temperature.cpp:9-112
+// cluster analysis (connected components of the bond graph)   src/cluster.cpp:9-153
+// ---------------------------------------------------------------------------------------------------------------
+#include "grid.hpp"
+
+namespace mdh {
+
+__global__ __launch_bounds__(256) void k_atomic_temp(const int *__restrict__ verlet, const double *__restrict__ dist, int64_t N,
+                                                     int64_t M, const double *__restrict__ vx, const double *__restrict__ vy,
+                                                     const double *__restrict__ vz, const double *__restrict__ mass, double rc,
+                                                     double *__restrict__ T)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    constexpr double kb = 1.380649e-23, dim = 3.0, afu = 6.022140857e23;
+    constexpr double mass_factor = 1.0 / afu / 1000.0, vel_conv = 1e4;
+    const int *vi = verlet + i * M;
+    const double *di = dist + i * M;
+    const double mi = mass[i];
+    const double vxi = vx[i], vyi = vy[i], vzi = vz[i];
+    double sx = vxi * mi, sy = vyi * mi, sz = vzi * mi, ms = mi;
+    int n = 1;
+    for (int q = 0; q < M; ++q) { // mass-weighted mean velocity of the neighbourhood (:44-62)
+        const int j = vi[q];
+        if (j < 0)
+            break;
+        if (j != i && di[q] <= rc) {
+            const double mj = mass[j];
+            sx += vx[j] * mj; sy += vy[j] * mj; sz += vz[j] * mj;
+            ++n;
+            ms += mj;
+        }
+    }
+    const double mx = sx / ms, my = sy / ms, mz = sz / ms;
+    double dx = vxi - mx, dy = vyi - my, dz = vzi - mz;
+    double ke = 0.0;
+    ke += 0.5 * mi * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
+    for (int q = 0; q < M; ++q) { // kinetic energy relative to it (:78-101)
+        const int j = vi[q];
+        if (j < 0)
+            break;
+        if (j != i && di[q] <= rc) {
+            const double mj = mass[j];
+            dx = vx[j] - mx; dy = vy[j] - my; dz = vz[j] - mz;
+            ke += 0.5 * mj * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
+        }
+    }
+    T[i] = ke * 2.0 / (dim * n * kb);
+}
+
+// --- connected components: min-index hooking + pointer jumping -------------------------------------------------
+__device__ __forceinline__ int cc_find(int *parent, int i)
+{
+    int p = parent[i];
+    while (p != i) {
+        const int g = parent[p];
+        if (g != p) parent[i] = g; // path halving (benign race: any ancestor is a valid parent)
+        i = p;
+        p = g;
+    }
+    return i;
+}
+
+// BY_BOND: an entry > -1 is a bond (get_cluster_by_bond :63); otherwise distance <= rc (get_cluster :32)
+template <bool BY_BOND>
+__global__ __launch_bounds__(256) void k_cc_hook(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                 const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                 int *__restrict__ parent, int *__restrict__ changed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int n = nn[i];
+    bool any = false;
+    for (int q = 0; q < n; ++q) {
+        const int j = verlet[i * M + q];
+        const bool bond = BY_BOND ? (j > -1) : (dist[i * M + q] <= rc);
+        if (!bond || j < 0 || j >= N)
+            continue;
+        int a = cc_find(parent, (int)i), b = cc_find(parent, j);
+        while (a != b) { // hook the larger root under the smaller one
+            if (a < b) { const int t = a; a = b; b = t; }
+            const int old = atomicMin(&parent[a], b);
+            if (old == a) { any = true; break; }
+            a = cc_find(parent, old < a ? old : a);
+            b = cc_find(parent, b);
+            any = true;
+        }
+    }
+    if (any) *changed = 1;
+}
+
+__global__ __launch_bounds__(256) void k_cc_flatten(int *__restrict__ parent, int64_t N, unsigned *__restrict__ is_root)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int r = cc_find(parent, (int)i);
+    parent[i] = r;
+    is_root[i] = r == (int)i ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_cc_label(const int *__restrict__ parent, const int *__restrict__ rank, int64_t N,
+                                                  int *__restrict__ cluster, int *__restrict__ count)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    cluster[i] = rank[parent[i]] + 1; // clusters are numbered by their smallest atom index, from 1 (:23-27)
+    if (i == 0) *count = rank[N];
+}
+
+__global__ void k_iota(int *p, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void k_filter_by_type(int *__restrict__ verlet, const double *__restrict__ dist,
+                                                        const int *__restrict__ nn, const int *__restrict__ type, int64_t N,
+                                                        int64_t M, const int *__restrict__ t1, const int *__restrict__ t2,
+                                                        const double *__restrict__ r, int ntype)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int n = nn[i], ti = type[i];
+    for (int q = 0; q < n; ++q) {
+        const int j = verlet[i * M + q];
+        if (j < 0)
+            continue; // the reference would index type_list(-1) here; a row is filtered once
+        const int tj = type[j];
+        const double d = dist[i * M + q];
+        bool cut = false;
+        for (int k = 0; k < ntype; ++k)
+            cut = cut || (t1[k] == ti && t2[k] == tj && d > r[k]);
+        if (cut) verlet[i * M + q] = -1;
+    }
+}
+
+} // namespace mdh
+
+extern "C" int mdh_atomic_temperature(const int *verlet, const double *dist, int64_t N, int64_t M, const double *vx,
+                                      const double *vy, const double *vz, const double *mass, double *T, double rc, int space,
+                                      void *stream)
+{
+    if (N < 0 || M <= 0) { set_error("mdh_atomic_temperature: empty neighbor list"); return MDH_ERR_ARG; }
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const double *dd = sc.stage_in(dist, (size_t)(N * M), space);
+    const double *dvx = sc.stage_in(vx, (size_t)N, space), *dvy = sc.stage_in(vy, (size_t)N, space), *dvz = sc.stage_in(vz, (size_t)N, space);
+    const double *dm = sc.stage_in(mass, (size_t)N, space);
+    double *dT = sc.stage(T, (size_t)N, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    ProfRange pr("k_atomic_temp", sc.stream());
+    hipLaunchKernelGGL(k_atomic_temp, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, dvx, dvy, dvz, dm, rc, dT);
+    return sc.finish(space);
+}
+
+// by_bond = 0: get_cluster (dist may not be NULL); by_bond = 1: get_cluster_by_bond (dist unused).
+// cluster (N) i32 receives ids 1..n_clusters; *n_clusters_host receives the count (the functions' return value).
+extern "C" int mdh_cluster(const int *verlet, const double *dist, const int *nn, int64_t N, int64_t M, double rc, int by_bond,
+                           int *cluster, int *n_clusters_host, int space, void *stream)
+{
+    if (N < 0 || M <= 0 || (!by_bond && !dist)) { set_error("mdh_cluster: empty neighbor list"); return MDH_ERR_ARG; }
+    if (n_clusters_host) *n_clusters_host = 0;
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
+    const double *dd = by_bond ? nullptr : sc.stage_in(dist, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    int *dc = sc.stage(cluster, (size_t)N, space, false, true);
+    int *parent = sc.alloc_n<int>((size_t)N);
+    unsigned *is_root = sc.alloc_n<unsigned>((size_t)N);
+    int *rank = sc.alloc_n<int>((size_t)N + 1);
+    int *flag = sc.alloc_n<int>(2);
+    if (sc.failed())
+        return sc.error();
+    const dim3 grid(grid_for(N, 256)), block(256);
+    hipLaunchKernelGGL(k_iota, grid, block, 0, st, parent, N);
+    // one hooking pass joins every bond's two trees (the loop inside retries until its pair is merged); a second pass
+    // only confirms that nothing is left to do.  The flag is read back once per pass: this analysis is not on a hot loop.
+    for (int pass = 0; pass < 64; ++pass) {
+        MDH_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+        if (by_bond)
+            hipLaunchKernelGGL(k_cc_hook<true>, grid, block, 0, st, dv, dd, dn, N, M, rc, parent, flag);
+        else
+            hipLaunchKernelGGL(k_cc_hook<false>, grid, block, 0, st, dv, dd, dn, N, M, rc, parent, flag);
+        int h = 0;
+        MDH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        MDH_HIP(hipStreamSynchronize(st));
+        if (!h)
+            break;
+    }
+    hipLaunchKernelGGL(k_cc_flatten, grid, block, 0, st, parent, N, is_root);
+    MDH_TRY(exclusive_scan_u32(sc, is_root, rank, N));
+    hipLaunchKernelGGL(k_cc_label, grid, block, 0, st, parent, rank, N, dc, flag + 1);
+    int cnt = 0;
+    MDH_HIP(hipMemcpyAsync(&cnt, flag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDH_HIP(hipStreamSynchronize(st));
+    if (n_clusters_host) *n_clusters_host = cnt;
+    return sc.finish(space);
+}
+
+// replaces _cluster.filter_by_type (src/cluster.cpp:110-148): verlet entries whose pair distance exceeds the cutoff of
+// their (type_i, type_j) pair become -1.  t1, t2, r: host arrays of length ntype.
+extern "C" int mdh_filter_by_type(int *verlet, const double *dist, const int *nn, const int *type, int64_t N, int64_t M,
+                                  const int *t1_host, const int *t2_host, const double *r_host, int ntype, int space,
+                                  void *stream)
+{
+    if (N < 0 || M <= 0 || ntype < 0) { set_error("mdh_filter_by_type: bad sizes"); return MDH_ERR_ARG; }
+    if (N == 0 || ntype == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    int *dv = sc.stage(verlet, (size_t)(N * M), space, true, true);
+    const double *dd = sc.stage_in(dist, (size_t)(N * M), space);
+    const int *dn = sc.stage_in(nn, (size_t)N, space);
+    const int *dt = sc.stage_in(type, (size_t)N, space);
+    const int *d1 = sc.stage_in(t1_host, (size_t)ntype, MDH_HOST), *d2 = sc.stage_in(t2_host, (size_t)ntype, MDH_HOST);
+    const double *dr = sc.stage_in(r_host, (size_t)ntype, MDH_HOST);
+    if (sc.failed())
+        return sc.error();
+    hipLaunchKernelGGL(k_filter_by_type, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, dn, dt, N, M, d1, d2, dr, ntype);
+    MDH_HIP(hipStreamSynchronize(sc.stream())); // t1/t2/r are staged from caller memory
+    return sc.finish(space);
+}

@@ -101,4 +101,7 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g);
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
                     bool wrap_first, bool sort_desc, CellGrid &cg);
 
+// neighbor.hip: out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
+int exclusive_scan_u32(Scope &sc, const unsigned *in, int *out, int64_t n);
+
 } // namespace mdh

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(unsigned *__restrict__
         if (idx < nb) block_sum[idx] = carry + ex;
         carry += tot;
     }
+    if (threadIdx.x == 0) block_sum[nb] = carry; // grand total (slot nb is always allocated)
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int *__restrict__ out, const unsigned *__restrict__ block_sum,
@@ -145,7 +146,23 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int *__restrict__ out, 
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
         if (base + k < n) out[base + k] += (int)off;
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total >= 0 ? total : (int)block_sum[gridDim.x];
+}
+
+// out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); for other translation units (grid.hpp)
+int exclusive_scan_u32(Scope &sc, const unsigned *in, int *out, int64_t n)
+{
+    const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
+    const int64_t nblk = (n + per - 1) / per;
+    unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk + 1);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, in, out, block_sum, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, out, block_sum, n, -1);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
 }
 
 __global__ __launch_bounds__(256) void k_scatter(const int *__restrict__ cell_id, const int *__restrict__ rank,
@@ -232,7 +249,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     unsigned char *mv = sc.alloc_n<unsigned char>((size_t)N);
     cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
     const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-    unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk);
+    unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk + 1);
     cg.flags = sc.alloc_n<int>(4);
     if (sc.failed())
         return sc.error();

@@ -20,8 +20,10 @@ import numpy as np
 
 from . import tool_function as tool
 from .ackland_jones_analysis import AcklandJonesAnalysis
+from .atomic_temperature import AtomicTemperature
 from .box import Box
 from .centro_symmetry_parameter import CentroSymmetryParameter
+from .cluster_analysis import ClusterAnalysis
 from .common_neighbor_analysis import CommonNeighborAnalysis
 from .common_neighbor_parameter import CommonNeighborParameter
 from .devarray import as_numpy
@@ -230,6 +232,38 @@ class System:
         if average_rc > 0:
             data = data.with_columns(entropy_ave=as_numpy(se.entropy_ave)[: self.N])
         self.update_data(data)
+
+    def cal_atomic_temperature(self, rc: float, factor: float = 1.0, max_neigh: Optional[int] = None) -> None:
+        """column ``atomic_temp`` in K; velocities in A/fs x factor (system.py:1678-1714)"""
+        has_neigh = hasattr(self, "rc") and self.rc >= rc
+        if not has_neigh:
+            self.build_neighbor(rc, max_neigh)
+        _, data = self._get_compute_view()
+        at = AtomicTemperature(data, self.verlet_list, self.distance_list, rc, factor)
+        at.compute()
+        self.update_data(self.data.with_columns(atomic_temp=as_numpy(at.T)[: self.N]))
+
+    def cal_cluster_analysis(self, rc=5.0, max_neigh: Optional[int] = None) -> None:
+        """column ``cluster_id`` (system.py:2416-2479)"""
+        if isinstance(rc, (int, float, np.integer, np.floating)):
+            max_rc = float(rc)
+        elif isinstance(rc, dict):
+            max_rc = max(rc.values())
+        else:
+            raise TypeError("rc should be a positive number, or a dict like {'1-1':1.5, '1-2':1.3}")
+        if hasattr(self, "rc"):
+            if self.rc < max_rc:
+                self.build_neighbor(max_rc, max_neigh)
+        else:
+            self.build_neighbor(max_rc, max_neigh)
+        type_list = None
+        if isinstance(rc, dict):
+            assert "type" in self.data.columns, "Must have type for multi rc cluster calculation."
+            type_list = np.ascontiguousarray(self.data["type"].to_numpy(), dtype=np.int32)
+        ca = ClusterAnalysis(rc, self.verlet_list, self.distance_list, self.neighbor_number, type_list)
+        ca.compute()
+        self.cluster_number = ca.cluster_number
+        self.update_data(self.data.with_columns(cluster_id=as_numpy(ca.particleClusters)[: self.N]))
 
     def cal_centro_symmetry_parameter(self, N: int):
         """column ``csp`` (system.py:1972-2003)"""

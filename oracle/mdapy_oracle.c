@@ -1345,3 +1345,81 @@ ORC_API int orc_structure_entropy(double rc, double sigma, int use_local_density
     free(rl); free(rl2); free(pre);
     return 0;
 }
+
+/* atomic temperature                                          src/atomic_temperature.cpp:9-112 */
+ORC_API int orc_atomic_temperature(const int *verlet, const double *dist, int64_t n_atoms, int64_t M, const double *vx,
+                                   const double *vy, const double *vz, const double *mass, double *T, double rc, int num_t)
+{
+    const double kb = 1.380649e-23, dim = 3.0, afu = 6.022140857e23;
+    const double mass_factor = 1.0 / afu / 1000.0, vel_conv = 1e4;
+#pragma omp parallel for num_threads(num_t > 0 ? num_t : 1) schedule(static)
+    for (int64_t i = 0; i < n_atoms; ++i) {
+        const int *vi = verlet + i * M;
+        const double *di = dist + i * M;
+        const double mi = mass[i];
+        double sx = vx[i] * mi, sy = vy[i] * mi, sz = vz[i] * mi, ms = mi;
+        int n = 1;
+        for (int q = 0; q < M; ++q) {
+            const int j = vi[q];
+            if (j < 0) break;
+            if (j != i && di[q] <= rc) { sx += vx[j] * mass[j]; sy += vy[j] * mass[j]; sz += vz[j] * mass[j]; ++n; ms += mass[j]; }
+        }
+        const double mx = sx / ms, my = sy / ms, mz = sz / ms;
+        double dx = vx[i] - mx, dy = vy[i] - my, dz = vz[i] - mz;
+        double ke = 0.0;
+        ke += 0.5 * mi * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
+        for (int q = 0; q < M; ++q) {
+            const int j = vi[q];
+            if (j < 0) break;
+            if (j != i && di[q] <= rc) {
+                dx = vx[j] - mx; dy = vy[j] - my; dz = vz[j] - mz;
+                ke += 0.5 * mass[j] * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
+            }
+        }
+        T[i] = ke * 2.0 / (dim * n * kb);
+    }
+    return 0;
+}
+
+/* cluster analysis: serial breadth-first flood fill            src/cluster.cpp:9-106 (get_cluster / get_cluster_by_bond) */
+ORC_API int orc_cluster(const int *verlet, const double *dist, const int *nn, int64_t n_atoms, int64_t M, double rc,
+                        int by_bond, int *cluster)
+{
+    int *queue = (int *)malloc(sizeof(int) * (size_t)(n_atoms > 0 ? n_atoms * 2 + 2 : 2));
+    int cid = 0;
+    for (int64_t seed = 0; seed < n_atoms; ++seed) {
+        if (cluster[seed] != -1) continue;
+        int64_t head = 0, tail = 0, cap = n_atoms * 2 + 2;
+        queue[tail++] = (int)seed;
+        ++cid;
+        while (head < tail) {
+            const int cur = queue[head++];
+            int nl = 0;
+            for (int j = 0; j < nn[cur]; ++j) {
+                const int nb = verlet[(int64_t)cur * M + j];
+                const int bond = by_bond ? (nb > -1) : (dist[(int64_t)cur * M + j] <= rc);
+                if (bond) {
+                    ++nl;
+                    if (cluster[nb] == -1) { cluster[nb] = cid; if (tail < cap) queue[tail++] = nb; }
+                }
+            }
+            if (nl == 0) cluster[cur] = cid;
+        }
+    }
+    free(queue);
+    return cid;
+}
+
+/* src/cluster.cpp:108-148 */
+ORC_API int orc_filter_by_type(int *verlet, const double *dist, const int *nn, const int *type, int64_t n_atoms, int64_t M,
+                               const int *t1, const int *t2, const double *r, int ntype)
+{
+    for (int64_t i = 0; i < n_atoms; ++i)
+        for (int q = 0; q < nn[i]; ++q) {
+            const int j = verlet[i * M + q];
+            if (j < 0) continue;
+            for (int k = 0; k < ntype; ++k)
+                if (t1[k] == type[i] && t2[k] == type[j] && dist[i * M + q] > r[k]) verlet[i * M + q] = -1;
+        }
+    return 0;
+}

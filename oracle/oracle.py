@@ -307,3 +307,35 @@ def calculate_structure_entropy(rc, sigma, use_local_density, volume, distance_l
     _chk(lib().orc_structure_entropy(dbl(rc), dbl(sigma), cint(bool(use_local_density)), dbl(volume), _p(d, np.float64),
                                      _p(n, np.int32), i64(d.shape[0]), i64(d.shape[1]), _p(entropy, np.float64),
                                      cint(num_t)))
+
+
+def compute_temp(verlet_list, distance_list, vx, vy, vz, mass, T, rc, num_t=1):
+    """mdapy._atomtemp.compute_temp (src/atomic_temperature.cpp:9)"""
+    v, d = _ro(verlet_list, np.int32), _ro(distance_list, np.float64)
+    a = [_ro(q, np.float64) for q in (vx, vy, vz, mass)]
+    _chk(lib().orc_atomic_temperature(_p(v, np.int32), _p(d, np.float64), i64(v.shape[0]), i64(v.shape[1]),
+                                      _p(a[0], np.float64), _p(a[1], np.float64), _p(a[2], np.float64), _p(a[3], np.float64),
+                                      _p(T, np.float64), dbl(rc), cint(num_t)))
+
+
+def get_cluster(verlet_list, distance_list, neighbor_number, rc, particleClusters):
+    """mdapy._cluster.get_cluster (src/cluster.cpp:9); particleClusters pre-filled with -1; returns the cluster count"""
+    v, d, n = _ro(verlet_list, np.int32), _ro(distance_list, np.float64), _ro(neighbor_number, np.int32)
+    return int(lib().orc_cluster(_p(v, np.int32), _p(d, np.float64), _p(n, np.int32), i64(v.shape[0]), i64(v.shape[1]),
+                                 dbl(rc), cint(0), _p(particleClusters, np.int32)))
+
+
+def get_cluster_by_bond(verlet_list, neighbor_number, particleClusters):
+    """mdapy._cluster.get_cluster_by_bond (src/cluster.cpp:58)"""
+    v, n = _ro(verlet_list, np.int32), _ro(neighbor_number, np.int32)
+    return int(lib().orc_cluster(_p(v, np.int32), None, _p(n, np.int32), i64(v.shape[0]), i64(v.shape[1]), dbl(0.0),
+                                 cint(1), _p(particleClusters, np.int32)))
+
+
+def filter_by_type(verlet_list, distance_list, neighbor_number, type_list, type1, type2, r, num_t=1):
+    """mdapy._cluster.filter_by_type (src/cluster.cpp:108); verlet_list modified in place"""
+    d, n, t = _ro(distance_list, np.float64), _ro(neighbor_number, np.int32), _ro(type_list, np.int32)
+    t1, t2, rr = _ro(type1, np.int32), _ro(type2, np.int32), _ro(r, np.float64)
+    _chk(lib().orc_filter_by_type(_p(verlet_list, np.int32), _p(d, np.float64), _p(n, np.int32), _p(t, np.int32),
+                                  i64(verlet_list.shape[0]), i64(verlet_list.shape[1]), _p(t1, np.int32), _p(t2, np.int32),
+                                  _p(rr, np.float64), cint(len(t1))))

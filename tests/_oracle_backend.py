@@ -70,12 +70,28 @@ cnp = _mod(compute_cnp=lambda x, y, z, box, origin, boundary, v, d, nn, out, rc,
            O.compute_cnp(_np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(d), _np(nn), out, rc, NT))
 structure_entropy = _mod(calculate_structure_entropy=lambda rc, sigma, loc, vol, d, nn, out, num_t=1:
                          O.calculate_structure_entropy(rc, sigma, loc, vol, _np(d), _np(nn), out, NT))
+atomtemp = _mod(compute_temp=lambda v, d, vx, vy, vz, m, T, rc, num_t=1:
+                O.compute_temp(_np(v), _np(d), _np(vx), _np(vy), _np(vz), _np(m), T, rc, NT))
+
+
+def _fill(a):
+    a.fill(-1)
+    return a
+
+
+cluster = _mod(
+    get_cluster=lambda v, d, nn, rc, out: O.get_cluster(_np(v), _np(d), _np(nn), rc, _fill(out)),
+    get_cluster_by_bond=lambda v, nn, out: O.get_cluster_by_bond(_np(v), _np(nn), _fill(out)),
+    filter_by_type=lambda v, d, nn, t, t1, t2, r, num_t=1: O.filter_by_type(v, _np(d), _np(nn), _np(t), t1, t2, r, NT),
+)
 repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
 
 
 def install(monkeypatch):
     import mdapy_amd.ackland_jones_analysis as m_aja
+    import mdapy_amd.atomic_temperature as m_at
     import mdapy_amd.build_lattice as bl
+    import mdapy_amd.cluster_analysis as m_cl
     import mdapy_amd.common_neighbor_parameter as m_cnp
     import mdapy_amd.structure_entropy as m_se
     import mdapy_amd.centro_symmetry_parameter as m_csp
@@ -102,6 +118,8 @@ def install(monkeypatch):
     monkeypatch.setattr(m_rdf, "_rdf", rdf)
     monkeypatch.setattr(m_wcp, "_wcp", wcp)
     monkeypatch.setattr(m_aja, "_aja", aja)
+    monkeypatch.setattr(m_at, "_atomtemp", atomtemp)
+    monkeypatch.setattr(m_cl, "_cluster", cluster)
     monkeypatch.setattr(m_cnp, "_cnp", cnp)
     monkeypatch.setattr(m_se, "_structure_entropy", structure_entropy)
     monkeypatch.setattr(m_se, "_neighbor", neighbor)

@@ -556,3 +556,48 @@ def test_golden_structure_entropy(name, mode):
         s.cal_structure_entropy(5.0, 0.2, mode == "use_local_density")
         got = s.data["entropy"].to_numpy()
     assert np.allclose(got, expected, atol=1e-6)
+
+
+from mdapy_amd import _atomtemp, _cluster
+
+
+@pytest.mark.parametrize("case", ["fcc_rattled", "triclinic_random", "random_gas", "dense_blob"])
+def test_atomic_temperature_and_cluster_vs_oracle(case):
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    x, y, z = _xyz(pos)
+    N = len(pos)
+    rng = np.random.default_rng(12)
+    rc = 3.0
+    v, d, nn = O.build_neighbor_without_max_neigh(x, y, z, box, origin, bd, rc, 4)
+    vel = rng.normal(0, 300.0, (N, 3))
+    mass = rng.choice([26.98, 58.69, 63.546], N)
+    t0, t1 = np.zeros(N), np.full(N, -1.0)
+    O.compute_temp(v, d, vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy(), mass, t0, 2.8, 4)
+    _atomtemp.compute_temp(v, d, vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy(), mass, t1, 2.8, 1)
+    assert np.allclose(t1, t0, rtol=1e-12, atol=0)
+    for cut in (1.2, 2.0, 2.8):  # from many small clusters to a few big ones
+        c0, c1 = np.full(N, -1, np.int32), np.full(N, -7, np.int32)
+        n0 = O.get_cluster(v, d, nn, cut, c0)
+        n1 = _cluster.get_cluster(v, d, nn, cut, c1)
+        assert n1 == n0 and np.array_equal(c1, c0)
+    ty = rng.integers(1, 3, N).astype(np.int32)
+    t1a, t2a, r = np.array([1, 2, 1, 2], np.int32), np.array([1, 2, 2, 1], np.int32), np.array([2.8, 2.8, 1.5, 1.5])
+    va, vb = v.copy(), v.copy()
+    O.filter_by_type(va, d, nn, ty, t1a, t2a, r)
+    _cluster.filter_by_type(vb, d, nn, ty, t1a, t2a, r)
+    assert np.array_equal(vb, va) and (va != v).any()
+    c0, c1 = np.full(N, -1, np.int32), np.full(N, -7, np.int32)
+    assert _cluster.get_cluster_by_bond(vb, nn, c1) == O.get_cluster_by_bond(va, nn, c0)
+    assert np.array_equal(c1, c0)
+
+
+def test_cluster_system_flow_large():
+    """1 M atoms: two half-spaces separated by a gap wider than rc -> exactly 2 clusters (periodic in x,y; open in z)"""
+    pos, box = _fcc(64, 0.02, 3)
+    L = box[2, 2] if np.ndim(box) == 2 else box[2]
+    pos = pos[(pos[:, 2] < 0.4 * L) | (pos[:, 2] > 0.6 * L)]
+    s = mp.System(pos=pos, box=mp.Box(box, boundary=[1, 1, 0]))
+    s.cal_cluster_analysis(3.0)
+    cid = s.data["cluster_id"].to_numpy()
+    assert s.cluster_number == 2 and set(np.unique(cid)) == {1, 2}
+    assert np.array_equal(cid == cid[0], (pos[:, 2] < 0.5 * L) == (pos[0, 2] < 0.5 * L))

@@ -294,3 +294,59 @@ def test_structure_entropy_against_fixture(name, mode, oracle_backend):
         s.cal_structure_entropy(5.0, 0.2, mode == "use_local_density")
         got = s.data["entropy"].to_numpy()
     assert np.allclose(got, expected, atol=1e-6)
+
+
+# ---------------------------------------------------------------- atomic temperature / cluster analysis (no reference fixtures:
+# tests/test_atomic_temperature.py needs generate_velocity + the mass table; closed-form checks instead)
+def test_atomic_temperature_closed_forms(oracle_backend):
+    s = mp.build_crystal("Cu", "fcc", 3.615, nx=6, ny=6, nz=6)
+    rng = np.random.default_rng(2)
+    n = s.N
+    s.update_data(s.data.with_columns(vx=np.full(n, 1.5), vy=np.full(n, -0.5), vz=np.zeros(n)))
+    s.cal_atomic_temperature(5.0)
+    assert np.allclose(s.data["atomic_temp"].to_numpy(), 0.0, atol=1e-9)      # rigid translation: no thermal motion
+    # Maxwell velocities at T0: the neighbourhood temperature scatters around T0 * (n-1)/n (centre-of-mass removed)
+    kb, amu, T0, m = 1.380649e-23, 1.0 / 6.022140857e23 / 1000.0, 300.0, 63.546
+    sig = np.sqrt(kb * T0 / (m * amu)) / 1e5                                   # A/fs
+    v = rng.normal(0, sig, (n, 3))
+    s.update_data(s.data.with_columns(vx=v[:, 0], vy=v[:, 1], vz=v[:, 2]))
+    s.cal_atomic_temperature(8.0)
+    t = s.data["atomic_temp"].to_numpy()
+    assert abs(t.mean() / T0 - 1.0) < 0.03 and t.min() > 150 and t.max() < 450
+
+
+def test_cluster_analysis_known_components(oracle_backend):
+    rng = np.random.default_rng(4)
+    blobs = [rng.random((40, 3)) * 4.0 + c for c in ([5, 5, 5], [25, 25, 25], [5, 25, 5])]
+    lone = np.array([[40.0, 40.0, 40.0], [45.0, 10.0, 30.0]])
+    pos = np.concatenate(blobs + [lone])
+    perm = rng.permutation(len(pos))
+    pos = pos[perm]
+    s = mp.System(pos=pos, box=np.eye(3) * 50.0)
+    s.cal_cluster_analysis(3.0)
+    cid = s.data["cluster_id"].to_numpy()
+    # brute-force components, numbered by smallest member index
+    d = np.linalg.norm(pos[:, None] - pos[None], axis=2)
+    lab = np.arange(len(pos))
+    for _ in range(len(pos)):
+        new = np.array([lab[d[i] <= 3.0].min() for i in range(len(pos))])
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    roots = np.unique(lab)
+    expect = np.searchsorted(roots, lab) + 1
+    assert np.array_equal(cid, expect) and s.cluster_number == len(roots)
+    # type-pair cutoffs: bonds between unlike types are cut at 1.0
+    ty = (rng.random(len(pos)) < 0.5).astype(np.int32) + 1
+    s2 = mp.System(pos=pos, box=np.eye(3) * 50.0)
+    s2.update_data(s2.data.with_columns(type=ty))
+    s2.cal_cluster_analysis({"1-1": 3.0, "2-2": 3.0, "1-2": 1.0})
+    bond = (d <= 3.0) & ((ty[:, None] == ty[None]) | (d <= 1.0))
+    lab = np.arange(len(pos))
+    for _ in range(len(pos)):
+        new = np.array([lab[bond[i]].min() for i in range(len(pos))])
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    roots = np.unique(lab)
+    assert np.array_equal(s2.data["cluster_id"].to_numpy(), np.searchsorted(roots, lab) + 1)
