@@ -218,6 +218,13 @@ int mdh_cluster(const int *verlet, const double *dist, const int *nn, int64_t N,
 int mdh_filter_by_type(int *verlet, const double *dist, const int *nn, const int *type, int64_t N, int64_t M,
                        const int *t1_host, const int *t2_host, const double *r_host, int ntype, int space, void *stream);
 
+/* replaces _fccpft.identify_sftb_fcc                       src/identify_fcc_planar_faults.cpp:54-245
+ * hcp_indices (n_hcp) ascending atom ids with structure type 2; hcp_neighbors (n_hcp,12) caller scratch (written);
+ * ptm_indices (N,12) = columns 1..12 of the PTM neighbour rows; fault_types (N) pre-zeroed, HCP entries written:
+ * 1 other, 2 intrinsic SF, 3 twin boundary, 4 multi-layer SF, 5 extrinsic SF (only with identify_esf). */
+int mdh_identify_sftb_fcc(const int *hcp_indices, int64_t n_hcp, int *hcp_neighbors, const int *ptm_indices,
+                          const int *structure_types, int64_t N, int *fault_types, int identify_esf, int space, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

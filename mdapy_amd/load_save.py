@@ -102,9 +102,7 @@ def read_dump(path) -> Tuple[Frame, Box, Dict[str, Any]]:
                     cols[name] = col
                 else:
                     cols[name] = col.astype(np.float64)
-            if "id" in cols:  # the reference sorts dump rows by id
-                order = np.argsort(cols["id"], kind="stable")
-                cols = {k: v[order] for k, v in cols.items()}
+            # rows stay in file order, as in the reference (load_save.py:66-200 keeps the dump's row order)
             ordered = {k: cols[k] for k in ("x", "y", "z")}
             ordered.update({k: v for k, v in cols.items() if k not in ordered})
             return Frame(ordered), Box(box, boundary, origin), info

@@ -29,6 +29,7 @@ from .common_neighbor_parameter import CommonNeighborParameter
 from .devarray import as_numpy
 from .frame import Frame
 from .identify_diamond_structure import IdentifyDiamondStructure
+from .identify_fcc_planar_faults import IdentifyFccPlanarFaults
 from .knn import NearestNeighbor
 from .neighbor import Neighbor
 from .polyhedral_template_matching import PolyhedralTemplateMatching
@@ -166,9 +167,10 @@ class System:
         self.update_data(self.__data.with_columns(cna=as_numpy(cna.pattern)[: self.N]))
 
     def cal_polyhedral_template_matching(self, structure="fcc-hcp-bcc", rmsd_threshold=0.1, return_ordering=False,
-                                         return_rmsd=False, return_atomic_distance=False, return_orientation=False):
-        """column ``ptm`` (+ ``ordering``, ``rmsd``, ``interatomic_distance``, ``qx,qy,qz,qw``) (system.py:1863-1970);
-        the FCC planar-fault post-processing (``identify_fcc_planar_faults``) is outside the hot path."""
+                                         return_rmsd=False, return_atomic_distance=False, return_orientation=False,
+                                         identify_fcc_planar_faults=False, identify_esf=True):
+        """column ``ptm`` (+ ``ordering``, ``rmsd``, ``interatomic_distance``, ``qx,qy,qz,qw``, ``pft``)
+        (system.py:1863-1970)"""
         verlet_list = None
         if sum(self._safe_repeat()) == 3:
             if hasattr(self, "neighbor_number"):
@@ -189,6 +191,12 @@ class System:
         if return_orientation:
             new.update(qx=output[:, 5], qy=output[:, 6], qz=output[:, 7], qw=output[:, 4])
         self.ptm_indices = ptm.ptm_indices
+        if identify_fcc_planar_faults:  # system.py:1963-1968
+            structure_types = np.array(as_numpy(ptm.output)[:, 0], np.int32)
+            ptm12 = np.ascontiguousarray(as_numpy(ptm.ptm_indices)[:, 1:13])
+            ifpt = IdentifyFccPlanarFaults(structure_types, ptm12, identify_esf)
+            ifpt.compute()
+            new["pft"] = ifpt.fault_types[: self.N]
         self.update_data(self.__data.with_columns(**new))
 
     def cal_common_neighbor_parameter(self, rc: float, max_neigh: Optional[int] = None) -> None:

@@ -1423,3 +1423,88 @@ ORC_API int orc_filter_by_type(int *verlet, const double *dist, const int *nn, c
         }
     return 0;
 }
+
+/* FCC planar faults (stacking faults / twin boundaries among HCP-labelled atoms of an FCC crystal)
+ *                                                              src/identify_fcc_planar_faults.cpp:9-245
+ * fault: 0 non-hcp, 1 other, 2 intrinsic SF, 3 twin boundary, 4 multi-layer SF, 5 extrinsic SF */
+static int pft_stacked(int a, int b, const int *hn)
+{
+    static const int basal[6] = {0, 1, 5, 6, 7, 8};
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j)
+            if (hn[a * 12 + basal[i]] == hn[b * 12 + basal[j]]) return 0;
+    return 1;
+}
+static int pft_bsearch(const int *arr, int n, int value)
+{
+    int left = 0, right = n - 1, mid = 0;
+    while (left <= right) {
+        mid = (left + right) / 2;
+        if (value < arr[mid]) right = mid - 1;
+        else if (value > arr[mid]) left = mid + 1;
+        else break;
+    }
+    return mid;
+}
+ORC_API int orc_identify_sftb_fcc(const int *hcp_idx, int64_t n_hcp, int *hn, const int *ptm12, const int *stype,
+                                  int64_t n_atoms, int *fault, int identify_esf)
+{
+    static const int layer_dir[12] = {0, 0, -1, -1, -1, 0, 0, 0, 0, 1, 1, 1};
+    static const int basal[6] = {0, 1, 5, 6, 7, 8}, oop[6] = {2, 3, 4, 9, 10, 11};
+    (void)n_atoms;
+    for (int64_t i = 0; i < n_hcp; ++i)                                   /* :72-86 */
+        for (int j = 0; j < 12; ++j) {
+            const int b = ptm12[(int64_t)hcp_idx[i] * 12 + j];
+            hn[i * 12 + j] = stype[b] == 2 ? pft_bsearch(hcp_idx, (int)n_hcp, b) : -b - 1;
+        }
+    for (int64_t i = 0; i < n_hcp; ++i) {                                 /* :88-137 */
+        int nb = 0, np_ = 0, nn_ = 0, fp = 0, fn = 0;
+        for (int j = 0; j < 12; ++j) {
+            const int q = hn[i * 12 + j];
+            if (q >= 0) {
+                if (layer_dir[j] == 0) ++nb;
+                else if (pft_stacked((int)i, q, hn)) { if (layer_dir[j] == 1) ++np_; else ++nn_; }
+            } else if (layer_dir[j] != 0) {
+                if (stype[-q - 1] == 1) { if (layer_dir[j] > 0) ++fp; else ++fn; }
+            }
+        }
+        int f;
+        if ((np_ != 0 && nn_ == 0) || (np_ == 0 && nn_ != 0)) f = 2;
+        else if (nb >= 1 && np_ == 0 && nn_ == 0 && fp != 0 && fn != 0) f = 3;
+        else if (np_ != 0 && nn_ != 0) f = 4;
+        else f = 1;
+        fault[hcp_idx[i]] = f;
+    }
+    for (int64_t i = 0; i < n_hcp; ++i) {                                 /* :139-180: serial, order dependent */
+        const int a = hcp_idx[i];
+        if (fault[a] == 3 || fault[a] == 1) {
+            int nisf = 0, ntw = 0;
+            for (int jj = 0; jj < 6; ++jj) {
+                const int q = hn[i * 12 + basal[jj]];
+                if (q >= 0) { const int nf = fault[hcp_idx[q]]; if (nf == 2) ++nisf; else if (nf == 3) ++ntw; }
+            }
+            if (nisf != 0 && ntw == 0) fault[a] = 2; else if (nisf == 0 && ntw != 0) fault[a] = 3;
+        } else if (fault[a] == 4) {
+            for (int jj = 0; jj < 6; ++jj) {
+                const int q = hn[i * 12 + oop[jj]];
+                if (q >= 0 && fault[hcp_idx[q]] == 2) fault[hcp_idx[q]] = 4;
+            }
+        }
+    }
+    if (!identify_esf) return 0;
+    for (int64_t i = 0; i < n_hcp; ++i) {                                 /* :185-217 */
+        const int a = hcp_idx[i];
+        if (fault[a] != 3) continue;
+        for (int j = 0; j < 12; ++j) {
+            const int jn = ptm12[(int64_t)a * 12 + j];
+            if (stype[jn] != 1) continue;
+            int fc = 0, hc = 0;
+            for (int k = 0; k < 12; ++k) {
+                const int t = stype[ptm12[(int64_t)jn * 12 + k]];
+                if (t == 1) ++fc; else if (t == 2) ++hc;
+            }
+            if (fc >= 5 && fc <= 6 && hc >= 5 && hc <= 6) { fault[a] = 5; break; }
+        }
+    }
+    return 0;
+}

@@ -339,3 +339,10 @@ def filter_by_type(verlet_list, distance_list, neighbor_number, type_list, type1
     _chk(lib().orc_filter_by_type(_p(verlet_list, np.int32), _p(d, np.float64), _p(n, np.int32), _p(t, np.int32),
                                   i64(verlet_list.shape[0]), i64(verlet_list.shape[1]), _p(t1, np.int32), _p(t2, np.int32),
                                   _p(rr, np.float64), cint(len(t1))))
+
+
+def identify_sftb_fcc(hcp_indices, hcp_neighbors, ptm_indices, structure_types, fault_types, identify_esf, num_t=1):
+    """mdapy._fccpft.identify_sftb_fcc (src/identify_fcc_planar_faults.cpp:54)"""
+    h, p, s = _ro(hcp_indices, np.int32), _ro(ptm_indices, np.int32), _ro(structure_types, np.int32)
+    _chk(lib().orc_identify_sftb_fcc(_p(h, np.int32), i64(h.shape[0]), _p(hcp_neighbors, np.int32), _p(p, np.int32),
+                                     _p(s, np.int32), i64(s.shape[0]), _p(fault_types, np.int32), cint(bool(identify_esf))))

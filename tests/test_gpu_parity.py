@@ -601,3 +601,33 @@ def test_cluster_system_flow_large():
     cid = s.data["cluster_id"].to_numpy()
     assert s.cluster_number == 2 and set(np.unique(cid)) == {1, 2}
     assert np.array_equal(cid == cid[0], (pos[:, 2] < 0.5 * L) == (pos[0, 2] < 0.5 * L))
+
+
+# ------------------------------------------------------------------ FCC planar faults (ordered sweep reproduced in parallel rounds)
+from mdapy_amd import _fccpft
+
+
+def test_fcc_planar_faults_fixture_and_oracle():
+    expected = misc("fcc_planar_faults")["pft"]
+    s = mp.System(input_path("ISF.dump"))
+    s.cal_polyhedral_template_matching("all", identify_fcc_planar_faults=True, identify_esf=False)
+    got = s.data["pft"].to_numpy()
+    assert np.array_equal(got, expected)
+    # same PTM output, ESF pass on, and a scrambled atom order (the sweep is order dependent): HIP == serial oracle
+    st = s.data["ptm"].to_numpy().astype(np.int32)
+    p12 = np.ascontiguousarray(np.asarray(s.ptm_indices)[:, 1:13]).astype(np.int32)
+    rng = np.random.default_rng(8)
+    for scramble in (False, True):
+        if scramble:
+            perm = rng.permutation(len(st))
+            inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+            st_, p_ = st[perm], np.where(p12[perm] >= 0, inv[np.clip(p12[perm], 0, None)], -1).astype(np.int32)
+        else:
+            st_, p_ = st, p12
+        h = np.where(st_ == 2)[0].astype(np.int32)
+        f0, f1 = np.zeros_like(st_), np.zeros_like(st_)
+        hn0, hn1 = np.zeros((len(h), 12), np.int32), np.zeros((len(h), 12), np.int32)
+        O.identify_sftb_fcc(h, hn0, p_, st_, f0, True)
+        _fccpft.identify_sftb_fcc(h, hn1, p_, st_, f1, True)
+        assert np.array_equal(hn1, hn0) and np.array_equal(f1, f0)
+        assert len(np.unique(f0)) >= 4

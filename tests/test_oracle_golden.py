@@ -350,3 +350,13 @@ def test_cluster_analysis_known_components(oracle_backend):
         lab = new
     roots = np.unique(lab)
     assert np.array_equal(s2.data["cluster_id"].to_numpy(), np.searchsorted(roots, lab) + 1)
+
+
+# reference: tests/test_identify_fcc_planar_faults.py:9-19 (103 056-atom Cu dump with an intrinsic stacking fault)
+@needs_ref
+def test_fcc_planar_faults_against_fixture(oracle_backend):
+    expected = misc("fcc_planar_faults")["pft"]
+    s = mp.System(input_path("ISF.dump"))
+    s.cal_polyhedral_template_matching("all", identify_fcc_planar_faults=True, identify_esf=False)
+    got = s.data["pft"].to_numpy()
+    assert np.array_equal(got, expected), f"{int(np.sum(got != expected))} mismatches; labels {np.bincount(expected)}"
