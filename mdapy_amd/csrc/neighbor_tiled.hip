@@ -35,9 +35,15 @@
 
 namespace mdh {
 
-static constexpr int HALO_CAP = 1024; // atoms a tile's halo may hold in LDS (31 B each)
+#ifndef MDH_HALO_CAP
+#define MDH_HALO_CAP 1024
+#endif
+static constexpr int HALO_CAP = MDH_HALO_CAP; // atoms a tile's halo may hold in LDS (31 B each)
 static constexpr int NT = 256;        // threads per workgroup
-static constexpr int MAX_NH = 512;    // halo cells a tile may have
+#ifndef MDH_MAX_NH
+#define MDH_MAX_NH 512
+#endif
+static constexpr int MAX_NH = MDH_MAX_NH;    // halo cells a tile may have
 static constexpr int MAX_COLS = 64;   // (x,y) columns of centre cells a tile may have
 static constexpr int TICK_STRIDE = NT + 2; // ticket slot stride (u16 units): 516 B -> consecutive slots shift by one bank
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4); // image code of "no shift": (n+1) per axis, 2 bits each
