@@ -225,6 +225,12 @@ int mdh_filter_by_type(int *verlet, const double *dist, const int *nn, const int
 int mdh_identify_sftb_fcc(const int *hcp_indices, int64_t n_hcp, int *hcp_neighbors, const int *ptm_indices,
                           const int *structure_types, int64_t N, int *fault_types, int identify_esf, int space, void *stream);
 
+/* replaces _neighbor.filter_overlap_atom                   src/neighbor.cpp:390-486 (polycrystal builder)
+ * keep (N) u8: 0 for every atom that has a lower-numbered atom within rc, else 1 */
+int mdh_filter_overlap_atom(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+                            const double *origin3_host, const int *boundary3_host, double rc, unsigned char *keep,
+                            int space, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,22 @@ def average_by_neighbor(rc, verlet_list, distance_list, neighbor_number, value, 
                                              c.out(value_ave, f64, upload=False), int(bool(include_self)), c.space,
                                              c.stream)
     c.done(rc_)
+
+
+def filter_overlap_atom(x, y, z, box, origin, boundary, rc, num_t=1):
+    """src/neighbor.cpp:390 — bool array: False for every atom that has a lower-numbered atom within rc"""
+    keep_, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    n = int(len(x))
+    out = np.zeros(n, np.uint8)
+    c = Call(x, y, z)
+    if c.space == _lib.DEVICE:
+        from .devarray import HArray
+        h = HArray.empty(n, np.uint8)
+        rc_ = _lib.lib().mdh_filter_overlap_atom(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, float(rc),
+                                                 h.data_ptr(), c.space, c.stream)
+        c.done(rc_)
+        return h.dev().cpu().numpy().astype(bool)
+    rc_ = _lib.lib().mdh_filter_overlap_atom(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, float(rc),
+                                             out.ctypes.data, c.space, c.stream)
+    c.done(rc_)
+    return out.astype(bool)

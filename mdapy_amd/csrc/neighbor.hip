@@ -429,6 +429,50 @@ __global__ __launch_bounds__(256) void k_average(double rc, const int *__restric
     out[i] = cnt > 0 ? s / cnt : 0.0;
 }
 
+// filter_overlap_atom (neighbor.cpp:390-486): keep[j] = 0 iff some atom i < j lies within rc of j.  The reference lets
+// every centre i mark its higher-numbered neighbours; here every atom j looks for a lower-numbered i and evaluates the
+// very expression centre i would: raw x[j] - wrapped x[i], folded, squared, compared with rc^2.  The 27-cell
+// neighbourhood is symmetric, so the same pairs are examined.
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_filter_overlap(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                        const double *__restrict__ zs, const int *__restrict__ order,
+                                                        const int *__restrict__ cell_start, int64_t N, DBox b, Grid g,
+                                                        double rc, unsigned char *__restrict__ keep)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N)
+        return;
+    const double xr = xs[p], yr = ys[p], zr = zs[p]; // raw position of j
+    double xw = xr, yw = yr, zw = zr;
+    if (b.anypbc)
+        wrap<TRI>(b, xw, yw, zw);
+    int c0, c1, c2;
+    cell_coords<TRI>(b, g, xw, yw, zw, c0, c1, c2);
+    const int j = order[p];
+    const double rcsq = rc * rc;
+    bool hit = false;
+    for (int a = c0 - 1; a <= c0 + 1 && !hit; ++a) {
+        const int ca = pmod(a, g.nc[0]);
+        for (int bb = c1 - 1; bb <= c1 + 1 && !hit; ++bb) {
+            const int64_t base = ((int64_t)ca * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2];
+            for (int cc = c2 - 1; cc <= c2 + 1 && !hit; ++cc) {
+                const int64_t cell = base + pmod(cc, g.nc[2]);
+                for (int q = cell_start[cell]; q < cell_start[cell + 1]; ++q) {
+                    if (order[q] >= j)
+                        continue;
+                    double xi = xs[q], yi = ys[q], zi = zs[q]; // the lower-numbered atom is the centre: wrapped (:430-436)
+                    if (b.anypbc)
+                        wrap<TRI>(b, xi, yi, zi);
+                    double dx = xr - xi, dy = yr - yi, dz = zr - zi;
+                    pbc<TRI>(b, dx, dy, dz);
+                    if (dx * dx + dy * dy + dz * dz <= rcsq) { hit = true; break; }
+                }
+            }
+        }
+    }
+    keep[j] = hit ? 0 : 1;
+}
+
 } // namespace mdh
 
 using namespace mdh;
@@ -503,6 +547,30 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
     MDH_TRY(sc.finish(space));
     MDH_HIP(hipStreamSynchronize(sc.stream()));
     return MDH_OK;
+}
+
+int mdh_filter_overlap_atom(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                            const double *origin3, const int *boundary3, double rc, unsigned char *keep, int space,
+                            void *stream)
+{
+    if (N < 0 || N >= 2147483647LL || !(rc > 0)) { set_error("mdh_filter_overlap_atom: invalid N or rc"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    unsigned char *dk = sc.stage(keep, (size_t)N, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    CellGrid cg;
+    MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, false, cg));
+    if (b.tri)
+        hipLaunchKernelGGL(k_filter_overlap<true>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, dk);
+    else
+        hipLaunchKernelGGL(k_filter_overlap<false>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, dk);
+    return sc.finish(space);
 }
 
 int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M, int sort_num, int space, void *stream)

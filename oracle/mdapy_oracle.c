@@ -1508,3 +1508,42 @@ ORC_API int orc_identify_sftb_fcc(const int *hcp_idx, int64_t n_hcp, int *hn, co
     }
     return 0;
 }
+
+/* overlap filter of the polycrystal builder                   src/neighbor.cpp:390-486
+ * keep[j] = 0 iff a centre i < j finds j within rc (centre wrapped, j raw, minimum image) */
+ORC_API int orc_filter_overlap_atom(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                    const double *origin, const int *boundary, double rc, unsigned char *keep, int num_t)
+{
+    obox b;
+    if (obox_init(&b, box9, origin, boundary))
+        return -1;
+    ogrid g;
+    int rcode = ogrid_build(&g, &b, rc, x, y, z, N);
+    if (rcode)
+        return rcode;
+    const double rc_inv = 1.0 / rc, rcsq = rc * rc;
+    for (int64_t i = 0; i < N; ++i) keep[i] = 1;
+#pragma omp parallel for num_threads(num_t > 0 ? num_t : 1) schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        double xi, yi, zi;
+        int c[3];
+        center_of(&b, x, y, z, i, &xi, &yi, &zi);
+        cell_of(&b, rc_inv, g.nc, xi, yi, zi, c);
+        for (int a = c[0] - 1; a <= c[0] + 1; ++a)
+            for (int bb = c[1] - 1; bb <= c[1] + 1; ++bb)
+                for (int cc = c[2] - 1; cc <= c[2] + 1; ++cc) {
+                    int64_t cell = ((int64_t)pmod(a, g.nc[0]) * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2] + pmod(cc, g.nc[2]);
+                    for (int64_t p = g.start[cell]; p < g.start[cell + 1]; ++p) {
+                        int j = g.atoms[p];
+                        if (j <= i)
+                            continue;                                  /* :448 only the higher index is marked */
+                        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+                        obox_pbc(&b, &dx, &dy, &dz);
+                        if (dx * dx + dy * dy + dz * dz <= rcsq)
+                            keep[j] = 0;                               /* benign race: every writer stores 0 */
+                    }
+                }
+    }
+    ogrid_free(&g);
+    return 0;
+}

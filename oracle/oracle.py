@@ -346,3 +346,13 @@ def identify_sftb_fcc(hcp_indices, hcp_neighbors, ptm_indices, structure_types, 
     h, p, s = _ro(hcp_indices, np.int32), _ro(ptm_indices, np.int32), _ro(structure_types, np.int32)
     _chk(lib().orc_identify_sftb_fcc(_p(h, np.int32), i64(h.shape[0]), _p(hcp_neighbors, np.int32), _p(p, np.int32),
                                      _p(s, np.int32), i64(s.shape[0]), _p(fault_types, np.int32), cint(bool(identify_esf))))
+
+
+def filter_overlap_atom(x, y, z, box, origin, boundary, rc, num_t=1):
+    """mdapy._neighbor.filter_overlap_atom (src/neighbor.cpp:390) -> bool (N)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    keep = np.zeros(len(x), np.uint8)
+    _chk(lib().orc_filter_overlap_atom(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)), _p(b, np.float64),
+                                       _p(o, np.float64), _p(p, np.int32), dbl(rc), keep.ctypes.data_as(C.c_void_p), cint(num_t)))
+    return keep.astype(bool)

@@ -631,3 +631,14 @@ def test_fcc_planar_faults_fixture_and_oracle():
         _fccpft.identify_sftb_fcc(h, hn1, p_, st_, f1, True)
         assert np.array_equal(hn1, hn0) and np.array_equal(f1, f0)
         assert len(np.unique(f0)) >= 4
+
+
+@pytest.mark.parametrize("case", ["fcc_hot_shifted_origin", "fcc_unwrapped", "triclinic_random", "random_gas", "thin_box_3cells", "cluster_open"])
+def test_filter_overlap_atom_vs_oracle(case):
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    x, y, z = _xyz(pos)
+    for rc in (1.5, 2.7):
+        k0 = O.filter_overlap_atom(x, y, z, box, origin, bd, rc, 4)
+        k1 = _neighbor.filter_overlap_atom(x, y, z, box, origin, bd, rc, 1)
+        assert np.array_equal(k1, k0)
+    assert 0 < k0.sum() <= len(k0)

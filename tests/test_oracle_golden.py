@@ -360,3 +360,16 @@ def test_fcc_planar_faults_against_fixture(oracle_backend):
     s.cal_polyhedral_template_matching("all", identify_fcc_planar_faults=True, identify_esf=False)
     got = s.data["pft"].to_numpy()
     assert np.array_equal(got, expected), f"{int(np.sum(got != expected))} mismatches; labels {np.bincount(expected)}"
+
+
+def test_filter_overlap_atom_oracle_vs_brute_force():
+    """src/neighbor.cpp:390-486 — an atom is dropped iff a lower-numbered atom lies within rc (minimum image)"""
+    rng = np.random.default_rng(6)
+    L = 12.0
+    pos = rng.random((600, 3)) * L
+    keep = _O.filter_overlap_atom(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), np.eye(3) * L, np.zeros(3),
+                                  np.array([1, 1, 0], np.int32), 1.1, 2)
+    d = pos[:, None, :] - pos[None, :, :]
+    d[..., :2] -= L * np.round(d[..., :2] / L)
+    close = (np.sqrt((d ** 2).sum(-1)) <= 1.1) & (np.arange(600)[None, :] < np.arange(600)[:, None])
+    assert np.array_equal(keep, ~close.any(axis=1)) and 0 < keep.sum() < 600
