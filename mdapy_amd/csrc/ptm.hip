@@ -21,6 +21,39 @@ using ptmc::Tables;
 
 static constexpr int PTM_BLOCK = 64;
 
+// polygon of the neighbour-ordering pass in LDS: vertex i, coordinate c of lane l at [(i*3 + c) * PTM_BLOCK + l]
+// (bank = lane: conflict-free whatever the lanes' vertex indices)
+struct PolyLds {
+    static constexpr int CAP = 16;
+    double *base;
+    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 3 + c) * PTM_BLOCK]; }
+    __device__ __forceinline__ void set(int i, int c, double x) { base[(i * 3 + c) * PTM_BLOCK] = x; }
+};
+
+// working set of the canonical form in LDS (ptm_core.hpp: Canon is the private-array twin): per lane 256 + 84 + 16 bytes
+// and 16 half-words, element e of lane l at [e * PTM_BLOCK + l]
+struct CanonLds {
+    static constexpr int BYTES = 256 + 2 * ptmc::MAX_EDGES + ptmc::MAX_NBR; // common | best | index
+    static constexpr size_t LDS_BYTES = (size_t)(BYTES + 2 * ptmc::MAX_NBR) * PTM_BLOCK;
+    int8_t *b8;        // byte elements, stride PTM_BLOCK
+    uint16_t *h16;     // walked[], stride PTM_BLOCK
+    int8_t label[ptmc::MAX_PTS];
+    __device__ __forceinline__ int cm(int a, int b) const { return b8[(a * 16 + b) * PTM_BLOCK]; }
+    __device__ __forceinline__ void cm_set(int a, int b, int v) { b8[(a * 16 + b) * PTM_BLOCK] = (int8_t)v; }
+    __device__ __forceinline__ int bs(int i) const { return b8[(256 + i) * PTM_BLOCK]; }
+    __device__ __forceinline__ void bs_set(int i, int v) { b8[(256 + i) * PTM_BLOCK] = (int8_t)v; }
+    __device__ __forceinline__ int ix(int i) const { return b8[(256 + 2 * ptmc::MAX_EDGES + i) * PTM_BLOCK]; }
+    __device__ __forceinline__ void ix_set(int i, int v) { b8[(256 + 2 * ptmc::MAX_EDGES + i) * PTM_BLOCK] = (int8_t)v; }
+    __device__ __forceinline__ unsigned wk(int i) const { return h16[i * PTM_BLOCK]; }
+    __device__ __forceinline__ void wk_set(int i, unsigned v) { h16[i * PTM_BLOCK] = (uint16_t)v; }
+};
+
+#ifdef MDH_PTM_CANON_LDS
+static constexpr size_t PTM_INDEX_LDS = CanonLds::LDS_BYTES;
+#else
+static constexpr size_t PTM_INDEX_LDS = 0;
+#endif
+
 template <bool TRI> struct DevFold {
     const DBox &b;
     __device__ __forceinline__ void operator()(double &dx, double &dy, double &dz) const { pbc<TRI>(b, dx, dy, dz); }
@@ -37,7 +70,12 @@ __global__ __launch_bounds__(PTM_BLOCK) void k_ptm_order(const double *__restric
         return;
     const DevFold<TRI> fold{b};
     ptmc::Env env;
-    ptmc::build_env(x, y, z, N, verlet + i * M, (int)M, nullptr, (int)i, fold, nullptr, env);
+    extern __shared__ double poly_lds[]; // [PolyLds::CAP][3][PTM_BLOCK]: the lane's polygon is a stripe of stride PTM_BLOCK
+    PolyLds fast{poly_lds + threadIdx.x};
+    if (!ptmc::build_env(x, y, z, N, verlet + i * M, (int)M, nullptr, (int)i, fold, nullptr, env, fast)) {
+        ptmc::PolyLocal slow; // a face with more than 16 vertices: private (scratch) storage holds 28
+        ptmc::build_env(x, y, z, N, verlet + i * M, (int)M, nullptr, (int)i, fold, nullptr, env, slow);
+    }
     int8_t *o = orders + i * 18;
     for (int k = 0; k < 18; ++k)
         o[k] = k + 1 < env.num ? (int8_t)(env.corr[k + 1] - 1) : (int8_t)-1;
@@ -52,7 +90,8 @@ template <bool TRI> struct DevSrc {
     __device__ void get(int atom, ptmc::Env &env)
     {
         const DevFold<TRI> fold{b};
-        ptmc::build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, fold, orders + (int64_t)atom * 18, env);
+        ptmc::PolyLocal unused; // the order is given: no polygon work
+        ptmc::build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, fold, orders + (int64_t)atom * 18, env, unused);
     }
 };
 
@@ -72,7 +111,17 @@ __global__ __launch_bounds__(PTM_BLOCK) void k_ptm_index(const double *__restric
         return;
     DevSrc<TRI> src{x, y, z, N, M, verlet, types, orders, b};
     ptmc::Result r;
-    ptmc::index_atom<SHELL>(*tables, flags, src, (int)i, r);
+#ifdef MDH_PTM_CANON_LDS
+    extern __shared__ unsigned char canon_lds[];
+    CanonLds C;
+    C.b8 = reinterpret_cast<int8_t *>(canon_lds) + threadIdx.x;
+    C.h16 = reinterpret_cast<uint16_t *>(canon_lds + (size_t)CanonLds::BYTES * PTM_BLOCK) + threadIdx.x;
+#else
+    // Measured (1 M rattled fcc atoms): with the canonical-form arrays in LDS the kernel keeps 6 instead of 16 waves per
+    // CU and the hull phase, still in private memory, loses more than the canonical form gains (76 ms vs 63 ms).
+    ptmc::Canon C;
+#endif
+    ptmc::index_atom<SHELL>(*tables, flags, src, (int)i, r, C);
     int type = r.type, ordering = r.ordering;
     if (r.rmsd > rmsd_threshold || type == ptmc::T_NONE) { // :287-291
         type = 0;
@@ -188,16 +237,17 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     const dim3 grid(grid_for(N, PTM_BLOCK)), block(PTM_BLOCK);
     {
         ProfRange pr("k_ptm_order", sc.stream());
+        const size_t order_lds = sizeof(double) * PolyLds::CAP * 3 * PTM_BLOCK;
         if (b.tri)
-            hipLaunchKernelGGL(k_ptm_order<true>, grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
+            hipLaunchKernelGGL(k_ptm_order<true>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
         else
-            hipLaunchKernelGGL(k_ptm_order<false>, grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
+            hipLaunchKernelGGL(k_ptm_order<false>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
     }
     {
         ProfRange pr("k_ptm_index", sc.stream());
         const bool shell = (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) != 0;
 #define MDH_PTM_LAUNCH(TRI, SHELL)                                                                                              \
-    hipLaunchKernelGGL((k_ptm_index<TRI, SHELL>), grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dord, dt, flags,   \
+    hipLaunchKernelGGL((k_ptm_index<TRI, SHELL>), grid, block, PTM_INDEX_LDS, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dord, dt, flags,   \
                        rmsd_threshold, dout, ncol, dind, nind)
         if (b.tri && shell) MDH_PTM_LAUNCH(true, true);
         else if (b.tri) MDH_PTM_LAUNCH(true, false);

@@ -83,7 +83,7 @@ struct HostSrc {
     const int *verlet, *types;
     const HostFold *fold;
     const int8_t *orders; // (N,18) from pass 1
-    void get(int atom, Env &env) { build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, *fold, orders + (int64_t)atom * 18, env); }
+    void get(int atom, Env &env) { PolyLocal poly; build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, *fold, orders + (int64_t)atom * 18, env, poly); }
 };
 } // namespace
 
@@ -113,14 +113,16 @@ int ptmh_run(const double *x, const double *y, const double *z, int64_t N, const
     for (int64_t i = 0; i < N; ++i) { // pass 1: the Voronoi order of every atom's row
         Env env;
         int8_t *orow = orders.data() + i * 18;
-        build_env(x, y, z, N, verlet + i * M, (int)M, types, (int)i, fold, nullptr, env);
+        PolyLocal poly;
+        build_env(x, y, z, N, verlet + i * M, (int)M, types, (int)i, fold, nullptr, env, poly);
         for (int k = 1; k < env.num; ++k) orow[k - 1] = (int8_t)(env.corr[k] - 1);
     }
     if (order_out) std::memcpy(order_out, orders.data(), orders.size());
     HostSrc src{x, y, z, N, M, verlet, types, &fold, orders.data()};
     for (int64_t i = 0; i < N; ++i) {
         Result r;
-        index_atom<true>(g_tables, flags, src, (int)i, r);
+        Canon C;
+        index_atom<true>(g_tables, flags, src, (int)i, r, C);
         double *o = output + i * 8;
         int type = r.type, ordering = r.ordering;
         if (r.rmsd > rmsd_threshold || type == T_NONE) { type = 0; ordering = 0; }
