@@ -642,3 +642,77 @@ def test_filter_overlap_atom_vs_oracle(case):
         k1 = _neighbor.filter_overlap_atom(x, y, z, box, origin, bd, rc, 1)
         assert np.array_equal(k1, k0)
     assert 0 < k0.sum() <= len(k0)
+
+
+# ------------------------------------------------------------------ BASELINE.json configurations at FULL size (properties that do
+# not need a second implementation: closed forms, invariants, determinism) — full System flow, host arrays in/out
+def _fcc_system(cells, sigma=0.0, seed=0, binary=False):
+    pos, box = lattice_positions("fcc", 3.615, cells, cells, cells)
+    rng = np.random.default_rng(seed)
+    if sigma > 0:
+        pos = pos + rng.normal(0.0, sigma, pos.shape)
+    s = mp.System(pos=pos, box=box)
+    if binary:
+        s.update_data(s.data.with_columns(type=rng.integers(1, 3, len(pos)).astype(np.int32)))
+    return s
+
+
+def test_config1_1M_neighbor_cna_csp_bit_exact_vs_cpu():
+    """configs[1]: 1 M-atom FCC Cu, neighbor + CNA + CSP; labels / rows checked bit for bit against the CPU oracle"""
+    s = _fcc_system(63, 0.2, 1)  # 1 000 188 atoms, rattled so that not every label is FCC
+    x, y, z = (np.ascontiguousarray(s.data[c].to_numpy()) for c in "xyz")
+    rc = 0.854 * 3.615
+    s.build_neighbor(rc, max_neigh=20)
+    v, d, n = (np.asarray(a) for a in (s.verlet_list, s.distance_list, s.neighbor_number))
+    V = np.full_like(v, -1); D = np.full_like(d, rc + 1.0); N_ = np.zeros_like(n)
+    O.build_neighbor(x, y, z, s.box.box, s.box.origin, s.box.boundary, rc, V, D, N_, 64)
+    assert np.array_equal(n, N_) and np.array_equal(v, V) and np.array_equal(d, D)
+    s.cal_common_neighbor_analysis(rc=rc)
+    P = np.zeros(len(x), np.int32)
+    O.fcna(x, y, z, s.box.box, s.box.origin, s.box.boundary, V, N_, P, rc, 64)
+    assert np.array_equal(s.data["cna"].to_numpy(), P) and len(np.unique(P)) > 1
+    # CSP: the 12-neighbour search of the GPU (checked against the brute-force oracle at small sizes above; the oracle's
+    # search is O(N^2)) feeds both implementations of the parameter itself
+    from mdapy_amd import _fast_knn
+    I = np.zeros((len(x), 12), np.int32); Dk = np.zeros((len(x), 12))
+    _fast_knn.knn(x, y, z, s.box.box, s.box.origin, s.box.boundary, 12, I, Dk, 1)
+    s.cal_centro_symmetry_parameter(12)
+    C = np.zeros(len(x))
+    O.get_csp(x, y, z, s.box.box, s.box.origin, s.box.boundary, I, 12, C, 64)
+    assert np.allclose(s.data["csp"].to_numpy(), C, rtol=1e-6, atol=1e-9)
+    assert np.all(np.diff(Dk, axis=1) >= 0) and Dk[:, 0].min() > 1.0
+
+
+def test_config2_10M_ptm_steinhardt_closed_forms():
+    """configs[2]: 10 M-atom FCC Cu, PTM + Steinhardt q4/q6.  Perfect lattice: every atom FCC, rmsd ~ 0, d = a/sqrt(2),
+    identity orientation; q4 = 0.190941, q6 = 0.574524 (the reference's closed forms, tests/test_steinhardt_bond_orientation.py)."""
+    s = _fcc_system(136)  # 10 061 824 atoms
+    s.cal_polyhedral_template_matching(return_rmsd=True, return_atomic_distance=True, return_orientation=True)
+    assert np.all(s.data["ptm"].to_numpy() == 1)
+    assert s.data["rmsd"].to_numpy().max() < 1e-6
+    assert np.allclose(s.data["interatomic_distance"].to_numpy(), 3.615 / np.sqrt(2), rtol=1e-9)
+    assert np.allclose(np.abs(s.data["qw"].to_numpy()), 1.0, atol=1e-6)
+    ind = np.asarray(s.ptm_indices)
+    assert np.array_equal(ind[:, 0], np.arange(s.N)) and np.all(ind[:, 13:] == -1) and np.all(ind[:, 1:13] >= 0)
+    s.cal_steinhardt_bond_orientation([4, 6], rc=0.854 * 3.615)
+    assert np.allclose(s.data["ql4"].to_numpy(), 0.190941, atol=1e-6)
+    assert np.allclose(s.data["ql6"].to_numpy(), 0.574524, atol=1e-6)
+
+
+def test_config4_10M_binary_rdf_wcp_invariants():
+    """configs[4]: 10 M-atom binary system, partial g_ab(r) + Warren-Cowley.  Invariants: the species-weighted partials
+    add up to the total g(r); g averages to 1 beyond the first shell and vanishes inside the core; alpha_ab of a random
+    occupation vanishes (|alpha| < 2e-3 at 10 M atoms) and sum_b c_b (1 - alpha_ab) = 1 exactly."""
+    s = _fcc_system(136, 0.25, 5, binary=True)
+    rdf = s.cal_radial_distribution_function(6.0, nbin=120)
+    ty = s.data["type"].to_numpy()
+    c = np.bincount(ty)[1:] / len(ty)
+    gab = rdf.g_partial
+    keys = sorted(gab.keys())
+    total = sum(c[a_ - 1] * c[b_ - 1] * gab[(a_, b_)] * (1.0 if a_ == b_ else 2.0) for a_, b_ in keys)
+    assert np.allclose(total, rdf.g_total, rtol=1e-9, atol=1e-12)
+    assert abs(rdf.g_total[rdf.r > 3.0].mean() - 1.0) < 0.1 and rdf.g_total[rdf.r < 1.2].max() < 0.01
+    w = s.cal_warren_cowley_parameter(0.854 * 3.615)
+    alpha = np.asarray(w.WCP)
+    assert np.abs(alpha).max() < 2e-3
+    assert np.allclose(((1.0 - alpha) * c[None, :]).sum(axis=1), 1.0, atol=1e-12)
