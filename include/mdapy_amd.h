@@ -231,6 +231,17 @@ int mdh_filter_overlap_atom(const double *x, const double *y, const double *z, i
                             const double *origin3_host, const int *boundary3_host, double rc, unsigned char *keep,
                             int space, void *stream);
 
+/* ---- _voronoi (volume functions) ------------------------------ */
+/* replaces _voronoi.get_voronoi_volume_number_radius         src/voronoi.cpp:16-71 (and, called with a LAMMPS-aligned
+ * triclinic box and all-periodic boundary, get_voronoi_volume_number_radius_tri :73-147).
+ * volume (N) f64, nfaces (N) i32 (walls of open axes count, as voro++'s number_of_faces), radius (N) f64 =
+ * sqrt(max_radius_squared) of voro++ = twice the largest vertex distance.  Cells are built by half-space clipping from
+ * the neighbours within an automatically enlarged search radius; returns MDH_ERR_ARG when a cell would reach beyond half
+ * a periodic box length (replicate the system first). */
+int mdh_voronoi_volume_number_radius(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+                                     const double *origin3_host, const int *boundary3_host, double *volume, int *nfaces,
+                                     double *radius, int space, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

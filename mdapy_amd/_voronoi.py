@@ -1,0 +1,32 @@
+"""Drop-in for the volume functions of ``mdapy._voronoi`` (src/voronoi.cpp:544-545)."""
+import numpy as np
+
+from . import _lib
+from .devarray import Call
+
+f64, i32 = np.float64, np.int32
+
+
+def get_voronoi_volume_number_radius(x, y, z, box, origin, boundary, volume, neighbor_number, cavity_radius, num_t=1):
+    """src/voronoi.cpp:16 — per atom: Voronoi cell volume, number of faces (walls of open axes included), largest
+    vertex distance"""
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    c = Call(x, y, z, volume, neighbor_number, cavity_radius)
+    rc_ = _lib.lib().mdh_voronoi_volume_number_radius(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), int(len(x)), pb, po, pp,
+                                                      c.out(volume, f64, upload=False), c.out(neighbor_number, i32, upload=False),
+                                                      c.out(cavity_radius, f64, upload=False), c.space, c.stream)
+    c.done(rc_)
+
+
+def get_voronoi_volume_number_radius_tri(x, y, z, box, origin, boundary, rotation, volume, neighbor_number, cavity_radius,
+                                         need_rotation, num_t=1):
+    """src/voronoi.cpp:73 — the box is LAMMPS-aligned and treated as fully periodic (container_triclinic); the rotation
+    is a rigid motion, so cell volumes, face counts and vertex distances are those of the rotated positions"""
+    x = np.asarray(x, f64) - origin[0]
+    y = np.asarray(y, f64) - origin[1]
+    z = np.asarray(z, f64) - origin[2]
+    if need_rotation:
+        r = np.asarray(rotation, f64)
+        x, y, z = (x * r[0, k] + y * r[1, k] + z * r[2, k] for k in range(3))
+    get_voronoi_volume_number_radius(np.ascontiguousarray(x), np.ascontiguousarray(y), np.ascontiguousarray(z), box, np.zeros(3),
+                                     np.ones(3, i32), volume, neighbor_number, cavity_radius, num_t)

@@ -125,6 +125,18 @@ class Box:
                 f[i] -= np.floor(f[i] + 0.5)
         return f @ self.box
 
+    def align_to_lammps_box(self):
+        """the same cell as a LAMMPS-style lower-triangular box + the rotation that maps positions into it (box.py:425-443)"""
+        ax = np.linalg.norm(self.box[0])
+        bx = self.box[1] @ (self.box[0] / ax)
+        by = np.sqrt(np.linalg.norm(self.box[1]) ** 2 - bx ** 2)
+        cx = self.box[2] @ (self.box[0] / ax)
+        cy = (self.box[1] @ self.box[2] - bx * cx) / by
+        cz = np.sqrt(np.linalg.norm(self.box[2]) ** 2 - cx ** 2 - cy ** 2)
+        box = np.array([[ax, bx, cx], [0, by, cy], [0, 0, cz]], dtype=np.float64).T
+        rotation = np.linalg.solve(self.box, box)
+        return Box(box, self.boundary, self.origin), rotation
+
     def get_thickness(self) -> np.ndarray:
         """perpendicular thickness per axis (box.py:469-481)"""
         b = self.box

@@ -1,0 +1,248 @@
+// voronoi.hip — Voronoi cell volume, face count and cavity radius per atom on gfx950.
+//
+// Replaces src/voronoi.cpp:16-147 (get_voronoi_volume_number_radius / _tri), which hand every atom to voro++
+// (extern/voro++).  Here ONE WAVEFRONT builds one cell: the neighbours within a search radius (cell-list neighbor
+// build of this library, rows sorted by distance) become half-space constraints in LDS, lane f clips face f out of its
+// own plane against the others (voro_core.hpp; polygon in a per-lane LDS stripe), and the wave reduces volume, face
+// count and farthest vertex.  A cell is complete when no unseen atom can cut it, i.e. 2 R_max <= search radius; the
+// host enlarges the radius (x1.4) and repeats while a device counter reports incomplete cells.
+//   volume   = sum_f area_f h_f / 3          faces = non-degenerate faces, walls of open axes included
+//   radius   = 2 R_max                       (voro++ keeps cells doubled: sqrt(max_radius_squared()) is twice the
+//                                             farthest-vertex distance, and that is what the reference returns)
+#include "common.hpp"
+#include "voro_core.hpp"
+#include "../../include/mdapy_amd.h"
+
+namespace mdh {
+
+static constexpr int VORO_MAXC = 250;  // neighbours one cell may consider
+static constexpr int VORO_LANES = 64;
+
+struct PolyLdsV { // vertex i, coordinate c of lane l at [(i*3 + c) * 64 + l]
+    static constexpr int CAP = 16;
+    double *base;
+    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 3 + c) * VORO_LANES]; }
+    __device__ __forceinline__ void set(int i, int c, double x) { base[(i * 3 + c) * VORO_LANES] = x; }
+};
+
+template <bool TRI>
+__global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ z, int64_t N, DBox b,
+                                                        const int *__restrict__ verlet, const int *__restrict__ nn, int64_t M,
+                                                        double rc, double *__restrict__ volume, int *__restrict__ nfaces,
+                                                        double *__restrict__ radius, int *__restrict__ incomplete)
+{
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ double nrm[VORO_MAXC + 6][3];
+    __shared__ double off[VORO_MAXC + 6], dist[VORO_MAXC + 6];
+    __shared__ double poly_lds[PolyLdsV::CAP * 3 * VORO_LANES];
+    const double xi = x[i], yi = y[i], zi = z[i];
+    // rows are sorted by distance: a crowded atom uses its VORO_MAXC nearest neighbours and is complete within THEIR reach
+    const int n = min(min(nn[i], (int)M), VORO_MAXC);
+    const double big = 4 * rc;
+    // constraints 0..5: walls of open axes (orthogonal boxes), otherwise the bounding cube
+    if (lane < 6) {
+        const int a = lane >> 1;
+        const bool up = (lane & 1) == 0;
+        double o = big;
+        if (!TRI && !b.pbc[a]) {
+            const double p = (a == 0 ? xi : (a == 1 ? yi : zi)) - b.o[a];
+            const double len = a == 0 ? b.h[0] : (a == 1 ? b.h[4] : b.h[8]);
+            o = up ? len - p : p;
+        }
+        nrm[lane][0] = nrm[lane][1] = nrm[lane][2] = 0.0;
+        nrm[lane][a] = up ? 1.0 : -1.0;
+        off[lane] = o;
+        dist[lane] = o;
+    }
+    for (int c = lane; c < n; c += VORO_LANES) {
+        const int j = verlet[i * M + c];
+        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+        pbc<TRI>(b, dx, dy, dz);
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        nrm[6 + c][0] = dx; nrm[6 + c][1] = dy; nrm[6 + c][2] = dz;
+        off[6 + c] = 0.5 * d2;
+        dist[6 + c] = 0.5 * sqrt(d2);
+    }
+    __syncthreads();
+    const int nc = n + 6;
+    double vol = 0.0, mr2 = 0.0;
+    int nf = 0;
+    for (int f = lane; f < nc; f += VORO_LANES) {
+        if (f < 6 && (TRI || b.pbc[f >> 1]))
+            continue; // the bounding cube is not a face
+        PolyLdsV fast{poly_lds + lane};
+        voroc::FaceResult r = voroc::voronoi_face(fast, f, nc, nrm, off, dist, 6, big);
+        if (r.overflow) { // a face with more than 16 vertices: private storage holds 28
+            ptmc::PolyLocal slow;
+            r = voroc::voronoi_face(slow, f, nc, nrm, off, dist, 6, big);
+        }
+        if (!r.overflow && r.area > voroc::AREA_TOL * dist[f] * dist[f]) {
+            vol += r.area * dist[f] / 3.0;
+            ++nf;
+            mr2 = fmax(mr2, r.maxr2);
+        }
+    }
+    // wave reduction (fixed butterfly order: deterministic)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        vol += __shfl_xor(vol, d, 64);
+        nf += __shfl_xor(nf, d, 64);
+        mr2 = fmax(mr2, __shfl_xor(mr2, d, 64));
+    }
+    if (lane == 0) {
+        const double rmax = sqrt(mr2);
+        volume[i] = vol;
+        nfaces[i] = nf;
+        radius[i] = 2.0 * rmax;
+        const double reach = nn[i] > VORO_MAXC ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
+        if (2.0 * rmax > reach || nn[i] > M)
+            atomicAdd(incomplete, 1);
+    }
+}
+
+
+
+// images of the atoms along the periodic axes flagged in rep[]: image (a,b,c) of atom i at index ((a*ny + b)*nz + c)*N + i,
+// the (0,0,0) image first — so the first N rows of every result belong to the original atoms
+__global__ void k_replicate(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, int64_t N,
+                            int ny, int nz, int64_t total, const double *__restrict__ h9, double *__restrict__ ox,
+                            double *__restrict__ oy, double *__restrict__ oz)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total)
+        return;
+    const int64_t i = t % N, img = t / N;
+    const int c = (int)(img % nz), bq = (int)((img / nz) % ny), a = (int)(img / ((int64_t)nz * ny));
+    ox[t] = x[i] + a * h9[0] + bq * h9[3] + c * h9[6];
+    oy[t] = y[i] + a * h9[1] + bq * h9[4] + c * h9[7];
+    oz[t] = z[i] + a * h9[2] + bq * h9[5] + c * h9[8];
+}
+
+// cells of all `N` atoms of one (possibly replicated) system; 1 = some cells reach beyond half a period (caller replicates)
+static int voronoi_solve(void *stream, const double *dx, const double *dy, const double *dz, int64_t N, const double *box9,
+                         const double *origin3, const int *boundary3, double *dvol, int *dnf, double *drad, int *dnn, int *dflag,
+                         bool *too_small)
+{
+    *too_small = false;
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const double vol = fabs(b.h[0] * (b.h[4] * b.h[8] - b.h[5] * b.h[7]) - b.h[1] * (b.h[3] * b.h[8] - b.h[5] * b.h[6]) +
+                            b.h[2] * (b.h[3] * b.h[7] - b.h[4] * b.h[6]));
+    double rc_cap = 1.0e300; // minimum-image rows hold every atom once: the search radius must stay below half a period
+    for (int a = 0; a < 3; ++a)
+        if (b.pbc[a]) rc_cap = fmin(rc_cap, 0.5 * b.thick[a] * (1.0 - 1e-9));
+    double rc = fmin(2.2 * cbrt(vol / (double)N), rc_cap);
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        int maxc = 0;
+        MDH_TRY(mdh_neighbor_count(dx, dy, dz, N, box9, origin3, boundary3, rc, dnn, &maxc, MDH_DEVICE, stream));
+        const int64_t M = maxc > 0 ? maxc : 1;
+        if ((double)N * (double)M > 2.0e9) {
+            set_error("mdh_voronoi_volume_number_radius: the search list would exceed 2e9 entries (extremely inhomogeneous system)");
+            return MDH_ERR_ARG;
+        }
+        Scope inner(stream);
+        int *dv = inner.alloc_n<int>((size_t)(N * M));
+        double *dd = inner.alloc_n<double>((size_t)(N * M));
+        if (inner.failed())
+            return inner.error();
+        MDH_TRY(mdh_build_neighbor(dx, dy, dz, N, box9, origin3, boundary3, rc, dv, dd, dnn, M, 1, MDH_DEVICE, stream));
+        MDH_TRY(mdh_sort_verlet_by_distance(dv, dd, N, M, (int)M, MDH_DEVICE, stream));
+        MDH_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
+        {
+            ProfRange pr("k_voronoi", st);
+            if (b.tri)
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag);
+            else
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag);
+        }
+        int bad = 0;
+        MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+        MDH_HIP(hipStreamSynchronize(st));
+        if (bad == 0)
+            return MDH_OK;
+        if (rc >= rc_cap) {
+            *too_small = true;
+            return MDH_OK;
+        }
+        rc = fmin(rc * 1.4, rc_cap);
+    }
+    set_error("mdh_voronoi_volume_number_radius: search radius did not converge");
+    return MDH_ERR_ARG;
+}
+
+} // namespace mdh
+
+using namespace mdh;
+
+extern "C" int mdh_voronoi_volume_number_radius(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                                const double *origin3, const int *boundary3, double *volume, int *nfaces,
+                                                double *radius, int space, void *stream)
+{
+    if (N < 0 || N >= 2147483647LL) { set_error("mdh_voronoi_volume_number_radius: invalid N"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    double *dvol = sc.stage(volume, (size_t)N, space, false, true);
+    int *dnf = sc.stage(nfaces, (size_t)N, space, false, true);
+    double *drad = sc.stage(radius, (size_t)N, space, false, true);
+    int *dflag = sc.alloc_n<int>(1);
+    if (sc.failed())
+        return sc.error();
+    // Cells wider than half a period cannot be described by minimum-image rows: the periodic axes that are too thin are
+    // replicated (x3 per round, the original atoms first) and the cells of the original atoms are taken from the copy.
+    int rep[3] = {1, 1, 1};
+    for (int round = 0; round < 4; ++round) {
+        const int64_t total = N * rep[0] * rep[1] * rep[2];
+        if (total >= 2147483647LL / 4) {
+            set_error("mdh_voronoi_volume_number_radius: the replicated system would be too large");
+            return MDH_ERR_ARG;
+        }
+        double big9[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) big9[r * 3 + c] = box9[r * 3 + c] * rep[r];
+        Scope work(stream);
+        const double *px = dx, *py = dy, *pz = dz;
+        double *wv = dvol, *wr = drad;
+        int *wn = dnf;
+        int *dnn = work.alloc_n<int>((size_t)total);
+        if (total != N) {
+            double *rx = work.alloc_n<double>((size_t)total), *ry = work.alloc_n<double>((size_t)total), *rz = work.alloc_n<double>((size_t)total);
+            double *h9 = work.alloc_n<double>(9);
+            wv = work.alloc_n<double>((size_t)total); wr = work.alloc_n<double>((size_t)total); wn = work.alloc_n<int>((size_t)total);
+            if (work.failed())
+                return work.error();
+            MDH_HIP(hipMemcpyAsync(h9, box9, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_replicate, dim3(grid_for(total, 256)), dim3(256), 0, st, dx, dy, dz, N, rep[1], rep[2], total, h9, rx, ry, rz);
+            MDH_HIP(hipStreamSynchronize(st)); // box9 is caller memory
+            px = rx; py = ry; pz = rz;
+        }
+        if (work.failed())
+            return work.error();
+        bool too_small = false;
+        MDH_TRY(voronoi_solve(stream, px, py, pz, total, big9, origin3, boundary3, wv, wn, wr, dnn, dflag, &too_small));
+        if (!too_small) {
+            if (total != N) {
+                MDH_HIP(hipMemcpyAsync(dvol, wv, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+                MDH_HIP(hipMemcpyAsync(dnf, wn, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
+                MDH_HIP(hipMemcpyAsync(drad, wr, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+                MDH_HIP(hipStreamSynchronize(st));
+            }
+            return sc.finish(space);
+        }
+        // replicate the thinnest periodic axis (and any other that is not at least 1.5 times thicker)
+        double tmin = 1.0e300;
+        for (int a = 0; a < 3; ++a)
+            if (b.pbc[a]) tmin = fmin(tmin, b.thick[a] * rep[a]);
+        for (int a = 0; a < 3; ++a)
+            if (b.pbc[a] && b.thick[a] * rep[a] < 1.5 * tmin) rep[a] *= 3;
+    }
+    set_error("mdh_voronoi_volume_number_radius: cells still reach beyond half the replicated box (extremely dilute system)");
+    return MDH_ERR_ARG;
+}

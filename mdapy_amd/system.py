@@ -36,6 +36,7 @@ from .polyhedral_template_matching import PolyhedralTemplateMatching
 from .radial_distribution_function import RadialDistributionFunction
 from .steinhardt_bond_orientation import SteinhardtBondOrientation
 from .structure_entropy import StructureEntropy
+from .voronoi import Voronoi
 from .warren_cowley_parameter import WarrenCowleyParameter
 
 _NEIGH_ATTRS = ("verlet_list", "neighbor_number", "distance_list", "rc", "_enlarge_box", "_enlarge_data")
@@ -272,6 +273,12 @@ class System:
         ca.compute()
         self.cluster_number = ca.cluster_number
         self.update_data(self.data.with_columns(cluster_id=as_numpy(ca.particleClusters)[: self.N]))
+
+    def cal_voronoi_volume(self) -> None:
+        """columns ``volume``, ``neighbor_number`` (faces), ``cavity_radius`` (system.py:2544-2573)"""
+        vor = Voronoi(self.box, self.data)
+        volume, neighbor_number, cavity_radius = vor.get_volume()
+        self.update_data(self.data.with_columns(volume=volume, neighbor_number=neighbor_number, cavity_radius=cavity_radius))
 
     def cal_centro_symmetry_parameter(self, N: int):
         """column ``csp`` (system.py:1972-2003)"""

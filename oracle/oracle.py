@@ -356,3 +356,53 @@ def filter_overlap_atom(x, y, z, box, origin, boundary, rc, num_t=1):
     _chk(lib().orc_filter_overlap_atom(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)), _p(b, np.float64),
                                        _p(o, np.float64), _p(p, np.int32), dbl(rc), keep.ctypes.data_as(C.c_void_p), cint(num_t)))
     return keep.astype(bool)
+
+
+# --------------------------------------------------------------------- _voronoi  (oracle/_ref: the reference's own voro++)
+_VORO_SO = os.path.join(_HERE, "_ref", "libvoro_ref.so")
+_voro = None
+
+
+def have_voro_ref() -> bool:
+    build_ref()
+    return os.path.exists(_VORO_SO)
+
+
+def voro_lib():
+    global _voro
+    if _voro is None:
+        build_ref()
+        _voro = C.CDLL(_VORO_SO)
+    return _voro
+
+
+def get_voronoi_volume_number_radius(x, y, z, box, origin, boundary, volume, neighbor_number, cavity_radius, num_t=1):
+    """mdapy._voronoi.get_voronoi_volume_number_radius (src/voronoi.cpp:16) through the reference's voro++"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    _chk(voro_lib().ref_voronoi_volume_number_radius(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)),
+                                                     _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), _p(volume, np.float64),
+                                                     _p(neighbor_number, np.int32), _p(cavity_radius, np.float64)))
+
+
+def get_voronoi_volume_number_radius_tri(x, y, z, box, origin, boundary, rotation, volume, neighbor_number, cavity_radius,
+                                         need_rotation, num_t=1):
+    """mdapy._voronoi.get_voronoi_volume_number_radius_tri (src/voronoi.cpp:73)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    r = np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+    _chk(voro_lib().ref_voronoi_volume_number_radius_tri(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)),
+                                                         _p(b, np.float64), _p(o, np.float64), _p(r, np.float64),
+                                                         cint(bool(need_rotation)), _p(volume, np.float64),
+                                                         _p(neighbor_number, np.int32), _p(cavity_radius, np.float64)))
+
+
+def voronoi_faces(x, y, z, box, origin, boundary, width=64):
+    """per-cell neighbour ids (negative: wall) and face areas from voro++ (orthogonal container), for set comparisons"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    n = len(x)
+    nbr, area, cnt = np.full((n, width), -1, np.int32), np.zeros((n, width)), np.zeros(n, np.int32)
+    voro_lib().ref_voronoi_faces(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(n), _p(b, np.float64), _p(o, np.float64),
+                                 _p(p, np.int32), _p(nbr, np.int32), _p(area, np.float64), cint(width), _p(cnt, np.int32))
+    return nbr, area, cnt

@@ -1,0 +1,105 @@
+// voro_ref_driver.cpp — TEST INFRASTRUCTURE ONLY (part of oracle/_ref).
+//
+// C-ABI driver around the REFERENCE's own Voronoi library (extern/voro++, plain C++, C. Rycroft), compiled from the
+// sources where they lie (unity file extern/voro++/src/voro++.cc, as the reference's CMakeLists.txt:73-74 does) by
+// oracle/Makefile.ref into oracle/_ref/libvoro_ref.so.  The reference's driver src/voronoi.cpp includes nanobind and
+// cannot be compiled in this image; its logic is restated here:
+//   get_voronoi_volume_number_radius       src/voronoi.cpp:16-71
+//   get_voronoi_volume_number_radius_tri   src/voronoi.cpp:73-147
+//   get_voronoi_neighbor (orthogonal)      src/voronoi.cpp:307-447   (unfiltered: face areas and neighbour ids per cell)
+#include "voro++.hh"
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+
+// box9 row-major cell vectors (orthogonal), origin, boundary flags; outputs volume, number of faces, cavity radius
+__attribute__((visibility("default"))) int ref_voronoi_volume_number_radius(const double *x, const double *y, const double *z, int64_t N,
+                                                                            const double *box9, const double *origin, const int *boundary,
+                                                                            double *volume, int *nfaces, double *radius)
+{
+    const double bx = box9[0], by = box9[4], bz = box9[8];
+    const double vol = bx * by * bz, init_mem = 4.6;
+    const double ilscale = std::pow(N / (init_mem * vol), 1 / 3.0);
+    const int nx = int(bx * ilscale + 1), ny = int(by * ilscale + 1), nz = int(bz * ilscale + 1);
+    voro::container_3d con(0., bx, 0., by, 0., bz, nx, ny, nz, bool(boundary[0]), bool(boundary[1]), bool(boundary[2]), init_mem, 1);
+    for (int64_t i = 0; i < N; ++i) con.put((int)i, x[i] - origin[0], y[i] - origin[1], z[i] - origin[2]);
+    voro::voronoicell_neighbor_3d cell(con);
+    const int grid = con.nx * con.ny * con.nz;
+    for (int ijk = 0; ijk < grid; ++ijk)
+        for (int q = 0; q < con.co[ijk]; ++q)
+            if (con.compute_cell(cell, ijk, q)) {
+                const int i = con.id[ijk][q];
+                volume[i] = cell.volume();
+                nfaces[i] = cell.number_of_faces();
+                radius[i] = std::sqrt(cell.max_radius_squared());
+            }
+    return 0;
+}
+
+// LAMMPS-aligned triclinic box (bx, bxy, by, bxz, byz, bz from rows of box9), fully periodic (voronoi.py multiplies the
+// vectors of open axes by 3 beforehand); rotation (3,3) applied when need_rotation (:104-117)
+__attribute__((visibility("default"))) int ref_voronoi_volume_number_radius_tri(const double *x, const double *y, const double *z, int64_t N,
+                                                                                const double *box9, const double *origin, const double *rot9,
+                                                                                int need_rotation, double *volume, int *nfaces, double *radius)
+{
+    const double bx = box9[0], bxy = box9[3], by = box9[4], bxz = box9[6], byz = box9[7], bz = box9[8];
+    const double vol = std::fabs(bx * by * bz), init_mem = 4.6;
+    const double ilscale = std::pow(N / (init_mem * vol), 1 / 3.0);
+    auto len = [&](int r) { return std::sqrt(box9[3 * r] * box9[3 * r] + box9[3 * r + 1] * box9[3 * r + 1] + box9[3 * r + 2] * box9[3 * r + 2]); };
+    const int nx = int(len(0) * ilscale + 1), ny = int(len(1) * ilscale + 1), nz = int(len(2) * ilscale + 1);
+    voro::container_triclinic con(bx, bxy, by, bxz, byz, bz, nx, ny, nz, init_mem, 1);
+    for (int64_t i = 0; i < N; ++i) {
+        const double v[3] = {x[i] - origin[0], y[i] - origin[1], z[i] - origin[2]};
+        if (need_rotation)
+            con.put((int)i, v[0] * rot9[0] + v[1] * rot9[3] + v[2] * rot9[6], v[0] * rot9[1] + v[1] * rot9[4] + v[2] * rot9[7],
+                    v[0] * rot9[2] + v[1] * rot9[5] + v[2] * rot9[8]);
+        else
+            con.put((int)i, v[0], v[1], v[2]);
+    }
+    std::vector<int> co(con.co, con.co + con.oxyz);
+    voro::voronoicell_neighbor_3d cell(con);
+    for (int ijk = 0; ijk < con.oxyz; ++ijk)
+        for (int q = 0; q < co[ijk]; ++q)
+            if (con.compute_cell(cell, ijk, q)) {
+                const int i = con.id[ijk][q];
+                volume[i] = cell.volume();
+                nfaces[i] = cell.number_of_faces();
+                radius[i] = std::sqrt(cell.max_radius_squared());
+            }
+    return 0;
+}
+
+// per-cell neighbour ids (negative = wall) and face areas, row width `width` (-1 / 0 padded); returns the largest count
+__attribute__((visibility("default"))) int ref_voronoi_faces(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                                             const double *origin, const int *boundary, int *nbr, double *area, int width,
+                                                             int *count)
+{
+    const double bx = box9[0], by = box9[4], bz = box9[8];
+    const double vol = bx * by * bz, init_mem = 4.6;
+    const double ilscale = std::pow(N / (init_mem * vol), 1 / 3.0);
+    const int nx = int(bx * ilscale + 1), ny = int(by * ilscale + 1), nz = int(bz * ilscale + 1);
+    voro::container_3d con(0., bx, 0., by, 0., bz, nx, ny, nz, bool(boundary[0]), bool(boundary[1]), bool(boundary[2]), init_mem, 1);
+    for (int64_t i = 0; i < N; ++i) con.put((int)i, x[i] - origin[0], y[i] - origin[1], z[i] - origin[2]);
+    voro::voronoicell_neighbor_3d cell(con);
+    std::vector<int> ids;
+    std::vector<double> ar;
+    int mx = 0;
+    for (int ijk = 0; ijk < con.nx * con.ny * con.nz; ++ijk)
+        for (int q = 0; q < con.co[ijk]; ++q)
+            if (con.compute_cell(cell, ijk, q)) {
+                const int i = con.id[ijk][q];
+                cell.neighbors(ids);
+                cell.face_areas(ar);
+                count[i] = (int)ids.size();
+                mx = count[i] > mx ? count[i] : mx;
+                for (int k = 0; k < width; ++k) {
+                    nbr[(int64_t)i * width + k] = k < (int)ids.size() ? ids[k] : -1;
+                    area[(int64_t)i * width + k] = k < (int)ids.size() ? ar[k] : 0.0;
+                }
+            }
+    return mx;
+}
+}

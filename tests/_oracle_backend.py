@@ -85,6 +85,12 @@ cluster = _mod(
     filter_by_type=lambda v, d, nn, t, t1, t2, r, num_t=1: O.filter_by_type(v, _np(d), _np(nn), _np(t), t1, t2, r, NT),
 )
 fccpft = _mod(identify_sftb_fcc=lambda h, hn, p, s, f, esf, num_t=1: O.identify_sftb_fcc(h, hn, _np(p), _np(s), f, esf, NT))
+voronoi = _mod(
+    get_voronoi_volume_number_radius=lambda x, y, z, box, origin, boundary, v, n, r, num_t=1:
+        O.get_voronoi_volume_number_radius(_np(x), _np(y), _np(z), box, origin, boundary, v, n, r, NT),
+    get_voronoi_volume_number_radius_tri=lambda x, y, z, box, origin, boundary, rot, v, n, r, need, num_t=1:
+        O.get_voronoi_volume_number_radius_tri(_np(x), _np(y), _np(z), box, origin, boundary, rot, v, n, r, need, NT),
+)
 repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
 
 
@@ -93,6 +99,7 @@ def install(monkeypatch):
     import mdapy_amd.atomic_temperature as m_at
     import mdapy_amd.build_lattice as bl
     import mdapy_amd.cluster_analysis as m_cl
+    import mdapy_amd.voronoi as m_vor
     import mdapy_amd.identify_fcc_planar_faults as m_pft
     import mdapy_amd.common_neighbor_parameter as m_cnp
     import mdapy_amd.structure_entropy as m_se
@@ -122,6 +129,7 @@ def install(monkeypatch):
     monkeypatch.setattr(m_aja, "_aja", aja)
     monkeypatch.setattr(m_at, "_atomtemp", atomtemp)
     monkeypatch.setattr(m_cl, "_cluster", cluster)
+    monkeypatch.setattr(m_vor, "_voronoi", voronoi)
     monkeypatch.setattr(m_pft, "_fccpft", fccpft)
     monkeypatch.setattr(m_cnp, "_cnp", cnp)
     monkeypatch.setattr(m_se, "_structure_entropy", structure_entropy)

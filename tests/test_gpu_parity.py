@@ -716,3 +716,40 @@ def test_config4_10M_binary_rdf_wcp_invariants():
     alpha = np.asarray(w.WCP)
     assert np.abs(alpha).max() < 2e-3
     assert np.allclose(((1.0 - alpha) * c[None, :]).sum(axis=1), 1.0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ Voronoi volume / faces / cavity radius: HIP (half-space clipping,
+# one wave per cell) vs oracle/_ref (the reference's voro++) and the OVITO-derived fixtures
+from mdapy_amd import _voronoi
+
+VOR_PATHS = fixtures_with("voronoi_volume")
+needs_voro = pytest.mark.skipif(not O.have_voro_ref(), reason="oracle/_ref/libvoro_ref.so missing")
+
+
+@pytest.mark.parametrize("path", VOR_PATHS, ids=ids_of(VOR_PATHS))
+def test_golden_voronoi(path):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_voronoi_volume()
+    assert np.allclose(d["voronoi_volume"], s.data["volume"].to_numpy(), atol=1e-6)
+    assert np.allclose(d["voronoi_cavity_radius"], s.data["cavity_radius"].to_numpy() * 0.5, atol=1e-6)
+    assert np.array_equal(d["voronoi_coord"], s.data["neighbor_number"].to_numpy())
+
+
+@needs_voro
+@pytest.mark.parametrize("case", ["fcc_rattled", "fcc_hot_shifted_origin", "random_gas", "slab_open_z", "thin_box_3cells"])
+def test_voronoi_vs_reference_library(case):
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    if case == "slab_open_z":  # keep every atom inside the container along the open axis
+        pos = pos.copy(); pos[:, 2] = np.clip(pos[:, 2], 1e-3, (box[2, 2] if np.ndim(box) == 2 else box[2]) - 1e-3)
+    x, y, z = _xyz(pos)
+    N = len(pos)
+    v0, n0, r0 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
+    O.get_voronoi_volume_number_radius(x, y, z, box, origin, bd, v0, n0, r0)
+    v1, n1, r1 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
+    _voronoi.get_voronoi_volume_number_radius(x, y, z, box, origin, bd, v1, n1, r1)
+    assert np.allclose(v1, v0, rtol=1e-9, atol=1e-9) and np.allclose(r1, r0, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(n1, n0)
+    if all(bd):
+        vol = abs(np.linalg.det(np.asarray(box, float))) if np.ndim(box) == 2 else float(np.prod(box))
+        assert abs(v1.sum() - vol) < 1e-6 * vol  # the cells tile the periodic box

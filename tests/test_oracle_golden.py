@@ -373,3 +373,21 @@ def test_filter_overlap_atom_oracle_vs_brute_force():
     d[..., :2] -= L * np.round(d[..., :2] / L)
     close = (np.sqrt((d ** 2).sum(-1)) <= 1.1) & (np.arange(600)[None, :] < np.arange(600)[:, None])
     assert np.array_equal(keep, ~close.any(axis=1)) and 0 < keep.sum() < 600
+
+
+# ---------------------------------------------------------------- Voronoi volume / faces / cavity radius: oracle/_ref = the
+# reference's own voro++ behind the restated driver, pinned against the OVITO-derived fixtures
+VOR_PATHS = fixtures_with("voronoi_volume")
+needs_voro = pytest.mark.skipif(not _O.have_voro_ref(), reason="oracle/_ref/libvoro_ref.so not built (needs /root/reference)")
+
+
+# reference: tests/test_voronoi.py:11-36
+@needs_voro
+@pytest.mark.parametrize("path", VOR_PATHS, ids=ids_of(VOR_PATHS))
+def test_voronoi_against_fixture(path, oracle_backend):
+    d = np.load(path)
+    s = system_from_fixture(d)
+    s.cal_voronoi_volume()
+    assert np.allclose(d["voronoi_volume"], s.data["volume"].to_numpy(), atol=1e-6)
+    assert np.allclose(d["voronoi_cavity_radius"], s.data["cavity_radius"].to_numpy() * 0.5, atol=1e-6)  # OVITO convention
+    assert np.array_equal(d["voronoi_coord"], s.data["neighbor_number"].to_numpy())
