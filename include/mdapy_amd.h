@@ -242,6 +242,19 @@ int mdh_voronoi_volume_number_radius(const double *x, const double *y, const dou
                                      const double *origin3_host, const int *boundary3_host, double *volume, int *nfaces,
                                      double *radius, int space, void *stream);
 
+/* replaces _voronoi.get_voronoi_neighbor                      src/voronoi.cpp:307-447, in two calls:
+ * count: neighbor_number (N) i32 = faces per cell (walls included), *width_host = their maximum;
+ * rows:  verlet / distance / face_area (N, width): faces shared with atoms whose area exceeds
+ *        max(a_thr, r_thr * total face area of the cell), nearest first (voro++'s face order is internal to that
+ *        library; consumers skip -1 entries), padded with -1 / 10000 / 0. */
+int mdh_voronoi_neighbor_count(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+                               const double *origin3_host, const int *boundary3_host, int *neighbor_number, int *width_host,
+                               int space, void *stream);
+int mdh_voronoi_neighbor(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+                         const double *origin3_host, const int *boundary3_host, double a_face_area_threshold,
+                         double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width, int space,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

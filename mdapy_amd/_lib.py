@@ -65,6 +65,8 @@ _SIGNATURES = {
     "mdh_identify_sftb_fcc": [vp, i64, vp, vp, vp, i64, vp, cint, cint, vp],
     "mdh_filter_overlap_atom": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, cint, vp],
     "mdh_voronoi_volume_number_radius": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, cint, vp],
+    "mdh_voronoi_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, vp, vp, cint, vp],
+    "mdh_voronoi_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, dbl, vp, vp, vp, cint, cint, vp],
     "mdh_filter_by_type": [vp, vp, vp, vp, i64, i64, vp, vp, vp, cint, cint, vp],
 }
 _RESTYPES = {"mdh_last_error": C.c_char_p, "mdh_workspace_bytes": C.c_int64}

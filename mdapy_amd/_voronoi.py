@@ -30,3 +30,42 @@ def get_voronoi_volume_number_radius_tri(x, y, z, box, origin, boundary, rotatio
         x, y, z = (x * r[0, k] + y * r[1, k] + z * r[2, k] for k in range(3))
     get_voronoi_volume_number_radius(np.ascontiguousarray(x), np.ascontiguousarray(y), np.ascontiguousarray(z), box, np.zeros(3),
                                      np.ones(3, i32), volume, neighbor_number, cavity_radius, num_t)
+
+
+def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, r_face_area_threshold, num_t=1):
+    """src/voronoi.cpp:307 -> (verlet (N,W) i32, distance (N,W) f64, face_area (N,W) f64, neighbor_number (N) i32).
+    Rows list the faces shared with atoms, nearest first (the reference's rows follow voro++'s internal face order and
+    keep -1 holes where a face was filtered; every consumer skips -1 entries)."""
+    import ctypes
+
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    n = int(len(x))
+    nn = np.zeros(n, i32)
+    w = ctypes.c_int(0)
+    c = Call(x, y, z)
+    if c.space != _lib.HOST:
+        raise TypeError("get_voronoi_neighbor takes host (numpy) positions")
+    L = _lib.lib()
+    _lib.check(L.mdh_voronoi_neighbor_count(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, nn.ctypes.data,
+                                            ctypes.byref(w), c.space, c.stream))
+    width = max(int(w.value), 1)
+    verlet = np.full((n, width), -1, i32)
+    dist = np.full((n, width), 10000.0)
+    area = np.zeros((n, width))
+    _lib.check(L.mdh_voronoi_neighbor(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, float(a_face_area_threshold),
+                                      float(r_face_area_threshold), verlet.ctypes.data, dist.ctypes.data, area.ctypes.data, width,
+                                      c.space, c.stream))
+    return verlet, dist, area, nn
+
+
+def get_voronoi_neighbor_tri(x, y, z, box, origin, boundary, rotation, need_rotation, a_face_area_threshold,
+                             r_face_area_threshold, num_t=1):
+    """src/voronoi.cpp:149 — LAMMPS-aligned box, fully periodic; ids and areas are invariant under the rotation"""
+    x = np.asarray(x, f64) - origin[0]
+    y = np.asarray(y, f64) - origin[1]
+    z = np.asarray(z, f64) - origin[2]
+    if need_rotation:
+        r = np.asarray(rotation, f64)
+        x, y, z = (x * r[0, k] + y * r[1, k] + z * r[2, k] for k in range(3))
+    return get_voronoi_neighbor(np.ascontiguousarray(x), np.ascontiguousarray(y), np.ascontiguousarray(z), box, np.zeros(3),
+                                np.ones(3, i32), a_face_area_threshold, r_face_area_threshold, num_t)

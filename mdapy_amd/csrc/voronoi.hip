@@ -30,13 +30,17 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                                                         const double *__restrict__ z, int64_t N, DBox b,
                                                         const int *__restrict__ verlet, const int *__restrict__ nn, int64_t M,
                                                         double rc, double *__restrict__ volume, int *__restrict__ nfaces,
-                                                        double *__restrict__ radius, int *__restrict__ incomplete)
+                                                        double *__restrict__ radius, int *__restrict__ incomplete,
+                                                        int *__restrict__ row_id, double *__restrict__ row_dist,
+                                                        double *__restrict__ row_area, int W, double a_thr, double r_thr,
+                                                        int64_t n_orig, int *__restrict__ max_faces)
 {
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
     __shared__ double nrm[VORO_MAXC + 6][3];
     __shared__ double off[VORO_MAXC + 6], dist[VORO_MAXC + 6];
     __shared__ double poly_lds[PolyLdsV::CAP * 3 * VORO_LANES];
+    __shared__ double farea[VORO_MAXC + 6]; // area of face f (0: no face)
     const double xi = x[i], yi = y[i], zi = z[i];
     // rows are sorted by distance: a crowded atom uses its VORO_MAXC nearest neighbours and is complete within THEIR reach
     const int n = min(min(nn[i], (int)M), VORO_MAXC);
@@ -67,9 +71,10 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
     }
     __syncthreads();
     const int nc = n + 6;
-    double vol = 0.0, mr2 = 0.0;
+    double vol = 0.0, mr2 = 0.0, asum = 0.0;
     int nf = 0;
     for (int f = lane; f < nc; f += VORO_LANES) {
+        farea[f] = 0.0;
         if (f < 6 && (TRI || b.pbc[f >> 1]))
             continue; // the bounding cube is not a face
         PolyLdsV fast{poly_lds + lane};
@@ -82,12 +87,15 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
             vol += r.area * dist[f] / 3.0;
             ++nf;
             mr2 = fmax(mr2, r.maxr2);
+            farea[f] = r.area;
+            asum += r.area;
         }
     }
     // wave reduction (fixed butterfly order: deterministic)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         vol += __shfl_xor(vol, d, 64);
+        asum += __shfl_xor(asum, d, 64);
         nf += __shfl_xor(nf, d, 64);
         mr2 = fmax(mr2, __shfl_xor(mr2, d, 64));
     }
@@ -99,6 +107,37 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
         const double reach = nn[i] > VORO_MAXC ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
         if (2.0 * rmax > reach || nn[i] > M)
             atomicAdd(incomplete, 1);
+        if (max_faces && i < n_orig) atomicMax(max_faces, nf);
+    }
+    // Voronoi neighbour rows (src/voronoi.cpp:307-447): the faces shared with atoms — walls have no partner — whose area
+    // exceeds max(a_thr, r_thr * total face area), nearest first, padded with -1 / 10000 / 0
+    if (row_id && i < n_orig) {
+        __syncthreads();
+        double amin = a_thr > 0 ? a_thr : 0.0;
+        if (r_thr > 0) amin = asum * r_thr;
+        if (a_thr > amin) amin = a_thr;
+        int base = 0;
+        for (int f0 = 6; f0 < nc; f0 += VORO_LANES) {
+            const int f = f0 + lane;
+            const bool keep = f < nc && farea[f] > 0.0 && farea[f] > amin;
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < W) {
+                    const int64_t o = i * (int64_t)W + slot;
+                    row_id[o] = (int)(verlet[i * M + (f - 6)] % n_orig); // image of a replicated system -> original atom
+                    row_dist[o] = 2.0 * dist[f];
+                    row_area[o] = farea[f];
+                }
+            }
+            base += __popcll(m);
+        }
+        for (int slot = base + lane; slot < W; slot += VORO_LANES) {
+            const int64_t o = i * (int64_t)W + slot;
+            row_id[o] = -1;
+            row_dist[o] = 10000.0;
+            row_area[o] = 0.0;
+        }
     }
 }
 
@@ -123,7 +162,8 @@ __global__ void k_replicate(const double *__restrict__ x, const double *__restri
 // cells of all `N` atoms of one (possibly replicated) system; 1 = some cells reach beyond half a period (caller replicates)
 static int voronoi_solve(void *stream, const double *dx, const double *dy, const double *dz, int64_t N, const double *box9,
                          const double *origin3, const int *boundary3, double *dvol, int *dnf, double *drad, int *dnn, int *dflag,
-                         bool *too_small)
+                         bool *too_small, int *row_id, double *row_dist, double *row_area, int W, double a_thr, double r_thr,
+                         int64_t n_orig, int *dmaxf)
 {
     *too_small = false;
     DBox b;
@@ -151,12 +191,13 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         MDH_TRY(mdh_build_neighbor(dx, dy, dz, N, box9, origin3, boundary3, rc, dv, dd, dnn, M, 1, MDH_DEVICE, stream));
         MDH_TRY(mdh_sort_verlet_by_distance(dv, dd, N, M, (int)M, MDH_DEVICE, stream));
         MDH_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
+        if (dmaxf) MDH_HIP(hipMemsetAsync(dmaxf, 0, sizeof(int), st));
         {
             ProfRange pr("k_voronoi", st);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -177,9 +218,11 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
 
 using namespace mdh;
 
-extern "C" int mdh_voronoi_volume_number_radius(const double *x, const double *y, const double *z, int64_t N, const double *box9,
-                                                const double *origin3, const int *boundary3, double *volume, int *nfaces,
-                                                double *radius, int space, void *stream)
+// shared driver: volumes always; neighbour rows (width W, original atom ids) when row_id != nullptr; *max_faces_host
+// receives the largest face count (walls included) of the N atoms
+static int voronoi_driver(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+                          const int *boundary3, double *volume, int *nfaces, double *radius, int *row_id, double *row_dist,
+                          double *row_area, int W, double a_thr, double r_thr, int *max_faces_host, int space, void *stream)
 {
     if (N < 0 || N >= 2147483647LL) { set_error("mdh_voronoi_volume_number_radius: invalid N"); return MDH_ERR_ARG; }
     DBox b;
@@ -192,7 +235,10 @@ extern "C" int mdh_voronoi_volume_number_radius(const double *x, const double *y
     double *dvol = sc.stage(volume, (size_t)N, space, false, true);
     int *dnf = sc.stage(nfaces, (size_t)N, space, false, true);
     double *drad = sc.stage(radius, (size_t)N, space, false, true);
-    int *dflag = sc.alloc_n<int>(1);
+    int *dflag = sc.alloc_n<int>(2);
+    int *drid = row_id ? sc.stage(row_id, (size_t)N * (size_t)W, space, false, true) : nullptr;
+    double *drd = row_id ? sc.stage(row_dist, (size_t)N * (size_t)W, space, false, true) : nullptr;
+    double *dra = row_id ? sc.stage(row_area, (size_t)N * (size_t)W, space, false, true) : nullptr;
     if (sc.failed())
         return sc.error();
     // Cells wider than half a period cannot be described by minimum-image rows: the periodic axes that are too thin are
@@ -226,12 +272,17 @@ extern "C" int mdh_voronoi_volume_number_radius(const double *x, const double *y
         if (work.failed())
             return work.error();
         bool too_small = false;
-        MDH_TRY(voronoi_solve(stream, px, py, pz, total, big9, origin3, boundary3, wv, wn, wr, dnn, dflag, &too_small));
+        MDH_TRY(voronoi_solve(stream, px, py, pz, total, big9, origin3, boundary3, wv, wn, wr, dnn, dflag, &too_small, drid, drd, dra, W, a_thr,
+                              r_thr, N, dflag + 1));
         if (!too_small) {
             if (total != N) {
                 MDH_HIP(hipMemcpyAsync(dvol, wv, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
                 MDH_HIP(hipMemcpyAsync(dnf, wn, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
                 MDH_HIP(hipMemcpyAsync(drad, wr, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+                MDH_HIP(hipStreamSynchronize(st));
+            }
+            if (max_faces_host) {
+                MDH_HIP(hipMemcpyAsync(max_faces_host, dflag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
                 MDH_HIP(hipStreamSynchronize(st));
             }
             return sc.finish(space);
@@ -245,4 +296,65 @@ extern "C" int mdh_voronoi_volume_number_radius(const double *x, const double *y
     }
     set_error("mdh_voronoi_volume_number_radius: cells still reach beyond half the replicated box (extremely dilute system)");
     return MDH_ERR_ARG;
+}
+
+extern "C" int mdh_voronoi_volume_number_radius(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                                const double *origin3, const int *boundary3, double *volume, int *nfaces,
+                                                double *radius, int space, void *stream)
+{
+    return voronoi_driver(x, y, z, N, box9, origin3, boundary3, volume, nfaces, radius, nullptr, nullptr, nullptr, 0, -1.0, -1.0,
+                          nullptr, space, stream);
+}
+
+// replaces _voronoi.get_voronoi_neighbor (src/voronoi.cpp:307-447) in two calls, like the exact-width neighbor build:
+//   mdh_voronoi_neighbor_count: neighbor_number (N) = faces per cell (walls included, as voro++ reports them) and the
+//                               row width = their maximum;
+//   mdh_voronoi_neighbor:       verlet / distance / face_area (N, width): the faces shared with atoms whose area exceeds
+//                               max(a_thr, r_thr * total face area), NEAREST FIRST (voro++'s face order is an internal
+//                               detail of that library), then -1 / 10000 / 0.
+extern "C" int mdh_voronoi_neighbor_count(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                          const double *origin3, const int *boundary3, int *neighbor_number, int *width_host,
+                                          int space, void *stream)
+{
+    if (!width_host) { set_error("mdh_voronoi_neighbor_count: width_host is NULL"); return MDH_ERR_ARG; }
+    *width_host = 0;
+    if (N <= 0)
+        return N == 0 ? MDH_OK : MDH_ERR_ARG;
+    Scope sc(stream);
+    double *v = sc.alloc_n<double>((size_t)N), *r = sc.alloc_n<double>((size_t)N);
+    int *nf = sc.stage(neighbor_number, (size_t)N, space, false, true);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    if (sc.failed())
+        return sc.error();
+    MDH_TRY(voronoi_driver(dx, dy, dz, N, box9, origin3, boundary3, v, nf, r, nullptr, nullptr, nullptr, 0, -1.0, -1.0, width_host,
+                           MDH_DEVICE, stream));
+    return sc.finish(space);
+}
+
+extern "C" int mdh_voronoi_neighbor(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                    const double *origin3, const int *boundary3, double a_face_area_threshold,
+                                    double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width,
+                                    int space, void *stream)
+{
+    if (N < 0 || width <= 0) { set_error("mdh_voronoi_neighbor: invalid shape"); return MDH_ERR_ARG; }
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    double *v = sc.alloc_n<double>((size_t)N), *r = sc.alloc_n<double>((size_t)N);
+    int *nf = sc.alloc_n<int>((size_t)N);
+    if (sc.failed())
+        return sc.error();
+    // scratch volumes are device arrays whatever the caller's space: run the driver on device copies of the inputs
+    if (space == MDH_HOST) {
+        const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+        int *dv = sc.stage(verlet, (size_t)N * width, space, false, true);
+        double *dd = sc.stage(distance, (size_t)N * width, space, false, true), *da = sc.stage(face_area, (size_t)N * width, space, false, true);
+        if (sc.failed())
+            return sc.error();
+        MDH_TRY(voronoi_driver(dx, dy, dz, N, box9, origin3, boundary3, v, nf, r, dv, dd, da, width, a_face_area_threshold,
+                               r_face_area_threshold, nullptr, MDH_DEVICE, stream));
+        return sc.finish(space);
+    }
+    return voronoi_driver(x, y, z, N, box9, origin3, boundary3, v, nf, r, verlet, distance, face_area, width, a_face_area_threshold,
+                          r_face_area_threshold, nullptr, MDH_DEVICE, stream);
 }

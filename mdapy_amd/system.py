@@ -274,6 +274,16 @@ class System:
         self.cluster_number = ca.cluster_number
         self.update_data(self.data.with_columns(cluster_id=as_numpy(ca.particleClusters)[: self.N]))
 
+    def build_voronoi_neighbor(self, a_face_area_threshold: float = -1.0, r_face_area_threshold: float = -1.0) -> None:
+        """``voro_verlet_list / voro_distance_list / voro_face_area / voro_neighbor_number`` (system.py:1168-1230)"""
+        vor = Voronoi(self.box, self.data)
+        (self.voro_verlet_list, self.voro_distance_list, self.voro_face_area,
+         self.voro_neighbor_number) = vor.get_neighbor(a_face_area_threshold, r_face_area_threshold)
+        if hasattr(vor, "_enlarge_box"):
+            self._enlarge_box = vor._enlarge_box
+        if hasattr(vor, "_enlarge_data"):
+            self._enlarge_data = vor._enlarge_data
+
     def cal_voronoi_volume(self) -> None:
         """columns ``volume``, ``neighbor_number`` (faces), ``cavity_radius`` (system.py:2544-2573)"""
         vor = Voronoi(self.box, self.data)
@@ -319,9 +329,13 @@ class System:
                                         threshold: float = 0.7, n_bond: int = 7,
                                         max_neigh: Optional[int] = None) -> None:
         """columns ``ql{l}`` (+ ``wl{l}``, ``wlh{l}``, ``solidliquid``, ``nbond``) (system.py:1716-1861)"""
-        if use_voronoi:
-            raise NotImplementedError("Voronoi neighbors are outside the hot path built here (SURVEY.md §8f)")
-        if nnn > 0:
+        v_list = d_list = n_list = None
+        if use_voronoi:  # system.py:1781-1789
+            self.build_voronoi_neighbor(a_face_area_threshold, r_face_area_threshold)
+            v_list, d_list, n_list = self.voro_verlet_list, self.voro_distance_list, self.voro_neighbor_number
+            if use_weight and weight is None:
+                weight = self.voro_face_area
+        elif nnn > 0:
             has_sort_neigh = False
             if hasattr(self, "neighbor_number"):
                 if self.neighbor_number.min() >= nnn:
@@ -337,9 +351,12 @@ class System:
             else:
                 self.build_neighbor(rc, max_neigh)
         box, data = self._get_compute_view()
+        if use_voronoi and hasattr(self, "_enlarge_data"):
+            box, data = self._enlarge_box, self._enlarge_data
+        if v_list is None:
+            v_list, d_list, n_list = self.verlet_list, self.distance_list, self.neighbor_number
         SBO = SteinhardtBondOrientation(box, data, np.asarray(llist, int), nnn, rc, average, use_voronoi, use_weight,
-                                        weight, self.verlet_list, self.distance_list, self.neighbor_number, wl, wlhat,
-                                        identify_liquid, threshold, n_bond)
+                                        weight, v_list, d_list, n_list, wl, wlhat, identify_liquid, threshold, n_bond)
         SBO.compute()
         qn = as_numpy(SBO.qnarray)
         new = {}

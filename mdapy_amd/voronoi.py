@@ -1,5 +1,5 @@
 """Voronoi cell volume / face count / cavity radius.  Mirrors ``mdapy.voronoi.Voronoi.get_volume``
-(src/mdapy/voronoi.py:160-215); Voronoi neighbour lists (``get_neighbor``) are not built yet."""
+and ``get_neighbor`` (src/mdapy/voronoi.py:20-215).  ``get_cell_info`` (vertex lists for rendering) is not built."""
 from __future__ import annotations
 
 import numpy as np
@@ -16,6 +16,40 @@ class Voronoi:
     def __init__(self, box: Box, data: Frame):
         self.box = box
         self.data = data
+
+    def get_neighbor(self, a_face_area_threshold: float = -1.0, r_face_area_threshold: float = -1.0):
+        """-> verlet_list, distance_list, face_area (N, W), neighbor_number (N) (voronoi.py:20-110)"""
+        num_t = get_num_threads()
+        repeat = [1, 1, 1]
+        N = self.data.shape[0]
+        nopbc = False
+        if N < 50:
+            if sum(self.box.boundary) > 0:
+                while np.prod(repeat) * N < 50:
+                    for i in range(3):
+                        if self.box.boundary[i] == 1:
+                            repeat[i] += 1
+            else:
+                assert N > 1, "system with all free boundary must has at least 2 atoms."
+                nopbc = True
+        data, box = self.data, self.box
+        if sum(repeat) != 3:
+            self._enlarge_data, self._enlarge_box = tool._replicate_pos(data, box, *repeat)
+            data, box = self._enlarge_data, self._enlarge_box
+        x, y, z = (np.ascontiguousarray(as_numpy(a), dtype=np.float64) for a in tool.xyz(data))
+        if box.triclinic and not nopbc:
+            b = box.box
+            need_rotation = bool(abs(b[0, 1]) > 1e-10 or abs(b[0, 2]) > 1e-10 or abs(b[1, 2]) > 1e-10 or b[0, 0] < 0
+                                 or b[1, 1] < 0 or b[2, 2] < 0)
+            lbox, rotation = box.align_to_lammps_box()
+            bb = lbox.box.copy()
+            for i in range(3):
+                if lbox.boundary[i] == 0:
+                    bb[i] *= 3
+            return _voronoi.get_voronoi_neighbor_tri(x, y, z, bb, lbox.origin, lbox.boundary, rotation, need_rotation,
+                                                     a_face_area_threshold, r_face_area_threshold, num_t)
+        return _voronoi.get_voronoi_neighbor(x, y, z, box.box, box.origin, box.boundary, a_face_area_threshold,
+                                             r_face_area_threshold, num_t)
 
     def get_volume(self):
         n = self.data.shape[0]

@@ -406,3 +406,28 @@ def voronoi_faces(x, y, z, box, origin, boundary, width=64):
     voro_lib().ref_voronoi_faces(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(n), _p(b, np.float64), _p(o, np.float64),
                                  _p(p, np.int32), _p(nbr, np.int32), _p(area, np.float64), cint(width), _p(cnt, np.int32))
     return nbr, area, cnt
+
+
+def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, r_face_area_threshold, num_t=1):
+    """mdapy._voronoi.get_voronoi_neighbor (src/voronoi.cpp:307-447): voro++ faces, then the thresholds and the -1 holes
+    of :389-430, restated with numpy"""
+    nbr, area, cnt = voronoi_faces(x, y, z, box, origin, boundary, width=96)
+    width = max(int(cnt.max()), 1)
+    nbr, area = nbr[:, :width], area[:, :width]
+    n = len(cnt)
+    amin = np.full(n, a_face_area_threshold if a_face_area_threshold > 0 else 0.0)
+    if r_face_area_threshold > 0:
+        amin = area.sum(axis=1) * r_face_area_threshold
+    amin = np.maximum(amin, a_face_area_threshold)
+    valid = (np.arange(width)[None, :] < cnt[:, None]) & (nbr >= 0) & (area > amin[:, None])
+    verlet = np.where(valid, nbr, -1).astype(np.int32)
+    face = np.where(valid, area, 0.0)
+    b = np.asarray(box, float)
+    b = b if b.ndim == 2 else np.diag(b)
+    pos = np.stack([np.asarray(x, float), np.asarray(y, float), np.asarray(z, float)], axis=1)
+    d = pos[np.clip(verlet, 0, None)] - pos[:, None, :]
+    for a in range(3):
+        if boundary[a]:
+            d[..., a] -= b[a, a] * np.floor(d[..., a] / b[a, a] + 0.5)
+    dist = np.where(valid, np.sqrt((d ** 2).sum(-1)), 10000.0)
+    return verlet, dist, face, cnt.astype(np.int32)

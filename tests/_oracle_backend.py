@@ -90,6 +90,8 @@ voronoi = _mod(
         O.get_voronoi_volume_number_radius(_np(x), _np(y), _np(z), box, origin, boundary, v, n, r, NT),
     get_voronoi_volume_number_radius_tri=lambda x, y, z, box, origin, boundary, rot, v, n, r, need, num_t=1:
         O.get_voronoi_volume_number_radius_tri(_np(x), _np(y), _np(z), box, origin, boundary, rot, v, n, r, need, NT),
+    get_voronoi_neighbor=lambda x, y, z, box, origin, boundary, a, r, num_t=1:
+        O.get_voronoi_neighbor(_np(x), _np(y), _np(z), box, origin, boundary, a, r, NT),
 )
 repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
 

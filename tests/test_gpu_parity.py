@@ -753,3 +753,37 @@ def test_voronoi_vs_reference_library(case):
     if all(bd):
         vol = abs(np.linalg.det(np.asarray(box, float))) if np.ndim(box) == 2 else float(np.prod(box))
         assert abs(v1.sum() - vol) < 1e-6 * vol  # the cells tile the periodic box
+
+
+@needs_voro
+@pytest.mark.parametrize("case", ["fcc_rattled", "fcc_hot_shifted_origin", "random_gas", "slab_open_z"])
+def test_voronoi_neighbors_vs_reference_library(case):
+    """neighbour SETS with their face areas and distances (the reference's row order is voro++'s internal face order)"""
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    if case == "slab_open_z":
+        pos = pos.copy(); pos[:, 2] = np.clip(pos[:, 2], 1e-3, (box[2, 2] if np.ndim(box) == 2 else box[2]) - 1e-3)
+    x, y, z = _xyz(pos)
+    for a_thr, r_thr in ((-1.0, -1.0), (0.3, -1.0), (-1.0, 0.02)):
+        v0, d0, f0, n0 = O.get_voronoi_neighbor(x, y, z, box, origin, bd, a_thr, r_thr)
+        v1, d1, f1, n1 = _voronoi.get_voronoi_neighbor(x, y, z, box, origin, bd, a_thr, r_thr)
+        assert np.array_equal(n1, n0)
+        # canonical form of a row: entries sorted by (neighbour id, distance)
+        def canon(v, d, f):
+            key = np.where(v >= 0, v, np.iinfo(np.int32).max).astype(np.int64) * 1000003 + np.round(d * 1e3).astype(np.int64) % 1000003
+            o = np.argsort(key, axis=1, kind="stable")
+            return np.take_along_axis(v, o, 1), np.take_along_axis(d, o, 1), np.take_along_axis(f, o, 1)
+        w = max(v0.shape[1], v1.shape[1])
+        pad = lambda a, fill: np.pad(a, ((0, 0), (0, w - a.shape[1])), constant_values=fill)
+        c0 = canon(pad(v0, -1), pad(d0, 10000.0), pad(f0, 0.0))
+        c1 = canon(pad(v1, -1), pad(d1, 10000.0), pad(f1, 0.0))
+        assert np.array_equal(c1[0], c0[0])
+        assert np.allclose(c1[1], c0[1], rtol=1e-9, atol=1e-9) and np.allclose(c1[2], c0[2], rtol=1e-7, atol=1e-9)
+        dd = np.where(v1 >= 0, d1, 1e9)
+        assert np.all(np.diff(dd, axis=1) >= 0)  # rows are nearest-first, pads last
+
+
+def test_voronoi_weighted_steinhardt_system_flow():
+    s = mp.build_crystal("Al", "fcc", 4.05, nx=6, ny=6, nz=6)
+    s.cal_steinhardt_bond_orientation([4, 6], use_voronoi=True, use_weight=True)
+    assert np.allclose(s.data["ql4"].to_numpy(), 0.190941, atol=1e-6) and np.allclose(s.data["ql6"].to_numpy(), 0.574524, atol=1e-6)
+    assert np.all(np.asarray(s.voro_neighbor_number) == 12)

@@ -391,3 +391,19 @@ def test_voronoi_against_fixture(path, oracle_backend):
     assert np.allclose(d["voronoi_volume"], s.data["volume"].to_numpy(), atol=1e-6)
     assert np.allclose(d["voronoi_cavity_radius"], s.data["cavity_radius"].to_numpy() * 0.5, atol=1e-6)  # OVITO convention
     assert np.array_equal(d["voronoi_coord"], s.data["neighbor_number"].to_numpy())
+
+
+@needs_voro
+def test_voronoi_neighbors_and_voronoi_weighted_steinhardt_closed_forms(oracle_backend):
+    """perfect fcc: 12 Voronoi neighbours with equal faces (rhombic dodecahedron, face area a^2 sqrt(2) / 8); the
+    Voronoi-neighbour q6 equals the cutoff value 0.574524 (reference: tests/test_steinhardt_bond_orientation.py)"""
+    a = 4.05
+    s = mp.build_crystal("Al", "fcc", a, nx=4, ny=4, nz=4)
+    s.build_voronoi_neighbor()
+    v, d, f, n = (np.asarray(q) for q in (s.voro_verlet_list, s.voro_distance_list, s.voro_face_area, s.voro_neighbor_number))
+    assert np.all(n == 12) and np.all((v >= 0).sum(axis=1) == 12)
+    assert np.allclose(d[v >= 0], a / np.sqrt(2)) and np.allclose(f[v >= 0], a * a * np.sqrt(2) / 8)
+    s.cal_steinhardt_bond_orientation([6], use_voronoi=True)
+    assert np.allclose(s.data["ql6"].to_numpy(), 0.574524, atol=1e-6)
+    s.cal_steinhardt_bond_orientation([4, 6], use_voronoi=True, use_weight=True)
+    assert np.allclose(s.data["ql4"].to_numpy(), 0.190941, atol=1e-6)
