@@ -255,6 +255,19 @@ int mdh_voronoi_neighbor(const double *x, const double *y, const double *z, int6
                          double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width, int space,
                          void *stream);
 
+/* ---- _sfc (static structure factor, direct summation) ------------ */
+/* replaces _sfc.compute_sfc_direct                          src/structure_factor.cpp:654-680 (StructureFactorDirect :64-447)
+ * sf_host (bins) is always a host array; qx/qy/qz NULL = total S(k), otherwise the cross term between the two point sets
+ * (n_total required then).  Empty bins are NaN. */
+int mdh_sfc_direct(const double *x, const double *y, const double *z, int64_t n, const double *box9_host, double *sf_host, int bins,
+                   double k_max, double k_min, const double *qx, const double *qy, const double *qz, int64_t nq,
+                   unsigned n_total, int space, void *stream);
+/* replaces _sfc.compute_sfc_direct_partial                  src/structure_factor.cpp:682-705 (:451-640)
+ * out_host (ntype, ntype, bins) host array of Ashcroft-Langreth partials; type 0-based, ntype <= 16 */
+int mdh_sfc_direct_partial(const double *x, const double *y, const double *z, const int *type, int ntype, int64_t n,
+                           const double *box9_host, double *out_host, int bins, double k_max, double k_min, int space,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "mdh_voronoi_volume_number_radius": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, cint, vp],
     "mdh_voronoi_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, vp, vp, cint, vp],
     "mdh_voronoi_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, dbl, vp, vp, vp, cint, cint, vp],
+    "mdh_sfc_direct": [vp, vp, vp, i64, vp, vp, cint, dbl, dbl, vp, vp, vp, i64, C.c_uint, cint, vp],
+    "mdh_sfc_direct_partial": [vp, vp, vp, vp, cint, i64, vp, vp, cint, dbl, dbl, cint, vp],
     "mdh_filter_by_type": [vp, vp, vp, vp, i64, i64, vp, vp, vp, cint, cint, vp],
 }
 _RESTYPES = {"mdh_last_error": C.c_char_p, "mdh_workspace_bytes": C.c_int64}

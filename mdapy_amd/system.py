@@ -36,6 +36,7 @@ from .polyhedral_template_matching import PolyhedralTemplateMatching
 from .radial_distribution_function import RadialDistributionFunction
 from .steinhardt_bond_orientation import SteinhardtBondOrientation
 from .structure_entropy import StructureEntropy
+from .structure_factor import StructureFactor
 from .voronoi import Voronoi
 from .warren_cowley_parameter import WarrenCowleyParameter
 
@@ -283,6 +284,14 @@ class System:
             self._enlarge_box = vor._enlarge_box
         if hasattr(vor, "_enlarge_data"):
             self._enlarge_data = vor._enlarge_data
+
+    def cal_structure_factor(self, k_min: float, k_max: float, nbins: int, cal_partial: bool = False,
+                             atomic_form_factors: bool = False, mode: str = "debye", rc: Optional[float] = None,
+                             nbin_rdf: int = 200, window: bool = False) -> StructureFactor:
+        """-> StructureFactor with ``k``, ``Sk``, ``Sk_partial`` (system.py: cal_structure_factor)"""
+        sf = StructureFactor(self.data, self.box, k_min, k_max, nbins, cal_partial, atomic_form_factors, mode, rc, nbin_rdf, window)
+        sf.compute()
+        return sf
 
     def cal_voronoi_volume(self) -> None:
         """columns ``volume``, ``neighbor_number`` (faces), ``cavity_radius`` (system.py:2544-2573)"""

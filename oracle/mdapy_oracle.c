@@ -1547,3 +1547,154 @@ ORC_API int orc_filter_overlap_atom(const double *x, const double *y, const doub
     ogrid_free(&g);
     return 0;
 }
+
+/* ====================================================================== static structure factor, direct summation
+ *                                                                          src/structure_factor.cpp:64-447 (total / cross)
+ *                                                                          src/structure_factor.cpp:451-640 (all partials)
+ * The two classes enumerate the reciprocal-lattice points differently (:122-200 vs :595-630); both are restated. */
+typedef struct { double x, y, z; } sfc_v3;
+static void sfc_recip(const double *h, sfc_v3 *b)                          /* :66-103 */
+{
+    const double *a = h, *bb = h + 3, *c = h + 6;
+    const double vol = a[0] * (bb[1] * c[2] - bb[2] * c[1]) - a[1] * (bb[0] * c[2] - bb[2] * c[0]) + a[2] * (bb[0] * c[1] - bb[1] * c[0]);
+    const double tp = 2.0 * 3.14159265358979323846;
+    b[0].x = (bb[1] * c[2] - bb[2] * c[1]) / vol * tp; b[0].y = (bb[2] * c[0] - bb[0] * c[2]) / vol * tp; b[0].z = (bb[0] * c[1] - bb[1] * c[0]) / vol * tp;
+    b[1].x = (c[1] * a[2] - c[2] * a[1]) / vol * tp;   b[1].y = (c[2] * a[0] - c[0] * a[2]) / vol * tp;   b[1].z = (c[0] * a[1] - c[1] * a[0]) / vol * tp;
+    b[2].x = (a[1] * bb[2] - a[2] * bb[1]) / vol * tp; b[2].y = (a[2] * bb[0] - a[0] * bb[2]) / vol * tp; b[2].z = (a[0] * bb[1] - a[1] * bb[0]) / vol * tp;
+}
+static double sfc_norm(sfc_v3 v) { return sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+static double sfc_dot(sfc_v3 a, sfc_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+/* k-points of StructureFactorDirect::generateKPoints (:105-200); returns the count, fills kp (3 doubles each) if not NULL */
+ORC_API int64_t orc_sfc_kpoints_total(const double *box9, double k_max, double k_min, double *kp)
+{
+    const double tp = 2.0 * 3.14159265358979323846;
+    sfc_v3 b[3];
+    sfc_recip(box9, b);
+    const double q_max = k_max / tp, q_min = k_min / tp, q_max_sq = q_max * q_max, q_min_sq = q_min * q_min;
+    const int nkx = (int)ceil(q_max / (sfc_norm(b[0]) / tp)), nky = (int)ceil(q_max / (sfc_norm(b[1]) / tp)), nkz = (int)ceil(q_max / (sfc_norm(b[2]) / tp));
+    int64_t n = 0;
+    for (int i = 0; i < nkx; ++i) {
+        const sfc_v3 kx = {b[0].x * i, b[0].y * i, b[0].z * i};
+        for (int ky = 0; ky < nky; ++ky) {
+            const sfc_v3 kxy = {kx.x + b[1].x * ky, kx.y + b[1].y * ky, kx.z + b[1].z * ky};
+            const double ca = sfc_dot(b[2], b[2]), cb = -2.0 * sfc_dot(kxy, b[2]);
+            const double cmin = sfc_dot(kxy, kxy) - k_min * k_min, cmax = sfc_dot(kxy, kxy) - k_max * k_max;
+            const double b2a = cb / (2.0 * ca), dmin = b2a * b2a - cmin / ca, dmax = b2a * b2a - cmax / ca;
+            if (dmax < 0) continue;
+            const double zmin = dmin < 0 ? 0.0 : -b2a + sqrt(dmin), zmax = -b2a + sqrt(dmax);
+            int kz0 = (int)floor(zmin), kz1 = (int)ceil(zmax);
+            if (kz0 < 0) kz0 = 0;
+            if (kz1 > nkz - 1) kz1 = nkz - 1;
+            for (int kz = kz0; kz <= kz1; ++kz) {
+                const sfc_v3 k = {kxy.x + b[2].x * kz, kxy.y + b[2].y * kz, kxy.z + b[2].z * kz};
+                const double qd = sfc_dot(k, k) / (tp * tp);
+                if (qd <= q_max_sq && qd >= q_min_sq) {
+                    if (kp) { kp[3 * n] = k.x; kp[3 * n + 1] = k.y; kp[3 * n + 2] = k.z; }
+                    ++n;
+                }
+            }
+        }
+    }
+    return n;
+}
+/* k-points of StructureFactorDirectPartial::helper_kpoints (:595-630) */
+ORC_API int64_t orc_sfc_kpoints_partial(const double *box9, double k_max, double k_min, double *kp)
+{
+    const double tp = 2.0 * 3.14159265358979323846;
+    sfc_v3 b[3];
+    sfc_recip(box9, b);
+    const double q_max = k_max / tp;
+    const int nkx = (int)ceil(q_max / (sfc_norm(b[0]) / tp)), nky = (int)ceil(q_max / (sfc_norm(b[1]) / tp)), nkz = (int)ceil(q_max / (sfc_norm(b[2]) / tp));
+    int64_t n = 0;
+    for (int i = 0; i < nkx; ++i)
+        for (int j = 0; j < nky; ++j)
+            for (int k = 0; k < nkz; ++k) {
+                const sfc_v3 kv = {b[0].x * i + b[1].x * j + b[2].x * k, b[0].y * i + b[1].y * j + b[2].y * k, b[0].z * i + b[1].z * j + b[2].z * k};
+                /* the reference forms (bx*i + by*j) + bz*k: same association */
+                const double mag = sfc_norm(kv);
+                if (mag > k_min && mag <= k_max) {
+                    if (kp) { kp[3 * n] = kv.x; kp[3 * n + 1] = kv.y; kp[3 * n + 2] = kv.z; }
+                    ++n;
+                }
+            }
+    return n;
+}
+static int sfc_bin(double k, double k_min, double k_max, int bins)        /* :283-291 */
+{
+    if (k < k_min || k >= k_max) return -1;
+    int b = (int)((k - k_min) / (k_max - k_min) * bins);
+    return b < bins - 1 ? b : bins - 1;
+}
+/* total (qx == NULL) or cross structure factor between the point sets (:293-447) */
+ORC_API int orc_sfc_direct(const double *x, const double *y, const double *z, int64_t n, const double *box9, double *sf, int bins,
+                           double k_max, double k_min, const double *qx, const double *qy, const double *qz, int64_t nq,
+                           unsigned n_total, int num_t)
+{
+    const int64_t nk = orc_sfc_kpoints_total(box9, k_max, k_min, NULL);
+    if (nk <= 0) return -2;
+    double *kp = (double *)malloc(sizeof(double) * 3 * (size_t)nk);
+    orc_sfc_kpoints_total(box9, k_max, k_min, kp);
+    if (n_total == 0) n_total = (unsigned)n;
+    const double norm = 1.0 / sqrt((double)n_total);
+    double *sk = (double *)malloc(sizeof(double) * (size_t)nk);
+#pragma omp parallel for num_threads(num_t > 0 ? num_t : 1) schedule(dynamic)
+    for (int64_t k = 0; k < nk; ++k) {
+        double ar = 0, ai = 0, br = 0, bi = 0;
+        for (int64_t i = 0; i < n; ++i) { const double a = kp[3 * k] * x[i] + kp[3 * k + 1] * y[i] + kp[3 * k + 2] * z[i]; ar += cos(a); ai += sin(a); }
+        ar *= norm; ai *= norm;
+        if (qx) {
+            for (int64_t i = 0; i < nq; ++i) { const double a = kp[3 * k] * qx[i] + kp[3 * k + 1] * qy[i] + kp[3 * k + 2] * qz[i]; br += cos(a); bi += sin(a); }
+            br *= norm; bi *= norm;
+        } else { br = ar; bi = ai; }
+        sk[k] = ar * br + ai * bi;                                          /* Re(conj(F1) F2) */
+    }
+    unsigned *cnt = (unsigned *)calloc((size_t)bins, sizeof(unsigned));
+    for (int b = 0; b < bins; ++b) sf[b] = 0.0;
+    for (int64_t k = 0; k < nk; ++k) {
+        const double mag = sqrt(kp[3 * k] * kp[3 * k] + kp[3 * k + 1] * kp[3 * k + 1] + kp[3 * k + 2] * kp[3 * k + 2]);
+        const int b = sfc_bin(mag, k_min, k_max, bins);
+        if (b >= 0) { sf[b] += sk[k]; cnt[b]++; }
+    }
+    for (int b = 0; b < bins; ++b) sf[b] = cnt[b] ? sf[b] / cnt[b] : NAN;
+    free(kp); free(sk); free(cnt);
+    return 0;
+}
+/* all Ashcroft-Langreth partials, out (ntype, ntype, bins) (:451-560) */
+ORC_API int orc_sfc_direct_partial(const double *x, const double *y, const double *z, const int *type, int ntype, int64_t n,
+                                   const double *box9, double *out, int bins, double k_max, double k_min, int num_t)
+{
+    const int64_t nk = orc_sfc_kpoints_partial(box9, k_max, k_min, NULL);
+    if (nk <= 0) return -2;
+    double *kp = (double *)malloc(sizeof(double) * 3 * (size_t)nk);
+    orc_sfc_kpoints_partial(box9, k_max, k_min, kp);
+    double *fr = (double *)calloc((size_t)ntype * nk, sizeof(double)), *fi = (double *)calloc((size_t)ntype * nk, sizeof(double));
+    const double norm = 1.0 / sqrt((double)n);
+#pragma omp parallel for num_threads(num_t > 0 ? num_t : 1) schedule(dynamic)
+    for (int64_t k = 0; k < nk; ++k) {
+        double ar[64] = {0}, ai[64] = {0};
+        for (int64_t i = 0; i < n; ++i) { const double a = kp[3 * k] * x[i] + kp[3 * k + 1] * y[i] + kp[3 * k + 2] * z[i]; ar[type[i]] += cos(a); ai[type[i]] += sin(a); }
+        for (int t = 0; t < ntype; ++t) { fr[(size_t)t * nk + k] = ar[t] * norm; fi[(size_t)t * nk + k] = ai[t] * norm; }
+    }
+    unsigned *cnt = (unsigned *)calloc((size_t)bins, sizeof(unsigned));
+    int *bin = (int *)malloc(sizeof(int) * (size_t)nk);
+    for (int64_t k = 0; k < nk; ++k) {
+        const double mag = sqrt(kp[3 * k] * kp[3 * k] + kp[3 * k + 1] * kp[3 * k + 1] + kp[3 * k + 2] * kp[3 * k + 2]);
+        bin[k] = sfc_bin(mag, k_min, k_max, bins);
+        if (bin[k] >= 0) cnt[bin[k]]++;
+    }
+    for (int a = 0; a < ntype; ++a)
+        for (int b = a; b < ntype; ++b) {
+            double *loc = (double *)calloc((size_t)bins, sizeof(double));
+            for (int64_t k = 0; k < nk; ++k)
+                if (bin[k] >= 0) loc[bin[k]] += fr[(size_t)a * nk + k] * fr[(size_t)b * nk + k] + fi[(size_t)a * nk + k] * fi[(size_t)b * nk + k];
+            for (int q = 0; q < bins; ++q) {
+                const double v = cnt[q] ? loc[q] / cnt[q] : NAN;
+                out[((size_t)a * ntype + b) * bins + q] = v;
+                out[((size_t)b * ntype + a) * bins + q] = v;
+            }
+            free(loc);
+        }
+    free(kp); free(fr); free(fi); free(cnt); free(bin);
+    return 0;
+}

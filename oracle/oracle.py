@@ -431,3 +431,44 @@ def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, 
             d[..., a] -= b[a, a] * np.floor(d[..., a] / b[a, a] + 0.5)
     dist = np.where(valid, np.sqrt((d ** 2).sum(-1)), 10000.0)
     return verlet, dist, face, cnt.astype(np.int32)
+
+
+# --------------------------------------------------------------------- _sfc (static structure factor, direct summation)
+def compute_sfc_direct(x, y, z, box, origin, boundary, structure_factor_py, bins, k_max, k_min, query_x=None, query_y=None,
+                       query_z=None, N_total=0, num_t=1):
+    """mdapy._sfc.compute_sfc_direct (src/structure_factor.cpp:654)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b = _ro(box, np.float64).reshape(9)
+    q = [None, None, None] if query_x is None else [_ro(query_x, np.float64), _ro(query_y, np.float64), _ro(query_z, np.float64)]
+    if query_x is not None and N_total == 0:
+        raise ValueError("N_total is required when query points are provided.")
+    rc = lib().orc_sfc_direct(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)), _p(b, np.float64),
+                              _p(structure_factor_py, np.float64), cint(bins), dbl(k_max), dbl(k_min), _p(q[0], np.float64),
+                              _p(q[1], np.float64), _p(q[2], np.float64), i64(0 if q[0] is None else len(q[0])),
+                              C.c_uint(int(N_total)), cint(num_t))
+    if rc == -2:
+        raise RuntimeError("No k-points generated. Check k_min and k_max values.")
+    _chk(rc)
+
+
+def compute_sfc_direct_partial(x, y, z, type_list, Ntype, box, origin, boundary, partial_out, bins, k_max, k_min, num_t=1):
+    """mdapy._sfc.compute_sfc_direct_partial (src/structure_factor.cpp:682)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b = _ro(box, np.float64).reshape(9)
+    t = _ro(type_list, np.int32)
+    rc = lib().orc_sfc_direct_partial(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), _p(t, np.int32), cint(Ntype),
+                                      i64(len(x)), _p(b, np.float64), _p(partial_out, np.float64), cint(bins), dbl(k_max),
+                                      dbl(k_min), cint(num_t))
+    if rc == -2:
+        raise RuntimeError("No k-points generated")
+    _chk(rc)
+
+
+def sfc_kpoints(box, k_max, k_min, partial=False):
+    b = _ro(box, np.float64).reshape(9)
+    f = lib().orc_sfc_kpoints_partial if partial else lib().orc_sfc_kpoints_total
+    f.restype = C.c_int64
+    n = int(f(_p(b, np.float64), dbl(k_max), dbl(k_min), None))
+    kp = np.zeros((max(n, 1), 3))
+    f(_p(b, np.float64), dbl(k_max), dbl(k_min), _p(kp, np.float64))
+    return kp[:n]

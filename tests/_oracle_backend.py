@@ -93,6 +93,13 @@ voronoi = _mod(
     get_voronoi_neighbor=lambda x, y, z, box, origin, boundary, a, r, num_t=1:
         O.get_voronoi_neighbor(_np(x), _np(y), _np(z), box, origin, boundary, a, r, NT),
 )
+sfc = _mod(
+    compute_sfc_direct=lambda x, y, z, box, origin, boundary, sf, bins, k_max, k_min, query_x=None, query_y=None, query_z=None,
+    N_total=0, num_t=1: O.compute_sfc_direct(_np(x), _np(y), _np(z), box, origin, boundary, sf, bins, k_max, k_min, _np(query_x),
+                                             _np(query_y), _np(query_z), N_total, NT),
+    compute_sfc_direct_partial=lambda x, y, z, t, nt, box, origin, boundary, out, bins, k_max, k_min, num_t=1:
+        O.compute_sfc_direct_partial(_np(x), _np(y), _np(z), _np(t), nt, box, origin, boundary, out, bins, k_max, k_min, NT),
+)
 repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat_cell(new, ob, _np(op), nx, ny, nz, NT))
 
 
@@ -101,6 +108,7 @@ def install(monkeypatch):
     import mdapy_amd.atomic_temperature as m_at
     import mdapy_amd.build_lattice as bl
     import mdapy_amd.cluster_analysis as m_cl
+    import mdapy_amd.structure_factor as m_sf
     import mdapy_amd.voronoi as m_vor
     import mdapy_amd.identify_fcc_planar_faults as m_pft
     import mdapy_amd.common_neighbor_parameter as m_cnp
@@ -131,6 +139,7 @@ def install(monkeypatch):
     monkeypatch.setattr(m_aja, "_aja", aja)
     monkeypatch.setattr(m_at, "_atomtemp", atomtemp)
     monkeypatch.setattr(m_cl, "_cluster", cluster)
+    monkeypatch.setattr(m_sf, "_sfc", sfc)
     monkeypatch.setattr(m_vor, "_voronoi", voronoi)
     monkeypatch.setattr(m_pft, "_fccpft", fccpft)
     monkeypatch.setattr(m_cnp, "_cnp", cnp)

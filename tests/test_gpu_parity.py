@@ -787,3 +787,46 @@ def test_voronoi_weighted_steinhardt_system_flow():
     s.cal_steinhardt_bond_orientation([4, 6], use_voronoi=True, use_weight=True)
     assert np.allclose(s.data["ql4"].to_numpy(), 0.190941, atol=1e-6) and np.allclose(s.data["ql6"].to_numpy(), 0.574524, atol=1e-6)
     assert np.all(np.asarray(s.voro_neighbor_number) == 12)
+
+
+# ------------------------------------------------------------------ static structure factor (direct summation kernel + Debye over the
+# streaming RDF kernel): reference fixture, and HIP vs the CPU oracle on seeded inputs
+from mdapy_amd import _sfc
+
+
+@pytest.mark.parametrize("mode", ["direct", "debye"])
+def test_golden_structure_factor(mode):
+    d = misc("structure_factor")
+    n, nbins = int(d["N"]), int(d["nbins"])
+    s = mp.System(box=d["box"], pos=d["points"])
+    s.update_data(s.data.with_columns(type=np.array([1] * (n // 2) + [2] * (n // 2))))
+    sf = s.cal_structure_factor(float(d["k_min"]), float(d["k_max"]), nbins, cal_partial=True, mode=mode)
+    for key, name in (((1, 1), "11"), ((1, 2), "12"), ((2, 2), "22")):
+        assert np.allclose(sf.Sk_partial[key], d[f"{mode}_{name}"], atol=1e-4, equal_nan=True)
+    assert np.allclose(sf.Sk, d[f"{mode}_all"], atol=1e-4, equal_nan=True)
+    sf2 = s.cal_structure_factor(float(d["k_min"]), float(d["k_max"]), nbins, cal_partial=False, mode=mode)
+    assert np.allclose(sf2.Sk, d[f"{mode}_all"], atol=1e-4, equal_nan=True)
+
+
+def test_sfc_direct_vs_oracle():
+    rng = np.random.default_rng(21)
+    tri = np.array([[14.0, 0.0, 0.0], [2.0, 13.0, 0.0], [-1.5, 2.5, 15.0]])
+    for box in (np.diag([13.0, 15.0, 17.0]), tri):
+        pos = rng.random((1500, 3)) @ box
+        x, y, z = _xyz(pos)
+        ty = rng.integers(0, 3, len(pos)).astype(np.int32)
+        s0, s1 = np.zeros(40), np.zeros(40)
+        O.compute_sfc_direct(x, y, z, box, ORG0, PBC, s0, 40, 6.0, 0.3, num_t=8)
+        _sfc.compute_sfc_direct(x, y, z, box, ORG0, PBC, s1, 40, 6.0, 0.3)
+        assert np.array_equal(np.isnan(s1), np.isnan(s0)) and np.allclose(s1, s0, rtol=1e-9, atol=1e-9, equal_nan=True)
+        q = pos[ty == 1]
+        qx, qy, qz = _xyz(q)
+        O.compute_sfc_direct(x, y, z, box, ORG0, PBC, s0, 40, 6.0, 0.3, qx, qy, qz, len(pos), 8)
+        _sfc.compute_sfc_direct(x, y, z, box, ORG0, PBC, s1, 40, 6.0, 0.3, qx, qy, qz, len(pos))
+        assert np.allclose(s1, s0, rtol=1e-9, atol=1e-9, equal_nan=True)
+        p0, p1 = np.zeros((3, 3, 40)), np.zeros((3, 3, 40))
+        O.compute_sfc_direct_partial(x, y, z, ty, 3, box, ORG0, PBC, p0, 40, 6.0, 0.3, 8)
+        _sfc.compute_sfc_direct_partial(x, y, z, ty, 3, box, ORG0, PBC, p1, 40, 6.0, 0.3)
+        assert np.allclose(p1, p0, rtol=1e-9, atol=1e-9, equal_nan=True)
+    with pytest.raises(ValueError):
+        _sfc.compute_sfc_direct(x, y, z, box, ORG0, PBC, s1, 40, 6.0, 0.3, qx, qy, qz, 0)

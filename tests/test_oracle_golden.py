@@ -407,3 +407,18 @@ def test_voronoi_neighbors_and_voronoi_weighted_steinhardt_closed_forms(oracle_b
     assert np.allclose(s.data["ql6"].to_numpy(), 0.574524, atol=1e-6)
     s.cal_steinhardt_bond_orientation([4, 6], use_voronoi=True, use_weight=True)
     assert np.allclose(s.data["ql4"].to_numpy(), 0.190941, atol=1e-6)
+
+
+# reference: tests/test_structure_factor.py:12-52 (direct + Debye, partial + total)
+@pytest.mark.parametrize("mode", ["direct", "debye"])
+def test_structure_factor_against_fixture(mode, oracle_backend):
+    d = misc("structure_factor")
+    n, nbins = int(d["N"]), int(d["nbins"])
+    s = mp.System(box=d["box"], pos=d["points"])
+    s.update_data(s.data.with_columns(type=np.array([1] * (n // 2) + [2] * (n // 2))))
+    sf = s.cal_structure_factor(float(d["k_min"]), float(d["k_max"]), nbins, cal_partial=True, mode=mode)
+    for key, name in (((1, 1), "11"), ((1, 2), "12"), ((2, 2), "22")):
+        assert np.allclose(sf.Sk_partial[key], d[f"{mode}_{name}"], atol=1e-4, equal_nan=True)
+    assert np.allclose(sf.Sk, d[f"{mode}_all"], atol=1e-4, equal_nan=True)
+    sf2 = s.cal_structure_factor(float(d["k_min"]), float(d["k_max"]), nbins, cal_partial=False, mode=mode)
+    assert np.allclose(sf2.Sk, d[f"{mode}_all"], atol=1e-4, equal_nan=True)
