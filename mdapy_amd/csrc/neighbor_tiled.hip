@@ -38,7 +38,7 @@ namespace mdh {
 #ifndef MDH_HALO_CAP
 #define MDH_HALO_CAP 1024
 #endif
-static constexpr int HALO_CAP = MDH_HALO_CAP; // atoms a tile's halo may hold in LDS (31 B each)
+static constexpr int HALO_CAP = MDH_HALO_CAP; // atoms a tile's halo may hold in LDS (30 B each)
 static constexpr int NT = 256;        // threads per workgroup
 #ifndef MDH_MAX_NH
 #define MDH_MAX_NH 512
@@ -73,8 +73,13 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
     return off + inc - v;
 }
 
-// L * n for cell code cc and atom code ca (each (n+1) in 2 bits): n = n_cell + m_atom in [-2, 2]
-__device__ __forceinline__ double img_shift(double L, int cc, int ca) { return L * (double)(cc + ca - 2); }
+// L * n for a staged atom's combined image number n = n_cell + m_atom in [-2, 2], stored as n + 2 in three bits per axis
+__device__ __forceinline__ double img_shift(double L, int code) { return L * (double)(code - 2); }
+// cell code cc and atom code ca (each (n+1) per axis in 2 bits) -> combined code ((n_cell + m_atom) + 2 per axis in 3 bits)
+__device__ __forceinline__ int combine_codes(int cc, int ca)
+{
+    return ((cc & 3) + (ca & 3)) | ((((cc >> 2) & 3) + ((ca >> 2) & 3)) << 3) | ((((cc >> 4) & 3) + ((ca >> 4) & 3)) << 6);
+}
 
 // squared distance of one (centre, candidate) pair.
 //   PBCMODE 0: no shift at all (tile away from the seam, all atoms wrapped): d - L*0 == d
@@ -82,13 +87,13 @@ __device__ __forceinline__ double img_shift(double L, int cc, int ca) { return L
 //   PBCMODE 2: exact threshold / division search (common.hpp)
 template <int PBCMODE>
 __device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double yj, double zj, double xi, double yi,
-                                                double zi, int cc, int ca)
+                                                double zi, int sh)
 {
     double dx = xj - xi, dy = yj - yi, dz = zj - zi; // raw x[j] - wrapped centre (neighbor.cpp:164-166)
     if (PBCMODE == 1) {
-        dx = dx - img_shift(b.h[0], cc & 3, ca & 3); // == xij - L*floor(xij/L+0.5)   (box.h:120-124)
-        dy = dy - img_shift(b.h[4], (cc >> 2) & 3, (ca >> 2) & 3);
-        dz = dz - img_shift(b.h[8], (cc >> 4) & 3, (ca >> 4) & 3);
+        dx = dx - img_shift(b.h[0], sh & 7); // == xij - L*floor(xij/L+0.5)   (box.h:120-124)
+        dy = dy - img_shift(b.h[4], (sh >> 3) & 7);
+        dz = dz - img_shift(b.h[8], (sh >> 6) & 7);
     } else if (PBCMODE == 2) {
         pbc<false>(b, dx, dy, dz);
     }
@@ -98,9 +103,7 @@ __device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double
 struct TileLds {
     double *lx, *ly, *lz;        // staged raw positions [HALO_CAP]
     int *lid;                    // staged atom ids [HALO_CAP]
-    unsigned short *lcell;       // halo cell of a staged atom [HALO_CAP]
-    unsigned char *lmv;          // atom image code (raw vs wrapped) [HALO_CAP]
-    const unsigned char *h_img;  // cell image code [MAX_NH]
+    unsigned short *lsh;         // combined image code of a staged atom as seen from this tile [HALO_CAP]
 };
 
 // one run of candidates [k0, k3) for centre li; tickets (LDS indices) appended to my[]
@@ -111,21 +114,23 @@ __device__ __forceinline__ void scan_run(const DBox &b, const TileLds &L, int k0
     // four independent chains per step; the last step re-reads the run's last candidate for the lanes past the
     // end (clamped index) and masks them out.  Tickets are stored slot-major with a padded stride
     // (my[slot * TICK_STRIDE]) so that the lanes of a wave hit different LDS banks.
+    // `slot` walks the centre's ticket column (stride TICK_STRIDE) instead of being recomputed from `hits`.
+    unsigned short *slot = my + (hits < M ? hits : M) * TICK_STRIDE;
     for (int k = k0; k < k3; k += 4) {
         double d2[4];
-        int q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            q[u] = min(k + u, k3 - 1);
-            int cc = NEUTRAL, ca = NEUTRAL;
-            if (PBCMODE == 1) { cc = L.h_img[L.lcell[q[u]]]; ca = L.lmv[q[u]]; }
-            d2[u] = pair_d2_tiled<PBCMODE>(b, L.lx[q[u]], L.ly[q[u]], L.lz[q[u]], xi, yi, zi, cc, ca);
+            // lanes past the end of the run read whatever follows in LDS (the arrays are contiguous) and are masked out
+            const int qq = k + u;
+            int sh = 0;
+            if (PBCMODE == 1) sh = L.lsh[qq];
+            d2[u] = pair_d2_tiled<PBCMODE>(b, L.lx[qq], L.ly[qq], L.lz[qq], xi, yi, zi, sh);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool hit = (d2[u] <= rcsq) && (k + u < k3) && (!SELF || (q[u] != li));
+            const bool hit = (d2[u] <= rcsq) && (k + u < k3) && (!SELF || (k + u != li));
             if (hit) {
-                if (hits < M) my[hits * TICK_STRIDE] = (unsigned short)q[u];
+                if (hits < M) { *slot = (unsigned short)(k + u); slot += TICK_STRIDE; }
                 ++hits;
             }
         }
@@ -183,14 +188,11 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     L.lid = reinterpret_cast<int *>(czi + NT);
     int *crow = L.lid + HALO_CAP;                 // global atom id of the centre [NT]
     int *ccnt = crow + NT;                        // min(count, M) [NT]
-    L.lcell = reinterpret_cast<unsigned short *>(ccnt + NT);
-    unsigned short *tick = L.lcell + HALO_CAP;    // [M][TICK_STRIDE]
-    L.lmv = reinterpret_cast<unsigned char *>(tick + (size_t)TICK_STRIDE * M);
+    L.lsh = reinterpret_cast<unsigned short *>(ccnt + NT);
+    unsigned short *tick = L.lsh + HALO_CAP;      // [M][TICK_STRIDE]
     __shared__ unsigned short h_off[MAX_NH + 2];
-    __shared__ unsigned char h_img[MAX_NH]; // (nx+1) | (ny+1)<<2 | (nz+1)<<4
     __shared__ int c_off[MAX_COLS + 1];
     __shared__ int scan_tmp[4];
-    L.h_img = h_img;
 
     // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of tiles so that
     // neighbouring tiles (which share halo cells) meet in the same L2.
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
 
     // ---- halo cell table: source range, LDS offset, image code.  Thread t owns halo cells 2t and 2t+1
     // (adjacent in z, hence adjacent in memory).
-    int cnt2[2] = {0, 0}, src2[2] = {0, 0};
+    const float inv_hz = 1.0f / (float)HZ, inv_hxy = 1.0f / (float)HXY;
+    int cnt2[2] = {0, 0}, src2[2] = {0, 0}, img2[2] = {NEUTRAL, NEUTRAL};
     bool general = false; // does this tile need image shifts at all?
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -213,11 +216,18 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         if (h >= NH)
             continue;
         int cnt = 0, src = 0;
-        const int hz = h % HZ, hy = (h / HZ) % HXY, hx = h / (HZ * HXY);
+        // h < 512: quotients by the (runtime) tile extents through exact float reciprocals instead of integer division
+        const int hcol = (int)(((float)h + 0.5f) * inv_hz); // h / HZ
+        const int hz = h - hcol * HZ;
+        const int hx = (int)(((float)hcol + 0.5f) * inv_hxy); // hcol / HXY
+        const int hy = hcol - hx * HXY;
         const int g0 = T0 + hx - 1, g1 = T1 + hy - 1, g2 = T2 + hz - 1;
         int img = NEUTRAL;
         if (g0 >= -1 && g0 <= g.nc[0] && g1 >= -1 && g1 <= g.nc[1] && g2 >= -1 && g2 <= g.nc[2]) {
-            const int a0 = pmod(g0, g.nc[0]), a1 = pmod(g1, g.nc[1]), a2 = pmod(g2, g.nc[2]);
+            // g in [-1, nc]: the positive modulo (neighbor.cpp:18-22) is one conditional add / subtract
+            const int a0 = g0 < 0 ? g0 + g.nc[0] : (g0 >= g.nc[0] ? g0 - g.nc[0] : g0);
+            const int a1 = g1 < 0 ? g1 + g.nc[1] : (g1 >= g.nc[1] ? g1 - g.nc[1] : g1);
+            const int a2 = g2 < 0 ? g2 + g.nc[2] : (g2 >= g.nc[2] ? g2 - g.nc[2] : g2);
             const int64_t c = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
             src = cell_start[c];
             cnt = cell_start[c + 1] - src;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
             const int n2 = b.pbc[2] ? (g2 < 0 ? 1 : (g2 >= g.nc[2] ? -1 : 0)) : 0;
             img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
         }
-        h_img[h] = (unsigned char)img;
+        img2[u] = img;
         general = general || (img != NEUTRAL && cnt > 0);
         cnt2[u] = cnt;
         src2[u] = src;
@@ -249,7 +259,6 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int cnt = cnt2[u], src = src2[u], off = off0 + (u ? cnt2[0] : 0);
-        const unsigned short hcell = (unsigned short)(2 * tid + u);
         int k = 0;
         for (; k + 4 <= cnt; k += 4) { // four independent loads in flight per array
             double a[4], bb[4], c[4];
@@ -260,14 +269,14 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 L.lx[off + k + v] = a[v]; L.ly[off + k + v] = bb[v]; L.lz[off + k + v] = c[v]; L.lid[off + k + v] = d[v];
-                L.lcell[off + k + v] = hcell; L.lmv[off + k + v] = m[v];
+                L.lsh[off + k + v] = (unsigned short)combine_codes(img2[u], m[v]);
                 general = general || (m[v] != NEUTRAL);
             }
         }
         for (; k < cnt; ++k) {
             const unsigned char m = mvs[src + k];
             L.lx[off + k] = xs[src + k]; L.ly[off + k] = ys[src + k]; L.lz[off + k] = zs[src + k]; L.lid[off + k] = order[src + k];
-            L.lcell[off + k] = hcell; L.lmv[off + k] = m;
+            L.lsh[off + k] = (unsigned short)combine_codes(img2[u], m);
             general = general || (m != NEUTRAL);
         }
     }
@@ -299,9 +308,9 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     for (int base = 0; base < ncentres; base += NT) {
         const int q = base + tid;
         if (q < ncentres) {
-            int col = 0;
-            for (int k = 1; k < NCOL; ++k)
-                col += (q >= c_off[k]) ? 1 : 0;
+            int col = 0; // largest column with c_off[col] <= q
+            for (int step = 32; step > 0; step >>= 1)
+                if (col + step < NCOL && q >= c_off[col + step]) col += step;
             const int hx = col / TXY + 1, hy = col % TXY + 1;
             const int colbase = (hx * HXY + hy) * HZ;
             const int li = (int)h_off[colbase + zlo] + (q - c_off[col]); // LDS index of the centre atom
@@ -332,9 +341,9 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
             if (e < ccnt[c]) {
                 const int k = tick[e * TICK_STRIDE + c];
                 double d2;
-                if (!CELLSHIFT) d2 = pair_d2_tiled<2>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], NEUTRAL, NEUTRAL);
-                else if (tile_general) d2 = pair_d2_tiled<1>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], h_img[L.lcell[k]], L.lmv[k]);
-                else d2 = pair_d2_tiled<0>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], NEUTRAL, NEUTRAL);
+                if (!CELLSHIFT) d2 = pair_d2_tiled<2>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], 0);
+                else if (tile_general) d2 = pair_d2_tiled<1>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], L.lsh[k]);
+                else d2 = pair_d2_tiled<0>(b, L.lx[k], L.ly[k], L.lz[k], cxi[c], cyi[c], czi[c], 0);
                 verlet[o] = L.lid[k];
                 dist[o] = sqrt(d2);
             } else if (MODE == 2) {
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
 
 static size_t tiled_lds_bytes(int64_t M)
 {
-    return (size_t)HALO_CAP * (24 + 4 + 2 + 1) + (size_t)NT * (24 + 4 + 4) + (size_t)TICK_STRIDE * (size_t)M * 2;
+    return (size_t)HALO_CAP * (24 + 4 + 2) + (size_t)NT * (24 + 4 + 4) + (size_t)TICK_STRIDE * (size_t)M * 2;
 }
 
 // pick the tile shape for a mean cell population `pop`
