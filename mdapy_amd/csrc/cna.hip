@@ -98,8 +98,10 @@ __device__ __forceinline__ double fold(double d, double L, double t_zero, double
     return d - shift; // == d - L*floor(d/L+0.5)   (box.h:120-124) when n is one of {-1,0,1}
 }
 
+// 0: the coordinates spread too far for `fold` (generic variant), 1: every pair has n in {-1,0,1}, 2: every pair has n = 0
+// (no neighbour lies across the periodic seam: the minimum image is the plain difference, d - L*0 == d)
 template <int NN>
-__device__ __forceinline__ bool span_ok(const DBox &b, const double (&p)[NN], int axis)
+__device__ __forceinline__ int span_class(const DBox &b, const double (&p)[NN], int axis)
 {
     double mn = p[0], mx = p[0];
 #pragma unroll
@@ -107,8 +109,12 @@ __device__ __forceinline__ bool span_ok(const DBox &b, const double (&p)[NN], in
         mn = fmin(mn, p[a]);
         mx = fmax(mx, p[a]);
     }
+    const double span = mx - mn;
     const double lim = fmin(b.tn[axis][3], -b.tn[axis][0]); // |d| below this => n in {-1,0,1}
-    return (mx - mn) < lim; // false for NaN as well
+    const double zero = fmin(b.tn[axis][2], -b.tn[axis][1]); // |d| below this => n == 0
+    if (!(span < lim)) // false for NaN as well
+        return 0;
+    return span < zero ? 2 : 1;
 }
 
 // ---- bond matrix among NN listed neighbours: bit c of row a <=> pbcdis_sq(list[a], list[c]) <= cut2
@@ -124,18 +130,34 @@ __device__ __forceinline__ bool bond_rows(const DBox &b, const double *__restric
         const int j = ids[a];
         px[a] = x[j]; py[a] = y[j]; pz[a] = z[j];
     }
+    bool plain = false; // no fold needed on any axis
     if (!TRI && !GENERIC) {
-        bool ok = true;
-        if (b.pbc[0]) ok = ok && span_ok<NN>(b, px, 0);
-        if (b.pbc[1]) ok = ok && span_ok<NN>(b, py, 1);
-        if (b.pbc[2]) ok = ok && span_ok<NN>(b, pz, 2);
-        if (!ok)
+        int cls = 2;
+        if (b.pbc[0]) cls = min(cls, span_class<NN>(b, px, 0));
+        if (b.pbc[1]) cls = min(cls, span_class<NN>(b, py, 1));
+        if (b.pbc[2]) cls = min(cls, span_class<NN>(b, pz, 2));
+        if (cls == 0)
             return false;
+        plain = cls == 2;
     }
     unsigned adj[NN];
 #pragma unroll
     for (int a = 0; a < NN; ++a)
         adj[a] = 0;
+    if (!TRI && !GENERIC && plain) { // interior atoms (all but the layer at the periodic faces): 11 instructions per pair
+#pragma unroll
+        for (int a = 0; a < NN; ++a)
+#pragma unroll
+            for (int c = a + 1; c < NN; ++c) {
+                const double dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
+                if (dx * dx + dy * dy + dz * dz <= cut2) {
+                    adj[a] |= 1u << c;
+                    adj[c] |= 1u << a;
+                }
+            }
+        R = pack_rows<NN>(adj);
+        return true;
+    }
 #pragma unroll
     for (int a = 0; a < NN; ++a)
 #pragma unroll
