@@ -830,3 +830,76 @@ def test_sfc_direct_vs_oracle():
         assert np.allclose(p1, p0, rtol=1e-9, atol=1e-9, equal_nan=True)
     with pytest.raises(ValueError):
         _sfc.compute_sfc_direct(x, y, z, box, ORG0, PBC, s1, 40, 6.0, 0.3, qx, qy, qz, 0)
+
+
+# ------------------------------------------------------------------ SURVEY 8d synthetic configurations C4 / C5 at parity scale
+def _polycrystal(L=132.0, nseed=8, a=3.615, seed=2024):
+    """FCC grains: rotated lattices clipped to the Voronoi cells of random seeds under PBC (the construction of
+    create_polycrystal.py:684-848 in miniature), before overlap removal"""
+    rng = np.random.default_rng(seed)
+    seeds = rng.random((nseed, 3)) * L
+    ang = np.deg2rad(rng.uniform(-180, 180, (nseed, 3)))
+    out = []
+    n = int(np.ceil(L * np.sqrt(3) / a)) + 1
+    g = np.arange(-n // 2, n // 2 + 1)
+    basis = np.array([[0, 0, 0], [0.5, 0.5, 0], [0, 0.5, 0.5], [0.5, 0, 0.5]])
+    cells = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    lat = ((cells[:, None, :] + basis[None]) * a).reshape(-1, 3)
+    for s, (al, be, ga) in zip(seeds, ang):
+        ca, sa, cb, sb, cg, sg = np.cos(al), np.sin(al), np.cos(be), np.sin(be), np.cos(ga), np.sin(ga)
+        R = np.array([[ca * cb, ca * sb * sg - sa * cg, ca * sb * cg + sa * sg], [sa * cb, sa * sb * sg + ca * cg, sa * sb * cg - ca * sg],
+                      [-sb, cb * sg, cb * cg]])
+        p = lat @ R.T
+        p = p[np.all(np.abs(p) < L / 2, axis=1)] + s
+        d = p[:, None, :] - seeds[None]
+        d -= L * np.round(d / L)
+        own = np.argmin((d ** 2).sum(-1), axis=1)
+        k = np.nonzero(seeds == s)[0][0]
+        out.append(p[own == k] % L)
+    return np.concatenate(out), np.eye(3) * L
+
+
+def test_config3_polycrystal_overlap_filter_neighbor_cna():
+    """configs[3] at 1/512 scale: Voronoi-grain polycrystal, overlap removal at 2.0 A, neighbor + CNA — filter
+    mask, rows and labels bit-exact against the CPU oracle"""
+    pos, box = _polycrystal()
+    x, y, z = _xyz(pos)
+    k0 = O.filter_overlap_atom(x, y, z, box, ORG0, PBC, 2.0, 64)
+    k1 = _neighbor.filter_overlap_atom(x, y, z, box, ORG0, PBC, 2.0, 1)
+    assert np.array_equal(k1, k0) and 0 < (~k0).sum() < 0.1 * len(k0)
+    pos = pos[k0]
+    assert len(pos) > 150000
+    x, y, z = _xyz(pos)
+    rc, M = 0.854 * 3.615, 20
+    v0, d0, n0 = np.full((len(x), M), -1, np.int32), np.full((len(x), M), rc + 1.0), np.zeros(len(x), np.int32)
+    O.build_neighbor(x, y, z, box, ORG0, PBC, rc, v0, d0, n0, 64)
+    v1, d1, n1 = np.full((len(x), M), -1, np.int32), np.full((len(x), M), rc + 1.0), np.zeros(len(x), np.int32)
+    _neighbor.build_neighbor(x, y, z, box, ORG0, PBC, rc, v1, d1, n1, 1)
+    assert np.array_equal(n1, n0) and np.array_equal(v1, v0) and np.array_equal(d1, d0)
+    p0, p1 = np.zeros(len(x), np.int32), np.zeros(len(x), np.int32)
+    O.fcna(x, y, z, box, ORG0, PBC, v0, n0, p0, rc, 64)
+    _cna.fcna(x, y, z, box, ORG0, PBC, v1, n1, p1, rc, 1)
+    assert np.array_equal(p1, p0)
+    frac_fcc = (p0 == 1).mean()
+    assert 0.6 < frac_fcc < 0.99  # grain interiors are fcc, boundaries are not
+
+
+def test_config4_glass_streaming_rdf_wcp_vs_oracle():
+    """configs[4] at parity scale: 37^3 x 4 = 202 612 fcc sites (a = 4.0) displaced by N(0, 0.35), Cu64Zr36 by
+    shuffled repeat; streaming partial g_ab(r) with rc = 8, 200 bins — pair counts bit-exact; Warren-Cowley at rc = 3.6"""
+    pos, box = lattice_positions("fcc", 4.0, 37, 37, 37)
+    rng = np.random.default_rng(7)
+    pos = pos + rng.normal(0, 0.35, pos.shape)
+    n = len(pos)
+    ty = np.repeat([0, 1], [int(round(0.64 * n)), n - int(round(0.64 * n))]).astype(np.int32)
+    np.random.default_rng(42).shuffle(ty)
+    x, y, z = _xyz(pos)
+    g0, g1 = np.zeros((2, 2, 200)), np.zeros((2, 2, 200))
+    O._rdf_streaming(x, y, z, ty, box, ORG0, PBC, g0, 8.0, 200, 64)
+    _rdf._rdf_streaming(x, y, z, ty, box, ORG0, PBC, g1, 8.0, 200, 1)
+    assert np.array_equal(g1, g0) and g0.sum() > 1e7
+    v, d, nn = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, 3.6, 1)
+    w0, w1 = np.zeros((2, 2)), np.zeros((2, 2))
+    O.get_wcp(np.asarray(v), np.asarray(nn), ty, 2, w0, 8)
+    _wcp.get_wcp(v, nn, ty, 2, w1, 1)
+    assert np.array_equal(w1, w0) and np.abs(w0).max() < 0.02
