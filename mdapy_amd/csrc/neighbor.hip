@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     double m = 0.0;
-                    if (b.pbc[d]) {
+                    if (b.pbc[d] && raw[d] != wrp[d]) { // already wrapped (the common case): m = 0, no division
                         m = rint((raw[d] - wrp[d]) / b.h[d * 4]);
                         if (!(fabs(m) <= 1.0) || !(fabs(raw[d] - m * b.h[d * 4] - wrp[d]) <= slack)) { moved = true; m = 0.0; }
                     }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                                                         double *__restrict__ radius, int *__restrict__ incomplete,
                                                         int *__restrict__ row_id, double *__restrict__ row_dist,
                                                         double *__restrict__ row_area, int W, double a_thr, double r_thr,
-                                                        int64_t n_orig, int *__restrict__ max_faces)
+                                                        int64_t n_orig, int *__restrict__ max_faces, DBox b0)
 {
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
@@ -125,8 +125,13 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < W) {
                     const int64_t o = i * (int64_t)W + slot;
-                    row_id[o] = (int)(verlet[i * M + (f - 6)] % n_orig); // image of a replicated system -> original atom
-                    row_dist[o] = 2.0 * dist[f];
+                    const int64_t j = verlet[i * M + (f - 6)] % n_orig; // image of a replicated system -> original atom
+                    row_id[o] = (int)j;
+                    // the reference reports the MINIMUM-IMAGE distance of the pair in the caller's box (src/voronoi.cpp:419-424,
+                    // :277-282), also for a face that a thin box makes the cell share with a farther image of j
+                    double ddx = x[j] - xi, ddy = y[j] - yi, ddz = z[j] - zi;
+                    pbc<TRI>(b0, ddx, ddy, ddz);
+                    row_dist[o] = sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
                     row_area[o] = farea[f];
                 }
             }
@@ -163,11 +168,12 @@ __global__ void k_replicate(const double *__restrict__ x, const double *__restri
 static int voronoi_solve(void *stream, const double *dx, const double *dy, const double *dz, int64_t N, const double *box9,
                          const double *origin3, const int *boundary3, double *dvol, int *dnf, double *drad, int *dnn, int *dflag,
                          bool *too_small, int *row_id, double *row_dist, double *row_area, int W, double a_thr, double r_thr,
-                         int64_t n_orig, int *dmaxf)
+                         int64_t n_orig, int *dmaxf, const double *box9_orig)
 {
     *too_small = false;
-    DBox b;
+    DBox b, b0;
     MDH_TRY(make_box(b, box9, origin3, boundary3));
+    MDH_TRY(make_box(b0, box9_orig, origin3, boundary3));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const double vol = fabs(b.h[0] * (b.h[4] * b.h[8] - b.h[5] * b.h[7]) - b.h[1] * (b.h[3] * b.h[8] - b.h[5] * b.h[6]) +
                             b.h[2] * (b.h[3] * b.h[7] - b.h[4] * b.h[6]));
@@ -195,9 +201,9 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         {
             ProfRange pr("k_voronoi", st);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -273,7 +279,7 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
             return work.error();
         bool too_small = false;
         MDH_TRY(voronoi_solve(stream, px, py, pz, total, big9, origin3, boundary3, wv, wn, wr, dnn, dflag, &too_small, drid, drd, dra, W, a_thr,
-                              r_thr, N, dflag + 1));
+                              r_thr, N, dflag + 1, box9));
         if (!too_small) {
             if (total != N) {
                 MDH_HIP(hipMemcpyAsync(dvol, wv, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));

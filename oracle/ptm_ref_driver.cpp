@@ -12,6 +12,8 @@
 #include <ptm_functions.h>
 #include <ptm_initialize_data.h>
 #include <ptm_quat.h>
+#include <ptm_solid_angles.h>
+#include <ptm_voronoi_cell.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -192,6 +194,59 @@ __attribute__((visibility("default"))) int ref_get_ptm(const char *structure, co
     ptm_uninitialize_local(lh);
     if (cached_out) std::memcpy(cached_out, cached.data(), sizeof(uint64_t) * (size_t)N);
     return 0;
+}
+
+// the pass-1 neighbour order of one atom as a permutation of its row (0-based; debugging aid of the host tests)
+__attribute__((visibility("default"))) void ref_ptm_decode_order(uint64_t code, int8_t *order19)
+{
+    int8_t corr[PTM_MAX_INPUT_POINTS];
+    int dummy = 0;
+    ptm_decode_correspondences(PTM_MATCH_FCC, code, corr, &dummy);
+    for (int i = 0; i < 19; ++i) order19[i] = corr[i];
+}
+
+// solid angles of the Voronoi faces of a point set exactly as extern/ptm/ptm_neighbour_ordering.cpp:57-113 obtains them
+// from the library's own cell class (debugging aid of the host tests); nfv receives the number of vertices per face
+__attribute__((visibility("default"))) int ref_ptm_solid_angles(int num, const double *pts, double *areas, int *nfv)
+{
+    ptm_voro::voronoicell_neighbor v;
+    double max_norm = 0;
+    std::vector<double> nsq(num);
+    for (int i = 0; i < num; ++i) {
+        nsq[i] = pts[i * 3] * pts[i * 3] + pts[i * 3 + 1] * pts[i * 3 + 1] + pts[i * 3 + 2] * pts[i * 3 + 2];
+        max_norm = std::max(max_norm, nsq[i]);
+        areas[i] = 0;
+        nfv[i] = 0;
+    }
+    const double k = 10 * std::sqrt(max_norm);
+    v.init(-k, k, -k, k, -k, k);
+    for (int i = 0; i < num; ++i) v.nplane(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], nsq[i], i);
+    std::vector<int> nbr, fv;
+    std::vector<double> vert;
+    v.neighbors(nbr);
+    v.face_vertices(fv);
+    v.vertices(0, 0, 0, vert);
+    for (size_t i = 0; i < vert.size() / 3; ++i) {
+        const double n = std::sqrt(vert[i * 3] * vert[i * 3] + vert[i * 3 + 1] * vert[i * 3 + 1] + vert[i * 3 + 2] * vert[i * 3 + 2]);
+        vert[i * 3] /= n; vert[i * 3 + 1] /= n; vert[i * 3 + 2] /= n;
+    }
+    size_t c = 0;
+    for (int f = 0; f < v.number_of_faces(); ++f) {
+        const int nv = fv[c++];
+        if (nbr[f] >= 0) {
+            double sa = 0;
+            int u = fv[c], w1 = fv[c + 1];
+            for (int i = 2; i < nv; ++i) {
+                const int w = fv[c + i];
+                sa += ptm::calculate_solid_angle(&vert[u * 3], &vert[w1 * 3], &vert[w * 3]);
+                w1 = w;
+            }
+            areas[nbr[f]] = sa;
+            nfv[nbr[f]] = nv;
+        }
+        c += nv;
+    }
+    return v.number_of_faces();
 }
 
 // ---- read-only views of the reference's literal tables (used by tests to validate GENERATED tables) ----------

@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Randomised parity sweep on the GPU box: the parity checks of tests/test_gpu_parity.py (HIP path vs the CPU
+oracle / the oracle/_ref libraries) on freshly drawn systems instead of the fixed cases.
+
+    python tools/fuzz_parity.py [seconds] [first_seed]
+
+Every seed draws one system — orthogonal or triclinic box, random boundary flags, origin, density, lattice or
+gas, optionally out-of-box ("unwrapped") atoms — and runs the checks that support that kind of input.  A failure
+prints the seed and the check; the exit code is the number of failures.  Test infrastructure, like tests/.
+"""
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import test_gpu_parity as T
+from mdapy_amd.build_lattice import lattice_positions
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    sigma = -1.0
+    kind = rng.choice(["gas", "fcc", "bcc", "hcp", "blob"])
+    tri = rng.random() < 0.4
+    bnd = np.array(rng.random(3) < 0.75, np.int32)
+    origin = rng.normal(0, 5.0, 3) if rng.random() < 0.5 else np.zeros(3)
+    if kind in ("fcc", "bcc", "hcp"):
+        a = {"fcc": 3.615, "bcc": 2.87, "hcp": 2.95}[kind]
+        n = [int(rng.integers(4, 9)) for _ in range(3)]
+        pos, box = lattice_positions(kind, a, *n)
+        box = np.asarray(box, float)
+        sigma = float(rng.choice([0.0, 0.03, 0.15]))
+        pos = pos + rng.normal(0, sigma, pos.shape)
+        if tri:  # shear the whole crystal (still a periodic crystal of the sheared box)
+            sh = np.eye(3)
+            sh[1, 0], sh[2, 0], sh[2, 1] = rng.uniform(-0.3, 0.3, 3)
+            pos, box = pos @ sh, box @ sh
+    else:
+        L = rng.uniform(12.0, 34.0, 3)
+        box = np.diag(L)
+        if tri:
+            box[1, 0], box[2, 0], box[2, 1] = rng.uniform(-0.35, 0.35, 3) * L[0]
+        rho = rng.uniform(0.01, 0.07)
+        N = int(min(max(rho * abs(np.linalg.det(box)), 150), 5000))
+        frac = rng.random((N, 3))
+        if kind == "blob":
+            frac[: N // 2] = 0.3 + 0.25 * frac[: N // 2]
+        pos = frac @ box
+    pos = pos + origin
+    unwrapped = rng.random() < 0.2
+    if unwrapped:
+        pos = pos + (rng.integers(-2, 3, pos.shape) * bnd) @ box
+    return dict(seed=seed, sigma=sigma, kind=kind, tri=tri, unwrapped=unwrapped, pos=pos, box=box, origin=origin, bnd=bnd)
+
+
+def checks(s):
+    case = ("fuzz", s["pos"], s["box"], s["origin"], s["bnd"])
+    T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
+    rc = float(np.random.default_rng(s["seed"] + 7).uniform(2.6, 4.6))
+    out = [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc)),
+           ("sort_cna", lambda: T.test_sort_and_cna_vs_oracle(case)),
+           ("overlap", lambda: T.test_filter_overlap_atom_vs_oracle("fuzz"))]
+    if not s["unwrapped"]:
+        out += [("knn", lambda: T.test_knn_general_vs_oracle(case)),
+                ("steinhardt_rc", lambda: T.test_steinhardt_vs_oracle(case, "rc")),
+                ("steinhardt_nnn", lambda: T.test_steinhardt_vs_oracle(case, "nnn")),
+                ("aja_cnp_entropy", lambda: T.test_aja_cnp_entropy_vs_oracle("fuzz")),
+                ("temp_cluster", lambda: T.test_atomic_temperature_and_cluster_vs_oracle("fuzz"))]
+        if T.O.have_ref() and s["sigma"] != 0.0:  # perfect lattices: exact ties / degenerate hulls decide by rounding noise
+            r2 = np.random.default_rng(s["seed"] + 13)
+            structure = str(r2.choice(["default", "all", "fcc-hcp-bcc-ico-sc", "fcc-hcp-bcc", "dcub-dhex", "bcc,sc", "graphene-fcc", "ico"]))
+            types = r2.integers(1, 4, len(s["pos"])).astype(np.int32) if r2.random() < 0.4 else None
+            pc = ("fuzz", s["pos"] - s["origin"], s["box"], tuple(int(v) for v in s["bnd"]), structure, types, float(r2.choice([0.0, 0.05, 0.1, 0.3])))
+            out += [("ptm", lambda: T.test_ptm_vs_reference_library(pc))]
+        ortho = not np.any(s["box"] - np.diag(np.diag(s["box"])))  # the orthogonal entry points (hcp cells are hexagonal)
+        if T.O.have_voro_ref() and ortho and s["kind"] != "blob" and all(s["bnd"]):
+            out += [("voronoi", lambda: T.test_voronoi_vs_reference_library("fuzz")),
+                    ("voronoi_nb", lambda: T.test_voronoi_neighbors_vs_reference_library("fuzz"))]
+    return out
+
+
+NAMES = ["fuzz"]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.time()
+    fails, ran = [], 0
+    while time.time() - t0 < budget:
+        s = draw(seed)
+        for name, fn in checks(s):
+            try:
+                fn()
+                ran += 1
+            except AssertionError:
+                tb = traceback.extract_tb(sys.exc_info()[2])[-1]
+                fails.append((seed, name, f"assert at {os.path.basename(tb.filename)}:{tb.lineno}"))
+            except Exception as e:  # loud refusals are findings too: list them
+                fails.append((seed, name, f"{type(e).__name__}: {str(e)[:120]}"))
+        seed += 1
+    print(f"fuzz: {ran} checks passed over seeds up to {seed - 1}; {len(fails)} failures", flush=True)
+    by = {}
+    for f in fails:
+        by[f[1]] = by.get(f[1], 0) + 1
+    print("  by check:", by)
+    for f in fails[:60]:
+        s = draw(f[0])
+        print("  FAIL seed=%d check=%s %s  [kind=%s tri=%s unwrapped=%s bnd=%s N=%d]" % (f + (s["kind"], s["tri"], s["unwrapped"], s["bnd"].tolist(), len(s["pos"]))))
+    return len(fails)
+
+
+if __name__ == "__main__":
+    sys.exit(min(main(), 100))
