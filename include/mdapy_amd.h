@@ -255,6 +255,12 @@ int mdh_voronoi_neighbor(const double *x, const double *y, const double *z, int6
                          double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width, int space,
                          void *stream);
 
+/* distance column of _voronoi.get_voronoi_neighbor_tri         src/voronoi.cpp:277-282: sqrt(box.pbc(x[j] - x[i])) with the
+ * caller's UNROTATED positions and the LAMMPS-aligned box / boundary flags of that call; -1 entries -> 10000. */
+int mdh_voronoi_row_distance(const int *verlet, int64_t N, int width, const double *x, const double *y, const double *z,
+                             const double *box9_host, const double *origin3_host, const int *boundary3_host, double *distance,
+                             int space, void *stream);
+
 /* ---- _sfc (static structure factor, direct summation) ------------ */
 /* replaces _sfc.compute_sfc_direct                          src/structure_factor.cpp:654-680 (StructureFactorDirect :64-447)
  * sf_host (bins) is always a host array; qx/qy/qz NULL = total S(k), otherwise the cross term between the two point sets

@@ -60,12 +60,18 @@ def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, 
 
 def get_voronoi_neighbor_tri(x, y, z, box, origin, boundary, rotation, need_rotation, a_face_area_threshold,
                              r_face_area_threshold, num_t=1):
-    """src/voronoi.cpp:149 — LAMMPS-aligned box, fully periodic; ids and areas are invariant under the rotation"""
-    x = np.asarray(x, f64) - origin[0]
-    y = np.asarray(y, f64) - origin[1]
-    z = np.asarray(z, f64) - origin[2]
+    """src/voronoi.cpp:149 — LAMMPS-aligned box, fully periodic container; ids and areas are invariant under the rotation.
+    The distance column is the reference's: box.pbc of the UNROTATED x[j] - x[i] with this call's box and boundary flags
+    (:277-282)."""
+    x0, y0, z0 = (np.ascontiguousarray(np.asarray(v, f64)) for v in (x, y, z))
+    xr, yr, zr = x0 - origin[0], y0 - origin[1], z0 - origin[2]
     if need_rotation:
         r = np.asarray(rotation, f64)
-        x, y, z = (x * r[0, k] + y * r[1, k] + z * r[2, k] for k in range(3))
-    return get_voronoi_neighbor(np.ascontiguousarray(x), np.ascontiguousarray(y), np.ascontiguousarray(z), box, np.zeros(3),
-                                np.ones(3, i32), a_face_area_threshold, r_face_area_threshold, num_t)
+        xr, yr, zr = (xr * r[0, k] + yr * r[1, k] + zr * r[2, k] for k in range(3))
+    verlet, dist, area, nn = get_voronoi_neighbor(np.ascontiguousarray(xr), np.ascontiguousarray(yr), np.ascontiguousarray(zr), box,
+                                                  np.zeros(3), np.ones(3, i32), a_face_area_threshold, r_face_area_threshold, num_t)
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    c = Call(x0, y0, z0)
+    _lib.check(_lib.lib().mdh_voronoi_row_distance(verlet.ctypes.data, int(len(x0)), int(verlet.shape[1]), c.inp(x0, f64),
+                                                   c.inp(y0, f64), c.inp(z0, f64), pb, po, pp, dist.ctypes.data, c.space, c.stream))
+    return verlet, dist, area, nn

@@ -363,6 +363,100 @@ __global__ __launch_bounds__(256) void k_cc_label(const int *__restrict__ parent
     if (i == 0) *count = rank[N];
 }
 
+// Is every bond i -> j also listed as j -> i?  (cutoff lists are; k-nearest lists and one-sided type filters are not)
+template <bool BY_BOND>
+__global__ __launch_bounds__(256) void k_cc_symmetric(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                      const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                      int *__restrict__ asym)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int n = nn[i];
+    bool bad = false;
+    for (int q = 0; q < n && !bad; ++q) {
+        const int j = verlet[i * M + q];
+        const bool bond = BY_BOND ? (j > -1) : (dist[i * M + q] <= rc);
+        if (!bond || j < 0 || j >= N)
+            continue;
+        bool back = false;
+        const int nj = nn[j];
+        for (int p = 0; p < nj && !back; ++p)
+            back = verlet[(int64_t)j * M + p] == (int)i && (BY_BOND || dist[(int64_t)j * M + p] <= rc);
+        bad = !back;
+    }
+    if (bad) *asym = 1;
+}
+
+// The reference's sweep taken literally, for lists that are NOT symmetric (src/cluster.cpp:14-53, :56-93): seeds in index
+// order, each cluster = the still unlabelled atoms reachable from its seed along DIRECTED bonds; the seed itself is only
+// labelled when a member points back at it (or when it has no bond at all), so it may end up in a later cluster or stay -1.
+// One workgroup walks the frontiers level by level; the common symmetric case never comes here.
+static constexpr int CC_DIR_THREADS = 1024;
+template <bool BY_BOND>
+__global__ __launch_bounds__(CC_DIR_THREADS) void k_cc_directed(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                                const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                                int *__restrict__ cluster, int *__restrict__ qa,
+                                                                int *__restrict__ qb, int *__restrict__ count)
+{
+    __shared__ int s_seed, s_next;
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < N; i += CC_DIR_THREADS) cluster[i] = -1;
+    __syncthreads();
+    int cid = 0;
+    int64_t scan = 0;
+    for (;;) {
+        // next unlabelled seed at or after `scan`
+        int seed = 2147483647;
+        for (int64_t base = scan; base < N; base += CC_DIR_THREADS) {
+            if (tid == 0) s_seed = 2147483647;
+            __syncthreads();
+            const int64_t idx = base + tid;
+            if (idx < N && cluster[idx] == -1) atomicMin(&s_seed, (int)idx);
+            __syncthreads();
+            seed = s_seed;
+            __syncthreads();
+            if (seed != 2147483647)
+                break;
+        }
+        if (seed == 2147483647)
+            break;
+        scan = (int64_t)seed + 1;
+        ++cid;
+        if (tid == 0) qa[0] = seed;
+        int cnt = 1;
+        __syncthreads();
+        while (cnt > 0) {
+            if (tid == 0) s_next = 0;
+            // members without any bond label themselves (:45-48)
+            for (int e = tid; e < cnt; e += CC_DIR_THREADS) {
+                const int cur = qa[e];
+                const int n = nn[cur];
+                bool any = false;
+                for (int q = 0; q < n && !any; ++q)
+                    any = BY_BOND ? (verlet[(int64_t)cur * M + q] > -1) : (dist[(int64_t)cur * M + q] <= rc);
+                if (!any) cluster[cur] = cid;
+            }
+            __syncthreads();
+            for (int64_t it = tid; it < (int64_t)cnt * M; it += CC_DIR_THREADS) {
+                const int cur = qa[it / M];
+                const int q = (int)(it % M);
+                if (q >= nn[cur])
+                    continue;
+                const int nb = verlet[(int64_t)cur * M + q];
+                const bool bond = BY_BOND ? (nb > -1) : (dist[(int64_t)cur * M + q] <= rc);
+                if (bond && nb >= 0 && nb < N && atomicCAS(&cluster[nb], -1, cid) == -1)
+                    qb[atomicAdd(&s_next, 1)] = nb;
+            }
+            __syncthreads();
+            cnt = s_next;
+            int *t = qa; qa = qb; qb = t;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) *count = cid;
+}
+
 __global__ void k_iota(int *p, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -435,6 +529,30 @@ extern "C" int mdh_cluster(const int *verlet, const double *dist, const int *nn,
     if (sc.failed())
         return sc.error();
     const dim3 grid(grid_for(N, 256)), block(256);
+    {   // directed lists get the reference's sweep itself; symmetric ones (every cutoff list) the union-find below
+        MDH_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+        if (by_bond)
+            hipLaunchKernelGGL(k_cc_symmetric<true>, grid, block, 0, st, dv, dd, dn, N, M, rc, flag);
+        else
+            hipLaunchKernelGGL(k_cc_symmetric<false>, grid, block, 0, st, dv, dd, dn, N, M, rc, flag);
+        int asym = 0;
+        MDH_HIP(hipMemcpyAsync(&asym, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        MDH_HIP(hipStreamSynchronize(st));
+        if (asym) {
+            int *qa = sc.alloc_n<int>((size_t)N + 1), *qb = sc.alloc_n<int>((size_t)N + 1);
+            if (sc.failed())
+                return sc.error();
+            if (by_bond)
+                hipLaunchKernelGGL(k_cc_directed<true>, dim3(1), dim3(CC_DIR_THREADS), 0, st, dv, dd, dn, N, M, rc, dc, qa, qb, flag + 1);
+            else
+                hipLaunchKernelGGL(k_cc_directed<false>, dim3(1), dim3(CC_DIR_THREADS), 0, st, dv, dd, dn, N, M, rc, dc, qa, qb, flag + 1);
+            int cnt = 0;
+            MDH_HIP(hipMemcpyAsync(&cnt, flag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+            MDH_HIP(hipStreamSynchronize(st));
+            if (n_clusters_host) *n_clusters_host = cnt;
+            return sc.finish(space);
+        }
+    }
     hipLaunchKernelGGL(k_iota, grid, block, 0, st, parent, N);
     // one hooking pass joins every bond's two trees (the loop inside retries until its pair is merged); a second pass
     // only confirms that nothing is left to do.  The flag is read back once per pass: this analysis is not on a hot loop.

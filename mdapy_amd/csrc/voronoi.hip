@@ -33,10 +33,26 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                                                         double *__restrict__ radius, int *__restrict__ incomplete,
                                                         int *__restrict__ row_id, double *__restrict__ row_dist,
                                                         double *__restrict__ row_area, int W, double a_thr, double r_thr,
-                                                        int64_t n_orig, int *__restrict__ max_faces, DBox b0)
+                                                        int64_t n_orig, int *__restrict__ max_faces, DBox b0,
+                                                        const unsigned char *__restrict__ dropped)
 {
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
+    if (dropped && dropped[i % n_orig]) { // not in the reference's container (see k_mark_outside): no cell, no row
+        if (lane == 0) {
+            volume[i] = 0.0;
+            nfaces[i] = 0;
+            radius[i] = 0.0;
+        }
+        if (row_id && i < n_orig)
+            for (int slot = lane; slot < W; slot += VORO_LANES) {
+                const int64_t o = i * (int64_t)W + slot;
+                row_id[o] = -1;
+                row_dist[o] = 10000.0;
+                row_area[o] = 0.0;
+            }
+        return;
+    }
     __shared__ double nrm[VORO_MAXC + 6][3];
     __shared__ double off[VORO_MAXC + 6], dist[VORO_MAXC + 6];
     __shared__ double poly_lds[PolyLdsV::CAP * 3 * VORO_LANES];
@@ -148,6 +164,37 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
 
 
 
+// The reference stores an atom in its voro++ container only if, on every OPEN axis, its block index
+//   step_int((x - origin) * (1 / (L / n)))   (extern/voro++/src/container_3d.cc:439-456, v_base_3d.cc:21-22)
+// lies in [0, n), n = int(L * cbrt(N / (4.6 V)) + 1) (src/voronoi.cpp:36-44); other atoms get no cell (their outputs keep
+// the caller's zeros) and cut nobody's cell.  Such atoms are flagged and moved far away along that axis, out of everybody's reach.
+__global__ void k_mark_outside(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, int64_t N,
+                               DBox b, int n0, int n1, int n2, double *__restrict__ ox, double *__restrict__ oy,
+                               double *__restrict__ oz, unsigned char *__restrict__ dropped)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double p[3] = {x[i], y[i], z[i]};
+    const int nb[3] = {n0, n1, n2};
+    bool out = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (b.pbc[a])
+            continue;
+        const double len = b.h[a * 4];
+        const double sp = 1.0 / (len / (double)nb[a]);
+        const double t = (p[a] - b.o[a]) * sp;
+        const bool inside = !(t < 0) && t < 2147483647.0 && (int)t < nb[a]; // step_int: int(t) - 1 for t < 0
+        if (!inside && !out) {
+            out = true;
+            p[a] = b.o[a] + 1.0e4 * len + 1.0e4;
+        }
+    }
+    ox[i] = p[0]; oy[i] = p[1]; oz[i] = p[2];
+    dropped[i] = out ? 1 : 0;
+}
+
 // images of the atoms along the periodic axes flagged in rep[]: image (a,b,c) of atom i at index ((a*ny + b)*nz + c)*N + i,
 // the (0,0,0) image first — so the first N rows of every result belong to the original atoms
 __global__ void k_replicate(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, int64_t N,
@@ -168,7 +215,7 @@ __global__ void k_replicate(const double *__restrict__ x, const double *__restri
 static int voronoi_solve(void *stream, const double *dx, const double *dy, const double *dz, int64_t N, const double *box9,
                          const double *origin3, const int *boundary3, double *dvol, int *dnf, double *drad, int *dnn, int *dflag,
                          bool *too_small, int *row_id, double *row_dist, double *row_area, int W, double a_thr, double r_thr,
-                         int64_t n_orig, int *dmaxf, const double *box9_orig)
+                         int64_t n_orig, int *dmaxf, const double *box9_orig, const unsigned char *dropped)
 {
     *too_small = false;
     DBox b, b0;
@@ -201,9 +248,9 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         {
             ProfRange pr("k_voronoi", st);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -247,6 +294,18 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
     double *dra = row_id ? sc.stage(row_area, (size_t)N * (size_t)W, space, false, true) : nullptr;
     if (sc.failed())
         return sc.error();
+    unsigned char *ddrop = nullptr;
+    if (!b.tri && !(b.pbc[0] && b.pbc[1] && b.pbc[2])) {
+        const double vol = b.h[0] * b.h[4] * b.h[8];
+        const double ilscale = pow((double)N / (4.6 * vol), 1 / 3.0); // src/voronoi.cpp:39-43
+        const int n0 = (int)(b.h[0] * ilscale + 1), n1 = (int)(b.h[4] * ilscale + 1), n2 = (int)(b.h[8] * ilscale + 1);
+        double *sx = sc.alloc_n<double>((size_t)N), *sy = sc.alloc_n<double>((size_t)N), *sz = sc.alloc_n<double>((size_t)N);
+        ddrop = sc.alloc_n<unsigned char>((size_t)N);
+        if (sc.failed())
+            return sc.error();
+        hipLaunchKernelGGL(k_mark_outside, dim3(grid_for(N, 256)), dim3(256), 0, st, dx, dy, dz, N, b, n0, n1, n2, sx, sy, sz, ddrop);
+        dx = sx; dy = sy; dz = sz;
+    }
     // Cells wider than half a period cannot be described by minimum-image rows: the periodic axes that are too thin are
     // replicated (x3 per round, the original atoms first) and the cells of the original atoms are taken from the copy.
     int rep[3] = {1, 1, 1};
@@ -279,7 +338,7 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
             return work.error();
         bool too_small = false;
         MDH_TRY(voronoi_solve(stream, px, py, pz, total, big9, origin3, boundary3, wv, wn, wr, dnn, dflag, &too_small, drid, drd, dra, W, a_thr,
-                              r_thr, N, dflag + 1, box9));
+                              r_thr, N, dflag + 1, box9, ddrop));
         if (!too_small) {
             if (total != N) {
                 MDH_HIP(hipMemcpyAsync(dvol, wv, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
@@ -363,4 +422,49 @@ extern "C" int mdh_voronoi_neighbor(const double *x, const double *y, const doub
     }
     return voronoi_driver(x, y, z, N, box9, origin3, boundary3, v, nf, r, verlet, distance, face_area, width, a_face_area_threshold,
                           r_face_area_threshold, nullptr, MDH_DEVICE, stream);
+}
+
+// distance column of neighbour rows recomputed as the reference does it: sqrt of box.pbc(x[j] - x[i]) with the box and the
+// boundary flags of the CALL (src/voronoi.cpp:277-282 for the triclinic variant, whose positions are the caller's unrotated
+// ones while the box is the LAMMPS-aligned one); -1 entries get 10000
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_row_distance(const int *__restrict__ verlet, int64_t N, int W, const double *__restrict__ x,
+                                                      const double *__restrict__ y, const double *__restrict__ z, DBox b,
+                                                      double *__restrict__ dist)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * W)
+        return;
+    const int64_t i = t / W;
+    const int j = verlet[t];
+    double d = 10000.0;
+    if (j >= 0 && j < N) {
+        double dx = x[j] - x[i], dy = y[j] - y[i], dz = z[j] - z[i];
+        pbc<TRI>(b, dx, dy, dz);
+        d = sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    dist[t] = d;
+}
+
+extern "C" int mdh_voronoi_row_distance(const int *verlet, int64_t N, int width, const double *x, const double *y, const double *z,
+                                        const double *box9, const double *origin3, const int *boundary3, double *distance, int space,
+                                        void *stream)
+{
+    if (N < 0 || width <= 0) { set_error("mdh_voronoi_row_distance: bad sizes"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const int *dv = sc.stage_in(verlet, (size_t)N * (size_t)width, space);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    double *dd = sc.stage(distance, (size_t)N * (size_t)width, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    const dim3 grid(grid_for(N * width, 256)), block(256);
+    if (b.tri)
+        hipLaunchKernelGGL(k_row_distance<true>, grid, block, 0, sc.stream(), dv, N, width, dx, dy, dz, b, dd);
+    else
+        hipLaunchKernelGGL(k_row_distance<false>, grid, block, 0, sc.stream(), dv, N, width, dx, dy, dz, b, dd);
+    return sc.finish(space);
 }

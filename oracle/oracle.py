@@ -433,6 +433,46 @@ def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, 
     return verlet, dist, face, cnt.astype(np.int32)
 
 
+def get_voronoi_neighbor_tri(x, y, z, box, origin, boundary, rotation, need_rotation, a_face_area_threshold,
+                             r_face_area_threshold, num_t=1):
+    """mdapy._voronoi.get_voronoi_neighbor_tri (src/voronoi.cpp:149-305): faces from the triclinic container of the ROTATED
+    positions; thresholds as in the orthogonal variant; the reported distance is box.pbc of the UNROTATED difference
+    x[j] - x[i] in the aligned box (:277-282), whatever that means when a rotation was needed"""
+    xr, yr, zr = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    r = np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+    n, width = len(xr), 96
+    nbr, area, cnt = np.full((n, width), -1, np.int32), np.zeros((n, width)), np.zeros(n, np.int32)
+    voro_lib().ref_voronoi_faces_tri(_p(xr, np.float64), _p(yr, np.float64), _p(zr, np.float64), i64(n), _p(b, np.float64),
+                                     _p(o, np.float64), _p(r, np.float64), cint(bool(need_rotation)), _p(nbr, np.int32),
+                                     _p(area, np.float64), cint(width), _p(cnt, np.int32))
+    width = max(int(cnt.max()), 1)
+    nbr, area = nbr[:, :width], area[:, :width]
+    amin = np.full(n, a_face_area_threshold if a_face_area_threshold > 0 else 0.0)
+    if r_face_area_threshold > 0:
+        amin = area.sum(axis=1) * r_face_area_threshold
+    amin = np.maximum(amin, a_face_area_threshold)
+    valid = (np.arange(width)[None, :] < cnt[:, None]) & (nbr >= 0) & (area > amin[:, None])
+    verlet = np.where(valid, nbr, -1).astype(np.int32)
+    face = np.where(valid, area, 0.0)
+    h = np.asarray(box, float).reshape(3, 3)
+    pos = np.stack([xr, yr, zr], axis=1)
+    d = pos[np.clip(verlet, 0, None)] - pos[:, None, :]
+    tri = bool(np.any(np.abs(h - np.diag(np.diag(h))) > 1e-10) or np.any(np.diag(h) < 0))  # box.h:182-244
+    if tri:
+        f = d @ np.linalg.inv(h)  # box.h:86-118
+        for a in range(3):
+            if boundary[a]:
+                f[..., a] -= np.floor(f[..., a] + 0.5)
+        d = f @ h
+    else:
+        for a in range(3):
+            if boundary[a]:
+                d[..., a] -= h[a, a] * np.floor(d[..., a] / h[a, a] + 0.5)
+    dist = np.where(valid, np.sqrt((d ** 2).sum(-1)), 10000.0)
+    return verlet, dist, face, cnt.astype(np.int32)
+
+
 # --------------------------------------------------------------------- _sfc (static structure factor, direct summation)
 def compute_sfc_direct(x, y, z, box, origin, boundary, structure_factor_py, bins, k_max, k_min, query_x=None, query_y=None,
                        query_z=None, N_total=0, num_t=1):

@@ -7,6 +7,7 @@
 //   get_voronoi_volume_number_radius       src/voronoi.cpp:16-71
 //   get_voronoi_volume_number_radius_tri   src/voronoi.cpp:73-147
 //   get_voronoi_neighbor (orthogonal)      src/voronoi.cpp:307-447   (unfiltered: face areas and neighbour ids per cell)
+//   get_voronoi_neighbor_tri               src/voronoi.cpp:149-305   (likewise)
 #include "voro++.hh"
 #include <cmath>
 #include <cstdint>
@@ -89,6 +90,45 @@ __attribute__((visibility("default"))) int ref_voronoi_faces(const double *x, co
     int mx = 0;
     for (int ijk = 0; ijk < con.nx * con.ny * con.nz; ++ijk)
         for (int q = 0; q < con.co[ijk]; ++q)
+            if (con.compute_cell(cell, ijk, q)) {
+                const int i = con.id[ijk][q];
+                cell.neighbors(ids);
+                cell.face_areas(ar);
+                count[i] = (int)ids.size();
+                mx = count[i] > mx ? count[i] : mx;
+                for (int k = 0; k < width; ++k) {
+                    nbr[(int64_t)i * width + k] = k < (int)ids.size() ? ids[k] : -1;
+                    area[(int64_t)i * width + k] = k < (int)ids.size() ? ar[k] : 0.0;
+                }
+            }
+    return mx;
+}
+// the same for the LAMMPS-aligned triclinic container of get_voronoi_neighbor_tri (src/voronoi.cpp:149-232)
+__attribute__((visibility("default"))) int ref_voronoi_faces_tri(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                                                 const double *origin, const double *rot9, int need_rotation, int *nbr,
+                                                                 double *area, int width, int *count)
+{
+    const double bx = box9[0], bxy = box9[3], by = box9[4], bxz = box9[6], byz = box9[7], bz = box9[8];
+    const double vol = std::fabs(bx * by * bz), init_mem = 4.6;
+    const double ilscale = std::pow(N / (init_mem * vol), 1 / 3.0);
+    auto len = [&](int r) { return std::sqrt(box9[3 * r] * box9[3 * r] + box9[3 * r + 1] * box9[3 * r + 1] + box9[3 * r + 2] * box9[3 * r + 2]); };
+    const int nx = int(len(0) * ilscale + 1), ny = int(len(1) * ilscale + 1), nz = int(len(2) * ilscale + 1);
+    voro::container_triclinic con(bx, bxy, by, bxz, byz, bz, nx, ny, nz, init_mem, 1);
+    for (int64_t i = 0; i < N; ++i) {
+        const double v[3] = {x[i] - origin[0], y[i] - origin[1], z[i] - origin[2]};
+        if (need_rotation)
+            con.put((int)i, v[0] * rot9[0] + v[1] * rot9[3] + v[2] * rot9[6], v[0] * rot9[1] + v[1] * rot9[4] + v[2] * rot9[7],
+                    v[0] * rot9[2] + v[1] * rot9[5] + v[2] * rot9[8]);
+        else
+            con.put((int)i, v[0], v[1], v[2]);
+    }
+    std::vector<int> co(con.co, con.co + con.oxyz);
+    voro::voronoicell_neighbor_3d cell(con);
+    std::vector<int> ids;
+    std::vector<double> ar;
+    int mx = 0;
+    for (int ijk = 0; ijk < con.oxyz; ++ijk)
+        for (int q = 0; q < co[ijk]; ++q)
             if (con.compute_cell(cell, ijk, q)) {
                 const int i = con.id[ijk][q];
                 cell.neighbors(ids);

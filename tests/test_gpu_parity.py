@@ -591,6 +591,33 @@ def test_atomic_temperature_and_cluster_vs_oracle(case):
     assert np.array_equal(c1, c0)
 
 
+@pytest.mark.parametrize("case", ["random_gas", "fcc_hot_shifted_origin", "dense_blob"])
+def test_cluster_directed_lists_follow_the_reference_sweep(case):
+    """k-nearest lists (what System.verlet_list holds after cal_centro_symmetry_parameter) and one-sided type filters are
+    not symmetric: the reference's sweep follows bonds in one direction only (src/cluster.cpp:14-53)."""
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    x, y, z = _xyz(pos)
+    N = len(pos)
+    k = 6
+    idx, dk = np.zeros((N, k), np.int32), np.zeros((N, k))
+    O.knn(x, y, z, box, origin, bd, k, idx, dk, 4)
+    nn = np.full(N, k, np.int32)
+    for cut in (float(np.quantile(dk, 0.3)), float(np.quantile(dk, 0.7)), float(dk.max())):
+        c0, c1 = np.full(N, -1, np.int32), np.full(N, -7, np.int32)
+        n0 = O.get_cluster(idx, dk, nn, cut, c0)
+        n1 = _cluster.get_cluster(idx, dk, nn, cut, c1)
+        assert n1 == n0 and np.array_equal(c1, c0)
+    ty = np.random.default_rng(5).integers(1, 3, N).astype(np.int32)
+    va, vb = idx.copy(), idx.copy()
+    one_sided = (np.array([1], np.int32), np.array([2], np.int32), np.array([float(np.quantile(dk, 0.5))]))
+    O.filter_by_type(va, dk, nn, ty, *one_sided)
+    _cluster.filter_by_type(vb, dk, nn, ty, *one_sided)
+    assert np.array_equal(vb, va)
+    c0, c1 = np.full(N, -1, np.int32), np.full(N, -7, np.int32)
+    assert _cluster.get_cluster_by_bond(vb, nn, c1) == O.get_cluster_by_bond(va, nn, c0)
+    assert np.array_equal(c1, c0)
+
+
 def test_cluster_system_flow_large():
     """1 M atoms: two half-spaces separated by a gap wider than rc -> exactly 2 clusters (periodic in x,y; open in z)"""
     pos, box = _fcc(64, 0.02, 3)
