@@ -1,0 +1,34 @@
+"""GPU suite: a short, fixed-seed slice of the randomised sweeps in tools/fuzz_parity.py (C-ABI level, HIP vs oracle / the
+oracle/_ref libraries) and tools/fuzz_system.py (System level, HIP vs the host classes routed to the oracle).  The tools
+run the same checks for as long as one likes on fresh seeds; the suite pins a few dozen systems of every kind."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_c_abi_sweep_fixed_seeds():
+    import fuzz_parity as F
+
+    fails = []
+    for seed in range(31000, 31025):
+        for name, fn in F.checks(F.draw(seed)):
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001 - every kind of failure is a finding
+                fails.append((seed, name, type(e).__name__, str(e)[:120]))
+    assert not fails, fails
+
+
+def test_system_sweep_fixed_seeds():
+    import fuzz_system as F
+
+    fails, ran = [], 0
+    for seed in range(32000, 32040):
+        ran += F.run_seed(seed, fails)
+    assert not fails, fails
+    assert ran > 100

@@ -52,6 +52,10 @@ def draw(seed):
             frac[: N // 2] = 0.3 + 0.25 * frac[: N // 2]
         pos = frac @ box
     pos = pos + origin
+    if tri and rng.random() < 0.4:  # general orientation: upper-triangular entries, cell vectors off the axes
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        q *= np.sign(np.linalg.det(q))
+        pos, box, origin = pos @ q, box @ q, origin @ q
     unwrapped = rng.random() < 0.2
     if unwrapped:
         pos = pos + (rng.integers(-2, 3, pos.shape) * bnd) @ box
