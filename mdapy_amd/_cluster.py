@@ -37,6 +37,7 @@ def filter_by_type(verlet_list, distance_list, neighbor_number, type_list, type1
     rr = np.ascontiguousarray(r, dtype=f64)
     c = Call(verlet_list, distance_list, neighbor_number, type_list)
     N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
+    _lib.same_rows("filter_by_type", N, distance_list=distance_list, neighbor_number=neighbor_number, type_list=type_list)
     rc_ = _lib.lib().mdh_filter_by_type(c.out(verlet_list, i32), c.inp(distance_list, f64), c.inp(neighbor_number, i32),
                                         c.inp(type_list, i32), N, M, t1.ctypes.data, t2.ctypes.data, rr.ctypes.data,
                                         len(t1), c.space, c.stream)

@@ -9,6 +9,7 @@ f64, i32 = np.float64, np.int32
 
 def fcna(x, y, z, box, origin, boundary, verlet_list, neighbor_number, pattern, rc, num_t=1):
     """src/cna.cpp:429 — pattern must be pre-zeroed"""
+    _lib.same_rows("fcna", len(x), y=y, z=z, verlet_list=verlet_list, neighbor_number=neighbor_number, pattern=pattern)
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     c = Call(x, y, z, verlet_list, neighbor_number, pattern)
     N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
@@ -19,6 +20,7 @@ def fcna(x, y, z, box, origin, boundary, verlet_list, neighbor_number, pattern, 
 
 def acna(x, y, z, box, origin, boundary, verlet_list, pattern, num_t=1):
     """src/cna.cpp:289 — rows sorted by distance, >= 14 columns"""
+    _lib.same_rows("acna", len(x), y=y, z=z, verlet_list=verlet_list, pattern=pattern)
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     c = Call(x, y, z, verlet_list, pattern)
     N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
@@ -29,6 +31,7 @@ def acna(x, y, z, box, origin, boundary, verlet_list, pattern, num_t=1):
 
 def ids(x, y, z, box, origin, boundary, verlet_list, new_verlet_list, pattern, num_t=1):
     """src/cna.cpp:163"""
+    _lib.same_rows("ids", len(x), y=y, z=z, verlet_list=verlet_list, new_verlet_list=new_verlet_list, pattern=pattern)
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     c = Call(x, y, z, verlet_list, new_verlet_list, pattern)
     N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])

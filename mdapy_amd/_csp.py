@@ -9,6 +9,7 @@ f64, i32 = np.float64, np.int32
 
 def get_csp(x, y, z, box, origin, boundary, verlet_list, N, csp, num_t=1):
     """src/centro_symmetry_parameter.cpp:12"""
+    _lib.same_rows("get_csp", len(x), y=y, z=z, verlet_list=verlet_list, csp=csp)
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     c = Call(x, y, z, verlet_list, csp)
     n, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])

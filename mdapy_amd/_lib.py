@@ -119,6 +119,18 @@ def check(rc: int) -> None:
     raise RuntimeError(msg)
 
 
+def same_rows(what: str, n_atoms: int, **arrays) -> None:
+    """Every per-atom argument of one call must have one row per atom.  The reference indexes them with the length of
+    ``x`` without a check (e.g. src/centro_symmetry_parameter.cpp:24: out-of-bounds reads when a stale list is passed);
+    the drop-in refuses instead."""
+    for name, a in arrays.items():
+        if a is None:
+            continue
+        rows = int(a.shape[0]) if hasattr(a, "shape") else len(a)
+        if rows != int(n_atoms):
+            raise ValueError(f"{what}: {name} has {rows} rows for {int(n_atoms)} atoms")
+
+
 def host_box(box, origin, boundary):
     """(box9, origin3, boundary3) as C-contiguous host arrays + their pointers (kept alive by the caller)."""
     b = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3, 3))

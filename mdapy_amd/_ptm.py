@@ -10,6 +10,7 @@ f64, i32 = np.float64, np.int32
 def get_ptm(structure, x, y, z, box, origin, boundary, verlet_list, atom_types, rmsd_threshold, output, ptm_indices,
             num_t=1):
     """src/polyhedral_template_matching.cpp:135 — output (N,8) f64, ptm_indices (N,18) i32"""
+    _lib.same_rows("get_ptm", len(x), y=y, z=z, verlet_list=verlet_list, output=output, ptm_indices=ptm_indices)
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     has_types = atom_types is not None and len(atom_types) == len(x)
     t = atom_types if has_types else None

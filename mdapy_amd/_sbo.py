@@ -10,6 +10,7 @@ f64, i32 = np.float64, np.int32
 def get_sq(x, y, z, box, origin, boundary, verlet_list, distance_list, neighbor_number, weight, llist, nnn, lmax, wl,
            wlhat, average, use_voronoi, rc, use_weight, qlm_r, qlm_i, qnarray, num_t=1):
     """src/steinhardt_bond_orientation.cpp:677"""
+    _lib.same_rows("get_sq", len(x), y=y, z=z, verlet_list=verlet_list, distance_list=distance_list, neighbor_number=neighbor_number)
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     ll = np.ascontiguousarray(np.asarray(llist), dtype=i32)
     w = weight if use_weight else None

@@ -122,6 +122,9 @@ class System:
         neigh = Neighbor(rc, self.box, self.data, max_neigh)
         neigh.compute()
         self.rc = rc
+        for attr in ("_enlarge_box", "_enlarge_data"):  # see build_nearest_neighbor: the view belongs to the current list
+            if hasattr(self, attr):
+                delattr(self, attr)
         if hasattr(neigh, "_enlarge_box"):
             self._enlarge_box = neigh._enlarge_box
         if hasattr(neigh, "_enlarge_data"):
@@ -133,6 +136,12 @@ class System:
         """system.py:1226-1263 (sets no ``rc``; neighbor_number = k everywhere)"""
         kdt = NearestNeighbor(self.data, self.box, k)
         kdt.compute()
+        # The reference only ever SETS these (system.py:1257-1260): a replicated view left behind by an earlier cutoff
+        # build would then be paired with rows of the unreplicated system (out-of-bounds reads downstream).  The view
+        # always belongs to the list that is current.
+        for attr in ("_enlarge_box", "_enlarge_data"):
+            if hasattr(self, attr):
+                delattr(self, attr)
         if hasattr(kdt, "_enlarge_box"):
             self._enlarge_box = kdt._enlarge_box
         if hasattr(kdt, "_enlarge_data"):
@@ -269,7 +278,9 @@ class System:
         type_list = None
         if isinstance(rc, dict):
             assert "type" in self.data.columns, "Must have type for multi rc cluster calculation."
-            type_list = np.ascontiguousarray(self.data["type"].to_numpy(), dtype=np.int32)
+            # types of the atoms the list indexes: the replicated view when the box was small (the reference passes the
+            # unreplicated column, system.py:2472, which its filter then indexes out of bounds)
+            type_list = np.ascontiguousarray(self._get_compute_view()[1]["type"].to_numpy(), dtype=np.int32)
         ca = ClusterAnalysis(rc, self.verlet_list, self.distance_list, self.neighbor_number, type_list)
         ca.compute()
         self.cluster_number = ca.cluster_number

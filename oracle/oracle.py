@@ -56,6 +56,14 @@ def _boxargs(box, origin, boundary):
     return b, o, p
 
 
+def _rows(what, n, **arrays):
+    """the reference indexes per-atom arguments with len(x) unchecked (UB on a mismatch); the oracle refuses instead of
+    crashing the test process"""
+    for name, a in arrays.items():
+        if a is not None and int(np.shape(a)[0]) != int(n):
+            raise ValueError(f"{what}: {name} has {int(np.shape(a)[0])} rows for {int(n)} atoms")
+
+
 def _chk(rc):
     if rc == -1:
         raise RuntimeError("The volume of the box is zero.")
@@ -114,6 +122,7 @@ def average_by_neighbor(rc, verlet_list, distance_list, neighbor_number, value, 
 
 # --------------------------------------------------------------------- _cna
 def fcna(x, y, z, box, origin, boundary, verlet_list, neighbor_number, pattern, rc, num_t=1):
+    _rows("fcna", len(x), verlet_list=verlet_list, neighbor_number=neighbor_number)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v = _ro(verlet_list, np.int32)
@@ -124,6 +133,7 @@ def fcna(x, y, z, box, origin, boundary, verlet_list, neighbor_number, pattern, 
 
 
 def acna(x, y, z, box, origin, boundary, verlet_list, pattern, num_t=1):
+    _rows("acna", len(x), verlet_list=verlet_list)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v = _ro(verlet_list, np.int32)
@@ -134,6 +144,7 @@ def acna(x, y, z, box, origin, boundary, verlet_list, pattern, num_t=1):
 
 
 def ids(x, y, z, box, origin, boundary, verlet_list, new_verlet_list, pattern, num_t=1):
+    _rows("ids", len(x), verlet_list=verlet_list)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v = _ro(verlet_list, np.int32)
@@ -144,6 +155,7 @@ def ids(x, y, z, box, origin, boundary, verlet_list, new_verlet_list, pattern, n
 
 # --------------------------------------------------------------------- _csp
 def get_csp(x, y, z, box, origin, boundary, verlet_list, N, csp, num_t=1):
+    _rows("get_csp", len(x), verlet_list=verlet_list)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v = _ro(verlet_list, np.int32)
@@ -155,6 +167,7 @@ def get_csp(x, y, z, box, origin, boundary, verlet_list, N, csp, num_t=1):
 # --------------------------------------------------------------------- _sbo
 def get_sq(x, y, z, box, origin, boundary, verlet_list, distance_list, neighbor_number, weight, llist, nnn, lmax,
            wl, wlhat, average, use_voronoi, rc, use_weight, qlm_r, qlm_i, qnarray, num_t=1):
+    _rows("get_sq", len(x), verlet_list=verlet_list, neighbor_number=neighbor_number)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v = _ro(verlet_list, np.int32)
@@ -268,6 +281,7 @@ def ref_lib():
 def get_ptm(structure, x, y, z, box, origin, boundary, verlet_list, atom_types, rmsd_threshold, output, ptm_indices,
             num_t=1, cached=None):
     """mdapy._ptm.get_ptm (src/polyhedral_template_matching.cpp:135) through the reference PTM library."""
+    _rows("get_ptm", len(x), verlet_list=verlet_list)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v = _ro(verlet_list, np.int32)
@@ -283,6 +297,7 @@ def get_ptm(structure, x, y, z, box, origin, boundary, verlet_list, atom_types, 
 # --------------------------------------------------------------------- list consumers
 def compute_aja(x, y, z, box, origin, boundary, verlet_list, distance_list, aja, num_t=1):
     """mdapy._aja.compute_aja (src/ackland_jones_analysis.cpp:9)"""
+    _rows("compute_aja", len(x), verlet_list=verlet_list)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v, d = _ro(verlet_list, np.int32), _ro(distance_list, np.float64)
@@ -293,6 +308,7 @@ def compute_aja(x, y, z, box, origin, boundary, verlet_list, distance_list, aja,
 
 def compute_cnp(x, y, z, box, origin, boundary, verlet_list, distance_list, neighbor_number, cnp, rc, num_t=1):
     """mdapy._cnp.compute_cnp (src/common_neighbor_parameter.cpp:10)"""
+    _rows("compute_cnp", len(x), verlet_list=verlet_list, neighbor_number=neighbor_number)
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
     b, o, p = _boxargs(box, origin, boundary)
     v, d, n = _ro(verlet_list, np.int32), _ro(distance_list, np.float64), _ro(neighbor_number, np.int32)
@@ -334,6 +350,7 @@ def get_cluster_by_bond(verlet_list, neighbor_number, particleClusters):
 
 def filter_by_type(verlet_list, distance_list, neighbor_number, type_list, type1, type2, r, num_t=1):
     """mdapy._cluster.filter_by_type (src/cluster.cpp:108); verlet_list modified in place"""
+    _rows("filter_by_type", np.shape(verlet_list)[0], distance_list=distance_list, neighbor_number=neighbor_number, type_list=type_list)
     d, n, t = _ro(distance_list, np.float64), _ro(neighbor_number, np.int32), _ro(type_list, np.int32)
     t1, t2, rr = _ro(type1, np.int32), _ro(type2, np.int32), _ro(r, np.float64)
     _chk(lib().orc_filter_by_type(_p(verlet_list, np.int32), _p(d, np.float64), _p(n, np.int32), _p(t, np.int32),

@@ -70,7 +70,8 @@ def plan(s):
     if not s["unwrapped"]:
         if s["sigma"] != 0.0:
             calls.append(("ptm", lambda y: y.cal_polyhedral_template_matching("default", return_rmsd=True, return_ordering=True, return_atomic_distance=True)))
-        if O.have_voro_ref() and s["kind"] != "blob" and (ortho or all(s["bnd"])):
+            calls.append(("ptm_faults", lambda y: y.cal_polyhedral_template_matching("fcc-hcp-bcc", identify_fcc_planar_faults=True)))
+        if O.have_voro_ref() and s["kind"] not in ("blob", "tiny") and (ortho or all(s["bnd"])):
             calls.append(("voronoi_volume", lambda y: y.cal_voronoi_volume()))
             if all(s["bnd"]):
                 calls.append(("steinhardt_voronoi", lambda y: y.cal_steinhardt_bond_orientation([6], use_voronoi=True, use_weight=P["vw"])))
@@ -117,6 +118,8 @@ def run_seed(seed, fails):
         return 0
     a, b = make_system(s), make_system(s)
     for label, fn in calls:
+        if os.environ.get("FUZZ_TRACE"):
+            print("  call", label, flush=True)
         res = []
         for which, sysm in (("hip", a), ("oracle", b)):
             patch = MonkeyPatch()
@@ -152,6 +155,8 @@ def main():
     t0 = time.time()
     fails, ran = [], 0
     while time.time() - t0 < budget:
+        if os.environ.get("FUZZ_TRACE"):
+            print("seed", seed, flush=True)
         try:
             ran += run_seed(seed, fails)
         except Exception:
