@@ -46,7 +46,8 @@ def plan(s):
     P = dict(csp_n=int(rng.choice([8, 12])), ent_local=bool(rng.integers(0, 2)), ent_avg=float(rng.choice([0.0, rc * 0.8])),
              cl_rc=float(rng.uniform(1.5, 3.2)), st_avg=bool(rng.integers(0, 2)), nbin=int(rng.integers(20, 120)),
              rdf_long=float(rng.uniform(5.0, 9.0)), sf_kmax=float(rng.uniform(3.0, 6.0)), sf_partial=bool(rng.integers(0, 2)),
-             sf_rc=float(rng.uniform(6.0, 9.0)), vw=bool(rng.integers(0, 2)))
+             sf_rc=float(rng.uniform(6.0, 9.0)), vw=bool(rng.integers(0, 2)),
+             rep=[int(v) for v in rng.permutation([2, 1, 1])])
     calls = [
         ("neighbor", lambda y: y.build_neighbor(rc)),
         ("cna_rc", lambda y: y.cal_common_neighbor_analysis(rc=min(rc, 3.6))),
@@ -65,6 +66,9 @@ def plan(s):
         ("rdf_long", lambda y: y.cal_radial_distribution_function(P["rdf_long"], 60)),
         ("wcp", lambda y: y.cal_warren_cowley_parameter(rc)),
         ("sfc_direct", lambda y: y.cal_structure_factor(0.5, P["sf_kmax"], 40, cal_partial=P["sf_partial"], mode="direct")),
+        ("wrap", lambda y: y.wrap_pos()),
+        ("replicate", lambda y: y.replicate(*P["rep"])),
+        ("average", lambda y: y.average_by_neighbor(rc * 0.8, "vx", include_self=P["st_avg"])),
         ("sfc_debye", lambda y: y.cal_structure_factor(0.5, 8.0, 50, mode="debye", rc=P["sf_rc"])),
     ]
     if not s["unwrapped"]:
