@@ -231,6 +231,14 @@ int mdh_filter_overlap_atom(const double *x, const double *y, const double *z, i
                             const double *origin3_host, const int *boundary3_host, double rc, unsigned char *keep,
                             int space, void *stream);
 
+/* replaces _polycrystal.transform_and_filter                src/polycrystal.cpp:20-125 (polycrystal builder)
+ * p' = R (p - center) + target (rotation9 = row-major R, i.e. (p - center) @ R.T); kept when
+ * a*p'x + b*p'y + c*p'z + d < 0 for every row (a,b,c,d) of coeffs (nf <= 1024, host array); survivors in input order in
+ * rows [0, *count_host) of out_pos (capacity (n,3)). */
+int mdh_transform_and_filter(const double *x, const double *y, const double *z, int64_t n, const double *rotation9_host,
+                             const double *center3_host, const double *target3_host, const double *coeffs_host, int nf,
+                             double *out_pos, int64_t *count_host, int space, void *stream);
+
 /* ---- _voronoi (volume functions) ------------------------------ */
 /* replaces _voronoi.get_voronoi_volume_number_radius         src/voronoi.cpp:16-71 (and, called with a LAMMPS-aligned
  * triclinic box and all-periodic boundary, get_voronoi_volume_number_radius_tri :73-147).

@@ -16,10 +16,11 @@ from .polyhedral_template_matching import PolyhedralTemplateMatching
 from .radial_distribution_function import RadialDistributionFunction
 from .warren_cowley_parameter import WarrenCowleyParameter
 from .build_lattice import build_crystal
+from .create_polycrystal import CreatePolycrystal
 from .parallel import get_num_threads
 
 __all__ = [
     "Box", "Frame", "System", "Neighbor", "NearestNeighbor", "CommonNeighborAnalysis", "CentroSymmetryParameter",
     "IdentifyDiamondStructure", "SteinhardtBondOrientation", "PolyhedralTemplateMatching", "RadialDistributionFunction", "WarrenCowleyParameter",
-    "build_crystal", "get_num_threads",
+    "build_crystal", "CreatePolycrystal", "get_num_threads",
 ]

@@ -1509,6 +1509,31 @@ ORC_API int orc_identify_sftb_fcc(const int *hcp_idx, int64_t n_hcp, int *hn, co
     return 0;
 }
 
+/* _polycrystal.transform_and_filter                                  src/polycrystal.cpp:20-125
+ * out (n,3) capacity; returns the number of survivors (input order) */
+ORC_API int64_t orc_transform_and_filter(const double *x, const double *y, const double *z, int64_t n, const double *R,
+                                         const double *center, const double *target, const double *coeffs, int nf, double *out)
+{
+    const double RT00 = R[0], RT01 = R[3], RT02 = R[6]; /* RTck = R(k,c), :49-51 */
+    const double RT10 = R[1], RT11 = R[4], RT12 = R[7];
+    const double RT20 = R[2], RT21 = R[5], RT22 = R[8];
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double dx = x[i] - center[0], dy = y[i] - center[1], dz = z[i] - center[2];
+        const double px = dx * RT00 + dy * RT10 + dz * RT20 + target[0];
+        const double py = dx * RT01 + dy * RT11 + dz * RT21 + target[1];
+        const double pz = dx * RT02 + dy * RT12 + dz * RT22 + target[2];
+        int inside = 1;
+        for (int f = 0; f < nf; ++f) {
+            const double *pl = coeffs + 4 * f;
+            const double val = px * pl[0] + py * pl[1] + pz * pl[2] + pl[3];
+            if (val >= 0.0) { inside = 0; break; }
+        }
+        if (inside) { out[3 * cnt] = px; out[3 * cnt + 1] = py; out[3 * cnt + 2] = pz; ++cnt; }
+    }
+    return cnt;
+}
+
 /* overlap filter of the polycrystal builder                   src/neighbor.cpp:390-486
  * keep[j] = 0 iff a centre i < j finds j within rc (centre wrapped, j raw, minimum image) */
 ORC_API int orc_filter_overlap_atom(const double *x, const double *y, const double *z, int64_t N, const double *box9,

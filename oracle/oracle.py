@@ -375,6 +375,21 @@ def filter_overlap_atom(x, y, z, box, origin, boundary, rc, num_t=1):
     return keep.astype(bool)
 
 
+def transform_and_filter(x, y, z, rotation_matrix, center, target_center, coeffs, num_t=1):
+    """mdapy._polycrystal.transform_and_filter (src/polycrystal.cpp:20) -> (count, 3)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    r = np.ascontiguousarray(rotation_matrix, dtype=np.float64).reshape(9)
+    c = np.ascontiguousarray(center, dtype=np.float64).reshape(3)
+    t = np.ascontiguousarray(target_center, dtype=np.float64).reshape(3)
+    pl = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1, 4)
+    out = np.empty((len(x), 3))
+    f = lib().orc_transform_and_filter
+    f.restype = C.c_int64
+    cnt = f(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(len(x)), _p(r, np.float64), _p(c, np.float64),
+            _p(t, np.float64), _p(pl, np.float64), cint(len(pl)), _p(out, np.float64))
+    return out[: int(cnt)].copy()
+
+
 # --------------------------------------------------------------------- _voronoi  (oracle/_ref: the reference's own voro++)
 _VORO_SO = os.path.join(_HERE, "_ref", "libvoro_ref.so")
 _voro = None

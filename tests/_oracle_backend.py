@@ -34,6 +34,11 @@ neighbor = _mod(
     wrap_positions=lambda x, y, z, box, origin, boundary, num_t=1: O.wrap_positions(x, y, z, box, origin, boundary, NT),
     average_by_neighbor=lambda rc, v, d, nn, value, out, inc, num_t=1:
         O.average_by_neighbor(rc, _np(v), _np(d), _np(nn), _np(value), out, inc, NT),
+    filter_overlap_atom=lambda x, y, z, box, origin, boundary, rc, num_t=1:
+        O.filter_overlap_atom(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT),
+)
+polycrystal = _mod(
+    transform_and_filter=lambda x, y, z, rot, c, t, pl, num_t=1: O.transform_and_filter(_np(x), _np(y), _np(z), rot, c, t, pl, NT),
 )
 cna = _mod(
     fcna=lambda x, y, z, box, origin, boundary, v, nn, pat, rc, num_t=1:
@@ -110,6 +115,7 @@ def install(monkeypatch):
     import mdapy_amd.atomic_temperature as m_at
     import mdapy_amd.build_lattice as bl
     import mdapy_amd.cluster_analysis as m_cl
+    import mdapy_amd.create_polycrystal as m_poly
     import mdapy_amd.structure_factor as m_sf
     import mdapy_amd.voronoi as m_vor
     import mdapy_amd.identify_fcc_planar_faults as m_pft
@@ -127,6 +133,8 @@ def install(monkeypatch):
     import mdapy_amd.warren_cowley_parameter as m_wcp
 
     monkeypatch.setattr(m_nb, "_neighbor", neighbor)
+    monkeypatch.setattr(m_poly, "_neighbor", neighbor)
+    monkeypatch.setattr(m_poly, "_polycrystal", polycrystal)
     monkeypatch.setattr(m_tool, "_neighbor", neighbor)
     monkeypatch.setattr(m_tool, "_repeat_cell", repeat_cell)
     monkeypatch.setattr(bl, "_repeat_cell", repeat_cell)

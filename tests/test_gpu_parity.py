@@ -936,3 +936,57 @@ def test_config4_glass_streaming_rdf_wcp_vs_oracle():
     O.get_wcp(np.asarray(v), np.asarray(nn), ty, 2, w0, 8)
     _wcp.get_wcp(v, nn, ty, 2, w1, 1)
     assert np.array_equal(w1, w0) and np.abs(w0).max() < 0.02
+
+
+# ------------------------------------------------------------------ polycrystal builder: grain filling
+def test_transform_and_filter_bit_exact_vs_oracle():
+    from mdapy_amd import _polycrystal
+
+    rng = np.random.default_rng(17)
+    for n, nf in ((0, 4), (1, 1), (70_000, 14), (300_000, 40)):
+        pos = rng.random((n, 3)) * 60.0
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        centre = pos.mean(0) if n else np.zeros(3)
+        target = rng.random(3) * 30.0
+        nrm = rng.normal(size=(nf, 3)); nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+        planes = np.c_[nrm, -(nrm @ target) - rng.uniform(8.0, 25.0, nf)]  # a random polyhedron around the target
+        x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+        a = O.transform_and_filter(x, y, z, q, centre, target, planes)
+        b = _polycrystal.transform_and_filter(x, y, z, q, centre, target, planes, 1)
+        assert b.shape == a.shape and np.array_equal(b, a)  # same atoms, same order, same bits
+        if n > 1000:
+            assert 0 < len(a) < n
+    with pytest.raises(ValueError):
+        _polycrystal.transform_and_filter(x, y, z, q, centre, target, np.zeros((1100, 4)), 1)
+
+
+def test_create_polycrystal_hip_equals_oracle_build(monkeypatch):
+    """the same builder, once through the HIP library and once with its three device calls routed to the oracle: identical
+    atoms (positions bit for bit), and the geometric contract of a Voronoi polycrystal"""
+    import _oracle_backend as ob
+    from mdapy_amd import devarray
+
+    unit = mp.build_crystal("Al", "fcc", 4.05)
+    kw = dict(box=70.0, seed_number=9, randomseed=11, metal_overlap_dis=2.0)
+    a = mp.CreatePolycrystal(unit, **kw).compute()
+    with monkeypatch.context() as m:
+        ob.install(m)
+        m.setattr(devarray, "_gpu", False)
+        pb = mp.CreatePolycrystal(unit, **kw)
+        b = pb.compute()
+    assert a.N == b.N and a.data.columns == b.data.columns == ["element", "x", "y", "z", "grain_id", "type"]
+    for c in ("x", "y", "z", "grain_id", "type"):
+        assert np.array_equal(a.data[c].to_numpy(), b.data[c].to_numpy())
+    pos = np.c_[a.data["x"].to_numpy(), a.data["y"].to_numpy(), a.data["z"].to_numpy()]
+    assert pos.min() >= 0.0 and pos.max() < 70.0
+    d = pos[:, None, :] - pb.seed_position[None, :, :]
+    d -= 70.0 * np.round(d / 70.0)
+    assert np.array_equal(np.argmin((d ** 2).sum(-1), axis=1) + 1, a.data["grain_id"].to_numpy())  # Voronoi assignment
+    assert abs(pb.volume.sum() - 70.0 ** 3) < 1e-6 * 70.0 ** 3
+    assert 0.90 < a.N / (70.0 ** 3 * 4 / 4.05 ** 3) < 1.0  # bulk density minus the grain-boundary overlaps
+    a.build_neighbor(2.0 - 1e-9)
+    assert int(np.asarray(a.neighbor_number).max()) == 0  # no pair closer than the overlap distance is left
+    with pytest.raises(NotImplementedError):
+        mp.CreatePolycrystal(unit, box=70.0, seed_number=4, add_graphene=True)
+    with pytest.raises(ValueError, match="Triclinic"):
+        mp.CreatePolycrystal(unit, box=np.array([[70.0, 0, 0], [5.0, 70.0, 0], [0, 0, 70.0]]), seed_number=4)

@@ -422,3 +422,24 @@ def test_structure_factor_against_fixture(mode, oracle_backend):
     assert np.allclose(sf.Sk, d[f"{mode}_all"], atol=1e-4, equal_nan=True)
     sf2 = s.cal_structure_factor(float(d["k_min"]), float(d["k_max"]), nbins, cal_partial=False, mode=mode)
     assert np.allclose(sf2.Sk, d[f"{mode}_all"], atol=1e-4, equal_nan=True)
+
+
+def test_transform_and_filter_oracle_vs_numpy():
+    """src/polycrystal.cpp:20-125 restated in C against the formula of its docstring, pos_new = (pos - center) @ R.T + target,
+    and the half-space test, on a rotated cube and on an empty / full selection"""
+    rng = np.random.default_rng(3)
+    pos = rng.random((5000, 3)) * 20.0
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    centre, target = pos.mean(0), np.array([3.0, -2.0, 7.5])
+    new = (pos - centre) @ q.T + target
+    planes = []
+    for a in range(3):
+        e = np.zeros(3); e[a] = 1.0
+        planes += [np.r_[e, -(target[a] + 4.0)], np.r_[-e, target[a] - 4.0]]
+    planes = np.array(planes)
+    inside = (new @ planes[:, :3].T + planes[:, 3] < 0).all(1)
+    out = _O.transform_and_filter(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), q, centre, target, planes)
+    assert 0 < len(out) < len(pos) and out.shape == (int(inside.sum()), 3)
+    assert np.allclose(out, new[inside], rtol=0, atol=1e-12)  # same atoms, same order
+    assert len(_O.transform_and_filter(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), q, centre, target, np.array([[0, 0, 0, 1.0]]))) == 0
+    assert len(_O.transform_and_filter(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), q, centre, target, np.zeros((0, 4)))) == len(pos)
