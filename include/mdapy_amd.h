@@ -263,6 +263,15 @@ int mdh_voronoi_neighbor(const double *x, const double *y, const double *z, int6
                          double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width, int space,
                          void *stream);
 
+/* geometry of _voronoi.get_cell_info                          src/voronoi.cpp:449-540: per cell, every face (walls of open axes
+ * included) as a polygon.  face_nv (N,W) i32 vertices per face slot (0: none), face_area (N,W), face_vert (N,W,V,3) vertices
+ * relative to the atom in polygon order, nfaces / volume / radius (N) as in mdh_voronoi_volume_number_radius.
+ * W >= width of mdh_voronoi_neighbor_count; *need_v_host > V on return: repeat with that V. */
+int mdh_voronoi_cell_info(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+                          const double *origin3_host, const int *boundary3_host, int W, int V, int *nfaces, int *face_nv,
+                          double *face_area, double *face_vert, double *volume, double *radius, int *need_v_host, int space,
+                          void *stream);
+
 /* distance column of _voronoi.get_voronoi_neighbor_tri         src/voronoi.cpp:277-282: sqrt(box.pbc(x[j] - x[i])) with the
  * caller's UNROTATED positions and the LAMMPS-aligned box / boundary flags of that call; -1 entries -> 10000. */
 int mdh_voronoi_row_distance(const int *verlet, int64_t N, int width, const double *x, const double *y, const double *z,

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "mdh_voronoi_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, vp, vp, cint, vp],
     "mdh_voronoi_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, dbl, vp, vp, vp, cint, cint, vp],
     "mdh_transform_and_filter": [vp, vp, vp, i64, vp, vp, vp, vp, cint, vp, vp, cint, vp],
+    "mdh_voronoi_cell_info": [vp, vp, vp, i64, vp, vp, vp, cint, cint, vp, vp, vp, vp, vp, vp, vp, cint, vp],
     "mdh_voronoi_row_distance": [vp, i64, cint, vp, vp, vp, vp, vp, vp, vp, cint, vp],
     "mdh_sfc_direct": [vp, vp, vp, i64, vp, vp, cint, dbl, dbl, vp, vp, vp, i64, C.c_uint, cint, vp],
     "mdh_sfc_direct_partial": [vp, vp, vp, vp, cint, i64, vp, vp, cint, dbl, dbl, cint, vp],

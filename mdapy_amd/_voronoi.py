@@ -75,3 +75,72 @@ def get_voronoi_neighbor_tri(x, y, z, box, origin, boundary, rotation, need_rota
     _lib.check(_lib.lib().mdh_voronoi_row_distance(verlet.ctypes.data, int(len(x0)), int(verlet.shape[1]), c.inp(x0, f64),
                                                    c.inp(y0, f64), c.inp(z0, f64), pb, po, pp, dist.ctypes.data, c.space, c.stream))
     return verlet, dist, area, nn
+
+
+def get_cell_info(x, y, z, box, origin, boundary, num_t=1):
+    """src/voronoi.cpp:449 -> (face_vertices_indices, face_vertices_positions, volume, radius, face_areas), lists per atom like
+    the reference's: faces as lists of indices into the cell's vertex list, the vertex list (container frame: position minus
+    origin, wrapped on periodic axes, plus the vertex offsets), cell volume, cavity radius, face areas.
+
+    The polygons come from the device (``mdh_voronoi_cell_info``: each face clipped on its own); here the copies of a vertex
+    that three or more faces share are merged into one entry.  Faces are listed walls first, then nearest neighbour first,
+    vertices in order of first appearance — voro++'s own orders are internal to that library.  Atoms the reference's container
+    does not hold (outside on an open axis) get empty lists and zeros."""
+    import ctypes
+
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    n = int(len(x))
+    xs, ys, zs = (np.ascontiguousarray(np.asarray(a, f64)) for a in (x, y, z))
+    L = _lib.lib()
+    nn = np.zeros(n, i32)
+    w = ctypes.c_int(0)
+    _lib.check(L.mdh_voronoi_neighbor_count(xs.ctypes.data, ys.ctypes.data, zs.ctypes.data, n, pb, po, pp, nn.ctypes.data,
+                                            ctypes.byref(w), _lib.HOST, None))
+    W, V = max(int(w.value), 1), 12
+    while True:
+        nf = np.zeros(n, i32)
+        fnv = np.zeros((n, W), i32)
+        farea = np.zeros((n, W))
+        fvert = np.zeros((n, W, V, 3))
+        vol, rad = np.zeros(n), np.zeros(n)
+        need = ctypes.c_int(0)
+        _lib.check(L.mdh_voronoi_cell_info(xs.ctypes.data, ys.ctypes.data, zs.ctypes.data, n, pb, po, pp, W, V, nf.ctypes.data,
+                                           fnv.ctypes.data, farea.ctypes.data, fvert.ctypes.data, vol.ctypes.data, rad.ctypes.data,
+                                           ctypes.byref(need), _lib.HOST, None))
+        if need.value <= V:
+            break
+        V = int(need.value)
+    h = np.asarray(box, f64).reshape(3, 3)
+    o = np.asarray(origin, f64).reshape(3)
+    bd = np.asarray(boundary).reshape(3)
+    p = np.stack([xs, ys, zs], axis=1) - o
+    for a in range(3):  # the container holds periodic coordinates folded into [0, L)
+        if bd[a]:
+            p[:, a] -= h[a, a] * np.floor(p[:, a] / h[a, a])
+    face_idx, face_pos, areas = [], [], []
+    for i in range(n):
+        verts, faces, ar = [], [], []
+        tol = 1e-9 * max(float(rad[i]), 1e-300)
+        for s_ in range(W):
+            m = int(fnv[i, s_])
+            if m == 0:
+                continue
+            ids = []
+            for c in range(m):
+                v = fvert[i, s_, c]
+                hit = -1
+                for q, u in enumerate(verts):
+                    if abs(u[0] - v[0]) <= tol and abs(u[1] - v[1]) <= tol and abs(u[2] - v[2]) <= tol:
+                        hit = q
+                        break
+                if hit < 0:
+                    verts.append(v)
+                    hit = len(verts) - 1
+                if not ids or (ids[-1] != hit and ids[0] != hit):  # a sliver edge shorter than the tolerance collapses
+                    ids.append(hit)
+            faces.append(ids)
+            ar.append(float(farea[i, s_]))
+        face_idx.append(faces)
+        face_pos.append([(p[i] + np.asarray(v)).tolist() for v in verts])
+        areas.append(ar)
+    return face_idx, face_pos, vol.tolist(), rad.tolist(), areas

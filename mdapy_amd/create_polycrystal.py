@@ -3,15 +3,15 @@ for metallic grains: Voronoi tessellation of the seeds, every cell filled with t
 atoms at the grain boundaries removed, atoms wrapped into the box.
 
 Where the work is done
-* cell volumes and cavity radii of the seeds: ``_voronoi.get_voronoi_volume_number_radius`` (HIP);
+* Voronoi cells of the seeds (faces, vertices, volumes, cavity radii): ``_voronoi.get_cell_info`` (HIP);
 * filling a grain: ``_polycrystal.transform_and_filter`` (HIP) — rotate, translate, half-space test, compaction;
 * grain-boundary overlaps: ``_neighbor.filter_overlap_atom`` (HIP); wrapping: ``System.wrap_pos`` (HIP).
 
-The face planes of a grain are written down directly as the bisector planes between its seed and every periodic image of
-a seed within twice its cavity radius (every face of the cell lies on one of them; the others are redundant half-spaces).
-The reference derives the same planes from the first three vertices of each face of voro++'s cell
-(``_get_plane_equation_coeffs_for_cell``, :207-256), which agrees to rounding; atoms closer than that to a grain boundary
-plane are the only ones that can be assigned differently.
+The face planes of a grain come from the vertices of its Voronoi cell exactly as in the reference
+(``_get_plane_equation_coeffs_for_cell``, :207-256): normal = cross product of two edges at the first vertex of the face,
+oriented so that the seed is on the negative side.  The cells are those of ``mdapy_amd.voronoi.Container`` (HIP); their
+vertices agree with voro++'s to rounding, so only atoms closer than that to a grain-boundary plane can be assigned
+differently.
 
 Graphene-decorated grain boundaries (``add_graphene=True``, :331-520, ``filter_overlap_atom_with_grain``) are refused.
 """
@@ -26,9 +26,7 @@ from . import tool_function as tool
 from .box import Box
 from .frame import Frame
 from .parallel import get_num_threads
-from .voronoi import Voronoi
-
-MAX_PLANES = 1024  # capacity of the device kernel's plane table
+from .voronoi import Container
 
 
 class CreatePolycrystal:
@@ -84,28 +82,26 @@ class CreatePolycrystal:
                          [C * y * x + s * z, c + C * y * y, C * y * z - s * x],
                          [C * z * x - s * y, C * z * y + s * x, c + C * z * z]], dtype=float)
 
-    def _cell_planes(self, i: int, radius: float) -> np.ndarray:
-        """(n, 4) rows (a, b, c, d), a*x + b*y + c*z + d < 0 inside the Voronoi cell of seed ``i`` (box frame, origin at 0)"""
-        L = np.diag(self.box.box)
-        p = self.seed_position[i]
-        reach = 2.0 * radius * (1.0 + 1e-9) + 1e-9
-        span = [np.arange(-int(np.ceil(reach / L[a])) - 1, int(np.ceil(reach / L[a])) + 2) for a in range(3)]
-        shifts = np.stack(np.meshgrid(*span, indexing="ij"), axis=-1).reshape(-1, 3) * L
-        others = (self.seed_position[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
-        d = others - p
-        r = np.linalg.norm(d, axis=1)
-        keep = (r > 0) & (r <= reach)
-        d, r, others = d[keep], r[keep], others[keep]
-        order = np.argsort(r, kind="stable")  # nearest planes first: most atoms are rejected by the first few tests
-        d, r, others = d[order], r[order], others[order]
-        if len(r) > MAX_PLANES:
-            raise ValueError(f"grain {i}: {len(r)} seed images within twice the cavity radius (more than {MAX_PLANES})")
-        u = d / r[:, None]
-        mid = p + 0.5 * d
-        return np.ascontiguousarray(np.c_[u, -(u * mid).sum(1)])
+    @staticmethod
+    def _get_plane_equation_coeffs_for_cell(cell) -> np.ndarray:
+        """(n_faces, 4) rows (a, b, c, d) with a*x + b*y + c*z + d < 0 inside the cell (create_polycrystal.py:207-256)"""
+        coeffs = np.zeros((len(cell.face_vertices), 4))
+        for i, face in enumerate(cell.face_vertices):
+            p1, p2, p3 = cell.vertices[face[0]], cell.vertices[face[1]], cell.vertices[face[2]]
+            n = np.cross(p2 - p1, p3 - p1)
+            norm_n = np.linalg.norm(n)
+            if norm_n < 1e-10:
+                raise ValueError(f"Degenerate face vertices at face {i}")
+            n = n / norm_n
+            d = -np.dot(n, p1)
+            if np.dot(n, cell.pos) + d > 0:  # normal points outward: the seed is on the negative side
+                n, d = -n, -d
+            coeffs[i, :3] = n
+            coeffs[i, 3] = d
+        return coeffs
 
-    def _get_pos(self, radius: np.ndarray):
-        r_max = float(radius.max())
+    def _get_pos(self):
+        r_max = max(cell.cavity_radius for cell in self.con)
         thickness = self.unitcell.box.get_thickness()
         replicate_nums = np.ceil(r_max / thickness).astype(int)  # :597-600
         data, _ = tool._replicate_pos(self.unitcell.data, self.unitcell.box, *replicate_nums)
@@ -119,8 +115,9 @@ class CreatePolycrystal:
                        @ self._get_rotation_matrix(self.theta_list[n, 2], (0.0, 0.0, 1.0)))
             else:
                 rot = self._get_rotation_matrix(0, (1.0, 0.0, 0.0))
-            pos = _polycrystal.transform_and_filter(x, y, z, rot, pos_center, self.seed_position[n],
-                                                    self._cell_planes(n, float(radius[n])), get_num_threads())
+            cell = self.con[n]
+            pos = _polycrystal.transform_and_filter(x, y, z, rot, pos_center, cell.pos,
+                                                    self._get_plane_equation_coeffs_for_cell(cell), get_num_threads())
             pos_list.append(pos)
             grain_list.append(np.full(len(pos), n + 1, np.int32))
         return np.vstack(pos_list), np.concatenate(grain_list)
@@ -130,11 +127,11 @@ class CreatePolycrystal:
         from .system import System
 
         origin = self.box.origin.copy()
-        seeds = Frame({"x": self.seed_position[:, 0], "y": self.seed_position[:, 1], "z": self.seed_position[:, 2]})
-        self.volume, _, self.cavity_radius = Voronoi(Box(self.box.box), seeds).get_volume()
+        self.con = Container(np.ascontiguousarray(self.seed_position, dtype=np.float64), Box(self.box.box))
+        self.volume = np.array([cell.volume for cell in self.con])
         if verbose:
             print(f"  Number of grains: {self.seed_number}\n  Average volume:   {self.volume.mean():>10.2f} A^3")
-        pos, grain_id = self._get_pos(np.asarray(self.cavity_radius))
+        pos, grain_id = self._get_pos()
         n_generated = len(pos)
         x, y, z = pos[:, 0] + origin[0], pos[:, 1] + origin[1], pos[:, 2] + origin[2]
         type_list = np.ones(n_generated, np.int32)

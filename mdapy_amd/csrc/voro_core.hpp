@@ -23,6 +23,7 @@ struct FaceResult {
     double area;   // 0 when the face does not exist
     double maxr2;  // largest squared vertex distance of this face
     bool overflow; // polygon storage too small
+    int nv;        // vertices of the face polygon (left in `poly`, counter-clockwise or clockwise as clipped)
 };
 
 // constraint k: v . nrm[k] <= off[k]; dist[k] = off[k] / |nrm[k]| ascending for k >= first_sorted.
@@ -31,7 +32,7 @@ template <class P>
 PTM_HDN FaceResult voronoi_face(P &poly, int f, int nc, const double (*nrm)[3], const double *off, const double *dist,
                                 int first_sorted, double big)
 {
-    FaceResult r{0.0, 0.0, false};
+    FaceResult r{0.0, 0.0, false, 0};
     const double *p = nrm[f];
     const double pn2 = dot3(p, p);
     if (!(pn2 > 0))
@@ -94,6 +95,7 @@ PTM_HDN FaceResult voronoi_face(P &poly, int f, int nc, const double (*nrm)[3], 
     }
     r.area = 0.5 * sqrt(dot3(acc, acc));
     r.maxr2 = mx;
+    r.nv = m;
     return r;
 }
 

@@ -25,6 +25,15 @@ struct PolyLdsV { // vertex i, coordinate c of lane l at [(i*3 + c) * 64 + l]
     __device__ __forceinline__ void set(int i, int c, double x) { base[(i * 3 + c) * VORO_LANES] = x; }
 };
 
+// optional per-face output of the cell-info call: polygons relative to the atom
+struct CellOut {
+    int *nv = nullptr;      // (N, W) vertices per face, 0 = no face in this slot
+    double *area = nullptr; // (N, W)
+    double *vert = nullptr; // (N, W, V, 3)
+    int W = 0, V = 0;
+    int *need_v = nullptr;  // largest polygon seen when it did not fit V
+};
+
 template <bool TRI>
 __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict__ x, const double *__restrict__ y,
                                                         const double *__restrict__ z, int64_t N, DBox b,
@@ -34,7 +43,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                                                         int *__restrict__ row_id, double *__restrict__ row_dist,
                                                         double *__restrict__ row_area, int W, double a_thr, double r_thr,
                                                         int64_t n_orig, int *__restrict__ max_faces, DBox b0,
-                                                        const unsigned char *__restrict__ dropped)
+                                                        const unsigned char *__restrict__ dropped, CellOut co)
 {
     const int64_t i = blockIdx.x;
     const int lane = threadIdx.x;
@@ -89,24 +98,54 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
     const int nc = n + 6;
     double vol = 0.0, mr2 = 0.0, asum = 0.0;
     int nf = 0;
-    for (int f = lane; f < nc; f += VORO_LANES) {
-        farea[f] = 0.0;
-        if (f < 6 && (TRI || b.pbc[f >> 1]))
-            continue; // the bounding cube is not a face
+    int co_base = 0; // faces of this cell already written to the cell-info rows
+    for (int f0 = 0; f0 < nc; f0 += VORO_LANES) {
+        const int f = f0 + lane;
+        bool have = false;
+        voroc::FaceResult r{0.0, 0.0, false, 0};
         PolyLdsV fast{poly_lds + lane};
-        voroc::FaceResult r = voroc::voronoi_face(fast, f, nc, nrm, off, dist, 6, big);
-        if (r.overflow) { // a face with more than 16 vertices: private storage holds 28
-            ptmc::PolyLocal slow;
-            r = voroc::voronoi_face(slow, f, nc, nrm, off, dist, 6, big);
+        ptmc::PolyLocal slow;
+        bool in_slow = false;
+        if (f < nc) {
+            farea[f] = 0.0;
+            if (!(f < 6 && (TRI || b.pbc[f >> 1]))) { // the bounding cube is not a face
+                r = voroc::voronoi_face(fast, f, nc, nrm, off, dist, 6, big);
+                if (r.overflow) { // a face with more than 16 vertices: private storage holds 28
+                    r = voroc::voronoi_face(slow, f, nc, nrm, off, dist, 6, big);
+                    in_slow = true;
+                }
+                if (!r.overflow && r.area > voroc::AREA_TOL * dist[f] * dist[f]) {
+                    vol += r.area * dist[f] / 3.0;
+                    ++nf;
+                    mr2 = fmax(mr2, r.maxr2);
+                    farea[f] = r.area;
+                    asum += r.area;
+                    have = true;
+                }
+            }
         }
-        if (!r.overflow && r.area > voroc::AREA_TOL * dist[f] * dist[f]) {
-            vol += r.area * dist[f] / 3.0;
-            ++nf;
-            mr2 = fmax(mr2, r.maxr2);
-            farea[f] = r.area;
-            asum += r.area;
+        if (co.nv && i < n_orig) { // polygon of every face, walls included, in constraint order (walls, then nearest first)
+            const unsigned long long m = __ballot(have);
+            if (have) {
+                const int slot = co_base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < co.W) {
+                    const int64_t o = i * (int64_t)co.W + slot;
+                    co.nv[o] = r.nv;
+                    co.area[o] = r.area;
+                    if (r.nv > co.V) atomicMax(co.need_v, r.nv);
+                    for (int c = 0; c < r.nv && c < co.V; ++c)
+                        for (int d = 0; d < 3; ++d)
+                            co.vert[(o * co.V + c) * 3 + d] = in_slow ? slow.get(c, d) : fast.get(c, d);
+                }
+            }
+            co_base += __popcll(m);
         }
     }
+    if (co.nv && i < n_orig) // slots past the last face (also those of an earlier attempt with a smaller search radius)
+        for (int slot = co_base + lane; slot < co.W; slot += VORO_LANES) {
+            co.nv[i * (int64_t)co.W + slot] = 0;
+            co.area[i * (int64_t)co.W + slot] = 0.0;
+        }
     // wave reduction (fixed butterfly order: deterministic)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -215,7 +254,7 @@ __global__ void k_replicate(const double *__restrict__ x, const double *__restri
 static int voronoi_solve(void *stream, const double *dx, const double *dy, const double *dz, int64_t N, const double *box9,
                          const double *origin3, const int *boundary3, double *dvol, int *dnf, double *drad, int *dnn, int *dflag,
                          bool *too_small, int *row_id, double *row_dist, double *row_area, int W, double a_thr, double r_thr,
-                         int64_t n_orig, int *dmaxf, const double *box9_orig, const unsigned char *dropped)
+                         int64_t n_orig, int *dmaxf, const double *box9_orig, const unsigned char *dropped, const CellOut &co)
 {
     *too_small = false;
     DBox b, b0;
@@ -248,9 +287,9 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         {
             ProfRange pr("k_voronoi", st);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -275,7 +314,8 @@ using namespace mdh;
 // receives the largest face count (walls included) of the N atoms
 static int voronoi_driver(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
                           const int *boundary3, double *volume, int *nfaces, double *radius, int *row_id, double *row_dist,
-                          double *row_area, int W, double a_thr, double r_thr, int *max_faces_host, int space, void *stream)
+                          double *row_area, int W, double a_thr, double r_thr, int *max_faces_host, int space, void *stream,
+                          const CellOut &co = CellOut())
 {
     if (N < 0 || N >= 2147483647LL) { set_error("mdh_voronoi_volume_number_radius: invalid N"); return MDH_ERR_ARG; }
     DBox b;
@@ -338,7 +378,7 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
             return work.error();
         bool too_small = false;
         MDH_TRY(voronoi_solve(stream, px, py, pz, total, big9, origin3, boundary3, wv, wn, wr, dnn, dflag, &too_small, drid, drd, dra, W, a_thr,
-                              r_thr, N, dflag + 1, box9, ddrop));
+                              r_thr, N, dflag + 1, box9, ddrop, co));
         if (!too_small) {
             if (total != N) {
                 MDH_HIP(hipMemcpyAsync(dvol, wv, sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
@@ -422,6 +462,50 @@ extern "C" int mdh_voronoi_neighbor(const double *x, const double *y, const doub
     }
     return voronoi_driver(x, y, z, N, box9, origin3, boundary3, v, nf, r, verlet, distance, face_area, width, a_face_area_threshold,
                           r_face_area_threshold, nullptr, MDH_DEVICE, stream);
+}
+
+// replaces the geometry of _voronoi.get_cell_info (src/voronoi.cpp:449-540): for every cell its faces (walls of open axes
+// included) as polygons.  face_nv (N, W): vertices of face slot s (0: no face), face_area (N, W), face_vert (N, W, V, 3):
+// polygon vertices RELATIVE TO THE ATOM in polygon order; W >= the width reported by mdh_voronoi_neighbor_count.
+// *need_v_host > V on return: some polygon has more vertices than V (call again with that V); volume / radius as in
+// mdh_voronoi_volume_number_radius.  Faces are listed walls first, then nearest neighbour first (voro++ lists them in the
+// order of its internal vertex graph); every face is clipped on its own, so a vertex shared by three faces appears in
+// each of them with coordinates equal to rounding.  Host (numpy) outputs only: this is a small-system call.
+extern "C" int mdh_voronoi_cell_info(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                     const double *origin3, const int *boundary3, int W, int V, int *nfaces, int *face_nv,
+                                     double *face_area, double *face_vert, double *volume, double *radius, int *need_v_host,
+                                     int space, void *stream)
+{
+    if (N < 0 || W <= 0 || V < 3 || !need_v_host) { set_error("mdh_voronoi_cell_info: invalid shape"); return MDH_ERR_ARG; }
+    *need_v_host = 0;
+    if (N == 0)
+        return MDH_OK;
+    if ((double)N * W * V * 24.0 > 4.0e9) {
+        set_error("mdh_voronoi_cell_info: the polygon table would exceed 4 GB (this call is meant for small systems)");
+        return MDH_ERR_ARG;
+    }
+    Scope sc(stream);
+    CellOut co;
+    co.W = W; co.V = V;
+    co.nv = sc.stage(face_nv, (size_t)N * W, space, false, true);
+    co.area = sc.stage(face_area, (size_t)N * W, space, false, true);
+    co.vert = sc.stage(face_vert, (size_t)N * W * V * 3, space, false, true);
+    co.need_v = sc.alloc_n<int>(1);
+    double *v = sc.stage(volume, (size_t)N, space, false, true), *r = sc.stage(radius, (size_t)N, space, false, true);
+    int *nf = sc.stage(nfaces, (size_t)N, space, false, true);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    MDH_HIP(hipMemsetAsync(co.nv, 0, sizeof(int) * (size_t)N * W, st));
+    MDH_HIP(hipMemsetAsync(co.area, 0, sizeof(double) * (size_t)N * W, st));
+    MDH_HIP(hipMemsetAsync(co.vert, 0, sizeof(double) * (size_t)N * W * V * 3, st));
+    MDH_HIP(hipMemsetAsync(co.need_v, 0, sizeof(int), st));
+    MDH_TRY(voronoi_driver(dx, dy, dz, N, box9, origin3, boundary3, v, nf, r, nullptr, nullptr, nullptr, 0, -1.0, -1.0, nullptr,
+                           MDH_DEVICE, stream, co));
+    MDH_HIP(hipMemcpyAsync(need_v_host, co.need_v, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDH_HIP(hipStreamSynchronize(st));
+    return sc.finish(space);
 }
 
 // distance column of neighbour rows recomputed as the reference does it: sqrt of box.pbc(x[j] - x[i]) with the box and the

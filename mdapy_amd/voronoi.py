@@ -1,5 +1,5 @@
 """Voronoi cell volume / face count / cavity radius.  Mirrors ``mdapy.voronoi.Voronoi.get_volume``
-and ``get_neighbor`` (src/mdapy/voronoi.py:20-215).  ``get_cell_info`` (vertex lists for rendering) is not built."""
+``get_neighbor`` and ``get_cell_info`` (src/mdapy/voronoi.py:20-330) and the ``Cell`` / ``Container`` views (:331-440)."""
 from __future__ import annotations
 
 import numpy as np
@@ -72,3 +72,49 @@ class Voronoi:
             _voronoi.get_voronoi_volume_number_radius(x, y, z, self.box.box, self.box.origin, self.box.boundary, volume,
                                                       neighbor_number, cavity_radius, get_num_threads())
         return volume, neighbor_number, cavity_radius
+
+    def get_cell_info(self):
+        """-> face_vertices_indices, face_vertices_positions, volume, radius, face_areas (voronoi.py:184-246)"""
+        assert not self.box.triclinic, "Only support orthogonal box."
+        assert self.data.shape[0] > 1, "At least has one atom."
+        x, y, z = (np.ascontiguousarray(as_numpy(a), dtype=np.float64) for a in tool.xyz(self.data))
+        return _voronoi.get_cell_info(x, y, z, self.box.box, self.box.origin, self.box.boundary, get_num_threads())
+
+
+class Cell:
+    """One Voronoi cell (voronoi.py:331-369): faces as index lists into ``vertices``, volume, cavity radius, face areas,
+    position of the atom."""
+
+    def __init__(self, face_vertices, vertices, volume, cavity_radius, face_areas, pos):
+        self.face_vertices = face_vertices
+        self.vertices = vertices
+        self.volume = volume
+        self.cavity_radius = cavity_radius
+        self.face_areas = face_areas
+        self.pos = pos
+
+    def __repr__(self):
+        return f"Cell(faces={len(self.face_vertices)}, vertices={len(self.vertices)}, volume={self.volume:.6g})"
+
+
+class Container:
+    """The cells of every atom, list-like (voronoi.py:372-440)."""
+
+    def __init__(self, data, box: Box):
+        if isinstance(data, np.ndarray):
+            assert data.ndim == 2 and data.shape[1] == 3
+            data = Frame({"x": data[:, 0], "y": data[:, 1], "z": data[:, 2]})
+        fvi, fvp, volume, radius, face_areas = Voronoi(box, data).get_cell_info()
+        x, y, z = (as_numpy(a) for a in tool.xyz(data))
+        self._data = [Cell(fvi[i], np.array(fvp[i], np.float64).reshape(-1, 3), volume[i], radius[i], np.array(face_areas[i], np.float64),
+                           np.array([x[i], y[i], z[i]], np.float64)) for i in range(data.shape[0])]
+
+    def __getitem__(self, index: int):
+        return self._data[index]
+
+    def __len__(self):
+        return len(self._data)
+
+    def __iter__(self):
+        return iter(self._data)
+

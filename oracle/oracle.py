@@ -465,6 +465,38 @@ def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, 
     return verlet, dist, face, cnt.astype(np.int32)
 
 
+def get_cell_info(x, y, z, box, origin, boundary, num_t=1):
+    """mdapy._voronoi.get_cell_info (src/voronoi.cpp:449-540) through the reference's own voro++"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    b, o, p = _boxargs(box, origin, boundary)
+    n = len(x)
+    nf, nv = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    vol, rad = np.zeros(n), np.zeros(n)
+    nfv, nvert = C.c_int64(0), C.c_int64(0)
+    f = voro_lib().ref_voronoi_cell_info
+    args = (_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), i64(n), _p(b, np.float64), _p(o, np.float64), _p(p, np.int32),
+            _p(nf, np.int32), _p(nv, np.int32), C.byref(nfv), C.byref(nvert))
+    nface = f(*args, None, None, None, None, _p(vol, np.float64), _p(rad, np.float64))
+    fs, fid = np.zeros(max(nface, 1), np.int32), np.zeros(max(nfv.value, 1), np.int32)
+    vert, fa = np.zeros((max(nvert.value, 1), 3)), np.zeros(max(nface, 1))
+    f(*args, _p(fs, np.int32), _p(fid, np.int32), _p(vert, np.float64), _p(fa, np.float64), _p(vol, np.float64), _p(rad, np.float64))
+    face_idx, face_pos, areas = [], [], []
+    kf = kid = kv = 0
+    for i in range(n):
+        faces, ar = [], []
+        for _ in range(int(nf[i])):
+            m = int(fs[kf])
+            faces.append(fid[kid:kid + m].tolist())
+            ar.append(float(fa[kf]))
+            kid += m
+            kf += 1
+        face_idx.append(faces)
+        areas.append(ar)
+        face_pos.append(vert[kv:kv + int(nv[i])].tolist())
+        kv += int(nv[i])
+    return face_idx, face_pos, vol.tolist(), rad.tolist(), areas
+
+
 def get_voronoi_neighbor_tri(x, y, z, box, origin, boundary, rotation, need_rotation, a_face_area_threshold,
                              r_face_area_threshold, num_t=1):
     """mdapy._voronoi.get_voronoi_neighbor_tri (src/voronoi.cpp:149-305): faces from the triclinic container of the ROTATED

@@ -142,4 +142,59 @@ __attribute__((visibility("default"))) int ref_voronoi_faces_tri(const double *x
             }
     return mx;
 }
+// get_cell_info (src/voronoi.cpp:449-540) flattened: per cell the number of faces and vertices, then CSR-like tables.
+// Call once with the tables NULL to get the sizes (total face-vertex entries in *n_fv, total vertices in *n_vert).
+__attribute__((visibility("default"))) int ref_voronoi_cell_info(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                                                 const double *origin, const int *boundary, int *nfaces, int *nverts,
+                                                                 int64_t *n_fv, int64_t *n_vert, int *face_sizes, int *face_vertex_ids,
+                                                                 double *vertices, double *face_area, double *volume, double *radius)
+{
+    const double bx = box9[0], by = box9[4], bz = box9[8];
+    const double vol = bx * by * bz, init_mem = 4.6;
+    const double ilscale = std::pow(N / (init_mem * vol), 1 / 3.0);
+    const int nx = int(bx * ilscale + 1), ny = int(by * ilscale + 1), nz = int(bz * ilscale + 1);
+    voro::container_3d con(0., bx, 0., by, 0., bz, nx, ny, nz, bool(boundary[0]), bool(boundary[1]), bool(boundary[2]), init_mem, 1);
+    for (int64_t i = 0; i < N; ++i) con.put((int)i, x[i] - origin[0], y[i] - origin[1], z[i] - origin[2]);
+    voro::voronoicell_neighbor_3d cell(con);
+    // per-atom results first (cells come in container order), then flattened in atom order
+    std::vector<std::vector<int>> fv(N);
+    std::vector<std::vector<double>> vx(N), fa(N);
+    for (int64_t i = 0; i < N; ++i) { nfaces[i] = 0; nverts[i] = 0; volume[i] = 0; radius[i] = 0; }
+    for (int ijk = 0; ijk < con.nx * con.ny * con.nz; ++ijk)
+        for (int q = 0; q < con.co[ijk]; ++q)
+            if (con.compute_cell(cell, ijk, q)) {
+                const int i = con.id[ijk][q];
+                volume[i] = cell.volume();
+                radius[i] = std::sqrt(cell.max_radius_squared());
+                cell.face_vertices(fv[i]);
+                double *pp = con.p[ijk] + con.ps * q;
+                cell.vertices(pp[0], pp[1], pp[2], vx[i]);
+                cell.face_areas(fa[i]);
+                nfaces[i] = (int)fa[i].size();
+                nverts[i] = cell.p;
+            }
+    int64_t tf = 0, tv = 0, tface = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        size_t j = 0;
+        int f = 0;
+        while (j < fv[i].size()) {
+            const int m = fv[i][j];
+            if (face_sizes) face_sizes[tface] = m;
+            for (int k = 0; k < m; ++k) {
+                if (face_vertex_ids) face_vertex_ids[tf] = fv[i][j + 1 + k];
+                ++tf;
+            }
+            if (face_area) face_area[tface] = fa[i][f];
+            ++tface; ++f;
+            j += m + 1;
+        }
+        for (int k = 0; k < nverts[i] * 3; ++k) {
+            if (vertices) vertices[tv * 3 + k] = vx[i][k];
+        }
+        tv += nverts[i];
+    }
+    *n_fv = tf;
+    *n_vert = tv;
+    return (int)tface;
+}
 }

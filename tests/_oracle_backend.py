@@ -97,6 +97,7 @@ voronoi = _mod(
         O.get_voronoi_volume_number_radius_tri(_np(x), _np(y), _np(z), box, origin, boundary, rot, v, n, r, need, NT),
     get_voronoi_neighbor=lambda x, y, z, box, origin, boundary, a, r, num_t=1:
         O.get_voronoi_neighbor(_np(x), _np(y), _np(z), box, origin, boundary, a, r, NT),
+    get_cell_info=lambda x, y, z, box, origin, boundary, num_t=1: O.get_cell_info(_np(x), _np(y), _np(z), box, origin, boundary, NT),
     get_voronoi_neighbor_tri=lambda x, y, z, box, origin, boundary, rot, need, a, r, num_t=1:
         O.get_voronoi_neighbor_tri(_np(x), _np(y), _np(z), box, origin, boundary, rot, need, a, r, NT),
 )

@@ -990,3 +990,40 @@ def test_create_polycrystal_hip_equals_oracle_build(monkeypatch):
         mp.CreatePolycrystal(unit, box=70.0, seed_number=4, add_graphene=True)
     with pytest.raises(ValueError, match="Triclinic"):
         mp.CreatePolycrystal(unit, box=np.array([[70.0, 0, 0], [5.0, 70.0, 0], [0, 0, 70.0]]), seed_number=4)
+
+
+@needs_voro
+@pytest.mark.parametrize("case", ["fcc_rattled", "random_gas", "slab_open_z", "thin_box_3cells"])
+def test_voronoi_cell_info_vs_reference_library(case):
+    """get_cell_info (src/voronoi.cpp:449-540): the same polyhedra as voro++ builds — faces, vertices, areas, volume — up to the
+    order in which faces and vertices are listed (internal to either construction)"""
+    name, pos, box, origin, bd = next(c for c in _cases() if c[0] == case)
+    pos = pos[:400].copy() if case == "random_gas" else pos[:1200].copy()
+    if case == "fcc_rattled":  # a sub-block of the crystal in an open box: walls and bulk cells
+        bd = np.array([0, 0, 0], np.int32)
+        pos = pos[(pos < 14.0).all(1)]
+        box = np.eye(3) * 14.5
+    if case == "slab_open_z":
+        pos[:, 2] = np.clip(pos[:, 2], 1e-3, box[2, 2] - 1e-3)
+    x, y, z = _xyz(pos)
+    fi0, fp0, v0, r0, a0 = O.get_cell_info(x, y, z, box, origin, bd)
+    fi1, fp1, v1, r1, a1 = _voronoi.get_cell_info(x, y, z, box, origin, bd, 1)
+    assert np.allclose(v1, v0, rtol=1e-9, atol=1e-9) and np.allclose(r1, r0, rtol=1e-9, atol=1e-9)
+    scale = float(np.max(r0))
+    for i in range(len(pos)):
+        assert len(fi1[i]) == len(fi0[i]) and len(fp1[i]) == len(fp0[i]), i
+        if not len(fp0[i]):  # not in the reference's container (outside on an open axis): no cell on either side
+            continue
+        assert sorted(len(f) for f in fi1[i]) == sorted(len(f) for f in fi0[i])
+        assert np.allclose(np.sort(a1[i]), np.sort(a0[i]), rtol=1e-7, atol=1e-9 * scale ** 2)
+        p0, p1 = np.array(fp0[i]), np.array(fp1[i])
+        k0, k1 = np.lexsort(np.round(p0, 6).T), np.lexsort(np.round(p1, 6).T)
+        assert np.allclose(p1[k1], p0[k0], rtol=0, atol=1e-7 * scale)
+        n_edges = sum(len(f) for f in fi1[i]) // 2
+        assert len(fp1[i]) - n_edges + len(fi1[i]) == 2  # Euler: the merged faces close up into one polyhedron
+        for f, ar in zip(fi1[i], a1[i]):  # the index lists really are the polygons: area of the fan equals the reported area
+            q = p1[f]
+            cr = np.cross(q[1:-1] - q[0], q[2:] - q[0]).sum(0)
+            assert abs(0.5 * np.linalg.norm(cr) - ar) <= 1e-9 * scale ** 2 + 1e-9 * ar
+    con = mp.voronoi.Container(np.ascontiguousarray(pos - origin), mp.Box(box, boundary=bd))
+    assert len(con) == len(pos) and abs(con[3].volume - v0[3]) < 1e-9 * v0[3] and con[3].vertices.shape == (len(fp0[3]), 3)
