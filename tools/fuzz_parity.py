@@ -93,10 +93,13 @@ def checks(s):
         if T.O.have_voro_ref() and ortho and s["kind"] != "blob" and all(s["bnd"]):
             out += [("voronoi", lambda: T.test_voronoi_vs_reference_library("fuzz")),
                     ("voronoi_nb", lambda: T.test_voronoi_neighbors_vs_reference_library("fuzz"))]
+        if T.O.have_voro_ref() and ortho and s["kind"] == "gas":  # (a 400-atom corner of a crystal in its full periodic box is the
+            # cluster-in-vacuum case the Voronoi driver refuses)
+            out += [("cell_info", lambda: T.test_voronoi_cell_info_vs_reference_library("random_gas"))]
     return out
 
 
-NAMES = ["fuzz"]
+NAMES = ["fuzz", "random_gas"]  # "random_gas": the name under which the cell-info check takes a 400-atom subset
 
 
 def main():
