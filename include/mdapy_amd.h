@@ -85,6 +85,19 @@ int mdh_debug_image_thresholds(double L, double *out4);
 int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                        const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                        int64_t max_neigh, int fill_pads, int space, void *stream);
+/* The same with an ordering key (multi-GPU extension): inside a cell the atoms are listed by descending key[i]
+ * (i64, N) instead of descending index — the reference's rule (neighbor.cpp:97-98) applied to the GLOBAL atom ids of a
+ * slab's owned + ghost atoms, so that every row equals the row of the undivided system.  key == NULL: mdh_build_neighbor. */
+int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                             const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
+                             int64_t max_neigh, int fill_pads, const int64_t *key, int space, void *stream);
+
+/* Halo selection of the slab decomposition (multi-GPU extension): one pass over the owned atoms; up / down (n) i32
+ * receive the indices of the atoms whose wrapped fractional coordinate f along the decomposed axis (hi3 = that column of the
+ * inverse box) satisfies f >= up_from / f < down_below, counts_host[2] their numbers.  Order of the indices: unspecified. */
+int mdh_slab_halo_select(const double *x, const double *y, const double *z, int64_t n, const double *origin3_host,
+                         const double *hi3_host, double up_from, double down_below, int *up, int *down, int64_t *counts_host,
+                         int space, void *stream);
 
 /*
  * first half of _neighbor.build_neighbor_without_max_neigh  src/neighbor.cpp:189-349:

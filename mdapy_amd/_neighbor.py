@@ -12,17 +12,18 @@ f64, i32 = np.float64, np.int32
 
 
 def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_list, neighbor_number, num_t=1,
-                   fill_pads=False):
-    """src/neighbor.cpp:351.  ``fill_pads`` (extension): let the kernel write the -1 / rc+1 pads so the
-    caller may pass uninitialised buffers."""
+                   fill_pads=False, key=None):
+    """src/neighbor.cpp:351.  Extensions: ``fill_pads`` lets the kernel write the -1 / rc+1 pads so the caller may pass
+    uninitialised buffers; ``key`` (i64, N) orders the atoms of a cell by descending key instead of descending index (the
+    global ids of a slab's owned + ghost atoms: rows then equal those of the undivided system)."""
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
-    c = Call(x, y, z, verlet_list, distance_list, neighbor_number)
+    c = Call(x, y, z, verlet_list, distance_list, neighbor_number, key)
     N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
-    rc_ = _lib.lib().mdh_build_neighbor(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
-                                        c.out(verlet_list, i32, upload=not fill_pads),
-                                        c.out(distance_list, f64, upload=not fill_pads),
-                                        c.out(neighbor_number, i32, upload=False), M, int(bool(fill_pads)), c.space,
-                                        c.stream)
+    rc_ = _lib.lib().mdh_build_neighbor_keyed(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
+                                              c.out(verlet_list, i32, upload=not fill_pads),
+                                              c.out(distance_list, f64, upload=not fill_pads),
+                                              c.out(neighbor_number, i32, upload=False), M, int(bool(fill_pads)),
+                                              c.inp(key, np.int64), c.space, c.stream)
     c.done(rc_)
 
 

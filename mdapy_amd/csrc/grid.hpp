@@ -42,7 +42,9 @@ struct TileFilter {
     int tile = 1, tile_z = 1;
     int nt[3] = {1, 1, 1};
 };
-TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M);
+// occupied_cells: cells that hold atoms (occupied_cells_hint); 0 = assume all of them
+TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t occupied_cells);
+int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occupied);
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
                           int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, TileFilter &tf);
 
@@ -99,7 +101,7 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g);
 //   sort_desc  : order every cell's atoms by descending id (reference row order); otherwise the
 //                order inside a cell is whatever the atomic counters produced
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
-                    bool wrap_first, bool sort_desc, CellGrid &cg);
+                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key = nullptr);
 
 // neighbor.hip: out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
 int exclusive_scan_u32(Scope &sc, const unsigned *in, int *out, int64_t n);

@@ -179,8 +179,10 @@ __global__ __launch_bounds__(256) void k_scatter(const int *__restrict__ cell_id
 // atoms into DESCENDING id order (what a walk of the reference's linked list
 // sees, neighbor.cpp:97-98) so that rows come out in reference order and the
 // result is deterministic.  One thread per cell; cells hold a handful of atoms.
+// key != nullptr: descending key[id] instead of descending id (a decomposed system: key = global atom id, so that the rows of
+// a slab come out in the order the whole system's rows have)
 __global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell_start, int *__restrict__ order,
-                                                    int64_t ncell)
+                                                    int64_t ncell, const int64_t *__restrict__ key)
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell)
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell
     const int s = cell_start[c], e = cell_start[c + 1];
     for (int a = s + 1; a < e; ++a) {
         int v = order[a], q = a - 1;
-        while (q >= s && order[q] < v) {
+        const int64_t kv = key ? key[v] : (int64_t)v;
+        while (q >= s && (key ? key[order[q]] : (int64_t)order[q]) < kv) {
             order[q + 1] = order[q];
             --q;
         }
@@ -233,7 +236,7 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
 }
 
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
-                    bool wrap_first, bool sort_desc, CellGrid &cg)
+                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key)
 {
     const Grid &g = cg.g;
     hipStream_t st = sc.stream();
@@ -267,7 +270,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc)
-        hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell);
+        hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, sort_key);
     hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
@@ -483,6 +486,15 @@ int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_
                        const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                        int64_t max_neigh, int fill_pads, int space, void *stream)
 {
+    return mdh_build_neighbor_keyed(x, y, z, N, box9, origin3, boundary3, rc, verlet, dist, nn, max_neigh, fill_pads, nullptr,
+                                    space, stream);
+}
+
+// key (N) i64, or NULL: the atoms of a cell are listed by descending key instead of descending index
+int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                             const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
+                             int64_t max_neigh, int fill_pads, const int64_t *key, int space, void *stream)
+{
     if (N < 0 || N >= 2147483647LL || !(rc > 0) || max_neigh <= 0) { set_error("mdh_build_neighbor: invalid N, rc or max_neigh"); return MDH_ERR_ARG; }
     DBox b;
     MDH_TRY(make_box(b, box9, origin3, boundary3));
@@ -494,17 +506,21 @@ int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_
     int *dv = sc.stage(verlet, (size_t)(N * max_neigh), space, !fill_pads, true);
     double *dd = sc.stage(dist, (size_t)(N * max_neigh), space, !fill_pads, true);
     int *dn = sc.stage(nn, (size_t)N, space, false, true);
+    const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
     if (sc.failed())
         return sc.error();
     CellGrid cg;
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", sc.stream());
-        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey));
     }
     {
         ProfRange pr("k_neighbor", sc.stream());
-        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, 0, false} : plan_tiled(b, cg.g, N, max_neigh);
+        int64_t occ = 0;
+        if (g_neighbor_variant != 1 && !b.tri)
+            MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
+        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, 0, false} : plan_tiled(b, cg.g, N, max_neigh, occ);
         TileFilter tf{};
         if (plan.tile) // LDS-tiled kernel; the thread-per-atom kernel below then only mops up what it left
             MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));

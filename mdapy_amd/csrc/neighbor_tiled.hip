@@ -32,6 +32,9 @@
 // same pass writes the -1 / rc+1 pads.
 #include "common.hpp"
 #include "grid.hpp"
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace mdh {
 
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int mp_shift,
     int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved,
-    TileShape ts)
+    TileShape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live)
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ, NCOL = TXY * TXY;
@@ -194,13 +197,15 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     __shared__ int c_off[MAX_COLS + 1];
     __shared__ int scan_tmp[4];
 
-    // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of tiles so that
-    // neighbouring tiles (which share halo cells) meet in the same L2.
-    const int ntiles = nt0 * nt1 * nt2;
-    const int per = (ntiles + 7) / 8;
-    const int tile_id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile_id >= ntiles)
+    // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of the tiles THAT HOLD CENTRE ATOMS
+    // (tile_list, in tile order) so that neighbouring tiles (which share halo cells) meet in the same L2 and an empty part
+    // of the box (vacuum, the other ranks' slabs of a decomposed system) leaves no XCD idle.
+    const int nlive = *n_live;
+    const int per = (nlive + 7) / 8;
+    const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || slot >= nlive)
         return;
+    const int tile_id = tile_list[slot];
     const int t2 = tile_id % nt2, t1 = (tile_id / nt2) % nt1, t0 = tile_id / (nt2 * nt1);
     const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
     const int tid = threadIdx.x;
@@ -355,6 +360,31 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     }
 }
 
+// tiles with at least one centre atom: flag (one thread per tile), then an order-preserving compaction
+__global__ __launch_bounds__(256) void k_tile_live(const int *__restrict__ cell_start, Grid g, int nt0, int nt1, int nt2, TileShape ts,
+                                                   unsigned *__restrict__ live)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt0 * nt1 * nt2)
+        return;
+    const int t2 = t % nt2, t1 = (t / nt2) % nt1, t0 = t / (nt2 * nt1);
+    const int z0 = t2 * ts.tz, z1 = min(z0 + ts.tz, g.nc[2]);
+    bool any = false;
+    for (int a = t0 * ts.txy; a < min((t0 + 1) * ts.txy, g.nc[0]) && !any; ++a)
+        for (int c = t1 * ts.txy; c < min((t1 + 1) * ts.txy, g.nc[1]) && !any; ++c) {
+            const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+            any = cell_start[col + z1] > cell_start[col + z0]; // the z-run of a column is contiguous
+        }
+    live[t] = any ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_tile_compact(const unsigned *__restrict__ live, const int *__restrict__ slot, int ntiles,
+                                                      int *__restrict__ tile_list)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles && live[t]) tile_list[slot[t]] = t;
+}
+
 static size_t tiled_lds_bytes(int64_t M)
 {
     return (size_t)HALO_CAP * (24 + 4 + 2) + (size_t)NT * (24 + 4 + 4) + (size_t)TICK_STRIDE * (size_t)M * 2;
@@ -381,12 +411,80 @@ static TileShape choose_shape(double pop)
     return best;
 }
 
-TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
+// ---------------------------------------------------------------------------------------------------------------
+// How many cells hold atoms?  The tile shape is sized for the population of the OCCUPIED cells: a box that is mostly empty
+// (vacuum around a slab or a particle, the other ranks' slabs of a decomposed system) would otherwise get tiles whose
+// halo overflows LDS wherever the atoms are.  The count is taken on the device in every call; the host uses the value the
+// previous call with the same (N, grid) left in pinned memory — an MD-style sequence of calls never waits for it — and
+// waits only the first time it sees a new (N, grid).  A stale value costs speed, never correctness (overflowing tiles
+// fall back to the thread-per-atom kernel).
+// counted in blocks of 4 x 4 x 4 cells (a block counts with all its cells as soon as one of them holds an atom): the empty
+// cells that a lattice leaves between its occupied ones belong to the occupied region, vacuum does not
+__global__ __launch_bounds__(256) void k_count_occupied(const int *__restrict__ cell_start, Grid g, int *__restrict__ out)
+{
+    const int nb0 = (g.nc[0] + 3) >> 2, nb1 = (g.nc[1] + 3) >> 2, nb2 = (g.nc[2] + 3) >> 2;
+    const int64_t nblk = (int64_t)nb0 * nb1 * nb2;
+    int mine = 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nblk; q += (int64_t)gridDim.x * blockDim.x) {
+        const int b2 = (int)(q % nb2), b1 = (int)((q / nb2) % nb1), b0 = (int)(q / ((int64_t)nb2 * nb1));
+        const int x1 = min(b0 * 4 + 4, g.nc[0]), y1 = min(b1 * 4 + 4, g.nc[1]), z0 = b2 * 4, z1 = min(z0 + 4, g.nc[2]);
+        bool any = false;
+        for (int a = b0 * 4; a < x1 && !any; ++a)
+            for (int c = b1 * 4; c < y1 && !any; ++c) {
+                const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+                any = cell_start[col + z1] > cell_start[col + z0];
+            }
+        if (any) mine += (x1 - b0 * 4) * (y1 - b1 * 4) * (z1 - z0);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
+namespace {
+struct OccEntry { int64_t N, ncell; int device; int *host; };
+std::mutex g_occ_mu;
+std::vector<OccEntry> g_occ;
+} // namespace
+
+int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occupied)
+{
+    hipStream_t st = sc.stream();
+    int *dcnt = sc.alloc_n<int>(1);
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemsetAsync(dcnt, 0, sizeof(int), st));
+    const int blocks = (int)std::min<int64_t>((cg.g.ncell / 64 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(256), 0, st, cg.cell_start, cg.g, dcnt);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::lock_guard<std::mutex> lk(g_occ_mu);
+    for (auto &e : g_occ)
+        if (e.N == N && e.ncell == cg.g.ncell && e.device == device) {
+            const int last = *(volatile int *)e.host;
+            *occupied = last > 0 ? last : cg.g.ncell;
+            MDH_HIP(hipMemcpyAsync(e.host, dcnt, sizeof(int), hipMemcpyDeviceToHost, st)); // for the next call
+            return MDH_OK;
+        }
+    int *host = nullptr;
+    MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int), hipHostMallocDefault));
+    MDH_HIP(hipMemcpyAsync(host, dcnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDH_HIP(hipStreamSynchronize(st));
+    *occupied = *host > 0 ? *host : cg.g.ncell;
+    if (g_occ.size() >= 64) { // keep the table small: forget the oldest signature
+        (void)hipHostFree(g_occ.front().host);
+        g_occ.erase(g_occ.begin());
+    }
+    g_occ.push_back(OccEntry{N, cg.g.ncell, device, host});
+    return MDH_OK;
+}
+
+TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t occupied_cells)
 {
     TiledPlan p{0, 0, false};
     if (b.tri || g.mode != 0 || N <= 0 || M <= 0)
         return p;
-    const double pop = (double)N / (double)g.ncell; // mean atoms per cell
+    const double pop = (double)N / (double)(occupied_cells > 0 ? occupied_cells : g.ncell); // mean atoms per occupied cell
     const TileShape sh = choose_shape(pop);
     if (!sh.txy)
         return p;
@@ -407,7 +505,8 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M)
 
 template <bool CS>
 static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double rc, int *verlet, double *dist, int *nn,
-                       int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved, TileShape ts)
+                       int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved, TileShape ts,
+                       const int *tile_list, const int *n_live)
 {
     const int ntiles = nt[0] * nt[1] * nt[2];
     const int per = (ntiles + 7) / 8;
@@ -416,9 +515,9 @@ static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
     if (fill_pads)
-        hipLaunchKernelGGL((k_neighbor_tiled<CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
+        hipLaunchKernelGGL((k_neighbor_tiled<CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
     else
-        hipLaunchKernelGGL((k_neighbor_tiled<CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts);
+        hipLaunchKernelGGL((k_neighbor_tiled<CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
 }
 
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
@@ -434,12 +533,20 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
     unsigned char *tile_flag = sc.alloc_n<unsigned char>((size_t)ntiles);
     if (sc.failed())
         return sc.error();
+    unsigned *live = sc.alloc_n<unsigned>((size_t)ntiles);
+    int *slot = sc.alloc_n<int>((size_t)ntiles + 1);
+    int *tile_list = sc.alloc_n<int>((size_t)ntiles);
+    if (sc.failed())
+        return sc.error();
     hipStream_t st = sc.stream();
     MDH_HIP(hipMemsetAsync(tile_flag, 0, (size_t)ntiles, st));
+    hipLaunchKernelGGL(k_tile_live, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, cg.cell_start, cg.g, nt[0], nt[1], nt[2], ts, live);
+    MDH_TRY(exclusive_scan_u32(sc, live, slot, ntiles)); // slot[ntiles] = number of live tiles
+    hipLaunchKernelGGL(k_tile_compact, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, live, slot, (int)ntiles, tile_list);
     // Two launches, one of which returns at once on the device flag: image numbers from the cell / atom codes when
     // the binning pass found them valid (and the grid allows it), the exact threshold search otherwise.
-    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts);
-    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts);
+    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts, tile_list, slot + ntiles);
+    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts, tile_list, slot + ntiles);
     MDH_HIP(hipGetLastError());
     tf.flag = tile_flag;
     tf.any = cg.flags + 2;

@@ -271,8 +271,8 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         int maxc = 0;
         MDH_TRY(mdh_neighbor_count(dx, dy, dz, N, box9, origin3, boundary3, rc, dnn, &maxc, MDH_DEVICE, stream));
         const int64_t M = maxc > 0 ? maxc : 1;
-        if ((double)N * (double)M > 2.0e9) {
-            set_error("mdh_voronoi_volume_number_radius: the search list would exceed 2e9 entries (extremely inhomogeneous system)");
+        if ((double)N * (double)M > 4.0e8) { // 4.8 GB of rows: a homogeneous system needs ~60 entries per atom
+            set_error("mdh_voronoi_volume_number_radius: the search list would exceed 4e8 entries (extremely inhomogeneous system, e.g. a cluster in a periodic vacuum)");
             return MDH_ERR_ARG;
         }
         Scope inner(stream);
@@ -349,9 +349,9 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
     // Cells wider than half a period cannot be described by minimum-image rows: the periodic axes that are too thin are
     // replicated (x3 per round, the original atoms first) and the cells of the original atoms are taken from the copy.
     int rep[3] = {1, 1, 1};
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < 3; ++round) {
         const int64_t total = N * rep[0] * rep[1] * rep[2];
-        if (total >= 2147483647LL / 4) {
+        if (total >= 50000000LL) {
             set_error("mdh_voronoi_volume_number_radius: the replicated system would be too large");
             return MDH_ERR_ARG;
         }

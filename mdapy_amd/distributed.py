@@ -60,6 +60,25 @@ class SlabDecomposition:
         f = f - t.floor(f)
         return t.where(f >= 1.0, f - 1.0, f)
 
+    def _select_device(self, x, y, z, up_from: float, down_below: float):
+        import ctypes
+
+        from . import _lib
+
+        t = _torch()
+        x, y, z = x.contiguous(), y.contiguous(), z.contiguous()
+        assert x.dtype == t.float64 and y.dtype == t.float64 and z.dtype == t.float64
+        n = int(x.shape[0])
+        up = t.empty(n, dtype=t.int32, device=x.device)
+        down = t.empty(n, dtype=t.int32, device=x.device)
+        o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
+        hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
+        cnt = (ctypes.c_int64 * 2)(0, 0)
+        _lib.check(_lib.lib().mdh_slab_halo_select(x.data_ptr(), y.data_ptr(), z.data_ptr(), n, o.ctypes.data, hi3.ctypes.data,
+                                                   float(up_from), float(down_below), up.data_ptr(), down.data_ptr(), cnt,
+                                                   _lib.DEVICE, int(t.cuda.current_stream().cuda_stream)))
+        return up[: int(cnt[0])].to(t.int64), down[: int(cnt[1])].to(t.int64)
+
     def owner_of(self, x, y, z):
         t = _torch()
         return t.clamp((self.frac(x, y, z) * self.world).to(t.int64), 0, self.world - 1)
@@ -72,8 +91,12 @@ class SlabDecomposition:
         return h
 
     # -- halo exchange --------------------------------------------------------
-    def exchange_halo(self, x, y, z, gid, halo: float) -> LocalDomain:
-        """x,y,z (f64) and gid (i64) of the OWNED atoms (1-D tensors on this rank's device)."""
+    def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True) -> LocalDomain:
+        """x,y,z (f64) and gid (i64) of the OWNED atoms (1-D tensors on this rank's device).
+
+        sort=True: the local order is ascending global id (what index-ordered kernels need to reproduce the undivided
+        system's rows).  sort=False: owned atoms first, in the caller's order, then the ghosts — for kernels that take the
+        ids as an ordering key (``build_neighbor(..., key=dom.gid)``); no pass over the owned atoms beyond the copy."""
         t = _torch()
         import torch.distributed as dist
 
@@ -84,10 +107,13 @@ class SlabDecomposition:
                 x, y, z, gid = x[order], y[order], z[order], gid[order]
             return LocalDomain(x, y, z, gid, t.ones(n_owned, dtype=t.bool, device=x.device), n_owned)
         h = self.halo_fraction(halo)
-        f = self.frac(x, y, z)
         lo, hi = self.rank / self.world, (self.rank + 1) / self.world
-        up = (f >= hi - h).nonzero().flatten()    # goes to the right neighbour
-        down = (f < lo + h).nonzero().flatten()   # goes to the left neighbour
+        if x.is_cuda:  # one fused pass (slab.hip); the torch expressions below are its definition
+            up, down = self._select_device(x, y, z, hi - h, lo + h)
+        else:
+            f = self.frac(x, y, z)
+            up = (f >= hi - h).nonzero().flatten()    # goes to the right neighbour
+            down = (f < lo + h).nonzero().flatten()   # goes to the left neighbour
 
         def pack(sel):
             return t.stack([x[sel], y[sel], z[sel], gid[sel].to(t.float64)], dim=0).contiguous()  # ids < 2^53: exact
@@ -108,13 +134,40 @@ class SlabDecomposition:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         ghosts = t.cat([recv_l, recv_r], dim=1)
-        ggid = ghosts[3].to(t.int64)
-        if self.world == 2:  # the same atom can arrive through both faces of the single neighbour
-            ggid, first = _unique_first(ggid)
-            ghosts = ghosts[:, first]
+        dev = x.device
+        if not sort and self.world > 2:  # two different neighbours: every ghost arrives once, any order will do
+            ggid = ghosts[3].to(t.int64)
+            n_tot = n_owned + int(ggid.shape[0])
+            own = t.arange(n_tot, device=dev) < n_owned
+            return LocalDomain(t.cat([x, ghosts[0]]), t.cat([y, ghosts[1]]), t.cat([z, ghosts[2]]), t.cat([gid, ggid]), own, n_owned)
+        # ghosts in ascending id order, each once (world == 2: the same atom can arrive through both faces of the one neighbour)
+        ggid, first = _unique_first(ghosts[3].to(t.int64))
+        ghosts = ghosts[:, first]
+        n_ghost = int(ggid.shape[0])
+        n_tot = n_owned + n_ghost
+        if not sort:
+            own = t.arange(n_tot, device=dev) < n_owned
+            return LocalDomain(t.cat([x, ghosts[0]]), t.cat([y, ghosts[1]]), t.cat([z, ghosts[2]]), t.cat([gid, ggid]), own, n_owned)
+        if n_owned < 2 or bool((gid[1:] > gid[:-1]).all()):
+            # Local order = ascending global id (it fixes the order inside the reference's rows).  The owned ids are already
+            # ascending, the few ghosts are sorted: MERGE the two runs (two binary searches, three scatters per array) instead
+            # of sorting all of them every step.
+            gslot = t.searchsorted(gid, ggid) + t.arange(n_ghost, dtype=t.int64, device=dev)
+            oslot = t.searchsorted(ggid, gid) + t.arange(n_owned, dtype=t.int64, device=dev)
+
+            def merge(a_owned, a_ghost, dtype):
+                out = t.empty(n_tot, dtype=dtype, device=dev)
+                out[oslot] = a_owned
+                out[gslot] = a_ghost
+                return out
+
+            own = t.zeros(n_tot, dtype=t.bool, device=dev)
+            own[oslot] = True
+            return LocalDomain(merge(x, ghosts[0], t.float64), merge(y, ghosts[1], t.float64), merge(z, ghosts[2], t.float64),
+                               merge(gid, ggid, t.int64), own, n_owned)
         ax = t.cat([x, ghosts[0]]); ay = t.cat([y, ghosts[1]]); az = t.cat([z, ghosts[2]])
         ag = t.cat([gid, ggid])
-        own = t.cat([t.ones(n_owned, dtype=t.bool, device=x.device), t.zeros(ggid.shape[0], dtype=t.bool, device=x.device)])
+        own = t.cat([t.ones(n_owned, dtype=t.bool, device=dev), t.zeros(n_ghost, dtype=t.bool, device=dev)])
         order = t.argsort(ag)
         return LocalDomain(ax[order].contiguous(), ay[order].contiguous(), az[order].contiguous(), ag[order].contiguous(),
                            own[order].contiguous(), n_owned)
@@ -145,14 +198,15 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     indices; ``dom.gid[verlet]`` maps them to global ids.
     """
     t = _torch()
-    dom = dec.exchange_halo(x, y, z, gid, rc)
+    dom = dec.exchange_halo(x, y, z, gid, rc, sort=False)
     n = int(dom.x.shape[0])
     b = dec.box
     verlet = t.empty((n, max_neigh), dtype=t.int32, device=dom.x.device)
     dist = t.empty((n, max_neigh), dtype=t.float64, device=dom.x.device)
     nn = t.empty((n,), dtype=t.int32, device=dom.x.device)
     pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
-    _neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True)
+    _neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
+                             key=dom.gid if dec.world > 1 else None)
     _cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
     return dom, verlet, dist, nn, pattern
 

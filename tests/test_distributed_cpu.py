@@ -35,11 +35,20 @@ def _worker(rank, world, port, q):
         from oracle import oracle as O
 
         # oracle adapters for the two shim functions the distributed step calls (torch CPU tensors in / out)
-        def build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_pads=False):
+        def build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_pads=False, key=None):
             vn, dn, nnn = v.numpy(), d.numpy(), nn.numpy()
             if fill_pads:
                 vn.fill(-1); dn.fill(rc + 1.0); nnn.fill(0)
-            O.build_neighbor(x.numpy(), y.numpy(), z.numpy(), box, origin, boundary, rc, vn, dn, nnn, 2)
+            if key is None:
+                O.build_neighbor(x.numpy(), y.numpy(), z.numpy(), box, origin, boundary, rc, vn, dn, nnn, 2)
+                return
+            # "descending key inside a cell" == the reference's "descending index" after sorting the atoms by key
+            perm = np.argsort(key.numpy(), kind="stable")
+            vs, ds, ns = np.full_like(vn, -1), np.full_like(dn, rc + 1.0), np.zeros_like(nnn)
+            O.build_neighbor(x.numpy()[perm].copy(), y.numpy()[perm].copy(), z.numpy()[perm].copy(), box, origin, boundary, rc, vs, ds, ns, 2)
+            vn[perm] = np.where(vs >= 0, perm[np.clip(vs, 0, None)], -1)
+            dn[perm] = ds
+            nnn[perm] = ns
 
         def fcna(x, y, z, box, origin, boundary, v, nn, pat, rc, num_t=1):
             O.fcna(x.numpy(), y.numpy(), z.numpy(), box, origin, boundary, v.numpy(), nn.numpy(), pat.numpy(), rc, 2)
@@ -63,7 +72,7 @@ def _worker(rank, world, port, q):
         own = dom.owned.numpy()
         gid = dom.gid.numpy()
         assert own.sum() == len(owned_ids) and np.array_equal(np.sort(gid[own]), np.sort(owned_ids))
-        assert np.all(gid[1:] > gid[:-1])
+        assert own[: len(owned_ids)].all() and len(np.unique(gid)) == len(gid)  # owned atoms first, every atom once
         # single-process reference on the whole system
         x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
         org, bnd = np.zeros(3), np.array([1, 1, 1], np.int32)

@@ -1027,3 +1027,46 @@ def test_voronoi_cell_info_vs_reference_library(case):
             assert abs(0.5 * np.linalg.norm(cr) - ar) <= 1e-9 * scale ** 2 + 1e-9 * ar
     con = mp.voronoi.Container(np.ascontiguousarray(pos - origin), mp.Box(box, boundary=bd))
     assert len(con) == len(pos) and abs(con[3].volume - v0[3]) < 1e-9 * v0[3] and con[3].vertices.shape == (len(fp0[3]), 3)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[5], CASES[9]], ids=[CASES[0][0], CASES[2][0], CASES[5][0], CASES[9][0]])
+def test_neighbor_ordering_key_equals_reordered_system(case):
+    """build_neighbor(key=...) (multi-GPU extension): "descending key inside a cell" must give, for every atom, the row the
+    reference gives after the atoms have been renumbered in ascending key order"""
+    _, pos, box, org, bnd = case
+    x, y, z = _xyz(pos)
+    N, rc = len(x), 3.3
+    key = np.random.default_rng(3).permutation(N).astype(np.int64) * 7 + 5  # arbitrary distinct ids
+    perm = np.argsort(key, kind="stable")
+    v0, d0, n0 = O.build_neighbor_without_max_neigh(x[perm].copy(), y[perm].copy(), z[perm].copy(), box, org, bnd, rc, 4)
+    M = v0.shape[1]
+    v1, d1, n1 = np.zeros((N, M), np.int32), np.zeros((N, M)), np.zeros(N, np.int32)
+    _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, v1, d1, n1, 1, fill_pads=True, key=key)
+    assert np.array_equal(n1[perm], n0) and np.array_equal(d1[perm], d0)
+    assert np.array_equal(v1[perm], np.where(v0 >= 0, perm[np.clip(v0, 0, None)], -1))
+    v2, d2, n2 = np.zeros((N, M), np.int32), np.zeros((N, M)), np.zeros(N, np.int32)
+    _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, v2, d2, n2, 1, fill_pads=True, key=np.arange(N, dtype=np.int64))
+    va, da, na = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    assert np.array_equal(v2[:, : va.shape[1]], va) and np.array_equal(n2, na)  # key = index: the plain build
+
+
+def test_slab_halo_selection_kernel_equals_its_torch_definition():
+    import torch
+
+    from mdapy_amd.distributed import SlabDecomposition
+
+    rng = np.random.default_rng(8)
+    tri = np.array([[40.0, 0.0, 0.0], [6.0, 33.0, 0.0], [-4.0, 5.0, 28.0]])
+    for box, axis in ((mp.Box(np.diag([50.0, 20.0, 30.0])), 0), (mp.Box(tri, origin=np.array([1.0, -2.0, 3.0])), 0), (mp.Box(tri), 2)):
+        pos = (rng.random((200_000, 3)) * 1.4 - 0.2) @ box.box + box.origin  # some atoms outside the box: wrapped ownership
+        x, y, z = (torch.from_numpy(np.ascontiguousarray(pos[:, k])).cuda() for k in range(3))
+        for rank, world in ((0, 4), (3, 4), (1, 2)):
+            dec = SlabDecomposition(box, rank, world, axis=axis)
+            h = dec.halo_fraction(3.3)
+            lo, hi = rank / world, (rank + 1) / world
+            f = dec.frac(x, y, z)
+            up0 = (f >= hi - h).nonzero().flatten()
+            down0 = (f < lo + h).nonzero().flatten()
+            up1, down1 = dec._select_device(x, y, z, hi - h, lo + h)
+            assert torch.equal(torch.sort(up1).values, up0) and torch.equal(torch.sort(down1).values, down0)
+            assert 0 < len(up0) < len(f)
