@@ -467,14 +467,15 @@ int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occup
             return MDH_OK;
         }
     int *host = nullptr;
-    MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int), hipHostMallocDefault));
+    if (g_occ.size() >= 64) { // keep the table small: the oldest signature hands its pinned word on (never freed: a copy
+        host = g_occ.front().host; // enqueued on some other stream may still land in it — a wrong hint at worst)
+        g_occ.erase(g_occ.begin());
+    } else {
+        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int), hipHostMallocDefault));
+    }
     MDH_HIP(hipMemcpyAsync(host, dcnt, sizeof(int), hipMemcpyDeviceToHost, st));
     MDH_HIP(hipStreamSynchronize(st));
     *occupied = *host > 0 ? *host : cg.g.ncell;
-    if (g_occ.size() >= 64) { // keep the table small: forget the oldest signature
-        (void)hipHostFree(g_occ.front().host);
-        g_occ.erase(g_occ.begin());
-    }
     g_occ.push_back(OccEntry{N, cg.g.ncell, device, host});
     return MDH_OK;
 }

@@ -349,7 +349,7 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
     // Cells wider than half a period cannot be described by minimum-image rows: the periodic axes that are too thin are
     // replicated (x3 per round, the original atoms first) and the cells of the original atoms are taken from the copy.
     int rep[3] = {1, 1, 1};
-    for (int round = 0; round < 3; ++round) {
+    for (int round = 0; round < 4; ++round) {
         const int64_t total = N * rep[0] * rep[1] * rep[2];
         if (total >= 50000000LL) {
             set_error("mdh_voronoi_volume_number_radius: the replicated system would be too large");

@@ -60,7 +60,8 @@ class SlabDecomposition:
         f = f - t.floor(f)
         return t.where(f >= 1.0, f - 1.0, f)
 
-    def _select_device(self, x, y, z, up_from: float, down_below: float):
+    def _select_device(self, x, y, z, up_from: float, down_below: float, gid=None):
+        """-> (up, down) index tensors; with gid also the (n_sel, 4) rows (x, y, z, id as f64) of both selections"""
         import ctypes
 
         from . import _lib
@@ -74,10 +75,21 @@ class SlabDecomposition:
         o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
         hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
         cnt = (ctypes.c_int64 * 2)(0, 0)
+        pu = pd = g = None
+        if gid is not None:
+            g = gid.contiguous()
+            assert g.dtype == t.int64
+            pu = t.empty((n, 4), dtype=t.float64, device=x.device)
+            pd = t.empty((n, 4), dtype=t.float64, device=x.device)
         _lib.check(_lib.lib().mdh_slab_halo_select(x.data_ptr(), y.data_ptr(), z.data_ptr(), n, o.ctypes.data, hi3.ctypes.data,
                                                    float(up_from), float(down_below), up.data_ptr(), down.data_ptr(), cnt,
+                                                   g.data_ptr() if g is not None else None, pu.data_ptr() if pu is not None else None,
+                                                   pd.data_ptr() if pd is not None else None,
                                                    _lib.DEVICE, int(t.cuda.current_stream().cuda_stream)))
-        return up[: int(cnt[0])].to(t.int64), down[: int(cnt[1])].to(t.int64)
+        nu, nd = int(cnt[0]), int(cnt[1])
+        if gid is None:
+            return up[:nu].to(t.int64), down[:nd].to(t.int64)
+        return up[:nu], down[:nd], pu[:nu], pd[:nd]
 
     def owner_of(self, x, y, z):
         t = _torch()
@@ -108,17 +120,18 @@ class SlabDecomposition:
             return LocalDomain(x, y, z, gid, t.ones(n_owned, dtype=t.bool, device=x.device), n_owned)
         h = self.halo_fraction(halo)
         lo, hi = self.rank / self.world, (self.rank + 1) / self.world
-        if x.is_cuda:  # one fused pass (slab.hip); the torch expressions below are its definition
-            up, down = self._select_device(x, y, z, hi - h, lo + h)
+        if x.is_cuda:  # selection and packing in one fused pass (slab.hip); the torch expressions below are its definition
+            _, _, rows_r, rows_l = self._select_device(x, y, z, hi - h, lo + h, gid)
+            send_r, send_l = rows_r.t().contiguous(), rows_l.t().contiguous()
         else:
             f = self.frac(x, y, z)
             up = (f >= hi - h).nonzero().flatten()    # goes to the right neighbour
             down = (f < lo + h).nonzero().flatten()   # goes to the left neighbour
 
-        def pack(sel):
-            return t.stack([x[sel], y[sel], z[sel], gid[sel].to(t.float64)], dim=0).contiguous()  # ids < 2^53: exact
+            def pack(sel):
+                return t.stack([x[sel], y[sel], z[sel], gid[sel].to(t.float64)], dim=0).contiguous()  # ids < 2^53: exact
 
-        send_r, send_l = pack(up), pack(down)
+            send_r, send_l = pack(up), pack(down)
         # sizes first (order: to-right then to-left / from-left then from-right, consistent for world == 2)
         cnt_s = [t.tensor([send_r.shape[1]], dtype=t.int64, device=x.device),
                  t.tensor([send_l.shape[1]], dtype=t.int64, device=x.device)]
