@@ -33,6 +33,7 @@ struct TiledPlan {
     int tile;        // cells per tile edge in x and y; 0 = not applicable
     int tile_z;      // cells per tile edge in z
     bool cellshift;  // every periodic axis has >= 7 cells: per-cell image shifts may replace the minimum-image search
+    bool full;       // every 4x4x4 block of cells holds atoms (last known occupancy): all tiles are live
 };
 // what the LDS-tiled kernel leaves to the thread-per-atom kernel: tiles whose halo did not fit in LDS
 // (flag[t] != 0; *any counts them).  flag == nullptr: no filtering (the thread-per-atom kernel does everything).

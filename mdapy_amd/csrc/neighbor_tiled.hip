@@ -200,12 +200,12 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of the tiles THAT HOLD CENTRE ATOMS
     // (tile_list, in tile order) so that neighbouring tiles (which share halo cells) meet in the same L2 and an empty part
     // of the box (vacuum, the other ranks' slabs of a decomposed system) leaves no XCD idle.
-    const int nlive = *n_live;
+    const int nlive = tile_list ? *n_live : nt0 * nt1 * nt2; // no list: every tile is live (a box that is full of atoms)
     const int per = (nlive + 7) / 8;
     const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per || slot >= nlive)
         return;
-    const int tile_id = tile_list[slot];
+    const int tile_id = tile_list ? tile_list[slot] : slot;
     const int t2 = tile_id % nt2, t1 = (tile_id / nt2) % nt1, t0 = tile_id / (nt2 * nt1);
     const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
     const int tid = threadIdx.x;
@@ -482,7 +482,7 @@ int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occup
 
 TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t occupied_cells)
 {
-    TiledPlan p{0, 0, false};
+    TiledPlan p{0, 0, false, false};
     if (b.tri || g.mode != 0 || N <= 0 || M <= 0)
         return p;
     const double pop = (double)N / (double)(occupied_cells > 0 ? occupied_cells : g.ncell); // mean atoms per occupied cell
@@ -497,6 +497,7 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t
         return p;
     p.tile = sh.txy;
     p.tile_z = sh.tz;
+    p.full = occupied_cells >= g.ncell;
     p.cellshift = true;
     for (int d = 0; d < 3; ++d)
         if (b.pbc[d] && g.nc[d] < 7)
@@ -541,9 +542,13 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
         return sc.error();
     hipStream_t st = sc.stream();
     MDH_HIP(hipMemsetAsync(tile_flag, 0, (size_t)ntiles, st));
-    hipLaunchKernelGGL(k_tile_live, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, cg.cell_start, cg.g, nt[0], nt[1], nt[2], ts, live);
-    MDH_TRY(exclusive_scan_u32(sc, live, slot, ntiles)); // slot[ntiles] = number of live tiles
-    hipLaunchKernelGGL(k_tile_compact, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, live, slot, (int)ntiles, tile_list);
+    if (plan.full) { // the occupancy count says that no 4x4x4 block of cells is empty: all tiles are live, no list needed
+        tile_list = nullptr;
+    } else {
+        hipLaunchKernelGGL(k_tile_live, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, cg.cell_start, cg.g, nt[0], nt[1], nt[2], ts, live);
+        MDH_TRY(exclusive_scan_u32(sc, live, slot, ntiles)); // slot[ntiles] = number of live tiles
+        hipLaunchKernelGGL(k_tile_compact, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, live, slot, (int)ntiles, tile_list);
+    }
     // Two launches, one of which returns at once on the device flag: image numbers from the cell / atom codes when
     // the binning pass found them valid (and the grid allows it), the exact threshold search otherwise.
     if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts, tile_list, slot + ntiles);
