@@ -34,6 +34,7 @@ struct TiledPlan {
     int tile_z;      // cells per tile edge in z
     bool cellshift;  // every periodic axis has >= 7 cells: per-cell image shifts may replace the minimum-image search
     bool full;       // every 4x4x4 block of cells holds atoms (last known occupancy): all tiles are live
+    int64_t occupied; // cells of the occupied region (last known)
 };
 // what the LDS-tiled kernel leaves to the thread-per-atom kernel: tiles whose halo did not fit in LDS
 // (flag[t] != 0; *any counts them).  flag == nullptr: no filtering (the thread-per-atom kernel does everything).

@@ -520,7 +520,7 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
         int64_t occ = 0;
         if (g_neighbor_variant != 1 && !b.tri)
             MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
-        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, 0, false, false} : plan_tiled(b, cg.g, N, max_neigh, occ);
+        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, 0, false, false, 0} : plan_tiled(b, cg.g, N, max_neigh, occ);
         TileFilter tf{};
         if (plan.tile) // LDS-tiled kernel; the thread-per-atom kernel below then only mops up what it left
             MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));

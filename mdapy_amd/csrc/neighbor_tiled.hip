@@ -202,13 +202,15 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     // of the box (vacuum, the other ranks' slabs of a decomposed system) leaves no XCD idle.
     const int nlive = tile_list ? *n_live : nt0 * nt1 * nt2; // no list: every tile is live (a box that is full of atoms)
     const int per = (nlive + 7) / 8;
-    const int slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per || slot >= nlive)
-        return;
+    const int tid = threadIdx.x;
+    // the grid is sized from the last known occupancy; a workgroup takes further tiles of its XCD's chunk if that was too few
+    for (int jt = (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
+    const int slot = (blockIdx.x & 7) * per + jt;
+    if (slot >= nlive)
+        break;
     const int tile_id = tile_list ? tile_list[slot] : slot;
     const int t2 = tile_id % nt2, t1 = (tile_id / nt2) % nt1, t0 = tile_id / (nt2 * nt1);
     const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
-    const int tid = threadIdx.x;
 
     // ---- halo cell table: source range, LDS offset, image code.  Thread t owns halo cells 2t and 2t+1
     // (adjacent in z, hence adjacent in memory).
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
             tile_flag[tile_id] = 1;
             atomicAdd(&flags[2], 1);
         }
-        return;
+        continue; // (excl_scan_block ended with a barrier)
     }
     if (2 * tid < NH) h_off[2 * tid] = (unsigned short)off0;
     if (2 * tid + 1 < NH) h_off[2 * tid + 1] = (unsigned short)(off0 + cnt2[0]);
@@ -358,6 +360,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         }
         __syncthreads();
     }
+    if (jt + (int)(gridDim.x >> 3) < per) __syncthreads(); // LDS is reused by the next tile
+    } // tiles of this workgroup
 }
 
 // tiles with at least one centre atom: flag (one thread per tile), then an order-preserving compaction
@@ -482,7 +486,7 @@ int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occup
 
 TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t occupied_cells)
 {
-    TiledPlan p{0, 0, false, false};
+    TiledPlan p{0, 0, false, false, 0};
     if (b.tri || g.mode != 0 || N <= 0 || M <= 0)
         return p;
     const double pop = (double)N / (double)(occupied_cells > 0 ? occupied_cells : g.ncell); // mean atoms per occupied cell
@@ -498,6 +502,7 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t
     p.tile = sh.txy;
     p.tile_z = sh.tz;
     p.full = occupied_cells >= g.ncell;
+    p.occupied = occupied_cells > 0 ? occupied_cells : g.ncell;
     p.cellshift = true;
     for (int d = 0; d < 3; ++d)
         if (b.pbc[d] && g.nc[d] < 7)
@@ -508,10 +513,12 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t
 template <bool CS>
 static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double rc, int *verlet, double *dist, int *nn,
                        int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved, TileShape ts,
-                       const int *tile_list, const int *n_live)
+                       const int *tile_list, const int *n_live, int64_t est_live)
 {
     const int ntiles = nt[0] * nt[1] * nt[2];
-    const int per = (ntiles + 7) / 8;
+    int per = (ntiles + 7) / 8;
+    if (est_live > 0) // tiles expected to hold atoms (+25 %); more than that and workgroups loop (k_neighbor_tiled)
+        per = std::max(1, std::min(per, (int)((est_live + est_live / 4 + 7) / 8)));
     dim3 grid((unsigned)(per * 8)), block(NT);
     const size_t lds = tiled_lds_bytes(M);
     int mp_shift = 0;
@@ -542,6 +549,9 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
         return sc.error();
     hipStream_t st = sc.stream();
     MDH_HIP(hipMemsetAsync(tile_flag, 0, (size_t)ntiles, st));
+    // live tiles expected from the last known occupancy: occupied cells / cells per tile (tiles are cut partly empty at the
+    // surface of the occupied region, hence the head-room in launch_one)
+    const int64_t est_live = plan.full ? 0 : std::max<int64_t>(1, plan.occupied / std::max(1, ts.txy * ts.txy * ts.tz) * 2);
     if (plan.full) { // the occupancy count says that no 4x4x4 block of cells is empty: all tiles are live, no list needed
         tile_list = nullptr;
     } else {
@@ -551,8 +561,8 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
     }
     // Two launches, one of which returns at once on the device flag: image numbers from the cell / atom codes when
     // the binning pass found them valid (and the grid allows it), the exact threshold search otherwise.
-    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts, tile_list, slot + ntiles);
-    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts, tile_list, slot + ntiles);
+    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts, tile_list, slot + ntiles, est_live);
+    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts, tile_list, slot + ntiles, est_live);
     MDH_HIP(hipGetLastError());
     tf.flag = tile_flag;
     tf.any = cg.flags + 2;
