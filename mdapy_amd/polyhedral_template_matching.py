@@ -52,9 +52,8 @@ class PolyhedralTemplateMatching:
         if "type" in data.columns:  # :144-152
             type_list = np.ascontiguousarray(data["type"].to_numpy(), dtype=np.int32)
         elif "element" in data.columns:
-            ele = data["element"].to_numpy()
-            ele2type = {j: i + 1 for i, j in enumerate(sorted(set(ele.tolist())))}
-            type_list = np.array([ele2type[e] for e in ele.tolist()], dtype=np.int32)
+            _, dense = tool.dense_labels(data["element"].to_numpy())  # sorted element names -> 1, 2, ...
+            type_list = dense + 1
         else:
             type_list = np.ones(N, np.int32)
         x, y, z = tool.xyz(data)

@@ -8,6 +8,8 @@ from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 
+from . import tool_function as tool
+
 from . import _rdf
 from .box import Box
 from .parallel import get_num_threads
@@ -36,11 +38,8 @@ class RadialDistributionFunction:
             self.neighbor_number = neighbor_number
             self.N = int(self.verlet_list.shape[0])
         raw = np.zeros(self.N, dtype=np.int32) if type_list is None else np.asarray(type_list)
-        unique_sorted = sorted(set(raw.tolist()))  # :125-131 labels -> dense 0..Ntype-1
-        self.elements: List[Any] = list(unique_sorted)
+        self.elements, self.type_list = tool.dense_labels(raw)  # :125-142 labels -> dense 0..Ntype-1 in sorted order
         self.Ntype = len(self.elements)
-        label_to_idx = {label: i for i, label in enumerate(self.elements)}
-        self.type_list = np.array([label_to_idx[v] for v in raw.tolist()], dtype=np.int32)
 
     def compute(self) -> None:
         edges = np.linspace(0, self.rc, self.nbin + 1)

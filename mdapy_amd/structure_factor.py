@@ -118,7 +118,7 @@ class StructureFactor:
             else:
                 raise ValueError("cal_partial / atomic_form_factors require an 'element' or 'type' column.")
             labels = np.asarray(data[col].to_numpy())
-            uniele: List[Any] = sorted(set(labels.tolist()))
+            uniele, dense_idx = tool.dense_labels(labels)
         else:
             uniele = ["all"]
         n_total = data.shape[0]
@@ -126,8 +126,7 @@ class StructureFactor:
         self._density = self.num_density = self.density = n_total / box.volume
         x, y, z = (np.ascontiguousarray(as_numpy(data[c].to_numpy()), dtype=np.float64) for c in "xyz")
         if self.cal_partial:
-            idx = {sp: i for i, sp in enumerate(uniele)}
-            type_dense = np.array([idx[v] for v in labels.tolist()], dtype=np.int32)
+            type_dense = dense_idx
             c = np.bincount(type_dense, minlength=len(uniele)) / n_total
             self._concentrations = c
             al = np.zeros((len(uniele), len(uniele), self.nbins))

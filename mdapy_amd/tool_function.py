@@ -51,6 +51,20 @@ def replicate(data: Frame, box: Box, nx: int, ny: int, nz: int) -> Tuple[Frame, 
     return new, Box(new_box, box.boundary, box.origin)
 
 
+def dense_labels(labels) -> Tuple[list, np.ndarray]:
+    """(sorted unique labels as Python objects, index of every entry in that list as int32) — what the reference builds with
+    ``sorted(set(x.tolist()))`` and a per-atom dictionary lookup (e.g. radial_distribution_function.py:136-142), without the
+    per-atom Python loop: one comparison pass when all atoms carry the same label, ``np.unique`` otherwise."""
+    raw = np.asarray(labels)
+    if raw.size == 0:
+        return [], np.zeros(0, np.int32)
+    first = raw.flat[0]
+    if bool((raw == first).all()):
+        return [first.item() if hasattr(first, "item") else first], np.zeros(raw.shape[0], np.int32)
+    uniq, inv = np.unique(raw, return_inverse=True)
+    return uniq.tolist(), inv.reshape(-1).astype(np.int32)
+
+
 def _replicate_pos(data: Frame, box: Box, nx: int, ny: int, nz: int) -> Tuple[Frame, Box]:
     """positions only (tool_function.py:179-192)"""
     nx, ny, nz = int(nx), int(ny), int(nz)

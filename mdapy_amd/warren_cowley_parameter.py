@@ -5,6 +5,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _wcp
+from . import tool_function as tool
 from .frame import Frame
 from .parallel import get_num_threads
 
@@ -15,10 +16,8 @@ class WarrenCowleyParameter:
         self.neighbor_number = neighbor_number
         self.data = data
         if "element" in self.data.columns:  # elements -> index in sorted order (:82-89)
-            ele = self.data["element"].to_numpy()
-            names = sorted(set(ele.tolist()))
+            names, self.type_list = tool.dense_labels(self.data["element"].to_numpy())
             self.ele2type = {j: i for i, j in enumerate(names)}
-            self.type_list = np.array([self.ele2type[e] for e in ele.tolist()], dtype=np.int32)
             self.Ntype = len(self.ele2type)
         else:
             assert "type" in self.data.columns
