@@ -2,7 +2,7 @@
 """Randomised parity sweep on the GPU box: the parity checks of tests/test_gpu_parity.py (HIP path vs the CPU
 oracle / the oracle/_ref libraries) on freshly drawn systems instead of the fixed cases.
 
-    python tools/fuzz_parity.py [seconds] [first_seed]
+    python tests/fuzz_parity.py [seconds] [first_seed]
 
 Every seed draws one system — orthogonal or triclinic box, random boundary flags, origin, density, lattice or
 gas, optionally out-of-box ("unwrapped") atoms — and runs the checks that support that kind of input.  A failure

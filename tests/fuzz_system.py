@@ -3,7 +3,7 @@
 through the HIP library and once with the host classes routed to the CPU oracle (tests/_oracle_backend.py), then
 every per-atom column and every returned curve compared.
 
-    python tools/fuzz_system.py [seconds] [first_seed]
+    python tests/fuzz_system.py [seconds] [first_seed]
 
 This exercises the policy layer above the C ABI as well (small-box replication, list reuse, triclinic alignment of
 the Voronoi calls, column naming).  Integer columns must be equal, floating ones agree to 1e-6.  Test infrastructure.
@@ -16,7 +16,6 @@ import traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from _pytest.monkeypatch import MonkeyPatch
 

@@ -1,5 +1,5 @@
-"""GPU suite: a short, fixed-seed slice of the randomised sweeps in tools/fuzz_parity.py (C-ABI level, HIP vs oracle / the
-oracle/_ref libraries) and tools/fuzz_system.py (System level, HIP vs the host classes routed to the oracle).  The tools
+"""GPU suite: a short, fixed-seed slice of the randomised sweeps in tests/fuzz_parity.py (C-ABI level, HIP vs oracle / the
+oracle/_ref libraries) and tests/fuzz_system.py (System level, HIP vs the host classes routed to the oracle).  The tools
 run the same checks for as long as one likes on fresh seeds; the suite pins a few dozen systems of every kind."""
 import os
 import sys
@@ -7,8 +7,7 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_c_abi_sweep_fixed_seeds():
