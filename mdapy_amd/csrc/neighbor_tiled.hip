@@ -513,12 +513,14 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t
 template <bool CS>
 static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double rc, int *verlet, double *dist, int *nn,
                        int M, bool fill_pads, unsigned char *tile_flag, const int *nt, int want_moved, TileShape ts,
-                       const int *tile_list, const int *n_live, int64_t est_live)
+                       const int *tile_list, const int *n_live, int64_t est_live, bool standby)
 {
     const int ntiles = nt[0] * nt[1] * nt[2];
     int per = (ntiles + 7) / 8;
     if (est_live > 0) // tiles expected to hold atoms (+25 %); more than that and workgroups loop (k_neighbor_tiled)
         per = std::max(1, std::min(per, (int)((est_live + est_live / 4 + 7) / 8)));
+    if (standby) // the variant that the device flag will most likely send home: three workgroups per CU, looping if it does run
+        per = std::min(per, 96);
     dim3 grid((unsigned)(per * 8)), block(NT);
     const size_t lds = tiled_lds_bytes(M);
     int mp_shift = 0;
@@ -561,8 +563,8 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
     }
     // Two launches, one of which returns at once on the device flag: image numbers from the cell / atom codes when
     // the binning pass found them valid (and the grid allows it), the exact threshold search otherwise.
-    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts, tile_list, slot + ntiles, est_live);
-    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts, tile_list, slot + ntiles, est_live);
+    if (plan.cellshift) launch_one<true>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, 0, ts, tile_list, slot + ntiles, est_live, false);
+    launch_one<false>(st, cg, b, rc, verlet, dist, nn, (int)M, fill_pads, tile_flag, nt, plan.cellshift ? 1 : -1, ts, tile_list, slot + ntiles, est_live, plan.cellshift);
     MDH_HIP(hipGetLastError());
     tf.flag = tile_flag;
     tf.any = cg.flags + 2;
