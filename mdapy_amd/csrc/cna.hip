@@ -127,7 +127,7 @@ __device__ __forceinline__ bool bond_rows(const DBox &b, const double *__restric
     double px[NN], py[NN], pz[NN];
 #pragma unroll
     for (int a = 0; a < NN; ++a) {
-        const int j = ids[a];
+        const int j = ids[a]; // made safe by the caller (safe_id)
         px[a] = x[j]; py[a] = y[j]; pz[a] = z[j];
     }
     bool plain = false; // no fold needed on any axis
@@ -185,12 +185,13 @@ __device__ __forceinline__ bool bond_rows(const DBox &b, const double *__restric
 // returns the label (0 = none) or -1 when the atom must be redone by the generic variant
 template <bool TRI, bool GENERIC, int NN>
 __device__ __forceinline__ int fcna_atom(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
-                                         const double *__restrict__ z, const int *__restrict__ row, double cut2)
+                                         const double *__restrict__ z, const int *__restrict__ row, double cut2, int64_t i,
+                                         int64_t N)
 {
     int ids[NN];
 #pragma unroll
     for (int a = 0; a < NN; ++a)
-        ids[a] = row[a];
+        ids[a] = safe_id(row[a], i, N);
     Rows R;
     if (!bond_rows<TRI, GENERIC, NN>(b, x, y, z, ids, cut2, R))
         return -1;
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
     const int *row = verlet + i * M;
     // atoms with nn not in {12,14} keep the caller's value (cna.cpp:456)
     int t = 0;
-    if (n == 12 && M >= 12) t = fcna_atom<TRI, GENERIC, 12>(b, x, y, z, row, cut2);
-    else if (n == 14 && M >= 14) t = fcna_atom<TRI, GENERIC, 14>(b, x, y, z, row, cut2);
+    if (n == 12 && M >= 12) t = fcna_atom<TRI, GENERIC, 12>(b, x, y, z, row, cut2, i, N);
+    else if (n == 14 && M >= 14) t = fcna_atom<TRI, GENERIC, 14>(b, x, y, z, row, cut2, i, N);
     if (t > 0) pattern[i] = t;
     else if (!GENERIC && t < 0) defer(todo, i);
 }
@@ -250,13 +251,13 @@ __device__ __forceinline__ double dist2_to(const DBox &b, const double *__restri
 template <bool TRI, bool GENERIC>
 __device__ __forceinline__ int acna_atom(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
                                          const double *__restrict__ z, int64_t i, const int *__restrict__ row,
-                                         int label)
+                                         int label, int64_t N)
 {
     const double xi = x[i], yi = y[i], zi = z[i];
     int ids[14];
 #pragma unroll
     for (int a = 0; a < 14; ++a)
-        ids[a] = row[a];
+        ids[a] = safe_id(row[a], i, N);
     // ---- 12 nearest neighbours: FCC / HCP / ICO (cna.cpp:309-370)
     double rs = 0.0;
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void k_acna(const double *__restrict__ x, cons
     } else if (i >= N) {
         return;
     }
-    const int t = acna_atom<TRI, GENERIC>(b, x, y, z, i, verlet + i * M, pattern[i]);
+    const int t = acna_atom<TRI, GENERIC>(b, x, y, z, i, verlet + i * M, pattern[i], N);
     if (t >= 0) pattern[i] = t;
     else if (!GENERIC) defer(todo, i);
 }
@@ -345,10 +346,10 @@ __global__ __launch_bounds__(256) void k_ids_second(int64_t N, const int *__rest
         return;
     int cnt = 0;
     for (int m = 0; m < 4; ++m) { // :188-202; slots that are not reached keep the caller's content
-        const int j = verlet[i * M + m];
+        const int j = safe_id(verlet[i * M + m], i, N);
         int took = 0;
         for (int q = 0; q < 4; ++q) {
-            const int k = verlet[(int64_t)j * M + q];
+            const int k = safe_id(verlet[(int64_t)j * M + q], i, N);
             if (k != (int)i && took < 3) {
                 second[i * 12 + cnt] = k;
                 ++cnt;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256) void k_ids_claim(const int *__restrict__ verle
     if (t != src_a && t != src_b)
         return;
     for (int q = 0; q < 4; ++q) {
-        const int j = verlet[i * M + q];
+        const int j = safe_id(verlet[i * M + q], i, N);
         if (pattern[j] == 0)
             atomicMin(&claim[j], (int)i);
     }

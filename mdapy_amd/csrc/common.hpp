@@ -172,6 +172,11 @@ class Scope {
     int nouts_ = 0;
 };
 
+// An index taken from a caller's list, made safe to dereference: an entry outside [0, n) (a pad of a k-nearest list in a
+// system of fewer than k+1 atoms, a list that belongs to another system) reads atom `fallback` instead of faulting the
+// GPU.  The reference reads out of bounds there (undefined behaviour), so any defined result is as good as its.
+__device__ __forceinline__ int safe_id(int j, int64_t fallback, int64_t n) { return (unsigned)j < (unsigned)n ? j : (int)fallback; }
+
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
 // Scoped HIP-event pair around a kernel launch (no-op unless mdh_prof_enable(1)); prof.hip

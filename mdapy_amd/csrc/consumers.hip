@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_aja(const double *__restrict__ x, const
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
         if (j < n0) {
-            const int q = vi[j];
+            const int q = safe_id(vi[j], i, N);
             double ax = x[q] - xi, ay = y[q] - yi, az = z[q] - zi;
             pbc<TRI>(b, ax, ay, az);
             rx[j] = ax; ry[j] = ay; rz[j] = az;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(128) void k_cnp(const double *__restrict__ x, const
     for (int m = 0; m < ni; ++m) {
         if (!(di[m] <= rc))
             continue;
-        const int j = vi[m];
+        const int j = safe_id(vi[m], i, N);
         ++cnt;
         const double xj = x[j], yj = y[j], zj = z[j];
         double rx = 0, ry = 0, rz = 0;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(128) void k_cnp(const double *__restrict__ x, const
         const int *vj = verlet + (int64_t)j * M;
         const double *dj = dist + (int64_t)j * M;
         for (int s = 0; s < nj; ++s) {
-            const int k = vj[s];
+            const int k = safe_id(vj[s], i, N);
             for (int h = 0; h < ni; ++h)
                 if (k == vi[h]) { // first match only (:83-120)
                     if (dj[s] <= rc && di[h] <= rc) {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_atomic_temp(const int *__restrict__ ver
     int n = 1;
     for (int q = 0; q < M; ++q) { // mass-weighted mean velocity of the neighbourhood (:44-62)
         const int j = vi[q];
-        if (j < 0)
+        if ((unsigned)j >= (unsigned)N) // pad (-1) or an index of another system
             break;
         if (j != i && di[q] <= rc) {
             const double mj = mass[j];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_atomic_temp(const int *__restrict__ ver
     ke += 0.5 * mi * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
     for (int q = 0; q < M; ++q) { // kinetic energy relative to it (:78-101)
         const int j = vi[q];
-        if (j < 0)
+        if ((unsigned)j >= (unsigned)N) // pad (-1) or an index of another system
             break;
         if (j != i && di[q] <= rc) {
             const double mj = mass[j];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_filter_by_type(int *__restrict__ verlet
     const int n = nn[i], ti = type[i];
     for (int q = 0; q < n; ++q) {
         const int j = verlet[i * M + q];
-        if (j < 0)
+        if ((unsigned)j >= (unsigned)N)
             continue; // the reference would index type_list(-1) here; a row is filtered once
         const int tj = type[j];
         const double d = dist[i * M + q];

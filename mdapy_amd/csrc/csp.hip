@@ -16,14 +16,14 @@ namespace mdh {
 template <bool TRI, int K>
 __device__ __forceinline__ double csp_atom_static(const DBox &b, const double *__restrict__ x,
                                                   const double *__restrict__ y, const double *__restrict__ z,
-                                                  int64_t i, const int *__restrict__ row)
+                                                  int64_t i, const int *__restrict__ row, int64_t N)
 {
     constexpr int H = K / 2;
     const double xi = x[i], yi = y[i], zi = z[i]; // RAW centre (:46-48)
     double rx[K], ry[K], rz[K];
 #pragma unroll
     for (int a = 0; a < K; ++a) {
-        const int j = row[a];
+        const int j = safe_id(row[a], i, N);
         double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
         pbc<TRI>(b, dx, dy, dz);
         rx[a] = dx; ry[a] = dy; rz[a] = dz;
@@ -59,13 +59,13 @@ static constexpr int CSP_MAXK = 64;
 
 template <bool TRI>
 __device__ double csp_atom_dynamic(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
-                                   const double *__restrict__ z, int64_t i, const int *__restrict__ row, int K)
+                                   const double *__restrict__ z, int64_t i, const int *__restrict__ row, int K, int64_t N)
 {
     const int H = K / 2;
     const double xi = x[i], yi = y[i], zi = z[i];
     double rx[CSP_MAXK], ry[CSP_MAXK], rz[CSP_MAXK], top[CSP_MAXK / 2];
     for (int a = 0; a < K; ++a) {
-        const int j = row[a];
+        const int j = safe_id(row[a], i, N);
         double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
         pbc<TRI>(b, dx, dy, dz);
         rx[a] = dx; ry[a] = dy; rz[a] = dz;
@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void k_csp(const double *__restrict__ x, const
         return;
     const int *row = verlet + i * M;
     double v;
-    if (K == 12) v = csp_atom_static<TRI, 12>(b, x, y, z, i, row);
-    else if (K == 8) v = csp_atom_static<TRI, 8>(b, x, y, z, i, row);
-    else v = csp_atom_dynamic<TRI>(b, x, y, z, i, row, K);
+    if (K == 12) v = csp_atom_static<TRI, 12>(b, x, y, z, i, row, N);
+    else if (K == 8) v = csp_atom_static<TRI, 8>(b, x, y, z, i, row, N);
+    else v = csp_atom_dynamic<TRI>(b, x, y, z, i, row, K, N);
     csp[i] = v;
 }
 

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_average(double rc, const int *__restric
     if (include_self) { s += value[i]; ++cnt; }
     const int n = nn[i];
     for (int j = 0; j < n; ++j) // neighbor.cpp:729-736 (sequential sum in list order)
-        if (dist[i * M + j] <= rc) { s += value[verlet[i * M + j]]; ++cnt; }
+        if (dist[i * M + j] <= rc) { s += value[safe_id(verlet[i * M + j], i, N)]; ++cnt; }
     out[i] = cnt > 0 ? s / cnt : 0.0;
 }
 

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_rdf_list(const int *__restrict__ verlet
         const int it = single ? 0 : type[i];
         for (int q = 0; q < n; ++q) {
             const double d = dist[i * M + q];
-            const int j = verlet[i * M + q];
+            const int j = safe_id(verlet[i * M + q], i, N);
             const int k = (int)(d / dr);
             if (!(d < rc) || k >= nbin || k < 0) // k == nbin can only arise from rounding at d -> rc (the reference would write out of bounds there)
                 continue;

@@ -69,7 +69,7 @@ __global__ void k_sq_stage1(const double *__restrict__ x, const double *__restri
     for (int jj = 0; jj < cnt; ++jj) {
         const int64_t idx = i * M + jj;
         const int j = NL[idx];
-        if (j < 0)
+        if ((unsigned)j >= (unsigned)N) // pad or foreign index
             continue;
         double dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1; // :346-350
         pbc<TRI>(b, dx, dy, dz);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_sq_average(int64_t N, const int *__rest
     int nb = 1;
     for (int jj = 0; jj < cnt; ++jj) {
         const int j = NL[i * M + jj];
-        if (j < 0)
+        if ((unsigned)j >= (unsigned)N)
             continue;
         sr += ar[(int64_t)j * stride + c];
         si += ai[(int64_t)j * stride + c];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_solid_bonds(int q6index, const double *
     const double *ar = qlm_r + i * stride + q6index * nz, *ai = qlm_i + i * stride + q6index * nz;
     for (int jj = 0; jj < cnt; ++jj) {
         const int j = verlet[i * M + jj];
-        if (j < 0) continue;
+        if ((unsigned)j >= (unsigned)N) continue;
         if (dist[i * M + jj] > rc) continue;
         const double *br = qlm_r + (int64_t)j * stride + q6index * nz, *bi = qlm_i + (int64_t)j * stride + q6index * nz;
         double s = 0.0;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_solid_cleanup(const int *__restrict__ v
         cnt = nnn;
     for (int jj = 0; jj < cnt; ++jj) {
         const int j = verlet[i * M + jj];
-        if (j < 0) continue;
+        if ((unsigned)j >= (unsigned)N) continue;
         if (snap[j] == 1) return;
     }
     solid[i] = 0;

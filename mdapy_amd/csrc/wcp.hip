@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_wcp_count(const int *__restrict__ verle
         atomicAdd(&lds[T * T + T + ti], 1u);
         atomicAdd(&lds[T * T + ti], (unsigned)n);
         for (int q = 0; q < n; ++q)
-            atomicAdd(&lds[ti * T + type[verlet[i * M + q]]], 1u);
+            atomicAdd(&lds[ti * T + type[safe_id(verlet[i * M + q], i, N)]], 1u);
     }
     __syncthreads();
     for (int q = threadIdx.x; q < words; q += blockDim.x) {
