@@ -165,7 +165,9 @@ __device__ __forceinline__ int scan_centre(const DBox &b, const TileLds &L, cons
 }
 
 // CELLSHIFT: image numbers from codes (PBCMODE 0/1 chosen per tile); otherwise the exact search (PBCMODE 2)
-template <bool CELLSHIFT, int MODE>
+// LIST: the workgroup takes its tiles from the list of live tiles and may take more than one (partly empty box); otherwise
+// workgroup b owns tile b of a box that is full of atoms (straight-line code)
+template <bool CELLSHIFT, int MODE, bool LIST>
 __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     // XCD-aware tile order: block b runs on XCD b%8; give every XCD one contiguous chunk of the tiles THAT HOLD CENTRE ATOMS
     // (tile_list, in tile order) so that neighbouring tiles (which share halo cells) meet in the same L2 and an empty part
     // of the box (vacuum, the other ranks' slabs of a decomposed system) leaves no XCD idle.
-    const int nlive = tile_list ? *n_live : nt0 * nt1 * nt2; // no list: every tile is live (a box that is full of atoms)
+    const int nlive = (LIST && tile_list) ? *n_live : nt0 * nt1 * nt2; // no list: every tile is live
     const int per = (nlive + 7) / 8;
     const int tid = threadIdx.x;
     // the grid is sized from the last known occupancy; a workgroup takes further tiles of its XCD's chunk if that was too few
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     const int slot = (blockIdx.x & 7) * per + jt;
     if (slot >= nlive)
         break;
-    const int tile_id = tile_list ? tile_list[slot] : slot;
+    const int tile_id = (LIST && tile_list) ? tile_list[slot] : slot;
     const int t2 = tile_id % nt2, t1 = (tile_id / nt2) % nt1, t0 = tile_id / (nt2 * nt1);
     const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
 
@@ -360,6 +362,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         }
         __syncthreads();
     }
+    if (!LIST)
+        break;
     if (jt + (int)(gridDim.x >> 3) < per) __syncthreads(); // LDS is reused by the next tile
     } // tiles of this workgroup
 }
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256) void k_count_occupied(const int *__restrict__ 
 }
 
 namespace {
-struct OccEntry { int64_t N, ncell; int device; int *host; };
+struct OccEntry { int64_t N, ncell; int device; int *host; unsigned calls; };
 std::mutex g_occ_mu;
 std::vector<OccEntry> g_occ;
 } // namespace
@@ -454,20 +458,25 @@ std::vector<OccEntry> g_occ;
 int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occupied)
 {
     hipStream_t st = sc.stream();
-    int *dcnt = sc.alloc_n<int>(1);
-    if (sc.failed())
-        return sc.error();
-    MDH_HIP(hipMemsetAsync(dcnt, 0, sizeof(int), st));
-    const int blocks = (int)std::min<int64_t>((cg.g.ncell / 64 + 255) / 256 + 1, 4096);
-    hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(256), 0, st, cg.cell_start, cg.g, dcnt);
     int device = 0;
     (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lk(g_occ_mu);
+    auto count = [&](int *host_dst) -> int {
+        int *dcnt = sc.alloc_n<int>(1);
+        if (sc.failed())
+            return sc.error();
+        MDH_HIP(hipMemsetAsync(dcnt, 0, sizeof(int), st));
+        const int blocks = (int)std::min<int64_t>((cg.g.ncell / 64 + 255) / 256 + 1, 4096);
+        hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(256), 0, st, cg.cell_start, cg.g, dcnt);
+        MDH_HIP(hipMemcpyAsync(host_dst, dcnt, sizeof(int), hipMemcpyDeviceToHost, st));
+        return MDH_OK;
+    };
     for (auto &e : g_occ)
         if (e.N == N && e.ncell == cg.g.ncell && e.device == device) {
             const int last = *(volatile int *)e.host;
             *occupied = last > 0 ? last : cg.g.ncell;
-            MDH_HIP(hipMemcpyAsync(e.host, dcnt, sizeof(int), hipMemcpyDeviceToHost, st)); // for the next call
+            if ((++e.calls & 7u) == 0) // the occupied region of a running simulation drifts slowly: recount every 8th call
+                MDH_TRY(count(e.host));
             return MDH_OK;
         }
     int *host = nullptr;
@@ -477,10 +486,10 @@ int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occup
     } else {
         MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int), hipHostMallocDefault));
     }
-    MDH_HIP(hipMemcpyAsync(host, dcnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDH_TRY(count(host));
     MDH_HIP(hipStreamSynchronize(st));
     *occupied = *host > 0 ? *host : cg.g.ncell;
-    g_occ.push_back(OccEntry{N, cg.g.ncell, device, host});
+    g_occ.push_back(OccEntry{N, cg.g.ncell, device, host, 0u});
     return MDH_OK;
 }
 
@@ -525,10 +534,14 @@ static void launch_one(hipStream_t st, const CellGrid &cg, const DBox &b, double
     const size_t lds = tiled_lds_bytes(M);
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
-    if (fill_pads)
-        hipLaunchKernelGGL((k_neighbor_tiled<CS, 2>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
-    else
-        hipLaunchKernelGGL((k_neighbor_tiled<CS, 1>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
+    const bool list = tile_list != nullptr || standby || per * 8 < ntiles; // full box, one tile per workgroup: the straight-line kernel
+    if (fill_pads) {
+        if (list) hipLaunchKernelGGL((k_neighbor_tiled<CS, 2, true>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
+        else hipLaunchKernelGGL((k_neighbor_tiled<CS, 2, false>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
+    } else {
+        if (list) hipLaunchKernelGGL((k_neighbor_tiled<CS, 1, true>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
+        else hipLaunchKernelGGL((k_neighbor_tiled<CS, 1, false>), grid, block, lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, mp_shift, cg.flags, tile_flag, nt[0], nt[1], nt[2], want_moved, ts, tile_list, n_live);
+    }
 }
 
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
