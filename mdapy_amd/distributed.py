@@ -21,7 +21,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from . import _cna, _csp, _fast_knn, _neighbor, _ptm, _rdf, _wcp
+from . import _cna, _csp, _fast_knn, _neighbor, _ptm, _rdf, _sbo, _wcp
 from .box import Box
 
 
@@ -323,6 +323,33 @@ def knn_analysis_step(dec: SlabDecomposition, x, y, z, gid, what=("acna", "csp",
         out["ptm_indices"] = ind
     out["knn_idx"], out["knn_dist"], out["valid"] = idx, dst, valid
     return dom, out
+
+
+def steinhardt_step(dec: SlabDecomposition, x, y, z, gid, llist, rc: float, max_neigh: int, average: bool = False,
+                    wl: bool = False, wlhat: bool = False):
+    """Steinhardt q_l (w_l, w_l-hat) of the owned atoms over all neighbours within ``rc`` (steinhardt_bond_orientation.py:
+    cutoff mode, src/steinhardt_bond_orientation.cpp:288-575).  q_lm of an atom needs its neighbours within rc: halo rc.
+    ``average=True`` (Lechner-Dellago) also needs the q_lm of those neighbours, i.e. THEIR neighbourhoods: halo 2 rc, no second
+    exchange.  Rows come from the keyed neighbor build, so sums run in the order of the undivided system: identical bits.
+    Returns (dom, qnarray) in ``dom`` order; rows with ``dom.owned`` are meaningful."""
+    t = _torch()
+    dom = dec.exchange_halo(x, y, z, gid, (2.0 if average else 1.0) * rc, sort=False)
+    n = int(dom.x.shape[0])
+    b = dec.box
+    dev = dom.x.device
+    verlet = t.empty((n, max_neigh), dtype=t.int32, device=dev)
+    dist = t.empty((n, max_neigh), dtype=t.float64, device=dev)
+    nn = t.empty((n,), dtype=t.int32, device=dev)
+    _neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
+                             key=dom.gid if dec.world > 1 else None)
+    ll = np.ascontiguousarray(np.asarray(llist), dtype=np.int32)
+    nl, lmax = int(ll.shape[0]), int(ll.max())
+    qlm_r = t.zeros((n, nl, 2 * lmax + 1), dtype=t.float64, device=dev)
+    qlm_i = t.zeros((n, nl, 2 * lmax + 1), dtype=t.float64, device=dev)
+    qn = t.zeros((n, nl * (1 + int(bool(wl)) + int(bool(wlhat)))), dtype=t.float64, device=dev)
+    _sbo.get_sq(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, dist, nn, np.zeros((2, 2)), ll, 0, lmax, wl, wlhat,
+                average, False, rc, False, qlm_r, qlm_i, qn, 1)
+    return dom, qn
 
 
 def _gather_by_gid(dec: SlabDecomposition, gid, values):

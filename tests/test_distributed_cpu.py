@@ -53,8 +53,13 @@ def _worker(rank, world, port, q):
         def fcna(x, y, z, box, origin, boundary, v, nn, pat, rc, num_t=1):
             O.fcna(x.numpy(), y.numpy(), z.numpy(), box, origin, boundary, v.numpy(), nn.numpy(), pat.numpy(), rc, 2)
 
+        def get_sq(x, y, z, box, origin, boundary, v, d, nn, w, ll, nnn, lmax, wl, wlhat, average, use_vor, rc, use_w, qr, qi, qn, num_t=1):
+            O.get_sq(x.numpy(), y.numpy(), z.numpy(), box, origin, boundary, v.numpy(), d.numpy(), nn.numpy(), w, ll, nnn, lmax, wl, wlhat,
+                     average, use_vor, rc, use_w, qr.numpy(), qi.numpy(), qn.numpy(), 2)
+
         D._neighbor = type("M", (), {"build_neighbor": staticmethod(build_neighbor)})
         D._cna = type("M", (), {"fcna": staticmethod(fcna)})
+        D._sbo = type("M", (), {"get_sq": staticmethod(get_sq)})
 
         a = 3.615
         pos, boxm = lattice_positions("fcc", a, 12, 6, 6)
@@ -85,6 +90,18 @@ def _worker(rank, world, port, q):
         vglob = np.where(vloc >= 0, gid[np.clip(vloc, 0, None)], -1)   # local indices -> global ids
         ok = (np.array_equal(nn.numpy()[own], NN[g_own]) and np.array_equal(vglob, V[g_own])
               and np.array_equal(d.numpy()[own], Dd[g_own]) and np.array_equal(pat.numpy()[own], P[g_own]))
+        # Steinhardt q4, q6 (+ w_l) over the cutoff list, plain and neighbour-averaged: bit-identical to the whole system's
+        ll = np.array([4, 6], np.int32)
+        Mq = int(NN.max())
+        Vq = np.full((len(x), Mq), -1, np.int32); Dq = np.full((len(x), Mq), rc + 1.0); Nq = np.zeros(len(x), np.int32)
+        O.build_neighbor(x, y, z, boxm, org, bnd, rc, Vq, Dq, Nq, 2)
+        for average in (False, True):
+            qr = np.zeros((len(x), 2, 13)); qi = np.zeros((len(x), 2, 13)); qn = np.zeros((len(x), 4))
+            O.get_sq(x, y, z, boxm, org, bnd, Vq, Dq, Nq, np.zeros((2, 2)), ll, 0, 6, True, False, average, False, rc, False, qr, qi, qn, 2)
+            dq, qloc = D.steinhardt_step(dec, t(pos[owned_ids, 0]), t(pos[owned_ids, 1]), t(pos[owned_ids, 2]), t(owned_ids), ll, rc, Mq,
+                                         average=average, wl=True)
+            oq = dq.owned.numpy()
+            ok = ok and np.array_equal(qloc.numpy()[oq], qn[dq.gid.numpy()[oq]])
         q.put((rank, bool(ok), int(own.sum()), int((~own).sum())))
     except Exception as e:  # pragma: no cover
         import traceback
