@@ -245,6 +245,15 @@ int mdh_filter_overlap_atom(const double *x, const double *y, const double *z, i
                             const double *origin3_host, const int *boundary3_host, double rc, unsigned char *keep,
                             int space, void *stream);
 
+/* replaces _neighbor.filter_overlap_atom_with_grain          src/neighbor.cpp:489-672 (graphene-decorated polycrystals)
+ * type: 1 metal / 2 carbon, grain_id per atom.  keep (N) u8 = the result of the reference's sweep run SERIALLY (index order;
+ * metal-metal: the higher index goes; carbon-carbon: same grain -> higher index, different grains -> larger grain id;
+ * metal-carbon: the metal goes; removed atoms do not act).  With several threads the reference's result depends on the schedule. */
+int mdh_filter_overlap_atom_with_grain(const double *x, const double *y, const double *z, const int *type, const int *grain_id,
+                                       int64_t N, const double *box9_host, const double *origin3_host, const int *boundary3_host,
+                                       double rc_metal_metal, double rc_cc, double rc_metal_c, unsigned char *keep, int space,
+                                       void *stream);
+
 /* replaces _polycrystal.transform_and_filter                src/polycrystal.cpp:20-125 (polycrystal builder)
  * p' = R (p - center) + target (rotation9 = row-major R, i.e. (p - center) @ R.T); kept when
  * a*p'x + b*p'y + c*p'z + d < 0 for every row (a,b,c,d) of coeffs (nf <= 1024, host array); survivors in input order in

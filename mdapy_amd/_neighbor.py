@@ -97,3 +97,19 @@ def filter_overlap_atom(x, y, z, box, origin, boundary, rc, num_t=1):
                                              out.ctypes.data, c.space, c.stream)
     c.done(rc_)
     return out.astype(bool)
+
+
+def filter_overlap_atom_with_grain(x, y, z, type_list, grain_id, box, origin, boundary, rc_metal_metal, rc_cc, rc_metal_c, num_t=1):
+    """src/neighbor.cpp:489 — bool array of the atoms that stay (type 1 metal / 2 carbon, grain ids); the reference's sweep as it
+    runs with one thread (with several its result depends on the schedule)"""
+    keep_, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    n = int(len(x))
+    _lib.same_rows("filter_overlap_atom_with_grain", n, y=y, z=z, type=type_list, grain_id=grain_id)
+    xs, ys, zs = (np.ascontiguousarray(np.asarray(a, f64)) for a in (x, y, z))
+    t = np.ascontiguousarray(np.asarray(type_list), dtype=i32)
+    g = np.ascontiguousarray(np.asarray(grain_id), dtype=i32)
+    out = np.zeros(n, np.uint8)
+    _lib.check(_lib.lib().mdh_filter_overlap_atom_with_grain(xs.ctypes.data, ys.ctypes.data, zs.ctypes.data, t.ctypes.data, g.ctypes.data, n,
+                                                             pb, po, pp, float(rc_metal_metal), float(rc_cc), float(rc_metal_c),
+                                                             out.ctypes.data, _lib.HOST, None))
+    return out.astype(bool)

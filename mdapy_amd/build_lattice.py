@@ -40,7 +40,12 @@ def unit_cell(structure: str, a: float, c: Optional[float] = None):
             c = a * float(np.sqrt(8 / 3))
         box = np.array([[a, 0.0, 0.0], [-0.5 * a, 0.5 * _SQRT3 * a, 0.0], [0.0, 0.0, c]])
         return box, np.array([[0.0, 0.0, 0.0], [1.0 / 3.0, 2.0 / 3.0, 0.5]])
-    raise ValueError(f"Unrecognized structure '{structure}'. Supported here: {sorted(_CUBIC) + ['hcp']}")
+    if s == "graphene":  # build_lattice.py:238-251: one honeycomb layer in the hexagonal cell, c = vacuum spacing (must be given)
+        if c is None:
+            raise ValueError("graphene needs c (the spacing of the periodic images along z)")
+        box = np.array([[a, 0.0, 0.0], [-0.5 * a, 0.5 * _SQRT3 * a, 0.0], [0.0, 0.0, c]])
+        return box, np.array([[0.0, 0.0, 0.0], [1.0 / 3.0, 2.0 / 3.0, 0.0]])
+    raise ValueError(f"Unrecognized structure '{structure}'. Supported here: {sorted(_CUBIC) + ['hcp', 'graphene']}")
 
 
 def lattice_positions(structure: str, a: float, nx: int = 1, ny: int = 1, nz: int = 1, c: Optional[float] = None):

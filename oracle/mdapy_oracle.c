@@ -1509,6 +1509,44 @@ ORC_API int orc_identify_sftb_fcc(const int *hcp_idx, int64_t n_hcp, int *hn, co
     return 0;
 }
 
+/* _neighbor.filter_overlap_atom_with_grain                             src/neighbor.cpp:489-672, run with ONE thread
+ * (the reference's parallel loop reads and sets the removal flags concurrently; its serial order is the defined one).
+ * Brute force over pairs instead of the cell list: the cell list only prunes, it does not change which pairs interact. */
+ORC_API int orc_filter_overlap_atom_with_grain(const double *x, const double *y, const double *z, const int *type, const int *grain,
+                                               int64_t N, const double *box9, const double *origin, const int *boundary,
+                                               double rc_mm, double rc_cc, double rc_mc, unsigned char *keep)
+{
+    obox b;
+    if (obox_init(&b, box9, origin, boundary))
+        return -1;
+    unsigned char *removed = (unsigned char *)calloc((size_t)(N > 0 ? N : 1), 1);
+    const double q_mm = rc_mm * rc_mm, q_cc = rc_cc * rc_cc, q_mc = rc_mc * rc_mc;
+    const int anypbc = boundary[0] || boundary[1] || boundary[2];
+    for (int64_t i = 0; i < N; ++i) {
+        if (removed[i]) continue; /* :548-551 */
+        double xi = x[i], yi = y[i], zi = z[i];
+        if (anypbc) obox_wrap(&b, &xi, &yi, &zi); /* :557-560 */
+        for (int64_t j = i + 1; j < N; ++j) {
+            if (removed[j]) continue;
+            double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+            obox_pbc(&b, &dx, &dy, &dz);
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            int64_t target = -1;
+            if (type[i] == 1 && type[j] == 1) {
+                if (d2 <= q_mm) target = j;
+            } else if (type[i] == 2 && type[j] == 2) {
+                if (d2 <= q_cc) target = (grain[i] != grain[j]) ? ((grain[i] > grain[j]) ? i : j) : j;
+            } else if (type[i] != type[j]) {
+                if (d2 <= q_mc) target = (type[i] == 1) ? i : j;
+            }
+            if (target >= 0) removed[target] = 1;
+        }
+    }
+    for (int64_t i = 0; i < N; ++i) keep[i] = removed[i] ? 0 : 1;
+    free(removed);
+    return 0;
+}
+
 /* _polycrystal.transform_and_filter                                  src/polycrystal.cpp:20-125
  * out (n,3) capacity; returns the number of survivors (input order) */
 ORC_API int64_t orc_transform_and_filter(const double *x, const double *y, const double *z, int64_t n, const double *R,

@@ -375,6 +375,18 @@ def filter_overlap_atom(x, y, z, box, origin, boundary, rc, num_t=1):
     return keep.astype(bool)
 
 
+def filter_overlap_atom_with_grain(x, y, z, type_list, grain_id, box, origin, boundary, rc_metal_metal, rc_cc, rc_metal_c, num_t=1):
+    """mdapy._neighbor.filter_overlap_atom_with_grain (src/neighbor.cpp:489), serial order -> bool (N)"""
+    x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)
+    t, g = _ro(type_list, np.int32), _ro(grain_id, np.int32)
+    b, o, p = _boxargs(box, origin, boundary)
+    keep = np.zeros(len(x), np.uint8)
+    _chk(lib().orc_filter_overlap_atom_with_grain(_p(x, np.float64), _p(y, np.float64), _p(z, np.float64), _p(t, np.int32), _p(g, np.int32),
+                                                  i64(len(x)), _p(b, np.float64), _p(o, np.float64), _p(p, np.int32), dbl(rc_metal_metal),
+                                                  dbl(rc_cc), dbl(rc_metal_c), keep.ctypes.data_as(C.c_void_p)))
+    return keep.astype(bool)
+
+
 def transform_and_filter(x, y, z, rotation_matrix, center, target_center, coeffs, num_t=1):
     """mdapy._polycrystal.transform_and_filter (src/polycrystal.cpp:20) -> (count, 3)"""
     x, y, z = _ro(x, np.float64), _ro(y, np.float64), _ro(z, np.float64)

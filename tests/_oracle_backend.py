@@ -36,6 +36,8 @@ neighbor = _mod(
         O.average_by_neighbor(rc, _np(v), _np(d), _np(nn), _np(value), out, inc, NT),
     filter_overlap_atom=lambda x, y, z, box, origin, boundary, rc, num_t=1:
         O.filter_overlap_atom(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT),
+    filter_overlap_atom_with_grain=lambda x, y, z, t, g, box, origin, boundary, mm, cc, mc, num_t=1:
+        O.filter_overlap_atom_with_grain(_np(x), _np(y), _np(z), _np(t), _np(g), box, origin, boundary, mm, cc, mc, NT),
 )
 polycrystal = _mod(
     transform_and_filter=lambda x, y, z, rot, c, t, pl, num_t=1: O.transform_and_filter(_np(x), _np(y), _np(z), rot, c, t, pl, NT),

@@ -443,3 +443,25 @@ def test_transform_and_filter_oracle_vs_numpy():
     assert np.allclose(out, new[inside], rtol=0, atol=1e-12)  # same atoms, same order
     assert len(_O.transform_and_filter(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), q, centre, target, np.array([[0, 0, 0, 1.0]]))) == 0
     assert len(_O.transform_and_filter(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), q, centre, target, np.zeros((0, 4)))) == len(pos)
+
+
+def test_filter_overlap_atom_with_grain_oracle_hand_cases():
+    """src/neighbor.cpp:489-672 in serial order, on pairs and chains whose outcome can be read off the rules"""
+    box, org, bd = np.eye(3) * 20.0, np.zeros(3), np.ones(3, np.int32)
+
+    def run(pos, types, grains, mm=2.0, cc=1.4, mc=3.0):
+        p = np.asarray(pos, float)
+        return _O.filter_overlap_atom_with_grain(p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy(), np.asarray(types, np.int32),
+                                                 np.asarray(grains, np.int32), box, org, bd, mm, cc, mc).tolist()
+
+    assert run([[1, 1, 1], [2.5, 1, 1]], [1, 1], [1, 2]) == [True, False]            # metal-metal: the higher index goes
+    assert run([[1, 1, 1], [2.0, 1, 1]], [2, 2], [3, 1]) == [False, True]            # carbon-carbon, grains differ: larger grain id goes
+    assert run([[1, 1, 1], [2.0, 1, 1]], [2, 2], [1, 1]) == [True, False]            # same grain: the higher index goes
+    assert run([[1, 1, 1], [3.5, 1, 1]], [2, 1], [1, 1]) == [True, False]            # metal-carbon: the metal goes (here j)
+    assert run([[1, 1, 1], [3.5, 1, 1]], [1, 2], [1, 1]) == [False, True]            # ... and here i
+    # a chain of metals 1.5 apart: 0 removes 1; 1 no longer acts, so 2 stays; 2 removes 3
+    assert run([[1, 1, 1], [2.5, 1, 1], [4.0, 1, 1], [5.5, 1, 1]], [1] * 4, [1] * 4) == [True, False, True, False]
+    # across the periodic face
+    assert run([[0.3, 1, 1], [19.5, 1, 1]], [1, 1], [1, 2]) == [True, False]
+    # a metal that removes itself against a carbon still removes a later metal in the same turn
+    assert run([[1, 1, 1], [3.0, 1, 1], [2.0, 2.0, 1]], [1, 2, 1], [1, 1, 2]) == [False, True, False]
