@@ -160,7 +160,9 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
         nfaces[i] = nf;
         radius[i] = 2.0 * rmax;
         const double reach = nn[i] > VORO_MAXC ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
-        if (2.0 * rmax > reach || nn[i] > M)
+        // no face at all: nothing within the search radius cut the bounding cube (a lone atom of a tiny periodic cell) —
+        // the cell is not known yet, whatever the vertex distances of an empty face list say
+        if (2.0 * rmax > reach || nn[i] > M || nf == 0)
             atomicAdd(incomplete, 1);
         if (max_faces && i < n_orig) atomicMax(max_faces, nf);
     }

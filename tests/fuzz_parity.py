@@ -75,6 +75,8 @@ def checks(s):
     out = [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc)),
            ("sort_cna", lambda: T.test_sort_and_cna_vs_oracle(case)),
            ("overlap", lambda: T.test_filter_overlap_atom_vs_oracle("fuzz"))]
+    if len(s["pos"]) >= 300 and s["kind"] in ("fcc", "bcc", "blob"):  # (the check also wants some atoms removed by its last cutoff set)
+        out += [("overlap_grain", lambda: T.test_filter_overlap_atom_with_grain_vs_oracle("fuzz"))]
     if not s["unwrapped"] and (len(s["pos"]) >= 20 or all(s["bnd"])):  # open box with fewer atoms than neighbours asked for: the reference indexes x[-1]
         out += [("knn", lambda: T.test_knn_general_vs_oracle(case)),
                 ("steinhardt_rc", lambda: T.test_steinhardt_vs_oracle(case, "rc")),

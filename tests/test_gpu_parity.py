@@ -1142,3 +1142,25 @@ def test_create_polycrystal_with_graphene_hip_equals_oracle_build(monkeypatch):
     tj = ty[np.clip(v, 0, None)]
     assert not (valid & (ty[:, None] != tj)).any()
     assert not (valid & (ty[:, None] == 1) & (tj == 1) & (d <= 2.0 - 1e-9)).any()
+
+
+@needs_voro
+def test_voronoi_few_atoms_in_a_small_periodic_cell():
+    """2 ... 8 atoms in a cell of a few Angstrom: every face is shared with a periodic image; an atom that has nobody within
+    the first search radius must not come back with an empty cell"""
+    for N in (2, 3, 4, 8):
+        for seed in range(6):
+            rng = np.random.default_rng(100 * N + seed)
+            L = rng.uniform(6, 11, 3)
+            box, pos = np.diag(L), rng.random((N, 3)) * L
+            x, y, z = _xyz(pos)
+            v0, n0, r0 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
+            O.get_voronoi_volume_number_radius(x, y, z, box, ORG0, PBC, v0, n0, r0)
+            v1, n1, r1 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
+            _voronoi.get_voronoi_volume_number_radius(x, y, z, box, ORG0, PBC, v1, n1, r1)
+            assert np.allclose(v1, v0, rtol=1e-9) and np.allclose(r1, r0, rtol=1e-9) and np.array_equal(n1, n0)
+            assert abs(v1.sum() - L.prod()) < 1e-9 * L.prod()
+    v1, n1, r1 = np.zeros(1), np.zeros(1, np.int32), np.zeros(1)
+    _voronoi.get_voronoi_volume_number_radius(np.array([1.0]), np.array([2.0]), np.array([3.0]), np.diag([4.0, 5.0, 6.0]), ORG0,
+                                              np.zeros(3, np.int32), v1, n1, r1)
+    assert abs(v1[0] - 120.0) < 1e-12 and n1[0] == 6  # a lone atom in an open box owns the box
