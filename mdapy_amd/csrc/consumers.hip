@@ -343,14 +343,26 @@ __global__ __launch_bounds__(256) void k_cc_hook(const int *__restrict__ verlet,
     if (any) *changed = 1;
 }
 
-__global__ __launch_bounds__(256) void k_cc_flatten(int *__restrict__ parent, int64_t N, unsigned *__restrict__ is_root)
+// read-only walk to the root (the forest no longer changes once the hooking passes are over)
+__device__ __forceinline__ int cc_root(const int *__restrict__ parent, int i)
+{
+    int p = parent[i];
+    while (p != i) {
+        i = p;
+        p = parent[p];
+    }
+    return i;
+}
+
+// Roots only.  No pointer is written here or in k_cc_label: a path-halving store of one thread (a stale grandparent) landing
+// after another thread's "parent[i] = root" left atoms pointing at a non-root, whose rank is not a cluster number (found by
+// the randomised sweep: same clusters, ids off by the number of roots skipped).
+__global__ __launch_bounds__(256) void k_cc_flatten(const int *__restrict__ parent, int64_t N, unsigned *__restrict__ is_root)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    const int r = cc_find(parent, (int)i);
-    parent[i] = r;
-    is_root[i] = r == (int)i ? 1u : 0u;
+    is_root[i] = parent[i] == (int)i ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_cc_label(const int *__restrict__ parent, const int *__restrict__ rank, int64_t N,
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256) void k_cc_label(const int *__restrict__ parent
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    cluster[i] = rank[parent[i]] + 1; // clusters are numbered by their smallest atom index, from 1 (:23-27)
+    cluster[i] = rank[cc_root(parent, (int)i)] + 1; // clusters are numbered by their smallest atom index, from 1 (:23-27)
     if (i == 0) *count = rank[N];
 }
 

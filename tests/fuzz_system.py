@@ -147,6 +147,17 @@ def run_seed(seed, fails):
         bad += [f"curve {k}" for k in ca if k not in cb or not same(ca[k], cb[k])]
         if bad:
             fails.append((seed, label, "differs: " + ", ".join(bad)))
+            if os.environ.get("FUZZ_DEBUG") and hasattr(a, "verlet_list") and hasattr(b, "verlet_list"):
+                va, vb = np.asarray(a.verlet_list), np.asarray(b.verlet_list)
+                print("   debug", seed, label, "lists", va.shape, vb.shape, "equal", va.shape == vb.shape and np.array_equal(va, vb),
+                      "dist equal", np.array_equal(np.asarray(a.distance_list), np.asarray(b.distance_list)),
+                      "nn equal", np.array_equal(np.asarray(a.neighbor_number), np.asarray(b.neighbor_number)),
+                      "rc", getattr(a, "rc", None), getattr(b, "rc", None), "ncl", getattr(a, "cluster_number", None), getattr(b, "cluster_number", None), flush=True)
+                if "cluster_id" in a.data.columns:
+                    ca, cb = a.data["cluster_id"].to_numpy(), b.data["cluster_id"].to_numpy()
+                    w = np.flatnonzero(ca != cb)
+                    print("   debug ids: N", len(ca), "differ at", len(w), w[:8], "hip", ca[w[:8]], "oracle", cb[w[:8]], "hip min/max", ca.min(), ca.max(), "oracle min/max", cb.min(), cb.max(),
+                          "nn of those", np.asarray(a.neighbor_number)[w[:8]], flush=True)
             break
         ran += 1
     return ran
