@@ -100,6 +100,6 @@ PTM_HDN FaceResult voronoi_face(P &poly, int f, int nc, const double (*nrm)[3], 
 }
 
 // faces smaller than this fraction of the squared plane distance are rounding debris of a plane that only touches the cell
-constexpr double AREA_TOL = 1e-12;
+constexpr double AREA_TOL = 1e-14;
 
 } // namespace voroc

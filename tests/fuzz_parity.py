@@ -111,7 +111,10 @@ def main():
     fails, ran = [], 0
     while time.time() - t0 < budget:
         s = draw(seed)
+        only = os.environ.get("FUZZ_ONLY")
         for name, fn in checks(s):
+            if only and not name.startswith(only):
+                continue
             if os.environ.get("FUZZ_TRACE"):
                 print("seed", seed, name, flush=True)
             try:
