@@ -812,7 +812,7 @@ def test_voronoi_neighbors_vs_reference_library(case):
         L = np.diag(np.asarray(box, float)) if np.ndim(box) == 2 else np.asarray(box, float)
         vs = np.sort(np.where(v1 >= 0, v1, -np.arange(1, v1.shape[1] + 1)[None, :]), axis=1)
         once = (np.diff(vs, axis=1) != 0).all(axis=1)  # rows in which no neighbour appears through two images
-        if 2.0 * d1[v1 >= 0].max() < L[np.asarray(bd) != 0].min(initial=np.inf):
+        if 4.0 * d1[v1 >= 0].max() < L[np.asarray(bd) != 0].min(initial=np.inf):  # no cell reaches a farther image
             assert np.all(np.diff(dd[once], axis=1) >= 0)
         assert np.all(np.diff((v1 < 0).astype(int), axis=1) >= 0)
 
