@@ -30,6 +30,12 @@
 // slots of a row, so a wave store covers whole 64 B / 128 B row segments instead of 64 scattered
 // rows; the distance is recomputed from the same operands (identical bits).  With fill_pads the
 // same pass writes the -1 / rc+1 pads.
+//
+// Partly empty boxes (vacuum around a slab or a particle, a rank's slab of a decomposed system).  The tile shape is sized
+// for the population of the OCCUPIED region (occupied_cells_hint: counted on the device, read by the next call), the XCD
+// chunks are cut from the list of tiles that hold centre atoms (k_tile_live + scan), and the launch grid follows the same
+// estimate — a workgroup takes further tiles of its chunk when the estimate was too small.  A box that is full of atoms
+// takes the straight-line instance (LIST = false): workgroup b owns tile b.
 #include "common.hpp"
 #include "grid.hpp"
 #include <algorithm>
