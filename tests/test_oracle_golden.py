@@ -465,3 +465,43 @@ def test_filter_overlap_atom_with_grain_oracle_hand_cases():
     assert run([[0.3, 1, 1], [19.5, 1, 1]], [1, 1], [1, 2]) == [True, False]
     # a metal that removes itself against a carbon still removes a later metal in the same turn
     assert run([[1, 1, 1], [3.0, 1, 1], [2.0, 2.0, 1]], [1, 2, 1], [1, 1, 2]) == [False, True, False]
+
+
+def test_dense_labels_equals_the_reference_mapping():
+    """tool.dense_labels == sorted(set(labels)) + per-atom dictionary lookup (radial_distribution_function.py:136-142)"""
+    from mdapy_amd import tool_function as tool
+
+    rng = np.random.default_rng(1)
+    for raw in (np.array(["Cu", "Al", "Cu", "Ni", "Al"]), rng.integers(1, 5, 1000).astype(np.int32), np.full(50, 7, np.int64),
+                np.array(["Fe"] * 9), np.array([], np.int32)):
+        names, idx = tool.dense_labels(raw)
+        ref_names = sorted(set(raw.tolist()))
+        lut = {v: i for i, v in enumerate(ref_names)}
+        assert names == ref_names and idx.dtype == np.int32
+        assert np.array_equal(idx, np.array([lut[v] for v in raw.tolist()], dtype=np.int32))
+
+
+def test_readers_fast_and_line_by_line_paths_agree(monkeypatch):
+    """the pandas tokenizer path of load_save returns the values and dtypes of the line-by-line parser on every input file
+    of the reference's test-suite"""
+    import glob
+    import os
+
+    import mdapy_amd.load_save as LS
+
+    pytest.importorskip("pandas")
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "golden", "input_files", "*")))
+    assert files
+    for f in files:
+        fast = LS.read_file(f)
+        with monkeypatch.context() as m:
+            m.setattr(LS, "_table", lambda *a, **k: None)
+            slow = LS.read_file(f)
+        assert fast[0].columns == slow[0].columns and np.array_equal(fast[1].box, slow[1].box)
+        for c in fast[0].columns:
+            a, b = fast[0][c].to_numpy(), slow[0][c].to_numpy()
+            if a.dtype == object or b.dtype == object:
+                assert list(a) == list(b)
+            else:
+                assert a.dtype == b.dtype and np.array_equal(a, b)
