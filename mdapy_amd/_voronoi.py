@@ -117,10 +117,8 @@ def get_cell_info(x, y, z, box, origin, boundary, num_t=1):
     for a in range(3):  # the container holds periodic coordinates folded into [0, L)
         if bd[a]:
             p[:, a] -= h[a, a] * np.floor(p[:, a] / h[a, a])
-    face_idx, face_pos, areas = [], [], []
-    for i in range(n):
+    def assemble(i, tol):
         verts, faces, ar = [], [], []
-        tol = 1e-9 * max(float(rad[i]), 1e-300)
         for s_ in range(W):
             m = int(fnv[i, s_])
             if m == 0:
@@ -140,6 +138,19 @@ def get_cell_info(x, y, z, box, origin, boundary, num_t=1):
                     ids.append(hit)
             faces.append(ids)
             ar.append(float(farea[i, s_]))
+        return verts, faces, ar
+
+    face_idx, face_pos, areas = [], [], []
+    for i in range(n):
+        # The copies of a shared vertex agree to rounding, usually ~1e-13 of the cell size, worse where planes meet at a
+        # shallow angle.  The merge tolerance is the smallest one for which the faces close up into a polyhedron
+        # (Euler: V - E + F = 2 with every edge shared by two faces).
+        verts, faces, ar = assemble(i, 1e-9 * max(float(rad[i]), 1e-300))
+        for scale in (1e-8, 1e-7, 1e-6, 1e-5):
+            n_half_edges = sum(len(f) for f in faces)
+            if not faces or (n_half_edges % 2 == 0 and len(verts) - n_half_edges // 2 + len(faces) == 2):
+                break
+            verts, faces, ar = assemble(i, scale * max(float(rad[i]), 1e-300))
         face_idx.append(faces)
         face_pos.append([(p[i] + np.asarray(v)).tolist() for v in verts])
         areas.append(ar)
