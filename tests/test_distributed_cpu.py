@@ -258,3 +258,57 @@ def test_knn_analyses_and_reductions_match_single_process(world):
     for rank, ok, failed, n_own in sorted(res):
         assert ok is True, f"rank {rank}: {failed}"
     assert sum(r[3] for r in res) == 10 * 5 * 5 * 4
+
+
+def test_exchange_halo_merge_equals_sort_single_process(monkeypatch):
+    """The three local orders of exchange_halo — ascending id by MERGING (owned ids already ascending), ascending id by sorting
+    (arbitrary owned order) and owned-first (sort=False) — hold the same atoms; the first two are identical arrays.  The two P2P
+    exchanges are looped back: the slab receives shifted copies of its own boundary layers as its neighbours' atoms."""
+    import torch
+    import torch.distributed as dist
+
+    import mdapy_amd as mp
+    from mdapy_amd import distributed as D
+
+    world, rank, n = 4, 1, 4000
+    rng = np.random.default_rng(3)
+    Lx = 40.0
+    box = mp.Box(np.diag([Lx * world, 30.0, 30.0]))
+    pos = rng.random((n, 3)) * np.array([Lx, 30.0, 30.0]) + np.array([Lx * rank, 0.0, 0.0])
+    gid = np.arange(n, dtype=np.int64) * 3 + 100000  # ascending, with gaps
+
+    class _Op:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor = op, tensor
+
+    class _Work:
+        def wait(self):
+            pass
+
+    def loopback(ops):
+        sends = [o.tensor for o in ops if o.op is dist.isend]
+        recvs = [o.tensor for o in ops if o.op is dist.irecv]
+        if sends[0].dim() == 1:
+            recvs[0].copy_(sends[0]); recvs[1].copy_(sends[1])
+        else:
+            a, b = sends[0].clone(), sends[1].clone()
+            a[0] -= Lx; a[3] -= 50000      # the left neighbour's upper layer: smaller ids
+            b[0] += Lx; b[3] += 50000      # the right neighbour's lower layer: larger ids
+            recvs[0].copy_(a); recvs[1].copy_(b)
+        return [_Work()]
+
+    monkeypatch.setattr(dist, "batch_isend_irecv", loopback)
+    monkeypatch.setattr(dist, "P2POp", _Op)
+    dec = D.SlabDecomposition(box, rank, world, axis=0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    merged = dec.exchange_halo(t(pos[:, 0]), t(pos[:, 1]), t(pos[:, 2]), t(gid), 3.0)
+    perm = rng.permutation(n)  # arbitrary owned order -> the sorting branch
+    sorted_ = dec.exchange_halo(t(pos[perm, 0]), t(pos[perm, 1]), t(pos[perm, 2]), t(gid[perm]), 3.0)
+    plain = dec.exchange_halo(t(pos[:, 0]), t(pos[:, 1]), t(pos[:, 2]), t(gid), 3.0, sort=False)
+    assert bool((merged.gid[1:] > merged.gid[:-1]).all()) and int(merged.owned.sum()) == n and merged.x.shape[0] > n
+    for name in ("x", "y", "z", "gid", "owned"):
+        assert torch.equal(getattr(merged, name), getattr(sorted_, name))
+    order = torch.argsort(plain.gid)
+    assert bool(plain.owned[:n].all()) and not bool(plain.owned[n:].any())
+    for name in ("x", "y", "z", "gid", "owned"):
+        assert torch.equal(getattr(plain, name)[order], getattr(merged, name))
