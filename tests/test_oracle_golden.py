@@ -505,3 +505,33 @@ def test_readers_fast_and_line_by_line_paths_agree(monkeypatch):
                 assert list(a) == list(b)
             else:
                 assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+@pytest.mark.skipif(not _O.have_voro_ref(), reason="oracle/_ref/libvoro_ref.so missing")
+def test_create_polycrystal_host_logic_on_the_oracle(oracle_backend):
+    """CreatePolycrystal with its device calls routed to the oracle: every atom in the Voronoi cell of its grain's seed, bulk
+    density minus the boundary overlaps, reproducible from the random seed; graphene variant: carbon on the cell faces"""
+    unit = mp.build_crystal("Al", "fcc", 4.05)
+    kw = dict(box=48.0, seed_number=5, randomseed=12, metal_overlap_dis=2.0)
+    pa = mp.CreatePolycrystal(unit, **kw)
+    a = pa.compute()
+    b = mp.CreatePolycrystal(unit, **kw).compute()
+    assert a.N == b.N and np.array_equal(a.data["x"].to_numpy(), b.data["x"].to_numpy())
+    pos = np.c_[a.data["x"].to_numpy(), a.data["y"].to_numpy(), a.data["z"].to_numpy()]
+    d = pos[:, None, :] - pa.seed_position[None, :, :]
+    d -= 48.0 * np.round(d / 48.0)
+    assert np.array_equal(np.argmin((d ** 2).sum(-1), axis=1) + 1, a.data["grain_id"].to_numpy())
+    assert abs(pa.volume.sum() - 48.0 ** 3) < 1e-6 * 48.0 ** 3 and 0.88 < a.N / (48.0 ** 3 * 4 / 4.05 ** 3) < 1.0
+    assert pos.min() >= 0.0 and pos.max() < 48.0
+    g = mp.CreatePolycrystal(unit, add_graphene=True, face_threshold=5.0, **kw).compute()
+    ty = g.data["type"].to_numpy()
+    assert set(np.unique(ty).tolist()) == {1, 2} and set(g.data["element"].to_numpy()[ty == 2].tolist()) == {"C"}
+    gp = np.c_[g.data["x"].to_numpy(), g.data["y"].to_numpy(), g.data["z"].to_numpy()][ty == 2][::5]
+    shifts = np.array([[i, j, k] for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1)]) * 48.0
+    others = (pa.seed_position[None, :, :] + shifts[:, None, :]).reshape(-1, 3)
+    dist = np.sort(np.linalg.norm(others[None, :, :] - gp[:, None, :], axis=2), axis=1)
+    assert (dist[:, 1] - dist[:, 0]).max() < 1.1  # carbon within 0.5 A of a bisector plane of two seeds
+    with pytest.raises(ValueError, match="Triclinic"):
+        mp.CreatePolycrystal(unit, box=np.array([[48.0, 0, 0], [5.0, 48.0, 0], [0, 0, 48.0]]), seed_number=4)
+    with pytest.raises(ValueError, match="Free boundary"):
+        mp.CreatePolycrystal(unit, box=mp.Box(np.eye(3) * 48.0, boundary=[1, 1, 0]), seed_number=4)
