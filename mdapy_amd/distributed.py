@@ -140,8 +140,9 @@ class SlabDecomposition:
                dist.P2POp(dist.irecv, cnt_r[0], self.left, self.group), dist.P2POp(dist.irecv, cnt_r[1], self.right, self.group)]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        recv_l = t.empty((4, int(cnt_r[0].item())), dtype=t.float64, device=x.device)
-        recv_r = t.empty((4, int(cnt_r[1].item())), dtype=t.float64, device=x.device)
+        n_from_left, n_from_right = (int(v) for v in t.cat(cnt_r).tolist())  # one device-to-host read for both counts
+        recv_l = t.empty((4, n_from_left), dtype=t.float64, device=x.device)
+        recv_r = t.empty((4, n_from_right), dtype=t.float64, device=x.device)
         ops = [dist.P2POp(dist.isend, send_r, self.right, self.group), dist.P2POp(dist.isend, send_l, self.left, self.group),
                dist.P2POp(dist.irecv, recv_l, self.left, self.group), dist.P2POp(dist.irecv, recv_r, self.right, self.group)]
         for w in dist.batch_isend_irecv(ops):
