@@ -41,6 +41,9 @@ struct TiledPlan {
 struct TileFilter {
     const unsigned char *flag = nullptr;
     const int *any = nullptr;
+    const int *moved = nullptr; // != nullptr and *moved != 0: the tiled kernel stood down (unwrapped input), take every atom
+    const int *list = nullptr;  // != nullptr: ids of the flagged tiles, *any of them (k_neighbor_tiles walks the list; the flag scan over all atoms is skipped)
+    int list_cap = 0;
     int tile = 1, tile_z = 1;
     int nt[3] = {1, 1, 1};
 };
@@ -49,6 +52,26 @@ TiledPlan plan_tiled(const DBox &b, const Grid &g, int64_t N, int64_t M, int64_t
 int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occupied);
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
                           int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, TileFilter &tf);
+
+// neighbor_wave.hip: one wavefront per centre cell, one lane per candidate (see the file header)
+struct GridStats {
+    static constexpr int NBIN = 67; // v[0] = cells of the occupied region; v[1 + len] = 3-cell z-runs of that length (66: longer than 64)
+    int v[NBIN];
+};
+struct WavePlan {
+    int txy, tz;      // tile shape in cells; txy == 0: not applicable
+    int cap;          // atoms a tile's halo may hold in LDS
+    int S, NG;        // lanes per run, groups of 64 lanes per centre
+    float lo, hi;     // decision band of the single-precision scan around rc^2
+    float mid, T;     // the same band as centre (rc^2 in single precision) and half-width
+    bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live
+    int64_t occupied; // cells of the occupied region (last known)
+};
+int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out);
+WavePlan plan_wave(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc);
+int launch_neighbor_wave(Scope &sc, const CellGrid &cg, const WavePlan &plan, int64_t N, const DBox &b, double rc,
+                         int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,
+                         TileFilter &tf);
 
 __host__ __device__ __forceinline__ int pmod(int a, int n) // neighbor.cpp:18-22
 {

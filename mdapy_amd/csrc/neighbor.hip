@@ -21,7 +21,7 @@
 
 namespace mdh {
 
-int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel (A/B measurements, tests)
+int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel, 2 = the round-1 LDS-tiled kernel (A/B measurements, tests)
 
 // ----------------------------------------------------------------------------
 // cell assignment: wrap, bin, take a slot from the cell's atomic counter
@@ -283,6 +283,62 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
 //   MODE 1: reference semantics   (write valid slots only, caller pre-filled pads)
 //   MODE 2: also write the pads   (-1, rc+1)
 // ----------------------------------------------------------------------------
+// one centre atom (position p of the cell-sorted arrays): the reference's 27-cell walk, neighbor.cpp:139-177
+template <bool TRI, int MODE>
+__device__ __forceinline__ int neighbor_one(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
+                                            const int *__restrict__ order, const int *__restrict__ cell_start, const DBox &b,
+                                            const Grid &g, double rc, int *__restrict__ verlet, double *__restrict__ dist,
+                                            int *__restrict__ nn, int64_t M, int64_t p, double xi, double yi, double zi, int c0, int c1,
+                                            int c2)
+{
+    int cnt = 0;
+    const int i = order[p];
+    const double rcsq = rc * rc; // neighbor.cpp:127
+    const int64_t row = (int64_t)i * M;
+    const bool zrun = (c2 >= 1) && (c2 + 1 < g.nc[2]); // the three z-cells are one contiguous run
+    for (int a = c0 - 1; a <= c0 + 1; ++a) {            // neighbor.cpp:147-151
+        const int ca = pmod(a, g.nc[0]);
+        for (int bb = c1 - 1; bb <= c1 + 1; ++bb) {
+            const int64_t base = ((int64_t)ca * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2];
+            for (int seg = 0; seg < (zrun ? 1 : 3); ++seg) {
+                int s, e;
+                if (zrun) {
+                    s = cell_start[base + c2 - 1];
+                    e = cell_start[base + c2 + 2];
+                } else {
+                    const int cc = pmod(c2 - 1 + seg, g.nc[2]);
+                    s = cell_start[base + cc];
+                    e = cell_start[base + cc + 1];
+                }
+                for (int q = s; q < e; ++q) {
+                    const int j = order[q];
+                    if (j == i)
+                        continue;
+                    double dx = xs[q] - xi, dy = ys[q] - yi, dz = zs[q] - zi; // raw x[j] - wrapped centre, :164-166
+                    pbc<TRI>(b, dx, dy, dz);
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 <= rcsq) {
+                        if (MODE != 0 && cnt < M) {
+                            verlet[row + cnt] = j;
+                            dist[row + cnt] = sqrt(d2);
+                        }
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+    nn[i] = cnt;
+    if (MODE == 2) {
+        const double pad = rc + 1.0;
+        for (int64_t n = cnt; n < M; ++n) {
+            verlet[row + n] = -1;
+            dist[row + n] = pad;
+        }
+    }
+    return cnt;
+}
+
 template <bool TRI, int MODE>
 __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs, const double *__restrict__ ys,
                                                   const double *__restrict__ zs, const int *__restrict__ order,
@@ -291,7 +347,8 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
                                                   int *__restrict__ nn, int64_t M, int *__restrict__ max_count,
                                                   TileFilter tf)
 {
-    if (tf.flag && *tf.any == 0) // mop-up pass with nothing to mop up
+    const bool take_all = tf.moved && *tf.moved != 0; // the tiled kernel stood down: this kernel does the whole call
+    if (tf.flag && !take_all && (tf.list || *tf.any == 0)) // nothing to mop up here (flagged tiles go to k_neighbor_tiles when listed)
         return;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cnt = 0;
@@ -305,55 +362,11 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         if (tf.flag) { // fallback pass: only atoms of tiles the LDS-tiled kernel could not hold (or all of them when it stood down)
             const int t = ((c0 / tf.tile) * tf.nt[1] + (c1 / tf.tile)) * tf.nt[2] + (c2 / tf.tile_z);
-            mine = tf.flag[t] != 0;
+            mine = take_all || tf.flag[t] != 0;
         }
     }
-    if (mine) {
-        const int i = order[p];
-        const double rcsq = rc * rc; // neighbor.cpp:127
-        const int64_t row = (int64_t)i * M;
-        const bool zrun = (c2 >= 1) && (c2 + 1 < g.nc[2]); // the three z-cells are one contiguous run
-        for (int a = c0 - 1; a <= c0 + 1; ++a) {            // neighbor.cpp:147-151
-            const int ca = pmod(a, g.nc[0]);
-            for (int bb = c1 - 1; bb <= c1 + 1; ++bb) {
-                const int64_t base = ((int64_t)ca * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2];
-                for (int seg = 0; seg < (zrun ? 1 : 3); ++seg) {
-                    int s, e;
-                    if (zrun) {
-                        s = cell_start[base + c2 - 1];
-                        e = cell_start[base + c2 + 2];
-                    } else {
-                        const int cc = pmod(c2 - 1 + seg, g.nc[2]);
-                        s = cell_start[base + cc];
-                        e = cell_start[base + cc + 1];
-                    }
-                    for (int q = s; q < e; ++q) {
-                        const int j = order[q];
-                        if (j == i)
-                            continue;
-                        double dx = xs[q] - xi, dy = ys[q] - yi, dz = zs[q] - zi; // raw x[j] - wrapped centre, :164-166
-                        pbc<TRI>(b, dx, dy, dz);
-                        const double d2 = dx * dx + dy * dy + dz * dz;
-                        if (d2 <= rcsq) {
-                            if (MODE != 0 && cnt < M) {
-                                verlet[row + cnt] = j;
-                                dist[row + cnt] = sqrt(d2);
-                            }
-                            ++cnt;
-                        }
-                    }
-                }
-            }
-        }
-        nn[i] = cnt;
-        if (MODE == 2) {
-            const double pad = rc + 1.0;
-            for (int64_t n = cnt; n < M; ++n) {
-                verlet[row + n] = -1;
-                dist[row + n] = pad;
-            }
-        }
-    }
+    if (mine)
+        cnt = neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2);
     if (MODE == 0) {
         int m = cnt;
 #pragma unroll
@@ -366,6 +379,52 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
     }
 }
 
+// mop-up of the tiles the wave kernel listed (halo over the LDS budget, atoms far outside the box): a workgroup per listed
+// tile, its threads over the tile's centre atoms — the cost follows the number of listed tiles, not N
+template <int MODE>
+__global__ __launch_bounds__(256) void k_neighbor_tiles(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                        const double *__restrict__ zs, const int *__restrict__ order,
+                                                        const int *__restrict__ cell_start, DBox b, Grid g, double rc,
+                                                        int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
+                                                        int64_t M, int *__restrict__ max_count, TileFilter tf)
+{
+    if (tf.moved && *tf.moved != 0) // k_neighbor takes the whole call
+        return;
+    const int nlist = min(*tf.any, tf.list_cap);
+    int best = 0;
+    for (int q = blockIdx.x; q < nlist; q += gridDim.x) {
+        const int t = tf.list[q];
+        const int t2 = t % tf.nt[2], t1 = (t / tf.nt[2]) % tf.nt[1], t0 = t / (tf.nt[2] * tf.nt[1]);
+        const int z0 = t2 * tf.tile_z, z1 = min(z0 + tf.tile_z, g.nc[2]);
+        // the tile's (x, y) columns side by side: a group of threads per column, each thread its share of the column's atoms
+        const int ncol = tf.tile * tf.tile;
+        int tpc = 1;
+        while (tpc * 2 * ncol <= (int)blockDim.x) tpc *= 2;
+        const int colq = (int)threadIdx.x / tpc, sub = (int)threadIdx.x % tpc;
+        if (colq < ncol) {
+            const int a = t0 * tf.tile + colq / tf.tile, c = t1 * tf.tile + colq % tf.tile;
+            if (a < g.nc[0] && c < g.nc[1]) {
+                const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+                const int s = cell_start[col + z0], e = cell_start[col + z1]; // the z-run of a column is contiguous
+                for (int p = s + sub; p < e; p += tpc) {
+                    double xi = xs[p], yi = ys[p], zi = zs[p];
+                    if (b.anypbc)
+                        wrap<false>(b, xi, yi, zi);
+                    int c0, c1, c2;
+                    cell_coords<false>(b, g, xi, yi, zi, c0, c1, c2);
+                    best = max(best, neighbor_one<false, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+        if ((threadIdx.x & 63) == 0 && best > 0)
+            atomicMax(max_count, best);
+    }
+}
+
 template <int MODE>
 static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const DBox &b, double rc, int *verlet,
                             double *dist, int *nn, int64_t M, int *max_count, TileFilter tf = TileFilter{})
@@ -375,6 +434,8 @@ static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const
         hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else
         hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+    if (tf.list && !b.tri) // the listed tiles (at most list_cap; a longer list falls back to the flag scan above via tf.list == nullptr)
+        hipLaunchKernelGGL((k_neighbor_tiles<MODE>), dim3(512), block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
 }
 
 // ----------------------------------------------------------------------------
@@ -517,13 +578,24 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
     }
     {
         ProfRange pr("k_neighbor", sc.stream());
-        int64_t occ = 0;
-        if (g_neighbor_variant != 1 && !b.tri)
-            MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
-        const TiledPlan plan = g_neighbor_variant == 1 ? TiledPlan{0, 0, false, false, 0} : plan_tiled(b, cg.g, N, max_neigh, occ);
         TileFilter tf{};
-        if (plan.tile) // LDS-tiled kernel; the thread-per-atom kernel below then only mops up what it left
-            MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));
+        bool done = false;
+        if (g_neighbor_variant == 0 && !b.tri) { // wave-per-cell kernel; the thread-per-atom kernel below then only mops up what it left
+            GridStats gs;
+            MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
+            const WavePlan wp = plan_wave(b, cg.g, N, max_neigh, gs, rc);
+            if (wp.txy) {
+                MDH_TRY(launch_neighbor_wave(sc, cg, wp, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, false, nullptr, tf));
+                done = true;
+            }
+        }
+        if (!done && g_neighbor_variant == 2 && !b.tri) {
+            int64_t occ = 0;
+            MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
+            const TiledPlan plan = plan_tiled(b, cg.g, N, max_neigh, occ);
+            if (plan.tile)
+                MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));
+        }
         if (fill_pads)
             launch_neighbor<2>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr, tf);
         else
@@ -558,7 +630,15 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
     CellGrid cg;
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
-    launch_neighbor<0>(sc.stream(), cg, N, b, rc, nullptr, nullptr, dn, 1, dmax);
+    TileFilter tf{};
+    if (g_neighbor_variant == 0 && !b.tri) {
+        GridStats gs;
+        MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
+        const WavePlan wp = plan_wave(b, cg.g, N, 1, gs, rc);
+        if (wp.txy)
+            MDH_TRY(launch_neighbor_wave(sc, cg, wp, N, b, rc, nullptr, nullptr, dn, 1, false, true, dmax, tf));
+    }
+    launch_neighbor<0>(sc.stream(), cg, N, b, rc, nullptr, nullptr, dn, 1, dmax, tf);
     MDH_HIP(hipMemcpyAsync(max_count, dmax, sizeof(int), hipMemcpyDeviceToHost, sc.stream()));
     MDH_TRY(sc.finish(space));
     MDH_HIP(hipStreamSynchronize(sc.stream()));

@@ -38,7 +38,7 @@ def report(tag):
 
 
 ref = None
-for variant in (1, 0):
+for variant in (1, 2, 0):
     L.mdh_debug_set_neighbor_variant(variant)
     for it in range(2):
         _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, rc, verlet, dist, nn, 1, fill_pads=True)

@@ -1,0 +1,34 @@
+"""wave-kernel probe: plan + debug counters + per-kernel time.  python tools/nbw_probe.py [cells] [M] [rc/a] [sigma] [reps]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import mdapy_amd as mp
+from mdapy_amd import _lib, _neighbor
+from bench import slab_positions, A_CU
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 136
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+rc = (float(sys.argv[3]) if len(sys.argv) > 3 else 0.854) * A_CU
+sigma = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+dev = torch.device("cuda", 0)
+x, y, z, gid = slab_positions(torch, dev, cells, 0, sigma)
+n = x.shape[0]
+box = mp.Box(np.diag([A_CU * cells] * 3))
+L = _lib.lib()
+verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty((n, M), dtype=torch.float64, device=dev)
+nn = torch.empty((n,), dtype=torch.int32, device=dev)
+for _ in range(2):
+    _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, rc, verlet, dist, nn, 1, fill_pads=True)
+torch.cuda.synchronize()
+plan = (ctypes.c_int * 8)(); dbg = (ctypes.c_int * 4)()
+L.mdh_debug_wave_info(plan, dbg)
+L.mdh_prof_reset(); L.mdh_prof_enable(1)
+for _ in range(reps):
+    _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, rc, verlet, dist, nn, 1, fill_pads=True)
+torch.cuda.synchronize()
+L.mdh_prof_enable(0)
+L.mdh_debug_wave_info(plan, dbg)
+buf = ctypes.create_string_buffer(1 << 16); L.mdh_prof_report(buf, len(buf))
+print("plan txy,tz,cap,S,NG,full,pop*1000,occ:", list(plan), "dbg/rep slow,cells,flush,exact:", [d / reps for d in dbg])
+print(buf.value.decode().strip(), "N", n, "env", {k: v for k, v in os.environ.items() if k.startswith("MDH_")}, flush=True)
