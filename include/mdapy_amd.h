@@ -64,8 +64,12 @@ int mdh_prof_enable(int on);
 int mdh_prof_reset(void);
 int mdh_prof_report(char *buf, int buflen);
 /* A/B switch for measurements and tests: 0 = automatic kernel choice (default), 1 = force the
- * thread-per-atom neighbor kernel even where the LDS-tiled one applies.  Results are identical. */
+ * thread-per-atom neighbor kernel, 2 = force the round-1 LDS-tiled kernel where it applies.  Results are identical. */
 int mdh_debug_set_neighbor_variant(int variant);
+/* test hook: the tile plan of the last neighbor build that took the LDS-tile kernel (neighbor_lane.hip):
+ * plan8 = {tile cells in x/y, in z, halo atoms per tile, LDS bytes, box full of atoms, 1000 * atoms per cell,
+ * cells of the occupied region, 1 if a plan was made since the last query}. */
+int mdh_debug_neighbor_plan(int *plan8);
 /* test hook: out4[k] = smallest double d with floor(d/L + 0.5) >= k-1 (k = 0..3) for a periodic orthogonal
  * axis of length L — the exact decision points that let the kernels replace floor(d/L+0.5) by compares. */
 int mdh_debug_image_thresholds(double L, double *out4);

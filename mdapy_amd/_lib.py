@@ -34,6 +34,7 @@ _SIGNATURES = {
     "mdh_prof_reset": [],
     "mdh_prof_report": [vp, cint],
     "mdh_debug_set_neighbor_variant": [cint],
+    "mdh_debug_neighbor_plan": [vp],
     "mdh_debug_image_thresholds": [dbl, vp],
     "mdh_build_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, cint, vp],
     "mdh_slab_halo_select": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, cint, vp],

@@ -28,7 +28,7 @@ struct CellGrid {
     unsigned char *mvs; // [N] per-atom image code (raw vs wrapped coordinate), in `order`
 };
 
-// neighbor_tiled.hip: LDS-tiled 27-cell scan for orthogonal boxes (see the file header)
+// neighbor_tiled.hip: the round-1 LDS-tiled kernel (double-precision scan, any run length); serves the cells too full for neighbor_lane.hip
 struct TiledPlan {
     int tile;        // cells per tile edge in x and y; 0 = not applicable
     int tile_z;      // cells per tile edge in z
@@ -53,23 +53,21 @@ int occupied_cells_hint(Scope &sc, const CellGrid &cg, int64_t N, int64_t *occup
 int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, int64_t N, const DBox &b, double rc,
                           int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, TileFilter &tf);
 
-// neighbor_wave.hip: one wavefront per centre cell, one lane per candidate (see the file header)
+// neighbor_lane.hip: LDS tiles, one thread per centre atom, single-precision pruning (see the file header)
 struct GridStats {
     static constexpr int NBIN = 67; // v[0] = cells of the occupied region; v[1 + len] = 3-cell z-runs of that length (66: longer than 64)
     int v[NBIN];
 };
-struct WavePlan {
+struct LanePlan {
     int txy, tz;      // tile shape in cells; txy == 0: not applicable
     int cap;          // atoms a tile's halo may hold in LDS
-    int S, NG;        // lanes per run, groups of 64 lanes per centre
-    float lo, hi;     // decision band of the single-precision scan around rc^2
-    float mid, T;     // the same band as centre (rc^2 in single precision) and half-width
+    float mid, T;     // rc^2 in single precision and the half-width of the decision band around it
     bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live
     int64_t occupied; // cells of the occupied region (last known)
 };
 int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out);
-WavePlan plan_wave(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc);
-int launch_neighbor_wave(Scope &sc, const CellGrid &cg, const WavePlan &plan, int64_t N, const DBox &b, double rc,
+LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc);
+int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,
                          TileFilter &tf);
 

@@ -21,7 +21,7 @@
 
 namespace mdh {
 
-int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel, 2 = the round-1 LDS-tiled kernel (A/B measurements, tests)
+int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel, 2 = force the round-1 LDS-tiled kernel (A/B measurements, tests)
 
 // ----------------------------------------------------------------------------
 // cell assignment: wrap, bin, take a slot from the cell's atomic counter
@@ -580,16 +580,16 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
         ProfRange pr("k_neighbor", sc.stream());
         TileFilter tf{};
         bool done = false;
-        if (g_neighbor_variant == 0 && !b.tri) { // wave-per-cell kernel; the thread-per-atom kernel below then only mops up what it left
+        if (g_neighbor_variant == 0 && !b.tri) { // tile kernel; the thread-per-atom code below then only mops up what it listed
             GridStats gs;
             MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
-            const WavePlan wp = plan_wave(b, cg.g, N, max_neigh, gs, rc);
-            if (wp.txy) {
-                MDH_TRY(launch_neighbor_wave(sc, cg, wp, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, false, nullptr, tf));
+            const LanePlan lp = plan_lane(b, cg.g, N, max_neigh, gs, rc);
+            if (lp.txy) {
+                MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, false, nullptr, tf));
                 done = true;
             }
         }
-        if (!done && g_neighbor_variant == 2 && !b.tri) {
+        if (!done && g_neighbor_variant != 1 && !b.tri) { // cells too full for the kernel above (or forced): the round-1 tiled kernel
             int64_t occ = 0;
             MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
             const TiledPlan plan = plan_tiled(b, cg.g, N, max_neigh, occ);
@@ -634,9 +634,9 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
     if (g_neighbor_variant == 0 && !b.tri) {
         GridStats gs;
         MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
-        const WavePlan wp = plan_wave(b, cg.g, N, 1, gs, rc);
-        if (wp.txy)
-            MDH_TRY(launch_neighbor_wave(sc, cg, wp, N, b, rc, nullptr, nullptr, dn, 1, false, true, dmax, tf));
+        const LanePlan lp = plan_lane(b, cg.g, N, 1, gs, rc);
+        if (lp.txy)
+            MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, nullptr, nullptr, dn, 1, false, true, dmax, tf));
     }
     launch_neighbor<0>(sc.stream(), cg, N, b, rc, nullptr, nullptr, dn, 1, dmax, tf);
     MDH_HIP(hipMemcpyAsync(max_count, dmax, sizeof(int), hipMemcpyDeviceToHost, sc.stream()));

@@ -1,0 +1,755 @@
+// neighbor_lane.hip — cutoff neighbor search on LDS tiles, one thread per centre atom, single-precision pruning with
+// hit masks in registers (gfx950).
+//
+// Same result, bit for bit, as the thread-per-atom kernel in neighbor.hip and therefore as src/neighbor.cpp:102-187 of
+// the reference (ids, order inside a row, counts, distances).  This is the fast path of mdh_build_neighbor /
+// mdh_neighbor_count for orthogonal boxes.
+//
+// A workgroup owns a tile of TXY x TXY x TZ cells and stages the atoms of the halo ((TXY+2)^2 x (TZ+2) cells, ONE CELL
+// PER THREAD, coalesced loads from the cell-sorted arrays) into LDS once: raw doubles for the values that are written,
+// and single-precision coordinates relative to the tile corner with the periodic image shift folded in
+// (u = x - (X0 + L n), n = image number of the candidate's cell as seen from the tile + the atom's own image code) for the
+// values that only decide.  The staging pass also lists the tile's centre atoms and tabulates, per halo cell, the LDS range
+// of the 3-cell z-run around it (cells (i+da, j+db, k-1..k+1) are contiguous), so a centre finds each of its 9 runs with
+// one 4-byte LDS read.
+//
+// Scan (hand-written, scan_run_asm).  A thread walks its 9 runs in the reference's order (neighbor.cpp:147-151), four
+// candidates per trip: four 16-byte LDS reads in flight, then per candidate 3 subtractions, an FMA chain ending in
+// d' = d2 - rc^2, ONE compare whose VCC is shifted into a hit mask by an add-with-carry, and one v_min tracking the
+// smallest |d'| seen.  No per-candidate branch, ticket store or address arithmetic: 9 VALU instructions per candidate,
+// 7 of them register-only single-precision operations (2.7 cycles each on this chip against 4.4 for anything that
+// touches SGPRs / VCC or is double precision; tools/ubench).  |d'_f32 - d'_exact| <= T (host, from the tile extent): a pair
+// with d' < -T is a hit, d' > +T a miss; a thread that saw |d'| <= T redoes ITS masks with the reference's own
+// double-precision expression.  Single precision only prunes: every distance that is WRITTEN is recomputed in double
+// precision from the raw coordinates exactly as the reference does (raw x[j] - wrapped x[i], minimum image,
+// (dx*dx + dy*dy) + dz*dz, sqrt), so rows are bit-identical.
+//
+// Output.  The masks are expanded into 2-byte tickets (LDS index of the candidate) in walk order; then the workgroup
+// writes rows cooperatively — MP adjacent lanes write the MP slots of one row, pads included — so a wave store covers whole
+// 64 B / 128 B row segments instead of 64 scattered rows.
+//
+// Tiles whose halo does not fit the LDS budget are listed and taken by a SECOND launch of the same kernel on one-cell
+// slices of those tiles; what is left after that (a dense blob, atoms far outside the box on an open axis, a run of more
+// than 32 atoms) is listed again for the thread-per-atom code (k_neighbor_tiles).  Not taken at all (thread-per-atom
+// kernel / round-1 tiled kernel, same results): triclinic boxes, fewer than 7 cells on a periodic axis or 4 on an open
+// one, unwrapped input (device flag), max_neigh > 64, cells so full that runs exceed 32 atoms.
+//
+// Measured alternatives (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16): round-1 tiled kernel (thread per
+// centre, double-precision scan, per-hit ticket stores) 1.80 ms; one WAVEFRONT per centre cell with one LANE per candidate
+// (packed-f32 distances, hit masks straight from VCC, v_mbcnt slots, hand-written body) 2.0 ms — fewer LDS reads but
+// ~50 wave-level instructions per centre, most of them scalar bookkeeping; this kernel 1.40 ms.
+#include "common.hpp"
+#include "grid.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+namespace mdh {
+namespace lane {
+
+static constexpr int NT = 256;      // threads per workgroup
+static constexpr int MAX_NH = 256;  // halo cells of a tile: one per thread
+static constexpr int CEN_CAP = 512; // centre atoms a tile may hold
+static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
+static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
+
+struct Shape { int txy, tz; };
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+static int g_last_plan[8]; // test hook (mdh_debug_neighbor_plan)
+
+__device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) scratch[w] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < (NT >> 6); ++k) {
+        if (k < w) off += scratch[k];
+        tot += scratch[k];
+    }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
+}
+
+// cell code cc and atom code ca (each (n+1) per axis in 2 bits) -> combined code ((n_cell + m_atom) + 2 per axis in 3 bits)
+__device__ __forceinline__ int combine_codes(int cc, int ca)
+{
+    return ((cc & 3) + (ca & 3)) | ((((cc >> 2) & 3) + ((ca >> 2) & 3)) << 3) | ((((cc >> 4) & 3) + ((ca >> 4) & 3)) << 6);
+}
+
+// the reference's squared distance of one pair: raw x[j] - wrapped x[i] (neighbor.cpp:164-166), minimum image
+// d - L*floor(d/L+0.5) with the image number n taken from the code (box.h:120-124; L*n exact, d - L*0 == d), then
+// (dx*dx + dy*dy) + dz*dz (neighbor.cpp:170)
+template <bool GENERAL>
+__device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, double zj, double xi, double yi, double zi,
+                                           int code)
+{
+    double dx = xj - xi, dy = yj - yi, dz = zj - zi;
+    if (GENERAL) {
+        dx = dx - b.h[0] * (double)((code & 7) - 2);
+        dy = dy - b.h[4] * (double)(((code >> 3) & 7) - 2);
+        dz = dz - b.h[8] * (double)(((code >> 6) & 7) - 2);
+    }
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v130-v151).  Four candidates per trip: four 16-byte LDS reads in
+// flight, then per candidate 3 subtractions, an FMA chain that ends in d' = d2 - rc^2, one compare whose VCC is shifted
+// into the trip's hit nibble by an add-with-carry, and one v_min that tracks the smallest |d'| the lane has seen (the
+// decision-band test happens once per centre).  Lanes whose run is exhausted leave EXEC; the others go on.
+// a: LDS byte address of the run's first candidate; rem: its length; bit (L4-1-j) of `mask` is candidate j, L4 = length
+// rounded up to 4.  Candidates past the end of a run are other staged atoms: their hit bits are masked, a small |d'| of
+// theirs only costs a redundant double-precision pass.
+__device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, float sy, float sz, float nmid, float negT,
+                                             unsigned &mask, float &w)
+{
+    unsigned long long save;
+    unsigned m;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "v_mov_b32 %[m], 0\n"
+        ".Lscan_top_%=:\n\t"
+        "v_cmp_lt_i32 vcc, 0, %[rem]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz .Lscan_end_%=\n\t"
+        "ds_read_b128 v[130:133], %[a]\n\t"
+        "ds_read_b128 v[134:137], %[a] offset:16\n\t"
+        "ds_read_b128 v[138:141], %[a] offset:32\n\t"
+        "ds_read_b128 v[142:145], %[a] offset:48\n\t"
+        "v_min_u32 v150, 4, %[rem]\n\t"
+        "v_sub_u32 v151, 4, v150\n\t"
+        "v_bfm_b32 v150, v150, v151\n\t"        // ((1 << valid) - 1) << (4 - valid): the valid candidates of this trip
+        "v_add_u32 %[a], 64, %[a]\n\t"
+        "v_add_u32 %[rem], -4, %[rem]\n\t"
+        "v_mov_b32 v149, 0\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_sub_f32 v146, v130, %[sx]\n\t"
+        "v_sub_f32 v147, v131, %[sy]\n\t"
+        "v_sub_f32 v148, v132, %[sz]\n\t"
+        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
+        "v_fmac_f32 v146, v147, v147\n\t"
+        "v_fmac_f32 v146, v148, v148\n\t"
+        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
+        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
+        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_sub_f32 v146, v134, %[sx]\n\t"
+        "v_sub_f32 v147, v135, %[sy]\n\t"
+        "v_sub_f32 v148, v136, %[sz]\n\t"
+        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
+        "v_fmac_f32 v146, v147, v147\n\t"
+        "v_fmac_f32 v146, v148, v148\n\t"
+        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
+        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
+        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_sub_f32 v146, v138, %[sx]\n\t"
+        "v_sub_f32 v147, v139, %[sy]\n\t"
+        "v_sub_f32 v148, v140, %[sz]\n\t"
+        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
+        "v_fmac_f32 v146, v147, v147\n\t"
+        "v_fmac_f32 v146, v148, v148\n\t"
+        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
+        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
+        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_sub_f32 v146, v142, %[sx]\n\t"
+        "v_sub_f32 v147, v143, %[sy]\n\t"
+        "v_sub_f32 v148, v144, %[sz]\n\t"
+        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
+        "v_fmac_f32 v146, v147, v147\n\t"
+        "v_fmac_f32 v146, v148, v148\n\t"
+        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
+        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
+        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
+        "v_and_b32 v149, v149, v150\n\t"
+        "v_lshl_or_b32 %[m], %[m], 4, v149\n\t"
+        "s_branch .Lscan_top_%=\n"
+        ".Lscan_end_%=:\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)
+        : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [nmid] "v"(nmid), [negT] "s"(negT)
+        : "vcc", "scc", "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141",
+          "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151");
+    mask = m;
+}
+
+// the same run decided by the reference's double-precision expression (threads with a pair inside the decision band)
+template <bool SELF>
+__device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy, const double *__restrict__ lz,
+                                                 const unsigned short *__restrict__ lsh, const DBox &b, double rcsq, int k0, int len,
+                                                 int li, double xi, double yi, double zi)
+{
+    unsigned m = 0;
+    const int L4 = (len + 3) & ~3;
+    for (int j = 0; j < L4; ++j) {
+        const int k = k0 + j;
+        bool h = false;
+        if (j < len) {
+            const double2 cj = lxy[k];
+            const double d2 = exact_d2<true>(b, cj.x, cj.y, lz[k], xi, yi, zi, lsh[k]);
+            h = (d2 <= rcsq) && (!SELF || k != li); // neighbor.cpp:162,171
+        }
+        m = m + m + (h ? 1u : 0u);
+    }
+    return m;
+}
+
+// COUNT: nn and the largest count only (first pass of the exact-width variant)
+// parent != nullptr: second pass over the tiles the first pass listed (halo over the LDS budget): the same tiling cut into
+// nsub slices along z (this launch's TZ = parent's TZ / nsub); what still does not fit goes to `flagged` (counter
+// flags[flag_slot]) and from there to the thread-per-atom code
+template <bool COUNT>
+__global__ __launch_bounds__(NT) void k_neighbor_lane(
+    const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
+    const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
+    Grid g, double rc, float nmid, float T, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
+    int M, int mp_shift, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
+    int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
+    int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
+    int flag_slot)
+{
+    if (flags[0] != 0) // unwrapped input: the image codes are not valid, the thread-per-atom kernel takes the whole call
+        return;
+    const int TXY = ts.txy, TZ = ts.tz;
+    const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap+8] staged (ux, uy, uz, bits of the atom id)
+    double2 *lxy = reinterpret_cast<double2 *>(f4 + cap + 8);       // [cap] staged raw x, y
+    double2 *rxy = lxy + cap;                                       // [NT] this pass's rows: wrapped centre x, y
+    double2 *rzc = rxy + NT;                                        // [NT] wrapped centre z, (atom id | min(count, M) << 32)
+    double *lz = reinterpret_cast<double *>(rzc + NT);              // [cap] staged raw z
+    unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 16
+    unsigned short *tk = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [NT][M] tickets
+    unsigned short *lsh = tk + (size_t)NT * M + (((size_t)NT * M) & 1); // [cap] combined image code of a staged atom seen from this tile
+    const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
+    __shared__ unsigned hc[MAX_NH + 2]; // halo cell: LDS offset | population << 16
+    __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
+    __shared__ int scan_tmp[4];
+    __shared__ int s_flag[3];
+
+    const double rcsq = rc * rc, pad = rc + 1.0; // neighbor.cpp:127; pads neighbor.py:125-129
+    const double cw = rc;                        // cell width of the rc-wide grid (neighbor.cpp:29-62)
+    int vmax = 0;
+
+    // XCD-aware tile order: block b runs on XCD b%8; every XCD gets one contiguous chunk of the tiles THAT HOLD CENTRE ATOMS
+    // (neighbouring tiles share halo cells through the same L2; vacuum leaves no XCD idle)
+    const int nlive = parent ? min(*n_live, nt0 * nt1 * parent_nt2) * nsub : ((list_mode && tile_list) ? *n_live : nt0 * nt1 * nt2);
+    const int per = (nlive + 7) / 8;
+    for (int jt = (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
+        const int slot = (blockIdx.x & 7) * per + jt;
+        if (slot >= nlive)
+            break;
+        int tile_id, t0, t1, t2;
+        if (parent) {
+            const int pt = parent[slot / nsub]; // tile of the first pass
+            t2 = (pt % parent_nt2) * nsub + slot % nsub;
+            t1 = (pt / parent_nt2) % nt1;
+            t0 = pt / (parent_nt2 * nt1);
+            tile_id = (t0 * nt1 + t1) * nt2 + t2;
+        } else {
+            tile_id = (list_mode && tile_list) ? tile_list[slot] : slot;
+            t2 = tile_id % nt2; t1 = (tile_id / nt2) % nt1; t0 = tile_id / (nt2 * nt1);
+        }
+        const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
+        if (T2 >= g.nc[2]) // (a slice beyond the grid: the parent tile was a clipped one)
+            continue;
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+
+        // ---- halo cell of this thread: source range, image code, is it a centre cell
+        int cnt = 0, src = 0, img = NEUTRAL, hz = 0;
+        bool edge = false, centre_cell = false; // edge: first / last cell of an open axis (atoms outside the box are clamped into it, neighbor.cpp:58-61)
+        if (tid < NH) {
+            const int hcol = tid / HZ;
+            hz = tid - hcol * HZ;
+            const int hx = hcol / HXY, hy = hcol - hx * HXY;
+            const int g0 = T0 + hx - 1, g1 = T1 + hy - 1, g2 = T2 + hz - 1;
+            // a cell beyond an OPEN face is the far side of the box in the reference's modulo walk (neighbor.cpp:18-27); with
+            // >= 4 cells on the axis its atoms are >= 2 rc from every centre of this tile: no hits, not staged
+            const bool in0 = b.pbc[0] ? (g0 >= -1 && g0 <= g.nc[0]) : (g0 >= 0 && g0 < g.nc[0]);
+            const bool in1 = b.pbc[1] ? (g1 >= -1 && g1 <= g.nc[1]) : (g1 >= 0 && g1 < g.nc[1]);
+            const bool in2 = b.pbc[2] ? (g2 >= -1 && g2 <= g.nc[2]) : (g2 >= 0 && g2 < g.nc[2]);
+            if (in0 && in1 && in2) {
+                const int a0 = g0 < 0 ? g0 + g.nc[0] : (g0 >= g.nc[0] ? g0 - g.nc[0] : g0);
+                const int a1 = g1 < 0 ? g1 + g.nc[1] : (g1 >= g.nc[1] ? g1 - g.nc[1] : g1);
+                const int a2 = g2 < 0 ? g2 + g.nc[2] : (g2 >= g.nc[2] ? g2 - g.nc[2] : g2);
+                const int64_t c = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
+                src = cell_start[c];
+                cnt = cell_start[c + 1] - src;
+                // image of the candidate cell seen from an in-grid centre cell: below the box -> raw coordinates are ~+L
+                // away (n = +1); above -> n = -1
+                const int n0 = g0 < 0 ? 1 : (g0 >= g.nc[0] ? -1 : 0);
+                const int n1 = g1 < 0 ? 1 : (g1 >= g.nc[1] ? -1 : 0);
+                const int n2 = g2 < 0 ? 1 : (g2 >= g.nc[2] ? -1 : 0);
+                img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
+                edge = (!b.pbc[0] && (a0 == 0 || a0 == g.nc[0] - 1)) || (!b.pbc[1] && (a1 == 0 || a1 == g.nc[1] - 1)) ||
+                       (!b.pbc[2] && (a2 == 0 || a2 == g.nc[2] - 1));
+                centre_cell = hx >= 1 && hx <= TXY && hy >= 1 && hy <= TXY && hz >= 1 && hz <= TZ && g0 < g.nc[0] && g1 < g.nc[1] && g2 < g.nc[2];
+            }
+        }
+        int total2;
+        const int off2 = excl_scan_block(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
+        const int total = total2 & 0xffff, ncentres = total2 >> 16;
+        const int off0 = off2 & 0xffff, coff = off2 >> 16;
+        if (total > cap || ncentres > CEN_CAP) { // list this tile for the next pass
+            if (tid == 0) {
+                if (tile_flag) tile_flag[tile_id] = 1;
+                flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
+            }
+            continue; // (excl_scan_block ended with a barrier)
+        }
+        if (tid < NH) hc[tid] = (unsigned)off0 | ((unsigned)cnt << 16);
+        // ---- stage this cell's atoms
+        if (cnt > 0) {
+            const double X0 = b.o[0] + (double)(T0 - 1) * cw, Y0 = b.o[1] + (double)(T1 - 1) * cw, Z0 = b.o[2] + (double)(T2 - 1) * cw;
+            const int code0 = combine_codes(img, NEUTRAL); // an atom inside the box (image code 0): the cell's own shift
+            const double XS = X0 + b.h[0] * (double)((code0 & 7) - 2), YS = Y0 + b.h[4] * (double)(((code0 >> 3) & 7) - 2),
+                         ZS = Z0 + b.h[8] * (double)(((code0 >> 6) & 7) - 2);
+            const float flo = (float)(-1.5 * cw);
+            const float fhx = (float)(((double)HXY + 1.5) * cw), fhz = (float)(((double)HZ + 1.5) * cw);
+            bool general = code0 != NEUTRAL3, far = false;
+            for (int k = 0; k < cnt; k += 4) {
+                double a[4], bb[4], c[4];
+                int d[4];
+                unsigned char m[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { // twenty independent loads in flight
+                    const int q = src + min(k + v, cnt - 1);
+                    a[v] = xs[q]; bb[v] = ys[q]; c[v] = zs[q]; d[v] = order[q]; m[v] = mvs[q];
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (k + v < cnt) {
+                        int code = code0;
+                        float ux = (float)(a[v] - XS), uy = (float)(bb[v] - YS), uz = (float)(c[v] - ZS);
+                        if (m[v] != NEUTRAL) { // an atom handed in outside the box on a periodic axis: its own image number on top
+                            code = combine_codes(img, m[v]);
+                            ux = (float)((a[v] - b.h[0] * (double)((code & 7) - 2)) - X0);
+                            uy = (float)((bb[v] - b.h[4] * (double)(((code >> 3) & 7) - 2)) - Y0);
+                            uz = (float)((c[v] - b.h[8] * (double)(((code >> 6) & 7) - 2)) - Z0);
+                            general = true;
+                        }
+                        // the decision band assumes coordinates inside the tile's halo; an atom clamped into an edge cell from
+                        // far outside the box (open axis) sends the tile to the thread-per-atom code
+                        if (edge)
+                            far = far || !(ux >= flo && ux <= fhx && uy >= flo && uy <= fhx && uz >= flo && uz <= fhz);
+                        const int p = off0 + k + v;
+                        f4[p] = make_float4(ux, uy, uz, __int_as_float(d[v]));
+                        lxy[p] = make_double2(a[v], bb[v]);
+                        lz[p] = c[v];
+                        lsh[p] = (unsigned short)code;
+                        if (centre_cell) cen[coff + k + v] = (unsigned)p | ((unsigned)tid << 16);
+                    }
+                }
+            }
+            if (general) s_flag[0] = 1;
+            if (far) s_flag[1] = 1;
+        }
+        __syncthreads(); // publishes hc, the staged atoms, the centre list and the flags
+        // the 3-cell run around every cell that can be a column entry of a centre's walk
+        if (tid < NH && hz >= 1 && hz <= HZ - 2) {
+            const unsigned lo_c = hc[tid - 1], hi_c = hc[tid + 1];
+            const unsigned k0 = lo_c & 0xffffu, k3 = (hi_c & 0xffffu) + (hi_c >> 16);
+            hr[tid] = k0 | ((k3 - k0) << 16);
+            if (k3 - k0 > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
+        }
+        __syncthreads();
+        if (s_flag[1] | s_flag[2]) {
+            if (tid == 0) {
+                if (tile_flag) tile_flag[tile_id] = 1;
+                flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
+            }
+            if (list_mode) __syncthreads();
+            continue;
+        }
+        const bool general_tile = s_flag[0] != 0;
+
+        for (int base = 0; base < ncentres; base += NT) {
+            const int q = base + tid;
+            if (q < ncentres) {
+                const unsigned cv = cen[q];
+                const int li = (int)(cv & 0xffffu), cb = (int)(cv >> 16);
+                const float4 s = f4[li];
+                unsigned hv[9], mk[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
+                    hv[r] = hr[cb + ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ];
+                float w = 3.0e38f; // smallest |d2 - rc^2| this centre has seen
+#pragma unroll
+                for (int r = 0; r < 9; ++r)
+                    scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), (int)(hv[r] >> 16), s.x, s.y, s.z, nmid, -T, mk[r], w);
+                {   // the centre itself sits in run 4 with d2 = 0: not a neighbour (neighbor.cpp:162)
+                    const int L4 = ((int)(hv[4] >> 16) + 3) & ~3;
+                    mk[4] &= ~(1u << (L4 - 1 - (li - (int)(hv[4] & 0xffffu))));
+                }
+                const double2 ci = lxy[li];
+                double xi = ci.x, yi = ci.y, zi = lz[li];
+                if (b.anypbc) // neighbor.cpp:139-142
+                    wrap<false>(b, xi, yi, zi);
+                if (__builtin_expect(!(w > T), 0)) { // a pair inside the decision band: this centre again in double precision
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        if (r == 4) mk[r] = scan_run_f64<true>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        else mk[r] = scan_run_f64<false>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                    }
+                }
+                int hits = 0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]);
+                const int id = __float_as_int(s.w);
+                nn[id] = hits; // keeps counting past M (neighbor.cpp:172-177)
+                if (COUNT) {
+                    vmax = max(vmax, hits);
+                } else {
+                    // masks -> tickets in walk order: bit (L4-1-j) of a run's mask is its candidate j
+                    unsigned short *my = tk + (size_t)tid * M;
+                    int sl = 0;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        const int k0 = (int)(hv[r] & 0xffffu), L4 = ((int)(hv[r] >> 16) + 3) & ~3;
+                        unsigned m = mk[r];
+                        while (m) {
+                            const int bpos = 31 - __builtin_clz(m);
+                            if (sl < M) my[sl] = (unsigned short)(k0 + (L4 - 1 - bpos));
+                            ++sl;
+                            m &= ~(1u << bpos);
+                        }
+                    }
+                    rxy[tid] = make_double2(xi, yi);
+                    rzc[tid] = make_double2(zi, __longlong_as_double((long long)(((unsigned long long)(unsigned)(hits < M ? hits : M) << 32) | (unsigned)id)));
+                }
+            }
+            if (!COUNT) {
+                __syncthreads();
+                // ---- tickets -> rows: MP adjacent lanes serve the slots of one centre
+                const int nrows = min(NT, ncentres - base);
+                const int MP = 1 << mp_shift; // smallest power of two >= M
+                const int e = tid & (MP - 1);
+                if (e < M) {
+                    for (int c = tid >> mp_shift; c < nrows; c += (NT >> mp_shift)) {
+                        const double2 cz = rzc[c];
+                        const long long ic = __double_as_longlong(cz.y);
+                        const int64_t o = (int64_t)(int)(ic & 0xffffffffll) * M + e;
+                        if (e < (int)(ic >> 32)) {
+                            const int k = tk[c * M + e];
+                            const double2 cj = lxy[k], cc = rxy[c];
+                            double d2;
+                            if (general_tile) d2 = exact_d2<true>(b, cj.x, cj.y, lz[k], cc.x, cc.y, cz.x, lsh[k]);
+                            else d2 = exact_d2<false>(b, cj.x, cj.y, lz[k], cc.x, cc.y, cz.x, 0);
+                            verlet[o] = __float_as_int(f4[k].w);
+                            dist[o] = sqrt(d2); // neighbor.cpp:174
+                        } else if (write_pads) {
+                            verlet[o] = -1;
+                            dist[o] = pad;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!list_mode)
+            break;
+        if (jt + (int)(gridDim.x >> 3) < per) __syncthreads(); // LDS is reused by the next tile
+    } // tiles of this workgroup
+    if (COUNT) {
+        int m = vmax;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+        if (lane == 0 && m > 0) atomicMax(max_count, m);
+    }
+}
+
+// tiles with at least one centre atom: flag (one thread per tile), then an order-preserving compaction
+__global__ __launch_bounds__(256) void k_tile_live(const int *__restrict__ cell_start, Grid g, int nt0, int nt1, int nt2, Shape ts,
+                                                   unsigned *__restrict__ live)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt0 * nt1 * nt2)
+        return;
+    const int t2 = t % nt2, t1 = (t / nt2) % nt1, t0 = t / (nt2 * nt1);
+    const int z0 = t2 * ts.tz, z1 = min(z0 + ts.tz, g.nc[2]);
+    bool any = false;
+    for (int a = t0 * ts.txy; a < min((t0 + 1) * ts.txy, g.nc[0]) && !any; ++a)
+        for (int c = t1 * ts.txy; c < min((t1 + 1) * ts.txy, g.nc[1]) && !any; ++c) {
+            const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+            any = cell_start[col + z1] > cell_start[col + z0]; // the z-run of a column is contiguous
+        }
+    live[t] = any ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_tile_compact(const unsigned *__restrict__ live, const int *__restrict__ slot, int ntiles,
+                                                      int *__restrict__ tile_list)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles && live[t]) tile_list[slot[t]] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grid statistics that size the launch: how many cells belong to the occupied region (counted in 4x4x4-cell blocks: the
+// empty cells a lattice leaves between occupied ones belong to it, vacuum does not) and the histogram of the lengths of the
+// 3-cell z-runs — a run's hit mask is one 32-bit register.  Counted on the device; the host uses the values the previous call
+// with the same (N, grid) left in pinned memory — an MD-style sequence of calls never waits — and waits only the first
+// time it sees a new (N, grid).  A stale value costs speed, never correctness.
+// out[0] = occupied cells; out[1 + len] = number of runs of that length (len 0..64; out[66] = longer)
+__global__ __launch_bounds__(256) void k_grid_stats(const int *__restrict__ cell_start, Grid g, int *__restrict__ out)
+{
+    __shared__ int hist[GridStats::NBIN];
+    for (int k = threadIdx.x; k < GridStats::NBIN; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int nb0 = (g.nc[0] + 3) >> 2, nb1 = (g.nc[1] + 3) >> 2, nb2 = (g.nc[2] + 3) >> 2;
+    const int64_t nblk = (int64_t)nb0 * nb1 * nb2;
+    int mine = 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nblk; q += (int64_t)gridDim.x * blockDim.x) {
+        const int b2 = (int)(q % nb2), b1 = (int)((q / nb2) % nb1), b0 = (int)(q / ((int64_t)nb2 * nb1));
+        const int x1 = min(b0 * 4 + 4, g.nc[0]), y1 = min(b1 * 4 + 4, g.nc[1]), z0 = b2 * 4, z1 = min(z0 + 4, g.nc[2]);
+        bool any = false;
+        for (int a = b0 * 4; a < x1; ++a)
+            for (int c = b1 * 4; c < y1; ++c) {
+                const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+                any = any || cell_start[col + z1] > cell_start[col + z0];
+            }
+        if (any) {
+            mine += (x1 - b0 * 4) * (y1 - b1 * 4) * (z1 - z0);
+            for (int a = b0 * 4; a < x1; ++a)
+                for (int c = b1 * 4; c < y1; ++c) {
+                    const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+                    for (int k = z0; k < z1; ++k) {
+                        const int len = cell_start[col + min(k + 2, g.nc[2])] - cell_start[col + max(k - 1, 0)];
+                        atomicAdd(&hist[1 + min(len, 65)], 1);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&hist[0], mine);
+    __syncthreads();
+    for (int k = threadIdx.x; k < GridStats::NBIN; k += blockDim.x)
+        if (hist[k]) atomicAdd(&out[k], hist[k]);
+}
+
+namespace {
+struct StatEntry { int64_t N, ncell; int device; int *host; unsigned calls; };
+std::mutex g_stat_mu;
+std::vector<StatEntry> g_stat;
+} // namespace
+
+} // namespace lane
+
+int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
+{
+    using namespace lane;
+    hipStream_t st = sc.stream();
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::lock_guard<std::mutex> lk(g_stat_mu);
+    auto count = [&](int *host_dst) -> int {
+        int *dcnt = sc.alloc_n<int>(GridStats::NBIN);
+        if (sc.failed())
+            return sc.error();
+        MDH_HIP(hipMemsetAsync(dcnt, 0, sizeof(int) * GridStats::NBIN, st));
+        const int blocks = (int)std::min<int64_t>((cg.g.ncell / 64 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_grid_stats, dim3(blocks), dim3(256), 0, st, cg.cell_start, cg.g, dcnt);
+        MDH_HIP(hipMemcpyAsync(host_dst, dcnt, sizeof(int) * GridStats::NBIN, hipMemcpyDeviceToHost, st));
+        return MDH_OK;
+    };
+    auto read = [&](const int *host) {
+        // the copy may be landing right now: a torn read mixes two generations of a slowly drifting statistic
+        for (int k = 0; k < GridStats::NBIN; ++k) out->v[k] = ((const volatile int *)host)[k];
+        if (out->v[0] <= 0) out->v[0] = (int)std::min<int64_t>(cg.g.ncell, 2147483647);
+    };
+    for (auto &e : g_stat)
+        if (e.N == N && e.ncell == cg.g.ncell && e.device == device) {
+            read(e.host);
+            if ((++e.calls & 7u) == 0) // the occupied region of a running simulation drifts slowly: recount every 8th call
+                MDH_TRY(count(e.host));
+            return MDH_OK;
+        }
+    int *host = nullptr;
+    if (g_stat.size() >= 64) { // keep the table small: the oldest signature hands its pinned block on (never freed: a copy
+        host = g_stat.front().host; // enqueued on some other stream may still land in it — a wrong hint at worst)
+        g_stat.erase(g_stat.begin());
+    } else {
+        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int) * GridStats::NBIN, hipHostMallocDefault));
+    }
+    MDH_TRY(count(host));
+    MDH_HIP(hipStreamSynchronize(st));
+    read(host);
+    g_stat.push_back(StatEntry{N, cg.g.ncell, device, host, 0u});
+    return MDH_OK;
+}
+
+namespace lane {
+
+static size_t lds_bytes(int cap, int64_t M)
+{
+    size_t tk = (size_t)NT * M;
+    tk += tk & 1;
+    return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (size_t)NT * 32 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + tk * 2 + (size_t)cap * 2;
+}
+
+} // namespace lane
+
+LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc)
+{
+    using namespace lane;
+    LanePlan p{};
+    if (b.tri || g.mode != 0 || N <= 0 || M <= 0 || M > 64)
+        return p;
+    for (int d = 0; d < 3; ++d)
+        if (g.nc[d] < (b.pbc[d] ? 7 : 4)) // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
+            return p;
+    if (!(rc > 1e-12 && rc < 1e12))
+        return p;
+    int64_t runs = 0, longer = 0;
+    for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
+    for (int len = 29; len <= 65; ++len) longer += gs.v[1 + len];
+    if (runs > 0 && (double)longer > 0.002 * (double)runs) // cells so full that many runs would not fit a 32-bit hit mask
+        return p;
+    const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
+    const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
+    static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
+    // LDS budget: three workgroups per CU if the tile that allows is not much worse than what two would get
+    Shape best{0, 0};
+    int best_cap = 0;
+    double best_score = -1.0;
+    for (int wgs = 3; wgs >= 2; --wgs) {
+        const long budget = 160 * 1024 / wgs - 3700; // static tables + allocation granularity (52.9 KB per workgroup still gives three per CU, 54.3 KB does not)
+        long fixed = (long)lds_bytes(0, M);
+        int cap = (int)((budget - fixed) / 42) & ~7;
+        if (cap_env > 0) cap = cap_env;
+        if (cap < 64)
+            continue;
+        cap = std::min(cap, 16384);
+        for (int txy = 1; txy <= 8; ++txy)
+            for (int tz = 1; tz <= 24; ++tz) {
+                const int nh = (txy + 2) * (txy + 2) * (tz + 2);
+                if (nh > MAX_NH || nh * pop > 0.86 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
+                    continue;
+                const int ncc = txy * txy * tz;
+                const double c = ncc * pop;                                 // centre atoms per tile
+                const double passes = std::ceil(c * 1.15 / NT);             // (head-room: a second pass for a handful of centres is a waste)
+                if (c * 1.15 > CEN_CAP)
+                    continue;
+                const double util = c / (passes * NT);                     // lane utilisation of the scan
+                const double reuse = (double)ncc / (double)nh;             // centre cells per staged cell
+                const double score = util * (0.35 + reuse) * (wgs == 3 ? 1.0 : 0.85);
+                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; }
+            }
+        if (cap_env > 0)
+            break;
+    }
+    if (!best.txy)
+        return p;
+    // Decision band of the single-precision scan (file header).  E bounds the staged coordinates (far-atom check of the
+    // kernel), du the error of one staged coordinate: rounding to f32 plus what the double-precision shift can lose;
+    // |d2_f32 - d2| <= (2 du)(2 sqrt(3) |d| + 6 du) + 5 * 2^-24 max(d2, rc^2) for the three subtractions and the FMA chain.
+    const int hmax = std::max(best.txy, best.tz) + 2;
+    const double E = ((double)hmax + 1.5) * rc;
+    double big = E;
+    for (int d = 0; d < 3; ++d) big = std::max(big, std::fabs(b.o[d]) + 2.0 * std::fabs(b.h[d * 4]) + E);
+    const double du = std::ldexp(E, -24) * 1.01 + std::ldexp(big, -49);
+    const double rcsq = rc * rc;
+    const double tol = 2.0 * (11.0 * du * rc + 12.0 * std::ldexp(rcsq, -24)); // twice the bound: a wider band costs nothing
+    p.mid = (float)rcsq;
+    const double want = tol + std::fabs((double)p.mid - rcsq);
+    float T = (float)want;
+    while ((double)T < want) T = std::nextafterf(T, INFINITY);
+    p.T = T;
+    p.txy = best.txy;
+    p.tz = best.tz;
+    p.cap = best_cap;
+    p.occupied = occ;
+    p.full = occ >= g.ncell;
+    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M);
+    g_last_plan[4] = p.full; g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
+    return p;
+}
+
+// count == true: nn and *max_count only (first pass of the exact-width variant); M is then 1
+int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
+                         int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,
+                         TileFilter &tf)
+{
+    using namespace lane;
+    const Shape ts{plan.txy, plan.tz};
+    int nt[3];
+    for (int d = 0; d < 3; ++d) {
+        const int T = d == 2 ? ts.tz : ts.txy;
+        nt[d] = (cg.g.nc[d] + T - 1) / T;
+    }
+    const int64_t ntiles = (int64_t)nt[0] * nt[1] * nt[2];
+    const int nsub = ts.tz; // second pass: one-cell slices along z
+    unsigned *live = sc.alloc_n<unsigned>((size_t)ntiles);
+    int *slot = sc.alloc_n<int>((size_t)ntiles + 1);
+    int *tile_list = sc.alloc_n<int>((size_t)ntiles);
+    int *flagged = sc.alloc_n<int>((size_t)ntiles);                   // tiles of the first pass for the second (each listed at most once)
+    int *flagged2 = sc.alloc_n<int>((size_t)ntiles * (size_t)nsub);   // slices of the second pass for the thread-per-atom code
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    int per = (int)((ntiles + 7) / 8);
+    int list_mode = 0;
+    if (plan.full) { // the statistics say that no 4x4x4 block of cells is empty: all tiles are live, workgroup b owns tile b
+        tile_list = nullptr;
+    } else {
+        hipLaunchKernelGGL(k_tile_live, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, cg.cell_start, cg.g, nt[0], nt[1], nt[2], ts, live);
+        MDH_TRY(exclusive_scan_u32(sc, live, slot, ntiles)); // slot[ntiles] = number of live tiles
+        hipLaunchKernelGGL(k_tile_compact, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, live, slot, (int)ntiles, tile_list);
+        // live tiles expected from the last known occupancy (+25 %); a workgroup takes further tiles of its chunk if that was too few
+        const int64_t est_live = std::max<int64_t>(1, plan.occupied / std::max(1, ts.txy * ts.txy * ts.tz) * 2);
+        per = std::max(1, std::min(per, (int)((est_live + est_live / 4 + 7) / 8)));
+        list_mode = 1;
+    }
+    const dim3 grid((unsigned)(per * 8));
+    const size_t lds = lds_bytes(plan.cap, count ? 1 : M);
+    int mp_shift = 0;
+    while ((1 << mp_shift) < M) ++mp_shift;
+    const int Mi = (int)M, wp = fill_pads ? 1 : 0;
+    const float nmid = -plan.mid;
+    const Shape ts2{ts.txy, 1};
+    const int nt2b = nt[2] * nsub;
+    if (lds > 60 * 1024) // above the default dynamic-LDS limit: raise it for the instance about to run
+        (void)hipFuncSetAttribute(count ? reinterpret_cast<const void *>(&k_neighbor_lane<true>) : reinterpret_cast<const void *>(&k_neighbor_lane<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (count) {
+        hipLaunchKernelGGL((k_neighbor_lane<true>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);
+        hipLaunchKernelGGL((k_neighbor_lane<true>), dim3(1024), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);
+    } else {
+        hipLaunchKernelGGL((k_neighbor_lane<false>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);
+        hipLaunchKernelGGL((k_neighbor_lane<false>), dim3(1024), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);
+    }
+    MDH_HIP(hipGetLastError());
+    // what the two passes listed for the thread-per-atom code (k_neighbor_tiles), in the tiling of the second pass
+    tf.flag = reinterpret_cast<const unsigned char *>(flagged2); // (non-null: "a tiled kernel ran"; the per-tile byte flags are not used with a list)
+    tf.any = cg.flags + 3;
+    tf.moved = cg.flags;
+    tf.list = flagged2;
+    tf.list_cap = (int)std::min<int64_t>(ntiles * nsub, 2147483647);
+    tf.tile = ts2.txy;
+    tf.tile_z = ts2.tz;
+    tf.nt[0] = nt[0]; tf.nt[1] = nt[1]; tf.nt[2] = nt2b;
+    return MDH_OK;
+}
+
+} // namespace mdh
+
+extern "C" int mdh_debug_neighbor_plan(int *plan8)
+{
+    for (int k = 0; k < 8; ++k) plan8[k] = mdh::lane::g_last_plan[k];
+    mdh::lane::g_last_plan[7] = 0; // [7] = 1: the plan was made since the last query
+    return MDH_OK;
+}

@@ -1,4 +1,4 @@
-"""wave-kernel probe: plan + debug counters + per-kernel time.  python tools/nbw_probe.py [cells] [M] [rc/a] [sigma] [reps]"""
+"""wave-kernel probe: plan + debug counters + per-kernel time.  python tools/nb_probe.py [cells] [M] [rc/a] [sigma] [reps]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,14 +21,13 @@ nn = torch.empty((n,), dtype=torch.int32, device=dev)
 for _ in range(2):
     _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, rc, verlet, dist, nn, 1, fill_pads=True)
 torch.cuda.synchronize()
-plan = (ctypes.c_int * 8)(); dbg = (ctypes.c_int * 4)()
-L.mdh_debug_wave_info(plan, dbg)
+plan = (ctypes.c_int * 8)()
 L.mdh_prof_reset(); L.mdh_prof_enable(1)
 for _ in range(reps):
     _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, rc, verlet, dist, nn, 1, fill_pads=True)
 torch.cuda.synchronize()
 L.mdh_prof_enable(0)
-L.mdh_debug_wave_info(plan, dbg)
+L.mdh_debug_neighbor_plan(plan)
 buf = ctypes.create_string_buffer(1 << 16); L.mdh_prof_report(buf, len(buf))
-print("plan txy,tz,cap,S,NG,full,pop*1000,occ:", list(plan), "dbg/rep slow,cells,flush,exact:", [d / reps for d in dbg])
+print("plan txy,tz,cap,lds,full,pop*1000,occ,fresh:", list(plan))
 print(buf.value.decode().strip(), "N", n, "env", {k: v for k, v in os.environ.items() if k.startswith("MDH_")}, flush=True)

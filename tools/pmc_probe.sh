@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: tools/pmc_probe.sh <tag> <counter list...>   one rocprofv3 PMC pass over tools/nbw_probe.py (csv under gpurun_out/pmc_<tag>)
+# usage: tools/pmc_probe.sh <tag> <counter list...>   one rocprofv3 PMC pass over tools/nb_probe.py (csv under gpurun_out/pmc_<tag>)
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag -o p -- python $R/tools/nbw_probe.py ${PROBE_ARGS:-136 16 0.854 0 2} > $R/gpurun_out/pmc_$tag.log 2>&1
+timeout -s KILL 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$tag -o p -- python $R/tools/nb_probe.py ${PROBE_ARGS:-136 16 0.854 0 2} > $R/gpurun_out/pmc_$tag.log 2>&1
 echo "pass $tag rc=$?"
 python - <<PY
 import csv, glob, collections
