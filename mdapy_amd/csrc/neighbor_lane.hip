@@ -60,6 +60,13 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 static int g_last_plan[8]; // test hook (mdh_debug_neighbor_plan)
 
+// workgroup barrier that orders LDS accesses only: global stores issued before it stay in flight (__syncthreads() would
+// wait for their acknowledgement)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -185,6 +192,25 @@ __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, floa
     mask = m;
 }
 
+// IEEE double-precision square root.  For x >= 2^-767 this is the compiler's own expansion of sqrt(x) (v_rsq_f64 seed, one
+// Goldschmidt step, two correction steps) minus its input scaling, which is the identity there: bit-identical results,
+// seven instructions fewer; smaller arguments (and 0, inf, NaN) take the library path.
+__device__ __forceinline__ double sqrt_f64(double x)
+{
+    if (__builtin_expect(!(x >= 0x1p-767 && x < 0x1p+1000), 0))
+        return sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    return __builtin_fma(d1, h, g);
+}
+
 // the same run decided by the reference's double-precision expression (threads with a pair inside the decision band)
 template <bool SELF>
 __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy, const double *__restrict__ lz,
@@ -233,8 +259,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     double2 *rzc = rxy + NT;                                        // [NT] wrapped centre z, (atom id | min(count, M) << 32)
     double *lz = reinterpret_cast<double *>(rzc + NT);              // [cap] staged raw z
     unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 16
-    unsigned short *tk = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [NT][M] tickets
-    unsigned short *lsh = tk + (size_t)NT * M + (((size_t)NT * M) & 1); // [cap] combined image code of a staged atom seen from this tile
+    unsigned short *tk = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [NT][M+1] tickets (slot M swallows the hits past M)
+    unsigned short *lsh = tk + (size_t)NT * (M + 1) + (((size_t)NT * (M + 1)) & 1); // [cap] combined image code of a staged atom seen from this tile
     const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
     __shared__ unsigned hc[MAX_NH + 2]; // halo cell: LDS offset | population << 16
     __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
@@ -414,18 +440,28 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 if (COUNT) {
                     vmax = max(vmax, hits);
                 } else {
-                    // masks -> tickets in walk order: bit (L4-1-j) of a run's mask is its candidate j
-                    unsigned short *my = tk + (size_t)tid * M;
+                    // masks -> tickets in walk order: bit (L4-1-j) of a run's mask is its candidate j.  A run rarely holds more
+                    // than a few hits: four predicated steps without a loop, then a loop for what is left
+                    unsigned short *my = tk + (size_t)tid * (M + 1);
                     int sl = 0;
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        const int k0 = (int)(hv[r] & 0xffffu), L4 = ((int)(hv[r] >> 16) + 3) & ~3;
+                        const int kend = (int)(hv[r] & 0xffffu) + ((((int)(hv[r] >> 16) + 3) & ~3) - 32); // + clz(m) = LDS index of the hit
                         unsigned m = mk[r];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (m) {
+                                const int z = __builtin_clz(m);
+                                my[min(sl, M)] = (unsigned short)(kend + z);
+                                ++sl;
+                                m &= ~(0x80000000u >> z);
+                            }
+                        }
                         while (m) {
-                            const int bpos = 31 - __builtin_clz(m);
-                            if (sl < M) my[sl] = (unsigned short)(k0 + (L4 - 1 - bpos));
+                            const int z = __builtin_clz(m);
+                            my[min(sl, M)] = (unsigned short)(kend + z);
                             ++sl;
-                            m &= ~(1u << bpos);
+                            m &= ~(0x80000000u >> z);
                         }
                     }
                     rxy[tid] = make_double2(xi, yi);
@@ -439,30 +475,46 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 const int MP = 1 << mp_shift; // smallest power of two >= M
                 const int e = tid & (MP - 1);
                 if (e < M) {
-                    for (int c = tid >> mp_shift; c < nrows; c += (NT >> mp_shift)) {
-                        const double2 cz = rzc[c];
-                        const long long ic = __double_as_longlong(cz.y);
-                        const int64_t o = (int64_t)(int)(ic & 0xffffffffll) * M + e;
-                        if (e < (int)(ic >> 32)) {
-                            const int k = tk[c * M + e];
-                            const double2 cj = lxy[k], cc = rxy[c];
-                            double d2;
-                            if (general_tile) d2 = exact_d2<true>(b, cj.x, cj.y, lz[k], cc.x, cc.y, cz.x, lsh[k]);
-                            else d2 = exact_d2<false>(b, cj.x, cj.y, lz[k], cc.x, cc.y, cz.x, 0);
-                            verlet[o] = __float_as_int(f4[k].w);
-                            dist[o] = sqrt(d2); // neighbor.cpp:174
-                        } else if (write_pads) {
-                            verlet[o] = -1;
-                            dist[o] = pad;
+                    const int step = NT >> mp_shift;
+                    for (int c0 = tid >> mp_shift; c0 < nrows; c0 += 2 * step) {
+                        // two rows per trip: their LDS reads are issued together, one wait serves both
+                        const int c1 = c0 + step;
+                        const bool two = c1 < nrows;
+                        const int ca = c0, cb2 = two ? c1 : c0;
+                        const double2 za = rzc[ca], zb = rzc[cb2];
+                        const long long ia = __double_as_longlong(za.y), ib = __double_as_longlong(zb.y);
+                        const bool ha = e < (int)(ia >> 32), hb = e < (int)(ib >> 32);
+                        const int ka = tk[ca * (M + 1) + (ha ? e : 0)], kb = tk[cb2 * (M + 1) + (hb ? e : 0)]; // (slot 0 of a row with no hit: any staged index, unused)
+                        const int kka = ha ? ka : 0, kkb = hb ? kb : 0;
+                        const double2 ja = lxy[kka], jb = lxy[kkb], wa = rxy[ca], wb = rxy[cb2];
+                        const double jza = lz[kka], jzb = lz[kkb];
+                        const int ida = __float_as_int(f4[kka].w), idb = __float_as_int(f4[kkb].w);
+                        double d2a, d2b;
+                        if (general_tile) {
+                            d2a = exact_d2<true>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, lsh[kka]);
+                            d2b = exact_d2<true>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, lsh[kkb]);
+                        } else {
+                            d2a = exact_d2<false>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
+                            d2b = exact_d2<false>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
+                        }
+                        const double ra = ha ? sqrt_f64(d2a) : pad, rb = hb ? sqrt_f64(d2b) : pad; // neighbor.cpp:174; pads neighbor.py:125-129
+                        const int64_t oa = (int64_t)(int)(ia & 0xffffffffll) * M + e, ob = (int64_t)(int)(ib & 0xffffffffll) * M + e;
+                        if (ha || write_pads) {
+                            __builtin_nontemporal_store(ha ? ida : -1, &verlet[oa]); // rows are written once and not read back here
+                            __builtin_nontemporal_store(ra, &dist[oa]);
+                        }
+                        if (two && (hb || write_pads)) {
+                            __builtin_nontemporal_store(hb ? idb : -1, &verlet[ob]);
+                            __builtin_nontemporal_store(rb, &dist[ob]);
                         }
                     }
                 }
-                __syncthreads();
+                lds_barrier(); // the row stores stay in flight
             }
         }
         if (!list_mode)
             break;
-        if (jt + (int)(gridDim.x >> 3) < per) __syncthreads(); // LDS is reused by the next tile
+        if (jt + (int)(gridDim.x >> 3) < per) lds_barrier(); // LDS is reused by the next tile
     } // tiles of this workgroup
     if (COUNT) {
         int m = vmax;
@@ -596,7 +648,7 @@ namespace lane {
 
 static size_t lds_bytes(int cap, int64_t M)
 {
-    size_t tk = (size_t)NT * M;
+    size_t tk = (size_t)NT * (size_t)(M + 1);
     tk += tk & 1;
     return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (size_t)NT * 32 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + tk * 2 + (size_t)cap * 2;
 }
