@@ -114,6 +114,18 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
                        const double *origin3, const int *boundary3, double rc, int *nn, int *max_count, int space,
                        void *stream);
 
+/*
+ * replaces _neighbor.build_neighbor_without_max_neigh       src/neighbor.cpp:189-349 in ONE call: the cell grid is built
+ * once and serves the counting pass and the build.  The reference returns freshly allocated arrays owned by capsules
+ * (:312-317); here the caller supplies the allocator: after counting, alloc(user, N, M, &verlet, &dist) must hand back
+ * (N, M) int32 / f64 arrays in the memory space of the call (M = max(max count, 1), also stored in *width); the rows are
+ * then written pads included (-1 / rc+1, :320-329).  nn (N) int32.  Synchronises `stream` once (between the passes).
+ */
+typedef int (*mdh_alloc_rows_fn)(void *user, int64_t N, int64_t M, int **verlet, double **dist);
+int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                             const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
+                             mdh_alloc_rows_fn alloc, void *user, int space, void *stream);
+
 /* replaces _neighbor.sort_verlet_by_distance               src/neighbor.cpp:745-775 */
 int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M, int sort_num, int space,
                                 void *stream);

@@ -21,6 +21,8 @@ ERR_BOX, ERR_HIP, ERR_ARG, ERR_NOMEM = -1, -2, -3, -4
 _lib = None
 
 i64, dbl, cint, vp = C.c_int64, C.c_double, C.c_int, C.c_void_p
+# mdh_alloc_rows_fn (include/mdapy_amd.h): int (*)(void *user, int64_t N, int64_t M, int **verlet, double **dist)
+ALLOC_ROWS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_double)))
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mdapy_amd.h
 _SIGNATURES = {
@@ -40,6 +42,7 @@ _SIGNATURES = {
     "mdh_slab_halo_select": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, cint, vp],
     "mdh_build_neighbor_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, cint, vp],
     "mdh_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, cint, vp],
+    "mdh_build_neighbor_exact": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, cint, vp],
     "mdh_sort_verlet_by_distance": [vp, vp, i64, i64, cint, cint, vp],
     "mdh_wrap_positions": [vp, vp, vp, i64, vp, vp, vp, cint, vp],
     "mdh_average_by_neighbor": [dbl, vp, vp, vp, i64, i64, vp, vp, cint, cint, vp],

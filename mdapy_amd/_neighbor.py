@@ -29,26 +29,40 @@ def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_lis
 
 def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1):
     """src/neighbor.cpp:189: exact row width = max neighbour count (>= 1); returns (verlet, dist, nn).
+    One library call (mdh_build_neighbor_exact): the cell grid is built once for the counting pass and the build; the rows
+    are allocated between the two through a callback, as the reference allocates them inside the call (:312-317).
     The arrays are HBM resident when the inputs are (or when a GPU is present and inputs are frame columns)."""
+    import ctypes
+
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
     N = int(len(x))
     on_dev = not all(isinstance(a, np.ndarray) for a in (x, y, z))
     nn = HArray.empty((N,), i32) if on_dev else np.zeros(N, i32)
-    import ctypes
+    rows = {}
 
-    mx = ctypes.c_int(0)
+    @_lib.ALLOC_ROWS
+    def alloc(user, n, m, pv, pd):
+        try:
+            if on_dev:
+                v, d = HArray.empty((int(n), int(m)), i32), HArray.empty((int(n), int(m)), f64)
+                pv[0] = ctypes.cast(v.data_ptr(), ctypes.POINTER(ctypes.c_int))
+                pd[0] = ctypes.cast(d.data_ptr(), ctypes.POINTER(ctypes.c_double))
+            else:
+                v, d = np.empty((int(n), int(m)), i32), np.empty((int(n), int(m)), f64)
+                pv[0] = v.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+                pd[0] = d.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            rows["v"], rows["d"] = v, d
+            return 0
+        except Exception:  # an exception must not cross the C frame: the library reports the failed allocation
+            return 1
+
+    width = ctypes.c_int64(0)
     c = Call(x, y, z, nn)
-    px, py, pz = c.inp(x, f64), c.inp(y, f64), c.inp(z, f64)
-    rc_ = _lib.lib().mdh_neighbor_count(px, py, pz, N, pb, po, pp, float(rc), c.out(nn, i32, upload=False),
-                                        ctypes.addressof(mx), c.space, c.stream)
+    rc_ = _lib.lib().mdh_build_neighbor_exact(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
+                                              c.out(nn, i32, upload=False), ctypes.addressof(width), alloc, None, c.space,
+                                              c.stream)
     c.done(rc_)
-    M = max(int(mx.value), 1)  # :301-304
-    if on_dev:
-        verlet, dist = HArray.empty((N, M), i32), HArray.empty((N, M), f64)
-    else:
-        verlet, dist = np.empty((N, M), i32), np.empty((N, M), f64)
-    build_neighbor(x, y, z, box, origin, boundary, rc, verlet, dist, nn, num_t, fill_pads=True)
-    return verlet, dist, nn
+    return rows["v"], rows["d"], nn
 
 
 def sort_verlet_by_distance(verlet_list, distance_list, sortNum, num_t=1):

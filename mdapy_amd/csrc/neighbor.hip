@@ -537,6 +537,38 @@ __global__ __launch_bounds__(256) void k_filter_overlap(const double *__restrict
     keep[j] = hit ? 0 : 1;
 }
 
+// One pass over a built cell grid: mode 0 = counts only (nn, *dmax), 1 = reference semantics (caller's pads), 2 = pads written.
+// The tile kernel where it applies, the round-1 tiled kernel for cells too full for it, the thread-per-atom code for the rest.
+static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N, double rc, int *dv, double *dd, int *dn,
+                         int64_t M, int mode, int *dmax)
+{
+    hipStream_t st = sc.stream();
+    MDH_HIP(hipMemsetAsync(cg.flags + 2, 0, sizeof(int) * 2, st)); // the tile lists of this pass (flags[0], unwrapped input, stays)
+    TileFilter tf{};
+    bool done = false;
+    if (g_neighbor_variant == 0 && !b.tri) { // tile kernel; the thread-per-atom code below then only mops up what it listed
+        GridStats gs;
+        MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
+        const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc);
+        if (lp.txy) {
+            MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, mode == 0 ? 1 : M, mode == 2, mode == 0, dmax, tf));
+            done = true;
+        }
+    }
+    if (!done && mode != 0 && g_neighbor_variant != 1 && !b.tri) { // cells too full for the kernel above (or forced): the round-1 tiled kernel
+        int64_t occ = 0;
+        MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
+        const TiledPlan plan = plan_tiled(b, cg.g, N, M, occ);
+        if (plan.tile)
+            MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, M, mode == 2, tf));
+    }
+    if (mode == 0) launch_neighbor<0>(st, cg, N, b, rc, nullptr, nullptr, dn, 1, dmax, tf);
+    else if (mode == 2) launch_neighbor<2>(st, cg, N, b, rc, dv, dd, dn, M, nullptr, tf);
+    else launch_neighbor<1>(st, cg, N, b, rc, dv, dd, dn, M, nullptr, tf);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
+
 } // namespace mdh
 
 using namespace mdh;
@@ -578,28 +610,7 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
     }
     {
         ProfRange pr("k_neighbor", sc.stream());
-        TileFilter tf{};
-        bool done = false;
-        if (g_neighbor_variant == 0 && !b.tri) { // tile kernel; the thread-per-atom code below then only mops up what it listed
-            GridStats gs;
-            MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
-            const LanePlan lp = plan_lane(b, cg.g, N, max_neigh, gs, rc);
-            if (lp.txy) {
-                MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, false, nullptr, tf));
-                done = true;
-            }
-        }
-        if (!done && g_neighbor_variant != 1 && !b.tri) { // cells too full for the kernel above (or forced): the round-1 tiled kernel
-            int64_t occ = 0;
-            MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
-            const TiledPlan plan = plan_tiled(b, cg.g, N, max_neigh, occ);
-            if (plan.tile)
-                MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, max_neigh, fill_pads != 0, tf));
-        }
-        if (fill_pads)
-            launch_neighbor<2>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr, tf);
-        else
-            launch_neighbor<1>(sc.stream(), cg, N, b, rc, dv, dd, dn, max_neigh, nullptr, tf);
+        MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, max_neigh, fill_pads ? 2 : 1, nullptr));
     }
     return sc.finish(space);
 }
@@ -630,19 +641,61 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
     CellGrid cg;
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
-    TileFilter tf{};
-    if (g_neighbor_variant == 0 && !b.tri) {
-        GridStats gs;
-        MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
-        const LanePlan lp = plan_lane(b, cg.g, N, 1, gs, rc);
-        if (lp.txy)
-            MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, nullptr, nullptr, dn, 1, false, true, dmax, tf));
-    }
-    launch_neighbor<0>(sc.stream(), cg, N, b, rc, nullptr, nullptr, dn, 1, dmax, tf);
+    MDH_TRY(neighbor_pass(sc, cg, b, N, rc, nullptr, nullptr, dn, 1, 0, dmax));
     MDH_HIP(hipMemcpyAsync(max_count, dmax, sizeof(int), hipMemcpyDeviceToHost, sc.stream()));
     MDH_TRY(sc.finish(space));
     MDH_HIP(hipStreamSynchronize(sc.stream()));
     return MDH_OK;
+}
+
+// _neighbor.build_neighbor_without_max_neigh in one call: ONE cell grid serves the counting pass and the build
+int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                             const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
+                             mdh_alloc_rows_fn alloc, void *user, int space, void *stream)
+{
+    if (N < 0 || N >= 2147483647LL || !(rc > 0) || !width || !alloc) { set_error("mdh_build_neighbor_exact: invalid N, rc, width or allocator"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    int *verlet = nullptr;
+    double *dist = nullptr;
+    *width = 1; // neighbor.cpp:301-304: at least one column
+    if (N == 0) {
+        if (alloc(user, 0, 1, &verlet, &dist) != 0) { set_error("mdh_build_neighbor_exact: the row allocator failed"); return MDH_ERR_NOMEM; }
+        return MDH_OK;
+    }
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    int *dn = sc.stage(nn, (size_t)N, space, false, true);
+    int *dmax = sc.alloc_n<int>(1);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    MDH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), st));
+    CellGrid cg;
+    MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    {
+        ProfRange pr("cell_grid", st);
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
+    }
+    int hmax = 0;
+    {
+        ProfRange pr("k_neighbor_count", st);
+        MDH_TRY(neighbor_pass(sc, cg, b, N, rc, nullptr, nullptr, dn, 1, 0, dmax));
+        MDH_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    MDH_HIP(hipStreamSynchronize(st));
+    const int64_t M = hmax > 1 ? hmax : 1;
+    *width = M;
+    if (alloc(user, N, M, &verlet, &dist) != 0 || !verlet || !dist) { set_error("mdh_build_neighbor_exact: the row allocator failed"); return MDH_ERR_NOMEM; }
+    int *dv = sc.stage(verlet, (size_t)(N * M), space, false, true);
+    double *dd = sc.stage(dist, (size_t)(N * M), space, false, true);
+    if (sc.failed())
+        return sc.error();
+    {
+        ProfRange pr("k_neighbor", st);
+        MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, M, 2, nullptr));
+    }
+    return sc.finish(space);
 }
 
 int mdh_filter_overlap_atom(const double *x, const double *y, const double *z, int64_t N, const double *box9,
