@@ -1,26 +1,19 @@
-"""Ackland-Jones analysis.  Mirrors ``mdapy.ackland_jones_analysis.AcklandJonesAnalysis``
-(src/mdapy/ackland_jones_analysis.py:15-120): 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico."""
-from __future__ import annotations
-
+"""Ackland-Jones bond-angle analysis — the drop-in for ``mdapy.ackland_jones_analysis.AcklandJonesAnalysis``
+(src/mdapy/ackland_jones_analysis.py:15-120).  ``aja``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico; needs the 14 nearest
+neighbours with their distances, nearest first."""
 import numpy as np
 
-from . import _aja
-from . import tool_function as tool
-from .box import Box
+from . import kernels, policy
 from .devarray import empty
-from .frame import Frame
 from .parallel import get_num_threads
 
 
 class AcklandJonesAnalysis:
-    def __init__(self, data: Frame, box: Box, verlet_list, distance_list) -> None:
-        self.data = data
-        self.box = box
-        self.verlet_list = verlet_list
-        self.distance_list = distance_list
+    def __init__(self, data, box, verlet_list, distance_list):
+        self.data, self.box = data, box
+        self.verlet_list, self.distance_list = verlet_list, distance_list
 
-    def compute(self) -> None:
+    def compute(self):
         self.aja = empty(self.data.shape[0], np.int32)
-        x, y, z = tool.xyz(self.data)
-        _aja.compute_aja(x, y, z, self.box.box, self.box.origin, self.box.boundary, self.verlet_list, self.distance_list,
-                         self.aja, get_num_threads())
+        kernels.aja.compute_aja(*policy.positions(self.data), *policy.box_args(self.box), self.verlet_list,
+                                self.distance_list, self.aja, get_num_threads())

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import _atomtemp
+from . import kernels
 from .devarray import as_numpy, empty
 from .frame import Frame
 from .parallel import get_num_threads
@@ -51,5 +51,5 @@ class AtomicTemperature:
             raise ValueError("No atomic mass.")
         self.T = empty(self.data.shape[0], np.float64)
         v = [np.ascontiguousarray(as_numpy(self.data[c].to_numpy()) * 1e3 * self.factor) for c in ("vx", "vy", "vz")]
-        _atomtemp.compute_temp(self.verlet_list, self.distance_list, v[0], v[1], v[2], amass, self.T, self.rc,
+        kernels.atomtemp.compute_temp(self.verlet_list, self.distance_list, v[0], v[1], v[2], amass, self.T, self.rc,
                                get_num_threads())

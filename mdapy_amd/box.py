@@ -1,164 +1,126 @@
-"""Simulation box (host side).  Mirrors the public surface of the reference's
-``mdapy.box.Box`` (src/mdapy/box.py:93-502): row-vector 3x3 matrix, origin,
-0/1 boundary flags, perpendicular thickness and the small-box replication rule.
-The kernels rebuild their own device-side box from (box, origin, boundary) on
-every call (csrc/runtime.hip: make_box), exactly like the reference's C++
-``get_box`` (src/box.h:208)."""
-from __future__ import annotations
+"""Simulation box, host side — the drop-in for ``mdapy.box.Box`` (src/mdapy/box.py:93-502).
 
-from typing import Iterable, Optional, Tuple, Union
-
+Rows of the 3x3 matrix are the cell vectors a, b, c; ``origin`` is the corner they start from; ``boundary`` holds 1 for a
+periodic direction and 0 for an open one.  The kernels rebuild their own device-side box from these three arrays on every
+call (csrc/runtime.hip: make_box), as the reference's C++ does (src/box.h:208)."""
 import numpy as np
+
+_SCALARS = (int, float, np.integer, np.floating)
+_SEQUENCES = (list, tuple, np.ndarray)
+
+
+def _three(values, what, kind):
+    """a 3-vector of the given dtype from a list / tuple / array, with the reference's error texts"""
+    if not isinstance(values, _SEQUENCES):
+        raise TypeError(f"Invalid {what.lower()} type: {type(values)}")
+    vec = np.array(values, kind)
+    if vec.shape != (3,):
+        raise ValueError(f"{what} must be a 3-element array, got shape {vec.shape}")
+    return vec
+
+
+def _cell_and_origin(spec, origin):
+    """(3x3 cell, origin-or-None) from any of the accepted box descriptions: one edge length, three edge lengths, a 3x3
+    matrix, a 4x3 matrix whose last row is the origin (old mdapy files), a 3x4 matrix whose last column is (OVITO)"""
+    if isinstance(spec, _SCALARS):
+        return np.eye(3, dtype=np.float64) * float(spec), origin
+    if not isinstance(spec, _SEQUENCES):
+        raise TypeError(f"Invalid box type: {type(spec)}")
+    m = np.array(spec, np.float64)
+    if m.shape == (3,):
+        return np.diag(m), origin
+    if m.shape == (3, 3):
+        return m, origin
+    if m.shape == (4, 3):
+        return np.array(m[:3]), np.array(m[3])
+    if m.shape == (3, 4):
+        return np.array(m[:, :3]), np.array(m[:, 3])
+    raise ValueError(f"Invalid box shape: {m.shape}")
 
 
 class Box:
-    def __init__(self, box, boundary: Optional[Iterable[int]] = None, origin: Optional[Iterable[float]] = None):
-        if isinstance(box, Box):  # copy constructor (box.py:107-113)
-            self._box = box.box.copy()
-            self._origin = box.origin.copy()
-            self._boundary = box.boundary.copy()
-            self._update()
+    def __init__(self, box, boundary=None, origin=None):
+        if isinstance(box, Box):  # copy
+            self._box, self._origin, self._boundary = box.box.copy(), box.origin.copy(), box.boundary.copy()
+            self._derive()
             return
-        self._box, self._origin = self._parse_box_origin(box, origin)
-        self._update()
+        cell, start = _cell_and_origin(box, origin)
+        self._box = np.ascontiguousarray(cell)
+        self._origin = np.zeros(3, np.float64) if start is None else _three(start, "Origin", np.float64)
+        self._derive()
         self.set_boundary(boundary)
 
-    # ---- parsing (box.py:120-223)
-    @staticmethod
-    def _parse_origin(origin) -> np.ndarray:
-        if origin is None:
-            return np.zeros(3, np.float64)
-        if isinstance(origin, (list, tuple, np.ndarray)):
-            o = np.array(origin, np.float64)
-            if o.shape != (3,):
-                raise ValueError(f"Origin must be a 3-element array, got shape {o.shape}")
-            return o
-        raise TypeError(f"Invalid origin type: {type(origin)}")
-
-    @classmethod
-    def _parse_box_origin(cls, box, origin) -> Tuple[np.ndarray, np.ndarray]:
-        if isinstance(box, (int, float, np.integer, np.floating)):
-            b = np.eye(3, dtype=np.float64) * float(box)
-        elif isinstance(box, (list, tuple, np.ndarray)):
-            b = np.array(box, np.float64)
-            if b.shape == (3,):
-                b = np.diag(b)
-            elif b.shape == (3, 3):
-                pass
-            elif b.shape == (4, 3):  # old mdapy format: last row is the origin
-                origin = np.array(b[-1])
-                b = np.array(b[:-1])
-            elif b.shape == (3, 4):  # ovito format: last column is the origin
-                origin = np.array(b[:, -1])
-                b = np.array(b[:, :-1])
-            else:
-                raise ValueError(f"Invalid box shape: {b.shape}")
-        else:
-            raise TypeError(f"Invalid box type: {type(box)}")
-        return np.ascontiguousarray(b), cls._parse_origin(origin)
-
-    def _update(self):
-        b = self._box
-        self._triclinic = bool(
-            any(abs(b[i, j]) > 1e-10 for i in range(3) for j in range(3) if i != j) or np.any(np.diag(b) < 0)
-        )  # box.py:262-276
-        self._inverse = np.linalg.inv(b)
-        self._volume = float(np.linalg.det(b))
+    def _derive(self):
+        cell = self._box
+        off_diagonal = cell[~np.eye(3, dtype=bool)]
+        # sheared, or mirrored along an axis: the general (triclinic) code path of the kernels (src/box.h:216-222)
+        self._triclinic = bool(np.any(np.abs(off_diagonal) > 1e-10) or np.any(np.diag(cell) < 0))
+        self._inverse = np.linalg.inv(cell)
+        self._volume = float(np.linalg.det(cell))
 
     # ---- setters
-    def set_box(self, box) -> None:
-        if isinstance(box, (list, tuple, np.ndarray)) and np.array(box).shape not in ((3,), (3, 3)):
+    def set_box(self, box):
+        if isinstance(box, _SEQUENCES) and np.array(box).shape not in ((3,), (3, 3)):
             raise ValueError(f"Invalid box shape: {np.array(box).shape}")
-        self._box, _ = self._parse_box_origin(box, self._origin)
-        self._update()
+        self._box = np.ascontiguousarray(_cell_and_origin(box, None)[0])
+        self._derive()
 
-    def set_origin(self, origin) -> None:
-        self._origin = self._parse_origin(origin)
+    def set_origin(self, origin):
+        self._origin = np.zeros(3, np.float64) if origin is None else _three(origin, "Origin", np.float64)
 
-    def set_boundary(self, boundary) -> None:
+    def set_boundary(self, boundary):
         if boundary is None:
             self._boundary = np.array([1, 1, 1], np.int32)
-            return
-        if isinstance(boundary, (list, tuple, np.ndarray)):
-            p = np.array(boundary, np.int32)
-            if p.shape != (3,):
-                raise ValueError(f"Boundary must be a 3-element array, got shape {p.shape}")
-            self._boundary = np.where(p != 0, 1, 0)  # box.py:255 (int64 result, as in the reference)
-            return
-        raise TypeError(f"Invalid boundary type: {type(boundary)}")
+        else:
+            flags = _three(boundary, "Boundary", np.int32)
+            self._boundary = np.where(flags != 0, 1, 0)  # (platform integer, like the reference's)
 
-    # ---- properties
-    @property
-    def box(self) -> np.ndarray:
-        return self._box
+    # ---- read access
+    box = property(lambda self: self._box)
+    origin = property(lambda self: self._origin)
+    boundary = property(lambda self: self._boundary)
+    triclinic = property(lambda self: self._triclinic)
+    inverse_box = property(lambda self: self._inverse)
+    volume = property(lambda self: self._volume)
 
-    @property
-    def origin(self) -> np.ndarray:
-        return self._origin
-
-    @property
-    def boundary(self) -> np.ndarray:
-        return self._boundary
-
-    @property
-    def triclinic(self) -> bool:
-        return self._triclinic
-
-    @property
-    def inverse_box(self) -> np.ndarray:
-        return self._inverse
-
-    @property
-    def volume(self) -> float:
-        return self._volume
-
-    def __repr__(self) -> str:
+    def __repr__(self):
         return (f"Box information:\n{self.box}\nOrigin: {self.origin}\nTriclinic: {self.triclinic}\n"
                 f"Boundary: {self.boundary}")
 
     # ---- geometry
-    def pbc(self, rij: np.ndarray) -> np.ndarray:
-        """minimum-image convention for one displacement vector (box.py:448-467)"""
-        f = np.asarray(rij, np.float64) @ self.inverse_box
-        for i in range(3):
-            if self.boundary[i] == 1:
-                f[i] -= np.floor(f[i] + 0.5)
-        return f @ self.box
+    def pbc(self, rij):
+        """minimum image of one displacement vector"""
+        frac = np.asarray(rij, np.float64) @ self.inverse_box
+        periodic = self.boundary == 1
+        frac[periodic] -= np.floor(frac[periodic] + 0.5)
+        return frac @ self.box
 
     def align_to_lammps_box(self):
-        """the same cell as a LAMMPS-style lower-triangular box + the rotation that maps positions into it (box.py:425-443)"""
-        ax = np.linalg.norm(self.box[0])
-        bx = self.box[1] @ (self.box[0] / ax)
-        by = np.sqrt(np.linalg.norm(self.box[1]) ** 2 - bx ** 2)
-        cx = self.box[2] @ (self.box[0] / ax)
-        cy = (self.box[1] @ self.box[2] - bx * cx) / by
-        cz = np.sqrt(np.linalg.norm(self.box[2]) ** 2 - cx ** 2 - cy ** 2)
-        box = np.array([[ax, bx, cx], [0, by, cy], [0, 0, cz]], dtype=np.float64).T
-        rotation = np.linalg.solve(self.box, box)
-        return Box(box, self.boundary, self.origin), rotation
+        """(the same cell with a along x and b in the xy plane, the rotation that takes positions into it)"""
+        a, b, c = self.box
+        ax = np.linalg.norm(a)
+        ahat = a / ax
+        bx = b @ ahat
+        by = np.sqrt(np.linalg.norm(b) ** 2 - bx ** 2)
+        cx = c @ ahat
+        cy = (b @ c - bx * cx) / by
+        cz = np.sqrt(np.linalg.norm(c) ** 2 - cx ** 2 - cy ** 2)
+        lower = np.array([[ax, bx, cx], [0, by, cy], [0, 0, cz]], dtype=np.float64).T
+        return Box(lower, self.boundary, self.origin), np.linalg.solve(self.box, lower)
 
-    def get_thickness(self) -> np.ndarray:
-        """perpendicular thickness per axis (box.py:469-481)"""
-        b = self.box
-        return np.array(
-            [
-                self.volume / np.linalg.norm(np.cross(b[1], b[2])),
-                self.volume / np.linalg.norm(np.cross(b[0], b[2])),
-                self.volume / np.linalg.norm(np.cross(b[0], b[1])),
-            ],
-            dtype=np.float64,
-        )
+    def get_thickness(self):
+        """distance between opposite faces, per direction: volume over the area of the face the other two vectors span"""
+        a, b, c = self.box
+        faces = (np.cross(b, c), np.cross(a, c), np.cross(a, b))
+        return np.array([self.volume / np.linalg.norm(f) for f in faces], dtype=np.float64)
 
-    def check_small_box(self, rc: float) -> np.ndarray:
-        """replications needed so that every periodic thickness is >= 2 rc (box.py:483-502)"""
-        t = self.get_thickness()
-        repeat = np.ones(3, dtype=np.int32)
-        for i in range(3):
-            if self.boundary[i] == 1 and t[i] < 2 * rc:
-                repeat[i] = int(np.ceil(2.0 * rc / t[i]))
-        return repeat
+    def check_small_box(self, rc):
+        """copies per axis after which every periodic direction is at least two cutoffs thick"""
+        from .policy import axis_copies
 
-    def is_general_box(self, tol: float = 1e-6) -> bool:
-        b = self.box
-        return bool(b[0, 0] <= tol or b[1, 1] <= tol or b[2, 2] <= tol or abs(b[0, 1]) > tol
-                    or abs(b[0, 2]) > tol or abs(b[1, 2]) > tol)
+        return axis_copies(self, 2 * rc)
+
+    def is_general_box(self, tol=1e-6):
+        m = self.box
+        upper = (m[0, 1], m[0, 2], m[1, 2])
+        return bool(min(m[0, 0], m[1, 1], m[2, 2]) <= tol or max(abs(v) for v in upper) > tol)

@@ -1,66 +1,49 @@
-"""Common neighbour analysis.  Mirrors ``mdapy.common_neighbor_analysis.CommonNeighborAnalysis``
-(src/mdapy/common_neighbor_analysis.py:64-154): 0 other, 1 FCC, 2 HCP, 3 BCC, 4 ICO."""
-from __future__ import annotations
+"""Common neighbour analysis — the drop-in for ``mdapy.common_neighbor_analysis.CommonNeighborAnalysis``
+(src/mdapy/common_neighbor_analysis.py:64-154).  ``pattern``: 0 other, 1 FCC, 2 HCP, 3 BCC, 4 ICO.
 
-from typing import Optional
-
+``rc`` given: fixed-cutoff variant over a cutoff list (atoms with 12 or 14 neighbours are classified);
+``rc=None``: adaptive variant over the 14 nearest neighbours.  A list handed in by the caller is used as it is; without
+one the class searches itself, on a replica if a periodic direction is thinner than 15 A."""
 import numpy as np
 
-from . import _cna
-from . import tool_function as tool
-from .box import Box
+from . import kernels, policy
 from .devarray import zeros
-from .frame import Frame
-from .knn import NearestNeighbor
 from .neighbor import Neighbor
 from .parallel import get_num_threads
 
+ADAPTIVE_DEPTH = 14
+
 
 class CommonNeighborAnalysis:
-    def __init__(self, data: Frame, box: Box, verlet_list=None, neighbor_number=None, rc: Optional[float] = None):
-        self.data = data
-        self.box = box
-        self.verlet_list = verlet_list
-        self.neighbor_number = neighbor_number
+    def __init__(self, data, box, verlet_list=None, neighbor_number=None, rc=None):
         if rc is not None:
             assert rc > 0
-        self.rc = rc
+        self.data, self.box, self.rc = data, box, rc
+        self.verlet_list, self.neighbor_number = verlet_list, neighbor_number
         self.pattern = None
 
-    def compute(self):
-        N = self.data.shape[0]
-        if sum(self.box.boundary) == 0 and N <= 14:  # :88-91
-            self.pattern = np.zeros(N, dtype=np.int32)
-            return
-        box, data = self.box, self.data
-        verlet_list, neighbor_number = self.verlet_list, self.neighbor_number
-        wrap_pos_L = 15
-        if self.verlet_list is None:
-            repeat = np.ceil(wrap_pos_L / self.box.get_thickness()).astype(int)
-            for i in range(3):
-                if self.box.boundary[i] == 0:
-                    repeat[i] = 1
-            if sum(repeat) != 3:
-                data, box = tool._replicate_pos(data, box, *repeat)
-            if self.rc is None:
-                knn = NearestNeighbor(data, box, 14)
-                knn.compute()
-                verlet_list = knn.indices_py
-            else:
-                repeat = box.check_small_box(self.rc)
-                if sum(repeat) != 3:
-                    data, box = tool._replicate_pos(data, box, *repeat)
-                neigh = Neighbor(self.rc, box, data)
-                neigh.compute()
-                verlet_list = neigh.verlet_list
-                neighbor_number = neigh.neighbor_number
-        else:
-            assert neighbor_number is not None or self.rc is None
-        N = data.shape[0]
-        self.pattern = zeros(N, np.int32)  # the kernels rely on the pre-zeroing (:128)
-        x, y, z = tool.xyz(data)
+    def _own_lists(self):
+        """(frame, box, rows, counts) from a search of our own"""
+        frame, cell, _ = policy.widened(self.data, self.box, policy.NEAREST_SPAN)
         if self.rc is None:
-            _cna.acna(x, y, z, box.box, box.origin, box.boundary, verlet_list, self.pattern, get_num_threads())
+            return frame, cell, policy.nearest_rows(frame, cell, ADAPTIVE_DEPTH), None
+        frame, cell, _ = policy.widened(frame, cell, 2.0 * self.rc)
+        found = Neighbor(self.rc, cell, frame)
+        found.compute()
+        return frame, cell, found.verlet_list, found.neighbor_number
+
+    def compute(self):
+        if policy.hopeless(self.box, self.data.shape[0], ADAPTIVE_DEPTH):
+            self.pattern = np.zeros(self.data.shape[0], dtype=np.int32)
+            return
+        if self.verlet_list is None:
+            frame, cell, rows, counts = self._own_lists()
         else:
-            _cna.fcna(x, y, z, box.box, box.origin, box.boundary, verlet_list, neighbor_number, self.pattern,
-                      self.rc, get_num_threads())
+            frame, cell, rows, counts = self.data, self.box, self.verlet_list, self.neighbor_number
+            assert counts is not None or self.rc is None
+        self.pattern = zeros(frame.shape[0], np.int32)  # the kernels only ever raise a label: start from "other"
+        where = (*policy.positions(frame), *policy.box_args(cell), rows)
+        if self.rc is None:
+            kernels.cna.acna(*where, self.pattern, get_num_threads())
+        else:
+            kernels.cna.fcna(*where, counts, self.pattern, self.rc, get_num_threads())

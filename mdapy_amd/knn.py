@@ -1,52 +1,57 @@
-"""k nearest neighbours.  Mirrors ``mdapy.knn.NearestNeighbor`` (src/mdapy/knn.py:17-129)."""
-from __future__ import annotations
+"""k nearest neighbours — the drop-in for ``mdapy.knn.NearestNeighbor`` (src/mdapy/knn.py:17-129).
 
+``compute()`` leaves ``indices_py`` (N, k) int32 and ``distances_py`` (N, k) f64, nearest first; periodic images count
+as separate neighbours.  Only a system with fewer than k atoms is replicated (three more copies per periodic axis
+until k atoms exist), and then ``_enlarge_data`` / ``_enlarge_box`` describe what the indices refer to."""
 import numpy as np
 
-from . import _fast_knn
-from . import tool_function as tool
-from .box import Box
+from . import kernels, policy
 from .devarray import empty
-from .frame import Frame
 from .parallel import get_num_threads
 
-MAX_K = 24  # knn.py:14
+MAX_K = 24  # the search keeps its candidates in a fixed-size list (src/mdapy/knn.py:14)
 
 
 class NearestNeighbor:
-    def __init__(self, data: Frame, box: Box, k: int):
-        for col in ("x", "y", "z"):
-            assert col in data.columns, f"data must contain column {col!r}."
-        assert data.shape[0] > 0, "data must contain at least one atom."
-        k = int(k)
-        assert 1 <= k <= MAX_K, f"k must be in [1, {MAX_K}], got {k}."
-        self.data = data
-        self.box = box
-        self.k = k
+    def __init__(self, data, box, k):
+        for name in ("x", "y", "z"):
+            if name not in data.columns:
+                raise AssertionError(f"data must contain column {name!r}.")
+        if data.shape[0] <= 0:
+            raise AssertionError("data must contain at least one atom.")
+        self.k = int(k)
+        if not (1 <= self.k <= MAX_K):
+            raise AssertionError(f"k must be in [1, {MAX_K}], got {self.k}.")
+        self.data, self.box = data, box
+
+    def _copies_for_k(self):
+        """copies per axis so that the searched system holds at least k atoms"""
+        copies = [1, 1, 1]
+        atoms = self.data.shape[0]
+        if atoms >= self.k:
+            return copies
+        periodic = [a for a in range(3) if self.box.boundary[a] == 1]
+        if not periodic:
+            raise AssertionError(
+                f"Need periodic boundary if you want to query {self.k} neighbors " f"in {atoms}-atom system."
+            )
+        while atoms * copies[0] * copies[1] * copies[2] < self.k:
+            for a in periodic:
+                copies[a] += 3
+        return copies
+
+    # (name kept: part of the reference class' surface)
+    def _check_repeat_nearest(self):
+        return self._copies_for_k()
 
     def compute(self):
-        data, box = self.data, self.box
-        repeat = self._check_repeat_nearest()
-        if sum(repeat) != 3:
-            self._enlarge_data, self._enlarge_box = tool.replicate(data, box, *repeat)
-            box, data = self._enlarge_box, self._enlarge_data
-        N = data.shape[0]
-        self.indices_py = empty((N, self.k), np.int32)
-        self.distances_py = empty((N, self.k), np.float64)
-        x, y, z = tool.xyz(data)
-        _fast_knn.knn(x, y, z, box.box, box.origin, box.boundary, self.k, self.indices_py, self.distances_py,
-                      get_num_threads())
-
-    def _check_repeat_nearest(self):
-        """replicate (+3 per periodic axis) until the system holds at least k atoms (knn.py:105-129)"""
-        repeat = [1, 1, 1]
-        N = self.data.shape[0]
-        if self.k > N:
-            assert sum(self.box.boundary) > 0, (
-                f"Need periodic boundary if you want to query {self.k} neighbors " f"in {N}-atom system."
-            )
-            while np.prod(repeat) * N < self.k:
-                for i in range(3):
-                    if self.box.boundary[i] == 1:
-                        repeat[i] += 3
-        return repeat
+        frame, cell = self.data, self.box
+        copies = self._copies_for_k()
+        if not policy.is_single(copies):
+            frame, cell = policy.replica(frame, cell, copies, all_columns=True)
+            self._enlarge_data, self._enlarge_box = frame, cell
+        rows = frame.shape[0]
+        self.indices_py = empty((rows, self.k), np.int32)
+        self.distances_py = empty((rows, self.k), np.float64)
+        kernels.fast_knn.knn(*policy.positions(frame), *policy.box_args(cell), self.k, self.indices_py, self.distances_py,
+                             get_num_threads())

@@ -1,73 +1,66 @@
-"""Cutoff neighbor list.  Mirrors ``mdapy.neighbor.Neighbor`` (src/mdapy/neighbor.py:13-142):
-same constructor checks, small-box replication, the two kernels (exact width when
-``max_neigh`` is None, fixed width otherwise) and the ``ValueError`` on overflow."""
-from __future__ import annotations
+"""Cutoff neighbor list — the drop-in for ``mdapy.neighbor.Neighbor`` (src/mdapy/neighbor.py:13-142).
 
-from typing import Optional
-
+Same constructor, checks and error texts; ``compute()`` leaves ``verlet_list`` (N, M) int32 padded with -1,
+``distance_list`` (N, M) f64 padded with rc + 1 and ``neighbor_number`` (N) int32, plus ``_enlarge_data`` /
+``_enlarge_box`` when a thin periodic box had to be replicated first.  With ``max_neigh=None`` M is the largest
+count found (one library call, one cell grid for counting and building); with a fixed ``max_neigh`` an overflow is a
+``ValueError`` that names the width that would have fitted."""
 import numpy as np
 
-from . import _neighbor
-from . import tool_function as tool
-from .box import Box
+from . import kernels, policy
 from .devarray import empty
-from .frame import Frame
 from .parallel import get_num_threads
+
+_NEEDS = ("x", "y", "z")
 
 
 class Neighbor:
-    def __init__(self, rc: float, box: Box, data: Frame, max_neigh: Optional[int] = None):
-        rc = float(rc)
-        assert rc > 0, f"rc must be positive, got {rc}."
-        if max_neigh is not None:
-            max_neigh = int(max_neigh)
-            assert max_neigh > 0, f"max_neigh must be positive, got {max_neigh}."
-        for col in ("x", "y", "z"):
-            assert col in data.columns, f"data must contain column {col!r}."
-        self.rc = rc
-        self.box = box
-        self.data = data
-        self.max_neigh = max_neigh
-        self.N = self.data.shape[0]
-        assert self.N > 0, "data must contain at least one atom."
+    def __init__(self, rc, box, data, max_neigh=None):
+        self.rc = float(rc)
+        if not self.rc > 0:
+            raise AssertionError(f"rc must be positive, got {self.rc}.")
+        self.max_neigh = None if max_neigh is None else int(max_neigh)
+        if self.max_neigh is not None and self.max_neigh <= 0:
+            raise AssertionError(f"max_neigh must be positive, got {self.max_neigh}.")
+        missing = [name for name in _NEEDS if name not in data.columns]
+        if missing:
+            raise AssertionError(f"data must contain column {missing[0]!r}.")
+        self.box, self.data = box, data
+        self.N = data.shape[0]
+        if self.N <= 0:
+            raise AssertionError("data must contain at least one atom.")
 
     def compute(self):
-        repeat = self.box.check_small_box(self.rc)  # neighbor.py:94
-        if sum(repeat) != 3:
-            self._enlarge_data, self._enlarge_box = tool.replicate(self.data, self.box, *repeat)
-            data, box = self._enlarge_data, self._enlarge_box
-        else:
-            data, box = self.data, self.box
-        x, y, z = tool.xyz(data)
-        N = data.shape[0]
-
-        if self.max_neigh is None:  # neighbor.py:108-117
-            self.verlet_list, self.distance_list, self.neighbor_number = _neighbor.build_neighbor_without_max_neigh(
-                x, y, z, box.box, box.origin, box.boundary, self.rc, get_num_threads()
-            )
+        # a periodic direction thinner than two cutoffs would make an atom its own neighbour's image: search a replica
+        frame, cell, grown = policy.widened(self.data, self.box, 2.0 * self.rc, all_columns=True)
+        if grown:
+            self._enlarge_data, self._enlarge_box = frame, cell
+        where = (*policy.positions(frame), *policy.box_args(cell), self.rc)
+        if self.max_neigh is None:
+            rows = kernels.neighbor.build_neighbor_without_max_neigh(*where, get_num_threads())
+            self.verlet_list, self.distance_list, self.neighbor_number = rows
             return
-
-        # fixed width (neighbor.py:125-134): the kernel writes the -1 / rc+1 pads itself
-        self.verlet_list = empty((N, self.max_neigh), np.int32)
-        self.distance_list = empty((N, self.max_neigh), np.float64)
-        self.neighbor_number = empty((N,), np.int32)
-        self._fill(x, y, z, box)
-        real_max = int(self.neighbor_number.max(initial=0))
-        if real_max > self.max_neigh:  # neighbor.py:135-142
+        width, atoms = self.max_neigh, frame.shape[0]
+        self.verlet_list = empty((atoms, width), np.int32)
+        self.distance_list = empty((atoms, width), np.float64)
+        self.neighbor_number = empty((atoms,), np.int32)
+        self._search_fixed(where)
+        longest = int(self.neighbor_number.max(initial=0))
+        if longest > width:
             raise ValueError(
-                f"max_neigh={self.max_neigh} is too small: at least one "
-                f"atom has {real_max} neighbors within rc={self.rc}. "
-                f"Re-run with max_neigh>={real_max} (or omit max_neigh "
+                f"max_neigh={width} is too small: at least one "
+                f"atom has {longest} neighbors within rc={self.rc}. "
+                f"Re-run with max_neigh>={longest} (or omit max_neigh "
                 "to let mdapy size the buffer automatically)."
             )
 
-    def _fill(self, x, y, z, box):
-        if isinstance(self.verlet_list, np.ndarray):  # host buffers (backend patched in CPU tests): reference init
-            self.verlet_list.fill(-1)
-            self.distance_list.fill(self.rc + 1.0)
-            self.neighbor_number.fill(0)
-            _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, self.rc, self.verlet_list,
-                                     self.distance_list, self.neighbor_number, get_num_threads())
-        else:
-            _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, self.rc, self.verlet_list,
-                                     self.distance_list, self.neighbor_number, get_num_threads(), fill_pads=True)
+    def _search_fixed(self, where):
+        out = (self.verlet_list, self.distance_list, self.neighbor_number)
+        if isinstance(self.verlet_list, np.ndarray):
+            # host buffers: the caller pre-fills the pads, as the reference's Python does (neighbor.py:125-129)
+            self.verlet_list[...] = -1
+            self.distance_list[...] = self.rc + 1.0
+            self.neighbor_number[...] = 0
+            kernels.neighbor.build_neighbor(*where, *out, get_num_threads())
+        else:  # HBM buffers: the kernel writes the pads itself, no extra pass over 12 M bytes per atom
+            kernels.neighbor.build_neighbor(*where, *out, get_num_threads(), fill_pads=True)

@@ -1,17 +1,11 @@
-"""Thread-count plumbing kept for signature compatibility with the reference
-(src/mdapy/parallel.py:1-53, MDAPY_NUM_THREADS in src/mdapy/__init__.py:14-33).
-Every native function of the reference takes a trailing ``num_t``; the HIP
-kernels ignore it."""
+"""Thread count of the reference's native functions (src/mdapy/parallel.py:1-53, MDAPY_NUM_THREADS in
+src/mdapy/__init__.py:14-33).  Every one of them takes a trailing ``num_t``; the shims accept it for signature
+compatibility and the HIP kernels have no use for it."""
 import os
 
 
-def get_num_threads() -> int:
-    v = os.environ.get("MDAPY_NUM_THREADS")
-    if v is not None:
-        try:
-            n = int(v)
-            if n > 0:
-                return n
-        except ValueError:
-            pass
+def get_num_threads():
+    asked = os.environ.get("MDAPY_NUM_THREADS", "")
+    if asked.strip().lstrip("+").isdigit() and int(asked) > 0:
+        return int(asked)
     return os.cpu_count() or 1

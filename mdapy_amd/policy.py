@@ -1,0 +1,117 @@
+"""Host-side policy of the hot path, in one place.
+
+What the reference decides in Python, scattered over its analysis classes, is a handful of rules.  They are stated
+here once, as functions, and the classes / ``System`` only combine them:
+
+* **thin periodic boxes are replicated** before a search — up to twice the cutoff for a cutoff list
+  (src/mdapy/box.py:483-502), up to 15 A for the analyses that take a fixed number of nearest neighbours
+  (src/mdapy/common_neighbor_analysis.py:99-109, system.py:2032-2036); replicas are cell-major with the original
+  atoms first, so results are read back as the first N rows;
+* **an open system too small to have k neighbours** gets the analysis' "nothing found" answer without any search;
+* **species labels become dense codes** in sorted label order (radial_distribution_function.py:125-142);
+* **pair counts become g(r)** by shell volume and number density (radial_distribution_function.py:147-211).
+"""
+import numpy as np
+
+from . import kernels
+from .box import Box
+from .frame import Frame, concat
+from .parallel import get_num_threads
+
+NEAREST_SPAN = 15.0  # A: thickness below which a periodic direction is replicated for the k-nearest analyses
+
+
+def axis_copies(box, span):
+    """copies per axis that bring every periodic direction thinner than ``span`` up to it (open directions: 1)"""
+    thick = box.get_thickness()
+    copies = np.ones(3, dtype=np.int32)
+    for axis in range(3):
+        if box.boundary[axis] == 1 and thick[axis] < span:
+            copies[axis] = int(np.ceil(span / thick[axis]))
+    return copies
+
+
+def is_single(copies):
+    return int(copies[0]) == 1 and int(copies[1]) == 1 and int(copies[2]) == 1
+
+
+def positions(frame):
+    """x, y, z columns (frame columns carry their HBM mirror)"""
+    return frame["x"], frame["y"], frame["z"]
+
+
+def box_args(box):
+    return box.box, box.origin, box.boundary
+
+
+def tiled_positions(frame, box, copies):
+    """positions of the nx*ny*nz replica (cell-major, originals first; src/repeat_cell.cpp:19-61) and its cell matrix"""
+    nx, ny, nz = (int(c) for c in copies)
+    source = np.ascontiguousarray(frame.select("x", "y", "z").to_numpy(), dtype=np.float64)
+    flat = np.zeros(source.shape[0] * nx * ny * nz * 3, dtype=np.float64)
+    kernels.repeat_cell.repeat_cell(flat, box.box, source, nx, ny, nz, get_num_threads())
+    return flat.reshape((-1, 3)), box.box * np.array([[nx], [ny], [nz]])
+
+
+def replica(frame, box, copies, all_columns):
+    """(frame, box) of the replicated system.  ``all_columns``: carry every per-atom column along (an ``id`` column is
+    renumbered from 1); otherwise positions only — enough for a structure analysis that reads nothing else."""
+    pos, cell = tiled_positions(frame, box, copies)
+    if all_columns:
+        n = int(copies[0]) * int(copies[1]) * int(copies[2])
+        out = concat([frame] * n).with_columns(x=pos[:, 0], y=pos[:, 1], z=pos[:, 2])
+        if "id" in out.columns:
+            out = out.with_columns(id=np.arange(1, out.shape[0] + 1, dtype=np.asarray(frame["id"]).dtype))
+    else:
+        out = Frame({"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2]})
+    return out, Box(cell, box.boundary, box.origin)
+
+
+def widened(frame, box, span, all_columns=False):
+    """(frame, box, replicated?) with every periodic direction at least ``span`` thick"""
+    copies = axis_copies(box, span)
+    if is_single(copies):
+        return frame, box, False
+    grown, grown_box = replica(frame, box, copies, all_columns)
+    return grown, grown_box, True
+
+
+def hopeless(box, natoms, k):
+    """an open system of at most k atoms: no atom has k neighbours, the analyses answer 'other' without a search"""
+    return int(np.sum(box.boundary)) == 0 and natoms <= k
+
+
+def nearest_rows(frame, box, k):
+    """rows of the k nearest neighbours of every atom, searched here (the caller had no list to offer)"""
+    from .knn import NearestNeighbor
+
+    finder = NearestNeighbor(frame, box, k)
+    finder.compute()
+    return finder.indices_py
+
+
+def label_codes(labels):
+    """(sorted distinct labels as Python objects, int32 code of every atom in that order)"""
+    raw = np.asarray(labels)
+    if raw.size == 0:
+        return [], np.zeros(0, np.int32)
+    head = raw.flat[0]
+    if bool((raw == head).all()):  # one species: no sort needed
+        return [head.item() if hasattr(head, "item") else head], np.zeros(raw.shape[0], np.int32)
+    names, codes = np.unique(raw, return_inverse=True)
+    return names.tolist(), codes.reshape(-1).astype(np.int32)
+
+
+def species_of(frame):
+    """per-atom species labels of a frame: elements if it has them, numeric types otherwise, one species if neither"""
+    for column in ("element", "type"):
+        if column in frame.columns:
+            return frame[column].to_numpy()
+    return np.zeros(frame.shape[0], np.int32)
+
+
+def shell_table(rc, nbin, volume):
+    """(bin centres, shell volume / system volume per bin) of nbin equal-width shells out to rc"""
+    edge = np.linspace(0, rc, nbin + 1)
+    outer, inner = edge[1:], edge[:-1]
+    return (outer + inner) / 2, (4.0 * np.pi / 3.0 * (outer ** 3 - inner ** 3)) / volume

@@ -1,78 +1,68 @@
-"""Radial distribution function.  Mirrors
-``mdapy.radial_distribution_function.RadialDistributionFunction``
-(src/mdapy/radial_distribution_function.py:20-211): the kernels return ordered-pair
-counts; the normalisation to g(r) is done here in numpy exactly as in the reference."""
-from __future__ import annotations
+"""Radial distribution function — the drop-in for
+``mdapy.radial_distribution_function.RadialDistributionFunction`` (src/mdapy/radial_distribution_function.py:20-211).
 
-from typing import Any, Dict, List, Optional, Tuple
-
+The kernels return ordered-pair counts per (species a, species b, shell); this class turns them into ``r``,
+``g_total`` and ``g_partial[(label_a, label_b)]`` (a <= b in sorted label order).  Two sources of counts: an existing
+cutoff list, or — ``streaming=True`` — the positions themselves through a cell grid of their own, for cutoffs whose list
+would not fit in memory."""
 import numpy as np
 
-from . import tool_function as tool
-
-from . import _rdf
-from .box import Box
+from . import kernels, policy
 from .parallel import get_num_threads
 
 
 class RadialDistributionFunction:
-    def __init__(self, rc: float, nbin: int, box: Box, verlet_list=None, distance_list=None, neighbor_number=None,
-                 type_list=None, streaming: bool = False, x=None, y=None, z=None) -> None:
-        self.rc = float(rc)
-        self.nbin = int(nbin)
-        self.box = box
-        self.vol = self.box.volume
+    def __init__(self, rc, nbin, box, verlet_list=None, distance_list=None, neighbor_number=None, type_list=None,
+                 streaming=False, x=None, y=None, z=None):
+        self.rc, self.nbin = float(rc), int(nbin)
+        self.box, self.vol = box, box.volume
         self.streaming = bool(streaming)
+        self.verlet_list = self.distance_list = self.neighbor_number = None
         if self.streaming:
-            if x is None or y is None or z is None:
+            if any(c is None for c in (x, y, z)):
                 raise ValueError("streaming=True requires x, y, z position arrays.")
-            self._x, self._y, self._z = x, y, z
             assert len(x) == len(y) == len(z), "x, y, z must have the same shape"
+            self._x, self._y, self._z = x, y, z
             self.N = int(len(x))
-            self.verlet_list = self.distance_list = self.neighbor_number = None
         else:
-            if verlet_list is None or distance_list is None or neighbor_number is None:
+            if any(c is None for c in (verlet_list, distance_list, neighbor_number)):
                 raise ValueError("streaming=False requires verlet_list, distance_list, " "neighbor_number.")
-            self.verlet_list = verlet_list
-            self.distance_list = distance_list
-            self.neighbor_number = neighbor_number
-            self.N = int(self.verlet_list.shape[0])
-        raw = np.zeros(self.N, dtype=np.int32) if type_list is None else np.asarray(type_list)
-        self.elements, self.type_list = tool.dense_labels(raw)  # :125-142 labels -> dense 0..Ntype-1 in sorted order
+            self.verlet_list, self.distance_list, self.neighbor_number = verlet_list, distance_list, neighbor_number
+            self.N = int(verlet_list.shape[0])
+        labels = np.zeros(self.N, dtype=np.int32) if type_list is None else np.asarray(type_list)
+        self.elements, self.type_list = policy.label_codes(labels)
         self.Ntype = len(self.elements)
 
-    def compute(self) -> None:
-        edges = np.linspace(0, self.rc, self.nbin + 1)
-        const = (4.0 * np.pi / 3.0 * (edges[1:] ** 3 - edges[:-1] ** 3)) / self.vol
-        self.r = (edges[1:] + edges[:-1]) / 2
-        counts = np.zeros((self.Ntype, self.Ntype, self.nbin), dtype=np.float64)
+    def _pair_counts(self):
+        """ordered-pair counts (species, species, shell) as f64 — integers, exactly"""
+        kinds, reach, shells = self.Ntype, self.rc, self.nbin
+        counts = np.zeros((kinds, kinds, shells), np.float64)
+        lists = (self.verlet_list, self.distance_list, self.neighbor_number)
         if self.streaming:
-            _rdf._rdf_streaming(self._x, self._y, self._z, self.type_list, self.box.box, self.box.origin,
-                                self.box.boundary, counts, self.rc, self.nbin, get_num_threads())
-        elif self.Ntype > 1:
-            _rdf._rdf(self.verlet_list, self.distance_list, self.neighbor_number, self.type_list, counts, self.rc,
-                      self.nbin)
+            where = (self._x, self._y, self._z, self.type_list, *policy.box_args(self.box))
+            kernels.rdf._rdf_streaming(*where, counts, reach, shells, get_num_threads())
+        elif kinds == 1:
+            kernels.rdf._rdf_single_species(*lists, counts[0, 0], reach, shells)
         else:
-            flat = np.zeros(self.nbin, dtype=np.float64)
-            _rdf._rdf_single_species(self.verlet_list, self.distance_list, self.neighbor_number, flat, self.rc,
-                                     self.nbin)
-            counts[0, 0] = flat
-        number_per_type = np.bincount(self.type_list, minlength=self.Ntype)
-        total = np.zeros(self.nbin, dtype=np.float64)
-        for a in range(self.Ntype):
-            for b in range(self.Ntype):
-                total += counts[a, b]
-        self.g_total = total / const / self.N**2
-        self.g_partial: Dict[Tuple[Any, Any], np.ndarray] = {}
-        for a in range(self.Ntype):
-            n_a = number_per_type[a]
-            for b in range(a, self.Ntype):
-                n_b = number_per_type[b]
-                raw = counts[a, b] if a == b else counts[a, b] + counts[b, a]
-                if n_a > 0 and n_b > 0:
-                    g_ab = raw / (n_a * n_b) / const
-                    if a != b:
-                        g_ab *= 0.5
-                else:
-                    g_ab = np.zeros_like(self.r)
-                self.g_partial[(self.elements[a], self.elements[b])] = g_ab
+            kernels.rdf._rdf(*lists, self.type_list, counts, reach, shells)
+        return counts
+
+    def compute(self):
+        self.r, shell = policy.shell_table(self.rc, self.nbin, self.vol)
+        counts = self._pair_counts()
+        # all pairs against the ideal-gas expectation N^2 * shell / V
+        self.g_total = counts.sum(axis=(0, 1)) / shell / self.N ** 2
+        names = self.elements
+        population = np.bincount(self.type_list, minlength=len(names))
+        both_orders = counts + counts.transpose(1, 0, 2)  # [a, b] + [b, a]
+        self.g_partial = {}
+        for a, name_a in enumerate(names):
+            for b in range(a, len(names)):
+                pairs = population[a] * population[b]
+                if pairs == 0:
+                    curve = np.zeros(self.nbin)
+                elif a == b:
+                    curve = counts[a, a] / pairs / shell
+                else:  # both ordered halves, averaged
+                    curve = both_orders[a, b] / pairs / shell * 0.5
+                self.g_partial[(name_a, names[b])] = curve

@@ -1,73 +1,66 @@
-"""Steinhardt bond-orientational order.  Mirrors
-``mdapy.steinhardt_bond_orientation.SteinhardtBondOrientation``
-(src/mdapy/steinhardt_bond_orientation.py:162-302)."""
-from __future__ import annotations
+"""Steinhardt bond-orientational order — the drop-in for
+``mdapy.steinhardt_bond_orientation.SteinhardtBondOrientation`` (src/mdapy/steinhardt_bond_orientation.py:162-302).
 
+``qnarray`` (N, columns): q_l for every l of ``llist``, then w_l, then w_l-hat when asked for; ``qlm_r`` / ``qlm_i`` the
+complex q_lm they were built from.  The neighbourhood is one of: a Voronoi list (optionally face-area weighted), the
+``nnn`` nearest neighbours, or everything within ``rc``.  ``identify_liquid`` adds ``solidliquid`` / ``nbond`` from the
+q6-q6 bond criterion."""
 import numpy as np
 
-from . import _sbo
-from . import tool_function as tool
-from .box import Box
+from . import kernels, policy
 from .devarray import as_numpy, zeros
-from .frame import Frame
 from .parallel import get_num_threads
+
+# the kernels cut the neighbourhood by distance; a k-nearest or Voronoi list is passed through with a cut nothing reaches
+NO_CUT_NEAREST = 1000000000.0
+NO_CUT_VORONOI = 10000000000.0
 
 
 class SteinhardtBondOrientation:
-    def __init__(self, box: Box, data: Frame, llist, nnn: int, rc: float, average: bool, use_voronoi: bool,
-                 use_weight: bool, weight, verlet_list, distance_list, neighbor_number, wl: bool, wlhat: bool,
-                 identify_liquid: bool, threshold: float, n_bond: int) -> None:
-        self.box = box
-        self.data = data
+    def __init__(self, box, data, llist, nnn, rc, average, use_voronoi, use_weight, weight, verlet_list, distance_list,
+                 neighbor_number, wl, wlhat, identify_liquid, threshold, n_bond):
+        self.box, self.data = box, data
         self.llist = np.asarray(llist, int)
-        self.nnn = nnn
-        self.rc = rc
-        self.average = average
-        self.use_voronoi = use_voronoi
-        self.use_weight = use_weight
-        self.weight = weight
-        self.verlet_list = verlet_list
-        self.distance_list = distance_list
-        self.neighbor_number = neighbor_number
-        self.wl = wl
-        self.wlhat = wlhat
-        self.identify_liquid = identify_liquid
-        self.threshold = threshold
-        self.n_bond = n_bond
+        self.nnn, self.rc, self.average = nnn, rc, average
+        self.use_voronoi, self.use_weight, self.weight = use_voronoi, use_weight, weight
+        self.verlet_list, self.distance_list, self.neighbor_number = verlet_list, distance_list, neighbor_number
+        self.wl, self.wlhat = wl, wlhat
+        self.identify_liquid, self.threshold, self.n_bond = identify_liquid, threshold, n_bond
 
-    def compute(self) -> None:
+    def _effective_cut(self):
+        if self.use_voronoi:
+            return NO_CUT_VORONOI
+        if self.nnn > 0:
+            return NO_CUT_NEAREST
+        assert self.rc > 0
+        return self.rc
+
+    def compute(self):
         if self.identify_liquid:
             assert 6 in self.llist
             assert self.threshold > 0
             assert self.n_bond > 0
-        N = self.data.shape[0]
-        nl = self.llist.shape[0]
-        lmax = int(self.llist.max())
-        self.qlm_r = zeros((N, nl, 2 * lmax + 1), np.float64)
-        self.qlm_i = zeros((N, nl, 2 * lmax + 1), np.float64)
-        ncol = nl + (nl if self.wl else 0) + (nl if self.wlhat else 0)
-        self.qnarray = zeros((N, ncol), np.float64)
-        if self.use_voronoi:  # :240-246
-            self.rc = 10000000000.0
-        elif self.nnn > 0:
-            self.rc = 1000000000.0
-        else:
-            assert self.rc > 0
-        if not self.use_weight:
-            self.weight = np.zeros((2, 2))
-        else:
+        atoms, orders = self.data.shape[0], self.llist.shape[0]
+        top = int(self.llist.max())
+        shape_lm = (atoms, orders, 2 * top + 1)
+        self.qlm_r, self.qlm_i = zeros(shape_lm, np.float64), zeros(shape_lm, np.float64)
+        blocks = 1 + int(bool(self.wl)) + int(bool(self.wlhat))
+        self.qnarray = zeros((atoms, orders * blocks), np.float64)
+        self.rc = self._effective_cut()
+        if self.use_weight:
             assert tuple(self.weight.shape) == tuple(self.verlet_list.shape)
-        x, y, z = tool.xyz(self.data)
-        _sbo.get_sq(x, y, z, self.box.box, self.box.origin, self.box.boundary, self.verlet_list, self.distance_list,
-                    self.neighbor_number, self.weight, self.llist, self.nnn, lmax, self.wl, self.wlhat, self.average,
-                    self.use_voronoi, self.rc, self.use_weight, self.qlm_r, self.qlm_i, self.qnarray,
-                    get_num_threads())
-        if self.identify_liquid:
-            Q6index = int(np.where(self.llist == 6)[0][0])
-            Q6 = np.ascontiguousarray(as_numpy(self.qnarray)[:, Q6index])
-            self.solidliquid = zeros(N, np.int32)
-            self.nbond = zeros(N, np.int32)
-            _sbo.identifySolidLiquid(Q6index, Q6, self.verlet_list, self.distance_list, self.neighbor_number,
-                                     self.qlm_r, self.qlm_i, float(self.threshold), int(self.n_bond),
-                                     self.solidliquid, self.nbond, self.use_voronoi, self.nnn, self.rc,
-                                     get_num_threads())
+        else:
+            self.weight = np.zeros((2, 2))  # placeholder the unweighted kernel never reads
+        lists = (self.verlet_list, self.distance_list, self.neighbor_number)
+        mode = (self.wl, self.wlhat, self.average, self.use_voronoi, self.rc, self.use_weight)
+        moments = (self.qlm_r, self.qlm_i)
+        kernels.sbo.get_sq(*policy.positions(self.data), *policy.box_args(self.box), *lists, self.weight, self.llist,
+                           self.nnn, top, *mode, *moments, self.qnarray, get_num_threads())
+        if not self.identify_liquid:
+            return
+        slot = int(np.flatnonzero(self.llist == 6)[0])
+        q6 = np.ascontiguousarray(as_numpy(self.qnarray)[:, slot])
+        self.solidliquid, self.nbond = zeros(atoms, np.int32), zeros(atoms, np.int32)
+        rule = (float(self.threshold), int(self.n_bond))
+        kernels.sbo.identifySolidLiquid(slot, q6, *lists, *moments, *rule, self.solidliquid, self.nbond, self.use_voronoi,
+                                        self.nnn, self.rc, get_num_threads())

@@ -1,23 +1,21 @@
-"""``System``: the user-facing object of the hot path.
+"""``System`` — the user-facing object of the hot path, with the surface of ``mdapy.System`` (src/mdapy/system.py) above
+the neighbor list and the per-atom structural analyses.
 
-Mirrors the part of ``mdapy.System`` (src/mdapy/system.py) that sits above the
-neighbor list and the per-atom structural analyses: construction from
-(pos, box) / (data, box) / a file, the cached neighbor attributes
-(``verlet_list``, ``distance_list``, ``neighbor_number``, ``rc``,
-``_enlarge_data``, ``_enlarge_box`` — system.py:1155-1166), their invalidation
-rules (:232-245, :748-763), and ``build_neighbor`` / ``build_nearest_neighbor`` /
-``cal_*`` with the reference's list-reuse and replication policy.  Results land
-as columns of ``system.data`` or as returned objects, like in the reference.
+A system is a frame of per-atom columns plus a box.  It remembers ONE neighbor list at a time — ``verlet_list``,
+``distance_list``, ``neighbor_number`` and, for a cutoff list, its ``rc`` (system.py:1155-1166) — and, when that list
+was built on a replica of a thin periodic box, the replica (``_enlarge_data`` / ``_enlarge_box``) its indices refer to.
+Assigning a box or replacing the data with ``reset_neighbor=True`` forgets the list (system.py:232-245, 748-763).
 
-The neighbor arrays stay in HBM between calls (:class:`mdapy_amd.devarray.HArray`);
-they convert to numpy on first host access.
+Every ``cal_*`` method first makes sure a suitable list exists, following the reference's reuse rules (SURVEY.md 3,
+Appendix C), then runs its analysis class and stores the first N rows of the result as columns of ``data`` or returns
+the result object.  The reuse rules are three helpers here — ``_require_cutoff_list``, ``_nearest_prefix`` and
+``_borrow_nearest`` — instead of being restated in every method.
+
+The lists stay in HBM between calls (:class:`mdapy_amd.devarray.HArray`) and turn into numpy on first host access.
 """
-from __future__ import annotations
-
-from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
-
 import numpy as np
 
+from . import policy
 from . import tool_function as tool
 from .ackland_jones_analysis import AcklandJonesAnalysis
 from .atomic_temperature import AtomicTemperature
@@ -40,413 +38,336 @@ from .structure_factor import StructureFactor
 from .voronoi import Voronoi
 from .warren_cowley_parameter import WarrenCowleyParameter
 
-_NEIGH_ATTRS = ("verlet_list", "neighbor_number", "distance_list", "rc", "_enlarge_box", "_enlarge_data")
+_REPLICA = ("_enlarge_box", "_enlarge_data")
+_LIST = ("verlet_list", "neighbor_number", "distance_list", "rc") + _REPLICA
 
 
 class System:
-    def __init__(self, filename: Optional[str] = None, data=None, pos: Optional[np.ndarray] = None, box=None,
-                 format: Optional[str] = None, global_info: Optional[Dict[str, Any]] = None):
-        self.__global_info: Dict[str, Any] = {}
+    def __init__(self, filename=None, data=None, pos=None, box=None, format=None, global_info=None):
+        self._info = {}
         if isinstance(filename, str):
             from .load_save import read_file
 
-            self.__data, self.box, self.__global_info = read_file(filename, format)
-        elif data is not None and box is not None:
-            frame = Frame.from_any(data)
-            for c in ("x", "y", "z"):
-                assert c in frame.columns, f"data must contain column {c!r}."
-            self.__data, self.box = frame, box
-        elif pos is not None and box is not None:
-            pos = np.asarray(pos, dtype=np.float64)
-            assert pos.ndim == 2 and pos.shape[1] == 3, "pos must have shape (N, 3)."
-            self.__data = Frame({"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2]})
+            self._frame, self.box, self._info = read_file(filename, format)
+        elif box is not None and data is not None:
+            self._frame = Frame.from_any(data)
+            for name in ("x", "y", "z"):
+                if name not in self._frame.columns:
+                    raise AssertionError(f"data must contain column {name!r}.")
+            self.box = box
+        elif box is not None and pos is not None:
+            xyz = np.asarray(pos, dtype=np.float64)
+            if xyz.ndim != 2 or xyz.shape[1] != 3:
+                raise AssertionError("pos must have shape (N, 3).")
+            self._frame = Frame(dict(zip("xyz", xyz.T)))
             self.box = box
         else:
             raise RuntimeError("One must at least provide filename or [data, box] or [pos, box].")
-        if not len(self.__global_info) and global_info is not None:
-            self.__global_info = dict(global_info)
+        if global_info is not None and not self._info:
+            self._info = dict(global_info)
 
-    # ------------------------------------------------------------------ state
+    # ---------------------------------------------------------------- state
+    def _forget(self, names):
+        for name in names:
+            self.__dict__.pop(name, None)
+
     @property
-    def box(self) -> Box:
-        return self.__box
+    def box(self):
+        return self._cell
 
     @box.setter
     def box(self, value):
-        """Assigning a box keeps Cartesian coordinates and drops everything that depends on it (system.py:232-245)."""
-        self.__box = value if isinstance(value, Box) else Box(value)
-        for attr in _NEIGH_ATTRS:
-            if hasattr(self, attr):
-                delattr(self, attr)
+        # Cartesian coordinates stay as they are; everything computed with the old box is gone
+        self._cell = value if isinstance(value, Box) else Box(value)
+        self._forget(_LIST)
 
-    @property
-    def data(self) -> Frame:
-        return self.__data
+    data = property(lambda self: self._frame)
+    global_info = property(lambda self: self._info)
+    N = property(lambda self: self._frame.shape[0])
 
-    @property
-    def global_info(self) -> Dict[str, Any]:
-        return self.__global_info
-
-    @property
-    def N(self) -> int:
-        return self.__data.shape[0]
-
-    def __repr__(self) -> str:
+    def __repr__(self):
         return f"Atom Number: {self.N}\n{self.box}\nParticle Information:\n{self.data}"
 
-    def update_data(self, data, reset_calculator: bool = False, reset_neighbor: bool = False) -> None:
-        """Replace the per-atom frame; ``reset_neighbor`` drops the cached lists (system.py:686-763)."""
-        self.__data = Frame.from_any(data)
+    def update_data(self, data, reset_calculator=False, reset_neighbor=False):
+        """replace the per-atom frame; ``reset_neighbor`` also forgets the neighbor list"""
+        self._frame = Frame.from_any(data)
         if reset_neighbor:
-            for attr in _NEIGH_ATTRS:
-                if hasattr(self, attr):
-                    delattr(self, attr)
+            self._forget(_LIST)
 
-    def _get_compute_view(self) -> Tuple[Box, Frame]:
-        """(box, data) the cached neighbor indices refer to (system.py:765-784)"""
-        if hasattr(self, "_enlarge_data"):
+    def _get_compute_view(self):
+        """(box, frame) the remembered list's indices refer to: the replica if there is one"""
+        if "_enlarge_data" in self.__dict__:
             return self._enlarge_box, self._enlarge_data
         return self.box, self.data
 
-    def wrap_pos(self) -> None:
-        self.update_data(tool.wrap_pos(self.__data, self.box), reset_neighbor=True)
+    def _store(self, **columns):
+        """results of an analysis over the compute view -> columns of the N real atoms"""
+        n = self.N
+        self.update_data(self._frame.with_columns(**{name: as_numpy(values)[:n] for name, values in columns.items()}))
 
-    def replicate(self, nx: int, ny: int, nz: int) -> None:
-        data, box = tool.replicate(self.__data, self.box, nx, ny, nz)
-        self.__data = data
-        self.box = box
+    def wrap_pos(self):
+        self.update_data(tool.wrap_pos(self._frame, self.box), reset_neighbor=True)
 
-    # ------------------------------------------------------------ neighbor lists
-    def build_neighbor(self, rc: float, max_neigh: Optional[int] = None) -> None:
-        """system.py:1108-1166"""
-        neigh = Neighbor(rc, self.box, self.data, max_neigh)
-        neigh.compute()
+    def replicate(self, nx, ny, nz):
+        self._frame, self.box = tool.replicate(self._frame, self.box, nx, ny, nz)
+
+    # ------------------------------------------------------- neighbor lists
+    def _remember(self, search, rows, distances, counts):
+        """take over the list a search object built, and its replica if it made one (the replica always belongs to the
+        list that is current: one left behind by an earlier search would be paired with rows it does not describe)"""
+        self._forget(_REPLICA)
+        for name in _REPLICA:
+            if name in search.__dict__:
+                setattr(self, name, getattr(search, name))
+        self.verlet_list, self.distance_list, self.neighbor_number = rows, distances, counts
+
+    def build_neighbor(self, rc, max_neigh=None):
+        search = Neighbor(rc, self.box, self.data, max_neigh)
+        search.compute()
         self.rc = rc
-        for attr in ("_enlarge_box", "_enlarge_data"):  # see build_nearest_neighbor: the view belongs to the current list
-            if hasattr(self, attr):
-                delattr(self, attr)
-        if hasattr(neigh, "_enlarge_box"):
-            self._enlarge_box = neigh._enlarge_box
-        if hasattr(neigh, "_enlarge_data"):
-            self._enlarge_data = neigh._enlarge_data
-        self.verlet_list, self.distance_list, self.neighbor_number = (
-            neigh.verlet_list, neigh.distance_list, neigh.neighbor_number)
+        self._remember(search, search.verlet_list, search.distance_list, search.neighbor_number)
 
-    def build_nearest_neighbor(self, k: int) -> None:
-        """system.py:1226-1263 (sets no ``rc``; neighbor_number = k everywhere)"""
-        kdt = NearestNeighbor(self.data, self.box, k)
-        kdt.compute()
-        # The reference only ever SETS these (system.py:1257-1260): a replicated view left behind by an earlier cutoff
-        # build would then be paired with rows of the unreplicated system (out-of-bounds reads downstream).  The view
-        # always belongs to the list that is current.
-        for attr in ("_enlarge_box", "_enlarge_data"):
-            if hasattr(self, attr):
-                delattr(self, attr)
-        if hasattr(kdt, "_enlarge_box"):
-            self._enlarge_box = kdt._enlarge_box
-        if hasattr(kdt, "_enlarge_data"):
-            self._enlarge_data = kdt._enlarge_data
-        self.verlet_list, self.distance_list = kdt.indices_py, kdt.distances_py
-        self.neighbor_number = np.full(self.verlet_list.shape[0], k, np.int32)
+    def build_nearest_neighbor(self, k):
+        """k nearest neighbours as the current list (no ``rc``; every count is k)"""
+        search = NearestNeighbor(self.data, self.box, k)
+        search.compute()
+        self._remember(search, search.indices_py, search.distances_py, np.full(search.indices_py.shape[0], k, np.int32))
 
-    def _safe_repeat(self, safe_L: float = 15) -> np.ndarray:
-        repeat = np.ceil(safe_L / self.box.get_thickness()).astype(int)
-        for i in range(3):
-            if self.box.boundary[i] == 0:
-                repeat[i] = 1
-        return repeat
+    def _require_cutoff_list(self, rc, max_neigh):
+        """a cutoff list reaching at least rc: the remembered one if it does, a new one otherwise"""
+        if not ("rc" in self.__dict__ and self.rc >= rc):
+            self.build_neighbor(rc, max_neigh)
 
-    # ------------------------------------------------------------------ analyses
-    def cal_common_neighbor_analysis(self, rc: Optional[float] = None, max_neigh: Optional[int] = None):
-        """column ``cna`` (system.py:2005-2064)"""
-        verlet_list = neighbor_number = None
-        if sum(self._safe_repeat()) == 3:
-            if hasattr(self, "rc"):
-                if rc is None:
-                    if self.neighbor_number.min() >= 14:
-                        tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, 14)
-                        verlet_list = self.verlet_list
-                elif self.rc < rc:
-                    self.build_neighbor(rc, max_neigh)
-                    verlet_list, neighbor_number = self.verlet_list, self.neighbor_number
-            elif rc is not None:
-                self.build_neighbor(rc, max_neigh)
-                verlet_list, neighbor_number = self.verlet_list, self.neighbor_number
-        box, data = self._get_compute_view()
-        cna = CommonNeighborAnalysis(data, box, verlet_list, neighbor_number, rc)
-        cna.compute()
-        self.update_data(self.__data.with_columns(cna=as_numpy(cna.pattern)[: self.N]))
+    def _deep_enough(self, k):
+        return "neighbor_number" in self.__dict__ and self.neighbor_number.min() >= k
+
+    def _nearest_prefix(self, k, cutoff_lists_only=False):
+        """make the first k columns of the current list the k nearest neighbours, nearest first: by sorting the remembered
+        list when every atom has k entries, by a k-nearest search otherwise"""
+        if self._deep_enough(k) and (not cutoff_lists_only or "rc" in self.__dict__):
+            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, k)
+        else:
+            self.build_nearest_neighbor(k)
+
+    def _safe_repeat(self, safe_L=15):
+        return policy.axis_copies(self.box, safe_L)
+
+    def _borrow_nearest(self, k):
+        """rows to lend to an analysis that otherwise searches its k nearest neighbours itself: the remembered list,
+        sorted, if it is deep enough — but never for a box so thin that the analysis would replicate it (the list of the
+        unreplicated system would miss images)"""
+        if policy.is_single(self._safe_repeat()) and self._deep_enough(k):
+            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, k)
+            return self.verlet_list
+        return None
+
+    # ------------------------------------------------------------- analyses
+    def cal_common_neighbor_analysis(self, rc=None, max_neigh=None):
+        """column ``cna``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico; fixed cutoff ``rc`` or adaptive (None)"""
+        rows = counts = None
+        if rc is None:
+            if "rc" in self.__dict__:  # (only a cutoff list is lent to the adaptive variant)
+                rows = self._borrow_nearest(14)
+        elif policy.is_single(self._safe_repeat()) and not ("rc" in self.__dict__ and self.rc >= rc):
+            self.build_neighbor(rc, max_neigh)
+            rows, counts = self.verlet_list, self.neighbor_number
+        cell, frame = self._get_compute_view()
+        job = CommonNeighborAnalysis(frame, cell, rows, counts, rc)
+        job.compute()
+        self._store(cna=job.pattern)
 
     def cal_polyhedral_template_matching(self, structure="fcc-hcp-bcc", rmsd_threshold=0.1, return_ordering=False,
                                          return_rmsd=False, return_atomic_distance=False, return_orientation=False,
                                          identify_fcc_planar_faults=False, identify_esf=True):
-        """column ``ptm`` (+ ``ordering``, ``rmsd``, ``interatomic_distance``, ``qx,qy,qz,qw``, ``pft``)
-        (system.py:1863-1970)"""
-        verlet_list = None
-        if sum(self._safe_repeat()) == 3:
-            if hasattr(self, "neighbor_number"):
-                if self.neighbor_number.min() >= 18:
-                    tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, 18)
-                    verlet_list = self.verlet_list
-        box, data = self._get_compute_view()
-        ptm = PolyhedralTemplateMatching(structure, data, box, rmsd_threshold, verlet_list)
-        ptm.compute()
-        output = as_numpy(ptm.output)[: self.N]
-        new = {"ptm": output[:, 0].astype(np.int32)}
-        if return_ordering:
-            new["ordering"] = output[:, 1]
-        if return_rmsd:
-            new["rmsd"] = output[:, 2]
-        if return_atomic_distance:
-            new["interatomic_distance"] = output[:, 3]
-        if return_orientation:
-            new.update(qx=output[:, 5], qy=output[:, 6], qz=output[:, 7], qw=output[:, 4])
-        self.ptm_indices = ptm.ptm_indices
-        if identify_fcc_planar_faults:  # system.py:1963-1968
-            structure_types = np.array(as_numpy(ptm.output)[:, 0], np.int32)
-            ptm12 = np.ascontiguousarray(as_numpy(ptm.ptm_indices)[:, 1:13])
-            ifpt = IdentifyFccPlanarFaults(structure_types, ptm12, identify_esf)
-            ifpt.compute()
-            new["pft"] = ifpt.fault_types[: self.N]
-        self.update_data(self.__data.with_columns(**new))
+        """column ``ptm`` and, on request, ``ordering``, ``rmsd``, ``interatomic_distance``, ``qx qy qz qw``, ``pft``"""
+        rows = self._borrow_nearest(18)
+        cell, frame = self._get_compute_view()
+        job = PolyhedralTemplateMatching(structure, frame, cell, rmsd_threshold, rows)
+        job.compute()
+        table = as_numpy(job.output)
+        found = {"ptm": table[:, 0].astype(np.int32)}
+        for wanted, name, col in ((return_ordering, "ordering", 1), (return_rmsd, "rmsd", 2),
+                                  (return_atomic_distance, "interatomic_distance", 3)):
+            if wanted:
+                found[name] = table[:, col]
+        if return_orientation:  # stored x, y, z, w; the kernel's quaternion is w, x, y, z
+            found.update(qx=table[:, 5], qy=table[:, 6], qz=table[:, 7], qw=table[:, 4])
+        self.ptm_indices = job.ptm_indices
+        if identify_fcc_planar_faults:
+            shell = np.ascontiguousarray(as_numpy(job.ptm_indices)[:, 1:13])  # the 12 neighbours in template order
+            faults = IdentifyFccPlanarFaults(np.array(table[:, 0], np.int32), shell, identify_esf)
+            faults.compute()
+            found["pft"] = faults.fault_types
+        self._store(**found)
 
-    def cal_common_neighbor_parameter(self, rc: float, max_neigh: Optional[int] = None) -> None:
-        """column ``cnp`` (system.py:1572-1603)"""
-        has_neigh = hasattr(self, "rc") and self.rc >= rc
-        if not has_neigh:
-            self.build_neighbor(rc, max_neigh)
-        box, data = self._get_compute_view()
-        cnp = CommonNeighborParameter(data, box, rc, self.verlet_list, self.distance_list, self.neighbor_number)
-        cnp.compute()
-        self.update_data(self.__data.with_columns(cnp=as_numpy(cnp.cnp)[: self.N]))
+    def cal_common_neighbor_parameter(self, rc, max_neigh=None):
+        """column ``cnp``"""
+        self._require_cutoff_list(rc, max_neigh)
+        cell, frame = self._get_compute_view()
+        job = CommonNeighborParameter(frame, cell, rc, self.verlet_list, self.distance_list, self.neighbor_number)
+        job.compute()
+        self._store(cnp=job.cnp)
 
-    def cal_ackland_jones_analysis(self) -> None:
-        """column ``aja``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico (system.py:1605-1636)"""
-        n_neigh = 14
-        if self.data.shape[0] < n_neigh and sum(self.box.boundary) == 0:
-            self.update_data(self.__data.with_columns(aja=np.zeros(self.N, np.int32)))
+    def cal_ackland_jones_analysis(self):
+        """column ``aja``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico"""
+        depth = 14
+        if self.N < depth and int(np.sum(self.box.boundary)) == 0:
+            self._store(aja=np.zeros(self.N, np.int32))
             return
-        if hasattr(self, "neighbor_number") and self.neighbor_number.min() >= n_neigh:
-            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, n_neigh)
-        else:
-            self.build_nearest_neighbor(n_neigh)
-        box, data = self._get_compute_view()
-        aja = AcklandJonesAnalysis(data, box, self.verlet_list, self.distance_list)
-        aja.compute()
-        self.update_data(self.__data.with_columns(aja=as_numpy(aja.aja)[: self.N]))
+        self._nearest_prefix(depth)
+        cell, frame = self._get_compute_view()
+        job = AcklandJonesAnalysis(frame, cell, self.verlet_list, self.distance_list)
+        job.compute()
+        self._store(aja=job.aja)
 
-    def cal_structure_entropy(self, rc: float, sigma: float, use_local_density: bool = False, average_rc: float = 0.0,
-                              max_neigh: Optional[int] = None) -> None:
-        """columns ``entropy`` (+ ``entropy_ave`` when average_rc > 0) (system.py:2481-2542)"""
-        if hasattr(self, "rc"):
-            if self.rc < rc:
-                self.build_neighbor(rc, max_neigh)
-        else:
-            self.build_neighbor(rc, max_neigh)
-        box, _ = self._get_compute_view()
-        se = StructureEntropy(box, self.verlet_list, self.distance_list, self.neighbor_number, rc, sigma, use_local_density,
-                              average_rc)
-        se.compute()
-        data = self.data.with_columns(entropy=as_numpy(se.entropy)[: self.N])
+    def cal_structure_entropy(self, rc, sigma, use_local_density=False, average_rc=0.0, max_neigh=None):
+        """column ``entropy`` (and ``entropy_ave`` when average_rc > 0)"""
+        self._require_cutoff_list(rc, max_neigh)
+        cell, _ = self._get_compute_view()
+        job = StructureEntropy(cell, self.verlet_list, self.distance_list, self.neighbor_number, rc, sigma,
+                               use_local_density, average_rc)
+        job.compute()
+        found = {"entropy": job.entropy}
         if average_rc > 0:
-            data = data.with_columns(entropy_ave=as_numpy(se.entropy_ave)[: self.N])
-        self.update_data(data)
+            found["entropy_ave"] = job.entropy_ave
+        self._store(**found)
 
-    def cal_atomic_temperature(self, rc: float, factor: float = 1.0, max_neigh: Optional[int] = None) -> None:
-        """column ``atomic_temp`` in K; velocities in A/fs x factor (system.py:1678-1714)"""
-        has_neigh = hasattr(self, "rc") and self.rc >= rc
-        if not has_neigh:
-            self.build_neighbor(rc, max_neigh)
-        _, data = self._get_compute_view()
-        at = AtomicTemperature(data, self.verlet_list, self.distance_list, rc, factor)
-        at.compute()
-        self.update_data(self.data.with_columns(atomic_temp=as_numpy(at.T)[: self.N]))
+    def cal_atomic_temperature(self, rc, factor=1.0, max_neigh=None):
+        """column ``atomic_temp`` (K); velocities are A/fs times ``factor``"""
+        self._require_cutoff_list(rc, max_neigh)
+        job = AtomicTemperature(self._get_compute_view()[1], self.verlet_list, self.distance_list, rc, factor)
+        job.compute()
+        self._store(atomic_temp=job.T)
 
-    def cal_cluster_analysis(self, rc=5.0, max_neigh: Optional[int] = None) -> None:
-        """column ``cluster_id`` (system.py:2416-2479)"""
-        if isinstance(rc, (int, float, np.integer, np.floating)):
-            max_rc = float(rc)
-        elif isinstance(rc, dict):
-            max_rc = max(rc.values())
+    def cal_cluster_analysis(self, rc=5.0, max_neigh=None):
+        """column ``cluster_id`` and attribute ``cluster_number``; ``rc`` one number or a dict per type pair"""
+        per_pair = isinstance(rc, dict)
+        if per_pair:
+            reach = max(rc.values())
+        elif isinstance(rc, (int, float, np.integer, np.floating)):
+            reach = float(rc)
         else:
             raise TypeError("rc should be a positive number, or a dict like {'1-1':1.5, '1-2':1.3}")
-        if hasattr(self, "rc"):
-            if self.rc < max_rc:
-                self.build_neighbor(max_rc, max_neigh)
-        else:
-            self.build_neighbor(max_rc, max_neigh)
-        type_list = None
-        if isinstance(rc, dict):
-            assert "type" in self.data.columns, "Must have type for multi rc cluster calculation."
-            # types of the atoms the list indexes: the replicated view when the box was small (the reference passes the
-            # unreplicated column, system.py:2472, which its filter then indexes out of bounds)
-            type_list = np.ascontiguousarray(self._get_compute_view()[1]["type"].to_numpy(), dtype=np.int32)
-        ca = ClusterAnalysis(rc, self.verlet_list, self.distance_list, self.neighbor_number, type_list)
-        ca.compute()
-        self.cluster_number = ca.cluster_number
-        self.update_data(self.data.with_columns(cluster_id=as_numpy(ca.particleClusters)[: self.N]))
+        self._require_cutoff_list(reach, max_neigh)
+        types = None
+        if per_pair:
+            if "type" not in self.data.columns:
+                raise AssertionError("Must have type for multi rc cluster calculation.")
+            # types of the atoms the list indexes, i.e. of the replica when there is one
+            types = np.ascontiguousarray(self._get_compute_view()[1]["type"].to_numpy(), dtype=np.int32)
+        job = ClusterAnalysis(rc, self.verlet_list, self.distance_list, self.neighbor_number, types)
+        job.compute()
+        self.cluster_number = job.cluster_number
+        self._store(cluster_id=job.particleClusters)
 
-    def build_voronoi_neighbor(self, a_face_area_threshold: float = -1.0, r_face_area_threshold: float = -1.0) -> None:
-        """``voro_verlet_list / voro_distance_list / voro_face_area / voro_neighbor_number`` (system.py:1168-1230)"""
-        vor = Voronoi(self.box, self.data)
-        (self.voro_verlet_list, self.voro_distance_list, self.voro_face_area,
-         self.voro_neighbor_number) = vor.get_neighbor(a_face_area_threshold, r_face_area_threshold)
-        if hasattr(vor, "_enlarge_box"):
-            self._enlarge_box = vor._enlarge_box
-        if hasattr(vor, "_enlarge_data"):
-            self._enlarge_data = vor._enlarge_data
+    def build_voronoi_neighbor(self, a_face_area_threshold=-1.0, r_face_area_threshold=-1.0):
+        """``voro_verlet_list``, ``voro_distance_list``, ``voro_face_area``, ``voro_neighbor_number``"""
+        cells = Voronoi(self.box, self.data)
+        lists = cells.get_neighbor(a_face_area_threshold, r_face_area_threshold)
+        self.voro_verlet_list, self.voro_distance_list, self.voro_face_area, self.voro_neighbor_number = lists
+        for name in _REPLICA:
+            if name in cells.__dict__:
+                setattr(self, name, getattr(cells, name))
 
-    def cal_structure_factor(self, k_min: float, k_max: float, nbins: int, cal_partial: bool = False,
-                             atomic_form_factors: bool = False, mode: str = "debye", rc: Optional[float] = None,
-                             nbin_rdf: int = 200, window: bool = False) -> StructureFactor:
-        """-> StructureFactor with ``k``, ``Sk``, ``Sk_partial`` (system.py: cal_structure_factor)"""
-        sf = StructureFactor(self.data, self.box, k_min, k_max, nbins, cal_partial, atomic_form_factors, mode, rc, nbin_rdf, window)
-        sf.compute()
-        return sf
+    def cal_structure_factor(self, k_min, k_max, nbins, cal_partial=False, atomic_form_factors=False, mode="debye",
+                             rc=None, nbin_rdf=200, window=False):
+        """-> StructureFactor with ``k``, ``Sk``, ``Sk_partial``"""
+        job = StructureFactor(self.data, self.box, k_min, k_max, nbins, cal_partial, atomic_form_factors, mode, rc,
+                              nbin_rdf, window)
+        job.compute()
+        return job
 
-    def cal_voronoi_volume(self) -> None:
-        """columns ``volume``, ``neighbor_number`` (faces), ``cavity_radius`` (system.py:2544-2573)"""
-        vor = Voronoi(self.box, self.data)
-        volume, neighbor_number, cavity_radius = vor.get_volume()
-        self.update_data(self.data.with_columns(volume=volume, neighbor_number=neighbor_number, cavity_radius=cavity_radius))
+    def cal_voronoi_volume(self):
+        """columns ``volume``, ``neighbor_number`` (faces of the cell), ``cavity_radius``"""
+        volume, faces, radius = Voronoi(self.box, self.data).get_volume()
+        self.update_data(self.data.with_columns(volume=volume, neighbor_number=faces, cavity_radius=radius))
 
-    def cal_centro_symmetry_parameter(self, N: int):
-        """column ``csp`` (system.py:1972-2003)"""
-        assert N % 2 == 0 and N > 0, f"N must be a positive even number: {N}."
-        if self.N <= N and sum(self.box.boundary) == 0:
-            res = np.full(self.N, 10000, float)
-        else:
-            has_verlet = False
-            if hasattr(self, "neighbor_number"):
-                if self.neighbor_number.min() >= N and hasattr(self, "rc"):
-                    tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, N)
-                    has_verlet = True
-            if not has_verlet:
-                self.build_nearest_neighbor(N)
-            box, data = self._get_compute_view()
-            csp = CentroSymmetryParameter(data, box, N, self.verlet_list)
-            csp.compute()
-            res = as_numpy(csp.csp)[: self.N]
-        self.update_data(self.data.with_columns(csp=res))
+    def cal_centro_symmetry_parameter(self, N):
+        """column ``csp`` from the N nearest neighbours (N even)"""
+        if not (N > 0 and N % 2 == 0):
+            raise AssertionError(f"N must be a positive even number: {N}.")
+        if self.N <= N and int(np.sum(self.box.boundary)) == 0:
+            self._store(csp=np.full(self.N, 10000, float))  # an open system with too few atoms: "as asymmetric as it gets"
+            return
+        self._nearest_prefix(N, cutoff_lists_only=True)
+        cell, frame = self._get_compute_view()
+        job = CentroSymmetryParameter(frame, cell, N, self.verlet_list)
+        job.compute()
+        self._store(csp=job.csp)
 
-    def cal_identify_diamond_structure(self) -> None:
-        """column ``ids`` (system.py:1493-1529)"""
-        verlet_list = None
-        if sum(self._safe_repeat()) == 3:
-            if hasattr(self, "neighbor_number"):
-                if self.neighbor_number.min() >= 4:
-                    tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, 4)
-                    verlet_list = self.verlet_list
-        box, data = self._get_compute_view()
-        ids = IdentifyDiamondStructure(data, box, verlet_list)
-        ids.compute()
-        self.update_data(self.__data.with_columns(ids=as_numpy(ids.pattern)[: self.N]))
+    def cal_identify_diamond_structure(self):
+        """column ``ids``: 0 other, 1 cubic diamond (2, 3 its shells), 4 hexagonal diamond (5, 6 its shells)"""
+        rows = self._borrow_nearest(4)
+        cell, frame = self._get_compute_view()
+        job = IdentifyDiamondStructure(frame, cell, rows)
+        job.compute()
+        self._store(ids=job.pattern)
 
-    def cal_steinhardt_bond_orientation(self, llist, use_voronoi: bool = False, nnn: int = 0, rc: float = -1.0,
-                                        average: bool = False, use_weight: bool = False, weight=None,
-                                        wl: bool = False, wlhat: bool = False, a_face_area_threshold: float = -1,
-                                        r_face_area_threshold: float = -1, identify_liquid: bool = False,
-                                        threshold: float = 0.7, n_bond: int = 7,
-                                        max_neigh: Optional[int] = None) -> None:
-        """columns ``ql{l}`` (+ ``wl{l}``, ``wlh{l}``, ``solidliquid``, ``nbond``) (system.py:1716-1861)"""
-        v_list = d_list = n_list = None
-        if use_voronoi:  # system.py:1781-1789
+    def cal_steinhardt_bond_orientation(self, llist, use_voronoi=False, nnn=0, rc=-1.0, average=False, use_weight=False,
+                                        weight=None, wl=False, wlhat=False, a_face_area_threshold=-1,
+                                        r_face_area_threshold=-1, identify_liquid=False, threshold=0.7, n_bond=7,
+                                        max_neigh=None):
+        """columns ``ql{l}`` (and ``wl{l}``, ``wlh{l}``, ``solidliquid``, ``nbond`` on request)"""
+        if use_voronoi:
             self.build_voronoi_neighbor(a_face_area_threshold, r_face_area_threshold)
-            v_list, d_list, n_list = self.voro_verlet_list, self.voro_distance_list, self.voro_neighbor_number
+            lists = (self.voro_verlet_list, self.voro_distance_list, self.voro_neighbor_number)
             if use_weight and weight is None:
                 weight = self.voro_face_area
-        elif nnn > 0:
-            has_sort_neigh = False
-            if hasattr(self, "neighbor_number"):
-                if self.neighbor_number.min() >= nnn:
-                    tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, nnn)
-                    has_sort_neigh = True
-            if not has_sort_neigh:
-                self.build_nearest_neighbor(nnn)
         else:
-            assert rc > 0, "At least use voronoi, or set positive nnn, or positive rc."
-            if hasattr(self, "rc"):
-                if self.rc < rc:
-                    self.build_neighbor(rc, max_neigh)
+            if nnn > 0:
+                self._nearest_prefix(nnn)
             else:
-                self.build_neighbor(rc, max_neigh)
-        box, data = self._get_compute_view()
-        if use_voronoi and hasattr(self, "_enlarge_data"):
-            box, data = self._enlarge_box, self._enlarge_data
-        if v_list is None:
-            v_list, d_list, n_list = self.verlet_list, self.distance_list, self.neighbor_number
-        SBO = SteinhardtBondOrientation(box, data, np.asarray(llist, int), nnn, rc, average, use_voronoi, use_weight,
-                                        weight, v_list, d_list, n_list, wl, wlhat, identify_liquid, threshold, n_bond)
-        SBO.compute()
-        qn = as_numpy(SBO.qnarray)
-        new = {}
-        if qn.shape[1] > 1:
-            columns = [f"ql{i}" for i in llist]
-            if wl:
-                columns.extend(f"wl{i}" for i in llist)
-            if wlhat:
-                columns.extend(f"wlh{i}" for i in llist)
-            for i, name in enumerate(columns):
-                new[name] = qn[: self.N, i]
+                assert rc > 0, "At least use voronoi, or set positive nnn, or positive rc."
+                self._require_cutoff_list(rc, max_neigh)
+            lists = (self.verlet_list, self.distance_list, self.neighbor_number)
+        cell, frame = self._get_compute_view()
+        job = SteinhardtBondOrientation(cell, frame, np.asarray(llist, int), nnn, rc, average, use_voronoi, use_weight,
+                                        weight, *lists, wl, wlhat, identify_liquid, threshold, n_bond)
+        job.compute()
+        values = as_numpy(job.qnarray)
+        if values.shape[1] == 1:
+            found = {f"ql{llist[0]}": values.flatten()}
         else:
-            new[f"ql{llist[0]}"] = qn.flatten()[: self.N]
+            names = [f"ql{l}" for l in llist]
+            names += [f"wl{l}" for l in llist] if wl else []
+            names += [f"wlh{l}" for l in llist] if wlhat else []
+            found = {name: values[:, col] for col, name in enumerate(names)}
         if identify_liquid:
-            new["solidliquid"] = as_numpy(SBO.solidliquid)[: self.N]
-            new["nbond"] = as_numpy(SBO.nbond)[: self.N]
-        self.update_data(self.data.with_columns(**new))
+            found.update(solidliquid=job.solidliquid, nbond=job.nbond)
+        self._store(**found)
 
-    def cal_radial_distribution_function(self, rc: float, nbin: int = 100, max_neigh: Optional[int] = None,
-                                         streaming: Optional[bool] = None) -> RadialDistributionFunction:
-        """system.py:2235-2361"""
-        box, data = self._get_compute_view()
-        if streaming is None:  # :2279-2288
-            thickness = box.get_thickness()
-            periodic = [thickness[i] for i in range(3) if box.boundary[i]]
-            min_thick = min(periodic) if periodic else float("inf")
-            streaming = rc >= min_thick / 3.0
-
-        def _species_labels(view):
-            if "element" in view.columns:
-                return view["element"].to_numpy()
-            if "type" in view.columns:
-                return view["type"].to_numpy()
-            return np.zeros(view.shape[0], np.int32)
-
+    def cal_radial_distribution_function(self, rc, nbin=100, max_neigh=None, streaming=None):
+        """-> RadialDistributionFunction (``r``, ``g_total``, ``g_partial``).  ``streaming=None`` decides by itself: a cutoff
+        of a third of the thinnest periodic direction or more is counted straight from the positions, without a list"""
+        cell, frame = self._get_compute_view()
+        if streaming is None:
+            spans = [t for t, periodic in zip(cell.get_thickness(), cell.boundary) if periodic]
+            streaming = rc >= (min(spans) if spans else float("inf")) / 3.0
         if streaming:
-            repeat = self.box.check_small_box(rc)
-            if sum(repeat) != 3:
-                rep_data, rep_box = tool.replicate(data, box, *repeat)
-                rdf = RadialDistributionFunction(rc, nbin, rep_box, type_list=_species_labels(rep_data),
-                                                 streaming=True, x=rep_data["x"], y=rep_data["y"], z=rep_data["z"])
-            else:
-                rdf = RadialDistributionFunction(rc, nbin, box, type_list=_species_labels(data), streaming=True,
-                                                 x=data["x"], y=data["y"], z=data["z"])
+            copies = self.box.check_small_box(rc)
+            if not policy.is_single(copies):
+                frame, cell = tool.replicate(frame, cell, *copies)
+            job = RadialDistributionFunction(rc, nbin, cell, type_list=policy.species_of(frame), streaming=True,
+                                             x=frame["x"], y=frame["y"], z=frame["z"])
         else:
-            if not (hasattr(self, "rc") and self.rc >= rc):
-                self.build_neighbor(rc, max_neigh)
-            box, data = self._get_compute_view()
-            rdf = RadialDistributionFunction(rc, nbin, box, verlet_list=self.verlet_list,
-                                             distance_list=self.distance_list, neighbor_number=self.neighbor_number,
-                                             type_list=_species_labels(data))
-        rdf.compute()
-        return rdf
+            self._require_cutoff_list(rc, max_neigh)
+            cell, frame = self._get_compute_view()
+            job = RadialDistributionFunction(rc, nbin, cell, verlet_list=self.verlet_list, distance_list=self.distance_list,
+                                             neighbor_number=self.neighbor_number, type_list=policy.species_of(frame))
+        job.compute()
+        return job
 
-    def cal_warren_cowley_parameter(self, rc: float, max_neigh: Optional[int] = None) -> WarrenCowleyParameter:
-        """system.py:1638-1676"""
-        if not (hasattr(self, "rc") and self.rc >= rc):
-            self.build_neighbor(rc, max_neigh)
-        _, data = self._get_compute_view()
-        wcp = WarrenCowleyParameter(self.verlet_list, self.neighbor_number, data)
-        wcp.compute()
-        return wcp
+    def cal_warren_cowley_parameter(self, rc, max_neigh=None):
+        """-> WarrenCowleyParameter (``WCP`` matrix)"""
+        self._require_cutoff_list(rc, max_neigh)
+        job = WarrenCowleyParameter(self.verlet_list, self.neighbor_number, self._get_compute_view()[1])
+        job.compute()
+        return job
 
-    def average_by_neighbor(self, average_rc: float, property_name: str, include_self: bool = True,
-                            output_name: Optional[str] = None, max_neigh: Optional[int] = None) -> None:
-        """system.py:2363-2414"""
-        if not (hasattr(self, "rc") and self.rc >= average_rc):
-            self.build_neighbor(average_rc, max_neigh)
-        _, data = self._get_compute_view()
-        out = tool.average_by_neighbor(average_rc, data, self.verlet_list, self.distance_list, self.neighbor_number,
-                                       property_name, include_self, output_name)
-        name = output_name if output_name is not None else f"{property_name}_ave"
-        self.update_data(self.data.with_columns(**{name: out[name].to_numpy()[: self.N]}))
+    def average_by_neighbor(self, average_rc, property_name, include_self=True, output_name=None, max_neigh=None):
+        """column ``<property>_ave`` (or ``output_name``): neighbourhood mean of a column within ``average_rc``"""
+        self._require_cutoff_list(average_rc, max_neigh)
+        averaged = tool.average_by_neighbor(average_rc, self._get_compute_view()[1], self.verlet_list, self.distance_list,
+                                            self.neighbor_number, property_name, include_self, output_name)
+        name = f"{property_name}_ave" if output_name is None else output_name
+        self._store(**{name: averaged[name].to_numpy()})

@@ -1,30 +1,27 @@
-"""Warren-Cowley short-range order.  Mirrors
-``mdapy.warren_cowley_parameter.WarrenCowleyParameter`` (src/mdapy/warren_cowley_parameter.py:76-112)."""
-from __future__ import annotations
-
+"""Warren-Cowley short-range order — the drop-in for ``mdapy.warren_cowley_parameter.WarrenCowleyParameter``
+(src/mdapy/warren_cowley_parameter.py:76-112): ``WCP[a, b] = 1 - Z_ab / (c_b Z_a)`` over a cutoff list.  Species are the
+elements in sorted order (``ele2type`` maps a name to its row) or, without an element column, ``type - 1``."""
 import numpy as np
 
-from . import _wcp
-from . import tool_function as tool
-from .frame import Frame
+from . import kernels, policy
 from .parallel import get_num_threads
 
 
 class WarrenCowleyParameter:
-    def __init__(self, verlet_list, neighbor_number, data: Frame) -> None:
-        self.verlet_list = verlet_list
-        self.neighbor_number = neighbor_number
-        self.data = data
-        if "element" in self.data.columns:  # elements -> index in sorted order (:82-89)
-            names, self.type_list = tool.dense_labels(self.data["element"].to_numpy())
-            self.ele2type = {j: i for i, j in enumerate(names)}
-            self.Ntype = len(self.ele2type)
-        else:
-            assert "type" in self.data.columns
-            self.type_list = (self.data["type"].to_numpy() - 1).astype(np.int32)
-            self.Ntype = len(np.unique(self.type_list))
-            assert self.type_list.max() + 1 == self.Ntype
+    def __init__(self, verlet_list, neighbor_number, data):
+        self.verlet_list, self.neighbor_number, self.data = verlet_list, neighbor_number, data
+        if "element" in data.columns:
+            names, self.type_list = policy.label_codes(data["element"].to_numpy())
+            self.ele2type = dict(zip(names, range(len(names))))
+            self.Ntype = len(names)
+            return
+        assert "type" in data.columns
+        codes = np.asarray(data["type"].to_numpy()).astype(np.int32) - np.int32(1)
+        kinds = len(np.unique(codes))
+        assert int(codes.max()) + 1 == kinds  # types must be 1..Ntype without gaps
+        self.type_list, self.Ntype = codes, kinds
 
-    def compute(self) -> None:
-        self.WCP = np.zeros((self.Ntype, self.Ntype), float)
-        _wcp.get_wcp(self.verlet_list, self.neighbor_number, self.type_list, self.Ntype, self.WCP, get_num_threads())
+    def compute(self):
+        kinds = self.Ntype
+        self.WCP = np.zeros((kinds, kinds), float)
+        kernels.wcp.get_wcp(self.verlet_list, self.neighbor_number, self.type_list, kinds, self.WCP, get_num_threads())

@@ -114,47 +114,12 @@ repeat_cell = _mod(repeat_cell=lambda new, ob, op, nx, ny, nz, num_t=1: O.repeat
 
 
 def install(monkeypatch):
-    import mdapy_amd.ackland_jones_analysis as m_aja
-    import mdapy_amd.atomic_temperature as m_at
-    import mdapy_amd.build_lattice as bl
-    import mdapy_amd.cluster_analysis as m_cl
-    import mdapy_amd.create_polycrystal as m_poly
-    import mdapy_amd.structure_factor as m_sf
-    import mdapy_amd.voronoi as m_vor
-    import mdapy_amd.identify_fcc_planar_faults as m_pft
-    import mdapy_amd.common_neighbor_parameter as m_cnp
-    import mdapy_amd.structure_entropy as m_se
-    import mdapy_amd.centro_symmetry_parameter as m_csp
-    import mdapy_amd.common_neighbor_analysis as m_cna
-    import mdapy_amd.identify_diamond_structure as m_ids
-    import mdapy_amd.knn as m_knn
-    import mdapy_amd.neighbor as m_nb
-    import mdapy_amd.polyhedral_template_matching as m_ptm
-    import mdapy_amd.radial_distribution_function as m_rdf
-    import mdapy_amd.steinhardt_bond_orientation as m_sbo
-    import mdapy_amd.tool_function as m_tool
-    import mdapy_amd.warren_cowley_parameter as m_wcp
+    """swap the shim modules behind mdapy_amd.kernels (the package's one door to the C ABI) for the adapters above"""
+    import mdapy_amd.kernels as K
 
-    monkeypatch.setattr(m_nb, "_neighbor", neighbor)
-    monkeypatch.setattr(m_poly, "_neighbor", neighbor)
-    monkeypatch.setattr(m_poly, "_polycrystal", polycrystal)
-    monkeypatch.setattr(m_tool, "_neighbor", neighbor)
-    monkeypatch.setattr(m_tool, "_repeat_cell", repeat_cell)
-    monkeypatch.setattr(bl, "_repeat_cell", repeat_cell)
-    monkeypatch.setattr(m_knn, "_fast_knn", fast_knn)
-    monkeypatch.setattr(m_cna, "_cna", cna)
-    monkeypatch.setattr(m_ids, "_cna", cna)
-    monkeypatch.setattr(m_csp, "_csp", csp)
-    monkeypatch.setattr(m_sbo, "_sbo", sbo)
-    monkeypatch.setattr(m_ptm, "_ptm", ptm)
-    monkeypatch.setattr(m_rdf, "_rdf", rdf)
-    monkeypatch.setattr(m_wcp, "_wcp", wcp)
-    monkeypatch.setattr(m_aja, "_aja", aja)
-    monkeypatch.setattr(m_at, "_atomtemp", atomtemp)
-    monkeypatch.setattr(m_cl, "_cluster", cluster)
-    monkeypatch.setattr(m_sf, "_sfc", sfc)
-    monkeypatch.setattr(m_vor, "_voronoi", voronoi)
-    monkeypatch.setattr(m_pft, "_fccpft", fccpft)
-    monkeypatch.setattr(m_cnp, "_cnp", cnp)
-    monkeypatch.setattr(m_se, "_structure_entropy", structure_entropy)
-    monkeypatch.setattr(m_se, "_neighbor", neighbor)
+    table = dict(neighbor=neighbor, polycrystal=polycrystal, repeat_cell=repeat_cell, fast_knn=fast_knn, cna=cna, csp=csp,
+                 sbo=sbo, ptm=ptm, rdf=rdf, wcp=wcp, aja=aja, atomtemp=atomtemp, cluster=cluster, sfc=sfc, voronoi=voronoi,
+                 fccpft=fccpft, cnp=cnp, structure_entropy=structure_entropy)
+    assert set(table) == set(K.NAMES), "an adapter per shim module"
+    for name, adapter in table.items():
+        monkeypatch.setattr(K, name, adapter)
