@@ -1,22 +1,32 @@
 #!/usr/bin/env python
 """bench.py — headline metric of BASELINE.json: atoms/sec for neighbor-build + CNA on FCC Cu.
 
-A "step" is one pass of the hot path over the whole (synthetic) system, positions already resident
-in HBM: cell-list neighbor build (rc = 0.854 a, max_neigh = 16: the `System.cal_common_neighbor_analysis(rc)`
-configuration the reference's own CNA tests and SURVEY.md §6 use) followed by fixed-cutoff CNA, all through
-the C ABI of libmdapy_amd.so with device pointers.  At N GPUs every rank owns a 136^3-cell slab of a
-(136 N) x 136 x 136-cell box (weak scaling) and exchanges a one-cutoff ghost halo with its two ring
-neighbours over RCCL each step.
+A "step" is one pass of the hot path over the whole (synthetic) system, positions already resident in HBM: cell-list
+neighbor build (rc = 0.854 a, max_neigh = 16: the `System.cal_common_neighbor_analysis(rc)` configuration the reference's
+own CNA tests and SURVEY.md 6 use) followed by fixed-cutoff CNA, all through the C ABI of libmdapy_amd.so with device
+pointers.  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling) and exchanges a
+one-cutoff ghost halo with its two ring neighbours over RCCL each step.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_neighbor), timed with HIP events
-recorded inside the library on the launch stream; `cpu_baseline` is the CPU oracle (a parity-checked port of
-the reference's OpenMP C++, oracle/mdapy_oracle.c) timed on this box's host cores on a bounded sample.
+Prints ONE JSON line (rank 0):
+* `roofline` is for the dominant kernel of the step (the neighbor kernel, `k_neighbor` = everything between the cell grid
+  and the CNA of one build), timed with HIP events recorded inside the library on the launch stream.  `traffic` is the
+  HBM byte count of that kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) taken by THIS run when rocprofv3 is
+  on PATH (`traffic_source: "live"`), else the committed measurement under profiles/ (`"committed"`); FETCH_SIZE is
+  doubled as MI355X_MICROARCH.md prescribes for gfx950 (the raw sum is reported beside it).
+* `extra` times, on the same box, the two other ways the step is reached through the API: `max_neigh=None` (exact-width
+  rows: counting pass + build on one cell grid, mdh_build_neighbor_exact) and a thermally rattled lattice (sigma = 0.05 A).
+* `cpu_baseline` is the CPU oracle (a parity-checked port of the reference's OpenMP C++, oracle/mdapy_oracle.c) timed on
+  this box's host cores on a 1 M-atom sample, best thread count of a sweep.
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,6 +37,9 @@ sys.path.insert(0, ROOT)
 A_CU = 3.615
 RC = 0.854 * A_CU
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# the OpenMP port against the reference's own C++ on identical input and cores (1 000 188-atom FCC Cu, neighbor M = 16 + fixed
+# CNA, 8 threads, build container): port 0.315 s, reference 0.40 s
+PORT_OVER_REFERENCE = 0.40 / 0.315
 
 
 def parse():
@@ -38,7 +51,10 @@ def parse():
     p.add_argument("--max-neigh", type=int, default=16)
     p.add_argument("--sigma", type=float, default=0.0, help="optional thermal rattle (A) of the lattice")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the max_neigh=None / rattled-lattice timings")
+    p.add_argument("--no-pmc", action="store_true", help="do not take the live rocprofv3 PMC passes for roofline.traffic")
     p.add_argument("--cpu-cells", type=int, default=63, help="cells per axis of the CPU-baseline sample (63 -> 1 000 188 atoms)")
+    p.add_argument("--pmc-child", choices=["fetch", "write"], help=argparse.SUPPRESS)
     return p.parse_args()
 
 
@@ -75,26 +91,89 @@ def cpu_baseline(args):
     N, M = len(x), args.max_neigh
     org, bnd = np.zeros(3), np.array([1, 1, 1], np.int32)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    best = float("inf")
-    t_all = time.perf_counter()
-    reps = 0
-    while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 12):
+
+    def one(threads):
         v = np.full((N, M), -1, np.int32); d = np.full((N, M), RC + 1.0); nn = np.zeros(N, np.int32); pat = np.zeros(N, np.int32)
         t0 = time.perf_counter()
-        O.build_neighbor(x, y, z, box, org, bnd, RC, v, d, nn, cores)
-        O.fcna(x, y, z, box, org, bnd, v, nn, pat, RC, cores)
+        O.build_neighbor(x, y, z, box, org, bnd, RC, v, d, nn, threads)
+        O.fcna(x, y, z, box, org, bnd, v, nn, pat, RC, threads)
         dt = time.perf_counter() - t0
-        best = min(best, dt)
-        reps += 1
-        if time.perf_counter() - t_all > 40.0:
+        assert int((pat == 1).sum()) == N
+        return dt
+
+    one(min(cores, 16))  # first touch of the pages
+    sweep = {}
+    t_all = time.perf_counter()
+    for threads in sorted({t for t in (8, 16, 32, 64, 128, 256, cores) if t <= cores}):
+        sweep[threads] = min(one(threads) for _ in range(3))
+        if time.perf_counter() - t_all > 25.0:
             break
-    assert int((pat == 1).sum()) == N
-    return {"value": N / best, "unit": "atoms/s", "cores": cores, "kind": "port",
-            "sample": f"{N}-atom FCC Cu ({n}^3 cells), neighbor(rc={RC:.5f}, max_neigh={M}) + fixed CNA, OpenMP oracle port, best of {reps}"}
+    best_threads = min(sweep, key=sweep.get)
+    best = sweep[best_threads]
+    return {"value": N / best, "unit": "atoms/s", "cores": best_threads, "kind": "port",
+            "sample": f"{N}-atom FCC Cu ({n}^3 cells), neighbor(rc={RC:.5f}, max_neigh={M}) + fixed CNA, OpenMP oracle port, best of 3 at the "
+                      f"best thread count of the sweep {sorted(sweep)} on {cores} host cores; on the build container's 8 cores the port runs "
+                      f"{PORT_OVER_REFERENCE:.2f}x as fast as the reference's own C++ on this input (0.315 s vs 0.40 s)",
+            "threads_sweep_atoms_per_s": {str(k): N / v for k, v in sweep.items()}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the neighbor kernel: two rocprofv3 PMC passes over a child process that runs two builds
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_child(args):
+    import torch
+
+    import mdapy_amd as mp
+    from mdapy_amd import _neighbor
+
+    dev = torch.device("cuda", 0)
+    x, y, z, _ = slab_positions(torch, dev, args.cells, 0, args.sigma)
+    n, M = int(x.shape[0]), args.max_neigh
+    box = mp.Box(np.diag([A_CU * args.cells] * 3))
+    verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty((n, M), dtype=torch.float64, device=dev)
+    nn = torch.empty((n,), dtype=torch.int32, device=dev)
+    for _ in range(2):
+        _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, RC, verlet, dist, nn, 1, fill_pads=True)
+    torch.cuda.synchronize()
+
+
+def live_traffic(args):
+    """(fetch_bytes_raw, write_bytes) per call of the neighbor kernel, or None"""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    import csv
+
+    got = {}
+    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        out = tempfile.mkdtemp(prefix="mdh_pmc_", dir="/tmp")
+        cmd = ["timeout", "-s", "KILL", "180", exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", which, "--cells", str(args.cells), "--max-neigh", str(args.max_neigh),
+               "--sigma", str(args.sigma)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "p_counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            per_dispatch = {}
+            for row in csv.DictReader(open(files[0])):
+                if "k_neighbor_lane" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per_dispatch:
+                return None
+            # two launches of the kernel per build (tiles, then the slices of the listed tiles), two builds: KB per build
+            got[which] = sum(per_dispatch.values()) / 2.0 * 1024.0
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return got["fetch"], got["write"]
 
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
     import torch
     import torch.distributed as dist
 
@@ -104,12 +183,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
     import mdapy_amd as mp
     from mdapy_amd import _cna, _lib, _neighbor
@@ -122,6 +203,33 @@ def main():
     n_local = int(x.shape[0])
     box = mp.Box(np.diag([A_CU * cells * world, A_CU * cells, A_CU * cells]))
     dec = SlabDecomposition(box, rank, world, axis=0)
+    bx = (box.box, box.origin, box.boundary)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            out = step()
+        sync()
+        L.mdh_prof_reset()
+        L.mdh_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        L.mdh_prof_enable(0)
+        buf = ctypes.create_string_buffer(1 << 16)
+        prof = {}
+        if L.mdh_prof_report(buf, len(buf)) > 0:
+            for line in buf.value.decode().strip().splitlines():
+                name, cnt, tot = line.split()
+                prof[name] = (int(cnt), float(tot))
+        return elapsed, out, prof
 
     if world == 1:
         verlet = torch.empty((n_local, M), dtype=torch.int32, device=dev)
@@ -131,31 +239,15 @@ def main():
 
         def step():
             pattern.zero_()  # the kernels rely on the caller's pre-zeroing (common_neighbor_analysis.py:128)
-            _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, RC, verlet, distl, nn, 1, fill_pads=True)
-            _cna.fcna(x, y, z, box.box, box.origin, box.boundary, verlet, nn, pattern, RC, 1)
+            _neighbor.build_neighbor(x, y, z, *bx, RC, verlet, distl, nn, 1, fill_pads=True)
+            _cna.fcna(x, y, z, *bx, verlet, nn, pattern, RC, 1)
             return nn, pattern, None
     else:
         def step():
             dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M)
             return nn_, pat_, dom
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-    sync()
-    L.mdh_prof_reset()
-    L.mdh_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    L.mdh_prof_enable(0)
+    elapsed, out, prof = timed(step, args.steps, args.warmup)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -165,19 +257,11 @@ def main():
     nn_o, pat_o, dom = out
     if dom is not None:
         nn_o, pat_o = nn_o[dom.owned], pat_o[dom.owned]
-    ok = True
+    ok = int(nn_o.shape[0]) == n_local
     if args.sigma == 0.0:
-        ok = bool((nn_o == 12).all().item()) and bool((pat_o == 1).all().item()) and int(nn_o.shape[0]) == n_local
+        ok = ok and bool((nn_o == 12).all().item()) and bool((pat_o == 1).all().item())
     if not ok:
         raise SystemExit(f"rank {rank}: timed result is wrong (expected 12 neighbours / FCC label everywhere)")
-
-    buf = ctypes.create_string_buffer(1 << 16)
-    nbytes = L.mdh_prof_report(buf, len(buf))
-    prof = {}
-    if nbytes > 0:
-        for line in buf.value.decode().strip().splitlines():
-            name, cnt, tot = line.split()
-            prof[name] = (int(cnt), float(tot))
 
     if rank == 0:
         n_total = n_local * world
@@ -192,24 +276,58 @@ def main():
             "config": {"workload": f"FCC Cu a={A_CU}, {cells}^3 cells per GPU ({n_local} atoms/GPU, {n_total} total), "
                                    f"build_neighbor(rc=0.854a={RC:.5f}, max_neigh={M}) + fixed-cutoff CNA, positions resident in HBM",
                        "atoms_per_gpu": n_local, "rc": RC, "max_neigh": M, "sigma": args.sigma,
-                       "parallelism": f"slab{world}" if world > 1 else "single"},
+                       "parallelism": f"slab{world}" if world > 1 else "single", "world_size_checked": world},
         }
         if "k_neighbor" in prof:
             cnt, tot = prof["k_neighbor"]
             avg_ms = tot / cnt
-            alg_bytes = (28 + 12 * M) * n_rows  # SURVEY.md §8d: read x,y,z (24 B) + write nn (4 B) + rows (12 M B) per atom
+            alg_bytes = (28 + 12 * M) * n_rows  # SURVEY.md 8d: read x,y,z (24 B) + write nn (4 B) + rows (12 M B) per atom
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-            # HBM traffic of this kernel comes from separate rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot share
-            # a pass); the committed measurement applies to the default workload only
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath) and cells == 136 and M == 16 and world == 1 and args.sigma == 0.0:
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("traffic_bytes_per_launch_raw")
+            traffic = traffic_raw = None
+            source = None
+            if world == 1 and not args.no_pmc:
+                live = live_traffic(args)
+                if live is not None:
+                    traffic, traffic_raw, source = 2.0 * live[0] + live[1], live[0] + live[1], "live"
+            if traffic is None:
+                tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+                if os.path.exists(tpath) and cells == 136 and M == 16 and world == 1 and args.sigma == 0.0:
+                    with open(tpath) as fh:
+                        t = json.load(fh)
+                    traffic, traffic_raw, source = t["traffic_bytes_per_launch_fetch_x2"], t["traffic_bytes_per_launch_raw"], "committed"
             res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": avg_ms, "launches": cnt,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw_fetch_plus_write": traffic_raw,
+                               "traffic_source": source, "avg_kernel_ms": avg_ms, "launches": cnt,
                                "algorithmic_bytes_per_launch": alg_bytes}
             res["kernels_ms"] = {k: v[1] / v[0] for k, v in prof.items()}
+        if world == 1 and not args.no_extra:
+            extra = {}
+            # (a) the default API path: max_neigh=None -> exact-width rows, counting pass + build on one cell grid
+            def step_exact():
+                v_, d_, n_ = _neighbor.build_neighbor_without_max_neigh(x, y, z, *bx, RC, 1)
+                p_ = torch.zeros((n_local,), dtype=torch.int32, device=dev)
+                _cna.fcna(x, y, z, *bx, v_, n_, p_, RC, 1)
+                return n_, p_, v_
+
+            del verlet, distl
+            e2, o2, p2 = timed(step_exact, max(3, args.steps // 4), 2)
+            extra["max_neigh_none"] = {"ms_per_step": e2 / max(3, args.steps // 4) * 1e3, "row_width": int(o2[2].shape[1]),
+                                       "kernels_ms": {k: v[1] / v[0] for k, v in p2.items()}}
+            del o2
+            # (b) a thermally rattled lattice (sigma = 0.05 A), same box, max_neigh = 16
+            xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, 0.05)
+            v3 = torch.empty((n_local, M), dtype=torch.int32, device=dev); d3 = torch.empty((n_local, M), dtype=torch.float64, device=dev)
+
+            def step_rattled():
+                pattern.zero_()
+                _neighbor.build_neighbor(xs, ys, zs, *bx, RC, v3, d3, nn, 1, fill_pads=True)
+                _cna.fcna(xs, ys, zs, *bx, v3, nn, pattern, RC, 1)
+                return nn, pattern, None
+
+            e3, o3, p3 = timed(step_rattled, max(3, args.steps // 4), 2)
+            extra["sigma_0.05"] = {"ms_per_step": e3 / max(3, args.steps // 4) * 1e3, "fcc_fraction": float((o3[1] == 1).float().mean().item()),
+                                   "kernels_ms": {k: v[1] / v[0] for k, v in p3.items()}}
+            res["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res))

@@ -99,10 +99,12 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
 /* Halo selection of the slab decomposition (multi-GPU extension): one pass over the owned atoms; up / down (n) i32
  * receive the indices of the atoms whose wrapped fractional coordinate f along the decomposed axis (hi3 = that column of the
  * inverse box) satisfies f >= up_from / f < down_below, counts_host[2] their numbers.  Order of the indices: unspecified.
- * gid (n) i64 + up_pack / down_pack (n,4) f64 (or all NULL): rows (x, y, z, id) of the selected atoms, in the same order. */
+ * gid (n) i64 + up_pack / down_pack (capacity,4) f64 (or all NULL): rows (x, y, z, id) of the selected atoms, in the same order.
+ * up / down hold `capacity` entries; a count above it says that the buffers were too small (only the first `capacity`
+ * selections were stored): call again with larger ones. */
 int mdh_slab_halo_select(const double *x, const double *y, const double *z, int64_t n, const double *origin3_host,
                          const double *hi3_host, double up_from, double down_below, int *up, int *down, int64_t *counts_host,
-                         const int64_t *gid, double *up_pack, double *down_pack, int space, void *stream);
+                         const int64_t *gid, double *up_pack, double *down_pack, int64_t capacity, int space, void *stream);
 
 /*
  * first half of _neighbor.build_neighbor_without_max_neigh  src/neighbor.cpp:189-349:

@@ -520,7 +520,9 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         int m = vmax;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
-        if (lane == 0 && m > 0) atomicMax(max_count, m);
+        // one word takes ~90 atomics per microsecond: 200 000 waves must not all queue on it.  Almost every wave finds the
+        // maximum already there (a plain device-scope read), the few that raise it use the atomic.
+        if (lane == 0 && m > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, m);
     }
 }
 

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k_slab_select(const double *__restrict__ 
                                                      double h0, double h1, double h2, double up_from, double down_below,
                                                      int *__restrict__ up, int *__restrict__ down, int *__restrict__ counts,
                                                      const int64_t *__restrict__ gid, double *__restrict__ up_pack,
-                                                     double *__restrict__ down_pack)
+                                                     double *__restrict__ down_pack, int capacity)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool is_up = false, is_down = false;
@@ -37,13 +37,17 @@ __global__ __launch_bounds__(256) void k_slab_select(const double *__restrict__ 
     bd = __shfl(bd, 0, 64);
     if (is_up) {
         const int s = bu + __popcll(mu & ((1ull << lane) - 1ull));
-        up[s] = (int)i;
-        if (up_pack) { double *o = up_pack + (int64_t)s * 4; o[0] = x[i]; o[1] = y[i]; o[2] = z[i]; o[3] = (double)gid[i]; }
+        if (s < capacity) { // (the counters keep running: the host sees that the buffers were too small and comes back)
+            up[s] = (int)i;
+            if (up_pack) { double *o = up_pack + (int64_t)s * 4; o[0] = x[i]; o[1] = y[i]; o[2] = z[i]; o[3] = (double)gid[i]; }
+        }
     }
     if (is_down) {
         const int s = bd + __popcll(md & ((1ull << lane) - 1ull));
-        down[s] = (int)i;
-        if (down_pack) { double *o = down_pack + (int64_t)s * 4; o[0] = x[i]; o[1] = y[i]; o[2] = z[i]; o[3] = (double)gid[i]; }
+        if (s < capacity) {
+            down[s] = (int)i;
+            if (down_pack) { double *o = down_pack + (int64_t)s * 4; o[0] = x[i]; o[1] = y[i]; o[2] = z[i]; o[3] = (double)gid[i]; }
+        }
     }
 }
 
@@ -51,36 +55,39 @@ __global__ __launch_bounds__(256) void k_slab_select(const double *__restrict__ 
 
 using namespace mdh;
 
-// up / down: (n) i32 capacity each; counts_host[0..1] receive the numbers of selected atoms.  hi3 = column `axis` of the
+// up / down: (capacity) i32 each; counts_host[0..1] receive the numbers of selected atoms — if one of them exceeds `capacity`
+// the buffers hold the first `capacity` selections only and the caller repeats the call with larger ones (a slab's halo is a
+// few per cent of its atoms: buffers sized for all of them would be ~72 B per owned atom of transient memory per step).  hi3 = column `axis` of the
 // inverse box matrix, origin3: host arrays.  gid (n) i64 with up_pack / down_pack (n, 4) f64, or all three NULL: the
 // selected atoms' (x, y, z, id) rows, ready to be sent (ids < 2^53 are exact in f64).  Synchronises the stream (the counts
 // size the exchange that follows).
 extern "C" int mdh_slab_halo_select(const double *x, const double *y, const double *z, int64_t n, const double *origin3,
                                     const double *hi3, double up_from, double down_below, int *up, int *down,
-                                    int64_t *counts_host, const int64_t *gid, double *up_pack, double *down_pack, int space,
-                                    void *stream)
+                                    int64_t *counts_host, const int64_t *gid, double *up_pack, double *down_pack, int64_t capacity,
+                                    int space, void *stream)
 {
     if ((gid || up_pack || down_pack) && !(gid && up_pack && down_pack)) {
         set_error("mdh_slab_halo_select: gid, up_pack and down_pack go together");
         return MDH_ERR_ARG;
     }
-    if (n < 0 || n >= 2147483647LL || !counts_host) { set_error("mdh_slab_halo_select: bad arguments"); return MDH_ERR_ARG; }
+    if (n < 0 || n >= 2147483647LL || !counts_host || capacity < 0) { set_error("mdh_slab_halo_select: bad arguments"); return MDH_ERR_ARG; }
+    if (capacity > n) capacity = n;
     counts_host[0] = counts_host[1] = 0;
     if (n == 0)
         return MDH_OK;
     Scope sc(stream);
     hipStream_t st = sc.stream();
     const double *dx = sc.stage_in(x, (size_t)n, space), *dy = sc.stage_in(y, (size_t)n, space), *dz = sc.stage_in(z, (size_t)n, space);
-    int *du = sc.stage(up, (size_t)n, space, false, true), *dd = sc.stage(down, (size_t)n, space, false, true);
+    int *du = sc.stage(up, (size_t)capacity, space, false, true), *dd = sc.stage(down, (size_t)capacity, space, false, true);
     int *dc = sc.alloc_n<int>(2);
     const int64_t *dg = gid ? sc.stage_in(gid, (size_t)n, space) : nullptr;
-    double *dup = up_pack ? sc.stage(up_pack, (size_t)n * 4, space, false, true) : nullptr;
-    double *ddp = down_pack ? sc.stage(down_pack, (size_t)n * 4, space, false, true) : nullptr;
+    double *dup = up_pack ? sc.stage(up_pack, (size_t)capacity * 4, space, false, true) : nullptr;
+    double *ddp = down_pack ? sc.stage(down_pack, (size_t)capacity * 4, space, false, true) : nullptr;
     if (sc.failed())
         return sc.error();
     MDH_HIP(hipMemsetAsync(dc, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(k_slab_select, dim3(grid_for(n, 256)), dim3(256), 0, st, dx, dy, dz, n, origin3[0], origin3[1], origin3[2],
-                       hi3[0], hi3[1], hi3[2], up_from, down_below, du, dd, dc, dg, dup, ddp);
+                       hi3[0], hi3[1], hi3[2], up_from, down_below, du, dd, dc, dg, dup, ddp, (int)capacity);
     int c[2] = {0, 0};
     MDH_HIP(hipMemcpyAsync(c, dc, sizeof(c), hipMemcpyDeviceToHost, st));
     MDH_HIP(hipStreamSynchronize(st));

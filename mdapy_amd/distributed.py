@@ -1,27 +1,25 @@
 """Multi-GPU: slab domain decomposition with a ghost halo exchanged over RCCL (xGMI).
 
-The reference is a single-process library; this layer is added by the build
-(SURVEY.md §8e).  One process per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm;
-"gloo" for the CPU tests).  Atoms are owned by the rank whose slab (along one box axis, in
-wrapped fractional coordinates) contains them; before a neighbor build every rank receives, from
-its two ring neighbours, the atoms lying within `halo` of the shared faces (ncclSend/ncclRecv
-pairs — there is no other data-path collective).
+The reference is a single-process library; this layer is added by the build.  One process
+per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm).  Atoms are owned by the rank whose slab (along one box axis,
+in wrapped fractional coordinates) contains them; before a neighbor build every rank receives, from its two ring
+neighbours, the atoms lying within `halo` of the shared faces (ncclSend / ncclRecv pairs — no other data-path collective).
 
-Exactness.  The local problem is solved with the GLOBAL box: ghost positions are NOT shifted, the
-kernels apply the same minimum-image arithmetic and use the same global cell grid as a
-single-GPU run, and the local arrays are ordered by global atom id so that "descending local
-index inside a cell" == "descending global id".  The rows of owned atoms (ids, order, counts,
-distances) and every label derived from them are therefore bit-identical to the single-GPU
-result for the whole system; rows of ghost atoms are incomplete and discarded.
+Exactness.  The local problem is solved with the GLOBAL box: ghost positions are NOT shifted, the kernels apply the same
+minimum-image arithmetic and use the same global cell grid as a single-GPU run, and the global ids order the atoms inside
+a cell (``build_neighbor(..., key=gid)``).  The rows of owned atoms (ids, order, counts, distances) and every label derived
+from them are therefore bit-identical to the single-GPU result for the whole system; rows of ghost atoms are incomplete and
+discarded.
+
+Transport.  With a process group that carries device tensors (nccl) the messages go GPU to GPU.  With "gloo" — the CPU
+tests, and the `-m gpu` test that runs several ranks on ONE GPU — device tensors are staged through host memory; the code
+path above the wire is the same.
 """
-from __future__ import annotations
-
-from dataclasses import dataclass
-from typing import Optional, Tuple
+from dataclasses import dataclass, field
 
 import numpy as np
 
-from . import _cna, _csp, _fast_knn, _neighbor, _ptm, _rdf, _sbo, _wcp
+from . import kernels
 from .box import Box
 
 
@@ -40,15 +38,54 @@ class LocalDomain:
     gid: "object"       # int64 global ids, ascending
     owned: "object"     # bool mask
     n_owned: int
+    extra: tuple = field(default_factory=tuple)  # further per-atom columns that travelled with the halo (e.g. types), f64
 
 
 class SlabDecomposition:
     def __init__(self, box: Box, rank: int, world: int, axis: int = 0, group=None):
-        assert 0 <= rank < world
-        assert box.boundary[axis] == 1 or world == 1, "the decomposed axis must be periodic (ring of slabs)"
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside a world of {world}")
+        if world > 1 and box.boundary[axis] != 1:
+            raise ValueError("the decomposed axis must be periodic (ring of slabs)")
         self.box, self.rank, self.world, self.axis, self.group = box, rank, world, axis, group
         self.left = (rank - 1) % world
         self.right = (rank + 1) % world
+        self._cap = 0  # rows of the halo pack buffers (grown on demand, sized from the last exchange)
+
+    # -- wire -----------------------------------------------------------------
+    def _host_staged(self):
+        import torch.distributed as dist
+
+        return dist.get_backend(self.group) == "gloo"
+
+    def _ring(self, to_right, to_left, from_left, from_right):
+        """one exchange around the ring: two sends, two receives, batched"""
+        import torch.distributed as dist
+
+        stage = to_right.is_cuda and self._host_staged()
+        sr, sl = (to_right.cpu(), to_left.cpu()) if stage else (to_right, to_left)
+        rl, rr = (from_left.cpu(), from_right.cpu()) if stage else (from_left, from_right)
+        ops = [dist.P2POp(dist.isend, sr, self.right, self.group), dist.P2POp(dist.isend, sl, self.left, self.group),
+               dist.P2POp(dist.irecv, rl, self.left, self.group), dist.P2POp(dist.irecv, rr, self.right, self.group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if stage:
+            from_left.copy_(rl)
+            from_right.copy_(rr)
+
+    def all_reduce_(self, tensor):
+        """in-place sum over the ranks"""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return tensor
+        if tensor.is_cuda and self._host_staged():
+            host = tensor.cpu()
+            dist.all_reduce(host, group=self.group)
+            tensor.copy_(host)
+        else:
+            dist.all_reduce(tensor, group=self.group)
+        return tensor
 
     # -- geometry -----------------------------------------------------------
     def frac(self, x, y, z):
@@ -70,23 +107,34 @@ class SlabDecomposition:
         x, y, z = x.contiguous(), y.contiguous(), z.contiguous()
         assert x.dtype == t.float64 and y.dtype == t.float64 and z.dtype == t.float64
         n = int(x.shape[0])
-        up = t.empty(n, dtype=t.int32, device=x.device)
-        down = t.empty(n, dtype=t.int32, device=x.device)
         o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
         hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
         cnt = (ctypes.c_int64 * 2)(0, 0)
-        pu = pd = g = None
+        g = None
         if gid is not None:
             g = gid.contiguous()
             assert g.dtype == t.int64
-            pu = t.empty((n, 4), dtype=t.float64, device=x.device)
-            pd = t.empty((n, 4), dtype=t.float64, device=x.device)
-        _lib.check(_lib.lib().mdh_slab_halo_select(x.data_ptr(), y.data_ptr(), z.data_ptr(), n, o.ctypes.data, hi3.ctypes.data,
-                                                   float(up_from), float(down_below), up.data_ptr(), down.data_ptr(), cnt,
-                                                   g.data_ptr() if g is not None else None, pu.data_ptr() if pu is not None else None,
-                                                   pd.data_ptr() if pd is not None else None,
-                                                   _lib.DEVICE, int(t.cuda.current_stream().cuda_stream)))
-        nu, nd = int(cnt[0]), int(cnt[1])
+        # A halo is a thin layer: the buffers hold what the last exchange needed plus a quarter (the first call guesses an
+        # eighth of the slab); when a count comes back larger, the call is repeated with room for it.
+        cap = min(n, self._cap if self._cap > 0 else max(1024, n // 8))
+        while True:
+            up = t.empty(cap, dtype=t.int32, device=x.device)
+            down = t.empty(cap, dtype=t.int32, device=x.device)
+            pu = pd = None
+            if g is not None:
+                pu = t.empty((cap, 4), dtype=t.float64, device=x.device)
+                pd = t.empty((cap, 4), dtype=t.float64, device=x.device)
+            _lib.check(_lib.lib().mdh_slab_halo_select(x.data_ptr(), y.data_ptr(), z.data_ptr(), n, o.ctypes.data, hi3.ctypes.data,
+                                                       float(up_from), float(down_below), up.data_ptr(), down.data_ptr(), cnt,
+                                                       g.data_ptr() if g is not None else None, pu.data_ptr() if pu is not None else None,
+                                                       pd.data_ptr() if pd is not None else None, cap,
+                                                       _lib.DEVICE, int(t.cuda.current_stream().cuda_stream)))
+            nu, nd = int(cnt[0]), int(cnt[1])
+            need = max(nu, nd)
+            self._cap = min(n, need + need // 4 + 64)
+            if need <= cap:
+                break
+            cap = self._cap
         if gid is None:
             return up[:nu].to(t.int64), down[:nd].to(t.int64)
         return up[:nu], down[:nd], pu[:nu], pd[:nd]
@@ -98,93 +146,89 @@ class SlabDecomposition:
     def halo_fraction(self, halo: float) -> float:
         thick = float(self.box.get_thickness()[self.axis])
         h = (halo * (1.0 + 1e-9) + 1e-9) / thick
-        assert h <= 1.0 / self.world + 1e-12 or self.world == 1, (
-            f"slab thickness {thick / self.world:.3f} is smaller than the halo {halo}: use fewer ranks")
+        if self.world > 1 and h > 1.0 / self.world + 1e-12:
+            raise ValueError(f"slab thickness {thick / self.world:.3f} is smaller than the halo {halo}: use fewer ranks")
         return h
 
     # -- halo exchange --------------------------------------------------------
-    def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True) -> LocalDomain:
+    def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True, extra=()) -> LocalDomain:
         """x,y,z (f64) and gid (i64) of the OWNED atoms (1-D tensors on this rank's device).
 
         sort=True: the local order is ascending global id (what index-ordered kernels need to reproduce the undivided
         system's rows).  sort=False: owned atoms first, in the caller's order, then the ghosts — for kernels that take the
-        ids as an ordering key (``build_neighbor(..., key=dom.gid)``); no pass over the owned atoms beyond the copy."""
+        ids as an ordering key (``build_neighbor(..., key=dom.gid)``); no pass over the owned atoms beyond the copy.
+        extra: further per-owned-atom columns (numbers exact in f64, e.g. int32 types); they travel in the same message
+        as the positions and come back as ``dom.extra`` in local order."""
         t = _torch()
-        import torch.distributed as dist
-
         n_owned = int(x.shape[0])
+        dev = x.device
+        cols = [x, y, z] + [e.to(t.float64) for e in extra]  # everything that follows an atom (besides its id)
         if self.world == 1:
-            order = t.argsort(gid) if n_owned and not bool((gid[1:] > gid[:-1]).all()) else None
-            if order is not None:
-                x, y, z, gid = x[order], y[order], z[order], gid[order]
-            return LocalDomain(x, y, z, gid, t.ones(n_owned, dtype=t.bool, device=x.device), n_owned)
+            if n_owned and not bool((gid[1:] > gid[:-1]).all()):
+                order = t.argsort(gid)
+                cols, gid = [c[order] for c in cols], gid[order]
+            return LocalDomain(cols[0], cols[1], cols[2], gid, t.ones(n_owned, dtype=t.bool, device=dev), n_owned, tuple(cols[3:]))
         h = self.halo_fraction(halo)
         lo, hi = self.rank / self.world, (self.rank + 1) / self.world
         if x.is_cuda:  # selection and packing in one fused pass (slab.hip); the torch expressions below are its definition
-            _, _, rows_r, rows_l = self._select_device(x, y, z, hi - h, lo + h, gid)
-            send_r, send_l = rows_r.t().contiguous(), rows_l.t().contiguous()
+            up, down, rows_r, rows_l = self._select_device(x, y, z, hi - h, lo + h, gid)
+            send_r, send_l = rows_r.t(), rows_l.t()  # rows x, y, z, id
+            if extra:
+                iu, idn = up.long(), down.long()
+                send_r = t.cat([send_r[:3]] + [c[iu][None] for c in cols[3:]] + [send_r[3:]])
+                send_l = t.cat([send_l[:3]] + [c[idn][None] for c in cols[3:]] + [send_l[3:]])
+            send_r, send_l = send_r.contiguous(), send_l.contiguous()
         else:
             f = self.frac(x, y, z)
             up = (f >= hi - h).nonzero().flatten()    # goes to the right neighbour
             down = (f < lo + h).nonzero().flatten()   # goes to the left neighbour
 
             def pack(sel):
-                return t.stack([x[sel], y[sel], z[sel], gid[sel].to(t.float64)], dim=0).contiguous()  # ids < 2^53: exact
+                return t.stack([c[sel] for c in cols] + [gid[sel].to(t.float64)], dim=0).contiguous()  # ids < 2^53: exact
 
             send_r, send_l = pack(up), pack(down)
-        # sizes first (order: to-right then to-left / from-left then from-right, consistent for world == 2)
-        cnt_s = [t.tensor([send_r.shape[1]], dtype=t.int64, device=x.device),
-                 t.tensor([send_l.shape[1]], dtype=t.int64, device=x.device)]
-        cnt_r = [t.zeros(1, dtype=t.int64, device=x.device), t.zeros(1, dtype=t.int64, device=x.device)]
-        ops = [dist.P2POp(dist.isend, cnt_s[0], self.right, self.group), dist.P2POp(dist.isend, cnt_s[1], self.left, self.group),
-               dist.P2POp(dist.irecv, cnt_r[0], self.left, self.group), dist.P2POp(dist.irecv, cnt_r[1], self.right, self.group)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        n_from_left, n_from_right = (int(v) for v in t.cat(cnt_r).tolist())  # one device-to-host read for both counts
-        recv_l = t.empty((4, n_from_left), dtype=t.float64, device=x.device)
-        recv_r = t.empty((4, n_from_right), dtype=t.float64, device=x.device)
-        ops = [dist.P2POp(dist.isend, send_r, self.right, self.group), dist.P2POp(dist.isend, send_l, self.left, self.group),
-               dist.P2POp(dist.irecv, recv_l, self.left, self.group), dist.P2POp(dist.irecv, recv_r, self.right, self.group)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        width = len(cols) + 1
+        # sizes first, then the payload
+        cnt_in = t.zeros(2, dtype=t.int64, device=dev)
+        self._ring(t.tensor([send_r.shape[1]], dtype=t.int64, device=dev), t.tensor([send_l.shape[1]], dtype=t.int64, device=dev),
+                   cnt_in[0:1], cnt_in[1:2])
+        n_from_left, n_from_right = (int(v) for v in cnt_in.tolist())  # one device-to-host read for both counts
+        recv_l = t.empty((width, n_from_left), dtype=t.float64, device=dev)
+        recv_r = t.empty((width, n_from_right), dtype=t.float64, device=dev)
+        self._ring(send_r, send_l, recv_l, recv_r)
         ghosts = t.cat([recv_l, recv_r], dim=1)
-        dev = x.device
-        if not sort and self.world > 2:  # two different neighbours: every ghost arrives once, any order will do
-            ggid = ghosts[3].to(t.int64)
-            n_tot = n_owned + int(ggid.shape[0])
-            own = t.arange(n_tot, device=dev) < n_owned
-            return LocalDomain(t.cat([x, ghosts[0]]), t.cat([y, ghosts[1]]), t.cat([z, ghosts[2]]), t.cat([gid, ggid]), own, n_owned)
-        # ghosts in ascending id order, each once (world == 2: the same atom can arrive through both faces of the one neighbour)
-        ggid, first = _unique_first(ghosts[3].to(t.int64))
-        ghosts = ghosts[:, first]
+        ggid = ghosts[-1].to(t.int64)
+        if sort or self.world == 2:
+            # ghosts in ascending id order, each once (world == 2: the same atom can arrive through both faces of the one neighbour)
+            ggid, first = _unique_first(ggid)
+            ghosts = ghosts[:, first]
         n_ghost = int(ggid.shape[0])
         n_tot = n_owned + n_ghost
-        if not sort:
+        if not sort:  # owned first, then the ghosts
             own = t.arange(n_tot, device=dev) < n_owned
-            return LocalDomain(t.cat([x, ghosts[0]]), t.cat([y, ghosts[1]]), t.cat([z, ghosts[2]]), t.cat([gid, ggid]), own, n_owned)
+            full = [t.cat([c, ghosts[k]]) for k, c in enumerate(cols)]
+            return LocalDomain(full[0], full[1], full[2], t.cat([gid, ggid]), own, n_owned, tuple(full[3:]))
         if n_owned < 2 or bool((gid[1:] > gid[:-1]).all()):
-            # Local order = ascending global id (it fixes the order inside the reference's rows).  The owned ids are already
-            # ascending, the few ghosts are sorted: MERGE the two runs (two binary searches, three scatters per array) instead
-            # of sorting all of them every step.
+            # Local order = ascending global id.  The owned ids are already ascending, the few ghosts are sorted: MERGE the two
+            # runs (two binary searches, two scatters per array) instead of sorting all of them every step.
             gslot = t.searchsorted(gid, ggid) + t.arange(n_ghost, dtype=t.int64, device=dev)
             oslot = t.searchsorted(ggid, gid) + t.arange(n_owned, dtype=t.int64, device=dev)
 
-            def merge(a_owned, a_ghost, dtype):
-                out = t.empty(n_tot, dtype=dtype, device=dev)
+            def merge(a_owned, a_ghost):
+                out = t.empty(n_tot, dtype=a_owned.dtype, device=dev)
                 out[oslot] = a_owned
-                out[gslot] = a_ghost
+                out[gslot] = a_ghost.to(a_owned.dtype)
                 return out
 
             own = t.zeros(n_tot, dtype=t.bool, device=dev)
             own[oslot] = True
-            return LocalDomain(merge(x, ghosts[0], t.float64), merge(y, ghosts[1], t.float64), merge(z, ghosts[2], t.float64),
-                               merge(gid, ggid, t.int64), own, n_owned)
-        ax = t.cat([x, ghosts[0]]); ay = t.cat([y, ghosts[1]]); az = t.cat([z, ghosts[2]])
+            full = [merge(c, ghosts[k]) for k, c in enumerate(cols)]
+            return LocalDomain(full[0], full[1], full[2], merge(gid, ggid), own, n_owned, tuple(full[3:]))
         ag = t.cat([gid, ggid])
-        own = t.cat([t.ones(n_owned, dtype=t.bool, device=dev), t.zeros(n_ghost, dtype=t.bool, device=dev)])
         order = t.argsort(ag)
-        return LocalDomain(ax[order].contiguous(), ay[order].contiguous(), az[order].contiguous(), ag[order].contiguous(),
-                           own[order].contiguous(), n_owned)
+        own = (t.arange(n_tot, device=dev) < n_owned)[order].contiguous()
+        full = [t.cat([c, ghosts[k]])[order].contiguous() for k, c in enumerate(cols)]
+        return LocalDomain(full[0], full[1], full[2], ag[order].contiguous(), own, n_owned, tuple(full[3:]))
 
 
 def _unique_first(ids):
@@ -219,17 +263,16 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     dist = t.empty((n, max_neigh), dtype=t.float64, device=dom.x.device)
     nn = t.empty((n,), dtype=t.int32, device=dom.x.device)
     pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
-    _neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
+    kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
                              key=dom.gid if dec.world > 1 else None)
-    _cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
+    kernels.cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
     return dom, verlet, dist, nn, pattern
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # k-nearest-neighbour analyses (adaptive CNA, CSP, PTM, ...): the halo is not known in advance
 # ------------------------------------------------------------------------------------------------------------------
-def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo: Optional[float] = None, neighbor_rows: int = 0,
-             max_tries: int = 6):
+def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo=None, neighbor_rows: int = 0, max_tries: int = 6, extra=()):
     """k nearest neighbours of every owned atom, bit-identical to a single-GPU search of the whole system.
 
     A slab knows the atoms within `halo` of its faces.  The k-th neighbour distance r_k(i) of an atom proves its own row
@@ -242,8 +285,6 @@ def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo: Optional[float]
     ``valid`` marks the rows proven complete (all owned rows are).
     """
     t = _torch()
-    import torch.distributed as dist_
-
     b = dec.box
     thick = float(b.get_thickness()[dec.axis])
     if halo is None:  # about the k-th neighbour distance of a uniform system of the local density, with head-room
@@ -253,11 +294,11 @@ def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo: Optional[float]
     for _ in range(max_tries):
         if dec.world > 1:
             halo = min(halo, thick / dec.world * (1.0 - 1e-6))
-        dom = dec.exchange_halo(x, y, z, gid, halo)
+        dom = dec.exchange_halo(x, y, z, gid, halo, extra=extra)
         n = int(dom.x.shape[0])
         idx = t.empty((n, k), dtype=t.int32, device=dom.x.device)
         dst = t.empty((n, k), dtype=t.float64, device=dom.x.device)
-        _fast_knn.knn(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, k, idx, dst, 1)
+        kernels.fast_knn.knn(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, k, idx, dst, 1)
         if dec.world == 1:
             return dom, idx, dst, t.ones(n, dtype=t.bool, device=dom.x.device)
         h = dec.halo_fraction(halo)
@@ -276,8 +317,7 @@ def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo: Optional[float]
             m = min(neighbor_rows, k)
             nb = idx[dom.owned][:, :m].long()
             ok = ok & valid[nb.clamp(min=0)].all(dim=1)
-        bad = t.tensor([int((~ok).sum().item())], dtype=t.int64, device=dom.x.device)
-        dist_.all_reduce(bad, group=dec.group)
+        bad = dec.all_reduce_(t.tensor([int((~ok).sum().item())], dtype=t.int64, device=dom.x.device))
         if int(bad.item()) == 0:
             return dom, idx, dst, valid
         if halo >= thick / dec.world * (1.0 - 1e-6):
@@ -289,39 +329,37 @@ def knn_step(dec: SlabDecomposition, x, y, z, gid, k: int, halo: Optional[float]
 
 def knn_analysis_step(dec: SlabDecomposition, x, y, z, gid, what=("acna", "csp", "ptm"), csp_neighbors: int = 12,
                       ptm_structure: str = "fcc-hcp-bcc", ptm_threshold: float = 0.1, types=None):
-    """Adaptive CNA / CSP / PTM of the owned atoms from one verified 18-neighbour search (rows sorted by distance, as the
-    reference's classes build them: common_neighbor_analysis.py:125-140, centro_symmetry_parameter.py:79-100,
-    polyhedral_template_matching.py:110-150).  ``types``: optional int32 per OWNED atom (PTM alloy ordering) — it
-    travels with the halo as a fifth packed column.  Returns (dom, results) with results[name] in ``dom`` order;
-    only rows with ``dom.owned`` are meaningful."""
+    """Adaptive CNA / CSP / PTM of the owned atoms from ONE verified k-neighbour search, k = the deepest any of the requested
+    analyses needs (rows sorted by distance, as the reference's classes build them: common_neighbor_analysis.py:125-140,
+    centro_symmetry_parameter.py:79-100, polyhedral_template_matching.py:110-150).  ``types``: optional int32 per OWNED atom
+    (PTM alloy ordering) — it travels with the halo as one more packed column.  Returns (dom, results) with results[name] in
+    ``dom`` order; only rows with ``dom.owned`` are meaningful."""
     t = _torch()
     flags = ptm_structure.replace("all", "dcub-dhex-graphene")
     two_shell = "ptm" in what and any(s in flags for s in ("dcub", "dhex", "graphene"))
-    k = 18 if "ptm" in what else max(14 if "acna" in what else 0, csp_neighbors if "csp" in what else 0)
-    tdom = None
-    if types is not None:  # ghosts need their types: ship them as an extra coordinate-like payload keyed by gid
-        tdom = _gather_by_gid(dec, gid, types)
-    dom, idx, dst, valid = knn_step(dec, x, y, z, gid, k, neighbor_rows=13 if two_shell else 0)
+    k = max(18 if "ptm" in what else 0, 14 if "acna" in what else 0, int(csp_neighbors) if "csp" in what else 0)
+    if k <= 0:
+        raise ValueError(f"nothing to do: what={what!r}")
+    dom, idx, dst, valid = knn_step(dec, x, y, z, gid, k, neighbor_rows=13 if two_shell else 0,
+                                    extra=() if types is None else (types,))
     n = int(dom.x.shape[0])
     b = dec.box
+    dev = dom.x.device
+    where = (dom.x, dom.y, dom.z, b.box, b.origin, b.boundary)
     out = {}
     if "acna" in what:
-        pat = t.zeros((n,), dtype=t.int32, device=dom.x.device)
-        _cna.acna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, idx, pat, 1)
-        out["acna"] = pat
+        out["acna"] = t.zeros((n,), dtype=t.int32, device=dev)
+        kernels.cna.acna(*where, idx, out["acna"], 1)
     if "csp" in what:
-        csp = t.zeros((n,), dtype=t.float64, device=dom.x.device)
-        _csp.get_csp(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, idx, csp_neighbors, csp, 1)
-        out["csp"] = csp
+        out["csp"] = t.zeros((n,), dtype=t.float64, device=dev)
+        kernels.csp.get_csp(*where, idx, csp_neighbors, out["csp"], 1)
     if "ptm" in what:
-        res = t.zeros((n, 8), dtype=t.float64, device=dom.x.device)
-        ind = t.zeros((n, 18), dtype=t.int32, device=dom.x.device)
-        ty = None
-        if tdom is not None:
-            ty = tdom(dom.gid)
-        _ptm.get_ptm(ptm_structure, dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, idx, ty, ptm_threshold, res, ind, 1)
-        out["ptm"] = res
-        out["ptm_indices"] = ind
+        res = t.zeros((n, 8), dtype=t.float64, device=dev)
+        ind = t.zeros((n, 18), dtype=t.int32, device=dev)
+        rows18 = idx if k == 18 else idx[:, :18].contiguous()  # PTM reads exactly 18 columns
+        ty = dom.extra[0].to(t.int32).contiguous() if types is not None else None
+        kernels.ptm.get_ptm(ptm_structure, *where, rows18, ty, ptm_threshold, res, ind, 1)
+        out["ptm"], out["ptm_indices"] = res, ind
     out["knn_idx"], out["knn_dist"], out["valid"] = idx, dst, valid
     return dom, out
 
@@ -341,47 +379,16 @@ def steinhardt_step(dec: SlabDecomposition, x, y, z, gid, llist, rc: float, max_
     verlet = t.empty((n, max_neigh), dtype=t.int32, device=dev)
     dist = t.empty((n, max_neigh), dtype=t.float64, device=dev)
     nn = t.empty((n,), dtype=t.int32, device=dev)
-    _neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
+    kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
                              key=dom.gid if dec.world > 1 else None)
     ll = np.ascontiguousarray(np.asarray(llist), dtype=np.int32)
     nl, lmax = int(ll.shape[0]), int(ll.max())
     qlm_r = t.zeros((n, nl, 2 * lmax + 1), dtype=t.float64, device=dev)
     qlm_i = t.zeros((n, nl, 2 * lmax + 1), dtype=t.float64, device=dev)
     qn = t.zeros((n, nl * (1 + int(bool(wl)) + int(bool(wlhat)))), dtype=t.float64, device=dev)
-    _sbo.get_sq(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, dist, nn, np.zeros((2, 2)), ll, 0, lmax, wl, wlhat,
+    kernels.sbo.get_sq(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, dist, nn, np.zeros((2, 2)), ll, 0, lmax, wl, wlhat,
                 average, False, rc, False, qlm_r, qlm_i, qn, 1)
     return dom, qn
-
-
-def _gather_by_gid(dec: SlabDecomposition, gid, values):
-    """all-gather a per-owned-atom int32 column so that any rank can look it up by global id (types are 4 B/atom:
-    one all-gather of N x 12 B in total; used for PTM alloy ordering only)"""
-    t = _torch()
-    import torch.distributed as dist_
-
-    if dec.world == 1:
-        g, v = gid, values
-    else:
-        n = t.tensor([int(gid.shape[0])], dtype=t.int64, device=gid.device)
-        sizes = [t.zeros(1, dtype=t.int64, device=gid.device) for _ in range(dec.world)]
-        dist_.all_gather(sizes, n, group=dec.group)
-        mx = int(max(int(s.item()) for s in sizes))
-        pad_g = t.full((mx,), -1, dtype=t.int64, device=gid.device); pad_g[: gid.shape[0]] = gid
-        pad_v = t.zeros((mx,), dtype=t.int64, device=gid.device); pad_v[: gid.shape[0]] = values.to(t.int64)
-        gs = [t.empty_like(pad_g) for _ in range(dec.world)]
-        vs = [t.empty_like(pad_v) for _ in range(dec.world)]
-        dist_.all_gather(gs, pad_g, group=dec.group)
-        dist_.all_gather(vs, pad_v, group=dec.group)
-        g = t.cat([a[: int(s.item())] for a, s in zip(gs, sizes)])
-        v = t.cat([a[: int(s.item())] for a, s in zip(vs, sizes)])
-    order = t.argsort(g)
-    g, v = g[order], v[order]
-
-    def lookup(q):
-        pos = t.searchsorted(g, q)
-        return v[pos].to(t.int32).contiguous()
-
-    return lookup
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -392,27 +399,19 @@ def rdf_counts_step(dec: SlabDecomposition, dom: LocalDomain, verlet, dist, nn, 
     radial_distribution_function.cpp:22-54): ghost rows are switched off through their neighbour count, the integer
     counts (exact in f64 below 2^53) are summed over the ranks.  `types` int32 0-based in ``dom`` order."""
     t = _torch()
-    import torch.distributed as dist_
-
     nn_own = t.where(dom.owned, nn, t.zeros_like(nn)).contiguous()
     g = t.zeros((ntype, ntype, nbin), dtype=t.float64, device=dom.x.device)
-    _rdf._rdf(verlet, dist, nn_own, types, g, rc, nbin)
-    if dec.world > 1:
-        dist_.all_reduce(g, group=dec.group)
-    return g
+    kernels.rdf._rdf(verlet, dist, nn_own, types, g, rc, nbin)
+    return dec.all_reduce_(g)
 
 
 def wcp_step(dec: SlabDecomposition, dom: LocalDomain, verlet, nn, types, ntype: int):
     """Warren-Cowley matrix of the whole system: Z_mn / Z_m / atoms-per-type counted over owned rows
     (`mdh_wcp_counts`), one int64 all-reduce, then warren_cowley_parameter.cpp:57-75."""
     t = _torch()
-    import torch.distributed as dist_
-
     counts = t.zeros((ntype * ntype + 2 * ntype,), dtype=t.int64, device=dom.x.device)
-    _wcp.get_wcp_counts(verlet, nn, types, ntype, counts, rows=dom.owned.to(t.uint8).contiguous())
-    if dec.world > 1:
-        dist_.all_reduce(counts, group=dec.group)
-    c = counts.cpu().numpy().astype(np.int64)
+    kernels.wcp.get_wcp_counts(verlet, nn, types, ntype, counts, rows=dom.owned.to(t.uint8).contiguous())
+    c = dec.all_reduce_(counts).cpu().numpy().astype(np.int64)
     T = ntype
     zmn, zm, cnt = c[: T * T].reshape(T, T), c[T * T: T * T + T], c[T * T + T:]
     ntot = float(cnt.sum())

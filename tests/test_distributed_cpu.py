@@ -57,9 +57,11 @@ def _worker(rank, world, port, q):
             O.get_sq(x.numpy(), y.numpy(), z.numpy(), box, origin, boundary, v.numpy(), d.numpy(), nn.numpy(), w, ll, nnn, lmax, wl, wlhat,
                      average, use_vor, rc, use_w, qr.numpy(), qi.numpy(), qn.numpy(), 2)
 
-        D._neighbor = type("M", (), {"build_neighbor": staticmethod(build_neighbor)})
-        D._cna = type("M", (), {"fcna": staticmethod(fcna)})
-        D._sbo = type("M", (), {"get_sq": staticmethod(get_sq)})
+        import mdapy_amd.kernels as K  # the package's one door to the C ABI: swap the shims behind it
+
+        K.neighbor = type("M", (), {"build_neighbor": staticmethod(build_neighbor)})
+        K.cna = type("M", (), {"fcna": staticmethod(fcna)})
+        K.sbo = type("M", (), {"get_sq": staticmethod(get_sq)})
 
         a = 3.615
         pos, boxm = lattice_positions("fcc", a, 12, 6, 6)
@@ -170,14 +172,16 @@ def _worker_analyses(rank, world, port, q):
                 for j in v[i, : nn[i]]:
                     counts[t[i] * Nt + t[j]] += 1
 
-        D._neighbor = _types.SimpleNamespace(build_neighbor=wrap(build_neighbor).__func__)
-        D._fast_knn = _types.SimpleNamespace(knn=wrap(lambda x, y, z, b, o, p, k, i, d, nt=1: O.knn(x, y, z, b, o, p, k, i, d, 2)).__func__)
-        D._cna = _types.SimpleNamespace(acna=wrap(lambda x, y, z, b, o, p, v, pat, nt=1: O.acna(x, y, z, b, o, p, v, pat, 2)).__func__)
-        D._csp = _types.SimpleNamespace(get_csp=wrap(lambda x, y, z, b, o, p, v, n, out, nt=1: O.get_csp(x, y, z, b, o, p, v, n, out, 2)).__func__)
-        D._ptm = _types.SimpleNamespace(get_ptm=wrap(lambda st, x, y, z, b, o, p, v, ty, thr, out, ind, nt=1:
+        import mdapy_amd.kernels as K  # the package's one door to the C ABI: swap the shims behind it
+
+        K.neighbor = _types.SimpleNamespace(build_neighbor=wrap(build_neighbor).__func__)
+        K.fast_knn = _types.SimpleNamespace(knn=wrap(lambda x, y, z, b, o, p, k, i, d, nt=1: O.knn(x, y, z, b, o, p, k, i, d, 2)).__func__)
+        K.cna = _types.SimpleNamespace(acna=wrap(lambda x, y, z, b, o, p, v, pat, nt=1: O.acna(x, y, z, b, o, p, v, pat, 2)).__func__)
+        K.csp = _types.SimpleNamespace(get_csp=wrap(lambda x, y, z, b, o, p, v, n, out, nt=1: O.get_csp(x, y, z, b, o, p, v, n, out, 2)).__func__)
+        K.ptm = _types.SimpleNamespace(get_ptm=wrap(lambda st, x, y, z, b, o, p, v, ty, thr, out, ind, nt=1:
                                                      O.get_ptm(st, x, y, z, b, o, p, v, ty, thr, out, ind)).__func__)
-        D._rdf = _types.SimpleNamespace(_rdf=wrap(lambda v, d, nn, ty, g, rc, nbin: O._rdf(v, d, nn, ty, g, rc, nbin)).__func__)
-        D._wcp = _types.SimpleNamespace(get_wcp_counts=wrap(wcp_counts).__func__)
+        K.rdf = _types.SimpleNamespace(_rdf=wrap(lambda v, d, nn, ty, g, rc, nbin: O._rdf(v, d, nn, ty, g, rc, nbin)).__func__)
+        K.wcp = _types.SimpleNamespace(get_wcp_counts=wrap(wcp_counts).__func__)
 
         a = 3.6
         pos, boxm = lattice_positions("fcc", a, 10, 5, 5)
@@ -223,7 +227,7 @@ def _worker_analyses(rank, world, port, q):
         dom = dec.exchange_halo(*own_args, rc)
         n = int(dom.x.shape[0])
         v = torch.empty((n, M), dtype=torch.int32); d = torch.empty((n, M), dtype=torch.float64); nn = torch.empty(n, dtype=torch.int32)
-        D._neighbor.build_neighbor(dom.x, dom.y, dom.z, boxm, org, bnd, rc, v, d, nn, 1, fill_pads=True)
+        K.neighbor.build_neighbor(dom.x, dom.y, dom.z, boxm, org, bnd, rc, v, d, nn, 1, fill_pads=True)
         ty = t(types_all[dom.gid.numpy()])
         g = D.rdf_counts_step(dec, dom, v, d, nn, ty, 2, rc, nbin)
         w = D.wcp_step(dec, dom, v, nn, ty, 2)

@@ -1,0 +1,176 @@
+"""-m gpu: the decomposed path on the HIP kernels.
+
+A one-GPU box cannot host two RCCL ranks, but it can host two PROCESSES that share the GPU and talk over gloo: the slab
+layer stages its messages through host memory then (mdapy_amd/distributed.py, "Transport") and everything above the wire
+— halo selection kernel, keyed neighbor build, CNA, Steinhardt, verified-halo kNN analyses incl. PTM with types
+travelling in the halo, RDF / Warren-Cowley reductions — runs exactly as it does over RCCL.  Every rank compares its owned
+rows bit for bit with the same kernels run on the undivided system."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _system(seed=5):
+    from mdapy_amd.build_lattice import lattice_positions
+
+    a = 3.615
+    pos, boxm = lattice_positions("fcc", a, 28, 14, 14)  # 21 952 atoms; 14 cells per rank and axis at world 2
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(0, 0.07, pos.shape)             # some atoms leave the box: ownership uses wrapped coordinates
+    pos[rng.random(len(pos)) < 0.03] += rng.normal(0, 0.5, 3)
+    types = rng.integers(1, 3, len(pos)).astype(np.int32)
+    perm = rng.permutation(len(pos))                        # arbitrary input order: global ids are not slab-contiguous
+    return pos[perm], types[perm], boxm, a
+
+
+def _undivided(torch, K, pos, types, boxm, rc, M, ll):
+    """the same kernels on the whole system (HBM resident)"""
+    dev = torch.device("cuda", 0)
+    x, y, z = (torch.from_numpy(np.ascontiguousarray(pos[:, k])).to(dev) for k in range(3))
+    org, bnd = np.zeros(3), np.array([1, 1, 1], np.int32)
+    N = len(pos)
+    where = (x, y, z, boxm, org, bnd)
+    v = torch.empty((N, M), dtype=torch.int32, device=dev); d = torch.empty((N, M), dtype=torch.float64, device=dev)
+    nn = torch.empty(N, dtype=torch.int32, device=dev)
+    K.neighbor.build_neighbor(*where, rc, v, d, nn, 1, fill_pads=True)
+    pat = torch.zeros(N, dtype=torch.int32, device=dev)
+    K.cna.fcna(*where, v, nn, pat, rc, 1)
+    out = {"v": v, "d": d, "nn": nn, "fcna": pat}
+    for average in (False, True):
+        qr = torch.zeros((N, 2, 13), dtype=torch.float64, device=dev); qi = torch.zeros_like(qr)
+        qn = torch.zeros((N, 4), dtype=torch.float64, device=dev)
+        K.sbo.get_sq(*where, v, d, nn, np.zeros((2, 2)), ll, 0, 6, True, False, average, False, rc, False, qr, qi, qn, 1)
+        out[f"q{int(average)}"] = qn
+    idx = torch.empty((N, 18), dtype=torch.int32, device=dev); dk = torch.empty((N, 18), dtype=torch.float64, device=dev)
+    K.fast_knn.knn(*where, 18, idx, dk, 1)
+    acna = torch.zeros(N, dtype=torch.int32, device=dev); K.cna.acna(*where, idx, acna, 1)
+    csp = torch.zeros(N, dtype=torch.float64, device=dev); K.csp.get_csp(*where, idx, 12, csp, 1)
+    res = torch.zeros((N, 8), dtype=torch.float64, device=dev); ind = torch.zeros((N, 18), dtype=torch.int32, device=dev)
+    K.ptm.get_ptm("fcc-hcp-bcc", *where, idx, torch.from_numpy(types).to(dev), 0.1, res, ind, 1)
+    out.update(knn_idx=idx, knn_dist=dk, acna=acna, csp=csp, ptm=res, ptm_indices=ind)
+    t0 = torch.from_numpy(types - 1).to(dev)
+    g = torch.zeros((2, 2, 40), dtype=torch.float64, device=dev)
+    K.rdf._rdf(v, d, nn, t0, g, rc, 40)
+    W = np.zeros((2, 2)); K.wcp.get_wcp(v, nn, t0, 2, W, 1)
+    out.update(rdf=g, wcp=W)
+    return {k: (a.cpu().numpy() if hasattr(a, "cpu") else a) for k, a in out.items()}
+
+
+def _run_rank(rank, world, torch, dist_ready=True):
+    import mdapy_amd as mp
+    import mdapy_amd.distributed as D
+    import mdapy_amd.kernels as K
+
+    dev = torch.device("cuda", 0)
+    pos, types, boxm, a = _system()
+    rc, M = 0.854 * a, 20
+    ll = np.array([4, 6], np.int32)
+    box = mp.Box(boxm)
+    ref = _undivided(torch, K, pos, types, boxm, rc, M, ll)
+    owned_ids = D.partition_atoms(pos, box, world, axis=0)[rank]
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    own_args = (t(pos[owned_ids, 0]), t(pos[owned_ids, 1]), t(pos[owned_ids, 2]), t(owned_ids))
+    dec = D.SlabDecomposition(box, rank, world, axis=0)
+    bad = []
+
+    def check(name, ok):
+        if not ok:
+            bad.append(name)
+
+    # ---- neighbor + fixed-cutoff CNA (the bench's step)
+    dom, v, d, nn, pat = D.neighbor_cna_step(dec, *own_args, rc, M)
+    own, gid = dom.owned.cpu().numpy(), dom.gid.cpu().numpy()
+    g_own = gid[own]
+    check("owned set", own.sum() == len(owned_ids) and np.array_equal(np.sort(g_own), np.sort(owned_ids)))
+    vloc = v.cpu().numpy()[own]
+    check("rows", np.array_equal(np.where(vloc >= 0, gid[np.clip(vloc, 0, None)], -1), np.where(ref["v"][g_own] >= 0, ref["v"][g_own], -1)))
+    check("counts", np.array_equal(nn.cpu().numpy()[own], ref["nn"][g_own]))
+    check("distances", np.array_equal(d.cpu().numpy()[own], ref["d"][g_own]))
+    check("fcna", np.array_equal(pat.cpu().numpy()[own], ref["fcna"][g_own]))
+    check("fcna nontrivial", len(np.unique(ref["fcna"])) > 1)
+    # ---- Steinhardt over the cutoff list, plain and neighbour-averaged (halo 2 rc)
+    for average in (False, True):
+        dq, qloc = D.steinhardt_step(dec, *own_args, ll, rc, M, average=average, wl=True)
+        oq = dq.owned.cpu().numpy()
+        check(f"steinhardt average={average}", np.array_equal(qloc.cpu().numpy()[oq], ref[f"q{int(average)}"][dq.gid.cpu().numpy()[oq]]))
+    # ---- verified-halo kNN analyses; the types of the ghosts travel with the halo
+    dk, res = D.knn_analysis_step(dec, *own_args, what=("acna", "csp", "ptm"), types=t(types[owned_ids]))
+    ok_, gk = dk.owned.cpu().numpy(), dk.gid.cpu().numpy()
+    gko = gk[ok_]
+    check("knn_dist", np.array_equal(res["knn_dist"].cpu().numpy()[ok_], ref["knn_dist"][gko]))
+    check("knn_ids", np.array_equal(gk[res["knn_idx"].cpu().numpy()[ok_]], ref["knn_idx"][gko]))
+    check("acna", np.array_equal(res["acna"].cpu().numpy()[ok_], ref["acna"][gko]))
+    check("csp", np.array_equal(res["csp"].cpu().numpy()[ok_], ref["csp"][gko]))
+    check("ptm", np.array_equal(res["ptm"].cpu().numpy()[ok_], ref["ptm"][gko]))
+    pi = res["ptm_indices"].cpu().numpy()[ok_]
+    check("ptm_indices", np.array_equal(np.where(pi >= 0, gk[np.clip(pi, 0, None)], -1), ref["ptm_indices"][gko]))
+    check("ptm nontrivial", len(np.unique(ref["ptm"][:, 0])) > 1)
+    # a deeper search than PTM's 18 (CSP over 24): PTM still gets its 18 columns
+    dk2, res2 = D.knn_analysis_step(dec, *own_args, what=("csp", "ptm"), csp_neighbors=24, types=t(types[owned_ids]))
+    o2 = dk2.owned.cpu().numpy()
+    check("ptm beside csp24", res2["knn_idx"].shape[1] == 24 and np.array_equal(res2["ptm"].cpu().numpy()[o2], ref["ptm"][dk2.gid.cpu().numpy()[o2]]))
+    # ---- list reductions
+    ty = t((types - 1)[gid])
+    g = D.rdf_counts_step(dec, dom, v, d, nn, ty, 2, rc, 40)
+    w = D.wcp_step(dec, dom, v, nn, ty, 2)
+    check("rdf counts", np.array_equal(g.cpu().numpy(), ref["rdf"]) and ref["rdf"].sum() > 0)
+    check("wcp", np.array_equal(w, ref["wcp"]))
+    return bad, int(own.sum()), int((~own).sum())
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _run_rank(rank, world, torch))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, [repr(e) + traceback.format_exc()[-1500:]], 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_decomposed_steps_world1_equal_the_undivided_system():
+    import torch
+
+    bad, n_own, n_ghost = _run_rank(0, 1, torch)
+    assert bad == [] and n_ghost == 0 and n_own == 28 * 14 * 14 * 4
+
+
+@pytest.mark.parametrize("world", [2])
+def test_decomposed_steps_on_hip_kernels_equal_the_undivided_system(world):
+    import torch.multiprocessing as tmp
+
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, bad, n_own, n_ghost in sorted(res):
+        assert bad == [], f"rank {rank}: {bad}"
+        assert n_own > 0 and n_ghost > 0
+    assert sum(r[2] for r in res) == 28 * 14 * 14 * 4
