@@ -8,7 +8,6 @@ import numpy as np
 
 from . import kernels
 from .box import Box
-from .devarray import have_gpu
 from .frame import Frame
 from .parallel import get_num_threads
 
@@ -44,7 +43,8 @@ def _supercell(cell, nx, ny, nz):
 
 
 def lattice_positions(structure, a, nx=1, ny=1, nz=1, c=None):
-    """(positions (N, 3), box (3, 3)) of an nx x ny x nz supercell, evaluated with numpy (no GPU needed)"""
+    """(positions (N, 3), box (3, 3)) of an nx x ny x nz supercell, evaluated with numpy — for test inputs and checks; build_crystal itself
+    always runs the replication kernel"""
     cell, basis = unit_cell(structure, a, c)
     sites = basis @ cell
     ix, iy, iz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
@@ -61,12 +61,9 @@ def build_crystal(name, structure, a, nx=1, ny=1, nz=1, c=None):
     if not isinstance(name, str):
         raise TypeError("only single-element crystals are supported here; pass one element symbol")
     cell, basis = unit_cell(structure, a, c)
-    if have_gpu():
-        sites = np.ascontiguousarray(basis @ cell)
-        flat = np.zeros(len(sites) * nx * ny * nz * 3, dtype=np.float64)
-        kernels.repeat_cell.repeat_cell(flat, cell, sites, nx, ny, nz, get_num_threads())
-        pos = flat.reshape((-1, 3))
-    else:  # the same expression in numpy (host-logic tests on a machine without a GPU)
-        pos = lattice_positions(structure, a, nx, ny, nz, c)[0]
+    sites = np.ascontiguousarray(basis @ cell)
+    flat = np.zeros(len(sites) * nx * ny * nz * 3, dtype=np.float64)
+    kernels.repeat_cell.repeat_cell(flat, cell, sites, nx, ny, nz, get_num_threads())  # HIP kernel; raises without a GPU
+    pos = flat.reshape((-1, 3))
     frame = Frame({"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2], "element": np.full(len(pos), name, dtype=object)})
     return System(data=frame, box=Box(_supercell(cell, nx, ny, nz)))

@@ -20,10 +20,38 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 
 // ----------------------------------------------------------------------------
 // scratch cache: blocks are handed out best-fit and returned at Scope exit
+//
+// A DEVICE-space call returns while its kernels are still queued, and its Scope gives the blocks back at that moment.
+// Reuse from the SAME stream is ordered by the stream; reuse from another stream (another host thread, a side stream of the
+// caller) is not.  Every Scope therefore records ONE event on its stream when it ends; the blocks it held remember that
+// event, and a later Scope on a different stream makes its stream wait for it before touching the block.
 // ----------------------------------------------------------------------------
-struct Block { void *p; size_t bytes; bool busy; int device; };
+struct DoneEvent { hipEvent_t ev; hipStream_t stream; int refs; };
+struct Block { void *p; size_t bytes; bool busy; int device; DoneEvent *done; };
 static std::mutex g_mu;
 static std::vector<Block> g_blocks;
+static std::vector<DoneEvent *> g_event_pool;
+
+static DoneEvent *event_acquire(hipStream_t st) // g_mu held
+{
+    DoneEvent *e = nullptr;
+    if (!g_event_pool.empty()) {
+        e = g_event_pool.back();
+        g_event_pool.pop_back();
+    } else {
+        e = new DoneEvent{nullptr, nullptr, 0};
+        if (hipEventCreateWithFlags(&e->ev, hipEventDisableTiming) != hipSuccess) { delete e; return nullptr; }
+    }
+    e->stream = st;
+    e->refs = 0;
+    return e;
+}
+
+static void event_release(DoneEvent *e) // g_mu held
+{
+    if (e && --e->refs == 0)
+        g_event_pool.push_back(e);
+}
 
 Scope::Scope(void *stream) : stream_(static_cast<hipStream_t>(stream))
 {
@@ -41,10 +69,28 @@ Scope::Scope(void *stream) : stream_(static_cast<hipStream_t>(stream))
 
 Scope::~Scope()
 {
+    if (nheld_ == 0)
+        return;
     std::lock_guard<std::mutex> lk(g_mu);
+    DoneEvent *done = event_acquire(stream_);
+    if (done && hipEventRecord(done->ev, stream_) != hipSuccess) { // cannot mark the end of this call's work: wait for it instead
+        (void)hipStreamSynchronize(stream_);
+        g_event_pool.push_back(done);
+        done = nullptr;
+    } else if (!done) {
+        (void)hipStreamSynchronize(stream_);
+    }
     for (int i = 0; i < nheld_; ++i)
         for (auto &b : g_blocks)
-            if (b.p == held_[i]) { b.busy = false; break; }
+            if (b.p == held_[i]) {
+                event_release(b.done);
+                b.done = done;
+                if (done) ++done->refs;
+                b.busy = false;
+                break;
+            }
+    if (done && done->refs == 0)
+        g_event_pool.push_back(done);
 }
 
 void *Scope::alloc(size_t bytes)
@@ -63,17 +109,20 @@ void *Scope::alloc(size_t bytes)
     }
     // reuse only if the block is not grossly oversized (keeps big list buffers from being pinned by tiny requests)
     if (best >= 0 && g_blocks[best].bytes <= 2 * bytes + (1u << 20)) {
-        g_blocks[best].busy = true;
-        held_[nheld_] = g_blocks[best].p;
-        held_bytes_[nheld_++] = g_blocks[best].bytes;
-        return g_blocks[best].p;
+        Block &b = g_blocks[best];
+        if (b.done && b.done->stream != stream_) // last used on another stream: its work there comes first
+            (void)hipStreamWaitEvent(stream_, b.done->ev, 0);
+        b.busy = true;
+        held_[nheld_] = b.p;
+        held_bytes_[nheld_++] = b.bytes;
+        return b.p;
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
-        // drop idle cached blocks of this device and retry once
+        // drop idle cached blocks of this device and retry once (hipFree waits for the device: nothing is in flight after it)
         for (size_t i = 0; i < g_blocks.size();) {
-            if (!g_blocks[i].busy && g_blocks[i].device == device_) { (void)hipFree(g_blocks[i].p); g_blocks.erase(g_blocks.begin() + i); }
+            if (!g_blocks[i].busy && g_blocks[i].device == device_) { (void)hipFree(g_blocks[i].p); event_release(g_blocks[i].done); g_blocks.erase(g_blocks.begin() + i); }
             else ++i;
         }
         e = hipMalloc(&p, bytes);
@@ -83,7 +132,7 @@ void *Scope::alloc(size_t bytes)
         failed_ = true;
         return nullptr;
     }
-    g_blocks.push_back(Block{p, bytes, true, device_});
+    g_blocks.push_back(Block{p, bytes, true, device_, nullptr});
     held_[nheld_] = p;
     held_bytes_[nheld_++] = bytes;
     return p;
@@ -248,7 +297,7 @@ int mdh_release_workspace(void)
 {
     std::lock_guard<std::mutex> lk(mdh::g_mu);
     for (size_t i = 0; i < mdh::g_blocks.size();) {
-        if (!mdh::g_blocks[i].busy) { (void)hipFree(mdh::g_blocks[i].p); mdh::g_blocks.erase(mdh::g_blocks.begin() + i); }
+        if (!mdh::g_blocks[i].busy) { (void)hipFree(mdh::g_blocks[i].p); mdh::event_release(mdh::g_blocks[i].done); mdh::g_blocks.erase(mdh::g_blocks.begin() + i); }
         else ++i;
     }
     return MDH_OK;
