@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "ptm_tables.hpp"
 #include <mutex>
+#include <vector>
 
 namespace mdh {
 
@@ -63,7 +64,8 @@ template <bool TRI> struct DevFold {
 template <bool TRI>
 __global__ __launch_bounds__(PTM_BLOCK) void k_ptm_order(const double *__restrict__ x, const double *__restrict__ y,
                                                          const double *__restrict__ z, int64_t N, DBox b,
-                                                         const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders)
+                                                         const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders,
+                                                         int *__restrict__ nbr)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
@@ -79,6 +81,8 @@ __global__ __launch_bounds__(PTM_BLOCK) void k_ptm_order(const double *__restric
     int8_t *o = orders + i * 18;
     for (int k = 0; k < 18; ++k)
         o[k] = k + 1 < env.num ? (int8_t)(env.corr[k + 1] - 1) : (int8_t)-1;
+    for (int k = 0; k < 18; ++k) // the same order as atom ids, lane-major: what the staged kernels (ptm_stages.hip) gather from
+        nbr[(int64_t)k * N + i] = k + 1 < env.num ? env.ids[k + 1] : -1;
 }
 
 template <bool TRI> struct DevSrc {
@@ -136,12 +140,23 @@ __global__ __launch_bounds__(PTM_BLOCK) void k_ptm_index(const double *__restric
         pi[k] = k < r.num_out && k < ptmc::MAX_PTS ? r.ids[k] : -1;
 }
 
-// device copy of the tables, one per device, created on first use
-static int device_tables(const Tables **out)
+// staged pipeline for the single-shell structure types (ptm_stages.hip)
+void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc);
+size_t ptm_stage_bytes(int64_t N);
+int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int *dtypes,
+                      const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol, int *dind,
+                      int nind, unsigned char *work, hipStream_t st);
+
+static Tables *g_host_tables = nullptr;
+const ptmc::Tables *ptm_host_tables() { return g_host_tables; }
+
+// device copy of the tables (+ the composed automorphism table), one per device, created on first use
+static int device_tables(const Tables **out, const int8_t **out_autc)
 {
     static std::mutex mu;
     static const Tables *dev[64] = {nullptr};
-    static Tables *host = nullptr;
+    static const int8_t *dev_autc[64] = {nullptr};
+    Tables *&host = g_host_tables;
     int d = 0;
     MDH_HIP(hipGetDevice(&d));
     std::lock_guard<std::mutex> lk(mu);
@@ -164,8 +179,14 @@ static int device_tables(const Tables **out)
         MDH_HIP(hipMalloc(&p, sizeof(Tables)));
         MDH_HIP(hipMemcpy(p, host, sizeof(Tables), hipMemcpyHostToDevice));
         dev[d] = static_cast<const Tables *>(p);
+        std::vector<int8_t> autc((size_t)ptmc::MAX_AUTS * ptmc::MAX_PTS);
+        ptm_compose_automorphisms(*host, autc.data());
+        MDH_HIP(hipMalloc(&p, autc.size()));
+        MDH_HIP(hipMemcpy(p, autc.data(), autc.size(), hipMemcpyHostToDevice));
+        dev_autc[d] = static_cast<const int8_t *>(p);
     }
     *out = dev[d];
+    *out_autc = dev_autc[d];
     return MDH_OK;
 }
 
@@ -223,7 +244,8 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     if (sc.failed())
         return sc.error();
     const Tables *dt = nullptr;
-    MDH_TRY(device_tables(&dt));
+    const int8_t *dautc = nullptr;
+    MDH_TRY(device_tables(&dt, &dautc));
     const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
     const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
     const int *dtp = types ? sc.stage_in(types, (size_t)N, space) : nullptr;
@@ -232,6 +254,9 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     if (sc.failed())
         return sc.error();
     int8_t *dord = sc.alloc_n<int8_t>((size_t)N * 18);
+    int *dnbr = sc.alloc_n<int>((size_t)N * 18);
+    const bool shell = (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) != 0;
+    unsigned char *work = shell ? nullptr : sc.alloc_n<unsigned char>(ptm_stage_bytes(N));
     if (sc.failed())
         return sc.error();
     const dim3 grid(grid_for(N, PTM_BLOCK)), block(PTM_BLOCK);
@@ -239,13 +264,14 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
         ProfRange pr("k_ptm_order", sc.stream());
         const size_t order_lds = sizeof(double) * PolyLds::CAP * 3 * PTM_BLOCK;
         if (b.tri)
-            hipLaunchKernelGGL(k_ptm_order<true>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
+            hipLaunchKernelGGL(k_ptm_order<true>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord, dnbr);
         else
-            hipLaunchKernelGGL(k_ptm_order<false>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord);
+            hipLaunchKernelGGL(k_ptm_order<false>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord, dnbr);
     }
-    {
+    if (!shell) {
+        MDH_TRY(launch_ptm_stages(dx, dy, dz, N, b, dnbr, dtp, dt, dautc, flags, rmsd_threshold, dout, ncol, dind, nind, work, sc.stream()));
+    } else {
         ProfRange pr("k_ptm_index", sc.stream());
-        const bool shell = (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) != 0;
 #define MDH_PTM_LAUNCH(TRI, SHELL)                                                                                              \
     hipLaunchKernelGGL((k_ptm_index<TRI, SHELL>), grid, block, PTM_INDEX_LDS, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dord, dt, flags,   \
                        rmsd_threshold, dout, ncol, dind, nind)

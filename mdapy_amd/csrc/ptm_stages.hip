@@ -1,0 +1,855 @@
+// ptm_stages.hip — polyhedral template matching as a pipeline of small kernels (gfx950).
+//
+// Same per-atom algorithm as ptm_core.hpp (which remains the host twin and the table generator; it cites the pieces of
+// extern/ptm it restates).  What changes is how the work sits on the machine.  The monolithic kernel kept ~3.7 KB of
+// dynamically indexed private arrays per lane (scratch memory: every access a trip to the L2) and, worse, let the 64
+// atoms of a wavefront walk different branches of nested data-dependent loops: the canonical form tried 60-72 start
+// edges one after the other although a lane needs 1-3 of them, the graph look-up serialised over the table's graphs.
+// Here the atom stays on ONE LANE (its work is a serial chain; a wavefront per atom would idle 60 lanes for most of it —
+// DESIGN.md 3c has the numbers), but
+//   * the work is cut into stages with a small working set each: hull -> canonical form -> template match.  A stage keeps
+//     its dynamically indexed state in a per-lane stripe of LDS (element e of lane l at [e * 64 + l]: bank = lane,
+//     conflict-free for any index pattern), everything else in registers: no scratch memory at all;
+//   * loops over data-dependent work lists are written with a per-lane cursor, so that all lanes of a wavefront run
+//     their t-th start edge / t-th automorphism together;
+//   * facet normals are not stored (672 B per lane); they are recomputed from the three vertices when a facet is tested.
+//     A cheap unnormalised test decides whenever the point is farther than 1e-9 from the plane; only closer calls
+//     (coplanar template faces of a perfect crystal) evaluate the reference's normalised expression, bit for bit.
+// Stages hand over through HBM in lane-major (structure-of-arrays) buffers: ~500 B per atom, read and written once.
+#include "common.hpp"
+#include "ptm_core.hpp"
+
+namespace mdh {
+namespace ptms {
+
+using ptmc::Tables;
+constexpr int BLK = 64;
+constexpr int NROW = 18;        // neighbours per atom handed over by the ordering pass
+constexpr int MAXF = ptmc::MAX_FACETS;
+
+enum { K_SC = 0, K_FCC = 1, K_BCC = 2, NKIND = 3 };
+__host__ __device__ constexpr int kind_points(int k) { return k == K_SC ? 7 : k == K_FCC ? 13 : 15; }
+
+template <bool TRI> __device__ __forceinline__ void fold(const DBox &b, double &dx, double &dy, double &dz) { pbc<TRI>(b, dx, dy, dz); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stage 1: convex hulls of the first 7 / 13 / 15 points (ptm_core.hpp convex_hull / hull_init / add_facet)
+// ---------------------------------------------------------------------------------------------------------------------
+// facet word: bits 0-14 the oriented triangle with its smallest index first (5 bits each), bits 15-16 how far the
+// oriented triple was rotated to get there, bit 17 whether the creation order (a,b,c) was swapped to (b,a,c).  The extra
+// bits let a later test rebuild the normal from the very operands the facet was created with.
+template <int NP> struct HullMem {
+    double *P;   // [NP][3]
+    uint32_t *F; // [MAXF]
+    uint32_t *E; // [NP-1]: edge marks of the current insertion, row = smaller endpoint, bit hi-1 seen in a visible facet, bit 16+hi-1 in a hidden one
+    uint16_t *A; // [MAXF]: horizon edges waiting to become facets
+    static constexpr size_t BYTES = (size_t)BLK * (NP * 3 * 8 + MAXF * 4 + (NP - 1) * 4 + MAXF * 2);
+    __device__ __forceinline__ void pt(int i, double *v) const
+    {
+        v[0] = P[(i * 3 + 0) * BLK];
+        v[1] = P[(i * 3 + 1) * BLK];
+        v[2] = P[(i * 3 + 2) * BLK];
+    }
+};
+
+struct HullState {
+    int num_facets, num_prev;
+    uint32_t processed;
+    bool ok;
+    double bary[3];
+};
+
+__device__ __forceinline__ void cross(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// sign class of  n . d  against `tol`, n = N/|N| (negated when neg): +1 above, 0 not above.  |N| <= |N0|+|N1|+|N2|, so
+// an unnormalised product beyond 1e-9 of that bound settles it; the rest goes through the reference's expression.
+__device__ __forceinline__ bool above_plane(const double *N, const double *d, bool neg, double tol)
+{
+    const double s0 = N[0] * d[0] + N[1] * d[1] + N[2] * d[2];
+    const double s = neg ? -s0 : s0;
+    const double S = 1e-9 * (fabs(N[0]) + fabs(N[1]) + fabs(N[2]));
+    if (s > S)
+        return true;
+    if (s < -S)
+        return false;
+    const double nr = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]); // plane_normal / plane_dist of ptm_core.hpp
+    double n[3] = {N[0] / nr, N[1] / nr, N[2] / nr};
+    if (neg) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    return n[0] * d[0] + n[1] * d[1] + n[2] * d[2] > tol;
+}
+
+template <int NP> __device__ __forceinline__ void raw_normal(const HullMem<NP> &m, int a, int b, int c, double *N, double *pa)
+{
+    double pb[3], pc[3];
+    m.pt(a, pa); m.pt(b, pb); m.pt(c, pc);
+    const double u[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double v[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+    cross(u, v, N);
+}
+
+// new facet through (a,b,c), oriented away from `inside`; 0xFFFFFFFF when it duplicates one of the first nf facets
+template <int NP> __device__ uint32_t make_facet(const HullMem<NP> &m, int a, int b, int c, const double *inside, int nf)
+{
+    double N[3], pa[3];
+    raw_normal(m, a, b, c, N, pa);
+    const double d[3] = {pa[0] - inside[0], pa[1] - inside[1], pa[2] - inside[2]};
+    const bool flip = above_plane(N, d, false, 0.0);
+    int o0 = flip ? b : a, o1 = flip ? a : b, o2 = c;
+    int r = 0;
+    if (o1 < o0 && o1 <= o2) r = 1;
+    if (o2 < o0 && o2 < o1) r = 2;
+    if (r == 1 && o2 < o1) r = 2; // (unreachable for distinct indices; keeps the smallest-first rule explicit)
+    const int c0 = r == 0 ? o0 : r == 1 ? o1 : o2, c1 = r == 0 ? o1 : r == 1 ? o2 : o0, c2 = r == 0 ? o2 : r == 1 ? o0 : o1;
+    const uint32_t w = (uint32_t)c0 | ((uint32_t)c1 << 5) | ((uint32_t)c2 << 10);
+    bool dup = false;
+    for (int j = 0; j < nf; ++j)
+        dup = dup || (m.F[j * BLK] & 0x7FFFu) == w;
+    return dup ? 0xFFFFFFFFu : (w | ((uint32_t)r << 15) | ((uint32_t)flip << 17));
+}
+
+// is point q (coordinates) strictly outside facet word w ?
+template <int NP> __device__ __forceinline__ bool facet_sees(const HullMem<NP> &m, uint32_t w, const double *q)
+{
+    const int c0 = w & 31, c1 = (w >> 5) & 31, c2 = (w >> 10) & 31, r = (w >> 15) & 3;
+    const bool flip = (w >> 17) & 1;
+    const int o0 = r == 0 ? c0 : r == 1 ? c2 : c1, o1 = r == 0 ? c1 : r == 1 ? c0 : c2, o2 = r == 0 ? c2 : r == 1 ? c1 : c0;
+    const int a = flip ? o1 : o0, b = flip ? o0 : o1;
+    double N[3], pa[3], pp[3];
+    raw_normal(m, a, b, o2, N, pa);
+    m.pt(c0, pp);
+    const double d[3] = {pp[0] - q[0], pp[1] - q[1], pp[2] - q[2]};
+    return above_plane(N, d, flip, ptmc::HULL_TOL);
+}
+
+template <int NP> __device__ int hull_start(const HullMem<NP> &m, int num, HullState &h)
+{
+    h.processed = 0;
+    int mn[3], mx[3];
+    for (int j = 0; j < 3; ++j) {
+        double dmin = 1.7976931348623157e308, dmax = -1.7976931348623157e308;
+        int imin = 0, imax = 0;
+        for (int i = 0; i < num; ++i) {
+            const double d = m.P[(i * 3 + j) * BLK];
+            if (d < dmin) { dmin = d; imin = i; }
+            if (d > dmax) { dmax = d; imax = i; }
+        }
+        if (imin == imax)
+            return -1;
+        mn[j] = imin; mx[j] = imax;
+    }
+    int a = 0, b = 0;
+    {
+        double best = 0.0;
+        bool any = false;
+        for (int j = 0; j < 3; ++j) {
+            double p0[3], p1[3];
+            m.pt(mn[j], p0); m.pt(mx[j], p1);
+            const double dl[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+            const double d = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
+            if (d > best) { best = d; a = mn[j]; b = mx[j]; any = true; }
+        }
+        if (!any)
+            return -1;
+    }
+    double pa[3], pb[3];
+    m.pt(a, pa); m.pt(b, pb);
+    int c = -1;
+    {
+        const double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        const double nab = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+        double md = 0.0;
+        for (int i = 0; i < num; ++i) {
+            if (i == a || i == b) continue;
+            double pi[3];
+            m.pt(i, pi);
+            const double w[3] = {pa[0] - pi[0], pa[1] - pi[1], pa[2] - pi[2]};
+            const double dt = w[0] * ab[0] + w[1] * ab[1] + w[2] * ab[2];
+            const double dist = ((w[0] * w[0] + w[1] * w[1] + w[2] * w[2]) * nab - dt * dt) / nab;
+            if (dist > md) { md = dist; c = i; }
+        }
+        if (!(md > ptmc::HULL_TOL))
+            return -2;
+    }
+    int d4 = -1;
+    {
+        double N[3], q[3];
+        raw_normal(m, a, b, c, N, q);
+        const double nr = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+        const double n[3] = {N[0] / nr, N[1] / nr, N[2] / nr};
+        double md = 0.0;
+        for (int i = 0; i < num; ++i) {
+            if (i == a || i == b || i == c) continue;
+            double pi[3];
+            m.pt(i, pi);
+            const double dist = fabs(n[0] * (pa[0] - pi[0]) + n[1] * (pa[1] - pi[1]) + n[2] * (pa[2] - pi[2]));
+            if (dist > md) { md = dist; d4 = i; }
+        }
+        if (!(md > ptmc::HULL_TOL))
+            return -3;
+    }
+    const int iv[4] = {a, b, c, d4};
+    h.bary[0] = h.bary[1] = h.bary[2] = 0;
+    for (int i = 0; i < 4; ++i) {
+        h.processed |= 1u << iv[i];
+        double p[3];
+        m.pt(iv[i], p);
+        h.bary[0] += p[0]; h.bary[1] += p[1]; h.bary[2] += p[2];
+    }
+    h.bary[0] /= 4; h.bary[1] /= 4; h.bary[2] /= 4;
+    m.F[0 * BLK] = make_facet(m, a, b, c, h.bary, 0);
+    m.F[1 * BLK] = make_facet(m, a, b, d4, h.bary, 0);
+    m.F[2 * BLK] = make_facet(m, a, c, d4, h.bary, 0);
+    m.F[3 * BLK] = make_facet(m, b, c, d4, h.bary, 0);
+    return 0;
+}
+
+// hull of points [0,num); continues the hull of fewer points when h.ok.  0 ok, 1 the centre is on the hull, <0 failure
+template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullState &h)
+{
+    int num_prev = h.num_prev;
+    h.num_prev = num;
+    if (!h.ok) {
+        const int r = hull_start(m, num, h);
+        if (r != 0)
+            return r;
+        h.num_facets = 4;
+        num_prev = 0;
+    }
+    for (int i = num_prev; i < num; ++i) {
+        if ((h.processed >> i) & 1u)
+            continue;
+        h.processed |= 1u << i;
+        double q[3];
+        m.pt(i, q);
+        for (int a = 0; a < NP - 1; ++a) m.E[a * BLK] = 0;
+        int nadd = 0;
+        for (int j = 0; j < h.num_facets; ++j) {
+            const uint32_t w = m.F[j * BLK];
+            const int a = w & 31, b = (w >> 5) & 31, c = (w >> 10) & 31;
+            const bool vis = facet_sees(m, w, q);
+            const uint32_t side = vis ? 0u : 16u;
+            // the three marks are independent LDS read-modify-writes (ds_or_rtn): issued back to back
+            const int lo0 = min(a, b), hi0 = max(a, b), lo1 = min(b, c), hi1 = max(b, c), lo2 = min(c, a), hi2 = max(c, a);
+            const uint32_t b0 = 1u << (side + hi0 - 1), b1 = 1u << (side + hi1 - 1), b2 = 1u << (side + hi2 - 1);
+            const uint32_t e0 = __hip_atomic_fetch_or(&m.E[lo0 * BLK], b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b0;
+            const uint32_t e1 = __hip_atomic_fetch_or(&m.E[lo1 * BLK], b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b1;
+            const uint32_t e2 = __hip_atomic_fetch_or(&m.E[lo2 * BLK], b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b2;
+            const bool u = ((e0 >> (hi0 - 1)) & (e0 >> (16 + hi0 - 1)) & 1u) != 0;
+            const bool v = ((e1 >> (hi1 - 1)) & (e1 >> (16 + hi1 - 1)) & 1u) != 0;
+            const bool x = ((e2 >> (hi2 - 1)) & (e2 >> (16 + hi2 - 1)) & 1u) != 0;
+            if (vis) { // drop the facet: the last one takes its slot and is looked at next
+                m.F[j * BLK] = m.F[(h.num_facets - 1) * BLK];
+                --h.num_facets;
+                --j;
+            }
+            if (u && nadd < MAXF) { m.A[nadd * BLK] = (uint16_t)(a | (b << 5)); ++nadd; }
+            if (v && nadd < MAXF) { m.A[nadd * BLK] = (uint16_t)(b | (c << 5)); ++nadd; }
+            if (x && nadd < MAXF) { m.A[nadd * BLK] = (uint16_t)(c | (a << 5)); ++nadd; }
+        }
+        for (int j = 0; j < nadd; ++j) {
+            if (h.num_facets >= MAXF)
+                return -4;
+            const int e = m.A[j * BLK];
+            const uint32_t w = make_facet(m, i, e & 31, (e >> 5) & 31, h.bary, h.num_facets);
+            if (w == 0xFFFFFFFFu)
+                return -5;
+            m.F[h.num_facets * BLK] = w;
+            ++h.num_facets;
+        }
+    }
+    bool centre = false;
+    for (int j = 0; j < h.num_facets; ++j) {
+        const uint32_t w = m.F[j * BLK];
+        centre = centre || (w & 31) == 0; // the smallest index comes first
+    }
+    return centre ? 1 : 0;
+}
+
+struct HullOut {
+    uint16_t *facets[NKIND]; // [MAXF][N], vertex indices - 1
+    int8_t *status[NKIND];   // [N]: number of facets of a usable hull, -1 otherwise
+};
+
+// gather the atom's ordered neighbourhood (centre first), subtract the barycentre of ALL points, scale by the mean
+// distance (ptm_core.hpp normalize_vertices); the first NP points go to m.P.  Returns the number of points.
+template <bool TRI, int NP>
+__device__ int load_normalized(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z, const DBox &b,
+                               const int *__restrict__ nbr, int64_t N, int64_t atom, const HullMem<NP> &m)
+{
+    const double xi = x[atom], yi = y[atom], zi = z[atom];
+    double sum[3] = {0, 0, 0};
+    double ex[NROW + 1 - NP][3]; // points beyond the hull's reach only count in the barycentre and the scale
+    int num = 1;
+    bool open = true;
+#pragma unroll
+    for (int k = 0; k < NROW; ++k) {
+        const int j = nbr[(int64_t)k * N + atom];
+        open = open && j >= 0;
+        double dx = 0, dy = 0, dz = 0;
+        if (open) {
+            dx = x[j] - xi; dy = y[j] - yi; dz = z[j] - zi;
+            fold<TRI>(b, dx, dy, dz);
+            sum[0] += dx; sum[1] += dy; sum[2] += dz;
+            ++num;
+        }
+        if (k + 1 < NP) {
+            m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
+        } else {
+            ex[k + 1 - NP][0] = dx; ex[k + 1 - NP][1] = dy; ex[k + 1 - NP][2] = dz;
+        }
+    }
+    const double s[3] = {sum[0] / num, sum[1] / num, sum[2] / num};
+    double scale = 0.0;
+    m.P[0 * BLK] = 0.0 - s[0]; m.P[1 * BLK] = 0.0 - s[1]; m.P[2 * BLK] = 0.0 - s[2];
+#pragma unroll
+    for (int i = 1; i <= NROW; ++i) {
+        double v[3];
+        if (i < NP) { m.pt(i, v); } else { v[0] = ex[i - NP][0]; v[1] = ex[i - NP][1]; v[2] = ex[i - NP][2]; }
+        v[0] -= s[0]; v[1] -= s[1]; v[2] -= s[2];
+        if (i < num)
+            scale += sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (i < NP) { m.P[(i * 3 + 0) * BLK] = v[0]; m.P[(i * 3 + 1) * BLK] = v[1]; m.P[(i * 3 + 2) * BLK] = v[2]; }
+    }
+    scale /= num;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        for (int c = 0; c < 3; ++c) m.P[(i * 3 + c) * BLK] = m.P[(i * 3 + c) * BLK] / scale;
+    return num;
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(BLK) void k_ptm_hull(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                  int64_t N, DBox b, const int *__restrict__ nbr, int flags, HullOut out)
+{
+    constexpr int NP = 15;
+    extern __shared__ unsigned char lds[];
+    const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (atom >= N)
+        return;
+    HullMem<NP> m;
+    m.P = reinterpret_cast<double *>(lds) + threadIdx.x;
+    m.F = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
+    m.E = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * 4)) + threadIdx.x;
+    m.A = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * 4 + (NP - 1) * 4)) + threadIdx.x;
+    const int num = load_normalized<TRI, NP>(x, y, z, b, nbr, N, atom, m);
+    HullState h;
+    h.ok = false; h.num_prev = 0; h.num_facets = 0; h.processed = 0;
+    h.bary[0] = h.bary[1] = h.bary[2] = 0;
+    for (int kind = 0; kind < NKIND; ++kind) {
+        const int np = kind_points(kind);
+        const int want = kind == K_SC ? ptmc::CHECK_SC : kind == K_FCC ? (ptmc::CHECK_FCC | ptmc::CHECK_HCP | ptmc::CHECK_ICO) : ptmc::CHECK_BCC;
+        if (!(flags & want))
+            continue;
+        int8_t st = -1;
+        if (num >= np) {
+            bool prev_ok = h.ok;
+            const bool retry = kind != K_FCC; // the reference repeats a failed continued hull from scratch for SC and BCC only
+            int ret = 0;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                ret = hull_grow(m, np, h);
+                h.ok = ret >= 0;
+                if (!(retry && prev_ok && !h.ok))
+                    break;
+                prev_ok = false;
+            }
+            if (ret == 0) {
+                st = (int8_t)h.num_facets;
+                for (int j = 0; j < h.num_facets; ++j) {
+                    const uint32_t w = m.F[j * BLK];
+                    out.facets[kind][(int64_t)j * N + atom] = (uint16_t)(((w & 31) - 1) | ((((w >> 5) & 31) - 1) << 5) | ((((w >> 10) & 31) - 1) << 10));
+                }
+            }
+        }
+        out.status[kind][atom] = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stage 2: Weinberg canonical form of the hull triangulation (ptm_core.hpp canonical_form / weinberg), one kind per launch
+// ---------------------------------------------------------------------------------------------------------------------
+struct CanonOut {
+    uint64_t *hash; // [N]
+    int8_t *label;  // [17][N]: canonical labelling, label[0] = 0
+    int8_t *ok;     // [N]
+};
+
+template <int NN> struct CanonMem {
+    static constexpr int NF = 2 * NN - 4, NE = 3 * NN - 6;
+    uint64_t *C; // [16]: row a, nibble b = third vertex of the facet left of a->b
+    uint16_t *M; // [16]: first the "edge defined" bits, then the walked bits of a traversal
+    uint16_t *F; // [NF]
+    int8_t *B;   // [2 NE]: best code
+    static constexpr size_t BYTES = (size_t)BLK * (16 * 8 + 16 * 2 + NF * 2 + 2 * NE);
+    __device__ __forceinline__ int cm(int a, int b) const { return (int)((C[a * BLK] >> (4 * b)) & 15u); }
+};
+
+template <int NN>
+__global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__restrict__ facets, const int8_t *__restrict__ status,
+                                                   int max_degree, int all_degree, CanonOut out)
+{
+    using Mem = CanonMem<NN>;
+    constexpr int NF = Mem::NF, NE = Mem::NE;
+    extern __shared__ unsigned char lds[];
+    const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (atom >= N)
+        return;
+    Mem m;
+    m.C = reinterpret_cast<uint64_t *>(lds) + threadIdx.x;
+    m.M = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * 128) + threadIdx.x;
+    m.F = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * 160) + threadIdx.x;
+    m.B = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (160 + NF * 2)) + threadIdx.x;
+    bool good = status[atom] == NF;
+    uint64_t deg = 0; // nibble v = degree of vertex v
+    if (good) {
+        for (int a = 0; a < 16; ++a) { m.C[a * BLK] = 0; m.M[a * BLK] = 0; }
+        for (int j = 0; j < NF; ++j) {
+            const int w = facets[(int64_t)j * N + atom];
+            m.F[j * BLK] = (uint16_t)w;
+            const int a = w & 31, b = (w >> 5) & 31, c = (w >> 10) & 31;
+            deg += (1ull << (4 * a)) + (1ull << (4 * b)) + (1ull << (4 * c));
+            // every directed edge may appear once (an oriented closed surface)
+            const uint16_t ma = m.M[a * BLK], mb = m.M[b * BLK], mc = m.M[c * BLK];
+            if (((ma >> b) | (mb >> c) | (mc >> a)) & 1)
+                good = false;
+            m.M[a * BLK] = (uint16_t)(ma | (1u << b));
+            m.M[b * BLK] = (uint16_t)(m.M[b * BLK] | (1u << c));
+            m.M[c * BLK] = (uint16_t)(m.M[c * BLK] | (1u << a));
+            m.C[a * BLK] |= (uint64_t)c << (4 * b);
+            m.C[b * BLK] |= (uint64_t)a << (4 * c);
+            m.C[c * BLK] |= (uint64_t)b << (4 * a);
+        }
+        int mx = 0;
+        bool equal = true, all_ok = true;
+        const int d0 = (int)(deg & 15u);
+        for (int v = 0; v < NN; ++v) {
+            const int d = (int)((deg >> (4 * v)) & 15u);
+            mx = d > mx ? d : mx;
+            equal = equal && d == d0;
+            all_ok = all_ok && (all_degree == 0 || d == all_degree);
+        }
+        good = good && mx <= max_degree && all_ok;
+        // start edges: rotation r of facet j at bit 3 j + r, in the order the reference tries them
+        uint64_t s_lo = 0;
+        uint32_t s_hi = 0;
+        if (good) {
+            if (equal) {
+                s_lo = 1;
+            } else {
+                uint32_t bestd = 0;
+                for (int j = 0; j < NF; ++j) {
+                    const int w = m.F[j * BLK];
+                    const uint32_t da = (uint32_t)((deg >> (4 * (w & 31))) & 15u), db = (uint32_t)((deg >> (4 * ((w >> 5) & 31))) & 15u),
+                                   dc = (uint32_t)((deg >> (4 * ((w >> 10) & 31))) & 15u);
+                    const uint32_t k0 = (da << 16) | (db << 8) | dc, k1 = da | (db << 16) | (dc << 8), k2 = (da << 8) | db | (dc << 16);
+                    bestd = max(bestd, max(k0, max(k1, k2)));
+                }
+                for (int j = 0; j < NF; ++j) {
+                    const int w = m.F[j * BLK];
+                    const uint32_t da = (uint32_t)((deg >> (4 * (w & 31))) & 15u), db = (uint32_t)((deg >> (4 * ((w >> 5) & 31))) & 15u),
+                                   dc = (uint32_t)((deg >> (4 * ((w >> 10) & 31))) & 15u);
+                    const uint32_t k0 = (da << 16) | (db << 8) | dc, k1 = da | (db << 16) | (dc << 8), k2 = (da << 8) | db | (dc << 16);
+                    uint32_t bits = (k0 == bestd ? 1u : 0u) | (k1 == bestd ? 2u : 0u) | (k2 == bestd ? 4u : 0u);
+                    const int pos = 3 * j;
+                    if (pos < 64) {
+                        s_lo |= (uint64_t)bits << pos;
+                        if (pos > 61) s_hi |= bits >> (64 - pos);
+                    } else {
+                        s_hi |= bits << (pos - 64);
+                    }
+                }
+            }
+            for (int i = 0; i < 2 * NE; ++i) m.B[i * BLK] = 127;
+        }
+        uint64_t best_label = 0;
+        // all lanes walk their t-th start edge together
+        while (true) {
+            const bool has = good && (s_lo != 0 || s_hi != 0);
+            if (__ballot(has) == 0)
+                break;
+            if (!has)
+                continue;
+            int pos;
+            if (s_lo) { pos = __builtin_ctzll(s_lo); s_lo &= s_lo - 1; }
+            else { pos = 64 + __builtin_ctz(s_hi); s_hi &= s_hi - 1; }
+            const int j = pos / 3, r = pos - 3 * j;
+            const int w = m.F[j * BLK];
+            const int v0 = w & 31, v1 = (w >> 5) & 31, v2 = (w >> 10) & 31;
+            int a = r == 0 ? v0 : r == 1 ? v1 : v2, bq = r == 0 ? v1 : r == 1 ? v2 : v0;
+            // one traversal (colours are all 0 for these kinds: a vertex's code is its visiting number)
+            for (int v = 0; v < 16; ++v) m.M[v * BLK] = 0;
+            uint64_t index = 0;   // nibble v = visiting number
+            uint32_t seen = 1u << a;
+            int n = 1;            // index[a] = 0
+            bool winning = false, alive = true;
+            {
+                const int cur = m.B[0];
+                if (0 > cur) alive = false; // (cannot happen: codes are >= 0)
+                if (0 < cur) { m.B[0] = 0; winning = true; }
+            }
+            for (int it = 1; it < 2 * NE && alive; ++it) {
+                const bool newv = !((seen >> bq) & 1u);
+                if (newv) {
+                    index |= (uint64_t)n << (4 * bq);
+                    seen |= 1u << bq;
+                    ++n;
+                }
+                const int val = (int)((index >> (4 * bq)) & 15u);
+                const int cur = m.B[it * BLK];
+                const uint16_t mb = m.M[bq * BLK];
+                int c = m.cm(a, bq);
+                if (!winning && val > cur) { alive = false; break; }
+                if (winning || val < cur) { winning = true; m.B[it * BLK] = (int8_t)val; }
+                if (!newv) {
+                    if (!((mb >> a) & 1u)) {
+                        c = a; // old vertex reached on a new path: go back
+                    } else {
+                        while ((mb >> c) & 1u) c = m.cm(c, bq); // right-most edge not yet walked in that direction
+                    }
+                }
+                m.M[a * BLK] = (uint16_t)(m.M[a * BLK] | (1u << bq));
+                a = bq;
+                bq = c;
+            }
+            if (alive && winning)
+                best_label = index;
+        }
+        if (good) {
+            uint64_t hsh = 0;
+            for (int i = 0; i < 2 * NE; ++i) {
+                uint64_t e = (uint64_t)(int64_t)m.B[i * BLK];
+                e += i % 8;
+                e &= 0xF;
+                e <<= (4 * i) % 64;
+                hsh ^= e;
+            }
+            out.hash[atom] = hsh;
+            out.label[atom] = 0;
+            for (int v = 0; v < NN; ++v)
+                out.label[(int64_t)(v + 1) * N + atom] = (int8_t)(((best_label >> (4 * v)) & 15u) + 1);
+        }
+    }
+    out.ok[atom] = good ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stage 3: template look-up, QCP superposition per automorphism, alloy ordering, fundamental-zone remap, outputs
+// ---------------------------------------------------------------------------------------------------------------------
+struct MatchIn {
+    const uint64_t *hash[NKIND];
+    const int8_t *label[NKIND];
+    const int8_t *ok[NKIND];
+};
+
+struct MatchMem {
+    static constexpr int NP = 15;
+    double *P;  // [NP][3] raw separations (centre first, Voronoi order)
+    int *I;     // [17] atom ids in the same order, later the matched ids in template order
+    int8_t *V;  // [20] inverse canonical labelling of the kind at hand
+    static constexpr size_t BYTES = (size_t)BLK * (NP * 24 + 17 * 4 + 20);
+};
+
+// rmsd of template `s` onto the points  P[map(i)] - bary  (ptm_core.hpp calc_rmsd); map(i) = V[autc[i]]
+__device__ double stage_rmsd(const MatchMem &m, const ptmc::TypeInfo &s, int np, const int8_t *__restrict__ autc, const double *bary,
+                             double G1, double G2, double E0, double *q, double *p_scale)
+{
+    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < np; ++i) {
+        const int k = m.V[autc[i] * BLK];
+        const double x1 = s.points[i][0], y1 = s.points[i][1], z1 = s.points[i][2];
+        const double x2 = m.P[(k * 3 + 0) * BLK] - bary[0], y2 = m.P[(k * 3 + 1) * BLK] - bary[1], z2 = m.P[(k * 3 + 2) * BLK] - bary[2];
+        A[0] += x1 * x2; A[1] += x1 * y2; A[2] += x1 * z2;
+        A[3] += y1 * x2; A[4] += y1 * y2; A[5] += y1 * z2;
+        A[6] += z1 * x2; A[7] += z1 * y2; A[8] += z1 * z2;
+    }
+    double nrmsdsq, rot[9];
+    ptmc::qcp_quaternion(A, E0, &nrmsdsq, q);
+    ptmc::quat_to_matrix(q, rot);
+    double k0 = 0;
+    for (int i = 0; i < np; ++i) {
+        const int k = m.V[autc[i] * BLK];
+        const double p[3] = {m.P[(k * 3 + 0) * BLK] - bary[0], m.P[(k * 3 + 1) * BLK] - bary[1], m.P[(k * 3 + 2) * BLK] - bary[2]};
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            for (int c = 0; c < 3; ++c) v += rot[j * 3 + c] * s.points[i][c];
+            k0 += v * p[j];
+        }
+    }
+    const double scale = k0 / G2;
+    *p_scale = scale;
+    return sqrt(fabs(G1 - scale * k0) / np);
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                   int64_t N, DBox b, const int *__restrict__ nbr, const int *__restrict__ types,
+                                                   const Tables *__restrict__ tables, const int8_t *__restrict__ autc, int flags,
+                                                   MatchIn in, double rmsd_threshold, double *__restrict__ output, int ncol,
+                                                   int *__restrict__ ptm_indices, int nind)
+{
+    constexpr int NP = MatchMem::NP;
+    extern __shared__ unsigned char lds[];
+    const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (atom >= N)
+        return;
+    MatchMem m;
+    m.P = reinterpret_cast<double *>(lds) + threadIdx.x;
+    m.I = reinterpret_cast<int *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
+    m.V = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (NP * 24 + 17 * 4)) + threadIdx.x;
+    const Tables &T = *tables;
+    // the neighbourhood: separations folded exactly as the ordering pass folded them
+    {
+        const double xi = x[atom], yi = y[atom], zi = z[atom];
+        m.P[0 * BLK] = 0; m.P[1 * BLK] = 0; m.P[2 * BLK] = 0;
+        m.I[0 * BLK] = (int)atom;
+        bool open = true;
+#pragma unroll
+        for (int k = 0; k < NP - 1; ++k) {
+            const int j = nbr[(int64_t)k * N + atom];
+            open = open && j >= 0;
+            double dx = 0, dy = 0, dz = 0;
+            if (open) {
+                dx = x[j] - xi; dy = y[j] - yi; dz = z[j] - zi;
+                fold<TRI>(b, dx, dy, dz);
+            }
+            m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
+            m.I[(k + 1) * BLK] = open ? j : -1;
+        }
+    }
+    // best match so far
+    int best_type = ptmc::T_NONE, best_aut = -1, best_kind = -1;
+    double best_rmsd = INFINITY, best_scale = 0, best_q[4] = {0, 0, 0, 0};
+    for (int kind = 0; kind < NKIND; ++kind) {
+        const int np = kind_points(kind);
+        const bool live = in.ok[kind] != nullptr && in.ok[kind][atom] != 0;
+        if (__ballot(live) == 0)
+            continue;
+        double bary[3] = {0, 0, 0}, G2 = 0;
+        uint64_t hash = 0;
+        if (live) {
+            hash = in.hash[kind][atom];
+            for (int i = 0; i < np; ++i) m.V[in.label[kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+            for (int i = 0; i < np; ++i) { bary[0] += m.P[(i * 3 + 0) * BLK]; bary[1] += m.P[(i * 3 + 1) * BLK]; bary[2] += m.P[(i * 3 + 2) * BLK]; }
+            bary[0] /= np; bary[1] /= np; bary[2] /= np;
+            for (int i = 0; i < np; ++i) {
+                const double v[3] = {m.P[(i * 3 + 0) * BLK] - bary[0], m.P[(i * 3 + 1) * BLK] - bary[1], m.P[(i * 3 + 2) * BLK] - bary[2]};
+                G2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            }
+        }
+        const int ntypes = kind == K_FCC ? 3 : 1;
+        for (int tk = 0; tk < ntypes; ++tk) {
+            const int type = kind == K_SC ? ptmc::T_SC : kind == K_BCC ? ptmc::T_BCC : tk == 0 ? ptmc::T_FCC : tk == 1 ? ptmc::T_HCP : ptmc::T_ICO;
+            const int bit = type == ptmc::T_SC ? ptmc::CHECK_SC : type == ptmc::T_BCC ? ptmc::CHECK_BCC : type == ptmc::T_FCC ? ptmc::CHECK_FCC
+                          : type == ptmc::T_HCP ? ptmc::CHECK_HCP : ptmc::CHECK_ICO;
+            if (!(flags & bit))
+                continue;
+            const ptmc::TypeInfo &s = T.types[type];
+            double G1 = 0;
+            for (int i = 0; i < np; ++i) G1 += s.points[i][0] * s.points[i][0] + s.points[i][1] * s.points[i][1] + s.points[i][2] * s.points[i][2];
+            const double E0 = (G1 + G2) / 2;
+            // cursor over (graph with the atom's hash, automorphism): every lane evaluates its t-th candidate together
+            int g = s.graph_begin, j = 0;
+            const int g_end = s.graph_begin + s.num_graphs;
+            while (true) {
+                bool has = false;
+                if (live) {
+                    while (g < g_end && (T.graphs[g].hash != hash || j >= T.graphs[g].num_aut)) { ++g; j = 0; }
+                    has = g < g_end;
+                }
+                if (__ballot(has) == 0)
+                    break;
+                if (has) {
+                    const int aut = T.graphs[g].aut_begin + j;
+                    double q[4], scale = 0;
+                    const double rmsd = stage_rmsd(m, s, np, autc + (size_t)aut * ptmc::MAX_PTS, bary, G1, G2, E0, q, &scale);
+                    if (rmsd < best_rmsd) {
+                        best_rmsd = rmsd; best_scale = scale; best_type = type; best_aut = aut; best_kind = kind;
+                        best_q[0] = q[0]; best_q[1] = q[1]; best_q[2] = q[2]; best_q[3] = q[3];
+                    }
+                    ++j;
+                }
+            }
+        }
+    }
+    // ---- outputs (ptm_core.hpp index_atom, second half)
+    int type = 0, ordering = 0, num_out = 0;
+    double o_rmsd = 0, o_inter = 0, o_q[4] = {0, 0, 0, 0};
+    if (best_type != ptmc::T_NONE) {
+        const ptmc::TypeInfo &s = T.types[best_type];
+        const int np = s.num_nbrs + 1;
+        const int8_t *ac = autc + (size_t)best_aut * ptmc::MAX_PTS;
+        for (int i = 0; i < np; ++i) m.V[in.label[best_kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+        // alloy ordering (ptm_core.hpp alloy_type); without a type column every atom is the same species
+        ordering = ptmc::ALLOY_PURE;
+        if (types) {
+            const int n0 = types[m.I[0]];
+            bool pure = true, none = n0 == -1, binary = true;
+            int other = -1;
+            for (int i = 1; i < np; ++i) {
+                const int ni = types[m.I[i * BLK]];
+                none = none || ni == -1;
+                if (ni != n0) {
+                    pure = false;
+                    if (other == -1) other = ni;
+                    else if (ni != other) binary = false;
+                }
+            }
+            if (none) ordering = ptmc::ALLOY_NONE;
+            else if (pure) ordering = ptmc::ALLOY_PURE;
+            else if (!binary) ordering = ptmc::ALLOY_NONE;
+            else {
+                uint32_t bin = 0; // bit i: template point i holds the other species
+                for (int i = 0; i < np; ++i)
+                    if (types[m.I[m.V[ac[i] * BLK] * BLK]] != n0) bin |= 1u << i;
+                uint32_t best = 0xFFFFFFFFu;
+                for (int r = 0; r < s.num_maps; ++r) {
+                    const int8_t *mp = T.maps[s.map_begin + r];
+                    uint32_t code = 0;
+                    for (int i = 0; i < np; ++i) code |= ((bin >> i) & 1u) << mp[i];
+                    best = code < best ? code : best;
+                }
+                ordering = ptmc::ALLOY_NONE;
+                if (best_type == ptmc::T_FCC) {
+                    if (best == 0x00000db6u) ordering = ptmc::ALLOY_L10;
+                    if (best == 0x00000492u) ordering = ptmc::ALLOY_L12_CU;
+                    if (best == 0x00001ffeu) ordering = ptmc::ALLOY_L12_AU;
+                }
+                if (ordering == ptmc::ALLOY_NONE && best_type == ptmc::T_BCC) {
+                    bool shell = true;
+                    for (int i = 1; i < 9; ++i) shell = shell && ((bin >> i) & 1u) != (bin & 1u);
+                    for (int i = 9; i < np; ++i) shell = shell && ((bin >> i) & 1u) == (bin & 1u);
+                    if (shell) ordering = ptmc::ALLOY_B2;
+                }
+            }
+        }
+        // fundamental-zone remap (ptm_core.hpp remap_template)
+        double mx = 0.0;
+        int bi = -1;
+        for (int i = 0; i < s.num_conv; ++i) {
+            const double *gq = T.gens[s.gen_begin + i];
+            const double t = fabs(best_q[0] * gq[0] - best_q[1] * gq[1] - best_q[2] * gq[2] - best_q[3] * gq[3]);
+            if (t > mx) { mx = t; bi = i; }
+        }
+        // matched atoms in template order: ids[perm[i]] = I[map(i)]
+        int ids_local[ptmc::MAX_PTS];
+#pragma unroll
+        for (int i = 0; i < ptmc::MAX_PTS; ++i) ids_local[i] = i < np ? m.I[m.V[ac[i] * BLK] * BLK] : -1;
+        if (bi >= 0) {
+            double f[4];
+            ptmc::quat_mul(best_q, T.gens[s.gen_begin + bi], f);
+            if (f[0] < 0) { f[0] = -f[0]; f[1] = -f[1]; f[2] = -f[2]; f[3] = -f[3]; }
+            best_q[0] = f[0]; best_q[1] = f[1]; best_q[2] = f[2]; best_q[3] = f[3];
+            const int8_t *perm = T.maps[s.conv_begin + bi];
+#pragma unroll
+            for (int i = 0; i < ptmc::MAX_PTS; ++i)
+                if (i < np) m.I[perm[i] * BLK] = ids_local[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ptmc::MAX_PTS; ++i)
+                if (i < np) m.I[i * BLK] = ids_local[i];
+        }
+        type = best_type;
+        o_rmsd = best_rmsd;
+        o_inter = ptmc::interatomic_distance(best_type, best_scale);
+        o_q[0] = best_q[0]; o_q[1] = best_q[1]; o_q[2] = best_q[2]; o_q[3] = best_q[3];
+        num_out = np;
+    }
+    if (o_rmsd > rmsd_threshold || type == ptmc::T_NONE) { // src/polyhedral_template_matching.cpp:287-291
+        type = 0;
+        ordering = 0;
+    }
+    double *o = output + atom * ncol;
+    const double vals[8] = {(double)type, (double)ordering, o_rmsd, o_inter, o_q[0], o_q[1], o_q[2], o_q[3]};
+    for (int k = 0; k < ncol; ++k)
+        o[k] = k < 8 ? vals[k] : 0.0;
+    int *pi = ptm_indices + atom * nind;
+    for (int k = 0; k < nind; ++k)
+        pi[k] = k < num_out ? m.I[k * BLK] : -1;
+}
+
+} // namespace ptms
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+// autc[aut][i] = canon_of_its_graph[aut^-1[i]]: with it, template point i maps to V[autc[i]] (V = inverse of the atom's
+// canonical labelling) — ptm_core.hpp check_graphs builds the same mapping by scattering through `aut`.
+void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
+{
+    for (int a = 0; a < ptmc::MAX_AUTS * ptmc::MAX_PTS; ++a) autc[a] = 0;
+    for (int g = 0; g < T.num_graphs; ++g) {
+        const ptmc::Graph &gr = T.graphs[g];
+        int np = 0;
+        for (int t = 1; t < 9; ++t)
+            if (g >= T.types[t].graph_begin && g < T.types[t].graph_begin + T.types[t].num_graphs) np = T.types[t].num_nbrs + 1;
+        for (int j = 0; j < gr.num_aut; ++j) {
+            const int8_t *aut = T.auts[gr.aut_begin + j];
+            int8_t *dst = autc + (size_t)(gr.aut_begin + j) * ptmc::MAX_PTS;
+            for (int k = 0; k < np; ++k) dst[aut[k]] = gr.canon[k];
+        }
+    }
+}
+
+size_t ptm_stage_bytes(int64_t N)
+{
+    const size_t n = (size_t)((N + 255) & ~int64_t(255));
+    return (size_t)ptms::NKIND * n * (ptms::MAXF * 2 + 1 + 8 + 17 + 1) + 4096;
+}
+
+int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int *dtypes,
+                      const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol, int *dind,
+                      int nind, unsigned char *work, hipStream_t st)
+{
+    using namespace ptms;
+    const size_t n = (size_t)((N + 255) & ~int64_t(255));
+    HullOut ho;
+    CanonOut co[NKIND];
+    MatchIn mi;
+    unsigned char *p = work;
+    for (int k = 0; k < NKIND; ++k) { co[k].hash = reinterpret_cast<uint64_t *>(p); p += n * 8; }
+    for (int k = 0; k < NKIND; ++k) { ho.facets[k] = reinterpret_cast<uint16_t *>(p); p += n * MAXF * 2; }
+    for (int k = 0; k < NKIND; ++k) { ho.status[k] = reinterpret_cast<int8_t *>(p); p += n; }
+    for (int k = 0; k < NKIND; ++k) { co[k].label = reinterpret_cast<int8_t *>(p); p += n * 17; }
+    for (int k = 0; k < NKIND; ++k) { co[k].ok = reinterpret_cast<int8_t *>(p); p += n; }
+    const int want[NKIND] = {ptmc::CHECK_SC, ptmc::CHECK_FCC | ptmc::CHECK_HCP | ptmc::CHECK_ICO, ptmc::CHECK_BCC};
+    const dim3 grid((unsigned)((N + BLK - 1) / BLK)), block(BLK);
+    {
+        ProfRange pr("k_ptm_hull", st);
+        if (b.tri)
+            hipLaunchKernelGGL(k_ptm_hull<true>, grid, block, HullMem<15>::BYTES, st, dx, dy, dz, N, b, nbr, flags, ho);
+        else
+            hipLaunchKernelGGL(k_ptm_hull<false>, grid, block, HullMem<15>::BYTES, st, dx, dy, dz, N, b, nbr, flags, ho);
+    }
+    {
+        ProfRange pr("k_ptm_canon", st);
+        // (max_degree, required degree) per kind from the generated tables: host copies are needed, the caller passes them in dt's twin
+        extern const ptmc::Tables *ptm_host_tables();
+        const ptmc::Tables &H = *ptm_host_tables();
+        if (flags & want[K_SC])
+            hipLaunchKernelGGL(k_ptm_canon<6>, grid, block, CanonMem<6>::BYTES, st, N, ho.facets[K_SC], ho.status[K_SC], H.types[ptmc::T_SC].max_degree, 4, co[K_SC]);
+        if (flags & want[K_FCC])
+            hipLaunchKernelGGL(k_ptm_canon<12>, grid, block, CanonMem<12>::BYTES, st, N, ho.facets[K_FCC], ho.status[K_FCC], H.types[ptmc::T_FCC].max_degree, 0, co[K_FCC]);
+        if (flags & want[K_BCC])
+            hipLaunchKernelGGL(k_ptm_canon<14>, grid, block, CanonMem<14>::BYTES, st, N, ho.facets[K_BCC], ho.status[K_BCC], H.types[ptmc::T_BCC].max_degree, 0, co[K_BCC]);
+    }
+    for (int k = 0; k < NKIND; ++k) {
+        const bool on = (flags & want[k]) != 0;
+        mi.hash[k] = on ? co[k].hash : nullptr;
+        mi.label[k] = on ? co[k].label : nullptr;
+        mi.ok[k] = on ? co[k].ok : nullptr;
+    }
+    {
+        ProfRange pr("k_ptm_match", st);
+        if (b.tri)
+            hipLaunchKernelGGL(k_ptm_match<true>, grid, block, MatchMem::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dautc, flags, mi, rmsd_threshold, dout, ncol, dind, nind);
+        else
+            hipLaunchKernelGGL(k_ptm_match<false>, grid, block, MatchMem::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dautc, flags, mi, rmsd_threshold, dout, ncol, dind, nind);
+    }
+    return MDH_OK;
+}
+
+} // namespace mdh
