@@ -70,9 +70,35 @@ int mdh_debug_set_neighbor_variant(int variant);
  * plan8 = {tile cells in x/y, in z, halo atoms per tile, LDS bytes, box full of atoms, 1000 * atoms per cell,
  * cells of the occupied region, 1 if a plan was made since the last query}. */
 int mdh_debug_neighbor_plan(int *plan8);
+/* test hook: vertex capacity of the first pass of the PTM neighbour ordering (15 default; 5 sends most atoms through the
+ * second, 28-vertex pass, whose results must be the same) */
+int mdh_debug_set_ptm_order_cap(int cap);
 /* test hook: out4[k] = smallest double d with floor(d/L + 0.5) >= k-1 (k = 0..3) for a periodic orthogonal
  * axis of length L — the exact decision points that let the kernels replace floor(d/L+0.5) by compares. */
 int mdh_debug_image_thresholds(double L, double *out4);
+
+/* ---- input side: the atom table of a text file ---------------------------- */
+/*
+ * replaces the per-atom block parsing of BuildSystem.read_dump / read_xyz:
+ *   src/mdapy/load_save.py:141-175 (dump rows -> typed columns), :825-845 (extended-XYZ rows)
+ * `text` = nbytes of rows separated by '\n' (fields separated by blanks / tabs; '\r' ignored), in host memory or in
+ * HBM (text_space); the first nrows rows are parsed, extra fields of a row are ignored as the reference's
+ * row.split()[:ncol] does.  kinds[c]: 0 float64, 1 int32, 2 up to 8 characters packed little-endian into an int64
+ * (element / typelabel columns), 3 skip.  columns[c] = array of nrows elements of that type (ignored for kind 3).
+ * Floating-point fields are converted with correct rounding (== Python float(), what the reference's readers
+ * produce).  Fields the device cannot decide — more than 19 significant digits whose truncation straddles a rounding
+ * boundary, nan / inf, integers written as 3.0, strings longer than 8 bytes — are reported in redo (2 * redo_cap
+ * int64): redo[2k] = row * ncol + column, redo[2k+1] = (byte offset of the field << 16) | its length, for
+ * k < min(status4[0], redo_cap); the caller converts those on the host.
+ * status4: [0] fields to redo, [1] rows missing or with fewer than ncol fields, [2] fields that are no numbers,
+ * [3] rows present in the text.
+ */
+int mdh_parse_table(const char *text, int64_t nbytes, int text_space, int64_t nrows, int ncol, const int *kinds,
+                    void *const *columns, int64_t *redo, int64_t redo_cap, int64_t *status4, int space, void *stream);
+/* test hooks (run on the host, no GPU needed): entry q (-342..308) of the generated 128-bit table of powers of five
+ * (high, low word); the field converter itself: 0 converted, 1 undecided (host must redo), 2 not a number */
+int mdh_debug_text_pow5(int q, uint64_t *out2);
+int mdh_debug_parse_double(const char *s, int64_t len, double *out);
 
 /* ---- _neighbor -------------------------------------------------------- */
 /*

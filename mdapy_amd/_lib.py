@@ -37,7 +37,11 @@ _SIGNATURES = {
     "mdh_prof_report": [vp, cint],
     "mdh_debug_set_neighbor_variant": [cint],
     "mdh_debug_neighbor_plan": [vp],
+    "mdh_debug_set_ptm_order_cap": [cint],
     "mdh_debug_image_thresholds": [dbl, vp],
+    "mdh_parse_table": [vp, i64, cint, i64, cint, vp, vp, vp, i64, vp, cint, vp],
+    "mdh_debug_text_pow5": [cint, vp],
+    "mdh_debug_parse_double": [C.c_char_p, i64, vp],
     "mdh_build_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, cint, vp],
     "mdh_slab_halo_select": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, cint, vp],
     "mdh_build_neighbor_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, cint, vp],

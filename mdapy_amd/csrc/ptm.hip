@@ -22,15 +22,6 @@ using ptmc::Tables;
 
 static constexpr int PTM_BLOCK = 64;
 
-// polygon of the neighbour-ordering pass in LDS: vertex i, coordinate c of lane l at [(i*3 + c) * PTM_BLOCK + l]
-// (bank = lane: conflict-free whatever the lanes' vertex indices)
-struct PolyLds {
-    static constexpr int CAP = 16;
-    double *base;
-    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 3 + c) * PTM_BLOCK]; }
-    __device__ __forceinline__ void set(int i, int c, double x) { base[(i * 3 + c) * PTM_BLOCK] = x; }
-};
-
 // working set of the canonical form in LDS (ptm_core.hpp: Canon is the private-array twin): per lane 256 + 84 + 16 bytes
 // and 16 half-words, element e of lane l at [e * PTM_BLOCK + l]
 struct CanonLds {
@@ -59,31 +50,6 @@ template <bool TRI> struct DevFold {
     const DBox &b;
     __device__ __forceinline__ void operator()(double &dx, double &dy, double &dz) const { pbc<TRI>(b, dx, dy, dz); }
 };
-
-// pass 1 (src/polyhedral_template_matching.cpp:215-255): the Voronoi order of every atom's row, 18 bytes per atom
-template <bool TRI>
-__global__ __launch_bounds__(PTM_BLOCK) void k_ptm_order(const double *__restrict__ x, const double *__restrict__ y,
-                                                         const double *__restrict__ z, int64_t N, DBox b,
-                                                         const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders,
-                                                         int *__restrict__ nbr)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    const DevFold<TRI> fold{b};
-    ptmc::Env env;
-    extern __shared__ double poly_lds[]; // [PolyLds::CAP][3][PTM_BLOCK]: the lane's polygon is a stripe of stride PTM_BLOCK
-    PolyLds fast{poly_lds + threadIdx.x};
-    if (!ptmc::build_env(x, y, z, N, verlet + i * M, (int)M, nullptr, (int)i, fold, nullptr, env, fast)) {
-        ptmc::PolyLocal slow; // a face with more than 16 vertices: private (scratch) storage holds 28
-        ptmc::build_env(x, y, z, N, verlet + i * M, (int)M, nullptr, (int)i, fold, nullptr, env, slow);
-    }
-    int8_t *o = orders + i * 18;
-    for (int k = 0; k < 18; ++k)
-        o[k] = k + 1 < env.num ? (int8_t)(env.corr[k + 1] - 1) : (int8_t)-1;
-    for (int k = 0; k < 18; ++k) // the same order as atom ids, lane-major: what the staged kernels (ptm_stages.hip) gather from
-        nbr[(int64_t)k * N + i] = k + 1 < env.num ? env.ids[k + 1] : -1;
-}
 
 template <bool TRI> struct DevSrc {
     const double *x, *y, *z;
@@ -143,6 +109,8 @@ __global__ __launch_bounds__(PTM_BLOCK) void k_ptm_index(const double *__restric
 // staged pipeline for the single-shell structure types (ptm_stages.hip)
 void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc);
 size_t ptm_stage_bytes(int64_t N);
+int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
+                     int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st);
 int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int *dtypes,
                       const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol, int *dind,
                       int nind, unsigned char *work, hipStream_t st);
@@ -220,6 +188,13 @@ static int parse_structures(const char *s)
 
 using namespace mdh;
 
+namespace mdh { void ptm_debug_order_cap(int cap); }
+extern "C" int mdh_debug_set_ptm_order_cap(int cap)
+{
+    mdh::ptm_debug_order_cap(cap);
+    return MDH_OK;
+}
+
 extern "C" int mdh_ptm_flags(const char *structure) { return parse_structures(structure); }
 
 extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, const double *z, int64_t N,
@@ -255,19 +230,14 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
         return sc.error();
     int8_t *dord = sc.alloc_n<int8_t>((size_t)N * 18);
     int *dnbr = sc.alloc_n<int>((size_t)N * 18);
+    unsigned char *dredo = sc.alloc_n<unsigned char>((size_t)N);
+    int *dcount = sc.alloc_n<int>(1);
     const bool shell = (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) != 0;
     unsigned char *work = shell ? nullptr : sc.alloc_n<unsigned char>(ptm_stage_bytes(N));
     if (sc.failed())
         return sc.error();
     const dim3 grid(grid_for(N, PTM_BLOCK)), block(PTM_BLOCK);
-    {
-        ProfRange pr("k_ptm_order", sc.stream());
-        const size_t order_lds = sizeof(double) * PolyLds::CAP * 3 * PTM_BLOCK;
-        if (b.tri)
-            hipLaunchKernelGGL(k_ptm_order<true>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord, dnbr);
-        else
-            hipLaunchKernelGGL(k_ptm_order<false>, grid, block, order_lds, sc.stream(), dx, dy, dz, N, b, dv, M, dord, dnbr);
-    }
+    MDH_TRY(launch_ptm_order(dx, dy, dz, N, b, dv, M, dord, dnbr, dredo, dcount, sc.stream()));
     if (!shell) {
         MDH_TRY(launch_ptm_stages(dx, dy, dz, N, b, dnbr, dtp, dt, dautc, flags, rmsd_threshold, dout, ncol, dind, nind, work, sc.stream()));
     } else {

@@ -33,6 +33,124 @@ __host__ __device__ constexpr int kind_points(int k) { return k == K_SC ? 7 : k 
 template <bool TRI> __device__ __forceinline__ void fold(const DBox &b, double &dx, double &dy, double &dz) { pbc<TRI>(b, dx, dy, dz); }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// stage 0: order every atom's row by Voronoi-face solid angle (src/polyhedral_template_matching.cpp:215-255, ptm_core.hpp
+// order_neighbours) — ONE FACE PER LANE.  The 18 faces of a cell are independent until the final sort, so a lane clips one
+// face's polygon (its own LDS stripe) against the cell's other bisector planes (read from the atom's shared LDS copy of the
+// row); the sort is a rank count over the 18 areas.  7 atoms (126 lanes) per 128-thread workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ORD_THREADS = 128, ORD_APB = ORD_THREADS / NROW; // 7 atoms per workgroup
+
+template <int CAP_> struct PolyStripe {
+    static constexpr int CAP = CAP_;
+    double *base;
+    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 3 + c) * ORD_THREADS]; }
+    __device__ __forceinline__ void set(int i, int c, double v) { base[(i * 3 + c) * ORD_THREADS] = v; }
+};
+
+struct OrderShared { // per workgroup
+    double pts[ORD_APB][NROW][3];
+    double nsq[ORD_APB][NROW];
+    double area[ORD_APB][NROW];
+    int ids[ORD_APB][NROW];
+    int raw[ORD_APB][NROW];
+    int cnt[ORD_APB];
+    int overflow[ORD_APB];
+};
+template <int CAP> constexpr size_t order_lds_bytes() { return sizeof(OrderShared) + (size_t)ORD_THREADS * CAP * 24; }
+
+// REDO = second pass over the atoms whose polygons outgrew the first pass's storage (flag set), with room for 28 vertices
+template <bool TRI, int CAP, bool REDO>
+__global__ __launch_bounds__(ORD_THREADS) void k_ptm_order_faces(const double *__restrict__ x, const double *__restrict__ y,
+                                                                 const double *__restrict__ z, int64_t N, DBox b,
+                                                                 const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders,
+                                                                 int *__restrict__ nbr, unsigned char *__restrict__ redo,
+                                                                 int *__restrict__ redo_count)
+{
+    extern __shared__ unsigned char lds[];
+    OrderShared &S = *reinterpret_cast<OrderShared *>(lds);
+    PolyStripe<CAP> poly{reinterpret_cast<double *>(lds + sizeof(OrderShared)) + threadIdx.x};
+    const int t = threadIdx.x, slot = t / NROW, f = t - slot * NROW;
+    if (REDO && *redo_count == 0) // the usual case: a small grid that leaves at once
+        return;
+  for (int64_t group = blockIdx.x; group * ORD_APB < N; group += gridDim.x) {
+    if (REDO) { // uniform per workgroup: skip the group unless one of its atoms asked for the second pass
+        bool any = false;
+        for (int a = 0; a < ORD_APB; ++a) {
+            const int64_t at = group * ORD_APB + a;
+            any = any || (at < N && redo[at] != 0);
+        }
+        if (!any)
+            continue;
+        __syncthreads();
+    }
+    const int64_t atom = group * ORD_APB + slot;
+    const bool lane_on = slot < ORD_APB && atom < N;
+    const bool work = lane_on && (!REDO || redo[atom] != 0);
+    // the row as build_env reads it: stop at the first invalid id, skip the atom itself, keep at most 18
+    const int scan = M < NROW ? (int)M : NROW;
+    if (lane_on) {
+        S.raw[slot][f] = f < scan ? verlet[atom * M + f] : -1;
+        if (f == 0) S.overflow[slot] = 0;
+    }
+    __syncthreads();
+    int pos = -1; // this lane's place in the compacted row
+    if (lane_on) {
+        bool open = true;
+        int before = 0;
+        for (int a = 0; a < f; ++a) {
+            const int j = S.raw[slot][a];
+            open = open && j >= 0 && j < N;
+            before += (open && j != atom) ? 1 : 0;
+        }
+        const int j = S.raw[slot][f];
+        open = open && j >= 0 && j < N;
+        if (open && j != atom) {
+            pos = before;
+            double dx = x[j] - x[atom], dy = y[j] - y[atom], dz = z[j] - z[atom];
+            fold<TRI>(b, dx, dy, dz);
+            S.pts[slot][pos][0] = dx; S.pts[slot][pos][1] = dy; S.pts[slot][pos][2] = dz;
+            S.nsq[slot][pos] = dx * dx + dy * dy + dz * dz;
+            S.ids[slot][pos] = j;
+        }
+        if (f == NROW - 1) {
+            int c = before + ((open && j != atom) ? 1 : 0);
+            S.cnt[slot] = c;
+        }
+    }
+    __syncthreads();
+    const int cnt = lane_on ? S.cnt[slot] : 0;
+    // face f of the compacted row
+    if (work && f < cnt) {
+        double maxn = 0;
+        for (int i = 0; i < cnt; ++i) maxn = fmax(maxn, S.nsq[slot][i]);
+        const double k = 10 * sqrt(maxn);
+        double a = 0;
+        if (!ptmc::face_solid_angle(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a))
+            S.overflow[slot] = 1;
+        S.area[slot][f] = a;
+    }
+    __syncthreads();
+    if (work) {
+        if (S.overflow[slot]) { // (never in the second pass: 28 vertices hold any face of an 18 + 6 plane cell)
+            if (!REDO && f == 0) { redo[atom] = 1; atomicAdd(redo_count, 1); }
+        } else {
+            if (f < cnt) {
+                int rank = 0;
+                for (int g = 0; g < cnt; ++g) rank += ptmc::face_before(g, f, S.area[slot], S.nsq[slot]) ? 1 : 0;
+                orders[atom * NROW + rank] = (int8_t)f;
+                nbr[(int64_t)rank * N + atom] = S.ids[slot][f];
+            } else {
+                orders[atom * NROW + f] = (int8_t)-1;
+                nbr[(int64_t)f * N + atom] = -1;
+            }
+            if (!REDO && f == 0) redo[atom] = 0;
+        }
+    }
+    if (REDO) __syncthreads(); // the shared arrays are reused by the next group
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // stage 1: convex hulls of the first 7 / 13 / 15 points (ptm_core.hpp convex_hull / hull_init / add_facet)
 // ---------------------------------------------------------------------------------------------------------------------
 // facet word: bits 0-14 the oriented triangle with its smallest index first (5 bits each), bits 15-16 how far the
@@ -792,6 +910,39 @@ void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
             for (int k = 0; k < np; ++k) dst[aut[k]] = gr.canon[k];
         }
     }
+}
+
+static int g_order_cap = 15;
+void ptm_debug_order_cap(int cap) { g_order_cap = cap <= 5 ? 5 : 15; }
+
+int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
+                     int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st)
+{
+    using namespace ptms;
+    ProfRange pr("k_ptm_order", st);
+    const dim3 grid((unsigned)((N + ORD_APB - 1) / ORD_APB)), block(ORD_THREADS);
+    // the second pass asks for more than the 64 KB of dynamic LDS a launch gets by default
+    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<true, 28, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds_bytes<28>()));
+    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<false, 28, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds_bytes<28>()));
+    MDH_HIP(hipMemsetAsync(redo_count, 0, sizeof(int), st));
+    const dim3 small(grid.x < 1024u ? grid.x : 1024u);
+    if (g_order_cap == 5) { // test hook: a first pass so small that most atoms take the second one
+        if (b.tri)
+            hipLaunchKernelGGL((k_ptm_order_faces<true, 5, false>), grid, block, order_lds_bytes<5>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        else
+            hipLaunchKernelGGL((k_ptm_order_faces<false, 5, false>), grid, block, order_lds_bytes<5>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        if (b.tri)
+            hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        else
+            hipLaunchKernelGGL((k_ptm_order_faces<false, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    } else if (b.tri) {
+        hipLaunchKernelGGL((k_ptm_order_faces<true, 15, false>), grid, block, order_lds_bytes<15>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    } else {
+        hipLaunchKernelGGL((k_ptm_order_faces<false, 15, false>), grid, block, order_lds_bytes<15>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        hipLaunchKernelGGL((k_ptm_order_faces<false, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    }
+    return MDH_OK;
 }
 
 size_t ptm_stage_bytes(int64_t N)

@@ -18,9 +18,16 @@ import numpy as np
 
 
 class Column:
-    __slots__ = ("name", "_host", "_dev")
+    __slots__ = ("name", "_host_arr", "_dev")
 
     def __init__(self, name: str, values):
+        self.name = name
+        if type(values).__name__ == "HArray":  # already in HBM (the file readers): the host copy is made on first use
+            if values.ndim != 1:
+                raise ValueError(f"column {name!r} must be one-dimensional")
+            self._host_arr = None
+            self._dev = values
+            return
         a = np.asarray(values)
         if a.ndim != 1:
             raise ValueError(f"column {name!r} must be one-dimensional")
@@ -29,9 +36,14 @@ class Column:
         if a.flags.writeable:  # never freeze (or alias) the caller's own buffer
             a = a.copy()
             a.setflags(write=False)
-        self.name = name
-        self._host = a
+        self._host_arr = a
         self._dev = None
+
+    @property
+    def _host(self) -> np.ndarray:
+        if self._host_arr is None:
+            self._host_arr = self._dev.numpy()  # read-only
+        return self._host_arr
 
     def to_numpy(self, allow_copy: bool = True, writable: bool = False) -> np.ndarray:
         if writable:
@@ -49,10 +61,10 @@ class Column:
 
     @property
     def dtype(self):
-        return self._host.dtype
+        return self._dev.dtype if self._host_arr is None else self._host_arr.dtype
 
     def __len__(self):
-        return self._host.shape[0]
+        return len(self._dev) if self._host_arr is None else self._host_arr.shape[0]
 
     def __array__(self, dtype=None, copy=None):
         a = self._host
@@ -83,7 +95,7 @@ class Frame:
         for name, v in (columns or {}).items():
             c = v if isinstance(v, Column) else Column(name, v)
             if c.name != name:
-                c = Column(name, c.to_numpy())
+                c = Column(name, c._dev if c._host_arr is None else c.to_numpy())
             if n is None:
                 n = len(c)
             elif len(c) != n:
@@ -133,6 +145,9 @@ class Frame:
         cols = dict(self._cols)
         n = self.shape[0] if self._cols else None
         for name, v in new.items():
+            if type(v).__name__ == "HArray":
+                cols[name] = Column(name, v)
+                continue
             a = v.to_numpy() if isinstance(v, Column) else np.asarray(v)
             if a.ndim == 0:
                 a = np.full(n, a[()])

@@ -420,6 +420,29 @@ def test_ptm_vs_reference_library(case):
     compare_ptm(out_g, ind_g, out_r, ind_r)
 
 
+def test_ptm_ordering_second_pass_gives_the_same_rows():
+    """the ordering kernel's second pass (28-vertex polygons, for faces that outgrow the first pass's 15): with the first
+    pass shrunk to 5 vertices most atoms take it, and every output must stay what it was"""
+    from mdapy_amd import _lib
+
+    pos, box = _fcc(8, 0.08, 3)
+    x, y, z = _xyz(pos)
+    N = len(x)
+    idx, dist = np.zeros((N, 18), np.int32), np.zeros((N, 18))
+    _fast_knn.knn(x, y, z, box, ORG0, PBC, 18, idx, dist, 1)
+    outs = []
+    for cap in (15, 5):
+        _lib.lib().mdh_debug_set_ptm_order_cap(cap)
+        try:
+            o, i = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
+            _ptm.get_ptm("all", x, y, z, box, ORG0, PBC, idx, None, 0.1, o, i)
+            outs.append((o, i))
+        finally:
+            _lib.lib().mdh_debug_set_ptm_order_cap(15)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert (outs[0][0][:, 0] == 1).mean() > 0.9
+
+
 PTM_PATHS = fixtures_with("ptm")
 
 
