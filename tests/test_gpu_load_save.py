@@ -99,7 +99,7 @@ def test_ten_million_atom_dump(tmp_path):
     with open(p) as f:
         lines = [next(f) for _ in range(9 + 50_000)][9:]
     assert np.array([[float(v) for v in ln.split()[2:]] for ln in lines]).tobytes() == pos[:50_000].tobytes()
-    s.build_neighbor(3.0, max_neigh=8)  # the columns feed the kernels as they are
+    s.build_neighbor(2.0)  # the columns feed the kernels as they are
     out = {"atoms": n, "file_bytes": size, "device_reader_s": timings, "device_reader_GBps": [size / t / 1e9 for t in timings],
            "atoms_per_s": [n / t for t in timings], "pandas_round_trip_s": t_host, "pandas_GBps": size / t_host / 1e9, "write_s": t_write}
     os.makedirs(os.path.join(HERE, "..", "gpurun_out"), exist_ok=True)
