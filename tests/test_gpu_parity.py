@@ -749,6 +749,108 @@ def test_config2_10M_ptm_steinhardt_closed_forms():
     assert np.allclose(s.data["ql6"].to_numpy(), 0.574524, atol=1e-6)
 
 
+def _reduced_rows(block, rows, n_total):
+    """sub-system for an oracle run on a block of a big system: the block's atoms plus every atom their rows name,
+    renumbered in ascending order; rows of the block's atoms translated, rows of the others a copy of the first block
+    atom's row (never looked at).  Returns (ids of the sub-system, translated rows, positions of the block in it)."""
+    ids = np.unique(np.concatenate([block, rows[block].ravel()]))
+    ids = ids[ids >= 0]
+    lut = np.full(n_total + 1, -1, np.int64)  # slot n_total serves the -1 pads
+    lut[ids] = np.arange(len(ids))
+    sub = np.tile(lut[rows[block[0]]], (len(ids), 1)).astype(np.int32)
+    where = lut[block]
+    sub[where] = lut[rows[block]]
+    return ids, sub, where
+
+
+def test_config2_at_spec_ptm_and_steinhardt_block_vs_reference():
+    """configs[2] as SURVEY 8d C3 states it: 136^3 fcc cells = 10 061 824 atoms displaced by N(0, 0.05) seed 0, kNN-18 ->
+    PTM("fcc-hcp-bcc", rmsd 0.1) and Steinhardt q4/q6 (nnn = 12 and rc = 0.85 a).  A contiguous block of 120 000 atoms is
+    recomputed by the reference's own PTM library (oracle/_ref) / the CPU oracle from the rows of the 10 M-atom lists."""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref/libptm_ref.so missing")
+    a = 3.615
+    s = _fcc_system(136, 0.05, 0)
+    n = s.N
+    assert n == 10_061_824
+    x, y, z = (np.ascontiguousarray(s.data[c].to_numpy()) for c in "xyz")
+    s.build_nearest_neighbor(18)
+    knn = np.asarray(s.verlet_list)
+    kd = np.asarray(s.distance_list)
+    assert knn.shape == (n, 18) and np.all(np.diff(kd, axis=1) >= 0)
+    s.cal_polyhedral_template_matching("fcc-hcp-bcc", rmsd_threshold=0.1, return_rmsd=True, return_atomic_distance=True, return_orientation=True,
+                                       return_ordering=True)
+    block = np.arange(4_000_000, 4_120_000)
+    ids, sub, where = _reduced_rows(block, knn, n)
+    out_r, ind_r = np.zeros((len(ids), 8)), np.zeros((len(ids), 18), np.int32)
+    O.get_ptm("fcc-hcp-bcc", x[ids], y[ids], z[ids], s.box.box, s.box.origin, s.box.boundary, sub, None, 0.1, out_r, ind_r)
+    d = s.data
+    out_g = np.column_stack([d["ptm"].to_numpy()[block], d["ordering"].to_numpy()[block], d["rmsd"].to_numpy()[block],
+                             d["interatomic_distance"].to_numpy()[block], d["qw"].to_numpy()[block], d["qx"].to_numpy()[block],
+                             d["qy"].to_numpy()[block], d["qz"].to_numpy()[block]]).astype(np.float64)
+    ind_g = np.asarray(s.ptm_indices)[block]
+    back = np.append(ids, -1)  # sub-system index -> atom id (-1 stays -1)
+    compare_ptm(out_g, ind_g, out_r[where], back[ind_r[where]].astype(np.int32))
+    labels = np.bincount(d["ptm"].to_numpy(), minlength=9)
+    assert labels[1] > 0.999 * n and labels.sum() == n
+    # Steinhardt, both neighbourhood conventions, against the CPU oracle on the same block
+    ll = np.array([4, 6], np.int32)
+    s.cal_steinhardt_bond_orientation([4, 6], nnn=12)
+    q_nnn = np.column_stack([s.data["ql4"].to_numpy()[block], s.data["ql6"].to_numpy()[block]])
+    ids12, sub12, where12 = _reduced_rows(block, knn[:, :12], n)
+    dsub = np.tile(kd[block[0], :12], (len(ids12), 1))
+    dsub[where12] = kd[block, :12]
+    qr = np.zeros((len(ids12), 2, 13)); qi = np.zeros_like(qr); qn = np.zeros((len(ids12), 2))
+    O.get_sq(x[ids12], y[ids12], z[ids12], s.box.box, s.box.origin, s.box.boundary, sub12, dsub, np.full(len(ids12), 12, np.int32),
+             np.zeros((2, 2)), ll, 12, 6, False, False, False, False, 1e9, False, qr, qi, qn, 64)
+    assert np.allclose(q_nnn, qn[where12], rtol=1e-6, atol=1e-12)
+    rc = 0.85 * a
+    s.build_neighbor(rc, max_neigh=16)
+    v, dd, nn = (np.asarray(t) for t in (s.verlet_list, s.distance_list, s.neighbor_number))
+    s.cal_steinhardt_bond_orientation([4, 6], rc=rc)
+    q_rc = np.column_stack([s.data["ql4"].to_numpy()[block], s.data["ql6"].to_numpy()[block]])
+    idsr, subr, wherer = _reduced_rows(block, v, n)
+    dr_ = np.tile(dd[block[0]], (len(idsr), 1)); dr_[wherer] = dd[block]
+    nr_ = np.full(len(idsr), nn[block[0]], np.int32); nr_[wherer] = nn[block]
+    qr = np.zeros((len(idsr), 2, 13)); qi = np.zeros_like(qr); qn = np.zeros((len(idsr), 2))
+    O.get_sq(x[idsr], y[idsr], z[idsr], s.box.box, s.box.origin, s.box.boundary, subr, dr_, nr_, np.zeros((2, 2)), ll, 0, 6, False, False,
+             False, False, rc, False, qr, qi, qn, 64)
+    assert np.allclose(q_rc, qn[wherer], rtol=1e-6, atol=1e-12)
+    assert 0.15 < q_rc[:, 0].mean() < 0.20 and 0.45 < q_rc[:, 1].mean() < 0.58  # rattled fcc: a little below 0.1909 / 0.5745
+
+
+def test_config4_at_spec_glass_rdf_wcp_full_size_vs_oracle():
+    """configs[4] as SURVEY 8d C5 states it: 135^3 x 4 = 9 841 500 fcc sites (a = 4.0) displaced by N(0, 0.35) seed 7,
+    Cu64Zr36 by a shuffled repeat (seed 42); streaming partial g_ab(r), rc = 8, 200 bins — the 2 x 2 x 200 pair counts of the
+    WHOLE system bit for bit against the CPU oracle, and conserved against an independent kernel (the counting pass of the
+    neighbour search); Warren-Cowley at rc = 3.6 against the oracle on the 10 M-atom list."""
+    pos, box = lattice_positions("fcc", 4.0, 135, 135, 135)
+    pos = pos + np.random.default_rng(7).normal(0.0, 0.35, pos.shape)
+    n = len(pos)
+    assert n == 9_841_500
+    ty = np.repeat([0, 1], [int(round(0.64 * n)), n - int(round(0.64 * n))]).astype(np.int32)
+    np.random.default_rng(42).shuffle(ty)
+    x, y, z = _xyz(pos)
+    g_gpu, g_cpu = np.zeros((2, 2, 200)), np.zeros((2, 2, 200))
+    _rdf._rdf_streaming(x, y, z, ty, box, ORG0, PBC, g_gpu, 8.0, 200, 1)
+    O._rdf_streaming(x, y, z, ty, box, ORG0, PBC, g_cpu, 8.0, 200, 64)
+    assert np.array_equal(g_gpu, g_cpu)
+    s = mp.System(pos=pos, box=box)
+    s.update_data(s.data.with_columns(type=(ty + 1).astype(np.int32)))
+    rdf = s.cal_radial_distribution_function(8.0, nbin=200, streaming=True)
+    conc = np.array([0.64, 0.36])
+    total = sum(conc[a_] * conc[b_] * rdf.g_partial[(a_ + 1, b_ + 1)] * (1.0 if a_ == b_ else 2.0) for a_ in range(2) for b_ in range(a_, 2))
+    assert np.allclose(total, rdf.g_total, rtol=1e-9, atol=1e-12)
+    assert abs(rdf.g_total[rdf.r > 6.0].mean() - 1.0) < 0.02 and rdf.g_total[rdf.r < 1.0].max() < 0.05
+    # Warren-Cowley at 3.6 on the full list, and the list's pair count against the histogram's first bins
+    v, d, nn = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, 3.6, 1)
+    w_cpu, w_gpu = np.zeros((2, 2)), np.zeros((2, 2))
+    O.get_wcp(np.asarray(v), np.asarray(nn), ty, 2, w_cpu, 64)
+    _wcp.get_wcp(v, nn, ty, 2, w_gpu, 1)
+    assert np.array_equal(w_gpu, w_cpu) and np.abs(w_cpu).max() < 5e-3
+    assert int(np.asarray(nn).sum()) == int(g_cpu[:, :, :90].sum())  # 90 bins of 0.04 = 3.6: every ordered pair once in each
+
+
 def test_config4_10M_binary_rdf_wcp_invariants():
     """configs[4]: 10 M-atom binary system, partial g_ab(r) + Warren-Cowley.  Invariants: the species-weighted partials
     add up to the total g(r); g averages to 1 beyond the first shell and vanishes inside the core; alpha_ab of a random
