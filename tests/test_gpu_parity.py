@@ -265,6 +265,102 @@ def test_steinhardt_vs_oracle(case, mode):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
 
 
+def _solid_liquid_serial(v, d, n, q, thr, n_bond, rc):
+    """the reference's identifySolidLiquid run with ONE thread (src/steinhardt_bond_orientation.cpp:605-674): bonds counted per
+    atom, then the in-place sweep in index order that turns a solid atom without a solid neighbour into a liquid one — an
+    atom visited later sees the labels the sweep has already changed.  q: (N, 13) real q6m vectors with |q| = 1 and
+    Q6 = sqrt(4 pi / 13), so that s_ij is the plain dot product."""
+    N = len(n)
+    nb = np.zeros(N, np.int32)
+    for i in range(N):
+        for jj in range(n[i]):
+            j = v[i, jj]
+            if j < 0 or d[i, jj] > rc:
+                continue
+            if float(q[i] @ q[j]) > thr:
+                nb[i] += 1
+    sl = (nb >= n_bond).astype(np.int32)
+    for i in range(N):
+        if sl[i] == 1 and not any(v[i, jj] >= 0 and sl[v[i, jj]] == 1 for jj in range(n[i])):
+            sl[i] = 0
+    return sl, nb
+
+
+def _run_solid_liquid(v, d, n, q, thr, n_bond, rc):
+    N = len(n)
+    qr = np.zeros((N, 1, 13)); qr[:, 0, :] = q
+    qi = np.zeros_like(qr)
+    Q6 = np.full(N, np.sqrt(4 * np.pi / 13))
+    out = []
+    for be in (_sbo, O):
+        sl, nb = np.zeros(N, np.int32), np.zeros(N, np.int32)
+        be.identifySolidLiquid(0, Q6, v, d, n, qr, qi, thr, n_bond, sl, nb, False, 0, rc, 1)
+        out.append((sl, nb))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    return out[0]
+
+
+def test_solid_liquid_second_pass_equals_the_serial_sweep():
+    """a16, pass 2.  The kernel judges every atom against the labels of pass 1 (no race, no order dependence); the
+    reference's serial sweep reads labels it is changing.  For symmetric lists (cutoff lists, Voronoi lists) the two agree
+    — an atom's solid neighbour cannot have been cleared before it, because the atom itself was that neighbour's solid
+    neighbour.  Checked on a hand-built graph with two adjacent isolated solids and a lone one, and on random symmetric
+    graphs; the one-sided lists of the nnn mode are where they can part, shown on the smallest example."""
+    e0 = np.zeros(13); e0[0] = 1.0          # "crystalline" orientation
+    def other(k):                           # mutually orthogonal, orthogonal to e0
+        u = np.zeros(13); u[1 + k % 12] = 1.0
+        return u
+    # A(0) - B(1) adjacent, each with two aligned leaves; C(6) alone with three aligned leaves; n_bond = 3 aligned neighbours
+    edges = [(0, 1), (0, 2), (0, 3), (1, 4), (1, 5), (6, 7), (6, 8), (6, 9)]
+    N = 10
+    rows = [[] for _ in range(N)]
+    for a_, b_ in edges:
+        rows[a_].append(b_); rows[b_].append(a_)
+    M = max(len(r) for r in rows)
+    v = np.full((N, M), -1, np.int32); d = np.full((N, M), 9.0)
+    n = np.array([len(r) for r in rows], np.int32)
+    for i, r in enumerate(rows):
+        v[i, :len(r)] = r; d[i, :len(r)] = 1.0
+    q = np.tile(e0, (N, 1))
+    sl, nb = _run_solid_liquid(v, d, n, q, 0.7, 3, 2.0)
+    ref_sl, ref_nb = _solid_liquid_serial(v, d, n, q, 0.7, 3, 2.0)
+    assert np.array_equal(nb, ref_nb) and np.array_equal(sl, ref_sl)
+    assert list(sl) == [1, 1, 0, 0, 0, 0, 0, 0, 0, 0] and list(nb[[0, 1, 6]]) == [3, 3, 3]  # the pair survives, the lone one does not
+    # random symmetric graphs, random orientations from a small set, both orders of the atoms
+    rng = np.random.default_rng(8)
+    for trial in range(20):
+        N = 400
+        pairs = rng.integers(0, N, (900, 2))
+        rows = [set() for _ in range(N)]
+        for a_, b_ in pairs:
+            if a_ != b_:
+                rows[a_].add(int(b_)); rows[b_].add(int(a_))
+        M = max(1, max(len(r) for r in rows))
+        v = np.full((N, M), -1, np.int32); d = np.full((N, M), 9.0); n = np.zeros(N, np.int32)
+        for i, r in enumerate(rows):
+            r = sorted(r); rng.shuffle(r)
+            v[i, :len(r)] = r; d[i, :len(r)] = rng.uniform(0.5, 2.5, len(r)); n[i] = len(r)
+        # distances must be symmetric too, or the cutoff makes the graph one-sided
+        for i in range(N):
+            for jj in range(n[i]):
+                j = v[i, jj]
+                d[i, jj] = 0.5 + ((i * 7919 + j * 7919) % 2000) / 1000.0
+        kinds = rng.integers(0, 3, N)
+        q = np.array([e0 if k == 0 else other(k + i % 5) for i, k in enumerate(kinds)])
+        for n_bond in (1, 2, 3):
+            sl, nb = _run_solid_liquid(v, d, n, q, 0.7, n_bond, 2.0)
+            ref_sl, ref_nb = _solid_liquid_serial(v, d, n, q, 0.7, n_bond, 2.0)
+            assert np.array_equal(nb, ref_nb) and np.array_equal(sl, ref_sl)
+    # one-sided lists (nnn mode): atom 0 lists nobody solid, atom 1 lists only atom 0.  The serial sweep clears 0 first and
+    # then 1; against the pass-1 labels atom 1 keeps its solid neighbour.  The kernel (and the oracle) do the latter.
+    v = np.array([[2, 3], [0, 0], [0, -1], [0, -1]], np.int32)
+    d = np.ones((4, 2)); n = np.array([2, 2, 1, 1], np.int32)
+    q = np.tile(e0, (4, 1))
+    sl, nb = _run_solid_liquid(v, d, n, q, 0.7, 2, 2.0)
+    ser, _ = _solid_liquid_serial(v, d, n, q, 0.7, 2, 2.0)
+    assert list(nb) == [2, 2, 1, 1] and list(sl) == [0, 1, 0, 0] and list(ser) == [0, 0, 0, 0]
+
+
 def test_rdf_and_wcp_vs_oracle():
     rng = np.random.default_rng(21)
     pos, box = lattice_positions("fcc", 4.0, 9, 9, 9)
