@@ -441,9 +441,58 @@ static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const
 // ----------------------------------------------------------------------------
 // small row-wise helpers
 // ----------------------------------------------------------------------------
-// neighbor.cpp:745-775: selection of the first k entries by strict '<' over all M columns
-__global__ __launch_bounds__(256) void k_sort_rows(int *__restrict__ verlet, double *__restrict__ dist, int64_t N,
-                                                   int64_t M, int k)
+// neighbor.cpp:745-775: selection of the first k entries by strict '<' over all M columns.
+// 64 consecutive rows per workgroup: the rows are one contiguous piece of memory, loaded with coalesced reads into LDS
+// (element c of row t at [c * 64 + t]: conflict-free for the per-row walk), selected there, and only written back when
+// something moved — the rows of a k-nearest search arrive sorted, and every analysis that borrows them "sorts" them again
+// (the reference does the same); for those the kernel is one read of the list.
+constexpr int SORT_ROWS = 64;
+__global__ __launch_bounds__(SORT_ROWS) void k_sort_rows(int *__restrict__ verlet, double *__restrict__ dist, int64_t N,
+                                                         int64_t M, int k)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    double *ld = reinterpret_cast<double *>(sort_lds);            // [M][64]
+    int *lv = reinterpret_cast<int *>(ld + (size_t)M * SORT_ROWS); // [M][64]
+    const int64_t row0 = (int64_t)blockIdx.x * SORT_ROWS;
+    const int rows = (int)((N - row0) < SORT_ROWS ? (N - row0) : SORT_ROWS);
+    const int64_t total = (int64_t)rows * M;
+    const int t = threadIdx.x;
+    for (int64_t e = t; e < total; e += SORT_ROWS) {
+        const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+        ld[c * SORT_ROWS + r] = dist[row0 * M + e];
+        lv[c * SORT_ROWS + r] = verlet[row0 * M + e];
+    }
+    __syncthreads();
+    bool moved = false;
+    if (t < rows) {
+        for (int a = 0; a < k; ++a) {
+            int best = a;
+            double db = ld[a * SORT_ROWS + t];
+            for (int c = a + 1; c < M; ++c) {
+                const double v = ld[c * SORT_ROWS + t];
+                if (v < db) { db = v; best = c; }
+            }
+            if (best != a) {
+                const double td = ld[a * SORT_ROWS + t];
+                ld[a * SORT_ROWS + t] = db; ld[best * SORT_ROWS + t] = td;
+                const int tv = lv[a * SORT_ROWS + t];
+                lv[a * SORT_ROWS + t] = lv[best * SORT_ROWS + t]; lv[best * SORT_ROWS + t] = tv;
+                moved = true;
+            }
+        }
+    }
+    if (!__syncthreads_or(moved ? 1 : 0))
+        return;
+    for (int64_t e = t; e < total; e += SORT_ROWS) {
+        const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+        dist[row0 * M + e] = ld[c * SORT_ROWS + r];
+        verlet[row0 * M + e] = lv[c * SORT_ROWS + r];
+    }
+}
+
+// the same in place in HBM, for rows too wide for the LDS copy
+__global__ __launch_bounds__(256) void k_sort_rows_wide(int *__restrict__ verlet, double *__restrict__ dist, int64_t N,
+                                                        int64_t M, int k)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
@@ -733,7 +782,11 @@ int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M,
     if (sc.failed())
         return sc.error();
     const int k = (int)(sort_num < M ? sort_num : M);
-    hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, k);
+    const size_t lds = (size_t)M * SORT_ROWS * 12;
+    if (lds <= 60 * 1024)
+        hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(N, SORT_ROWS)), dim3(SORT_ROWS), lds, sc.stream(), dv, dd, N, M, k);
+    else
+        hipLaunchKernelGGL(k_sort_rows_wide, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, k);
     return sc.finish(space);
 }
 

@@ -90,14 +90,50 @@ def nearest_rows(frame, box, k):
     return finder.indices_py
 
 
+_label_cache = []  # [(weak reference to a read-only label array, names, codes)]: frame columns are immutable, analyses re-ask
+
+
 def label_codes(labels):
     """(sorted distinct labels as Python objects, int32 code of every atom in that order)"""
     raw = np.asarray(labels)
     if raw.size == 0:
         return [], np.zeros(0, np.int32)
+    if not raw.flags.writeable:
+        for ref, names, codes in _label_cache:
+            if ref() is raw:
+                return list(names), codes
+        names, codes = _label_codes(raw)
+        import weakref
+
+        try:
+            _label_cache.append((weakref.ref(raw), names, codes))
+            del _label_cache[:-4]
+        except TypeError:
+            pass
+        return list(names), codes
+    return _label_codes(raw)
+
+
+def _label_codes(raw):
     head = raw.flat[0]
     if bool((raw == head).all()):  # one species: no sort needed
         return [head.item() if hasattr(head, "item") else head], np.zeros(raw.shape[0], np.int32)
+    if raw.dtype.kind in "iu":  # numeric types: a counting pass instead of a sort of N labels
+        low, high = int(raw.min()), int(raw.max())
+        if high - low < (1 << 20):
+            shifted = raw - low
+            present = np.flatnonzero(np.bincount(shifted.reshape(-1), minlength=high - low + 1))
+            lut = np.zeros(high - low + 1, np.int32)
+            lut[present] = np.arange(len(present), dtype=np.int32)
+            return (present + low).tolist(), lut[shifted.reshape(-1)]
+    elif raw.dtype == object:  # element symbols: hash them (pandas) rather than compare Python strings N log N times
+        try:
+            import pandas as pd
+
+            codes, names = pd.factorize(raw.reshape(-1), sort=True)
+            return list(names), codes.astype(np.int32)
+        except ImportError:
+            pass
     names, codes = np.unique(raw, return_inverse=True)
     return names.tolist(), codes.reshape(-1).astype(np.int32)
 

@@ -39,7 +39,7 @@ from .voronoi import Voronoi
 from .warren_cowley_parameter import WarrenCowleyParameter
 
 _REPLICA = ("_enlarge_box", "_enlarge_data")
-_LIST = ("verlet_list", "neighbor_number", "distance_list", "rc") + _REPLICA
+_LIST = ("verlet_list", "neighbor_number", "distance_list", "rc", "_sorted_columns") + _REPLICA
 
 
 class System:
@@ -120,6 +120,15 @@ class System:
             if name in search.__dict__:
                 setattr(self, name, getattr(search, name))
         self.verlet_list, self.distance_list, self.neighbor_number = rows, distances, counts
+        self._sorted_columns = (id(rows), 0)  # (the list it speaks of, leading columns known to hold the nearest neighbours in order)
+
+    def _sort_front(self, k):
+        """the k nearest of every row to the front, nearest first — once: a row prefix that is already in order (the rows of a
+        k-nearest search, or an earlier call) is not touched again"""
+        which, done = self.__dict__.get("_sorted_columns", (None, 0))
+        if which != id(self.verlet_list) or done < k:
+            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, k)
+            self._sorted_columns = (id(self.verlet_list), k)
 
     def build_neighbor(self, rc, max_neigh=None):
         search = Neighbor(rc, self.box, self.data, max_neigh)
@@ -132,6 +141,7 @@ class System:
         search = NearestNeighbor(self.data, self.box, k)
         search.compute()
         self._remember(search, search.indices_py, search.distances_py, np.full(search.indices_py.shape[0], k, np.int32))
+        self._sorted_columns = (id(self.verlet_list), k)
 
     def _require_cutoff_list(self, rc, max_neigh):
         """a cutoff list reaching at least rc: the remembered one if it does, a new one otherwise"""
@@ -145,7 +155,7 @@ class System:
         """make the first k columns of the current list the k nearest neighbours, nearest first: by sorting the remembered
         list when every atom has k entries, by a k-nearest search otherwise"""
         if self._deep_enough(k) and (not cutoff_lists_only or "rc" in self.__dict__):
-            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, k)
+            self._sort_front(k)
         else:
             self.build_nearest_neighbor(k)
 
@@ -157,7 +167,7 @@ class System:
         sorted, if it is deep enough — but never for a box so thin that the analysis would replicate it (the list of the
         unreplicated system would miss images)"""
         if policy.is_single(self._safe_repeat()) and self._deep_enough(k):
-            tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, k)
+            self._sort_front(k)
             return self.verlet_list
         return None
 
