@@ -20,100 +20,15 @@ namespace mdh {
 
 using ptmc::Tables;
 
-static constexpr int PTM_BLOCK = 64;
-
-// working set of the canonical form in LDS (ptm_core.hpp: Canon is the private-array twin): per lane 256 + 84 + 16 bytes
-// and 16 half-words, element e of lane l at [e * PTM_BLOCK + l]
-struct CanonLds {
-    static constexpr int BYTES = 256 + 2 * ptmc::MAX_EDGES + ptmc::MAX_NBR; // common | best | index
-    static constexpr size_t LDS_BYTES = (size_t)(BYTES + 2 * ptmc::MAX_NBR) * PTM_BLOCK;
-    int8_t *b8;        // byte elements, stride PTM_BLOCK
-    uint16_t *h16;     // walked[], stride PTM_BLOCK
-    int8_t label[ptmc::MAX_PTS];
-    __device__ __forceinline__ int cm(int a, int b) const { return b8[(a * 16 + b) * PTM_BLOCK]; }
-    __device__ __forceinline__ void cm_set(int a, int b, int v) { b8[(a * 16 + b) * PTM_BLOCK] = (int8_t)v; }
-    __device__ __forceinline__ int bs(int i) const { return b8[(256 + i) * PTM_BLOCK]; }
-    __device__ __forceinline__ void bs_set(int i, int v) { b8[(256 + i) * PTM_BLOCK] = (int8_t)v; }
-    __device__ __forceinline__ int ix(int i) const { return b8[(256 + 2 * ptmc::MAX_EDGES + i) * PTM_BLOCK]; }
-    __device__ __forceinline__ void ix_set(int i, int v) { b8[(256 + 2 * ptmc::MAX_EDGES + i) * PTM_BLOCK] = (int8_t)v; }
-    __device__ __forceinline__ unsigned wk(int i) const { return h16[i * PTM_BLOCK]; }
-    __device__ __forceinline__ void wk_set(int i, unsigned v) { h16[i * PTM_BLOCK] = (uint16_t)v; }
-};
-
-#ifdef MDH_PTM_CANON_LDS
-static constexpr size_t PTM_INDEX_LDS = CanonLds::LDS_BYTES;
-#else
-static constexpr size_t PTM_INDEX_LDS = 0;
-#endif
-
-template <bool TRI> struct DevFold {
-    const DBox &b;
-    __device__ __forceinline__ void operator()(double &dx, double &dy, double &dz) const { pbc<TRI>(b, dx, dy, dz); }
-};
-
-template <bool TRI> struct DevSrc {
-    const double *x, *y, *z;
-    int64_t N, M;
-    const int *verlet, *types;
-    const int8_t *orders;
-    const DBox &b;
-    __device__ void get(int atom, ptmc::Env &env)
-    {
-        const DevFold<TRI> fold{b};
-        ptmc::PolyLocal unused; // the order is given: no polygon work
-        ptmc::build_env(x, y, z, N, verlet + (int64_t)atom * M, (int)M, types, atom, fold, orders + (int64_t)atom * 18, env, unused);
-    }
-};
-
-// pass 2 (:258-318): match the templates, write the result row and the matched-neighbour row.  SHELL = diamond /
-// graphene stages compiled in (9 KB more private memory per lane; the common fcc-hcp-bcc call does without)
-template <bool TRI, bool SHELL>
-__global__ __launch_bounds__(PTM_BLOCK) void k_ptm_index(const double *__restrict__ x, const double *__restrict__ y,
-                                                         const double *__restrict__ z, int64_t N, DBox b,
-                                                         const int *__restrict__ verlet, int64_t M,
-                                                         const int *__restrict__ types, const int8_t *__restrict__ orders,
-                                                         const Tables *__restrict__ tables, int flags, double rmsd_threshold,
-                                                         double *__restrict__ output, int ncol, int *__restrict__ ptm_indices,
-                                                         int nind)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    DevSrc<TRI> src{x, y, z, N, M, verlet, types, orders, b};
-    ptmc::Result r;
-#ifdef MDH_PTM_CANON_LDS
-    extern __shared__ unsigned char canon_lds[];
-    CanonLds C;
-    C.b8 = reinterpret_cast<int8_t *>(canon_lds) + threadIdx.x;
-    C.h16 = reinterpret_cast<uint16_t *>(canon_lds + (size_t)CanonLds::BYTES * PTM_BLOCK) + threadIdx.x;
-#else
-    // Measured (1 M rattled fcc atoms): with the canonical-form arrays in LDS the kernel keeps 6 instead of 16 waves per
-    // CU and the hull phase, still in private memory, loses more than the canonical form gains (76 ms vs 63 ms).
-    ptmc::Canon C;
-#endif
-    ptmc::index_atom<SHELL>(*tables, flags, src, (int)i, r, C);
-    int type = r.type, ordering = r.ordering;
-    if (r.rmsd > rmsd_threshold || type == ptmc::T_NONE) { // :287-291
-        type = 0;
-        ordering = 0;
-    }
-    double *o = output + i * ncol;
-    const double vals[8] = {(double)type, (double)ordering, r.rmsd, r.interatomic, r.q[0], r.q[1], r.q[2], r.q[3]};
-    for (int k = 0; k < ncol; ++k)
-        o[k] = k < 8 ? vals[k] : 0.0;
-    int *pi = ptm_indices + (int64_t)i * nind;
-    for (int k = 0; k < nind; ++k)
-        pi[k] = k < r.num_out && k < ptmc::MAX_PTS ? r.ids[k] : -1;
-}
 
 // staged pipeline for the single-shell structure types (ptm_stages.hip)
 void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc);
 size_t ptm_stage_bytes(int64_t N);
 int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
                      int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st);
-int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int *dtypes,
-                      const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol, int *dind,
-                      int nind, unsigned char *work, hipStream_t st);
+int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int8_t *orders,
+                      const int *dtypes, const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol,
+                      int *dind, int nind, unsigned char *work, hipStream_t st);
 
 static Tables *g_host_tables = nullptr;
 const ptmc::Tables *ptm_host_tables() { return g_host_tables; }
@@ -232,24 +147,10 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     int *dnbr = sc.alloc_n<int>((size_t)N * 18);
     unsigned char *dredo = sc.alloc_n<unsigned char>((size_t)N);
     int *dcount = sc.alloc_n<int>(1);
-    const bool shell = (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX | ptmc::CHECK_GRAPHENE)) != 0;
-    unsigned char *work = shell ? nullptr : sc.alloc_n<unsigned char>(ptm_stage_bytes(N));
+    unsigned char *work = sc.alloc_n<unsigned char>(ptm_stage_bytes(N));
     if (sc.failed())
         return sc.error();
-    const dim3 grid(grid_for(N, PTM_BLOCK)), block(PTM_BLOCK);
     MDH_TRY(launch_ptm_order(dx, dy, dz, N, b, dv, M, dord, dnbr, dredo, dcount, sc.stream()));
-    if (!shell) {
-        MDH_TRY(launch_ptm_stages(dx, dy, dz, N, b, dnbr, dtp, dt, dautc, flags, rmsd_threshold, dout, ncol, dind, nind, work, sc.stream()));
-    } else {
-        ProfRange pr("k_ptm_index", sc.stream());
-#define MDH_PTM_LAUNCH(TRI, SHELL)                                                                                              \
-    hipLaunchKernelGGL((k_ptm_index<TRI, SHELL>), grid, block, PTM_INDEX_LDS, sc.stream(), dx, dy, dz, N, b, dv, M, dtp, dord, dt, flags,   \
-                       rmsd_threshold, dout, ncol, dind, nind)
-        if (b.tri && shell) MDH_PTM_LAUNCH(true, true);
-        else if (b.tri) MDH_PTM_LAUNCH(true, false);
-        else if (shell) MDH_PTM_LAUNCH(false, true);
-        else MDH_PTM_LAUNCH(false, false);
-#undef MDH_PTM_LAUNCH
-    }
+    MDH_TRY(launch_ptm_stages(dx, dy, dz, N, b, dnbr, dord, dtp, dt, dautc, flags, rmsd_threshold, dout, ncol, dind, nind, work, sc.stream()));
     return sc.finish(space);
 }

@@ -506,7 +506,9 @@ template <int NN> struct CanonMem {
     __device__ __forceinline__ int cm(int a, int b) const { return (int)((C[a * BLK] >> (4 * b)) & 15u); }
 };
 
-template <int NN>
+// COL: the first four vertices carry colour 1 (the inner atoms of the diamond cluster): a vertex's code is colour * NN + its
+// visiting number, so that inner atoms only map onto inner atoms
+template <int NN, bool COL>
 __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__restrict__ facets, const int8_t *__restrict__ status,
                                                    int max_degree, int all_degree, CanonOut out)
 {
@@ -550,6 +552,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
             equal = equal && d == d0;
             all_ok = all_ok && (all_degree == 0 || d == all_degree);
         }
+        equal = equal && !COL;
         good = good && mx <= max_degree && all_ok;
         // start edges: rotation r of facet j at bit 3 j + r, in the order the reference tries them
         uint64_t s_lo = 0;
@@ -605,9 +608,9 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
             int n = 1;            // index[a] = 0
             bool winning = false, alive = true;
             {
-                const int cur = m.B[0];
-                if (0 > cur) alive = false; // (cannot happen: codes are >= 0)
-                if (0 < cur) { m.B[0] = 0; winning = true; }
+                const int first = COL && a < 4 ? NN : 0, cur = m.B[0];
+                if (first > cur) alive = false;
+                if (first < cur) { m.B[0] = (int8_t)first; winning = true; }
             }
             for (int it = 1; it < 2 * NE && alive; ++it) {
                 const bool newv = !((seen >> bq) & 1u);
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
                     seen |= 1u << bq;
                     ++n;
                 }
-                const int val = (int)((index >> (4 * bq)) & 15u);
+                const int val = (int)((index >> (4 * bq)) & 15u) + (COL && bq < 4 ? NN : 0);
                 const int cur = m.B[it * BLK];
                 const uint16_t mb = m.M[bq * BLK];
                 int c = m.cm(a, bq);
@@ -655,29 +658,258 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// stage 3: template look-up, QCP superposition per automorphism, alloy ordering, fundamental-zone remap, outputs
+// two-shell clusters for the diamond / graphene templates (ptm_core.hpp two_shell_env, ptm_multishell.cpp:41-186) and the hull
+// of the 16-neighbour diamond cluster with its inner atoms folded in (match_dcub_dhex, ptm_structure_matcher.cpp:194-311)
 // ---------------------------------------------------------------------------------------------------------------------
-struct MatchIn {
-    const uint64_t *hash[NKIND];
-    const int8_t *label[NKIND];
-    const int8_t *ok[NKIND];
+struct ShellSet {
+    int *ids;     // [NPT][N]
+    double *pts;  // [NPT * 3][N] relative to the centre atom
+    int8_t *ok;   // [N]
 };
 
-struct MatchMem {
-    static constexpr int NP = 15;
-    double *P;  // [NP][3] raw separations (centre first, Voronoi order)
+// entry k of atom a's ordered row counts for the clusters only if it is among the 13 nearest (rank <= 12)
+__device__ __forceinline__ bool shell_entry(const int *__restrict__ nbr, const int8_t *__restrict__ orders, int64_t N, int a, int k, int *id)
+{
+    const int j = nbr[(int64_t)k * N + a];
+    const int o = orders[(int64_t)a * NROW + k];
+    *id = j;
+    return j >= 0 && o >= 0 && o <= ptmc::MAX_MULTISHELL - 1;
+}
+
+// centre + INNER nearest (Voronoi order, among the 13 nearest) + OUTER neighbours of each of them that are not part of the
+// cluster yet, taken rank by rank across the inner atoms
+template <bool TRI, int INNER, int OUTER>
+__global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                   int64_t N, DBox b, const int *__restrict__ nbr, const int8_t *__restrict__ orders, ShellSet out)
+{
+    constexpr int NPT = 1 + INNER + INNER * OUTER, WANT = INNER * OUTER;
+    extern __shared__ unsigned char lds[];
+    const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (atom >= N)
+        return;
+    double *OP = reinterpret_cast<double *>(lds) + threadIdx.x;                       // [NPT][3]
+    int *OI = reinterpret_cast<int *>(lds + (size_t)BLK * NPT * 24) + threadIdx.x;    // [NPT]
+    const double xi = x[atom], yi = y[atom], zi = z[atom];
+    OI[0] = (int)atom;
+    OP[0] = 0; OP[1 * BLK] = 0; OP[2 * BLK] = 0;
+    int m = 1;
+    for (int k = 0; k < NROW && m < INNER + 1; ++k) {
+        int j;
+        if (!shell_entry(nbr, orders, N, (int)atom, k, &j))
+            continue;
+        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+        fold<TRI>(b, dx, dy, dz);
+        OI[m * BLK] = j;
+        OP[(m * 3 + 0) * BLK] = dx; OP[(m * 3 + 1) * BLK] = dy; OP[(m * 3 + 2) * BLK] = dz;
+        ++m;
+    }
+    bool good = m == INNER + 1;
+    int found = 0;
+    if (good) {
+        double tol;
+        {
+            const double d[3] = {OP[0] - OP[3 * BLK], OP[1 * BLK] - OP[4 * BLK], OP[2 * BLK] - OP[5 * BLK]};
+            tol = 1E-5 * sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            tol = tol > 1E-5 ? tol : 1E-5;
+        }
+        int inner[INNER], lens[INNER], cursor[INNER], counts[INNER];
+        double ix[INNER], iy[INNER], iz[INNER];
+        int max_len = 0;
+#pragma unroll
+        for (int i = 0; i < INNER; ++i) {
+            inner[i] = OI[(1 + i) * BLK];
+            ix[i] = x[inner[i]]; iy[i] = y[inner[i]]; iz[i] = z[inner[i]];
+            int n = 1, dummy;
+            for (int k = 0; k < NROW; ++k) n += shell_entry(nbr, orders, N, inner[i], k, &dummy) ? 1 : 0;
+            lens[i] = n;
+            good = good && n >= INNER + 1;
+            max_len = n > max_len ? n : max_len;
+            cursor[i] = 0;
+            counts[i] = 0;
+        }
+        unsigned filled = 0; // bit s: outer slot s holds an atom
+        if (good)
+            for (int j = 1; j < max_len && found < WANT; ++j) {
+#pragma unroll
+                for (int i = 0; i < INNER; ++i) {
+                    if (j >= lens[i] || found >= WANT)
+                        continue;
+                    int id = -1;
+                    while (cursor[i] < NROW && !shell_entry(nbr, orders, N, inner[i], cursor[i], &id)) ++cursor[i]; // entry j of this inner atom
+                    ++cursor[i];
+                    if (counts[i] >= OUTER)
+                        continue;
+                    double dx = x[id] - ix[i], dy = y[id] - iy[i], dz = z[id] - iz[i];
+                    fold<TRI>(b, dx, dy, dz);
+                    const double px = dx + OP[((1 + i) * 3 + 0) * BLK], py = dy + OP[((1 + i) * 3 + 1) * BLK], pz = dz + OP[((1 + i) * 3 + 2) * BLK];
+                    bool claimed = false;
+#pragma unroll
+                    for (int k = 0; k < NPT; ++k) {
+                        if (k > INNER && !((filled >> k) & 1u))
+                            continue;
+                        if (id == OI[k * BLK]) {
+                            const double d[3] = {px - OP[(k * 3 + 0) * BLK], py - OP[(k * 3 + 1) * BLK], pz - OP[(k * 3 + 2) * BLK]};
+                            if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < tol) claimed = true;
+                        }
+                    }
+                    if (claimed)
+                        continue;
+                    const int slot = 1 + INNER + OUTER * i + counts[i];
+                    OI[slot * BLK] = id;
+                    OP[(slot * 3 + 0) * BLK] = px; OP[(slot * 3 + 1) * BLK] = py; OP[(slot * 3 + 2) * BLK] = pz;
+                    filled |= 1u << slot;
+                    ++counts[i];
+                    ++found;
+                }
+            }
+    }
+    good = good && found == WANT;
+    out.ok[atom] = good ? 1 : 0;
+    if (good) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            out.ids[(int64_t)k * N + atom] = OI[k * BLK];
+            out.pts[(int64_t)(k * 3 + 0) * N + atom] = OP[(k * 3 + 0) * BLK];
+            out.pts[(int64_t)(k * 3 + 1) * N + atom] = OP[(k * 3 + 1) * BLK];
+            out.pts[(int64_t)(k * 3 + 2) * N + atom] = OP[(k * 3 + 2) * BLK];
+        }
+    }
+}
+
+// hull of the normalised diamond cluster, then the reference's surgery on it: a facet spanned by the three outer atoms of
+// one inner atom is replaced by the three facets through that inner atom
+__global__ __launch_bounds__(BLK) void k_ptm_hull_shell(int64_t N, ShellSet in, int max_degree, uint16_t *__restrict__ facets,
+                                                        int8_t *__restrict__ status)
+{
+    constexpr int NP = 17;
+    extern __shared__ unsigned char lds[];
+    const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    if (atom >= N)
+        return;
+    HullMem<NP> m;
+    m.P = reinterpret_cast<double *>(lds) + threadIdx.x;
+    m.F = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
+    m.E = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * 4)) + threadIdx.x;
+    m.A = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * 4 + (NP - 1) * 4)) + threadIdx.x;
+    int8_t st = -1;
+    if (in.ok[atom]) {
+        double sum[3] = {0, 0, 0};
+        for (int i = 0; i < NP; ++i)
+            for (int c = 0; c < 3; ++c) {
+                const double v = in.pts[(int64_t)(i * 3 + c) * N + atom];
+                m.P[(i * 3 + c) * BLK] = v;
+                sum[c] += v;
+            }
+        const double s3[3] = {sum[0] / NP, sum[1] / NP, sum[2] / NP};
+        double scale = 0;
+        for (int i = 0; i < NP; ++i) {
+            double v[3];
+            for (int c = 0; c < 3; ++c) { v[c] = m.P[(i * 3 + c) * BLK] - s3[c]; m.P[(i * 3 + c) * BLK] = v[c]; }
+            if (i >= 1) scale += sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        }
+        scale /= NP;
+        for (int i = 0; i < NP * 3; ++i) m.P[i * BLK] = m.P[i * BLK] / scale;
+        HullState h;
+        h.ok = false; h.num_prev = 0; h.num_facets = 0; h.processed = 0;
+        h.bary[0] = h.bary[1] = h.bary[2] = 0;
+        bool good = hull_grow(m, NP, h) == 0;
+        int nfac = h.num_facets;
+        unsigned inverted = 0;
+        if (good) {
+            for (int j = 0; j < nfac; ++j) { // vertex indices - 1 from here on
+                const uint32_t w = m.F[j * BLK];
+                const uint32_t a = (w & 31) - 1, bq = ((w >> 5) & 31) - 1, c = ((w >> 10) & 31) - 1;
+                m.F[j * BLK] = a | (bq << 5) | (c << 10);
+                int n = 0; // an inner atom may lie on the hull, but never two on one facet
+                if (a <= 3) { inverted |= 1u << a; ++n; }
+                if (bq <= 3) { inverted |= 1u << bq; ++n; }
+                if (c <= 3) { inverted |= 1u << c; ++n; }
+                good = good && n <= 1;
+            }
+        }
+        const int num_inverted = __builtin_popcount(inverted);
+        good = good && nfac == 20 + 2 * num_inverted;
+        if (good) { // (sic) the degree bound looks at the first 20 facets only, ptm_structure_matcher.cpp:231
+            uint64_t deg = 0;
+            for (int j = 0; j < 20; ++j) {
+                const uint32_t w = m.F[j * BLK];
+                deg += (1ull << (4 * (w & 31))) + (1ull << (4 * ((w >> 5) & 31))) + (1ull << (4 * ((w >> 10) & 31)));
+            }
+            for (int v = 0; v < 16; ++v) good = good && (int)((deg >> (4 * v)) & 15u) <= max_degree;
+        }
+        int num_found = 0;
+        if (good) {
+            for (int j = 0; j < nfac; ++j) {
+                const uint32_t w = m.F[j * BLK];
+                const int a = w & 31, bq = (w >> 5) & 31, c = (w >> 10) & 31;
+                if (a <= 3 || bq <= 3 || c <= 3)
+                    continue;
+                const int i0 = (a - 4) / 3, i1 = (bq - 4) / 3, i2 = (c - 4) / 3;
+                if (i0 == i1 && i0 == i2) {
+                    if (num_found + num_inverted >= 4) { good = false; break; }
+                    m.A[num_found * BLK] = (uint16_t)w;
+                    ++num_found;
+                    m.F[j * BLK] = m.F[(nfac - 1) * BLK];
+                    --nfac;
+                    --j;
+                }
+            }
+        }
+        good = good && num_found + num_inverted == 4;
+        if (good) {
+            for (int t = 0; t < num_found; ++t) {
+                const uint32_t w = m.A[t * BLK];
+                const uint32_t a = w & 31, bq = (w >> 5) & 31, c = (w >> 10) & 31, i0 = (a - 4) / 3;
+                m.F[nfac * BLK] = i0 | (bq << 5) | (c << 10); ++nfac;
+                m.F[nfac * BLK] = a | (i0 << 5) | (c << 10); ++nfac;
+                m.F[nfac * BLK] = a | (bq << 5) | (i0 << 10); ++nfac;
+            }
+            // the canonical-form stage repeats the degree bound over all facets (its max_degree argument)
+            st = (int8_t)nfac;
+            for (int j = 0; j < nfac; ++j) facets[(int64_t)j * N + atom] = (uint16_t)m.F[j * BLK];
+        }
+    }
+    status[atom] = st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stage 3: template look-up, QCP superposition per automorphism, alloy ordering, fundamental-zone remap, outputs
+// ---------------------------------------------------------------------------------------------------------------------
+enum { K_DC = 3, K_GR = 4, NCANON = 4 };
+
+struct MatchIn {
+    const uint64_t *hash[NCANON];
+    const int8_t *label[NCANON];
+    const int8_t *ok[NCANON];
+    ShellSet dc, gr;
+};
+
+template <int NPM> struct MatchMem {
+    static constexpr int NP = NPM;
+    double *P;  // [NP][3] raw separations (centre first)
     int *I;     // [17] atom ids in the same order, later the matched ids in template order
     int8_t *V;  // [20] inverse canonical labelling of the kind at hand
     static constexpr size_t BYTES = (size_t)BLK * (NP * 24 + 17 * 4 + 20);
 };
 
-// rmsd of template `s` onto the points  P[map(i)] - bary  (ptm_core.hpp calc_rmsd); map(i) = V[autc[i]]
-__device__ double stage_rmsd(const MatchMem &m, const ptmc::TypeInfo &s, int np, const int8_t *__restrict__ autc, const double *bary,
-                             double G1, double G2, double E0, double *q, double *p_scale)
+struct GraphMap { // template point i -> cluster point V[autc[i]]
+    const int8_t *V;
+    const int8_t *__restrict__ autc;
+    __device__ __forceinline__ int operator()(int i) const { return V[autc[i] * BLK]; }
+};
+struct GrapheneMap { // the 2^3 assignments of each inner atom's two outer atoms: bit 2 swaps points 4,5, bit 1 6,7, bit 0 8,9
+    int bits;
+    __device__ __forceinline__ int operator()(int i) const { return i < 4 ? i : (((bits >> (2 - ((i - 4) >> 1))) & 1) ? (i ^ 1) : i); }
+};
+
+// rmsd of template `s` onto the points  P[map(i)] - bary  (ptm_core.hpp calc_rmsd)
+template <class Mem, class Map>
+__device__ double stage_rmsd(const Mem &m, const ptmc::TypeInfo &s, int np, const Map &map, const double *bary, double G1, double G2, double E0,
+                             double *q, double *p_scale)
 {
     double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < np; ++i) {
-        const int k = m.V[autc[i] * BLK];
+        const int k = map(i);
         const double x1 = s.points[i][0], y1 = s.points[i][1], z1 = s.points[i][2];
         const double x2 = m.P[(k * 3 + 0) * BLK] - bary[0], y2 = m.P[(k * 3 + 1) * BLK] - bary[1], z2 = m.P[(k * 3 + 2) * BLK] - bary[2];
         A[0] += x1 * x2; A[1] += x1 * y2; A[2] += x1 * z2;
@@ -689,7 +921,7 @@ __device__ double stage_rmsd(const MatchMem &m, const ptmc::TypeInfo &s, int np,
     ptmc::quat_to_matrix(q, rot);
     double k0 = 0;
     for (int i = 0; i < np; ++i) {
-        const int k = m.V[autc[i] * BLK];
+        const int k = map(i);
         const double p[3] = {m.P[(k * 3 + 0) * BLK] - bary[0], m.P[(k * 3 + 1) * BLK] - bary[1], m.P[(k * 3 + 2) * BLK] - bary[2]};
         for (int j = 0; j < 3; ++j) {
             double v = 0.0;
@@ -702,45 +934,118 @@ __device__ double stage_rmsd(const MatchMem &m, const ptmc::TypeInfo &s, int np,
     return sqrt(fabs(G1 - scale * k0) / np);
 }
 
-template <bool TRI>
+struct Best {
+    int type, aut, kind;
+    double rmsd, scale, q[4];
+};
+
+template <class Mem> __device__ __forceinline__ void barycentre(const Mem &m, int np, double *bary, double *G2)
+{
+    bary[0] = bary[1] = bary[2] = 0;
+    for (int i = 0; i < np; ++i) { bary[0] += m.P[(i * 3 + 0) * BLK]; bary[1] += m.P[(i * 3 + 1) * BLK]; bary[2] += m.P[(i * 3 + 2) * BLK]; }
+    bary[0] /= np; bary[1] /= np; bary[2] /= np;
+    double g = 0;
+    for (int i = 0; i < np; ++i) {
+        const double v[3] = {m.P[(i * 3 + 0) * BLK] - bary[0], m.P[(i * 3 + 1) * BLK] - bary[1], m.P[(i * 3 + 2) * BLK] - bary[2]};
+        g += v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    }
+    *G2 = g;
+}
+
+__device__ __forceinline__ double template_norm(const ptmc::TypeInfo &s, int np)
+{
+    double G1 = 0;
+    for (int i = 0; i < np; ++i) G1 += s.points[i][0] * s.points[i][0] + s.points[i][1] * s.points[i][1] + s.points[i][2] * s.points[i][2];
+    return G1;
+}
+
+// every automorphism of every table graph of `type` with the atom's hash; the lanes of a wavefront walk their t-th
+// candidate together (ptm_core.hpp check_graphs)
+template <class Mem>
+__device__ void try_graphs(const Mem &m, const Tables &T, const int8_t *__restrict__ autc, int type, int kind, int np, bool live, uint64_t hash,
+                           const double *bary, double G2, Best &best)
+{
+    const ptmc::TypeInfo &s = T.types[type];
+    const double G1 = template_norm(s, np);
+    const double E0 = (G1 + G2) / 2;
+    int g = s.graph_begin, j = 0;
+    const int g_end = s.graph_begin + s.num_graphs;
+    while (true) {
+        bool has = false;
+        if (live) {
+            while (g < g_end && (T.graphs[g].hash != hash || j >= T.graphs[g].num_aut)) { ++g; j = 0; }
+            has = g < g_end;
+        }
+        if (__ballot(has) == 0)
+            break;
+        if (has) {
+            const int aut = T.graphs[g].aut_begin + j;
+            double q[4], scale = 0;
+            const GraphMap map{m.V, autc + (size_t)aut * ptmc::MAX_PTS};
+            const double rmsd = stage_rmsd(m, s, np, map, bary, G1, G2, E0, q, &scale);
+            if (rmsd < best.rmsd) {
+                best.rmsd = rmsd; best.scale = scale; best.type = type; best.aut = aut; best.kind = kind;
+                best.q[0] = q[0]; best.q[1] = q[1]; best.q[2] = q[2]; best.q[3] = q[3];
+            }
+            ++j;
+        }
+    }
+}
+
+// the atom's own ordered neighbourhood into P / I: separations folded exactly as the ordering pass folded them
+template <bool TRI, class Mem>
+__device__ __forceinline__ void load_neighbourhood(const Mem &m, const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, const DBox &b, const int *__restrict__ nbr, int64_t N, int64_t atom)
+{
+    const double xi = x[atom], yi = y[atom], zi = z[atom];
+    m.P[0 * BLK] = 0; m.P[1 * BLK] = 0; m.P[2 * BLK] = 0;
+    m.I[0 * BLK] = (int)atom;
+    bool open = true;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) { // 15 points serve the largest single-shell template
+        const int j = nbr[(int64_t)k * N + atom];
+        open = open && j >= 0;
+        double dx = 0, dy = 0, dz = 0;
+        if (open) {
+            dx = x[j] - xi; dy = y[j] - yi; dz = z[j] - zi;
+            fold<TRI>(b, dx, dy, dz);
+        }
+        m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
+        m.I[(k + 1) * BLK] = open ? j : -1;
+    }
+}
+
+template <class Mem> __device__ __forceinline__ void load_cluster(const Mem &m, const ShellSet &set, int npt, int64_t N, int64_t atom)
+{
+    for (int k = 0; k < npt; ++k) {
+        m.I[k * BLK] = set.ids[(int64_t)k * N + atom];
+        for (int c = 0; c < 3; ++c) m.P[(k * 3 + c) * BLK] = set.pts[(int64_t)(k * 3 + c) * N + atom];
+    }
+}
+
+template <bool TRI, bool SHELL>
 __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                    int64_t N, DBox b, const int *__restrict__ nbr, const int *__restrict__ types,
                                                    const Tables *__restrict__ tables, const int8_t *__restrict__ autc, int flags,
                                                    MatchIn in, double rmsd_threshold, double *__restrict__ output, int ncol,
                                                    int *__restrict__ ptm_indices, int nind)
 {
-    constexpr int NP = MatchMem::NP;
+    using Mem = MatchMem<SHELL ? 17 : 15>;
+    constexpr int NP = Mem::NP;
     extern __shared__ unsigned char lds[];
     const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (atom >= N)
         return;
-    MatchMem m;
+    Mem m;
     m.P = reinterpret_cast<double *>(lds) + threadIdx.x;
     m.I = reinterpret_cast<int *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
     m.V = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (NP * 24 + 17 * 4)) + threadIdx.x;
     const Tables &T = *tables;
-    // the neighbourhood: separations folded exactly as the ordering pass folded them
-    {
-        const double xi = x[atom], yi = y[atom], zi = z[atom];
-        m.P[0 * BLK] = 0; m.P[1 * BLK] = 0; m.P[2 * BLK] = 0;
-        m.I[0 * BLK] = (int)atom;
-        bool open = true;
-#pragma unroll
-        for (int k = 0; k < NP - 1; ++k) {
-            const int j = nbr[(int64_t)k * N + atom];
-            open = open && j >= 0;
-            double dx = 0, dy = 0, dz = 0;
-            if (open) {
-                dx = x[j] - xi; dy = y[j] - yi; dz = z[j] - zi;
-                fold<TRI>(b, dx, dy, dz);
-            }
-            m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
-            m.I[(k + 1) * BLK] = open ? j : -1;
-        }
-    }
-    // best match so far
-    int best_type = ptmc::T_NONE, best_aut = -1, best_kind = -1;
-    double best_rmsd = INFINITY, best_scale = 0, best_q[4] = {0, 0, 0, 0};
+    load_neighbourhood<TRI>(m, x, y, z, b, nbr, N, atom);
+    Best best;
+    best.type = ptmc::T_NONE; best.aut = -1; best.kind = -1;
+    best.rmsd = INFINITY; best.scale = 0;
+    best.q[0] = best.q[1] = best.q[2] = best.q[3] = 0;
     for (int kind = 0; kind < NKIND; ++kind) {
         const int np = kind_points(kind);
         const bool live = in.ok[kind] != nullptr && in.ok[kind][atom] != 0;
@@ -751,44 +1056,49 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
         if (live) {
             hash = in.hash[kind][atom];
             for (int i = 0; i < np; ++i) m.V[in.label[kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
-            for (int i = 0; i < np; ++i) { bary[0] += m.P[(i * 3 + 0) * BLK]; bary[1] += m.P[(i * 3 + 1) * BLK]; bary[2] += m.P[(i * 3 + 2) * BLK]; }
-            bary[0] /= np; bary[1] /= np; bary[2] /= np;
-            for (int i = 0; i < np; ++i) {
-                const double v[3] = {m.P[(i * 3 + 0) * BLK] - bary[0], m.P[(i * 3 + 1) * BLK] - bary[1], m.P[(i * 3 + 2) * BLK] - bary[2]};
-                G2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-            }
+            barycentre(m, np, bary, &G2);
         }
         const int ntypes = kind == K_FCC ? 3 : 1;
         for (int tk = 0; tk < ntypes; ++tk) {
             const int type = kind == K_SC ? ptmc::T_SC : kind == K_BCC ? ptmc::T_BCC : tk == 0 ? ptmc::T_FCC : tk == 1 ? ptmc::T_HCP : ptmc::T_ICO;
             const int bit = type == ptmc::T_SC ? ptmc::CHECK_SC : type == ptmc::T_BCC ? ptmc::CHECK_BCC : type == ptmc::T_FCC ? ptmc::CHECK_FCC
                           : type == ptmc::T_HCP ? ptmc::CHECK_HCP : ptmc::CHECK_ICO;
-            if (!(flags & bit))
-                continue;
-            const ptmc::TypeInfo &s = T.types[type];
-            double G1 = 0;
-            for (int i = 0; i < np; ++i) G1 += s.points[i][0] * s.points[i][0] + s.points[i][1] * s.points[i][1] + s.points[i][2] * s.points[i][2];
-            const double E0 = (G1 + G2) / 2;
-            // cursor over (graph with the atom's hash, automorphism): every lane evaluates its t-th candidate together
-            int g = s.graph_begin, j = 0;
-            const int g_end = s.graph_begin + s.num_graphs;
-            while (true) {
-                bool has = false;
+            if (flags & bit)
+                try_graphs(m, T, autc, type, kind, np, live, hash, bary, G2, best);
+        }
+    }
+    if constexpr (SHELL) {
+        if (flags & (ptmc::CHECK_DCUB | ptmc::CHECK_DHEX)) { // the 17-point cluster, inner atoms coloured
+            const bool live = in.ok[K_DC] != nullptr && in.ok[K_DC][atom] != 0;
+            if (__ballot(live) != 0) {
+                double bary[3] = {0, 0, 0}, G2 = 0;
+                uint64_t hash = 0;
                 if (live) {
-                    while (g < g_end && (T.graphs[g].hash != hash || j >= T.graphs[g].num_aut)) { ++g; j = 0; }
-                    has = g < g_end;
+                    load_cluster(m, in.dc, 17, N, atom);
+                    hash = in.hash[K_DC][atom];
+                    for (int i = 0; i < 17; ++i) m.V[in.label[K_DC][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+                    barycentre(m, 17, bary, &G2);
                 }
-                if (__ballot(has) == 0)
-                    break;
-                if (has) {
-                    const int aut = T.graphs[g].aut_begin + j;
+                if (flags & ptmc::CHECK_DCUB) try_graphs(m, T, autc, ptmc::T_DCUB, K_DC, 17, live, hash, bary, G2, best);
+                if (flags & ptmc::CHECK_DHEX) try_graphs(m, T, autc, ptmc::T_DHEX, K_DC, 17, live, hash, bary, G2, best);
+            }
+        }
+        if (flags & ptmc::CHECK_GRAPHENE) { // 10 points, no graph: the eight assignments directly (ptm_core.hpp match_graphene)
+            const bool live = in.gr.ok[atom] != 0;
+            if (__ballot(live) != 0 && live) {
+                load_cluster(m, in.gr, 10, N, atom);
+                double bary[3], G2;
+                barycentre(m, 10, bary, &G2);
+                const ptmc::TypeInfo &s = T.types[ptmc::T_GRAPHENE];
+                const double G1 = template_norm(s, 10), E0 = (G1 + G2) / 2;
+                for (int t = 0; t < 8; ++t) {
+                    const GrapheneMap map{7 - t};
                     double q[4], scale = 0;
-                    const double rmsd = stage_rmsd(m, s, np, autc + (size_t)aut * ptmc::MAX_PTS, bary, G1, G2, E0, q, &scale);
-                    if (rmsd < best_rmsd) {
-                        best_rmsd = rmsd; best_scale = scale; best_type = type; best_aut = aut; best_kind = kind;
-                        best_q[0] = q[0]; best_q[1] = q[1]; best_q[2] = q[2]; best_q[3] = q[3];
+                    const double rmsd = stage_rmsd(m, s, 10, map, bary, G1, G2, E0, q, &scale);
+                    if (rmsd < best.rmsd) {
+                        best.rmsd = rmsd; best.scale = scale; best.type = ptmc::T_GRAPHENE; best.aut = 7 - t; best.kind = K_GR;
+                        best.q[0] = q[0]; best.q[1] = q[1]; best.q[2] = q[2]; best.q[3] = q[3];
                     }
-                    ++j;
                 }
             }
         }
@@ -796,11 +1106,26 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
     // ---- outputs (ptm_core.hpp index_atom, second half)
     int type = 0, ordering = 0, num_out = 0;
     double o_rmsd = 0, o_inter = 0, o_q[4] = {0, 0, 0, 0};
-    if (best_type != ptmc::T_NONE) {
-        const ptmc::TypeInfo &s = T.types[best_type];
+    if (best.type != ptmc::T_NONE) {
+        const ptmc::TypeInfo &s = T.types[best.type];
         const int np = s.num_nbrs + 1;
-        const int8_t *ac = autc + (size_t)best_aut * ptmc::MAX_PTS;
-        for (int i = 0; i < np; ++i) m.V[in.label[best_kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+        // the atoms of the winning cluster, and the map from template points to them
+        if constexpr (SHELL) {
+            if (best.kind == K_DC) load_cluster(m, in.dc, 17, N, atom);
+            else if (best.kind == K_GR) load_cluster(m, in.gr, 10, N, atom);
+            else load_neighbourhood<TRI>(m, x, y, z, b, nbr, N, atom);
+        }
+        int8_t pick[ptmc::MAX_PTS]; // pick[i] = cluster point matched to template point i
+        if (best.kind == K_GR) {
+            const GrapheneMap map{best.aut};
+#pragma unroll
+            for (int i = 0; i < ptmc::MAX_PTS; ++i) pick[i] = (int8_t)(i < 10 ? map(i) : 0);
+        } else {
+            const int8_t *ac = autc + (size_t)best.aut * ptmc::MAX_PTS;
+            for (int i = 0; i < np; ++i) m.V[in.label[best.kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+#pragma unroll
+            for (int i = 0; i < ptmc::MAX_PTS; ++i) pick[i] = (int8_t)(i < np ? m.V[ac[i] * BLK] : 0);
+        }
         // alloy ordering (ptm_core.hpp alloy_type); without a type column every atom is the same species
         ordering = ptmc::ALLOY_PURE;
         if (types) {
@@ -821,26 +1146,30 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
             else if (!binary) ordering = ptmc::ALLOY_NONE;
             else {
                 uint32_t bin = 0; // bit i: template point i holds the other species
-                for (int i = 0; i < np; ++i)
-                    if (types[m.I[m.V[ac[i] * BLK] * BLK]] != n0) bin |= 1u << i;
-                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < ptmc::MAX_PTS; ++i)
+                    if (i < np && types[m.I[pick[i] * BLK]] != n0) bin |= 1u << i;
+                uint32_t lowest = 0xFFFFFFFFu;
                 for (int r = 0; r < s.num_maps; ++r) {
                     const int8_t *mp = T.maps[s.map_begin + r];
                     uint32_t code = 0;
                     for (int i = 0; i < np; ++i) code |= ((bin >> i) & 1u) << mp[i];
-                    best = code < best ? code : best;
+                    lowest = code < lowest ? code : lowest;
                 }
                 ordering = ptmc::ALLOY_NONE;
-                if (best_type == ptmc::T_FCC) {
-                    if (best == 0x00000db6u) ordering = ptmc::ALLOY_L10;
-                    if (best == 0x00000492u) ordering = ptmc::ALLOY_L12_CU;
-                    if (best == 0x00001ffeu) ordering = ptmc::ALLOY_L12_AU;
+                if (best.type == ptmc::T_FCC) {
+                    if (lowest == 0x00000db6u) ordering = ptmc::ALLOY_L10;
+                    if (lowest == 0x00000492u) ordering = ptmc::ALLOY_L12_CU;
+                    if (lowest == 0x00001ffeu) ordering = ptmc::ALLOY_L12_AU;
                 }
-                if (ordering == ptmc::ALLOY_NONE && best_type == ptmc::T_BCC) {
+                // shell structure: the inner sites all differ from the centre, the outer ones all agree
+                const int inner = best.type == ptmc::T_BCC ? 8 : (best.type == ptmc::T_DCUB || best.type == ptmc::T_DHEX) ? 4
+                                : best.type == ptmc::T_GRAPHENE ? 3 : 0;
+                if (ordering == ptmc::ALLOY_NONE && inner) {
                     bool shell = true;
-                    for (int i = 1; i < 9; ++i) shell = shell && ((bin >> i) & 1u) != (bin & 1u);
-                    for (int i = 9; i < np; ++i) shell = shell && ((bin >> i) & 1u) == (bin & 1u);
-                    if (shell) ordering = ptmc::ALLOY_B2;
+                    for (int i = 1; i < inner + 1; ++i) shell = shell && ((bin >> i) & 1u) != (bin & 1u);
+                    for (int i = inner + 1; i < np; ++i) shell = shell && ((bin >> i) & 1u) == (bin & 1u);
+                    if (shell) ordering = best.type == ptmc::T_BCC ? ptmc::ALLOY_B2 : best.type == ptmc::T_GRAPHENE ? ptmc::ALLOY_BN : ptmc::ALLOY_SIC;
                 }
             }
         }
@@ -849,18 +1178,18 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
         int bi = -1;
         for (int i = 0; i < s.num_conv; ++i) {
             const double *gq = T.gens[s.gen_begin + i];
-            const double t = fabs(best_q[0] * gq[0] - best_q[1] * gq[1] - best_q[2] * gq[2] - best_q[3] * gq[3]);
+            const double t = fabs(best.q[0] * gq[0] - best.q[1] * gq[1] - best.q[2] * gq[2] - best.q[3] * gq[3]);
             if (t > mx) { mx = t; bi = i; }
         }
-        // matched atoms in template order: ids[perm[i]] = I[map(i)]
+        // matched atoms in template order: ids[perm[i]] = I[pick[i]]
         int ids_local[ptmc::MAX_PTS];
 #pragma unroll
-        for (int i = 0; i < ptmc::MAX_PTS; ++i) ids_local[i] = i < np ? m.I[m.V[ac[i] * BLK] * BLK] : -1;
+        for (int i = 0; i < ptmc::MAX_PTS; ++i) ids_local[i] = i < np ? m.I[pick[i] * BLK] : -1;
         if (bi >= 0) {
             double f[4];
-            ptmc::quat_mul(best_q, T.gens[s.gen_begin + bi], f);
+            ptmc::quat_mul(best.q, T.gens[s.gen_begin + bi], f);
             if (f[0] < 0) { f[0] = -f[0]; f[1] = -f[1]; f[2] = -f[2]; f[3] = -f[3]; }
-            best_q[0] = f[0]; best_q[1] = f[1]; best_q[2] = f[2]; best_q[3] = f[3];
+            best.q[0] = f[0]; best.q[1] = f[1]; best.q[2] = f[2]; best.q[3] = f[3];
             const int8_t *perm = T.maps[s.conv_begin + bi];
 #pragma unroll
             for (int i = 0; i < ptmc::MAX_PTS; ++i)
@@ -870,10 +1199,10 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
             for (int i = 0; i < ptmc::MAX_PTS; ++i)
                 if (i < np) m.I[i * BLK] = ids_local[i];
         }
-        type = best_type;
-        o_rmsd = best_rmsd;
-        o_inter = ptmc::interatomic_distance(best_type, best_scale);
-        o_q[0] = best_q[0]; o_q[1] = best_q[1]; o_q[2] = best_q[2]; o_q[3] = best_q[3];
+        type = best.type;
+        o_rmsd = best.rmsd;
+        o_inter = ptmc::interatomic_distance(best.type, best.scale);
+        o_q[0] = best.q[0]; o_q[1] = best.q[1]; o_q[2] = best.q[2]; o_q[3] = best.q[3];
         num_out = np;
     }
     if (o_rmsd > rmsd_threshold || type == ptmc::T_NONE) { // src/polyhedral_template_matching.cpp:287-291
@@ -948,57 +1277,96 @@ int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64
 size_t ptm_stage_bytes(int64_t N)
 {
     const size_t n = (size_t)((N + 255) & ~int64_t(255));
-    return (size_t)ptms::NKIND * n * (ptms::MAXF * 2 + 1 + 8 + 17 + 1) + 4096;
+    const size_t per_kind = ptms::MAXF * 2 + 1 + 8 + 17 + 1;                 // facets, status, hash, label, ok
+    const size_t clusters = (17 * 4 + 17 * 24 + 1) + (10 * 4 + 10 * 24 + 1); // diamond and graphene clusters: ids, points, ok
+    return n * (ptms::NCANON * per_kind + clusters) + 4096;
 }
 
-int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int *dtypes,
-                      const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol, int *dind,
-                      int nind, unsigned char *work, hipStream_t st)
+int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int8_t *orders,
+                      const int *dtypes, const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol,
+                      int *dind, int nind, unsigned char *work, hipStream_t st)
 {
     using namespace ptms;
     const size_t n = (size_t)((N + 255) & ~int64_t(255));
     HullOut ho;
-    CanonOut co[NKIND];
+    uint16_t *facets[NCANON];
+    int8_t *status[NCANON];
+    CanonOut co[NCANON];
     MatchIn mi;
+    ShellSet dc, gr;
     unsigned char *p = work;
-    for (int k = 0; k < NKIND; ++k) { co[k].hash = reinterpret_cast<uint64_t *>(p); p += n * 8; }
-    for (int k = 0; k < NKIND; ++k) { ho.facets[k] = reinterpret_cast<uint16_t *>(p); p += n * MAXF * 2; }
-    for (int k = 0; k < NKIND; ++k) { ho.status[k] = reinterpret_cast<int8_t *>(p); p += n; }
-    for (int k = 0; k < NKIND; ++k) { co[k].label = reinterpret_cast<int8_t *>(p); p += n * 17; }
-    for (int k = 0; k < NKIND; ++k) { co[k].ok = reinterpret_cast<int8_t *>(p); p += n; }
-    const int want[NKIND] = {ptmc::CHECK_SC, ptmc::CHECK_FCC | ptmc::CHECK_HCP | ptmc::CHECK_ICO, ptmc::CHECK_BCC};
+    // 8-byte items first, then 4, 2, 1: every array stays aligned
+    for (int k = 0; k < NCANON; ++k) { co[k].hash = reinterpret_cast<uint64_t *>(p); p += n * 8; }
+    dc.pts = reinterpret_cast<double *>(p); p += n * 17 * 24;
+    gr.pts = reinterpret_cast<double *>(p); p += n * 10 * 24;
+    dc.ids = reinterpret_cast<int *>(p); p += n * 17 * 4;
+    gr.ids = reinterpret_cast<int *>(p); p += n * 10 * 4;
+    for (int k = 0; k < NCANON; ++k) { facets[k] = reinterpret_cast<uint16_t *>(p); p += n * MAXF * 2; }
+    for (int k = 0; k < NCANON; ++k) { status[k] = reinterpret_cast<int8_t *>(p); p += n; }
+    for (int k = 0; k < NCANON; ++k) { co[k].label = reinterpret_cast<int8_t *>(p); p += n * 17; }
+    for (int k = 0; k < NCANON; ++k) { co[k].ok = reinterpret_cast<int8_t *>(p); p += n; }
+    dc.ok = reinterpret_cast<int8_t *>(p); p += n;
+    gr.ok = reinterpret_cast<int8_t *>(p); p += n;
+    for (int k = 0; k < NKIND; ++k) { ho.facets[k] = facets[k]; ho.status[k] = status[k]; }
+    const int want[NCANON] = {ptmc::CHECK_SC, ptmc::CHECK_FCC | ptmc::CHECK_HCP | ptmc::CHECK_ICO, ptmc::CHECK_BCC, ptmc::CHECK_DCUB | ptmc::CHECK_DHEX};
+    const int single = want[K_SC] | want[K_FCC] | want[K_BCC];
+    const bool shell = (flags & (want[K_DC] | ptmc::CHECK_GRAPHENE)) != 0;
     const dim3 grid((unsigned)((N + BLK - 1) / BLK)), block(BLK);
-    {
+    extern const ptmc::Tables *ptm_host_tables();
+    const ptmc::Tables &H = *ptm_host_tables();
+    if (flags & single) {
         ProfRange pr("k_ptm_hull", st);
         if (b.tri)
             hipLaunchKernelGGL(k_ptm_hull<true>, grid, block, HullMem<15>::BYTES, st, dx, dy, dz, N, b, nbr, flags, ho);
         else
             hipLaunchKernelGGL(k_ptm_hull<false>, grid, block, HullMem<15>::BYTES, st, dx, dy, dz, N, b, nbr, flags, ho);
     }
+    if (flags & want[K_DC]) {
+        ProfRange pr("k_ptm_shell", st);
+        const size_t lds = (size_t)BLK * 17 * 28;
+        if (b.tri)
+            hipLaunchKernelGGL((k_ptm_shell<true, 4, 3>), grid, block, lds, st, dx, dy, dz, N, b, nbr, orders, dc);
+        else
+            hipLaunchKernelGGL((k_ptm_shell<false, 4, 3>), grid, block, lds, st, dx, dy, dz, N, b, nbr, orders, dc);
+        hipLaunchKernelGGL(k_ptm_hull_shell, grid, block, HullMem<17>::BYTES, st, N, dc, H.types[ptmc::T_DCUB].max_degree, facets[K_DC], status[K_DC]);
+    }
+    if (flags & ptmc::CHECK_GRAPHENE) {
+        ProfRange pr("k_ptm_shell", st);
+        const size_t lds = (size_t)BLK * 10 * 28;
+        if (b.tri)
+            hipLaunchKernelGGL((k_ptm_shell<true, 3, 2>), grid, block, lds, st, dx, dy, dz, N, b, nbr, orders, gr);
+        else
+            hipLaunchKernelGGL((k_ptm_shell<false, 3, 2>), grid, block, lds, st, dx, dy, dz, N, b, nbr, orders, gr);
+    }
     {
         ProfRange pr("k_ptm_canon", st);
-        // (max_degree, required degree) per kind from the generated tables: host copies are needed, the caller passes them in dt's twin
-        extern const ptmc::Tables *ptm_host_tables();
-        const ptmc::Tables &H = *ptm_host_tables();
         if (flags & want[K_SC])
-            hipLaunchKernelGGL(k_ptm_canon<6>, grid, block, CanonMem<6>::BYTES, st, N, ho.facets[K_SC], ho.status[K_SC], H.types[ptmc::T_SC].max_degree, 4, co[K_SC]);
+            hipLaunchKernelGGL((k_ptm_canon<6, false>), grid, block, CanonMem<6>::BYTES, st, N, facets[K_SC], status[K_SC], H.types[ptmc::T_SC].max_degree, 4, co[K_SC]);
         if (flags & want[K_FCC])
-            hipLaunchKernelGGL(k_ptm_canon<12>, grid, block, CanonMem<12>::BYTES, st, N, ho.facets[K_FCC], ho.status[K_FCC], H.types[ptmc::T_FCC].max_degree, 0, co[K_FCC]);
+            hipLaunchKernelGGL((k_ptm_canon<12, false>), grid, block, CanonMem<12>::BYTES, st, N, facets[K_FCC], status[K_FCC], H.types[ptmc::T_FCC].max_degree, 0, co[K_FCC]);
         if (flags & want[K_BCC])
-            hipLaunchKernelGGL(k_ptm_canon<14>, grid, block, CanonMem<14>::BYTES, st, N, ho.facets[K_BCC], ho.status[K_BCC], H.types[ptmc::T_BCC].max_degree, 0, co[K_BCC]);
+            hipLaunchKernelGGL((k_ptm_canon<14, false>), grid, block, CanonMem<14>::BYTES, st, N, facets[K_BCC], status[K_BCC], H.types[ptmc::T_BCC].max_degree, 0, co[K_BCC]);
+        if (flags & want[K_DC])
+            hipLaunchKernelGGL((k_ptm_canon<16, true>), grid, block, CanonMem<16>::BYTES, st, N, facets[K_DC], status[K_DC], H.types[ptmc::T_DCUB].max_degree, 0, co[K_DC]);
     }
-    for (int k = 0; k < NKIND; ++k) {
+    for (int k = 0; k < NCANON; ++k) {
         const bool on = (flags & want[k]) != 0;
         mi.hash[k] = on ? co[k].hash : nullptr;
         mi.label[k] = on ? co[k].label : nullptr;
         mi.ok[k] = on ? co[k].ok : nullptr;
     }
+    mi.dc = dc;
+    mi.gr = gr;
     {
         ProfRange pr("k_ptm_match", st);
-        if (b.tri)
-            hipLaunchKernelGGL(k_ptm_match<true>, grid, block, MatchMem::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dautc, flags, mi, rmsd_threshold, dout, ncol, dind, nind);
-        else
-            hipLaunchKernelGGL(k_ptm_match<false>, grid, block, MatchMem::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dautc, flags, mi, rmsd_threshold, dout, ncol, dind, nind);
+#define MDH_PTM_MATCH(TRI, SHELL)                                                                                                        \
+    hipLaunchKernelGGL((k_ptm_match<TRI, SHELL>), grid, block, MatchMem<SHELL ? 17 : 15>::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dautc, \
+                       flags, mi, rmsd_threshold, dout, ncol, dind, nind)
+        if (b.tri && shell) MDH_PTM_MATCH(true, true);
+        else if (b.tri) MDH_PTM_MATCH(true, false);
+        else if (shell) MDH_PTM_MATCH(false, true);
+        else MDH_PTM_MATCH(false, false);
+#undef MDH_PTM_MATCH
     }
     return MDH_OK;
 }
