@@ -1242,7 +1242,7 @@ void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
 }
 
 static int g_order_cap = 15;
-void ptm_debug_order_cap(int cap) { g_order_cap = cap <= 5 ? 5 : 15; }
+void ptm_debug_order_cap(int cap) { g_order_cap = cap <= 5 ? 5 : cap <= 10 ? 10 : 15; }
 
 int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
                      int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st)
@@ -1260,6 +1260,15 @@ int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64
             hipLaunchKernelGGL((k_ptm_order_faces<true, 5, false>), grid, block, order_lds_bytes<5>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
         else
             hipLaunchKernelGGL((k_ptm_order_faces<false, 5, false>), grid, block, order_lds_bytes<5>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        if (b.tri)
+            hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        else
+            hipLaunchKernelGGL((k_ptm_order_faces<false, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    } else if (g_order_cap == 10) {
+        if (b.tri)
+            hipLaunchKernelGGL((k_ptm_order_faces<true, 10, false>), grid, block, order_lds_bytes<10>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+        else
+            hipLaunchKernelGGL((k_ptm_order_faces<false, 10, false>), grid, block, order_lds_bytes<10>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
         if (b.tri)
             hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
         else

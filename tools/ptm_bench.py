@@ -1,7 +1,7 @@
 """Time mdh_ptm on device-resident inputs: python tools/ptm_bench.py [cells]  (fcc cells per axis, default 64 -> 1.05 M atoms)"""
-import sys, time
+import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mdapy_amd as mp
 from mdapy_amd import _ptm, _lib
 from mdapy_amd.build_lattice import lattice_positions
@@ -20,6 +20,7 @@ out = torch.zeros((N, 8), dtype=torch.float64, device="cuda"); ind = torch.zeros
 b = np.asarray(box, float); b = b if b.shape == (3, 3) else np.diag(b)
 import ctypes
 L = _lib.lib()
+if len(sys.argv) > 3: L.mdh_debug_set_ptm_order_cap(int(sys.argv[3]))
 structures = sys.argv[2].split("+") if len(sys.argv) > 2 else ["fcc-hcp-bcc", "all"]
 for structure in structures:
     L.mdh_prof_reset(); L.mdh_prof_enable(1)
