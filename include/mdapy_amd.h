@@ -70,8 +70,8 @@ int mdh_debug_set_neighbor_variant(int variant);
  * plan8 = {tile cells in x/y, in z, halo atoms per tile, LDS bytes, box full of atoms, 1000 * atoms per cell,
  * cells of the occupied region, 1 if a plan was made since the last query}. */
 int mdh_debug_neighbor_plan(int *plan8);
-/* test hook: vertex capacity of the first pass of the PTM neighbour ordering (15 default; 5 sends most atoms through the
- * second, 28-vertex pass, whose results must be the same) */
+/* test hook: vertex capacity of the first pass of the PTM neighbour ordering (10 default, 15; 5 sends most atoms through
+ * the second, 28-vertex pass, whose results must be the same) */
 int mdh_debug_set_ptm_order_cap(int cap);
 /* test hook: out4[k] = smallest double d with floor(d/L + 0.5) >= k-1 (k = 0..3) for a periodic orthogonal
  * axis of length L — the exact decision points that let the kernels replace floor(d/L+0.5) by compares. */

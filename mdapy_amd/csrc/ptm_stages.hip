@@ -1241,7 +1241,7 @@ void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
     }
 }
 
-static int g_order_cap = 15;
+static int g_order_cap = 10; // polygon vertices in the first pass: 10 -> 4 workgroups per CU (15 -> 3, 22 % slower); larger faces take the second pass
 void ptm_debug_order_cap(int cap) { g_order_cap = cap <= 5 ? 5 : cap <= 10 ? 10 : 15; }
 
 int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,

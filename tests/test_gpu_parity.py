@@ -527,15 +527,16 @@ def test_ptm_ordering_second_pass_gives_the_same_rows():
     idx, dist = np.zeros((N, 18), np.int32), np.zeros((N, 18))
     _fast_knn.knn(x, y, z, box, ORG0, PBC, 18, idx, dist, 1)
     outs = []
-    for cap in (15, 5):
+    for cap in (15, 10, 5):
         _lib.lib().mdh_debug_set_ptm_order_cap(cap)
         try:
             o, i = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
             _ptm.get_ptm("all", x, y, z, box, ORG0, PBC, idx, None, 0.1, o, i)
             outs.append((o, i))
         finally:
-            _lib.lib().mdh_debug_set_ptm_order_cap(15)
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+            _lib.lib().mdh_debug_set_ptm_order_cap(10)
+    for o, i in outs[1:]:
+        assert np.array_equal(outs[0][0], o) and np.array_equal(outs[0][1], i)
     assert (outs[0][0][:, 0] == 1).mean() > 0.9
 
 
