@@ -326,6 +326,17 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 centre_cell = hx >= 1 && hx <= TXY && hy >= 1 && hy <= TXY && hz >= 1 && hz <= TZ && g0 < g.nc[0] && g1 < g.nc[1] && g2 < g.nc[2];
             }
         }
+        // the first four atoms of the cell are requested BEFORE the workgroup scan: their latency overlaps the scan's two
+        // barriers instead of following them (the loads do not need the LDS offsets, only the stores do)
+        double pa[4], pb[4], pc[4];
+        int pd[4];
+        unsigned char pm[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int q = src + min(v, max(cnt - 1, 0));
+            if (cnt > 0) { pa[v] = xs[q]; pb[v] = ys[q]; pc[v] = zs[q]; pd[v] = order[q]; pm[v] = mvs[q]; }
+            else { pa[v] = 0; pb[v] = 0; pc[v] = 0; pd[v] = 0; pm[v] = NEUTRAL; }
+        }
         int total2;
         const int off2 = excl_scan_block(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
         const int total = total2 & 0xffff, ncentres = total2 >> 16;
@@ -353,8 +364,11 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 unsigned char m[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { // twenty independent loads in flight
-                    const int q = src + min(k + v, cnt - 1);
-                    a[v] = xs[q]; bb[v] = ys[q]; c[v] = zs[q]; d[v] = order[q]; m[v] = mvs[q];
+                    if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = pm[v]; }
+                    else {
+                        const int q = src + min(k + v, cnt - 1);
+                        a[v] = xs[q]; bb[v] = ys[q]; c[v] = zs[q]; d[v] = order[q]; m[v] = mvs[q];
+                    }
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
