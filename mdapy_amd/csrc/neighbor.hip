@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
 
 // mop-up of the tiles the wave kernel listed (halo over the LDS budget, atoms far outside the box): a workgroup per listed
 // tile, its threads over the tile's centre atoms — the cost follows the number of listed tiles, not N
-template <int MODE>
+template <bool TRI, int MODE>
 __global__ __launch_bounds__(256) void k_neighbor_tiles(const double *__restrict__ xs, const double *__restrict__ ys,
                                                         const double *__restrict__ zs, const int *__restrict__ order,
                                                         const int *__restrict__ cell_start, DBox b, Grid g, double rc,
@@ -409,10 +409,10 @@ __global__ __launch_bounds__(256) void k_neighbor_tiles(const double *__restrict
                 for (int p = s + sub; p < e; p += tpc) {
                     double xi = xs[p], yi = ys[p], zi = zs[p];
                     if (b.anypbc)
-                        wrap<false>(b, xi, yi, zi);
+                        wrap<TRI>(b, xi, yi, zi);
                     int c0, c1, c2;
-                    cell_coords<false>(b, g, xi, yi, zi, c0, c1, c2);
-                    best = max(best, neighbor_one<false, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+                    cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+                    best = max(best, neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
                 }
             }
         }
@@ -434,8 +434,10 @@ static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const
         hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else
         hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
-    if (tf.list && !b.tri) // the listed tiles (at most list_cap; a longer list falls back to the flag scan above via tf.list == nullptr)
-        hipLaunchKernelGGL((k_neighbor_tiles<MODE>), dim3(512), block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+    if (tf.list && b.tri) // the listed tiles (at most list_cap; a longer list falls back to the flag scan above via tf.list == nullptr)
+        hipLaunchKernelGGL((k_neighbor_tiles<true, MODE>), dim3(512), block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+    else if (tf.list)
+        hipLaunchKernelGGL((k_neighbor_tiles<false, MODE>), dim3(512), block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
 }
 
 // ----------------------------------------------------------------------------
@@ -595,7 +597,7 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
     MDH_HIP(hipMemsetAsync(cg.flags + 2, 0, sizeof(int) * 2, st)); // the tile lists of this pass (flags[0], unwrapped input, stays)
     TileFilter tf{};
     bool done = false;
-    if (g_neighbor_variant == 0 && !b.tri) { // tile kernel; the thread-per-atom code below then only mops up what it listed
+    if (g_neighbor_variant == 0) { // tile kernel (orthogonal boxes, and triclinic ones periodic along all three vectors); the thread-per-atom code below then only mops up what it listed
         GridStats gs;
         MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
         const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc);

@@ -98,16 +98,20 @@ __device__ __forceinline__ int combine_codes(int cc, int ca)
 // the reference's squared distance of one pair: raw x[j] - wrapped x[i] (neighbor.cpp:164-166), minimum image
 // d - L*floor(d/L+0.5) with the image number n taken from the code (box.h:120-124; L*n exact, d - L*0 == d), then
 // (dx*dx + dy*dy) + dz*dz (neighbor.cpp:170)
-template <bool GENERAL>
+// KIND 0: both atoms in the box and the pair inside it (no image); 1: orthogonal box, image number from the code;
+// 2: triclinic box, the reference's fold through fractional coordinates (box.h:99-114) — the image is whatever it rounds to
+template <int KIND>
 __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, double zj, double xi, double yi, double zi,
                                            int code)
 {
     double dx = xj - xi, dy = yj - yi, dz = zj - zi;
-    if (GENERAL) {
+    if (KIND == 1) {
         dx = dx - b.h[0] * (double)((code & 7) - 2);
         dy = dy - b.h[4] * (double)(((code >> 3) & 7) - 2);
         dz = dz - b.h[8] * (double)(((code >> 6) & 7) - 2);
     }
+    if (KIND == 2)
+        pbc<true>(b, dx, dy, dz);
     return dx * dx + dy * dy + dz * dz;
 }
 
@@ -212,7 +216,7 @@ __device__ __forceinline__ double sqrt_f64(double x)
 }
 
 // the same run decided by the reference's double-precision expression (threads with a pair inside the decision band)
-template <bool SELF>
+template <bool SELF, bool TRI>
 __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy, const double *__restrict__ lz,
                                                  const unsigned short *__restrict__ lsh, const DBox &b, double rcsq, int k0, int len,
                                                  int li, double xi, double yi, double zi)
@@ -224,7 +228,7 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
         bool h = false;
         if (j < len) {
             const double2 cj = lxy[k];
-            const double d2 = exact_d2<true>(b, cj.x, cj.y, lz[k], xi, yi, zi, lsh[k]);
+            const double d2 = exact_d2<TRI ? 2 : 1>(b, cj.x, cj.y, lz[k], xi, yi, zi, TRI ? 0 : lsh[k]);
             h = (d2 <= rcsq) && (!SELF || k != li); // neighbor.cpp:162,171
         }
         m = m + m + (h ? 1u : 0u);
@@ -236,7 +240,11 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
 // parent != nullptr: second pass over the tiles the first pass listed (halo over the LDS budget): the same tiling cut into
 // nsub slices along z (this launch's TZ = parent's TZ / nsub); what still does not fit goes to `flagged` (counter
 // flags[flag_slot]) and from there to the thread-per-atom code
-template <bool COUNT>
+// TRI: triclinic box, periodic along all three vectors.  Cells are parallelepipeds in fractional coordinates; the staged
+// single-precision coordinates are Cartesian, relative to the tile's corner, of the WRAPPED atom shifted by the lattice
+// vectors its cell is away from the tile; every decision inside the band and every written distance goes through the
+// reference's fractional fold.
+template <bool COUNT, bool TRI>
 __global__ __launch_bounds__(NT) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
@@ -351,10 +359,22 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         if (tid < NH) hc[tid] = (unsigned)off0 | ((unsigned)cnt << 16);
         // ---- stage this cell's atoms
         if (cnt > 0) {
-            const double X0 = b.o[0] + (double)(T0 - 1) * cw, Y0 = b.o[1] + (double)(T1 - 1) * cw, Z0 = b.o[2] + (double)(T2 - 1) * cw;
+            double X0, Y0, Z0, XS, YS, ZS;
             const int code0 = combine_codes(img, NEUTRAL); // an atom inside the box (image code 0): the cell's own shift
-            const double XS = X0 + b.h[0] * (double)((code0 & 7) - 2), YS = Y0 + b.h[4] * (double)(((code0 >> 3) & 7) - 2),
-                         ZS = Z0 + b.h[8] * (double)(((code0 >> 6) & 7) - 2);
+            if (TRI) { // corner of the tile's halo and the cell's lattice shift, through the cell vectors (rows of h)
+                // (cell k of axis d starts at the fraction k * rc / thickness_d: cells of perpendicular width rc, grid.hpp)
+                const double f0 = (double)(T0 - 1) * (cw / b.thick[0]) + (double)((code0 & 7) - 2);
+                const double f1 = (double)(T1 - 1) * (cw / b.thick[1]) + (double)(((code0 >> 3) & 7) - 2);
+                const double f2 = (double)(T2 - 1) * (cw / b.thick[2]) + (double)(((code0 >> 6) & 7) - 2);
+                XS = b.o[0] + f0 * b.h[0] + f1 * b.h[3] + f2 * b.h[6];
+                YS = b.o[1] + f0 * b.h[1] + f1 * b.h[4] + f2 * b.h[7];
+                ZS = b.o[2] + f0 * b.h[2] + f1 * b.h[5] + f2 * b.h[8];
+                X0 = XS; Y0 = YS; Z0 = ZS;
+            } else {
+                X0 = b.o[0] + (double)(T0 - 1) * cw; Y0 = b.o[1] + (double)(T1 - 1) * cw; Z0 = b.o[2] + (double)(T2 - 1) * cw;
+                XS = X0 + b.h[0] * (double)((code0 & 7) - 2); YS = Y0 + b.h[4] * (double)(((code0 >> 3) & 7) - 2);
+                ZS = Z0 + b.h[8] * (double)(((code0 >> 6) & 7) - 2);
+            }
             const float flo = (float)(-1.5 * cw);
             const float fhx = (float)(((double)HXY + 1.5) * cw), fhz = (float)(((double)HZ + 1.5) * cw);
             bool general = code0 != NEUTRAL3, far = false;
@@ -374,8 +394,15 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 for (int v = 0; v < 4; ++v) {
                     if (k + v < cnt) {
                         int code = code0;
-                        float ux = (float)(a[v] - XS), uy = (float)(bb[v] - YS), uz = (float)(c[v] - ZS);
-                        if (m[v] != NEUTRAL) { // an atom handed in outside the box on a periodic axis: its own image number on top
+                        float ux, uy, uz;
+                        if (TRI) { // the atom as the cell grid saw it (wrapped), in the tile's frame
+                            double wx = a[v], wy = bb[v], wz = c[v];
+                            wrap<true>(b, wx, wy, wz);
+                            ux = (float)(wx - XS); uy = (float)(wy - YS); uz = (float)(wz - ZS);
+                        } else {
+                            ux = (float)(a[v] - XS); uy = (float)(bb[v] - YS); uz = (float)(c[v] - ZS);
+                        }
+                        if (!TRI && m[v] != NEUTRAL) { // an atom handed in outside the box on a periodic axis: its own image number on top
                             code = combine_codes(img, m[v]);
                             ux = (float)((a[v] - b.h[0] * (double)((code & 7) - 2)) - X0);
                             uy = (float)((bb[v] - b.h[4] * (double)(((code >> 3) & 7) - 2)) - Y0);
@@ -438,12 +465,12 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 const double2 ci = lxy[li];
                 double xi = ci.x, yi = ci.y, zi = lz[li];
                 if (b.anypbc) // neighbor.cpp:139-142
-                    wrap<false>(b, xi, yi, zi);
+                    wrap<TRI>(b, xi, yi, zi);
                 if (__builtin_expect(!(w > T), 0)) { // a pair inside the decision band: this centre again in double precision
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        if (r == 4) mk[r] = scan_run_f64<true>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
-                        else mk[r] = scan_run_f64<false>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
                     }
                 }
                 int hits = 0;
@@ -504,12 +531,15 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                         const double jza = lz[kka], jzb = lz[kkb];
                         const int ida = __float_as_int(f4[kka].w), idb = __float_as_int(f4[kkb].w);
                         double d2a, d2b;
-                        if (general_tile) {
-                            d2a = exact_d2<true>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, lsh[kka]);
-                            d2b = exact_d2<true>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, lsh[kkb]);
+                        if (TRI) {
+                            d2a = exact_d2<2>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
+                            d2b = exact_d2<2>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
+                        } else if (general_tile) {
+                            d2a = exact_d2<1>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, lsh[kka]);
+                            d2b = exact_d2<1>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, lsh[kkb]);
                         } else {
-                            d2a = exact_d2<false>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
-                            d2b = exact_d2<false>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
+                            d2a = exact_d2<0>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
+                            d2b = exact_d2<0>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
                         }
                         const double ra = ha ? sqrt_f64(d2a) : pad, rb = hb ? sqrt_f64(d2b) : pad; // neighbor.cpp:174; pads neighbor.py:125-129
                         const int64_t oa = (int64_t)(int)(ia & 0xffffffffll) * M + e, ob = (int64_t)(int)(ib & 0xffffffffll) * M + e;
@@ -675,18 +705,16 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
 {
     using namespace lane;
     LanePlan p{};
-    if (b.tri || g.mode != 0 || N <= 0 || M <= 0 || M > 64)
-        return p;
+    for (int k = 0; k < 8; ++k) g_last_plan[k] = 0;
+    if (g.mode != 0 || N <= 0 || M <= 0 || M > 64) { g_last_plan[6] = -1; return p; }
+    if (b.tri && !(b.pbc[0] && b.pbc[1] && b.pbc[2])) { g_last_plan[6] = -2; return p; } // open triclinic boxes: thread-per-atom kernel
     for (int d = 0; d < 3; ++d)
-        if (g.nc[d] < (b.pbc[d] ? 7 : 4)) // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
-            return p;
-    if (!(rc > 1e-12 && rc < 1e12))
-        return p;
+        if (g.nc[d] < (b.pbc[d] ? 7 : 4)) { g_last_plan[6] = -3; return p; } // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
+    if (!(rc > 1e-12 && rc < 1e12)) { g_last_plan[6] = -4; return p; }
     int64_t runs = 0, longer = 0;
     for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
     for (int len = 29; len <= 65; ++len) longer += gs.v[1 + len];
-    if (runs > 0 && (double)longer > 0.002 * (double)runs) // cells so full that many runs would not fit a 32-bit hit mask
-        return p;
+    if (runs > 0 && (double)longer > 0.002 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)longer; g_last_plan[4] = (int)runs; return p; } // cells so full that many runs would not fit a 32-bit hit mask
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
@@ -720,15 +748,27 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
         if (cap_env > 0)
             break;
     }
-    if (!best.txy)
-        return p;
+    if (!best.txy) { g_last_plan[6] = -6; return p; }
     // Decision band of the single-precision scan (file header).  E bounds the staged coordinates (far-atom check of the
     // kernel), du the error of one staged coordinate: rounding to f32 plus what the double-precision shift can lose;
     // |d2_f32 - d2| <= (2 du)(2 sqrt(3) |d| + 6 du) + 5 * 2^-24 max(d2, rc^2) for the three subtractions and the FMA chain.
     const int hmax = std::max(best.txy, best.tz) + 2;
-    const double E = ((double)hmax + 1.5) * rc;
+    double E = ((double)hmax + 1.5) * rc;
     double big = E;
-    for (int d = 0; d < 3; ++d) big = std::max(big, std::fabs(b.o[d]) + 2.0 * std::fabs(b.h[d * 4]) + E);
+    if (b.tri) { // the halo is a parallelepiped: its edges along the cell vectors, coordinates bounded by their sum
+        double ext = 0, span = 0;
+        for (int d = 0; d < 3; ++d) {
+            const double len = std::sqrt(b.h[3 * d] * b.h[3 * d] + b.h[3 * d + 1] * b.h[3 * d + 1] + b.h[3 * d + 2] * b.h[3 * d + 2]);
+            ext += ((double)((d == 2 ? best.tz : best.txy) + 2) + 1.5) * len * rc / b.thick[d]; // a cell is rc / thickness of the vector
+            span += len;
+        }
+        E = ext;
+        big = E + 3.0 * span;
+        for (int d = 0; d < 3; ++d) big += std::fabs(b.o[d]);
+        big *= 4.0; // the wrap and the frame shift go through the fractional coordinates: a few more roundings
+    } else {
+        for (int d = 0; d < 3; ++d) big = std::max(big, std::fabs(b.o[d]) + 2.0 * std::fabs(b.h[d * 4]) + E);
+    }
     const double du = std::ldexp(E, -24) * 1.01 + std::ldexp(big, -49);
     const double rcsq = rc * rc;
     const double tol = 2.0 * (11.0 * du * rc + 12.0 * std::ldexp(rcsq, -24)); // twice the bound: a wider band costs nothing
@@ -791,15 +831,21 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const Shape ts2{ts.txy, 1};
     const int nt2b = nt[2] * nsub;
     if (lds > 60 * 1024) // above the default dynamic-LDS limit: raise it for the instance about to run
-        (void)hipFuncSetAttribute(count ? reinterpret_cast<const void *>(&k_neighbor_lane<true>) : reinterpret_cast<const void *>(&k_neighbor_lane<false>),
+        (void)hipFuncSetAttribute(b.tri ? (count ? reinterpret_cast<const void *>(&k_neighbor_lane<true, true>) : reinterpret_cast<const void *>(&k_neighbor_lane<false, true>))
+                                        : (count ? reinterpret_cast<const void *>(&k_neighbor_lane<true, false>) : reinterpret_cast<const void *>(&k_neighbor_lane<false, false>)),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (count) {
-        hipLaunchKernelGGL((k_neighbor_lane<true>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);
-        hipLaunchKernelGGL((k_neighbor_lane<true>), dim3(1024), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);
-    } else {
-        hipLaunchKernelGGL((k_neighbor_lane<false>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);
-        hipLaunchKernelGGL((k_neighbor_lane<false>), dim3(1024), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);
-    }
+#define MDH_LANE_LAUNCH(COUNT, TRI)                                                                                                       \
+    do {                                                                                                                                  \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
+                           cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, \
+                           tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);                                       \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), dim3(1024), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs,             \
+                           cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0],  \
+                           nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);                       \
+    } while (0)
+    if (b.tri) { if (count) MDH_LANE_LAUNCH(true, true); else MDH_LANE_LAUNCH(false, true); }
+    else { if (count) MDH_LANE_LAUNCH(true, false); else MDH_LANE_LAUNCH(false, false); }
+#undef MDH_LANE_LAUNCH
     MDH_HIP(hipGetLastError());
     // what the two passes listed for the thread-per-atom code (k_neighbor_tiles), in the tiling of the second pass
     tf.flag = reinterpret_cast<const unsigned char *>(flagged2); // (non-null: "a tiled kernel ran"; the per-tile byte flags are not used with a list)

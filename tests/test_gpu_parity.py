@@ -57,6 +57,17 @@ def _cases():
     out.append(("dense_blob", blob, np.eye(3) * 60.0, ORG0, PBC))
     p, b = _fcc(9, 0.03, 8)
     out.append(("fcc_partial_tiles", p, b, ORG0, PBC))  # 9..10 cells per axis: clipped tiles, periodic seam inside a tile
+    # sheared boxes large enough for the tile kernel (>= 7 cells along every vector), atoms handed in one cell vector
+    # outside the box, an origin away from zero; and one with a dense blob (tiles over the LDS budget -> mop-up)
+    shear = np.array([[34.0, 0.0, 0.0], [3.4, 34.0, 0.0], [-1.7, 3.4, 34.0]])  # ~10.2 cells of 3.3 along every vector
+    p, b = _fcc(10, 0.06, 12, a=3.4)
+    fr = p / 34.0
+    fr = fr + (rng.random(fr.shape) < 0.02) * rng.integers(-1, 2, fr.shape)
+    org = np.array([2.0, -7.5, 11.0])
+    out.append(("triclinic_fcc_sheared", fr @ shear + org, shear, org, PBC))
+    big = np.array([[60.0, 0.0, 0.0], [6.0, 60.0, 0.0], [3.0, -6.0, 60.0]])
+    fr = np.concatenate([rng.random((2500, 3)) * 0.41 + 0.3, rng.random((2500, 3))])  # ~6 atoms per cell in the blob: tiles overflow, runs fit
+    out.append(("triclinic_dense_blob", fr @ big, big, ORG0, PBC))
     return out
 
 
@@ -107,14 +118,26 @@ def test_neighbor_tile_overflow_and_variants():
         assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
         assert np.array_equal(nc, na) and np.array_equal(vc, va) and np.array_equal(dc, da)
         res.append((vb, db, nb))
-    for case in CASES[:4]:
-        _, pos, box, org, bnd = case
+    for case in CASES[:4] + [c for c in CASES if c[0].startswith("triclinic")]:
+        name, pos, box, org, bnd = case
         x, y, z = _xyz(pos)
         outs = []
         for variant in (0, 1):
             _lib.lib().mdh_debug_set_neighbor_variant(variant)
             try:
                 outs.append(_neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, 3.3, 1))
+                if name in ("triclinic_fcc_sheared", "triclinic_dense_blob"):  # fixed rows (narrow ones overflow inside the blob)
+                    M = 20
+                    va = np.full((len(x), M), -1, np.int32); da = np.full((len(x), M), 4.3); na = np.zeros(len(x), np.int32)
+                    O.build_neighbor(x, y, z, box, org, bnd, 3.3, va, da, na, 4)
+                    vb = np.empty((len(x), M), np.int32); db = np.empty((len(x), M)); nb = np.empty(len(x), np.int32)
+                    _neighbor.build_neighbor(x, y, z, box, org, bnd, 3.3, vb, db, nb, 1, fill_pads=True)
+                    assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+                    assert (na.max() > M) == (name == "triclinic_dense_blob")  # narrow rows overflow inside the blob
+                    if variant == 0:
+                        plan = np.zeros(8, np.int32)
+                        _lib.lib().mdh_debug_neighbor_plan(plan.ctypes.data)
+                        assert plan[0] > 0 and plan[7] == 1, plan  # the tile kernel took the sheared box
             finally:
                 _lib.lib().mdh_debug_set_neighbor_variant(0)
         assert all(np.array_equal(a, b) for a, b in zip(*outs))

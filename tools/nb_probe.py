@@ -15,6 +15,11 @@ dev = torch.device("cuda", 0)
 x, y, z, gid = slab_positions(torch, dev, cells, 0, sigma)
 n = x.shape[0]
 box = mp.Box(np.diag([A_CU * cells] * 3))
+if len(sys.argv) > 6:  # sheared box: the same fractional coordinates in a triclinic cell
+    sh = float(sys.argv[6]); Lb = A_CU * cells
+    Hm = np.array([[Lb, 0, 0], [sh * Lb, Lb, 0], [0.5 * sh * Lb, sh * Lb, Lb]])
+    x, y, z = x + sh * y + 0.5 * sh * z, y + sh * z, z
+    box = mp.Box(Hm)
 L = _lib.lib()
 verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty((n, M), dtype=torch.float64, device=dev)
 nn = torch.empty((n,), dtype=torch.int32, device=dev)
