@@ -21,6 +21,7 @@ if len(sys.argv) > 6:  # sheared box: the same fractional coordinates in a tricl
     x, y, z = x + sh * y + 0.5 * sh * z, y + sh * z, z
     box = mp.Box(Hm)
 L = _lib.lib()
+if os.environ.get('NB_VARIANT'): L.mdh_debug_set_neighbor_variant(int(os.environ['NB_VARIANT']))
 verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty((n, M), dtype=torch.float64, device=dev)
 nn = torch.empty((n,), dtype=torch.int32, device=dev)
 for _ in range(2):
