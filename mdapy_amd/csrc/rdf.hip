@@ -9,9 +9,11 @@
 // reference's "+= 1.0" on doubles (exact below 2^53).
 #include "common.hpp"
 #include "grid.hpp"
+#include <algorithm>
 
 namespace mdh {
 
+static int g_rdf_variant = 0; // test hook: 1 = thread-per-atom kernel everywhere
 static constexpr int RDF_LDS_BINS = 8192; // u32 bins kept in LDS (32 KiB); larger histograms go straight to HBM
 
 __device__ __forceinline__ void hist_add(unsigned *lds, unsigned long long *glob, bool use_lds, int64_t bin)
@@ -84,6 +86,157 @@ __global__ __launch_bounds__(256) void k_rdf_cells(const double *__restrict__ xs
         }
     }
     hist_flush(lds, hist, use_lds, hsize);
+}
+
+// ---- streaming, cell-list path on LDS tiles (orthogonal boxes).  A workgroup takes one centre cell at a time and pairs its
+// atoms with those of the cell itself and of the 13 cells "ahead" of it in the walk order — every unordered pair of atoms
+// in neighbouring cells is met exactly once and counted in both directions, (ti, tj) and (tj, ti), which is what the
+// reference's full 27-cell walk over ordered pairs adds up to (:223-251), at half the distance evaluations.  The atoms are
+// staged into LDS once per cell (coalesced reads of the cell-sorted arrays) as single-precision coordinates relative to the
+// centre cell's corner, periodic image folded in; a lane keeps one candidate in registers and walks the centre atoms
+// (a broadcast LDS read), so the lanes are busy whatever the cell population.  Single precision only sorts the easy pairs
+// into their shells: a pair whose r^2 lies within `tol` of a shell boundary (or of rc^2) is listed and binned after the scan
+// with the reference's own double-precision expression, once per direction (raw x[j] - wrapped x[i], minimum image,
+// sqrt(r2)/dr, :236-251 — the two directions may round differently), so the counts are the reference's bit for bit.
+// |r2_f32 - r2| <= 1.8e-6 (rc^2 + r2) for coordinates inside the 3x3x3-cell frame (cell width < 1.34 rc): three roundings
+// to f32 of magnitudes <= 2.7 rc, the subtractions, the FMA chain.
+constexpr int RDF_CEN = 256, RDF_QUEUE = 1024, RDF_NB = 14;
+
+__device__ __forceinline__ void rdf_exact_pair(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
+                                               const DBox &b, int qi, int qj, int ti, int tj, int ntype, int nbin, double dr, double rcsq,
+                                               unsigned *lds)
+{
+    double xi = xs[qi], yi = ys[qi], zi = zs[qi];
+    if (b.anypbc) wrap<false>(b, xi, yi, zi);      // :213-214
+    double ex = xs[qj] - xi, ey = ys[qj] - yi, ez = zs[qj] - zi;
+    pbc<false>(b, ex, ey, ez);
+    const double e2 = ex * ex + ey * ey + ez * ez;
+    if (e2 < rcsq) {                               // strict, :246
+        const int kk = (int)(sqrt(e2) / dr);
+        if (kk < nbin) atomicAdd(&lds[(ti * ntype + tj) * nbin + kk], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
+                                                  const int *__restrict__ order, const int *__restrict__ cell_start,
+                                                  const int *__restrict__ type, DBox b, Grid g, double rc, int nbin, int ntype,
+                                                  unsigned long long *__restrict__ hist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rdf_lds[];
+    float4 *cen = reinterpret_cast<float4 *>(rdf_lds);               // [RDF_CEN] ux, uy, uz, bits of the position in the sorted arrays
+    unsigned *queue = reinterpret_cast<unsigned *>(cen + RDF_CEN);   // [RDF_QUEUE][2] sorted positions of a pair to bin exactly
+    unsigned char *etype = reinterpret_cast<unsigned char *>(queue + 2 * RDF_QUEUE); // [RDF_CEN]
+    unsigned *lds = reinterpret_cast<unsigned *>(etype + RDF_CEN);   // [ntype^2 nbin]
+    __shared__ int s_start[RDF_NB + 1], s_src[RDF_NB];
+    __shared__ float s_shift[RDF_NB][3];
+    __shared__ double s_lo[RDF_NB][3];
+    __shared__ unsigned s_nq;
+    const int tid = threadIdx.x;
+    const int64_t hsize = (int64_t)ntype * ntype * nbin;
+    for (int64_t q = tid; q < hsize; q += 256) lds[q] = 0u;
+    const double dr = rc / nbin, rcsq = rc * rc; // :158-159
+    const float drf = (float)dr, inv_dr = (float)(1.0 / dr), rc2f = (float)rcsq;
+    const double w[3] = {b.h[0] / g.nc[0], b.h[4] / g.nc[1], b.h[8] / g.nc[2]};
+    for (int64_t cell = blockIdx.x; cell < g.ncell; cell += gridDim.x) {
+        const int c2 = (int)(cell % g.nc[2]), c1 = (int)((cell / g.nc[2]) % g.nc[1]), c0 = (int)(cell / ((int64_t)g.nc[1] * g.nc[2]));
+        const int cs = cell_start[cell], ncen_all = cell_start[cell + 1] - cs;
+        if (ncen_all == 0)
+            continue;
+        __syncthreads(); // the tables below are reused
+        if (tid < RDF_NB) { // the cell itself (entry 0) and the 13 cells after it in the reference's walk order (:223-235)
+            const int o = tid == 0 ? 13 : 13 + tid; // position in the 27-cell walk
+            const int da = o / 9 - 1, db = (o / 3) % 3 - 1, dc = o % 3 - 1;
+            const int a = b.pbc[0] ? pmod(c0 + da, g.nc[0]) : c0 + da, bb = b.pbc[1] ? pmod(c1 + db, g.nc[1]) : c1 + db,
+                      cc = b.pbc[2] ? pmod(c2 + dc, g.nc[2]) : c2 + dc;
+            int n = 0, src = 0;
+            if (a >= 0 && a < g.nc[0] && bb >= 0 && bb < g.nc[1] && cc >= 0 && cc < g.nc[2]) { // open axes are not wrapped
+                const int64_t nb = ((int64_t)a * g.nc[1] + bb) * g.nc[2] + cc;
+                src = cell_start[nb];
+                n = cell_start[nb + 1] - src;
+            }
+            s_src[tid] = src;
+            s_start[tid + 1] = n; // turned into a prefix below
+            s_lo[tid][0] = b.o[0] + a * w[0]; s_lo[tid][1] = b.o[1] + bb * w[1]; s_lo[tid][2] = b.o[2] + cc * w[2];
+            s_shift[tid][0] = (float)(da * w[0]); s_shift[tid][1] = (float)(db * w[1]); s_shift[tid][2] = (float)(dc * w[2]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_start[0] = 0;
+            for (int k = 0; k < RDF_NB; ++k) s_start[k + 1] += s_start[k];
+            s_nq = 0;
+        }
+        __syncthreads();
+        const int ncand_all = s_start[RDF_NB];
+        for (int cbase = 0; cbase < ncen_all; cbase += RDF_CEN) {
+            const int ncen = min(RDF_CEN, ncen_all - cbase);
+            __syncthreads();
+            if (tid < ncen) { // centre atoms
+                const int q = cs + cbase + tid;
+                double xi = xs[q], yi = ys[q], zi = zs[q];
+                if (b.anypbc)
+                    wrap<false>(b, xi, yi, zi);
+                cen[tid] = make_float4((float)(xi - s_lo[0][0]), (float)(yi - s_lo[0][1]), (float)(zi - s_lo[0][2]), __int_as_float(q));
+                etype[tid] = (unsigned char)type[order[q]];
+            }
+            __syncthreads();
+            for (int gv = tid; gv < ncand_all; gv += 256) { // this lane's candidate: atom gv of the 14 cells laid end to end
+                int k = 0;
+                while (gv >= s_start[k + 1]) ++k;
+                const int qj = s_src[k] + (gv - s_start[k]);
+                double xj = xs[qj], yj = ys[qj], zj = zs[qj];
+                if (b.anypbc)
+                    wrap<false>(b, xj, yj, zj);
+                const float ux = (float)(xj - s_lo[k][0]) + s_shift[k][0], uy = (float)(yj - s_lo[k][1]) + s_shift[k][1],
+                            uz = (float)(zj - s_lo[k][2]) + s_shift[k][2];
+                const int tj = type[order[qj]];
+                const bool same_cell = k == 0;
+                for (int c = 0; c < ncen; ++c) {
+                    const float4 ce = cen[c]; // one address for the whole wavefront: a broadcast read
+                    const float dx = ux - ce.x, dy = uy - ce.y, dz = uz - ce.z;
+                    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    if (r2 < rc2f * 1.0001f) {
+                        const int qi = __float_as_int(ce.w);
+                        if (same_cell && qj <= qi)
+                            continue; // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
+                        const int kb = (int)(__builtin_sqrtf(r2) * inv_dr);
+                        const float lo = (float)kb * drf, hi = lo + drf;
+                        const float tol = 4.0e-6f * (rc2f + r2);
+                        const int ti = etype[c];
+                        if (r2 - lo * lo > tol && hi * hi - r2 > tol) {
+                            if (kb < nbin) {
+                                if (ti == tj) {
+                                    atomicAdd(&lds[(ti * ntype + tj) * nbin + kb], 2u);
+                                } else {
+                                    atomicAdd(&lds[(ti * ntype + tj) * nbin + kb], 1u);
+                                    atomicAdd(&lds[(tj * ntype + ti) * nbin + kb], 1u);
+                                }
+                            }
+                        } else {
+                            const unsigned slot = atomicAdd(&s_nq, 1u);
+                            if (slot < (unsigned)RDF_QUEUE) {
+                                queue[2 * slot] = (unsigned)qi;
+                                queue[2 * slot + 1] = (unsigned)qj;
+                            } else { // (a full list: this pair right away)
+                                rdf_exact_pair(xs, ys, zs, b, qi, qj, ti, tj, ntype, nbin, dr, rcsq, lds);
+                                rdf_exact_pair(xs, ys, zs, b, qj, qi, tj, ti, ntype, nbin, dr, rcsq, lds);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nq = (int)min(s_nq, (unsigned)RDF_QUEUE);
+        for (int e = tid; e < 2 * nq; e += 256) { // the pairs near a shell boundary, each direction as the reference bins it
+            const int qa = (int)queue[2 * (e >> 1) + (e & 1)], qb = (int)queue[2 * (e >> 1) + 1 - (e & 1)];
+            rdf_exact_pair(xs, ys, zs, b, qa, qb, type[order[qa]], type[order[qb]], ntype, nbin, dr, rcsq, lds);
+        }
+    }
+    __syncthreads();
+    for (int64_t q = tid; q < hsize; q += 256) {
+        const unsigned v = lds[q];
+        if (v) atomicAdd(&hist[q], (unsigned long long)v);
+    }
 }
 
 // ---- streaming, all-pairs fallback (:266-305): one thread per atom i, j tiled through LDS
@@ -178,6 +331,12 @@ using namespace mdh;
 
 extern "C" {
 
+int mdh_debug_set_rdf_variant(int v)
+{
+    g_rdf_variant = v;
+    return MDH_OK;
+}
+
 int mdh_rdf_streaming(const double *x, const double *y, const double *z, const int *type, int64_t N,
                       const double *box9, const double *origin3, const int *boundary3, double *g, int ntype,
                       double rc, int nbin, int space, void *stream)
@@ -213,7 +372,12 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         cg.g.rc_inv = 1.0 / rc;
         cg.g.mode = 1;
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, false, cg));
-        if (b.tri)
+        const size_t tile_lds = (size_t)RDF_CEN * 17 + (size_t)RDF_QUEUE * 8 + (size_t)hsize * 4;
+        if (!b.tri && ntype <= 255 && hsize <= RDF_LDS_BINS && g_rdf_variant == 0) {
+            ProfRange pr("k_rdf_tile", st);
+            const unsigned blocks = (unsigned)std::min<int64_t>(cg.g.ncell, 256 * 8);
+            hipLaunchKernelGGL(k_rdf_tile, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist);
+        } else if (b.tri)
             hipLaunchKernelGGL(k_rdf_cells<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, N, b, cg.g, rc, nbin, ntype, hist);
         else
             hipLaunchKernelGGL(k_rdf_cells<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, N, b, cg.g, rc, nbin, ntype, hist);

@@ -384,6 +384,45 @@ def test_solid_liquid_second_pass_equals_the_serial_sweep():
     assert list(nb) == [2, 2, 1, 1] and list(sl) == [0, 1, 0, 0] and list(ser) == [0, 0, 0, 0]
 
 
+def test_streaming_rdf_tile_kernel_edge_cases():
+    """the LDS-tile kernel of the streaming RDF (half shell, single-precision sorting, exact re-binning near shell
+    boundaries) against the CPU oracle and against the thread-per-atom kernel: open axes, three cells on a periodic axis,
+    atoms handed in outside the box, three species, cells that hold more centre atoms than one batch, many bins"""
+    from mdapy_amd import _lib
+
+    rng = np.random.default_rng(31)
+    jobs = []
+    pos, box = lattice_positions("fcc", 4.0, 9, 9, 9)
+    pos = pos + rng.normal(0, 0.3, pos.shape)
+    ty3 = rng.integers(0, 3, len(pos)).astype(np.int32)
+    jobs.append(("pbc_3types", pos, box, ORG0, PBC, ty3, 6.0, 150))
+    jobs.append(("open_z", pos, box, ORG0, np.array([1, 1, 0], np.int32), ty3, 6.0, 77))
+    jobs.append(("cluster", pos, box, ORG0, np.array([0, 0, 0], np.int32), ty3, 11.9, 40))   # three cells across
+    far = pos + rng.integers(-1, 2, pos.shape) * 36.0                                          # whole box lengths away
+    jobs.append(("unwrapped_shifted", far + 5.0, box, np.array([5.0, 5.0, 5.0]), PBC, ty3, 7.5, 200))
+    dense = rng.random((9000, 3)) * np.array([30.0, 30.0, 30.0])
+    jobs.append(("dense_gas", dense, np.eye(3) * 30.0, ORG0, PBC, rng.integers(0, 2, 9000).astype(np.int32), 9.9, 500))  # ~330 atoms per cell
+    edge = np.concatenate([np.arange(0, 200)[:, None] * np.array([[0.04, 0, 0]]) + 10.0, [[10.0, 10.0, 10.0]]])      # distances exactly on shell boundaries
+    jobs.append(("on_the_boundaries", edge, np.eye(3) * 40.0, ORG0, PBC, np.zeros(len(edge), np.int32), 8.0, 200))
+    for name, p, bx, org, bd, ty, rc, nbin in jobs:
+        x, y, z = _xyz(p)
+        nt = int(ty.max()) + 1
+        g0 = np.zeros((nt, nt, nbin))
+        O._rdf_streaming(x, y, z, ty, bx, org, bd, g0, rc, nbin, 8)
+        got = []
+        for variant in (0, 1):
+            _lib.lib().mdh_debug_set_rdf_variant(variant)
+            try:
+                g1 = np.zeros((nt, nt, nbin))
+                _rdf._rdf_streaming(x, y, z, ty, bx, org, bd, g1, rc, nbin, 1)
+                got.append(g1)
+            finally:
+                _lib.lib().mdh_debug_set_rdf_variant(0)
+        assert np.array_equal(got[0], g0), name
+        assert np.array_equal(got[1], g0), name
+        assert g0.sum() > 0
+
+
 def test_rdf_and_wcp_vs_oracle():
     rng = np.random.default_rng(21)
     pos, box = lattice_positions("fcc", 4.0, 9, 9, 9)
