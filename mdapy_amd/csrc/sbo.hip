@@ -155,16 +155,34 @@ __global__ __launch_bounds__(256) void k_sq_average(int64_t N, const int *__rest
     qlm_i[g] = si * inv;
 }
 
-// stage 3 (:506-575)
+// stage 3 (:506-575).  STAGED: the q_lm rows of the workgroup's 64 atoms are copied into LDS with coalesced reads first
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_sq_final(int64_t N, LList ll, int lmax, int wl, int wlhat,
                                                   const double *__restrict__ cg, const double *__restrict__ qlm_r,
                                                   const double *__restrict__ qlm_i, double *__restrict__ qn, int ncol)
 {
+    extern __shared__ double rows[];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nz = 2 * lmax + 1, nl = ll.n;
+    const int st = nl * nz, bd = blockDim.x + 1, t = threadIdx.x;
+    if (STAGED) {
+        const int64_t row0 = (int64_t)blockIdx.x * blockDim.x;
+        const int64_t nelem = (N - row0 < (int64_t)blockDim.x ? N - row0 : (int64_t)blockDim.x) * st;
+        for (int64_t e = t; e < nelem; e += blockDim.x) {
+            const int r = (int)(e / st), c = (int)(e - (int64_t)r * st);
+            rows[c * bd + r] = qlm_r[row0 * st + e];
+            rows[(st + c) * bd + r] = qlm_i[row0 * st + e];
+        }
+        __syncthreads();
+    }
     if (i >= N)
         return;
-    const int nz = 2 * lmax + 1, nl = ll.n;
-    const double *qr = qlm_r + i * nl * nz, *qi = qlm_i + i * nl * nz;
+    struct Row {
+        const double *g, *l;
+        int bd, t;
+        __device__ __forceinline__ double operator[](int c) const { return STAGED ? l[c * bd + t] : g[c]; }
+    };
+    const Row qr{qlm_r + i * nl * nz, rows, bd, t}, qi{qlm_i + i * nl * nz, rows + (size_t)st * bd, bd, t};
     double *out = qn + i * ncol;
     const double EPS = 1e-15;
     for (int il = 0; il < nl; ++il) {
@@ -179,16 +197,16 @@ __global__ __launch_bounds__(256) void k_sq_final(int64_t N, LList ll, int lmax,
         int c = 0;
         for (int il = 0; il < nl; ++il) {
             const int l = ll.l[il];
-            const double *pr = qr + il * nz, *pi = qi + il * nz;
+            const int off = il * nz;
             double ws = 0.0;
             for (int m1 = 0; m1 < 2 * l + 1; ++m1) {
                 const int lo = (l - m1) > 0 ? (l - m1) : 0;
                 const int hi = (2 * l + 1) < (3 * l - m1 + 1) ? (2 * l + 1) : (3 * l - m1 + 1);
                 for (int m2 = lo; m2 < hi; ++m2) {
                     const int m = m1 + m2 - l;
-                    const double a_r = pr[m1] * pr[m2] - pi[m1] * pi[m2];
-                    const double a_i = pr[m1] * pi[m2] + pi[m1] * pr[m2];
-                    ws += (a_r * pr[m] + a_i * pi[m]) * cg[c];
+                    const double a_r = qr[off + m1] * qr[off + m2] - qi[off + m1] * qi[off + m2];
+                    const double a_i = qr[off + m1] * qi[off + m2] + qi[off + m1] * qr[off + m2];
+                    ws += (a_r * qr[off + m] + a_i * qi[off + m]) * cg[c];
                     ++c;
                 }
             }
@@ -380,7 +398,10 @@ int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, con
         MDH_HIP(hipMemcpyAsync(ai, dqi, sizeof(double) * (size_t)(N * stride), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_sq_average, dim3(grid_for(N * stride, 256)), dim3(256), 0, st, N, dv, M, dn, ll, nnn, lmax, use_voronoi, ar, ai, dqr, dqi);
     }
-    hipLaunchKernelGGL(k_sq_final, dim3(grid_for(N, 256)), dim3(256), 0, st, N, ll, lmax, wl, wlhat, dcg, dqr, dqi, dqn, ncol);
+    if ((size_t)65 * 16 * (size_t)stride <= 60 * 1024)
+        hipLaunchKernelGGL(k_sq_final<true>, dim3(grid_for(N, 64)), dim3(64), (size_t)65 * 16 * (size_t)stride, st, N, ll, lmax, wl, wlhat, dcg, dqr, dqi, dqn, ncol);
+    else
+        hipLaunchKernelGGL(k_sq_final<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, N, ll, lmax, wl, wlhat, dcg, dqr, dqi, dqn, ncol);
     return sc.finish(space);
 }
 
