@@ -153,6 +153,18 @@ class HArray:
     def copy(self):
         return self.numpy().copy()
 
+    # ---- device-side reshaping for result columns (no host traffic)
+    def column(self, j, dtype=None):
+        """column j of a 2-D array as a contiguous 1-D array in HBM, optionally converted"""
+        piece = self._dev[:, j]
+        if dtype is not None:
+            piece = piece.to(_NP2T[np.dtype(dtype)])
+        return HArray(piece.contiguous())
+
+    def head(self, n):
+        """the first n rows (a view for 1-D and C-contiguous arrays)"""
+        return self if n >= self._dev.shape[0] else HArray(self._dev[:n].contiguous())
+
     def astype(self, dtype, **k):
         return self.numpy().astype(dtype, **k)
 

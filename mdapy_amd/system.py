@@ -24,7 +24,7 @@ from .centro_symmetry_parameter import CentroSymmetryParameter
 from .cluster_analysis import ClusterAnalysis
 from .common_neighbor_analysis import CommonNeighborAnalysis
 from .common_neighbor_parameter import CommonNeighborParameter
-from .devarray import as_numpy
+from .devarray import HArray, as_numpy
 from .frame import Frame
 from .identify_diamond_structure import IdentifyDiamondStructure
 from .identify_fcc_planar_faults import IdentifyFccPlanarFaults
@@ -103,7 +103,9 @@ class System:
     def _store(self, **columns):
         """results of an analysis over the compute view -> columns of the N real atoms"""
         n = self.N
-        self.update_data(self._frame.with_columns(**{name: as_numpy(values)[:n] for name, values in columns.items()}))
+        kept = {name: (values.head(n) if isinstance(values, HArray) and values.ndim == 1 else as_numpy(values)[:n])
+                for name, values in columns.items()}  # results that are in HBM stay there until somebody reads them
+        self.update_data(self._frame.with_columns(**kept))
 
     def wrap_pos(self):
         self.update_data(tool.wrap_pos(self._frame, self.box), reset_neighbor=True)
@@ -194,18 +196,22 @@ class System:
         cell, frame = self._get_compute_view()
         job = PolyhedralTemplateMatching(structure, frame, cell, rmsd_threshold, rows)
         job.compute()
-        table = as_numpy(job.output)
-        found = {"ptm": table[:, 0].astype(np.int32)}
+        table = job.output
+        if isinstance(table, HArray):  # columns are cut out in HBM; nothing crosses PCIe before it is asked for
+            take = table.column
+        else:
+            take = lambda col, dtype=None: table[:, col] if dtype is None else table[:, col].astype(dtype)
+        found = {"ptm": take(0, np.int32)}
         for wanted, name, col in ((return_ordering, "ordering", 1), (return_rmsd, "rmsd", 2),
                                   (return_atomic_distance, "interatomic_distance", 3)):
             if wanted:
-                found[name] = table[:, col]
+                found[name] = take(col)
         if return_orientation:  # stored x, y, z, w; the kernel's quaternion is w, x, y, z
-            found.update(qx=table[:, 5], qy=table[:, 6], qz=table[:, 7], qw=table[:, 4])
+            found.update(qx=take(5), qy=take(6), qz=take(7), qw=take(4))
         self.ptm_indices = job.ptm_indices
         if identify_fcc_planar_faults:
             shell = np.ascontiguousarray(as_numpy(job.ptm_indices)[:, 1:13])  # the 12 neighbours in template order
-            faults = IdentifyFccPlanarFaults(np.array(table[:, 0], np.int32), shell, identify_esf)
+            faults = IdentifyFccPlanarFaults(np.array(as_numpy(found["ptm"]), np.int32), shell, identify_esf)
             faults.compute()
             found["pft"] = faults.fault_types
         self._store(**found)
@@ -334,14 +340,15 @@ class System:
         job = SteinhardtBondOrientation(cell, frame, np.asarray(llist, int), nnn, rc, average, use_voronoi, use_weight,
                                         weight, *lists, wl, wlhat, identify_liquid, threshold, n_bond)
         job.compute()
-        values = as_numpy(job.qnarray)
+        values = job.qnarray
+        take = values.column if isinstance(values, HArray) else (lambda col: values[:, col])
         if values.shape[1] == 1:
-            found = {f"ql{llist[0]}": values.flatten()}
+            found = {f"ql{llist[0]}": take(0)}
         else:
             names = [f"ql{l}" for l in llist]
             names += [f"wl{l}" for l in llist] if wl else []
             names += [f"wlh{l}" for l in llist] if wlhat else []
-            found = {name: values[:, col] for col, name in enumerate(names)}
+            found = {name: take(col) for col, name in enumerate(names)}
         if identify_liquid:
             found.update(solidliquid=job.solidliquid, nbond=job.nbond)
         self._store(**found)
