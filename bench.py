@@ -184,11 +184,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree")
+    # MDH_BENCH_SHARED_GPU=1 (tests on a one-GPU box): every rank on cuda:0, gloo instead of RCCL — the same code path
+    # above the transport, no claim about its speed
+    shared = os.environ.get("MDH_BENCH_SHARED_GPU", "") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group of {dist.get_world_size()} ranks for --gpus {args.gpus}")
 
@@ -249,7 +254,7 @@ def main():
 
     elapsed, out, prof = timed(step, args.steps, args.warmup)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -174,3 +174,28 @@ def test_decomposed_steps_on_hip_kernels_equal_the_undivided_system(world):
         assert bad == [], f"rank {rank}: {bad}"
         assert n_own > 0 and n_ghost > 0
     assert sum(r[2] for r in res) == 28 * 14 * 14 * 4
+
+
+def test_bench_runs_its_multi_rank_path():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank), with the one
+    change a one-GPU box forces: MDH_BENCH_SHARED_GPU=1 puts both ranks on cuda:0 and swaps RCCL for gloo.  Checks the
+    JSON contract of the N > 1 line and that a world size that does not match --gpus is refused."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MDH_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cells", "40"]
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints ONE line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["world_size_checked"] == 2 and res["config"]["parallelism"] == "slab2"
+    assert res["config"]["atoms_per_gpu"] == 4 * 40 ** 3 and res["value"] > 0 and res["higher_is_better"] is True
+    assert abs(res["value"] - 2 * res["config"]["atoms_per_gpu"] / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1 and "cpu_baseline" not in res
+    wrong = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "20"], cwd=ROOT,
+                           capture_output=True, text=True, timeout=300)
+    assert wrong.returncode != 0 and "torch.distributed.run" in (wrong.stderr + wrong.stdout)
