@@ -15,6 +15,7 @@
 
 namespace mdh {
 
+static int g_sq_variant = 0; // test hook: 1 = generic stage-1 kernel for every degree
 static constexpr int SBO_MAXL = 16;  // entries of llist
 static constexpr int SBO_LMAX = 40;  // largest degree (3l+1 must index the 168-entry factorial table)
 static constexpr double MY_PI = 3.14159265358979323846;
@@ -119,6 +120,105 @@ __global__ void k_sq_stage1(const double *__restrict__ x, const double *__restri
         }
 #undef QR
 #undef QI
+}
+
+// Stage 1 for ONE degree l known at compile time: the 2l+1 running sums of an atom in registers, the Legendre recurrences
+// unrolled (same expressions as assoc_legendre, so the same values; the square root under them is computed once per bond),
+// the row segments of the 64 atoms of a workgroup copied in and out through LDS with coalesced accesses.  One launch per
+// entry of llist; sums and their order are those of the generic kernel (bond by bond in list order), bit for bit.
+template <bool TRI, int L>
+__global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                    int64_t N, DBox b, const int *__restrict__ NL, const double *__restrict__ DL, int64_t M,
+                                                    const int *__restrict__ NN, const double *__restrict__ weight, int il, int stride, int nz,
+                                                    int lmax, int nnn, int use_voronoi, double rc, int use_weight,
+                                                    const double *__restrict__ norm, double *__restrict__ qlm_r, double *__restrict__ qlm_i)
+{
+    constexpr int NM = 2 * L + 1;
+    __shared__ double sr[NM][65], si[NM][65];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + t;
+    const int rows = (int)(N - row0 < 64 ? N - row0 : 64);
+    const int o = il * nz; // this degree's segment of a row: components o .. o + 2l
+    for (int e = t; e < rows * NM; e += 64) {
+        const int r = e / NM, m = e - r * NM;
+        sr[m][r] = qlm_r[(row0 + r) * stride + o + m]; // the caller's (pre-zeroed) content: the reference adds onto it
+        si[m][r] = qlm_i[(row0 + r) * stride + o + m];
+    }
+    __syncthreads();
+    if (i < N) {
+        double ar[NM], ai[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { ar[m] = sr[m][t]; ai[m] = si[m][t]; }
+        double nrm[L + 1];
+#pragma unroll
+        for (int m = 0; m <= L; ++m) nrm[m] = norm[il * (lmax + 1) + m];
+        const double EPS = 1e-15;
+        const double x1 = x[i], y1 = y[i], z1 = z[i];
+        int cnt = NN[i];
+        if (!use_voronoi && nnn > 0) // :329-333
+            cnt = nnn;
+        double wsum = 0.0;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int64_t idx = i * M + jj;
+            const int j = NL[idx];
+            if ((unsigned)j >= (unsigned)N)
+                continue;
+            double dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1; // :346-350
+            pbc<TRI>(b, dx, dy, dz);
+            const double r = DL[idx];
+            if (!((r > EPS) && (r <= rc)))
+                continue;
+            const double w = use_weight ? weight[idx] : 1.0;
+            wsum += w;
+            const double rinv = 1.0 / r;
+            const double ct = dz * rinv;
+            double er = dx, ei = dy;
+            const double rxy2 = er * er + ei * ei;
+            if (rxy2 < EPS * EPS) { er = 1.0; ei = 0.0; }
+            else { const double sc = 1.0 / sqrt(rxy2); er *= sc; ei *= sc; }
+            ar[L] += w * (nrm[0] * assoc_legendre(L, 0, ct));
+            double mr = er, mi = ei;
+#pragma unroll
+            for (int m = 1; m < L + 1; ++m) {
+                const double pf = nrm[m] * assoc_legendre(L, m, ct);
+                const double cr = pf * mr, ci = pf * mi;
+                const double wr = w * cr, wi = w * ci;
+                ar[L + m] += wr;
+                ai[L + m] += wi;
+                if (m & 1) { ar[L - m] -= wr; ai[L - m] += wi; }
+                else { ar[L - m] += wr; ai[L - m] -= wi; }
+                const double tr = mr * er - mi * ei, ti = mr * ei + mi * er;
+                mr = tr; mi = ti;
+            }
+        }
+        const double f = 1.0 / wsum; // :422 (no guard: NaN/inf for an atom without neighbours)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { sr[m][t] = ar[m] * f; si[m][t] = ai[m] * f; }
+    }
+    __syncthreads();
+    for (int e = t; e < rows * NM; e += 64) {
+        const int r = e / NM, m = e - r * NM;
+        qlm_r[(row0 + r) * stride + o + m] = sr[m][r];
+        qlm_i[(row0 + r) * stride + o + m] = si[m][r];
+    }
+}
+
+template <bool TRI>
+static bool launch_stage1_l(int l, dim3 grid, hipStream_t st, const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b,
+                            const int *dv, const double *dd, int64_t M, const int *dn, const double *dw, int il, int stride, int nz, int lmax,
+                            int nnn, int use_voronoi, double rc, int use_weight, const double *dnorm, double *dqr, double *dqi)
+{
+#define MDH_SQ_L(LL)                                                                                                                     \
+    case LL:                                                                                                                             \
+        hipLaunchKernelGGL((k_sq_stage1_l<TRI, LL>), grid, dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, il, stride, nz, lmax, nnn, \
+                           use_voronoi, rc, use_weight, dnorm, dqr, dqi);                                                                \
+        return true;
+    switch (l) {
+        MDH_SQ_L(2) MDH_SQ_L(3) MDH_SQ_L(4) MDH_SQ_L(5) MDH_SQ_L(6) MDH_SQ_L(7) MDH_SQ_L(8) MDH_SQ_L(10) MDH_SQ_L(12)
+    default:
+        return false;
+    }
+#undef MDH_SQ_L
 }
 
 // stage 2 (:439-503): one thread per (atom, component); neighbours added in list order
@@ -318,6 +418,12 @@ using namespace mdh;
 
 extern "C" {
 
+int mdh_debug_set_sq_variant(int v)
+{
+    g_sq_variant = v;
+    return MDH_OK;
+}
+
 int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                const double *origin3, const int *boundary3, const int *verlet, const double *dist, int64_t M,
                const int *nn, const double *weight, const int *llist_host, int nl, int nnn, int lmax, int wl,
@@ -378,20 +484,37 @@ int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, con
     MDH_HIP(hipMemcpyAsync(dcg, cg.data(), cg.size() * sizeof(double), hipMemcpyHostToDevice, st));
     MDH_HIP(hipStreamSynchronize(st)); // norm/cg are host temporaries
 
-    // block size so that 2*stride doubles per thread fit in 64 KiB of LDS
-    int bd = (int)(65536 / (16 * stride)) / 64 * 64;
-    if (bd > 256) bd = 256;
-    if (bd >= 64) {
-        const size_t lds = (size_t)bd * 16 * (size_t)stride;
-        if (b.tri)
-            hipLaunchKernelGGL((k_sq_stage1<true, true>), dim3(grid_for(N, bd)), dim3(bd), lds, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
-        else
-            hipLaunchKernelGGL((k_sq_stage1<false, true>), dim3(grid_for(N, bd)), dim3(bd), lds, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+    // degrees with a compiled instantiation: one register-resident launch per entry of llist; any other degree in the list
+    // sends the whole call through the generic kernel (LDS accumulators)
+    bool special = g_sq_variant == 0;
+    for (int k = 0; k < nl && special; ++k) {
+        const int l = ll.l[k];
+        special = (l >= 2 && l <= 8) || l == 10 || l == 12;
+    }
+    if (special) {
+        const dim3 grid(grid_for(N, 64));
+        for (int k = 0; k < nl; ++k) {
+            if (b.tri)
+                launch_stage1_l<true>(ll.l[k], grid, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, k, (int)stride, 2 * lmax + 1, lmax, nnn, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+            else
+                launch_stage1_l<false>(ll.l[k], grid, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, k, (int)stride, 2 * lmax + 1, lmax, nnn, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+        }
     } else {
-        if (b.tri)
-            hipLaunchKernelGGL((k_sq_stage1<true, false>), dim3(grid_for(N, 64)), dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
-        else
-            hipLaunchKernelGGL((k_sq_stage1<false, false>), dim3(grid_for(N, 64)), dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+    // block size so that 2*stride doubles per thread fit in 64 KiB of LDS
+        int bd = (int)(65536 / (16 * stride)) / 64 * 64;
+        if (bd > 256) bd = 256;
+        if (bd >= 64) {
+            const size_t lds = (size_t)bd * 16 * (size_t)stride;
+            if (b.tri)
+                hipLaunchKernelGGL((k_sq_stage1<true, true>), dim3(grid_for(N, bd)), dim3(bd), lds, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+            else
+                hipLaunchKernelGGL((k_sq_stage1<false, true>), dim3(grid_for(N, bd)), dim3(bd), lds, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+        } else {
+            if (b.tri)
+                hipLaunchKernelGGL((k_sq_stage1<true, false>), dim3(grid_for(N, 64)), dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+            else
+                hipLaunchKernelGGL((k_sq_stage1<false, false>), dim3(grid_for(N, 64)), dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, ll, nnn, lmax, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+        }
     }
     if (average) {
         MDH_HIP(hipMemcpyAsync(ar, dqr, sizeof(double) * (size_t)(N * stride), hipMemcpyDeviceToDevice, st));

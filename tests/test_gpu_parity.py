@@ -288,6 +288,35 @@ def test_steinhardt_vs_oracle(case, mode):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
 
 
+def test_steinhardt_per_degree_kernels_equal_the_generic_one():
+    """stage 1 of the Steinhardt parameters has register-resident instantiations for l = 2..8, 10, 12 (one launch per entry of
+    llist); sums and their order are the generic kernel's, so q_lm, q_l, w_l agree bit for bit — cutoff and nnn lists,
+    weights, a degree list that mixes compiled and uncompiled degrees (falls back as a whole)"""
+    from mdapy_amd import _lib
+
+    _, pos, box, org, bnd = CASES[1]
+    x, y, z = _xyz(pos)
+    N = len(x)
+    v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, 3.4, 4)
+    w = np.random.default_rng(3).random(v.shape)
+    for ls, nnn, use_w in (([4, 6], 0, False), ([2, 3, 5, 7, 8, 10, 12], 0, True), ([6], 10, False), ([4, 9], 0, False)):
+        ll = np.array(ls, np.int32)
+        lmax = int(ll.max())
+        outs = []
+        for variant in (0, 1):
+            _lib.lib().mdh_debug_set_sq_variant(variant)
+            try:
+                qr = np.zeros((N, len(ls), 2 * lmax + 1)); qi = np.zeros_like(qr); qn = np.zeros((N, 3 * len(ls)))
+                _sbo.get_sq(x, y, z, box, org, bnd, v, d, n, w if use_w else np.zeros((2, 2)), ll, nnn, lmax, True, True, True, False,
+                            3.4 if nnn == 0 else 1e9, use_w, qr, qi, qn, 1)
+                outs.append((qr, qi, qn))
+            finally:
+                _lib.lib().mdh_debug_set_sq_variant(0)
+        for a, b_ in zip(*outs):
+            assert a.tobytes() == b_.tobytes(), ls
+        assert np.isfinite(outs[0][2]).any()
+
+
 def _solid_liquid_serial(v, d, n, q, thr, n_bond, rc):
     """the reference's identifySolidLiquid run with ONE thread (src/steinhardt_bond_orientation.cpp:605-674): bonds counted per
     atom, then the in-place sweep in index order that turns a solid atom without a solid neighbour into a liquid one — an
