@@ -57,6 +57,14 @@ def test_awkward_table(tmp_path, monkeypatch):
     got = np.column_stack([dev[0][c].to_numpy() for c in "xyz"])
     assert got.tobytes() == want.tobytes()
     assert list(dev[0]["id"].to_numpy()) == [1, 2, 3, 4, 5] and dev[0]["id"].dtype == np.int32
+    import gzip
+
+    pz = tmp_path / "awkward.dump.gz"  # a compressed file has no known size: the pieces are concatenated in HBM
+    with gzip.open(pz, "wb") as f:
+        f.write(text.encode())
+    devz, hostz = _both(str(pz), monkeypatch)
+    _same(devz, hostz)
+    assert np.column_stack([devz[0][c].to_numpy() for c in "xyz"]).tobytes() == want.tobytes()
     short = tmp_path / "short.dump"
     short.write_bytes(text.replace("5 1 0.30000000000000004 123456789012345678901234567890 1e-330 He", "5 1 0.3").encode())
     with monkeypatch.context() as m:
