@@ -152,6 +152,10 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
  * (:312-317); here the caller supplies the allocator: after counting, alloc(user, N, M, &verlet, &dist) must hand back
  * (N, M) int32 / f64 arrays in the memory space of the call (M = max(max count, 1), also stored in *width); the rows are
  * then written pads included (-1 / rc+1, :320-329).  nn (N) int32.  Synchronises `stream` once (between the passes).
+ * MDH_DEVICE calls remember the width found for a (N, grid) signature: the next call with the same signature builds at that
+ * width at once and lets the counts of the build confirm it (no counting pass); if they do not, alloc is called a SECOND
+ * time with the right width and the first arrays are to be dropped by the caller — *width and the arrays of the LAST
+ * alloc call are the result.
  */
 typedef int (*mdh_alloc_rows_fn)(void *user, int64_t N, int64_t M, int **verlet, double **dist);
 int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, int64_t N, const double *box9,

@@ -52,6 +52,7 @@ def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1
                 pv[0] = v.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
                 pd[0] = d.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
             rows["v"], rows["d"] = v, d
+            rows.setdefault("all", []).append((v, d))  # a first allocation at a hinted width may be discarded: alive until the call returns
             return 0
         except Exception:  # an exception must not cross the C frame: the library reports the failed allocation
             return 1

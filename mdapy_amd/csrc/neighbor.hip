@@ -18,6 +18,8 @@
 //                           contiguous and loads are coalesced).
 #include "common.hpp"
 #include "grid.hpp"
+#include <mutex>
+#include <vector>
 
 namespace mdh {
 
@@ -588,6 +590,34 @@ __global__ __launch_bounds__(256) void k_filter_overlap(const double *__restrict
     keep[j] = hit ? 0 : 1;
 }
 
+__global__ __launch_bounds__(256) void k_max_i32(const int *__restrict__ v, int64_t n, int *__restrict__ out)
+{
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = max(m, v[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+}
+
+// last exact row width seen for a (N, grid) signature; set < 0: query only
+static int width_hint(int64_t N, int64_t ncell, int set)
+{
+    struct Entry { int64_t N, ncell; int width; };
+    static std::mutex mu;
+    static std::vector<Entry> table;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : table)
+        if (e.N == N && e.ncell == ncell) {
+            if (set >= 0) e.width = set;
+            return e.width;
+        }
+    if (set > 0) {
+        if (table.size() >= 64) table.erase(table.begin());
+        table.push_back(Entry{N, ncell, set});
+    }
+    return 0;
+}
+
 // One pass over a built cell grid: mode 0 = counts only (nn, *dmax), 1 = reference semantics (caller's pads), 2 = pads written.
 // The tile kernel where it applies, the round-1 tiled kernel for cells too full for it, the thread-per-atom code for the rest.
 static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N, double rc, int *dv, double *dd, int *dn,
@@ -728,21 +758,42 @@ int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, 
         ProfRange pr("cell_grid", st);
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
     }
+    // Width hint: the largest count the previous call with the same (N, grid) found.  A sequence of calls on one system (a
+    // trajectory, the same analysis repeated) almost always finds the same maximum again, so the rows are built at that
+    // width at once and the counts written by the build confirm it — the counting pass is skipped.  A wrong hint costs one
+    // wasted build (the counts are then known) and is replaced; results never depend on it.
     int hmax = 0;
-    {
+    const int hint = space == MDH_DEVICE ? width_hint(N, cg.g.ncell, -1) : 0; // (host buffers: a discarded first allocation would still be a copy-back target)
+    bool built = false;
+    if (hint > 0) {
+        if (alloc(user, N, hint, &verlet, &dist) != 0 || !verlet || !dist) { set_error("mdh_build_neighbor_exact: the row allocator failed"); return MDH_ERR_NOMEM; }
+        int *dv = sc.stage(verlet, (size_t)(N * hint), space, false, true);
+        double *dd = sc.stage(dist, (size_t)(N * hint), space, false, true);
+        if (sc.failed())
+            return sc.error();
+        {
+            ProfRange pr("k_neighbor", st);
+            MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, hint, 2, nullptr));
+            hipLaunchKernelGGL(k_max_i32, dim3(1024), dim3(256), 0, st, dn, N, dmax);
+            MDH_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
+        }
+        MDH_HIP(hipStreamSynchronize(st));
+        built = (hmax > 1 ? hmax : 1) == hint;
+    } else {
         ProfRange pr("k_neighbor_count", st);
         MDH_TRY(neighbor_pass(sc, cg, b, N, rc, nullptr, nullptr, dn, 1, 0, dmax));
         MDH_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
+        MDH_HIP(hipStreamSynchronize(st));
     }
-    MDH_HIP(hipStreamSynchronize(st));
     const int64_t M = hmax > 1 ? hmax : 1;
     *width = M;
-    if (alloc(user, N, M, &verlet, &dist) != 0 || !verlet || !dist) { set_error("mdh_build_neighbor_exact: the row allocator failed"); return MDH_ERR_NOMEM; }
-    int *dv = sc.stage(verlet, (size_t)(N * M), space, false, true);
-    double *dd = sc.stage(dist, (size_t)(N * M), space, false, true);
-    if (sc.failed())
-        return sc.error();
-    {
+    width_hint(N, cg.g.ncell, (int)(M <= 4096 ? M : 0));
+    if (!built) {
+        if (alloc(user, N, M, &verlet, &dist) != 0 || !verlet || !dist) { set_error("mdh_build_neighbor_exact: the row allocator failed"); return MDH_ERR_NOMEM; }
+        int *dv = sc.stage(verlet, (size_t)(N * M), space, false, true);
+        double *dd = sc.stage(dist, (size_t)(N * M), space, false, true);
+        if (sc.failed())
+            return sc.error();
         ProfRange pr("k_neighbor", st);
         MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, M, 2, nullptr));
     }

@@ -1519,3 +1519,24 @@ def test_voronoi_few_atoms_in_a_small_periodic_cell():
     _voronoi.get_voronoi_volume_number_radius(np.array([1.0]), np.array([2.0]), np.array([3.0]), np.diag([4.0, 5.0, 6.0]), ORG0,
                                               np.zeros(3, np.int32), v1, n1, r1)
     assert abs(v1[0] - 120.0) < 1e-12 and n1[0] == 6  # a lone atom in an open box owns the box
+
+
+def test_exact_width_build_with_a_stale_width_hint():
+    """mdh_build_neighbor_exact remembers the row width per (N, grid) for HBM-resident calls and skips the counting pass when the
+    counts of the build confirm it; a system with the same signature but another maximum makes it allocate twice — the result
+    must not depend on the hint in either direction (wider, narrower, equal)"""
+    import torch
+
+    pos, box = _fcc(12, 0.02, 1)
+    rng = np.random.default_rng(5)
+    variants = [pos, pos.copy(), pos.copy(), pos]
+    variants[1][:40] = pos[40:80] + rng.normal(0, 0.4, (40, 3))   # a clump: larger maximum
+    variants[2] = pos + rng.normal(0, 0.01, pos.shape)            # back to the crystal's maximum
+    rc = 3.2
+    for p in variants:
+        x, y, z = _xyz(p)
+        v0, d0, n0 = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 4)
+        tx, ty, tz = (torch.from_numpy(a).cuda() for a in (x, y, z))
+        v1, d1, n1 = _neighbor.build_neighbor_without_max_neigh(tx, ty, tz, box, ORG0, PBC, rc, 1)
+        assert np.asarray(v1).shape == v0.shape
+        assert np.array_equal(np.asarray(n1), n0) and np.array_equal(np.asarray(v1), v0) and np.array_equal(np.asarray(d1), d0)
