@@ -25,11 +25,23 @@ from mdapy_amd.build_lattice import lattice_positions
 def draw(seed):
     rng = np.random.default_rng(seed)
     sigma = -1.0
-    kind = rng.choice(["gas", "fcc", "bcc", "hcp", "blob", "tiny"])
+    kind = rng.choice(["gas", "fcc", "bcc", "hcp", "blob", "tiny", "big"])
     tri = rng.random() < 0.4
     bnd = np.array(rng.random(3) < 0.75, np.int32)
     origin = rng.normal(0, 5.0, 3) if rng.random() < 0.5 else np.zeros(3)
-    if kind in ("fcc", "bcc", "hcp"):
+    if kind == "big":  # 10-16 cells per axis: large enough for the tile kernels (orthogonal and sheared, periodic and open)
+        n = [int(rng.integers(10, 17)) for _ in range(3)]
+        pos, box = lattice_positions("fcc", 3.615, *n)
+        box = np.asarray(box, float)
+        sigma = float(rng.choice([0.03, 0.15, 0.4]))
+        pos = pos + rng.normal(0, sigma, pos.shape)
+        if rng.random() < 0.6:
+            bnd = np.array([1, 1, 1], np.int32)
+        if tri:
+            sh = np.eye(3)
+            sh[1, 0], sh[2, 0], sh[2, 1] = rng.uniform(-0.15, 0.15, 3)
+            pos, box = pos @ sh, box @ sh
+    elif kind in ("fcc", "bcc", "hcp"):
         a = {"fcc": 3.615, "bcc": 2.87, "hcp": 2.95}[kind]
         n = [int(rng.integers(4, 9)) for _ in range(3)]
         pos, box = lattice_positions(kind, a, *n)
@@ -68,11 +80,32 @@ def draw(seed):
     return dict(seed=seed, sigma=sigma, kind=kind, tri=tri, unwrapped=unwrapped, pos=pos, box=box, origin=origin, bnd=bnd)
 
 
+def rdf_stream_check(s):
+    """streaming partial RDF (tile kernel for orthogonal boxes, thread-per-atom otherwise) against the oracle: integer counts"""
+    r = np.random.default_rng(s["seed"] + 23)
+    pos = s["pos"]
+    nt = int(r.integers(1, 4))
+    ty = r.integers(0, nt, len(pos)).astype(np.int32)
+    thick = np.abs(np.linalg.det(s["box"])) / np.array([np.linalg.norm(np.cross(s["box"][(d + 1) % 3], s["box"][(d + 2) % 3])) for d in range(3)])
+    rc = float(r.uniform(2.5, max(3.0, min(9.0, thick.min() * 0.45))))
+    nbin = int(r.integers(10, 400))
+    x, y, z = T._xyz(pos)
+    g0, g1 = np.zeros((nt, nt, nbin)), np.zeros((nt, nt, nbin))
+    T.O._rdf_streaming(x, y, z, ty, s["box"], s["origin"], s["bnd"], g0, rc, nbin, 8)
+    T._rdf._rdf_streaming(x, y, z, ty, s["box"], s["origin"], s["bnd"], g1, rc, nbin, 1)
+    assert np.array_equal(g0, g1)
+
+
 def checks(s):
     case = ("fuzz", s["pos"], s["box"], s["origin"], s["bnd"])
+    if s["kind"] == "big":  # the tile kernels: neighbour rows bit for bit (fixed and exact width), pair counts
+        rc_big = float(np.random.default_rng(s["seed"] + 7).uniform(2.8, 3.7))
+        T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
+        return [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc_big)), ("rdf_stream", lambda: rdf_stream_check(s))]
     T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
     rc = float(np.random.default_rng(s["seed"] + 7).uniform(2.6, 4.6))
     out = [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc)),
+           ("rdf_stream", lambda: rdf_stream_check(s)),
            ("sort_cna", lambda: T.test_sort_and_cna_vs_oracle(case)),
            ("overlap", lambda: T.test_filter_overlap_atom_vs_oracle("fuzz"))]
     if len(s["pos"]) >= 300 and s["kind"] in ("fcc", "bcc", "blob"):  # (the check also wants some atoms removed by its last cutoff set)
