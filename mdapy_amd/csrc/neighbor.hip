@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false;
+    int cell = -1 - (int)(threadIdx.x & 63); // lanes past the end: distinct negative values, no run, no atomic
     if (i < N) {
         const double xr = x[i], yr = y[i], zr = z[i];
         double xi = xr, yi = yr, zi = zr;
@@ -62,9 +63,27 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
         if (mv) mv[i] = (unsigned char)code;
         int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
-        int c = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
-        cell_id[i] = c;
-        rank[i] = (int)atomicAdd(&cell_count[c], 1u);
+        cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
+        cell_id[i] = cell;
+    }
+    // One returning atomic per RUN of adjacent lanes in the same cell instead of one per atom: atoms usually arrive in some
+    // spatial order (a lattice builder, a file written cell by cell, a previous sort), so neighbouring lanes share cells;
+    // the slot inside a cell is arbitrary anyway (k_sort_cells restores the reference's order).  Unordered input pays a
+    // ballot and two shuffles.
+    {
+        const int lane = threadIdx.x & 63;
+        const int prev = __shfl_up(cell, 1, 64);
+        const bool head = lane == 0 || prev != cell || cell < 0;
+        const unsigned long long heads = __ballot(head);
+        const int first = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));          // head of this lane's run
+        const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int last = later ? lane + __builtin_ctzll(later) : 63;                        // last lane of the run, as seen from its head
+        unsigned base = 0;
+        if (head && cell >= 0)
+            base = atomicAdd(&cell_count[cell], (unsigned)(last - lane + 1));
+        base = __shfl(base, first, 64);
+        if (cell >= 0)
+            rank[i] = (int)(base + (unsigned)(lane - first));
     }
     if (__any(moved) && (threadIdx.x & 63) == 0)
         flags[0] = 1;
