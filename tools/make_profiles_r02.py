@@ -87,10 +87,15 @@ ALG = [
     ("ptms::k_ptm_canon<12, false>", N3, 57 + 8 + 17 + 1, "facets in; hash, labelling, flag out"),
     ("ptms::k_ptm_canon<14, false>", N3, 57 + 8 + 17 + 1, "same, 15-point cluster"),
     ("ptms::k_ptm_match<false, false>", N3, 24 + 72 + 2 * 26 + 64 + 72, "positions, ids, 2 x (hash, labelling, flag) in; (N,8) f64 + (N,18) i32 out"),
-    ("k_sq_stage1<false, true>", N3, 24 + 4 + 12 * 12 + 16 * 2 * 13, "positions, count, 12 ids + distances in; q_lm (2 l-values x 13 x re,im) out"),
-    ("k_sq_final", N3, 16 * 2 * 13 + 16, "q_lm in; q4, q6 out"),
+    ("k_sq_stage1_l<false, 4>", N3, 24 + 4 + 12 * 12 + 2 * 16 * 9, "positions, count, 12 ids + distances in; q_4m (9 x re,im) read and written"),
+    ("k_sq_stage1_l<false, 6>", N3, 24 + 4 + 12 * 12 + 2 * 16 * 13, "same, q_6m (13 x re,im)"),
+    ("k_sq_final<true>", N3, 16 * 2 * 13 + 16, "q_lm rows in (416 B); q4, q6 out"),
     ("k_csp<false>", N3, 24 + 4 * 12 + 8, "positions, 12 ids in; csp out"),
     ("k_acna<false, false>", N3, 24 + 4 * 14 + 4, "positions, 14 ids in; label out"),
+    ("ptms::k_ptm_shell<false, 4, 3>", N3, 24 + 72 + 18 + 17 * 28 + 1, '"all": positions, ordered ids + ranks in; 17-point cluster (ids, points) out'),
+    ("ptms::k_ptm_hull_shell", N3, 17 * 24 + 1 + 57, '"all": cluster points in; 28 facets + status out'),
+    ("ptms::k_ptm_canon<16, true>", N3, 57 + 8 + 17 + 1, '"all": facets in; hash, labelling, flag out'),
+    ("ptms::k_ptm_match<false, true>", N3, 24 + 72 + 3 * 26 + 17 * 28 + 10 * 28 + 64 + 72, '"all": + both clusters in'),
     ("k_rdf_tile", N5, 28, "positions 24 + type 4 (the histogram is 6.4 kB)"),
     ("k_wcp_count", N5, 8 + 4 * 27, "count, type, row of the rc = 3.6 list (width 27)"),
 ]
