@@ -157,7 +157,7 @@ def test_decomposed_steps_world1_equal_the_undivided_system():
     assert bad == [] and n_ghost == 0 and n_own == 28 * 14 * 14 * 4
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_decomposed_steps_on_hip_kernels_equal_the_undivided_system(world):
     import torch.multiprocessing as tmp
 
