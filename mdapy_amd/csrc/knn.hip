@@ -77,7 +77,18 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
     int n = 0;
     double worst = __builtin_huge_val();
     int worst_id = 0x7fffffff;
-    for (int R = 0; R <= kg.rmax; ++R) {
+    // First try: rings 0 and 1 only, and only candidates within one cell width (the stop test after ring 1 demands
+    // k-th distance <= that width, so nothing farther can be in a result found there): a candidate beyond it costs one
+    // compare instead of a sorted insertion.  If fewer than k candidates are that close the search starts over without
+    // the bound and walks as many rings as it needs — the result is the same set in the same order either way.
+    const double one_cell = kg.wmin * (1.0 - 1e-9);
+    for (int attempt = kg.rmax >= 1 ? 0 : 1; attempt < 2; ++attempt) {
+    const double bound = attempt == 0 ? one_cell * one_cell : __builtin_huge_val();
+    const int last_ring = attempt == 0 ? 1 : kg.rmax;
+    n = 0;
+    worst = __builtin_huge_val();
+    worst_id = 0x7fffffff;
+    for (int R = 0; R <= last_ring; ++R) {
         for (int da = -R; da <= R; ++da) {
             const int e0 = c0 + da;
             int m0 = 0, a0 = e0;
@@ -117,6 +128,8 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
                         const double d2 = dx * dx + dy * dy + dz * dz;
                         if (j == i && d2 == 0.0)
                             continue;
+                        if (d2 > bound)
+                            continue;
                         if (n == k && !(d2 < worst || (d2 == worst && j < worst_id)))
                             continue;
                         int pos = n < k ? n : k - 1;
@@ -143,6 +156,9 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
             if (worst <= reach * reach)
                 break;
         }
+    }
+    if (attempt == 0 && n == k) // k candidates within one cell width after ring 1: the stop test above has passed
+        break;
     }
     for (int q = 0; q < n; ++q) {
         indices[(int64_t)i * k + q] = ti[q * bd + t];
