@@ -18,6 +18,7 @@
 //                           contiguous and loads are coalesced).
 #include "common.hpp"
 #include "grid.hpp"
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -371,23 +372,27 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
     const bool take_all = tf.moved && *tf.moved != 0; // the tiled kernel stood down: this kernel does the whole call
     if (tf.flag && !take_all && (tf.list || *tf.any == 0)) // nothing to mop up here (flagged tiles go to k_neighbor_tiles when listed)
         return;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cnt = 0;
-    bool mine = p < N;
-    int c0 = 0, c1 = 0, c2 = 0;
-    double xi = 0, yi = 0, zi = 0;
-    if (mine) {
-        xi = xs[p]; yi = ys[p]; zi = zs[p];
-        if (b.anypbc) // neighbor.cpp:139-142
-            wrap<TRI>(b, xi, yi, zi);
-        cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
-        if (tf.flag) { // fallback pass: only atoms of tiles the LDS-tiled kernel could not hold (or all of them when it stood down)
-            const int t = ((c0 / tf.tile) * tf.nt[1] + (c1 / tf.tile)) * tf.nt[2] + (c2 / tf.tile_z);
-            mine = take_all || tf.flag[t] != 0;
+    // the grid is capped (a stand-by launch then costs a few thousand workgroups that leave at once, not N / 256 of them):
+    // a workgroup strides over the atoms
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < N; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = base + threadIdx.x;
+        bool mine = p < N;
+        int c0 = 0, c1 = 0, c2 = 0;
+        double xi = 0, yi = 0, zi = 0;
+        if (mine) {
+            xi = xs[p]; yi = ys[p]; zi = zs[p];
+            if (b.anypbc) // neighbor.cpp:139-142
+                wrap<TRI>(b, xi, yi, zi);
+            cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+            if (tf.flag) { // fallback pass: only atoms of tiles the LDS-tiled kernel could not hold (or all of them when it stood down)
+                const int t = ((c0 / tf.tile) * tf.nt[1] + (c1 / tf.tile)) * tf.nt[2] + (c2 / tf.tile_z);
+                mine = take_all || tf.flag[t] != 0;
+            }
         }
+        if (mine)
+            cnt = max(cnt, neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
     }
-    if (mine)
-        cnt = neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2);
     if (MODE == 0) {
         int m = cnt;
 #pragma unroll
@@ -450,7 +455,7 @@ template <int MODE>
 static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const DBox &b, double rc, int *verlet,
                             double *dist, int *nn, int64_t M, int *max_count, TileFilter tf = TileFilter{})
 {
-    dim3 grid(grid_for(N, 256)), block(256);
+    dim3 grid(std::min(grid_for(N, 256), 8192)), block(256);
     if (b.tri)
         hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else

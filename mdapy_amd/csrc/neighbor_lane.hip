@@ -839,7 +839,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
                            cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, \
                            tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);                                       \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), dim3(1024), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs,             \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), dim3(512), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs,             \
                            cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0],  \
                            nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);                       \
     } while (0)
