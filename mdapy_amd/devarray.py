@@ -228,6 +228,33 @@ def empty(shape, dtype):
 # ---------------------------------------------------------------------------
 # marshalling
 # ---------------------------------------------------------------------------
+_mirrors = []  # [(weak reference to an immutable host array, its copy in HBM)]
+
+
+def _mirror_of(arr):
+    """HBM copy of a host array.  Large READ-ONLY arrays (frame columns, the species codes policy.label_codes caches) cannot
+    change under us, so their copy is kept while the array lives and the next call that is handed the same array does not
+    cross PCIe again."""
+    if arr.flags.writeable or not arr.flags.owndata or arr.nbytes < (1 << 20):  # (a read-only VIEW may still change through its base)
+        return HArray.from_numpy(arr)
+    import weakref
+
+    for k in range(len(_mirrors) - 1, -1, -1):
+        ref, dev = _mirrors[k]
+        if ref() is None:
+            del _mirrors[k]
+        elif ref() is arr:
+            return dev
+    dev = HArray.from_numpy(arr)
+    try:
+        _mirrors.append((weakref.ref(arr), dev))
+        del _mirrors[:-16]
+    except TypeError:
+        pass
+    return dev
+
+
+
 class Call:
     """Collects the array arguments of one C-ABI call and decides the memory space.
 
@@ -274,7 +301,7 @@ class Call:
             return int(a.data_ptr())
         arr = np.ascontiguousarray(as_numpy(a), dtype=dtype)  # read-only params accept convertible input (src/type.h:9-15)
         if self._is_dev():
-            h = HArray.from_numpy(arr)
+            h = _mirror_of(arr)
             self._keep.append(h)
             return h.data_ptr()
         self._keep.append(arr)

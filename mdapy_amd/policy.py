@@ -103,6 +103,7 @@ def label_codes(labels):
             if ref() is raw:
                 return list(names), codes
         names, codes = _label_codes(raw)
+        codes.setflags(write=False)  # shared by every later call on the same column (and mirrored in HBM once, devarray._mirror_of)
         import weakref
 
         try:
@@ -112,6 +113,24 @@ def label_codes(labels):
             pass
         return list(names), codes
     return _label_codes(raw)
+
+
+def label_population(codes, kinds):
+    """atoms per species code; cached with the codes of an immutable column"""
+    for ref, names, cached in _label_cache:
+        if cached is codes:
+            if len(_population) > 8:
+                _population.clear()
+            key = id(cached)
+            if key not in _population or _population[key][0]() is not cached:
+                import weakref
+
+                _population[key] = (weakref.ref(cached), np.bincount(cached, minlength=kinds))
+            return _population[key][1]
+    return np.bincount(codes, minlength=kinds)
+
+
+_population = {}
 
 
 def _label_codes(raw):

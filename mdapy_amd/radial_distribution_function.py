@@ -53,7 +53,7 @@ class RadialDistributionFunction:
         # all pairs against the ideal-gas expectation N^2 * shell / V
         self.g_total = counts.sum(axis=(0, 1)) / shell / self.N ** 2
         names = self.elements
-        population = np.bincount(self.type_list, minlength=len(names))
+        population = policy.label_population(self.type_list, len(names))
         both_orders = counts + counts.transpose(1, 0, 2)  # [a, b] + [b, a]
         self.g_partial = {}
         for a, name_a in enumerate(names):

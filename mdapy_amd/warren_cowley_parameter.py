@@ -16,9 +16,9 @@ class WarrenCowleyParameter:
             self.Ntype = len(names)
             return
         assert "type" in data.columns
-        codes = np.asarray(data["type"].to_numpy()).astype(np.int32) - np.int32(1)
-        kinds = len(np.unique(codes))
-        assert int(codes.max()) + 1 == kinds  # types must be 1..Ntype without gaps
+        present, codes = policy.label_codes(data["type"].to_numpy())  # (cached per immutable column, with its copy in HBM)
+        kinds = len(present)
+        assert present == list(range(1, kinds + 1))  # types must be 1..Ntype without gaps: then code == type - 1
         self.type_list, self.Ntype = codes, kinds
 
     def compute(self):
