@@ -122,30 +122,54 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
                     const double w0 = qx - s0, w1 = qy - s1, w2 = qz - s2;
                     const int64_t cell = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
                     const int sb = cell_start[cell], se = cell_start[cell + 1];
-                    for (int q = sb; q < se; ++q) {
-                        const int j = order[q];
-                        const double dx = xs[q] - w0, dy = ys[q] - w1, dz = zs[q] - w2;
-                        const double d2 = dx * dx + dy * dy + dz * dz;
-                        if (j == i && d2 == 0.0)
-                            continue;
-                        if (d2 > bound)
-                            continue;
-                        if (n == k && !(d2 < worst || (d2 == worst && j < worst_id)))
-                            continue;
-                        int pos = n < k ? n : k - 1;
-                        while (pos > 0) {
-                            const double pd = td[(pos - 1) * bd + t];
-                            const int pi = ti[(pos - 1) * bd + t];
-                            if (!(pd > d2 || (pd == d2 && pi > j)))
-                                break;
-                            td[pos * bd + t] = pd;
-                            ti[pos * bd + t] = pi;
-                            --pos;
+                    // candidates of a cell in batches of 8: the 32 loads of a batch are in flight together (one memory latency per
+                    // batch instead of one per candidate — the insertion below is data-dependent control flow, across which
+                    // the compiler does not move the next candidate's loads)
+                    for (int q0 = sb; q0 < se; q0 += 8) {
+                        double cx[8], cy[8], cz[8];
+                        int cj[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int q = min(q0 + u, se - 1);
+                            cx[u] = xs[q]; cy[u] = ys[q]; cz[u] = zs[q]; cj[u] = order[q];
                         }
-                        td[pos * bd + t] = d2;
-                        ti[pos * bd + t] = j;
-                        if (n < k) ++n;
-                        if (n == k) { worst = td[(k - 1) * bd + t]; worst_id = ti[(k - 1) * bd + t]; }
+                        // squared distances of the batch and a mask of the candidates that can still matter; then every lane
+                        // inserts ITS next such candidate per round: a wave runs max-over-lanes rounds (1-3 of 8) instead of
+                        // walking all 8 slots with the insertion loop live whenever any lane needs it
+                        double d2s[8];
+                        unsigned todo = 0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double dx = cx[u] - w0, dy = cy[u] - w1, dz = cz[u] - w2;
+                            d2s[u] = dx * dx + dy * dy + dz * dz;
+                            const bool live = q0 + u < se && !(cj[u] == i && d2s[u] == 0.0) && !(d2s[u] > bound);
+                            todo |= live ? 1u << u : 0u;
+                        }
+                        while (todo) {
+                            const int u = __builtin_ctz(todo);
+                            todo &= todo - 1;
+                            double d2 = d2s[0];
+                            int j = cj[0];
+#pragma unroll
+                            for (int v = 1; v < 8; ++v)
+                                if (u == v) { d2 = d2s[v]; j = cj[v]; }
+                            if (n == k && !(d2 < worst || (d2 == worst && j < worst_id)))
+                                continue;
+                            int pos = n < k ? n : k - 1;
+                            while (pos > 0) {
+                                const double pd = td[(pos - 1) * bd + t];
+                                const int pi = ti[(pos - 1) * bd + t];
+                                if (!(pd > d2 || (pd == d2 && pi > j)))
+                                    break;
+                                td[pos * bd + t] = pd;
+                                ti[pos * bd + t] = pi;
+                                --pos;
+                            }
+                            td[pos * bd + t] = d2;
+                            ti[pos * bd + t] = j;
+                            if (n < k) ++n;
+                            if (n == k) { worst = td[(k - 1) * bd + t]; worst_id = ti[(k - 1) * bd + t]; }
+                        }
                     }
                 }
             }
