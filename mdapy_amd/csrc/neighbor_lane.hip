@@ -115,85 +115,77 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
     return dx * dx + dy * dy + dz * dz;
 }
 
-// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v130-v151).  Four candidates per trip: four 16-byte LDS reads in
-// flight, then per candidate 3 subtractions, an FMA chain that ends in d' = d2 - rc^2, one compare whose VCC is shifted
-// into the trip's hit nibble by an add-with-carry, and one v_min that tracks the smallest |d'| the lane has seen (the
-// decision-band test happens once per centre).  Lanes whose run is exhausted leave EXEC; the others go on.
-// a: LDS byte address of the run's first candidate; rem: its length; bit (L4-1-j) of `mask` is candidate j, L4 = length
-// rounded up to 4.  Candidates past the end of a run are other staged atoms: their hit bits are masked, a small |d'| of
-// theirs only costs a redundant double-precision pass.
-__device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, float sy, float sz, float nmid, float negT,
-                                             unsigned &mask, float &w)
+// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v130-v148).  K candidates per trip
+// (K = 4, 8, 12 or 16, chosen on the host from the run-length histogram so that nearly every run is ONE trip): four
+// 16-byte LDS reads in flight all the time (a candidate's registers are re-loaded as soon as it is consumed), then per
+// candidate 3 subtractions, an FMA chain that ends in e = d2 - c (c a little below rc^2), v_alignbit shifting e's SIGN into
+// the hit mask, and an unsigned v_min of e's bits that tracks the smallest NON-NEGATIVE e the lane has seen (negative
+// floats are the large unsigned numbers).  Eight instructions, none of which touches VCC or an SGPR: e < 0 is a hit for
+// sure, e > W a miss for sure, 0 <= e <= W (decided once per centre from the tracked minimum) sends the lane to the
+// double-precision pass.  Lanes whose run is exhausted leave EXEC; the others go on.
+// a: LDS byte address of the run's first candidate; rem: its length; bit (S-1-j) of `mask` is candidate j, S = length
+// rounded up to a whole number of trips.  Candidates past the end of a run are other staged atoms (or, for the very last
+// runs of the tile, whatever LDS holds behind them): their bits are masked by the caller, a small e of theirs only costs a
+// redundant double-precision pass.
+#define MDH_CAND(X, Y, Z)                                                                                                            \
+    "v_sub_f32 v146, " X ", %[sx]\n\t"                                                                                               \
+    "v_sub_f32 v147, " Y ", %[sy]\n\t"                                                                                               \
+    "v_sub_f32 v148, " Z ", %[sz]\n\t"                                                                                               \
+    "v_fma_f32 v146, v146, v146, %[negc]\n\t"                                                                                        \
+    "v_fmac_f32 v146, v147, v147\n\t"                                                                                                \
+    "v_fmac_f32 v146, v148, v148\n\t"                                                                                                \
+    "v_alignbit_b32 %[m], %[m], v146, 31\n\t"                                                                                        \
+    "v_min_u32 %[w], %[w], v146\n\t"
+#define MDH_C0 MDH_CAND("v130", "v131", "v132")
+#define MDH_C1 MDH_CAND("v134", "v135", "v136")
+#define MDH_C2 MDH_CAND("v138", "v139", "v140")
+#define MDH_C3 MDH_CAND("v142", "v143", "v144")
+#define MDH_R0(OFF) "ds_read_b128 v[130:133], %[a] offset:" #OFF "\n\t"
+#define MDH_R1(OFF) "ds_read_b128 v[134:137], %[a] offset:" #OFF "\n\t"
+#define MDH_R2(OFF) "ds_read_b128 v[138:141], %[a] offset:" #OFF "\n\t"
+#define MDH_R3(OFF) "ds_read_b128 v[142:145], %[a] offset:" #OFF "\n\t"
+#define MDH_W(N) "s_waitcnt lgkmcnt(" #N ")\n\t"
+// four candidates consumed, the next four requested (byte offsets of those)
+#define MDH_QUAD(O0, O1, O2, O3) MDH_W(3) MDH_C0 MDH_R0(O0) MDH_W(3) MDH_C1 MDH_R1(O1) MDH_W(3) MDH_C2 MDH_R2(O2) MDH_W(3) MDH_C3 MDH_R3(O3)
+#define MDH_HEAD MDH_R0(0) MDH_R1(16) MDH_R2(32) MDH_R3(48)
+#define MDH_TAIL MDH_W(3) MDH_C0 MDH_W(2) MDH_C1 MDH_W(1) MDH_C2 MDH_W(0) MDH_C3
+#define MDH_SCAN_LOOP(BODY, BYTES, KNEG)                                                                                             \
+    asm volatile("s_mov_b64 %[save], exec\n\t"                                                                                       \
+                 "v_mov_b32 %[m], 0\n"                                                                                               \
+                 ".Lscan_top_%=:\n\t"                                                                                                \
+                 "v_cmp_lt_i32 vcc, 0, %[rem]\n\t"                                                                                   \
+                 "s_and_b64 exec, exec, vcc\n\t"                                                                                     \
+                 "s_cbranch_execz .Lscan_end_%=\n\t" BODY "v_add_u32 %[a], " #BYTES ", %[a]\n\t"                                     \
+                 "v_add_u32 %[rem], " #KNEG ", %[rem]\n\t"                                                                           \
+                 "s_branch .Lscan_top_%=\n"                                                                                          \
+                 ".Lscan_end_%=:\n\t"                                                                                                \
+                 "s_mov_b64 exec, %[save]\n\t"                                                                                       \
+                 : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)                                       \
+                 : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [negc] "v"(negc)                                                        \
+                 : "vcc", "scc", "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140",   \
+                   "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148")
+template <int K>
+__device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, float sy, float sz, float negc, unsigned &mask,
+                                             unsigned &w)
 {
+    static_assert(K == 4 || K == 8 || K == 12 || K == 16, "trip length");
     unsigned long long save;
     unsigned m;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n\t"
-        "v_mov_b32 %[m], 0\n"
-        ".Lscan_top_%=:\n\t"
-        "v_cmp_lt_i32 vcc, 0, %[rem]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "s_cbranch_execz .Lscan_end_%=\n\t"
-        "ds_read_b128 v[130:133], %[a]\n\t"
-        "ds_read_b128 v[134:137], %[a] offset:16\n\t"
-        "ds_read_b128 v[138:141], %[a] offset:32\n\t"
-        "ds_read_b128 v[142:145], %[a] offset:48\n\t"
-        "v_min_u32 v150, 4, %[rem]\n\t"
-        "v_sub_u32 v151, 4, v150\n\t"
-        "v_bfm_b32 v150, v150, v151\n\t"        // ((1 << valid) - 1) << (4 - valid): the valid candidates of this trip
-        "v_add_u32 %[a], 64, %[a]\n\t"
-        "v_add_u32 %[rem], -4, %[rem]\n\t"
-        "v_mov_b32 v149, 0\n\t"
-        "s_waitcnt lgkmcnt(3)\n\t"
-        "v_sub_f32 v146, v130, %[sx]\n\t"
-        "v_sub_f32 v147, v131, %[sy]\n\t"
-        "v_sub_f32 v148, v132, %[sz]\n\t"
-        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
-        "v_fmac_f32 v146, v147, v147\n\t"
-        "v_fmac_f32 v146, v148, v148\n\t"
-        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
-        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
-        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        "v_sub_f32 v146, v134, %[sx]\n\t"
-        "v_sub_f32 v147, v135, %[sy]\n\t"
-        "v_sub_f32 v148, v136, %[sz]\n\t"
-        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
-        "v_fmac_f32 v146, v147, v147\n\t"
-        "v_fmac_f32 v146, v148, v148\n\t"
-        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
-        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
-        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        "v_sub_f32 v146, v138, %[sx]\n\t"
-        "v_sub_f32 v147, v139, %[sy]\n\t"
-        "v_sub_f32 v148, v140, %[sz]\n\t"
-        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
-        "v_fmac_f32 v146, v147, v147\n\t"
-        "v_fmac_f32 v146, v148, v148\n\t"
-        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
-        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
-        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_sub_f32 v146, v142, %[sx]\n\t"
-        "v_sub_f32 v147, v143, %[sy]\n\t"
-        "v_sub_f32 v148, v144, %[sz]\n\t"
-        "v_fma_f32 v146, v146, v146, %[nmid]\n\t"
-        "v_fmac_f32 v146, v147, v147\n\t"
-        "v_fmac_f32 v146, v148, v148\n\t"
-        "v_cmp_gt_f32 vcc, %[negT], v146\n\t"
-        "v_addc_co_u32 v149, vcc, v149, v149, vcc\n\t"
-        "v_min_f32_e64 %[w], %[w], |v146|\n\t"
-        "v_and_b32 v149, v149, v150\n\t"
-        "v_lshl_or_b32 %[m], %[m], 4, v149\n\t"
-        "s_branch .Lscan_top_%=\n"
-        ".Lscan_end_%=:\n\t"
-        "s_mov_b64 exec, %[save]\n\t"
-        : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)
-        : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [nmid] "v"(nmid), [negT] "s"(negT)
-        : "vcc", "scc", "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141",
-          "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151");
+    if (K == 4)
+        MDH_SCAN_LOOP(MDH_HEAD MDH_TAIL, 64, -4);
+    else if (K == 8)
+        MDH_SCAN_LOOP(MDH_HEAD MDH_QUAD(64, 80, 96, 112) MDH_TAIL, 128, -8);
+    else if (K == 12)
+        MDH_SCAN_LOOP(MDH_HEAD MDH_QUAD(64, 80, 96, 112) MDH_QUAD(128, 144, 160, 176) MDH_TAIL, 192, -12);
+    else
+        MDH_SCAN_LOOP(MDH_HEAD MDH_QUAD(64, 80, 96, 112) MDH_QUAD(128, 144, 160, 176) MDH_QUAD(192, 208, 224, 240) MDH_TAIL, 256, -16);
     mask = m;
+}
+// slots a run of `len` candidates takes in its hit mask: whole trips
+template <int K>
+__device__ __forceinline__ int run_slots(int len)
+{
+    return K == 12 ? (len > 12 ? 24 : 12) : ((len + K - 1) & ~(K - 1));
 }
 
 // IEEE double-precision square root.  For x >= 2^-767 this is the compiler's own expansion of sqrt(x) (v_rsq_f64 seed, one
@@ -216,14 +208,14 @@ __device__ __forceinline__ double sqrt_f64(double x)
 }
 
 // the same run decided by the reference's double-precision expression (threads with a pair inside the decision band)
-template <bool SELF, bool TRI>
+template <bool SELF, bool TRI, int K>
 __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy, const double *__restrict__ lz,
                                                  const unsigned short *__restrict__ lsh, const DBox &b, double rcsq, int k0, int len,
                                                  int li, double xi, double yi, double zi)
 {
     unsigned m = 0;
-    const int L4 = (len + 3) & ~3;
-    for (int j = 0; j < L4; ++j) {
+    const int S = run_slots<K>(len);
+    for (int j = 0; j < S; ++j) {
         const int k = k0 + j;
         bool h = false;
         if (j < len) {
@@ -244,11 +236,12 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
 // single-precision coordinates are Cartesian, relative to the tile's corner, of the WRAPPED atom shifted by the lattice
 // vectors its cell is away from the tile; every decision inside the band and every written distance goes through the
 // reference's fractional fold.
-template <bool COUNT, bool TRI>
+// K: candidates per scan trip (runs longer than the mask allows — 24 for K = 12, else 32 — send the tile to the next pass)
+template <bool COUNT, bool TRI, int K>
 __global__ __launch_bounds__(NT) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
-    Grid g, double rc, float nmid, float T, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
+    Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
     int M, int mp_shift, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
@@ -431,7 +424,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
             const unsigned lo_c = hc[tid - 1], hi_c = hc[tid + 1];
             const unsigned k0 = lo_c & 0xffffu, k3 = (hi_c & 0xffffu) + (hi_c >> 16);
             hr[tid] = k0 | ((k3 - k0) << 16);
-            if (k3 - k0 > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
+            if (k3 - k0 > (K == 12 ? 24u : 32u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to whole trips)
         }
         __syncthreads();
         if (s_flag[1] | s_flag[2]) {
@@ -454,23 +447,26 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
 #pragma unroll
                 for (int r = 0; r < 9; ++r) // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
                     hv[r] = hr[cb + ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ];
-                float w = 3.0e38f; // smallest |d2 - rc^2| this centre has seen
+                unsigned w = 0x7f7fffffu; // bits of the smallest non-negative d2 - c this centre has seen
 #pragma unroll
-                for (int r = 0; r < 9; ++r)
-                    scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), (int)(hv[r] >> 16), s.x, s.y, s.z, nmid, -T, mk[r], w);
+                for (int r = 0; r < 9; ++r) {
+                    const int len = (int)(hv[r] >> 16);
+                    scan_run_asm<K>(f4_lds + ((hv[r] & 0xffffu) << 4), len, s.x, s.y, s.z, negc, mk[r], w);
+                    mk[r] &= ~0u << (run_slots<K>(len) - len); // slots past the end of the run
+                }
                 {   // the centre itself sits in run 4 with d2 = 0: not a neighbour (neighbor.cpp:162)
-                    const int L4 = ((int)(hv[4] >> 16) + 3) & ~3;
-                    mk[4] &= ~(1u << (L4 - 1 - (li - (int)(hv[4] & 0xffffu))));
+                    const int S = run_slots<K>((int)(hv[4] >> 16));
+                    mk[4] &= ~(1u << (S - 1 - (li - (int)(hv[4] & 0xffffu))));
                 }
                 const double2 ci = lxy[li];
                 double xi = ci.x, yi = ci.y, zi = lz[li];
                 if (b.anypbc) // neighbor.cpp:139-142
                     wrap<TRI>(b, xi, yi, zi);
-                if (__builtin_expect(!(w > T), 0)) { // a pair inside the decision band: this centre again in double precision
+                if (__builtin_expect(w <= __float_as_uint(W), 0)) { // a pair inside the decision band: this centre again in double precision
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
-                        else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        if (r == 4) mk[r] = scan_run_f64<true, TRI, K>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        else mk[r] = scan_run_f64<false, TRI, K>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
                     }
                 }
                 int hits = 0;
@@ -487,7 +483,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                     int sl = 0;
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        const int kend = (int)(hv[r] & 0xffffu) + ((((int)(hv[r] >> 16) + 3) & ~3) - 32); // + clz(m) = LDS index of the hit
+                        const int kend = (int)(hv[r] & 0xffffu) + (run_slots<K>((int)(hv[r] >> 16)) - 32); // + clz(m) = LDS index of the hit
                         unsigned m = mk[r];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -711,10 +707,28 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     for (int d = 0; d < 3; ++d)
         if (g.nc[d] < (b.pbc[d] ? 7 : 4)) { g_last_plan[6] = -3; return p; } // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
     if (!(rc > 1e-12 && rc < 1e12)) { g_last_plan[6] = -4; return p; }
-    int64_t runs = 0, longer = 0;
+    // candidates per scan trip: the shortest instruction stream for the run lengths at hand.  A wave leaves a run when its
+    // LONGEST lane does, so the length that counts is the one only a fraction of a percent of the runs exceed; a trip of K
+    // costs 8 K + 6 instructions.  Runs beyond what one mask register holds (24 slots for K = 12, else 32) send their tile to
+    // the thread-per-atom code: a variant that would do that to more than 0.2 % of the runs is not taken.
+    int64_t runs = 0;
     for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
-    for (int len = 29; len <= 65; ++len) longer += gs.v[1 + len];
-    if (runs > 0 && (double)longer > 0.002 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)longer; g_last_plan[4] = (int)runs; return p; } // cells so full that many runs would not fit a 32-bit hit mask
+    auto longer_than = [&](int len) { int64_t n = 0; for (int l = len + 1; l <= 65; ++l) n += gs.v[1 + l]; return n; };
+    int Lq = 1;
+    while (Lq < 65 && runs > 0 && (double)longer_than(Lq) > 0.003 * (double)runs) ++Lq;
+    static const int k_env = [] { const char *e = std::getenv("MDH_LANE_K"); return e ? std::atoi(e) : 0; }();
+    int K = 0;
+    double best_cost = 0;
+    for (int k : {4, 8, 12, 16}) {
+        const int limit = k == 12 ? 24 : 32;
+        if (runs > 0 && (double)longer_than(limit) > 0.002 * (double)runs)
+            continue;
+        if (k_env && k != k_env)
+            continue;
+        const double cost = (double)((Lq + k - 1) / k) * (8.0 * k + 6.0);
+        if (!K || cost < best_cost) { K = k; best_cost = cost; }
+    }
+    if (!K) { g_last_plan[6] = -5; g_last_plan[5] = (int)longer_than(32); g_last_plan[4] = (int)runs; return p; } // cells so full that many runs would not fit a 32-bit hit mask
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
@@ -772,18 +786,23 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     const double du = std::ldexp(E, -24) * 1.01 + std::ldexp(big, -49);
     const double rcsq = rc * rc;
     const double tol = 2.0 * (11.0 * du * rc + 12.0 * std::ldexp(rcsq, -24)); // twice the bound: a wider band costs nothing
-    p.mid = (float)rcsq;
-    const double want = tol + std::fabs((double)p.mid - rcsq);
-    float T = (float)want;
-    while ((double)T < want) T = std::nextafterf(T, INFINITY);
-    p.T = T;
+    // e = d2 - c in single precision is within tol of the exact value.  c: the largest float <= rc^2 - tol, so that e < 0 is
+    // a hit for sure; W: the smallest float >= (rc^2 - c) + tol, so that e > W is a miss for sure
+    float c = (float)(rcsq - tol);
+    while ((double)c > rcsq - tol) c = std::nextafterf(c, -INFINITY);
+    const double want = (rcsq - (double)c) + tol;
+    float W = (float)want;
+    while ((double)W < want) W = std::nextafterf(W, INFINITY);
+    p.mid = c;
+    p.T = W;
+    p.K = K;
     p.txy = best.txy;
     p.tz = best.tz;
     p.cap = best_cap;
     p.occupied = occ;
     p.full = occ >= g.ncell;
     g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M);
-    g_last_plan[4] = p.full; g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
+    g_last_plan[4] = p.full | (p.K << 8); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
 
@@ -827,24 +846,32 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
-    const float nmid = -plan.mid;
+    const float negc = -plan.mid;
     const Shape ts2{ts.txy, 1};
     const int nt2b = nt[2] * nsub;
-    if (lds > 60 * 1024) // above the default dynamic-LDS limit: raise it for the instance about to run
-        (void)hipFuncSetAttribute(b.tri ? (count ? reinterpret_cast<const void *>(&k_neighbor_lane<true, true>) : reinterpret_cast<const void *>(&k_neighbor_lane<false, true>))
-                                        : (count ? reinterpret_cast<const void *>(&k_neighbor_lane<true, false>) : reinterpret_cast<const void *>(&k_neighbor_lane<false, false>)),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-#define MDH_LANE_LAUNCH(COUNT, TRI)                                                                                                       \
+#define MDH_LANE_LAUNCH(COUNT, TRI, K)                                                                                                    \
     do {                                                                                                                                  \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
-                           cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, \
+        if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, K>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, \
                            tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);                                       \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI>), dim3(512), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs,             \
-                           cg.cell_start, b, cg.g, rc, nmid, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0],  \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, K>), dim3(512), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs,          \
+                           cg.cell_start, b, cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0],  \
                            nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);                       \
     } while (0)
-    if (b.tri) { if (count) MDH_LANE_LAUNCH(true, true); else MDH_LANE_LAUNCH(false, true); }
-    else { if (count) MDH_LANE_LAUNCH(true, false); else MDH_LANE_LAUNCH(false, false); }
+#define MDH_LANE_K(COUNT, TRI)                                                                                                            \
+    do {                                                                                                                                  \
+        switch (plan.K) {                                                                                                                 \
+        case 4: MDH_LANE_LAUNCH(COUNT, TRI, 4); break;                                                                                    \
+        case 8: MDH_LANE_LAUNCH(COUNT, TRI, 8); break;                                                                                    \
+        case 12: MDH_LANE_LAUNCH(COUNT, TRI, 12); break;                                                                                  \
+        default: MDH_LANE_LAUNCH(COUNT, TRI, 16); break;                                                                                  \
+        }                                                                                                                                 \
+    } while (0)
+    if (b.tri) { if (count) MDH_LANE_K(true, true); else MDH_LANE_K(false, true); }
+    else { if (count) MDH_LANE_K(true, false); else MDH_LANE_K(false, false); }
+#undef MDH_LANE_K
 #undef MDH_LANE_LAUNCH
     MDH_HIP(hipGetLastError());
     // what the two passes listed for the thread-per-atom code (k_neighbor_tiles), in the tiling of the second pass

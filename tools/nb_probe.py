@@ -20,6 +20,7 @@ if len(sys.argv) > 6:  # sheared box: the same fractional coordinates in a tricl
     Hm = np.array([[Lb, 0, 0], [sh * Lb, Lb, 0], [0.5 * sh * Lb, sh * Lb, Lb]])
     x, y, z = x + sh * y + 0.5 * sh * z, y + sh * z, z
     box = mp.Box(Hm)
+if os.environ.get('NB_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['NB_LIB'])  # A/B against another build of the library
 L = _lib.lib()
 if os.environ.get('NB_VARIANT'): L.mdh_debug_set_neighbor_variant(int(os.environ['NB_VARIANT']))
 verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty((n, M), dtype=torch.float64, device=dev)
