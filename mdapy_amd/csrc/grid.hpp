@@ -62,7 +62,6 @@ struct LanePlan {
     int txy, tz;      // tile shape in cells; txy == 0: not applicable
     int cap;          // atoms a tile's halo may hold in LDS
     float mid, T;     // single-precision scan: the constant c subtracted from d2 (a little below rc^2) and the width W of the band above it
-    int K;            // candidates per scan trip (4, 8, 12 or 16)
     bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live
     int64_t occupied; // cells of the occupied region (last known)
 };

@@ -115,18 +115,17 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
     return dx * dx + dy * dy + dz * dz;
 }
 
-// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v130-v148).  K candidates per trip
-// (K = 4, 8, 12 or 16, chosen on the host from the run-length histogram so that nearly every run is ONE trip): four
-// 16-byte LDS reads in flight all the time (a candidate's registers are re-loaded as soon as it is consumed), then per
-// candidate 3 subtractions, an FMA chain that ends in e = d2 - c (c a little below rc^2), v_alignbit shifting e's SIGN into
-// the hit mask, and an unsigned v_min of e's bits that tracks the smallest NON-NEGATIVE e the lane has seen (negative
-// floats are the large unsigned numbers).  Eight instructions, none of which touches VCC or an SGPR: e < 0 is a hit for
-// sure, e > W a miss for sure, 0 <= e <= W (decided once per centre from the tracked minimum) sends the lane to the
-// double-precision pass.  Lanes whose run is exhausted leave EXEC; the others go on.
-// a: LDS byte address of the run's first candidate; rem: its length; bit (S-1-j) of `mask` is candidate j, S = length
-// rounded up to a whole number of trips.  Candidates past the end of a run are other staged atoms (or, for the very last
-// runs of the tile, whatever LDS holds behind them): their bits are masked by the caller, a small e of theirs only costs a
-// redundant double-precision pass.
+// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v130-v148).  Four candidates per
+// trip: four 16-byte LDS reads in flight, then per candidate 3 subtractions, an FMA chain that ends in e = d2 - c (c a little
+// below rc^2), v_alignbit shifting e's SIGN into the hit mask, and an unsigned v_min of e's bits that tracks the smallest
+// NON-NEGATIVE e the lane has seen (negative floats are the large unsigned numbers).  Eight instructions, none of which
+// touches VCC or an SGPR: e < 0 is a hit for sure, e > W a miss for sure, 0 <= e <= W (decided once per centre from the
+// tracked minimum) sends the lane to the double-precision pass.  Lanes whose run is exhausted leave EXEC; the others go on.
+// a: LDS byte address of the run's first candidate; rem: its length; bit (L4-1-j) of `mask` is candidate j, L4 = length
+// rounded up to 4.  Candidates past the end of a run are other staged atoms: their bits are masked by the caller, a small
+// e of theirs only costs a redundant double-precision pass.  (Trips of 8, 12 and 16 candidates with the reads re-issued as
+// they are consumed were measured too: what counts is the number of candidate SLOTS a wave walks — 12 for the 10-atom runs
+// of the headline lattice with trips of 4 or 12, 16 with 8 or 16 — not the per-trip overhead)
 #define MDH_CAND(X, Y, Z)                                                                                                            \
     "v_sub_f32 v146, " X ", %[sx]\n\t"                                                                                               \
     "v_sub_f32 v147, " Y ", %[sy]\n\t"                                                                                               \
@@ -136,56 +135,41 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
     "v_fmac_f32 v146, v148, v148\n\t"                                                                                                \
     "v_alignbit_b32 %[m], %[m], v146, 31\n\t"                                                                                        \
     "v_min_u32 %[w], %[w], v146\n\t"
-#define MDH_C0 MDH_CAND("v130", "v131", "v132")
-#define MDH_C1 MDH_CAND("v134", "v135", "v136")
-#define MDH_C2 MDH_CAND("v138", "v139", "v140")
-#define MDH_C3 MDH_CAND("v142", "v143", "v144")
-#define MDH_R0(OFF) "ds_read_b128 v[130:133], %[a] offset:" #OFF "\n\t"
-#define MDH_R1(OFF) "ds_read_b128 v[134:137], %[a] offset:" #OFF "\n\t"
-#define MDH_R2(OFF) "ds_read_b128 v[138:141], %[a] offset:" #OFF "\n\t"
-#define MDH_R3(OFF) "ds_read_b128 v[142:145], %[a] offset:" #OFF "\n\t"
-#define MDH_W(N) "s_waitcnt lgkmcnt(" #N ")\n\t"
-// four candidates consumed, the next four requested (byte offsets of those)
-#define MDH_QUAD(O0, O1, O2, O3) MDH_W(3) MDH_C0 MDH_R0(O0) MDH_W(3) MDH_C1 MDH_R1(O1) MDH_W(3) MDH_C2 MDH_R2(O2) MDH_W(3) MDH_C3 MDH_R3(O3)
-#define MDH_HEAD MDH_R0(0) MDH_R1(16) MDH_R2(32) MDH_R3(48)
-#define MDH_TAIL MDH_W(3) MDH_C0 MDH_W(2) MDH_C1 MDH_W(1) MDH_C2 MDH_W(0) MDH_C3
-#define MDH_SCAN_LOOP(BODY, BYTES, KNEG)                                                                                             \
-    asm volatile("s_mov_b64 %[save], exec\n\t"                                                                                       \
-                 "v_mov_b32 %[m], 0\n"                                                                                               \
-                 ".Lscan_top_%=:\n\t"                                                                                                \
-                 "v_cmp_lt_i32 vcc, 0, %[rem]\n\t"                                                                                   \
-                 "s_and_b64 exec, exec, vcc\n\t"                                                                                     \
-                 "s_cbranch_execz .Lscan_end_%=\n\t" BODY "v_add_u32 %[a], " #BYTES ", %[a]\n\t"                                     \
-                 "v_add_u32 %[rem], " #KNEG ", %[rem]\n\t"                                                                           \
-                 "s_branch .Lscan_top_%=\n"                                                                                          \
-                 ".Lscan_end_%=:\n\t"                                                                                                \
-                 "s_mov_b64 exec, %[save]\n\t"                                                                                       \
-                 : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)                                       \
-                 : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [negc] "v"(negc)                                                        \
-                 : "vcc", "scc", "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140",   \
-                   "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148")
-template <int K>
 __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, float sy, float sz, float negc, unsigned &mask,
                                              unsigned &w)
 {
-    static_assert(K == 4 || K == 8 || K == 12 || K == 16, "trip length");
     unsigned long long save;
     unsigned m;
-    if (K == 4)
-        MDH_SCAN_LOOP(MDH_HEAD MDH_TAIL, 64, -4);
-    else if (K == 8)
-        MDH_SCAN_LOOP(MDH_HEAD MDH_QUAD(64, 80, 96, 112) MDH_TAIL, 128, -8);
-    else if (K == 12)
-        MDH_SCAN_LOOP(MDH_HEAD MDH_QUAD(64, 80, 96, 112) MDH_QUAD(128, 144, 160, 176) MDH_TAIL, 192, -12);
-    else
-        MDH_SCAN_LOOP(MDH_HEAD MDH_QUAD(64, 80, 96, 112) MDH_QUAD(128, 144, 160, 176) MDH_QUAD(192, 208, 224, 240) MDH_TAIL, 256, -16);
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "v_mov_b32 %[m], 0\n"
+                 ".Lscan_top_%=:\n\t"
+                 "v_cmp_lt_i32 vcc, 0, %[rem]\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "s_cbranch_execz .Lscan_end_%=\n\t"
+                 "ds_read_b128 v[130:133], %[a]\n\t"
+                 "ds_read_b128 v[134:137], %[a] offset:16\n\t"
+                 "ds_read_b128 v[138:141], %[a] offset:32\n\t"
+                 "ds_read_b128 v[142:145], %[a] offset:48\n\t"
+                 "v_add_u32 %[a], 64, %[a]\n\t"
+                 "v_add_u32 %[rem], -4, %[rem]\n\t"
+                 "s_waitcnt lgkmcnt(3)\n\t" MDH_CAND("v130", "v131", "v132")
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND("v134", "v135", "v136")
+                 "s_waitcnt lgkmcnt(1)\n\t" MDH_CAND("v138", "v139", "v140")
+                 "s_waitcnt lgkmcnt(0)\n\t" MDH_CAND("v142", "v143", "v144")
+                 "s_branch .Lscan_top_%=\n"
+                 ".Lscan_end_%=:\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)
+                 : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [negc] "v"(negc)
+                 : "vcc", "scc", "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140",
+                   "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148");
     mask = m;
 }
-// slots a run of `len` candidates takes in its hit mask: whole trips
-template <int K>
+#undef MDH_CAND
+// slots a run of `len` candidates takes in its hit mask: whole trips of four
 __device__ __forceinline__ int run_slots(int len)
 {
-    return K == 12 ? (len > 12 ? 24 : 12) : ((len + K - 1) & ~(K - 1));
+    return (len + 3) & ~3;
 }
 
 // IEEE double-precision square root.  For x >= 2^-767 this is the compiler's own expansion of sqrt(x) (v_rsq_f64 seed, one
@@ -208,13 +192,13 @@ __device__ __forceinline__ double sqrt_f64(double x)
 }
 
 // the same run decided by the reference's double-precision expression (threads with a pair inside the decision band)
-template <bool SELF, bool TRI, int K>
+template <bool SELF, bool TRI>
 __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy, const double *__restrict__ lz,
                                                  const unsigned short *__restrict__ lsh, const DBox &b, double rcsq, int k0, int len,
                                                  int li, double xi, double yi, double zi)
 {
     unsigned m = 0;
-    const int S = run_slots<K>(len);
+    const int S = run_slots(len);
     for (int j = 0; j < S; ++j) {
         const int k = k0 + j;
         bool h = false;
@@ -236,8 +220,10 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
 // single-precision coordinates are Cartesian, relative to the tile's corner, of the WRAPPED atom shifted by the lattice
 // vectors its cell is away from the tile; every decision inside the band and every written distance goes through the
 // reference's fractional fold.
-// K: candidates per scan trip (runs longer than the mask allows — 24 for K = 12, else 32 — send the tile to the next pass)
-template <bool COUNT, bool TRI, int K>
+// LOOP: the workgroup walks every (gridDim/8)-th tile of its XCD's chunk (tile lists whose length only the device knows);
+// false: one tile per workgroup, straight-line code (measurably faster: 1.13 against 1.22 ms on the headline build — the
+// loop-carried state costs scalar-register spills in every phase)
+template <bool COUNT, bool TRI, bool LOOP>
 __global__ __launch_bounds__(NT) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
@@ -276,34 +262,33 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     // (neighbouring tiles share halo cells through the same L2; vacuum leaves no XCD idle)
     const int nlive = parent ? min(*n_live, nt0 * nt1 * parent_nt2) * nsub : ((list_mode && tile_list) ? *n_live : nt0 * nt1 * nt2);
     const int per = (nlive + 7) / 8;
-    for (int jt = (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
-        const int slot = (blockIdx.x & 7) * per + jt;
-        if (slot >= nlive)
-            break;
-        int tile_id, t0, t1, t2;
+    struct Tile { int id, T0, T1, T2; bool empty; };
+    struct Halo { int cnt, src, img, hz; bool edge, centre; };
+    auto tile_of = [&](int slot) {
+        Tile t;
+        int t0, t1, t2;
         if (parent) {
             const int pt = parent[slot / nsub]; // tile of the first pass
             t2 = (pt % parent_nt2) * nsub + slot % nsub;
             t1 = (pt / parent_nt2) % nt1;
             t0 = pt / (parent_nt2 * nt1);
-            tile_id = (t0 * nt1 + t1) * nt2 + t2;
+            t.id = (t0 * nt1 + t1) * nt2 + t2;
         } else {
-            tile_id = (list_mode && tile_list) ? tile_list[slot] : slot;
-            t2 = tile_id % nt2; t1 = (tile_id / nt2) % nt1; t0 = tile_id / (nt2 * nt1);
+            t.id = (list_mode && tile_list) ? tile_list[slot] : slot;
+            t2 = t.id % nt2; t1 = (t.id / nt2) % nt1; t0 = t.id / (nt2 * nt1);
         }
-        const int T0 = t0 * TXY, T1 = t1 * TXY, T2 = t2 * TZ;
-        if (T2 >= g.nc[2]) // (a slice beyond the grid: the parent tile was a clipped one)
-            continue;
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
-
-        // ---- halo cell of this thread: source range, image code, is it a centre cell
-        int cnt = 0, src = 0, img = NEUTRAL, hz = 0;
-        bool edge = false, centre_cell = false; // edge: first / last cell of an open axis (atoms outside the box are clamped into it, neighbor.cpp:58-61)
-        if (tid < NH) {
+        t.T0 = t0 * TXY; t.T1 = t1 * TXY; t.T2 = t2 * TZ;
+        t.empty = t.T2 >= g.nc[2]; // (a slice beyond the grid: the parent tile was a clipped one)
+        return t;
+    };
+    // halo cell of this thread: source range, image code, is it a centre cell
+    auto halo_of = [&](const Tile &t) {
+        Halo h{0, 0, NEUTRAL, 0, false, false}; // edge: first / last cell of an open axis (atoms outside the box are clamped into it, neighbor.cpp:58-61)
+        if (tid < NH && !t.empty) {
             const int hcol = tid / HZ;
-            hz = tid - hcol * HZ;
+            h.hz = tid - hcol * HZ;
             const int hx = hcol / HXY, hy = hcol - hx * HXY;
-            const int g0 = T0 + hx - 1, g1 = T1 + hy - 1, g2 = T2 + hz - 1;
+            const int g0 = t.T0 + hx - 1, g1 = t.T1 + hy - 1, g2 = t.T2 + h.hz - 1;
             // a cell beyond an OPEN face is the far side of the box in the reference's modulo walk (neighbor.cpp:18-27); with
             // >= 4 cells on the axis its atoms are >= 2 rc from every centre of this tile: no hits, not staged
             const bool in0 = b.pbc[0] ? (g0 >= -1 && g0 <= g.nc[0]) : (g0 >= 0 && g0 < g.nc[0]);
@@ -314,44 +299,55 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 const int a1 = g1 < 0 ? g1 + g.nc[1] : (g1 >= g.nc[1] ? g1 - g.nc[1] : g1);
                 const int a2 = g2 < 0 ? g2 + g.nc[2] : (g2 >= g.nc[2] ? g2 - g.nc[2] : g2);
                 const int64_t c = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
-                src = cell_start[c];
-                cnt = cell_start[c + 1] - src;
+                h.src = cell_start[c];
+                h.cnt = cell_start[c + 1] - h.src;
                 // image of the candidate cell seen from an in-grid centre cell: below the box -> raw coordinates are ~+L
                 // away (n = +1); above -> n = -1
                 const int n0 = g0 < 0 ? 1 : (g0 >= g.nc[0] ? -1 : 0);
                 const int n1 = g1 < 0 ? 1 : (g1 >= g.nc[1] ? -1 : 0);
                 const int n2 = g2 < 0 ? 1 : (g2 >= g.nc[2] ? -1 : 0);
-                img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
-                edge = (!b.pbc[0] && (a0 == 0 || a0 == g.nc[0] - 1)) || (!b.pbc[1] && (a1 == 0 || a1 == g.nc[1] - 1)) ||
-                       (!b.pbc[2] && (a2 == 0 || a2 == g.nc[2] - 1));
-                centre_cell = hx >= 1 && hx <= TXY && hy >= 1 && hy <= TXY && hz >= 1 && hz <= TZ && g0 < g.nc[0] && g1 < g.nc[1] && g2 < g.nc[2];
+                h.img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
+                h.edge = (!b.pbc[0] && (a0 == 0 || a0 == g.nc[0] - 1)) || (!b.pbc[1] && (a1 == 0 || a1 == g.nc[1] - 1)) ||
+                         (!b.pbc[2] && (a2 == 0 || a2 == g.nc[2] - 1));
+                h.centre = hx >= 1 && hx <= TXY && hy >= 1 && hy <= TXY && h.hz >= 1 && h.hz <= TZ && g0 < g.nc[0] && g1 < g.nc[1] && g2 < g.nc[2];
             }
         }
+        return h;
+    };
+    // the first four atoms of a cell (twenty independent loads)
+    auto request = [&](const Halo &h, double (&ra)[4], double (&rb)[4], double (&rc4)[4], int (&rd)[4], unsigned char (&rm)[4]) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int q = h.src + min(v, max(h.cnt - 1, 0));
+            if (h.cnt > 0) { ra[v] = xs[q]; rb[v] = ys[q]; rc4[v] = zs[q]; rd[v] = order[q]; rm[v] = mvs[q]; }
+            else { ra[v] = 0; rb[v] = 0; rc4[v] = 0; rd[v] = 0; rm[v] = NEUTRAL; }
+        }
+    };
+    for (int jt = (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
+        const int slot = (int)(blockIdx.x & 7) * per + jt;
+        if (slot >= nlive)
+            break;
+        const Tile tile = tile_of(slot);
+        const Halo cur = halo_of(tile);
         // the first four atoms of the cell are requested BEFORE the workgroup scan: their latency overlaps the scan's two
         // barriers instead of following them (the loads do not need the LDS offsets, only the stores do)
         double pa[4], pb[4], pc[4];
         int pd[4];
         unsigned char pm[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int q = src + min(v, max(cnt - 1, 0));
-            if (cnt > 0) { pa[v] = xs[q]; pb[v] = ys[q]; pc[v] = zs[q]; pd[v] = order[q]; pm[v] = mvs[q]; }
-            else { pa[v] = 0; pb[v] = 0; pc[v] = 0; pd[v] = 0; pm[v] = NEUTRAL; }
-        }
+        request(cur, pa, pb, pc, pd, pm);
+        const int tile_id = tile.id, T0 = tile.T0, T1 = tile.T1, T2 = tile.T2;
+        const int cnt = cur.cnt, src = cur.src, img = cur.img, hz = cur.hz;
+        const bool edge = cur.edge, centre_cell = cur.centre;
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+
         int total2;
         const int off2 = excl_scan_block(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
         const int total = total2 & 0xffff, ncentres = total2 >> 16;
         const int off0 = off2 & 0xffff, coff = off2 >> 16;
-        if (total > cap || ncentres > CEN_CAP) { // list this tile for the next pass
-            if (tid == 0) {
-                if (tile_flag) tile_flag[tile_id] = 1;
-                flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
-            }
-            continue; // (excl_scan_block ended with a barrier)
-        }
-        if (tid < NH) hc[tid] = (unsigned)off0 | ((unsigned)cnt << 16);
+        bool ok = !(total > cap || ncentres > CEN_CAP); // else: listed for the next pass
+        if (ok && tid < NH) hc[tid] = (unsigned)off0 | ((unsigned)cnt << 16);
         // ---- stage this cell's atoms
-        if (cnt > 0) {
+        if (ok && cnt > 0) {
             double X0, Y0, Z0, XS, YS, ZS;
             const int code0 = combine_codes(img, NEUTRAL); // an atom inside the box (image code 0): the cell's own shift
             if (TRI) { // corner of the tile's halo and the cell's lattice shift, through the cell vectors (rows of h)
@@ -420,24 +416,22 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         }
         __syncthreads(); // publishes hc, the staged atoms, the centre list and the flags
         // the 3-cell run around every cell that can be a column entry of a centre's walk
-        if (tid < NH && hz >= 1 && hz <= HZ - 2) {
+        if (ok && tid < NH && hz >= 1 && hz <= HZ - 2) {
             const unsigned lo_c = hc[tid - 1], hi_c = hc[tid + 1];
             const unsigned k0 = lo_c & 0xffffu, k3 = (hi_c & 0xffffu) + (hi_c >> 16);
             hr[tid] = k0 | ((k3 - k0) << 16);
-            if (k3 - k0 > (K == 12 ? 24u : 32u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to whole trips)
+            if (k3 - k0 > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
         }
         __syncthreads();
-        if (s_flag[1] | s_flag[2]) {
-            if (tid == 0) {
-                if (tile_flag) tile_flag[tile_id] = 1;
-                flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
-            }
-            if (list_mode) __syncthreads();
-            continue;
+        if (ok && (s_flag[1] | s_flag[2]))
+            ok = false;
+        if (!ok && tid == 0) { // list this tile for the next pass
+            if (tile_flag) tile_flag[tile_id] = 1;
+            flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
         }
         const bool general_tile = s_flag[0] != 0;
 
-        for (int base = 0; base < ncentres; base += NT) {
+        for (int base = 0; ok && base < ncentres; base += NT) {
             const int q = base + tid;
             if (q < ncentres) {
                 const unsigned cv = cen[q];
@@ -451,11 +445,11 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
                     const int len = (int)(hv[r] >> 16);
-                    scan_run_asm<K>(f4_lds + ((hv[r] & 0xffffu) << 4), len, s.x, s.y, s.z, negc, mk[r], w);
-                    mk[r] &= ~0u << (run_slots<K>(len) - len); // slots past the end of the run
+                    scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), len, s.x, s.y, s.z, negc, mk[r], w);
+                    mk[r] &= ~0u << (run_slots(len) - len); // slots past the end of the run
                 }
                 {   // the centre itself sits in run 4 with d2 = 0: not a neighbour (neighbor.cpp:162)
-                    const int S = run_slots<K>((int)(hv[4] >> 16));
+                    const int S = run_slots((int)(hv[4] >> 16));
                     mk[4] &= ~(1u << (S - 1 - (li - (int)(hv[4] & 0xffffu))));
                 }
                 const double2 ci = lxy[li];
@@ -465,8 +459,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 if (__builtin_expect(w <= __float_as_uint(W), 0)) { // a pair inside the decision band: this centre again in double precision
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        if (r == 4) mk[r] = scan_run_f64<true, TRI, K>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
-                        else mk[r] = scan_run_f64<false, TRI, K>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
                     }
                 }
                 int hits = 0;
@@ -483,7 +477,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                     int sl = 0;
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        const int kend = (int)(hv[r] & 0xffffu) + (run_slots<K>((int)(hv[r] >> 16)) - 32); // + clz(m) = LDS index of the hit
+                        const int kend = (int)(hv[r] & 0xffffu) + (run_slots((int)(hv[r] >> 16)) - 32); // + clz(m) = LDS index of the hit
                         unsigned m = mk[r];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -552,7 +546,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 lds_barrier(); // the row stores stay in flight
             }
         }
-        if (!list_mode)
+        if (!LOOP)
             break;
         if (jt + (int)(gridDim.x >> 3) < per) lds_barrier(); // LDS is reused by the next tile
     } // tiles of this workgroup
@@ -707,28 +701,10 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     for (int d = 0; d < 3; ++d)
         if (g.nc[d] < (b.pbc[d] ? 7 : 4)) { g_last_plan[6] = -3; return p; } // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
     if (!(rc > 1e-12 && rc < 1e12)) { g_last_plan[6] = -4; return p; }
-    // candidates per scan trip: the shortest instruction stream for the run lengths at hand.  A wave leaves a run when its
-    // LONGEST lane does, so the length that counts is the one only a fraction of a percent of the runs exceed; a trip of K
-    // costs 8 K + 6 instructions.  Runs beyond what one mask register holds (24 slots for K = 12, else 32) send their tile to
-    // the thread-per-atom code: a variant that would do that to more than 0.2 % of the runs is not taken.
-    int64_t runs = 0;
+    int64_t runs = 0, longer = 0;
     for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
-    auto longer_than = [&](int len) { int64_t n = 0; for (int l = len + 1; l <= 65; ++l) n += gs.v[1 + l]; return n; };
-    int Lq = 1;
-    while (Lq < 65 && runs > 0 && (double)longer_than(Lq) > 0.003 * (double)runs) ++Lq;
-    static const int k_env = [] { const char *e = std::getenv("MDH_LANE_K"); return e ? std::atoi(e) : 0; }();
-    int K = 0;
-    double best_cost = 0;
-    for (int k : {4, 8, 12, 16}) {
-        const int limit = k == 12 ? 24 : 32;
-        if (runs > 0 && (double)longer_than(limit) > 0.002 * (double)runs)
-            continue;
-        if (k_env && k != k_env)
-            continue;
-        const double cost = (double)((Lq + k - 1) / k) * (8.0 * k + 6.0);
-        if (!K || cost < best_cost) { K = k; best_cost = cost; }
-    }
-    if (!K) { g_last_plan[6] = -5; g_last_plan[5] = (int)longer_than(32); g_last_plan[4] = (int)runs; return p; } // cells so full that many runs would not fit a 32-bit hit mask
+    for (int len = 29; len <= 65; ++len) longer += gs.v[1 + len];
+    if (runs > 0 && (double)longer > 0.002 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)longer; g_last_plan[4] = (int)runs; return p; } // cells so full that many runs would not fit a 32-bit hit mask
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
@@ -795,14 +771,13 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     while ((double)W < want) W = std::nextafterf(W, INFINITY);
     p.mid = c;
     p.T = W;
-    p.K = K;
     p.txy = best.txy;
     p.tz = best.tz;
     p.cap = best_cap;
     p.occupied = occ;
     p.full = occ >= g.ncell;
     g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M);
-    g_last_plan[4] = p.full | (p.K << 8); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
+    g_last_plan[4] = p.full; g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
 
@@ -849,29 +824,25 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const float negc = -plan.mid;
     const Shape ts2{ts.txy, 1};
     const int nt2b = nt[2] * nsub;
-#define MDH_LANE_LAUNCH(COUNT, TRI, K)                                                                                                    \
+#define MDH_LANE_PASS(COUNT, TRI, LOOP, GRID, ...)                                                                                          \
     do {                                                                                                                                  \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, K>), grid, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0], nt[1], nt[2], ts, \
-                           tile_list, slot + ntiles, list_mode, max_count, flagged, nullptr, 0, 1, 2);                                       \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, K>), dim3(512), dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs,          \
-                           cg.cell_start, b, cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, nt[0],  \
-                           nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3);                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__);          \
     } while (0)
-#define MDH_LANE_K(COUNT, TRI)                                                                                                            \
+    // first pass: all tiles (one per workgroup) or the list of live ones (walked); second pass: one-cell slices of what it listed
+#define MDH_LANE_LAUNCH(COUNT, TRI)                                                                                                       \
     do {                                                                                                                                  \
-        switch (plan.K) {                                                                                                                 \
-        case 4: MDH_LANE_LAUNCH(COUNT, TRI, 4); break;                                                                                    \
-        case 8: MDH_LANE_LAUNCH(COUNT, TRI, 8); break;                                                                                    \
-        case 12: MDH_LANE_LAUNCH(COUNT, TRI, 12); break;                                                                                  \
-        default: MDH_LANE_LAUNCH(COUNT, TRI, 16); break;                                                                                  \
-        }                                                                                                                                 \
+        if (list_mode)                                                                                                                    \
+            MDH_LANE_PASS(COUNT, TRI, true, grid, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+        else                                                                                                                              \
+            MDH_LANE_PASS(COUNT, TRI, false, grid, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
+        MDH_LANE_PASS(COUNT, TRI, true, dim3(512), nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
-    if (b.tri) { if (count) MDH_LANE_K(true, true); else MDH_LANE_K(false, true); }
-    else { if (count) MDH_LANE_K(true, false); else MDH_LANE_K(false, false); }
-#undef MDH_LANE_K
+    if (b.tri) { if (count) MDH_LANE_LAUNCH(true, true); else MDH_LANE_LAUNCH(false, true); }
+    else { if (count) MDH_LANE_LAUNCH(true, false); else MDH_LANE_LAUNCH(false, false); }
+#undef MDH_LANE_PASS
 #undef MDH_LANE_LAUNCH
     MDH_HIP(hipGetLastError());
     // what the two passes listed for the thread-per-atom code (k_neighbor_tiles), in the tiling of the second pass
