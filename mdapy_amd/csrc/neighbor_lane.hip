@@ -54,11 +54,18 @@ static constexpr int MAX_NH = 256;  // halo cells of a tile: one per thread
 static constexpr int CEN_CAP = 512; // centre atoms a tile may hold
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
 static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
+static constexpr long long ROW_MASK = (1ll << 57) - 1;   // id * M of a row (M <= 64, id < 2^31) under its 7-bit count
 
 struct Shape { int txy, tz; };
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 static int g_last_plan[8]; // test hook (mdh_debug_neighbor_plan)
+#ifdef MDH_STAMPS
+__device__ unsigned long long g_stamps[65536 * 8];
+#define STAMP(k) do { if (tid == 0 && !parent && tile.id < 65536) g_stamps[tile.id * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 // workgroup barrier that orders LDS accesses only: global stores issued before it stay in flight (__syncthreads() would
 // wait for their acknowledgement)
@@ -84,7 +91,7 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
         if (k < w) off += scratch[k];
         tot += scratch[k];
     }
-    __syncthreads();
+    // (no second barrier: the one call per tile is followed by several barriers before `scratch` is written again)
     *total = tot;
     return off + inc - v;
 }
@@ -172,13 +179,16 @@ __device__ __forceinline__ int run_slots(int len)
     return (len + 3) & ~3;
 }
 
-// IEEE double-precision square root.  For x >= 2^-767 this is the compiler's own expansion of sqrt(x) (v_rsq_f64 seed, one
-// Goldschmidt step, two correction steps) minus its input scaling, which is the identity there: bit-identical results,
-// seven instructions fewer; smaller arguments (and 0, inf, NaN) take the library path.
-__device__ __forceinline__ double sqrt_f64(double x)
+// IEEE double-precision square root.  For 2^-767 <= x < 2^1000 this is the compiler's own expansion of sqrt(x) (v_rsq_f64
+// seed, one Goldschmidt step, two correction steps) minus its input scaling, which is the identity there: bit-identical
+// results, seven instructions fewer, and no per-lane branch — the caller asks sqrt_fast_ok() for the whole wave and takes
+// the library path when any lane is outside (smaller arguments, 0, inf, NaN).
+__device__ __forceinline__ bool sqrt_fast_ok(double x)
 {
-    if (__builtin_expect(!(x >= 0x1p-767 && x < 0x1p+1000), 0))
-        return sqrt(x);
+    return x >= 0x1p-767 && x < 0x1p+1000;
+}
+__device__ __forceinline__ double sqrt_fast(double x)
+{
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
     double h = y * 0.5;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap+8] staged (ux, uy, uz, bits of the atom id)
     double2 *lxy = reinterpret_cast<double2 *>(f4 + cap + 8);       // [cap] staged raw x, y
     double2 *rxy = lxy + cap;                                       // [NT] this pass's rows: wrapped centre x, y
-    double2 *rzc = rxy + NT;                                        // [NT] wrapped centre z, (atom id | min(count, M) << 32)
+    double2 *rzc = rxy + NT;                                        // [NT] wrapped centre z, (first slot of the atom's row = id * M | min(count, M) << 57)
     double *lz = reinterpret_cast<double *>(rzc + NT);              // [cap] staged raw z
     unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 16
     unsigned short *tk = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [NT][M+1] tickets (slot M swallows the hits past M)
@@ -314,7 +324,8 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         }
         return h;
     };
-    // the first four atoms of a cell (twenty independent loads)
+    // the first four atoms of a cell (twenty independent loads), requested BEFORE the workgroup scan: their latency overlaps
+    // the scan's two barriers instead of following them (the loads do not need the LDS offsets, only the stores do)
     auto request = [&](const Halo &h, double (&ra)[4], double (&rb)[4], double (&rc4)[4], int (&rd)[4], unsigned char (&rm)[4]) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -328,9 +339,12 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         if (slot >= nlive)
             break;
         const Tile tile = tile_of(slot);
-        const Halo cur = halo_of(tile);
-        // the first four atoms of the cell are requested BEFORE the workgroup scan: their latency overlaps the scan's two
-        // barriers instead of following them (the loads do not need the LDS offsets, only the stores do)
+        STAMP(0);
+        Halo cur = halo_of(tile);
+#ifdef MDH_STAMPS
+        asm volatile("" : "+v"(cur.src), "+v"(cur.cnt));
+        STAMP(1);
+#endif
         double pa[4], pb[4], pc[4];
         int pd[4];
         unsigned char pm[4];
@@ -345,6 +359,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         const int total = total2 & 0xffff, ncentres = total2 >> 16;
         const int off0 = off2 & 0xffff, coff = off2 >> 16;
         bool ok = !(total > cap || ncentres > CEN_CAP); // else: listed for the next pass
+        STAMP(2);
         if (ok && tid < NH) hc[tid] = (unsigned)off0 | ((unsigned)cnt << 16);
         // ---- stage this cell's atoms
         if (ok && cnt > 0) {
@@ -423,6 +438,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
             if (k3 - k0 > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
         }
         __syncthreads();
+        STAMP(3);
         if (ok && (s_flag[1] | s_flag[2]))
             ok = false;
         if (!ok && tid == 0) { // list this tile for the next pass
@@ -452,6 +468,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                     const int S = run_slots((int)(hv[4] >> 16));
                     mk[4] &= ~(1u << (S - 1 - (li - (int)(hv[4] & 0xffffu))));
                 }
+                STAMP(4);
                 const double2 ci = lxy[li];
                 double xi = ci.x, yi = ci.y, zi = lz[li];
                 if (b.anypbc) // neighbor.cpp:139-142
@@ -496,11 +513,12 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                         }
                     }
                     rxy[tid] = make_double2(xi, yi);
-                    rzc[tid] = make_double2(zi, __longlong_as_double((long long)(((unsigned long long)(unsigned)(hits < M ? hits : M) << 32) | (unsigned)id)));
+                    rzc[tid] = make_double2(zi, __longlong_as_double((long long)(((unsigned long long)(unsigned)(hits < M ? hits : M) << 57) | (unsigned long long)((int64_t)id * M))));
                 }
             }
             if (!COUNT) {
                 __syncthreads();
+                STAMP(5);
                 // ---- tickets -> rows: MP adjacent lanes serve the slots of one centre
                 const int nrows = min(NT, ncentres - base);
                 const int MP = 1 << mp_shift; // smallest power of two >= M
@@ -514,7 +532,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                         const int ca = c0, cb2 = two ? c1 : c0;
                         const double2 za = rzc[ca], zb = rzc[cb2];
                         const long long ia = __double_as_longlong(za.y), ib = __double_as_longlong(zb.y);
-                        const bool ha = e < (int)(ia >> 32), hb = e < (int)(ib >> 32);
+                        const bool ha = e < (int)((unsigned long long)ia >> 57), hb = e < (int)((unsigned long long)ib >> 57);
                         const int ka = tk[ca * (M + 1) + (ha ? e : 0)], kb = tk[cb2 * (M + 1) + (hb ? e : 0)]; // (slot 0 of a row with no hit: any staged index, unused)
                         const int kka = ha ? ka : 0, kkb = hb ? kb : 0;
                         const double2 ja = lxy[kka], jb = lxy[kkb], wa = rxy[ca], wb = rxy[cb2];
@@ -531,8 +549,19 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                             d2a = exact_d2<0>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
                             d2b = exact_d2<0>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
                         }
-                        const double ra = ha ? sqrt_f64(d2a) : pad, rb = hb ? sqrt_f64(d2b) : pad; // neighbor.cpp:174; pads neighbor.py:125-129
-                        const int64_t oa = (int64_t)(int)(ia & 0xffffffffll) * M + e, ob = (int64_t)(int)(ib & 0xffffffffll) * M + e;
+                        // neighbor.cpp:174; pads neighbor.py:125-129.  Both roots for every lane (a lane without a hit holds the
+                        // distance to some staged atom), then a select: straight-line code whose two chains interleave
+                        double ra, rb;
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(sqrt_fast_ok(d2a) && sqrt_fast_ok(d2b))) == 0, 1)) {
+                            ra = sqrt_fast(d2a);
+                            rb = sqrt_fast(d2b);
+                        } else {
+                            ra = sqrt(d2a);
+                            rb = sqrt(d2b);
+                        }
+                        ra = ha ? ra : pad;
+                        rb = hb ? rb : pad;
+                        const int64_t oa = (ia & ROW_MASK) + e, ob = (ib & ROW_MASK) + e; // the row's first slot was worked out once, by the centre's lane
                         if (ha || write_pads) {
                             __builtin_nontemporal_store(ha ? ida : -1, &verlet[oa]); // rows are written once and not read back here
                             __builtin_nontemporal_store(ra, &dist[oa]);
@@ -543,7 +572,9 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                         }
                     }
                 }
+                STAMP(6);
                 lds_barrier(); // the row stores stay in flight
+                STAMP(7);
             }
         }
         if (!LOOP)
@@ -691,15 +722,23 @@ static size_t lds_bytes(int cap, int64_t M)
 
 } // namespace lane
 
+// reason (negative) the tile kernel cannot take a call with this box, grid and row width; 0: it can
+static int lane_refusal(const DBox &b, const Grid &g, int64_t M)
+{
+    if (g.mode != 0 || M <= 0 || M > 64) return -1;
+    if (b.tri && !(b.pbc[0] && b.pbc[1] && b.pbc[2])) return -2; // open triclinic boxes: thread-per-atom kernel
+    for (int d = 0; d < 3; ++d)
+        if (g.nc[d] < (b.pbc[d] ? 7 : 4)) return -3; // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
+    return 0;
+}
+
 LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc)
 {
     using namespace lane;
     LanePlan p{};
     for (int k = 0; k < 8; ++k) g_last_plan[k] = 0;
-    if (g.mode != 0 || N <= 0 || M <= 0 || M > 64) { g_last_plan[6] = -1; return p; }
-    if (b.tri && !(b.pbc[0] && b.pbc[1] && b.pbc[2])) { g_last_plan[6] = -2; return p; } // open triclinic boxes: thread-per-atom kernel
-    for (int d = 0; d < 3; ++d)
-        if (g.nc[d] < (b.pbc[d] ? 7 : 4)) { g_last_plan[6] = -3; return p; } // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
+    if (N <= 0) { g_last_plan[6] = -1; return p; }
+    if (const int why = lane_refusal(b, g, M)) { g_last_plan[6] = why; return p; }
     if (!(rc > 1e-12 && rc < 1e12)) { g_last_plan[6] = -4; return p; }
     int64_t runs = 0, longer = 0;
     for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
@@ -738,6 +777,8 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
         if (cap_env > 0)
             break;
     }
+    static const int tile_env = [] { const char *e = std::getenv("MDH_LANE_TILE"); return e ? std::atoi(e) : 0; }(); // experiments: txy * 100 + tz
+    if (tile_env > 0) best = Shape{tile_env / 100, tile_env % 100};
     if (!best.txy) { g_last_plan[6] = -6; return p; }
     // Decision band of the single-precision scan (file header).  E bounds the staged coordinates (far-atom check of the
     // kernel), du the error of one staged coordinate: rounding to f32 plus what the double-precision shift can lose;
@@ -859,6 +900,12 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
 
 } // namespace mdh
 
+#ifdef MDH_STAMPS
+extern "C" int mdh_debug_lane_stamps(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mdh::lane::g_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int mdh_debug_neighbor_plan(int *plan8)
 {
     for (int k = 0; k < 8; ++k) plan8[k] = mdh::lane::g_last_plan[k];

@@ -38,3 +38,13 @@ L.mdh_debug_neighbor_plan(plan)
 buf = ctypes.create_string_buffer(1 << 16); L.mdh_prof_report(buf, len(buf))
 print("plan txy,tz,cap,lds,full,pop*1000,occ,fresh:", list(plan))
 print(buf.value.decode().strip(), "N", n, "env", {k: v for k, v in os.environ.items() if k.startswith("MDH_")}, flush=True)
+
+if hasattr(L, "mdh_debug_lane_stamps"):  # experiment builds only (-DMDH_STAMPS): phase stamps of the first 51200 tiles
+    nt = 51200
+    st = np.zeros(nt * 8, dtype=np.uint64)
+    L.mdh_debug_lane_stamps(ctypes.c_void_p(st.ctypes.data), nt * 8)
+    st = st.reshape(nt, 8).astype(np.int64)
+    d = np.diff(st, axis=1)
+    good = (st[:, 0] > 0) & (d > 0).all(axis=1) & (d < 10**7).all(axis=1)
+    print("tiles stamped", int(good.sum()), "mean ticks per phase [cell ranges arrive, block scan, stage, scan, tickets+barrier, writeout, barrier]:", np.round(d[good].mean(axis=0), 0), "total", round(float((st[good, 7] - st[good, 0]).mean())))
+    print("median:", np.median(d[good], axis=0), "span of the launch", int(st[good, 7].max() - st[good, 0].min()))
