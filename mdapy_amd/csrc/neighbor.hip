@@ -455,7 +455,9 @@ template <int MODE>
 static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const DBox &b, double rc, int *verlet,
                             double *dist, int *nn, int64_t M, int *max_count, TileFilter tf = TileFilter{})
 {
-    dim3 grid(std::min(grid_for(N, 256), 8192)), block(256);
+    // behind a tile kernel that lists its leftovers this launch only stands by for unwrapped input (device flag): a small grid
+    // then, whose workgroups stride over the atoms if they do have to take the call (10 -> 3 us when they leave at once)
+    dim3 grid(std::min(grid_for(N, 256), tf.list ? 2048 : 8192)), block(256);
     if (b.tri)
         hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else

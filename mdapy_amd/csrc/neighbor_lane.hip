@@ -879,7 +879,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
             MDH_LANE_PASS(COUNT, TRI, true, grid, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
         else                                                                                                                              \
             MDH_LANE_PASS(COUNT, TRI, false, grid, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
-        MDH_LANE_PASS(COUNT, TRI, true, dim3(512), nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
+        MDH_LANE_PASS(COUNT, TRI, true, dim3(1024), nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
     if (b.tri) { if (count) MDH_LANE_LAUNCH(true, true); else MDH_LANE_LAUNCH(false, true); }
     else { if (count) MDH_LANE_LAUNCH(true, false); else MDH_LANE_LAUNCH(false, false); }
