@@ -126,6 +126,20 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
                              const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                              int64_t max_neigh, int fill_pads, const int64_t *key, int space, void *stream);
 
+/* Opt-in: mdh_build_neighbor followed by mdh_fcna(rc) — what System.cal_common_neighbor_analysis(rc, max_neigh) runs when it
+ * has no list yet (neighbor.cpp:351 then cna.cpp:429-506) — as ONE pass over the LDS tiles: a centre's 12 or 14 neighbours are
+ * still staged when its row is written, so the bond matrix is taken from LDS instead of 12-14 gathers per atom from HBM.
+ * verlet / dist / nn exactly as mdh_build_neighbor leaves them; pattern (N) i32 exactly as mdh_fcna leaves it
+ * (caller-initialised; atoms without 12 or 14 neighbours keep their value).  key: as in mdh_build_neighbor_keyed, or NULL.
+ * Where the tile kernel does not apply the two steps run one after the other inside the call.
+ * MEASURED SLOWER than the two calls on MI355X (10 M atoms: tile kernels 2.15 ms against 1.19 + 0.81 ms,
+ * profiles/r02_bench_fused_step.json): the analysis is bound by its ~1 700 double-precision instructions per atom, not by
+ * its gathers, and inside the tile kernel it runs at 3 waves per SIMD with 77 % of the lanes holding a centre.  The package
+ * therefore does not call it; it stays as the measured answer to "fuse CNA into the tile" (DESIGN.md 3a). */
+int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                            const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
+                            int64_t max_neigh, int fill_pads, int *pattern, const int64_t *key, int space, void *stream);
+
 /* Halo selection of the slab decomposition (multi-GPU extension): one pass over the owned atoms; up / down (n) i32
  * receive the indices of the atoms whose wrapped fractional coordinate f along the decomposed axis (hi3 = that column of the
  * inverse box) satisfies f >= up_from / f < down_below, counts_host[2] their numbers.  Order of the indices: unspecified.

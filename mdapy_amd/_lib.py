@@ -47,6 +47,7 @@ _SIGNATURES = {
     "mdh_build_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, cint, vp],
     "mdh_slab_halo_select": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, cint, vp],
     "mdh_build_neighbor_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, cint, vp],
+    "mdh_build_neighbor_fcna": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, vp, cint, vp],
     "mdh_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, cint, vp],
     "mdh_build_neighbor_exact": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, cint, vp],
     "mdh_sort_verlet_by_distance": [vp, vp, i64, i64, cint, cint, vp],

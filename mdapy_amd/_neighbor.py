@@ -27,6 +27,22 @@ def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_lis
     c.done(rc_)
 
 
+def build_neighbor_fcna(x, y, z, box, origin, boundary, rc, verlet_list, distance_list, neighbor_number, pattern, num_t=1,
+                        fill_pads=False, key=None):
+    """``build_neighbor`` (src/neighbor.cpp:351) and ``fcna`` (src/cna.cpp:429) with the same ``rc`` in one pass over the
+    tiles: the lists as ``build_neighbor`` leaves them, ``pattern`` (caller-initialised) as ``fcna`` leaves it; ``key`` as
+    in ``build_neighbor``."""
+    keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
+    c = Call(x, y, z, verlet_list, distance_list, neighbor_number, pattern, key)
+    N, M = int(verlet_list.shape[0]), int(verlet_list.shape[1])
+    rc_ = _lib.lib().mdh_build_neighbor_fcna(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
+                                             c.out(verlet_list, i32, upload=not fill_pads),
+                                             c.out(distance_list, f64, upload=not fill_pads),
+                                             c.out(neighbor_number, i32, upload=False), M, int(bool(fill_pads)),
+                                             c.out(pattern, i32), c.inp(key, np.int64), c.space, c.stream)
+    c.done(rc_)
+
+
 def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1):
     """src/neighbor.cpp:189: exact row width = max neighbour count (>= 1); returns (verlet, dist, nn).
     One library call (mdh_build_neighbor_exact): the cell grid is built once for the counting pass and the build; the rows

@@ -18,104 +18,9 @@
 // test (unwrapped input) are appended to a to-do list and finished by a second,
 // compact kernel that evaluates the reference expression as is (GENERIC = true).
 #include "common.hpp"
+#include "cna_core.hpp"
 
 namespace mdh {
-
-struct Rows { // bond matrix: row a = bits of the neighbours bonded to neighbour a (a < 16)
-    uint64_t w0, w1, w2, w3;
-    __device__ __forceinline__ unsigned row(int a) const
-    {
-        const uint64_t w = (a < 8) ? ((a < 4) ? w0 : w1) : ((a < 12) ? w2 : w3);
-        return (unsigned)(w >> ((a & 3) << 4)) & 0xffffu;
-    }
-};
-
-template <int NN>
-__device__ __forceinline__ Rows pack_rows(const unsigned (&adj)[NN])
-{
-    Rows r{0, 0, 0, 0};
-#pragma unroll
-    for (int a = 0; a < NN; ++a) {
-        const uint64_t v = (uint64_t)adj[a] << ((a & 3) << 4);
-        if (a < 4) r.w0 |= v;
-        else if (a < 8) r.w1 |= v;
-        else if (a < 12) r.w2 |= v;
-        else r.w3 |= v;
-    }
-    return r;
-}
-
-// (ncn, nb, chain) of the bond centre--neighbour ni.  Only neighbours in `limit_mask`
-// take part in the bond search (cna.cpp:69-92; the adaptive 12-neighbour pass hands 12, :344).
-__device__ __forceinline__ void signature(const Rows &R, int ni, unsigned limit_mask, int &ncn, int &nb, int &chain)
-{
-    const unsigned common = R.row(ni); // cna.cpp:52-64
-    ncn = __popc(common);
-    const unsigned pool = common & limit_mask;
-    int bonds = 0, maxdeg = 0;
-    for (unsigned m = pool; m; m &= m - 1) {
-        const int deg = __popc(R.row(__ffs(m) - 1) & pool);
-        bonds += deg;
-        maxdeg = deg > maxdeg ? deg : maxdeg;
-    }
-    nb = bonds >> 1;
-    // `chain` = number of bonds in the largest connected bond cluster (cna.cpp:97-147).  Shortcuts that are
-    // exact consequences of that definition:
-    //   nb <= 1           -> chain = nb
-    //   nb == 2           -> 2 if the two bonds share an atom (some degree is 2), else 1
-    //   k atoms, k bonds, k in {4,5} and every atom of the pool counted (ncn == popc(pool)):
-    //                        a graph on k <= 5 vertices with k edges cannot be split (3+1 vertices hold <= 3 edges,
-    //                        3+2 hold <= 4, 4+1 hold all of them in the connected 4-part) -> chain = k
-    // everything else (e.g. 6 atoms / 6 bonds: two triangles give 3) walks the clusters.
-    if (nb <= 1) { chain = nb; return; }
-    if (nb == 2) { chain = maxdeg == 2 ? 2 : 1; return; }
-    const int npool = __popc(pool);
-    if (nb == npool && (npool == 4 || npool == 5)) { chain = nb; return; }
-    int best = 0;
-    unsigned left = pool;
-    while (left) {
-        unsigned comp = left & (0u - left), frontier = comp;
-        while (frontier) {
-            const int a = __ffs(frontier) - 1;
-            frontier &= frontier - 1;
-            const unsigned grow = R.row(a) & pool & ~comp;
-            comp |= grow;
-            frontier |= grow;
-        }
-        int cb = 0;
-        for (unsigned m = comp; m; m &= m - 1)
-            cb += __popc(R.row(__ffs(m) - 1) & comp);
-        cb >>= 1;
-        best = cb > best ? cb : best;
-        left &= ~comp;
-    }
-    chain = best;
-}
-
-__device__ __forceinline__ double fold(double d, double L, double t_zero, double t_one)
-{
-    const double shift = (d >= t_one) ? L : ((d >= t_zero) ? 0.0 : -L);
-    return d - shift; // == d - L*floor(d/L+0.5)   (box.h:120-124) when n is one of {-1,0,1}
-}
-
-// 0: the coordinates spread too far for `fold` (generic variant), 1: every pair has n in {-1,0,1}, 2: every pair has n = 0
-// (no neighbour lies across the periodic seam: the minimum image is the plain difference, d - L*0 == d)
-template <int NN>
-__device__ __forceinline__ int span_class(const DBox &b, const double (&p)[NN], int axis)
-{
-    double mn = p[0], mx = p[0];
-#pragma unroll
-    for (int a = 1; a < NN; ++a) {
-        mn = fmin(mn, p[a]);
-        mx = fmax(mx, p[a]);
-    }
-    const double span = mx - mn;
-    const double lim = fmin(b.tn[axis][3], -b.tn[axis][0]); // |d| below this => n in {-1,0,1}
-    const double zero = fmin(b.tn[axis][2], -b.tn[axis][1]); // |d| below this => n == 0
-    if (!(span < lim)) // false for NaN as well
-        return 0;
-    return span < zero ? 2 : 1;
-}
 
 // ---- bond matrix among NN listed neighbours: bit c of row a <=> pbcdis_sq(list[a], list[c]) <= cut2
 // (cna.cpp:459-466; both ends RAW coordinates, cna.cpp:149-161).  Returns false (orthogonal hot path only)
@@ -130,54 +35,14 @@ __device__ __forceinline__ bool bond_rows(const DBox &b, const double *__restric
         const int j = ids[a]; // made safe by the caller (safe_id)
         px[a] = x[j]; py[a] = y[j]; pz[a] = z[j];
     }
-    bool plain = false; // no fold needed on any axis
-    if (!TRI && !GENERIC) {
-        int cls = 2;
-        if (b.pbc[0]) cls = min(cls, span_class<NN>(b, px, 0));
-        if (b.pbc[1]) cls = min(cls, span_class<NN>(b, py, 1));
-        if (b.pbc[2]) cls = min(cls, span_class<NN>(b, pz, 2));
-        if (cls == 0)
-            return false;
-        plain = cls == 2;
-    }
-    unsigned adj[NN];
-#pragma unroll
-    for (int a = 0; a < NN; ++a)
-        adj[a] = 0;
-    if (!TRI && !GENERIC && plain) { // interior atoms (all but the layer at the periodic faces): 11 instructions per pair
-#pragma unroll
-        for (int a = 0; a < NN; ++a)
-#pragma unroll
-            for (int c = a + 1; c < NN; ++c) {
-                const double dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
-                if (dx * dx + dy * dy + dz * dz <= cut2) {
-                    adj[a] |= 1u << c;
-                    adj[c] |= 1u << a;
-                }
-            }
-        R = pack_rows<NN>(adj);
+    if (TRI || GENERIC) {
+        R = bond_rows_reg<TRI, NN>(b, px, py, pz, cut2);
         return true;
     }
-#pragma unroll
-    for (int a = 0; a < NN; ++a)
-#pragma unroll
-        for (int c = a + 1; c < NN; ++c) {
-            double d2;
-            if (TRI || GENERIC) {
-                d2 = pair_d2<TRI>(b, px[a], py[a], pz[a], px[c], py[c], pz[c]);
-            } else {
-                double dx = px[c] - px[a], dy = py[c] - py[a], dz = pz[c] - pz[a];
-                if (b.pbc[0]) dx = fold(dx, b.h[0], b.tn[0][1], b.tn[0][2]);
-                if (b.pbc[1]) dy = fold(dy, b.h[4], b.tn[1][1], b.tn[1][2]);
-                if (b.pbc[2]) dz = fold(dz, b.h[8], b.tn[2][1], b.tn[2][2]);
-                d2 = dx * dx + dy * dy + dz * dz;
-            }
-            if (d2 <= cut2) {
-                adj[a] |= 1u << c;
-                adj[c] |= 1u << a;
-            }
-        }
-    R = pack_rows<NN>(adj);
+    const int cls = span_class3<NN>(b, px, py, pz);
+    if (cls == 0)
+        return false;
+    R = bond_rows_ortho<NN>(b, px, py, pz, cut2, cls == 2);
     return true;
 }
 
@@ -195,24 +60,8 @@ __device__ __forceinline__ int fcna_atom(const DBox &b, const double *__restrict
     Rows R;
     if (!bond_rows<TRI, GENERIC, NN>(b, x, y, z, ids, cut2, R))
         return -1;
-    int n421 = 0, n422 = 0, n555 = 0, n444 = 0, n666 = 0;
-    for (int ni = 0; ni < NN; ++ni) { // no early exit (cna.cpp:471-494)
-        int ncn, nb, ch;
-        signature(R, ni, (1u << NN) - 1u, ncn, nb, ch);
-        if (ncn == 4 && nb == 2) { n421 += (ch == 1); n422 += (ch == 2); }
-        else if (ncn == 5 && nb == 5 && ch == 5) ++n555;
-        else if (ncn == 4 && nb == 4 && ch == 4) ++n444;
-        else if (ncn == 6 && nb == 6 && ch == 6) ++n666;
-    }
-    if (n421 == 12) return 1; // cna.cpp:496-503
-    if (n421 == 6 && n422 == 6) return 2;
-    if (n555 == 12) return 4;
-    if (n666 == 8 && n444 == 6) return 3;
-    return 0;
+    return fcna_label<NN>(R);
 }
-
-// to-do list of atoms left to the generic variant: todo[0] = count, todo[1..] = atom ids
-__device__ __forceinline__ void defer(int *__restrict__ todo, int64_t i) { todo[1 + atomicAdd(&todo[0], 1)] = (int)i; }
 
 template <bool TRI, bool GENERIC>
 __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, const double *__restrict__ y,
@@ -444,6 +293,28 @@ __global__ __launch_bounds__(256) void k_fill_int(int *__restrict__ p, int64_t n
     if (i < n) p[i] = v;
 }
 
+void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
+                     int64_t M, const int *nn, int *pattern, double rc, int *todo)
+{
+    dim3 grid(grid_for(N, 256)), block(256);
+    if (b.tri) {
+        hipLaunchKernelGGL((k_fcna<true, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+    } else {
+        hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+    }
+}
+
+void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
+                        int64_t M, const int *nn, int *pattern, double rc, int *todo)
+{
+    dim3 grid(grid_for(N, 256)), block(256); // (the list's length is on the device: threads beyond it leave at once)
+    if (b.tri)
+        hipLaunchKernelGGL((k_fcna<true, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+    else
+        hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+}
+
 } // namespace mdh
 
 using namespace mdh;
@@ -471,13 +342,7 @@ int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const
     MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
     {
         ProfRange pr("k_fcna", st);
-        dim3 grid(grid_for(N, 256)), block(256);
-        if (b.tri) {
-            hipLaunchKernelGGL((k_fcna<true, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dn, dp, rc, todo);
-        } else {
-            hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dn, dp, rc, todo);
-            hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dn, dp, rc, todo);
-        }
+        launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
     }
     return sc.finish(space);
 }

@@ -44,6 +44,7 @@ struct TileFilter {
     const int *moved = nullptr; // != nullptr and *moved != 0: the tiled kernel stood down (unwrapped input), take every atom
     const int *list = nullptr;  // != nullptr: ids of the flagged tiles, *any of them (k_neighbor_tiles walks the list; the flag scan over all atoms is skipped)
     int list_cap = 0;
+    int *cna_todo = nullptr;    // != nullptr (fused neighbor + fixed CNA): the mop-up kernels list the atoms they take here, count first
     int tile = 1, tile_z = 1;
     int nt[3] = {1, 1, 1};
 };
@@ -67,9 +68,16 @@ struct LanePlan {
 };
 int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out);
 LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc);
+// pattern != nullptr: the fixed-cutoff CNA label (cna.cpp:429-506, same rc) of every centre the kernel takes is written too
 int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,
-                         TileFilter &tf);
+                         TileFilter &tf, int *pattern = nullptr);
+// cna.hip: fixed-cutoff CNA from finished lists on the caller's stream — of all atoms, or of the atoms listed in todo
+// (todo[0] = count, device side) with the reference expression
+void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
+                     int64_t M, const int *nn, int *pattern, double rc, int *todo);
+void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
+                        int64_t M, const int *nn, int *pattern, double rc, int *todo);
 
 __host__ __device__ __forceinline__ int pmod(int a, int n) // neighbor.cpp:18-22
 {

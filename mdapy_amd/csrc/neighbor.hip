@@ -18,6 +18,7 @@
 //                           contiguous and loads are coalesced).
 #include "common.hpp"
 #include "grid.hpp"
+#include "cna_core.hpp"
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -390,8 +391,10 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
                 mine = take_all || tf.flag[t] != 0;
             }
         }
-        if (mine)
+        if (mine) {
             cnt = max(cnt, neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+            if (tf.cna_todo) defer(tf.cna_todo, order[p]);
+        }
     }
     if (MODE == 0) {
         int m = cnt;
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(256) void k_neighbor_tiles(const double *__restrict
                     int c0, c1, c2;
                     cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
                     best = max(best, neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+                    if (tf.cna_todo) defer(tf.cna_todo, order[p]);
                 }
             }
         }
@@ -646,8 +650,11 @@ static int width_hint(int64_t N, int64_t ncell, int set)
 
 // One pass over a built cell grid: mode 0 = counts only (nn, *dmax), 1 = reference semantics (caller's pads), 2 = pads written.
 // The tile kernel where it applies, the round-1 tiled kernel for cells too full for it, the thread-per-atom code for the rest.
+// pattern != nullptr (mode 1 or 2): fixed-cutoff CNA labels as well.  Fused into the tile kernel where that runs (the
+// leftovers of its mop-up kernels are listed in todo and labelled from the finished rows); *fused = false: nothing was
+// labelled, the caller runs the analysis on the lists
 static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N, double rc, int *dv, double *dd, int *dn,
-                         int64_t M, int mode, int *dmax)
+                         int64_t M, int mode, int *dmax, int *pattern = nullptr, int *todo = nullptr, bool *fused = nullptr)
 {
     hipStream_t st = sc.stream();
     MDH_HIP(hipMemsetAsync(cg.flags + 2, 0, sizeof(int) * 2, st)); // the tile lists of this pass (flags[0], unwrapped input, stays)
@@ -658,8 +665,11 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
         MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
         const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc);
         if (lp.txy) {
-            MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, mode == 0 ? 1 : M, mode == 2, mode == 0, dmax, tf));
+            const bool cna = pattern && mode != 0;
+            if (cna) tf.cna_todo = todo;
+            MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, mode == 0 ? 1 : M, mode == 2, mode == 0, dmax, tf, cna ? pattern : nullptr));
             done = true;
+            if (cna && fused) *fused = true;
         }
     }
     if (!done && mode != 0 && g_neighbor_variant != 1 && !b.tri) { // cells too full for the kernel above (or forced): the round-1 tiled kernel
@@ -718,6 +728,47 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
     {
         ProfRange pr("k_neighbor", sc.stream());
         MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, max_neigh, fill_pads ? 2 : 1, nullptr));
+    }
+    return sc.finish(space);
+}
+
+// mdh_build_neighbor followed by mdh_fcna with the same rc, in one pass over the tiles where the tile kernel applies
+int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                            const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
+                            int64_t max_neigh, int fill_pads, int *pattern, const int64_t *key, int space, void *stream)
+{
+    if (N < 0 || N >= 2147483647LL || !(rc > 0) || max_neigh <= 0) { set_error("mdh_build_neighbor_fcna: invalid N, rc or max_neigh"); return MDH_ERR_ARG; }
+    DBox b;
+    MDH_TRY(make_box(b, box9, origin3, boundary3));
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    int *dv = sc.stage(verlet, (size_t)(N * max_neigh), space, !fill_pads, true);
+    double *dd = sc.stage(dist, (size_t)(N * max_neigh), space, !fill_pads, true);
+    int *dn = sc.stage(nn, (size_t)N, space, false, true);
+    int *dp = sc.stage(pattern, (size_t)N, space, true, true); // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
+    int *todo = sc.alloc_n<int>((size_t)N + 1);
+    const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), sc.stream()));
+    CellGrid cg;
+    MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    {
+        ProfRange pr("cell_grid", sc.stream());
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey));
+    }
+    bool fused = false;
+    {
+        ProfRange pr("k_neighbor", sc.stream());
+        MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, max_neigh, fill_pads ? 2 : 1, nullptr, dp, todo, &fused));
+    }
+    {
+        ProfRange pr("k_fcna", sc.stream());
+        if (fused) launch_fcna_listed(sc.stream(), b, dx, dy, dz, N, dv, max_neigh, dn, dp, rc, todo);
+        else launch_fcna_all(sc.stream(), b, dx, dy, dz, N, dv, max_neigh, dn, dp, rc, todo);
+        MDH_HIP(hipGetLastError());
     }
     return sc.finish(space);
 }

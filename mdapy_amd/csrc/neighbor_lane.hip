@@ -40,6 +40,7 @@
 // ~50 wave-level instructions per centre, most of them scalar bookkeeping; this kernel 1.40 ms.
 #include "common.hpp"
 #include "grid.hpp"
+#include "cna_core.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -222,6 +223,34 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
     return m;
 }
 
+// fixed-cutoff CNA of one centre (FixedCNA, cna.cpp:429-506) from the tile: its NN tickets are the LDS indices of the listed
+// neighbours in row order, their RAW positions are staged.  plain: no staged atom of this tile carries an image shift, and
+// two neighbours of one centre are less than 2 rc < L / 2 apart (>= 7 cells per periodic axis): the minimum image of every
+// pair is the plain difference, d - L * 0 == d as the reference computes it.  Tiles at a periodic face classify the spread
+// of the positions as k_fcna does; -1: spread too far (atoms handed in outside the box), the atom goes to the to-do list
+template <bool TRI, int NN>
+__device__ __forceinline__ int lane_fcna(const DBox &b, const unsigned short *__restrict__ my, const double2 *__restrict__ lxy,
+                                         const double *__restrict__ lz, bool plain, double cut2)
+{
+    double px[NN], py[NN], pz[NN];
+#pragma unroll
+    for (int a = 0; a < NN; ++a) {
+        const int k = my[a];
+        const double2 c = lxy[k];
+        px[a] = c.x; py[a] = c.y; pz[a] = lz[k];
+    }
+    Rows R;
+    if (TRI) {
+        R = bond_rows_reg<true, NN>(b, px, py, pz, cut2);
+    } else {
+        const int cls = plain ? 2 : span_class3<NN>(b, px, py, pz);
+        if (cls == 0)
+            return -1;
+        R = bond_rows_ortho<NN>(b, px, py, pz, cut2, cls == 2);
+    }
+    return fcna_label<NN>(R);
+}
+
 // COUNT: nn and the largest count only (first pass of the exact-width variant)
 // parent != nullptr: second pass over the tiles the first pass listed (halo over the LDS budget): the same tiling cut into
 // nsub slices along z (this launch's TZ = parent's TZ / nsub); what still does not fit goes to `flagged` (counter
@@ -233,7 +262,8 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
 // LOOP: the workgroup walks every (gridDim/8)-th tile of its XCD's chunk (tile lists whose length only the device knows);
 // false: one tile per workgroup, straight-line code (measurably faster: 1.13 against 1.22 ms on the headline build — the
 // loop-carried state costs scalar-register spills in every phase)
-template <bool COUNT, bool TRI, bool LOOP>
+// FCNA: the fixed-cutoff CNA label of every centre as well (mdh_build_neighbor_fcna)
+template <bool COUNT, bool TRI, bool LOOP, bool FCNA>
 __global__ __launch_bounds__(NT) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     int M, int mp_shift, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
-    int flag_slot)
+    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo)
 {
     if (flags[0] != 0) // unwrapped input: the image codes are not valid, the thread-per-atom kernel takes the whole call
         return;
@@ -511,6 +541,13 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                             ++sl;
                             m &= ~(0x80000000u >> z);
                         }
+                    }
+                    if (FCNA) { // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
+                        int label = 0;
+                        if (hits == 12 && M >= 12) label = lane_fcna<TRI, 12>(b, my, lxy, lz, !general_tile, rcsq);
+                        else if (hits == 14 && M >= 14) label = lane_fcna<TRI, 14>(b, my, lxy, lz, !general_tile, rcsq);
+                        if (label > 0) pattern[id] = label;
+                        else if (label < 0) defer(cna_todo, id);
                     }
                     rxy[tid] = make_double2(xi, yi);
                     rzc[tid] = make_double2(zi, __longlong_as_double((long long)(((unsigned long long)(unsigned)(hits < M ? hits : M) << 57) | (unsigned long long)((int64_t)id * M))));
@@ -825,7 +862,7 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
 // count == true: nn and *max_count only (first pass of the exact-width variant); M is then 1
 int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,
-                         TileFilter &tf)
+                         TileFilter &tf, int *pattern)
 {
     using namespace lane;
     const Shape ts{plan.txy, plan.tz};
@@ -865,24 +902,25 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const float negc = -plan.mid;
     const Shape ts2{ts.txy, 1};
     const int nt2b = nt[2] * nsub;
-#define MDH_LANE_PASS(COUNT, TRI, LOOP, GRID, ...)                                                                                          \
+#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, GRID, ...)                                                                                    \
     do {                                                                                                                                  \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__);          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo); \
     } while (0)
     // first pass: all tiles (one per workgroup) or the list of live ones (walked); second pass: one-cell slices of what it listed
-#define MDH_LANE_LAUNCH(COUNT, TRI)                                                                                                       \
+#define MDH_LANE_LAUNCH(COUNT, TRI, FCNA)                                                                                                 \
     do {                                                                                                                                  \
         if (list_mode)                                                                                                                    \
-            MDH_LANE_PASS(COUNT, TRI, true, grid, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+            MDH_LANE_PASS(COUNT, TRI, true, FCNA, grid, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
         else                                                                                                                              \
-            MDH_LANE_PASS(COUNT, TRI, false, grid, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
-        MDH_LANE_PASS(COUNT, TRI, true, dim3(1024), nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, grid, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
+        MDH_LANE_PASS(COUNT, TRI, true, FCNA, dim3(1024), nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
-    if (b.tri) { if (count) MDH_LANE_LAUNCH(true, true); else MDH_LANE_LAUNCH(false, true); }
-    else { if (count) MDH_LANE_LAUNCH(true, false); else MDH_LANE_LAUNCH(false, false); }
+    if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false); else MDH_LANE_LAUNCH(true, false, false); }
+    else if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true); else MDH_LANE_LAUNCH(false, false, true); }
+    else { if (b.tri) MDH_LANE_LAUNCH(false, true, false); else MDH_LANE_LAUNCH(false, false, false); }
 #undef MDH_LANE_PASS
 #undef MDH_LANE_LAUNCH
     MDH_HIP(hipGetLastError());

@@ -143,6 +143,62 @@ def test_neighbor_tile_overflow_and_variants():
         assert all(np.array_equal(a, b) for a, b in zip(*outs))
 
 
+
+def test_fused_neighbor_fcna_equals_the_two_calls():
+    """mdh_build_neighbor_fcna == mdh_build_neighbor then mdh_fcna, bit for bit (lists AND labels), on every kind of tile the
+    kernel meets: interior, periodic seam, open faces, atoms handed in outside the box / unwrapped (the stand-by kernel
+    takes the call), vacuum (walked tile list), tiles over the LDS budget (mop-up + to-do list), triclinic, rows exactly
+    12 / 14 wide, rows too narrow for a label; and against the oracle on the crystalline cases"""
+    from mdapy_amd import _cna
+
+    rng = np.random.default_rng(5)
+    cases = [c for c in CASES if c[0] in ("fcc_rattled", "fcc_hot_shifted_origin", "fcc_unwrapped", "slab_open_z", "cluster_open",
+                                          "dense_blob", "fcc_partial_tiles", "triclinic_fcc_sheared", "triclinic_dense_blob",
+                                          "triclinic_random")]
+    assert len(cases) == 10
+    # a bcc crystal (14 neighbours inside 1.2 a) and an fcc/hcp bicrystal-like stacking through random rattling
+    pb, bb = lattice_positions("bcc", 2.87, 12, 12, 12)
+    cases.append(("bcc_rattled", pb + rng.normal(0, 0.03, pb.shape), bb, ORG0, PBC))
+    ph, bh = lattice_positions("hcp", 2.95, 12, 14, 8)
+    cases.append(("hcp_rattled", ph + rng.normal(0, 0.03, ph.shape), bh, ORG0, PBC))
+    labelled = 0
+    for name, pos, box, org, bnd in cases:
+        x, y, z = _xyz(pos)
+        n = len(x)
+        rcs = {"bcc_rattled": 1.2 * 2.87, "hcp_rattled": 0.5 * (1 + 2 ** 0.5) * 2.95}.get(name, 0.854 * 3.615 if "fcc" in name or "slab" in name or "cluster" in name else 3.3)
+        if name.startswith("triclinic_fcc"):
+            rcs = 0.854 * 3.4
+        for M in ((14, 12, 20, 8) if name in ("fcc_rattled", "bcc_rattled") else (16,)):
+            va = np.full((n, M), -1, np.int32); da = np.full((n, M), rcs + 1.0); na = np.zeros(n, np.int32)
+            _neighbor.build_neighbor(x, y, z, box, org, bnd, rcs, va, da, na, 1)
+            pa = np.zeros(n, np.int32)
+            _cna.fcna(x, y, z, box, org, bnd, va, na, pa, rcs, 1)
+            for fill in (False, True):
+                vb = np.full((n, M), -1, np.int32) if not fill else np.empty((n, M), np.int32)
+                db = np.full((n, M), rcs + 1.0) if not fill else np.empty((n, M))
+                nb = np.zeros(n, np.int32); pb_ = np.zeros(n, np.int32)
+                _neighbor.build_neighbor_fcna(x, y, z, box, org, bnd, rcs, vb, db, nb, pb_, 1, fill_pads=fill)
+                assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da), (name, M, fill)
+                assert np.array_equal(pb_, pa), (name, M, fill, int((pb_ != pa).sum()))
+            if M == 8:
+                assert not pa.any()  # rows too narrow: nothing is labelled (cna.cpp:456)
+            labelled += int((pa > 0).sum())
+            if name in ("fcc_rattled", "bcc_rattled", "hcp_rattled", "slab_open_z") and M >= 14:
+                po = np.zeros(n, np.int32)
+                O.fcna(x, y, z, box, org, bnd, va, na, po, rcs, 4)
+                assert np.array_equal(pa, po) and (po > 0).any(), name
+    assert labelled > 10000
+    # caller-initialised labels survive where the analysis does not speak
+    _, pos, box, org, bnd = [c for c in CASES if c[0] == "random_gas"][0]
+    x, y, z = _xyz(pos)
+    n = len(x)
+    v = np.empty((n, 16), np.int32); d = np.empty((n, 16)); c_ = np.empty(n, np.int32); p7 = np.full(n, 7, np.int32)
+    _neighbor.build_neighbor_fcna(x, y, z, box, org, bnd, 3.0, v, d, c_, p7, 1, fill_pads=True)
+    p7b = np.full(n, 7, np.int32)
+    _cna.fcna(x, y, z, box, org, bnd, v, c_, p7b, 3.0, 1)
+    assert np.array_equal(p7, p7b) and (p7 == 7).any()
+
+
 def test_neighbor_device_space_and_pads():
     """HBM-resident path (torch tensors in, HArray out) == host-space path; kernel-written pads == -1 / rc+1."""
     import torch
