@@ -49,15 +49,16 @@ with open(os.path.join(P, "r02_bench_kernel_stats.md"), "w") as f:
         f.write(f"| `{k}` | {c} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} |\n")
 
 # ---- neighbour kernel counters
-nb = {}
+# every build = the main launch (instance <COUNT=false, TRI=false, LOOP=false, FCNA=false>: one tile per workgroup) + the slice
+# launch (<false, false, true, false>: the listed tiles, ~2 % of the work); pmc() gives the mean per dispatch of each instance
+nbm = {}
 for tag in ("nb_sq1", "nb_sq2", "nb_fetch", "nb_write"):
     for k, v in pmc(tag).items():
-        if "k_neighbor_lane<false" in k:
-            nb.update({c: val for c, val in v.items()})
-d = nb.get("dispatches", 8)
-main = d // 2  # every build = main launch + slice launch; the slice launch is ~2 % of the work
-nbm = {c: v * d / main for c, v in nb.items() if c != "dispatches"}
-nbm["_note"] = ("per BUILD (main launch + slice launch) of k_neighbor_lane<false,false>, tools/nb_probe.py 136 16 0.854; SQ_* summed over the chip. "
+        if "k_neighbor_lane<false, false" in k:
+            for c, val in v.items():
+                if c != "dispatches":
+                    nbm[c] = nbm.get(c, 0.0) + val
+nbm["_note"] = ("per BUILD (main launch + slice launch) of k_neighbor_lane<false,false,*,false>, tools/nb_probe.py 136 16 0.854; SQ_* summed over the chip. "
                 "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU are in units of 4 cycles per SIMD; FETCH_SIZE / WRITE_SIZE in KB (FETCH undoubled)")
 kernel_ms = rf["avg_kernel_ms"]
 cyc = kernel_ms * 1e-3 * 2.4e9
