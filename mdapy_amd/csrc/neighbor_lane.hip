@@ -814,8 +814,6 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
         if (cap_env > 0)
             break;
     }
-    static const int tile_env = [] { const char *e = std::getenv("MDH_LANE_TILE"); return e ? std::atoi(e) : 0; }(); // experiments: txy * 100 + tz
-    if (tile_env > 0) best = Shape{tile_env / 100, tile_env % 100};
     if (!best.txy) { g_last_plan[6] = -6; return p; }
     // Decision band of the single-precision scan (file header).  E bounds the staged coordinates (far-atom check of the
     // kernel), du the error of one staged coordinate: rounding to f32 plus what the double-precision shift can lose;

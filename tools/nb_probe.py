@@ -1,4 +1,6 @@
-"""wave-kernel probe: plan + debug counters + per-kernel time.  python tools/nb_probe.py [cells] [M] [rc/a] [sigma] [reps]"""
+"""lane-kernel probe: plan + per-range time.  python tools/nb_probe.py [cells] [M] [rc/a] [sigma] [reps] [shear]
+NB_LIB=<path>: another build of the library (A/B on one box); with mdapy_amd/csrc/libmdapy_amd_stamps.so (make stamps) the
+phase time stamps of the kernel are printed as well."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
