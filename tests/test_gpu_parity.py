@@ -1145,7 +1145,14 @@ def test_voronoi_vs_reference_library(case):
     v1, n1, r1 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
     _voronoi.get_voronoi_volume_number_radius(x, y, z, box, origin, bd, v1, n1, r1)
     assert np.allclose(v1, v0, rtol=1e-9, atol=1e-9) and np.allclose(r1, r0, rtol=1e-9, atol=1e-9)
-    assert np.array_equal(n1, n0)
+    if not np.array_equal(n1, n0):
+        # voro++ now and then keeps a sliver its vertex tolerance leaves behind (a "face" of 1e-14 A^2 where four cells meet
+        # almost in a line; found by the randomised sweep, seed 54901): the counts must agree once faces below 1e-10 A^2 are
+        # left out on both sides
+        va, da, fa, ca = O.get_voronoi_neighbor(x, y, z, box, origin, bd, -1.0, -1.0)
+        vb, db, fb, cb = _voronoi.get_voronoi_neighbor(x, y, z, box, origin, bd, -1.0, -1.0)
+        real = lambda f, c: np.array([(f[r, :c[r]] >= 1e-10).sum() for r in range(len(c))])
+        assert np.array_equal(ca, n0) and np.array_equal(cb, n1) and np.array_equal(real(fa, ca), real(fb, cb))
     if all(bd):
         vol = abs(np.linalg.det(np.asarray(box, float))) if np.ndim(box) == 2 else float(np.prod(box))
         assert abs(v1.sum() - vol) < 1e-6 * vol  # the cells tile the periodic box
@@ -1159,10 +1166,20 @@ def test_voronoi_neighbors_vs_reference_library(case):
     if case == "slab_open_z":
         pos = pos.copy(); pos[:, 2] = np.clip(pos[:, 2], 1e-3, (box[2, 2] if np.ndim(box) == 2 else box[2]) - 1e-3)
     x, y, z = _xyz(pos)
+    # voro++ now and then keeps a sliver its vertex tolerance leaves behind (test_voronoi_vs_reference_library): such "faces"
+    # (< 1e-10 A^2) are counted per side here and left out of every comparison below; the reference's count is the cell's
+    # number of faces whatever the thresholds filter out of the row
+    _, _, fa, ca = O.get_voronoi_neighbor(x, y, z, box, origin, bd, -1.0, -1.0)
+    _, _, fb, cb = _voronoi.get_voronoi_neighbor(x, y, z, box, origin, bd, -1.0, -1.0)
+    slivers = lambda f, c: np.array([(f[r, :c[r]] < 1e-10).sum() for r in range(len(c))])
+    sl0, sl1 = slivers(fa, ca), slivers(fb, cb)
     for a_thr, r_thr in ((-1.0, -1.0), (0.3, -1.0), (-1.0, 0.02)):
         v0, d0, f0, n0 = O.get_voronoi_neighbor(x, y, z, box, origin, bd, a_thr, r_thr)
         v1, d1, f1, n1 = _voronoi.get_voronoi_neighbor(x, y, z, box, origin, bd, a_thr, r_thr)
-        assert np.array_equal(n1, n0)
+        assert np.array_equal(n1 - sl1, n0 - sl0)
+        if a_thr < 0 and r_thr < 0 and (sl0.any() or sl1.any()):  # unfiltered rows list the slivers: make them look like pads
+            drop = lambda v, d, f: tuple(np.where(f >= 1e-10, a, fill) for a, fill in ((v, -1), (d, 10000.0), (f, 0.0)))
+            (v0, d0, f0), (v1, d1, f1) = drop(v0, d0, f0), drop(v1, d1, f1)
         # canonical form of a row: entries sorted by (neighbour id, face area)
         def canon(v, d, f):
             # (neighbour id, face area): one neighbour can appear twice (two images, same minimum-image distance)
@@ -1173,7 +1190,8 @@ def test_voronoi_neighbors_vs_reference_library(case):
         c0 = canon(pad(v0, -1), pad(d0, 10000.0), pad(f0, 0.0))
         c1 = canon(pad(v1, -1), pad(d1, 10000.0), pad(f1, 0.0))
         assert np.array_equal(c1[0], c0[0])
-        assert np.allclose(c1[1], c0[1], rtol=1e-9, atol=1e-9) and np.allclose(c1[2], c0[2], rtol=1e-7, atol=1e-9)
+        there = c0[0] >= 0
+        assert np.allclose(c1[1][there], c0[1][there], rtol=1e-9, atol=1e-9) and np.allclose(c1[2][there], c0[2][there], rtol=1e-7, atol=1e-9)
         # rows are ordered by the distance of the image that makes the face, pads last; the reported distance is the
         # reference's minimum-image one, so the two orders can only differ where a thin box makes a cell touch a
         # farther image of a neighbour
