@@ -259,9 +259,9 @@ __device__ __forceinline__ int lane_fcna(const DBox &b, const unsigned short *__
 // single-precision coordinates are Cartesian, relative to the tile's corner, of the WRAPPED atom shifted by the lattice
 // vectors its cell is away from the tile; every decision inside the band and every written distance goes through the
 // reference's fractional fold.
-// LOOP: the workgroup walks every (gridDim/8)-th tile of its XCD's chunk (tile lists whose length only the device knows);
-// false: one tile per workgroup, straight-line code (measurably faster: 1.13 against 1.22 ms on the headline build — the
-// loop-carried state costs scalar-register spills in every phase)
+// LOOP: the workgroup walks every (gridDim/8)-th tile of its XCD's chunk, from the jt0-th on (the slice pass; what a tile
+// list longer than the host expected leaves over); false: one tile per workgroup, straight-line code (measurably faster:
+// 1.15 against 1.23 ms on the headline build — the loop-carried state costs scalar-register spills in every phase)
 // FCNA: the fixed-cutoff CNA label of every centre as well (mdh_build_neighbor_fcna)
 template <bool COUNT, bool TRI, bool LOOP, bool FCNA>
 __global__ __launch_bounds__(NT) void k_neighbor_lane(
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     int M, int mp_shift, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
-    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo)
+    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0)
 {
     if (flags[0] != 0) // unwrapped input: the image codes are not valid, the thread-per-atom kernel takes the whole call
         return;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
             else { ra[v] = 0; rb[v] = 0; rc4[v] = 0; rd[v] = 0; rm[v] = NEUTRAL; }
         }
     };
-    for (int jt = (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
+    for (int jt = jt0 + (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
         const int slot = (int)(blockIdx.x & 7) * per + jt;
         if (slot >= nlive)
             break;
@@ -900,21 +900,26 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const float negc = -plan.mid;
     const Shape ts2{ts.txy, 1};
     const int nt2b = nt[2] * nsub;
-#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, GRID, ...)                                                                                    \
+#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, GRID, JT0, ...)                                                                                  \
     do {                                                                                                                                  \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo); \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0); \
     } while (0)
-    // first pass: all tiles (one per workgroup) or the list of live ones (walked); second pass: one-cell slices of what it listed
+    // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
+    // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
+    // otherwise); second pass: one-cell slices of what the first listed
 #define MDH_LANE_LAUNCH(COUNT, TRI, FCNA)                                                                                                 \
     do {                                                                                                                                  \
-        if (list_mode)                                                                                                                    \
-            MDH_LANE_PASS(COUNT, TRI, true, FCNA, grid, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
-        else                                                                                                                              \
-            MDH_LANE_PASS(COUNT, TRI, false, FCNA, grid, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
-        MDH_LANE_PASS(COUNT, TRI, true, FCNA, dim3(1024), nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
+        if (list_mode) {                                                                                                                  \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, grid, 0, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+            if ((int64_t)per * 8 < ntiles)                                                                                                \
+                MDH_LANE_PASS(COUNT, TRI, true, FCNA, dim3(512), per, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+        } else {                                                                                                                          \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, grid, 0, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
+        }                                                                                                                                 \
+        MDH_LANE_PASS(COUNT, TRI, true, FCNA, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
     if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false); else MDH_LANE_LAUNCH(true, false, false); }
     else if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true); else MDH_LANE_LAUNCH(false, false, true); }

@@ -199,6 +199,36 @@ def test_fused_neighbor_fcna_equals_the_two_calls():
     assert np.array_equal(p7, p7b) and (p7 == 7).any()
 
 
+
+def test_neighbor_live_tile_list_longer_than_expected():
+    """the tile kernel sizes its first launch from the occupancy statistics of the LAST call with the same (N, grid); when the
+    atoms have spread since (stale statistics: they are recounted only every 8th call), the list of live tiles is longer
+    than the launch and the stand-by launch walks the rest.  Same N and box, first a compact crystal in a corner of a
+    large open box, then the same number of atoms as a thin sheet across it: rows equal the oracle's both times."""
+    from mdapy_amd import _lib
+
+    a = 3.615
+    blob, _ = lattice_positions("fcc", a, 16, 16, 16)            # 16 384 atoms in a 58 A cube
+    sheet, _ = lattice_positions("fcc", a, 64, 64, 1)            # 16 384 atoms as a 231 x 231 x 3.6 A sheet
+    assert len(blob) == len(sheet)
+    rng = np.random.default_rng(3)
+    box = np.diag([260.0, 260.0, 260.0])
+    bnd = np.array([0, 0, 0], np.int32)
+    rc, M = 0.854 * a, 16
+    plan = np.zeros(8, np.int32)
+    for k, pos in enumerate((blob + 5.0, sheet + np.array([5.0, 5.0, 120.0]), sheet + np.array([9.0, 7.0, 60.0]))):
+        pos = pos + rng.normal(0, 0.03, pos.shape)
+        x, y, z = _xyz(pos)
+        n = len(x)
+        va = np.full((n, M), -1, np.int32); da = np.full((n, M), rc + 1.0); na = np.zeros(n, np.int32)
+        O.build_neighbor(x, y, z, box, ORG0, bnd, rc, va, da, na, 4)
+        vb = np.empty((n, M), np.int32); db = np.empty((n, M)); nb = np.empty(n, np.int32)
+        _neighbor.build_neighbor(x, y, z, box, ORG0, bnd, rc, vb, db, nb, 1, fill_pads=True)
+        _lib.lib().mdh_debug_neighbor_plan(plan.ctypes.data)
+        assert plan[0] > 0 and plan[4] == 0, plan  # the tile kernel ran, on a list of live tiles (vacuum around the atoms)
+        assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da), k
+
+
 def test_neighbor_device_space_and_pads():
     """HBM-resident path (torch tensors in, HArray out) == host-space path; kernel-written pads == -1 / rc+1."""
     import torch

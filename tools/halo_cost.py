@@ -20,6 +20,7 @@ x, y, z, gid = slab_positions(torch, dev, cells, rank, 0.0)
 n = int(x.shape[0])
 box = mp.Box(np.diag([A_CU * cells * world, A_CU * cells, A_CU * cells]))
 dec = D.SlabDecomposition(box, rank, world, axis=0)
+dec._host_staged = lambda: False  # (no process group here: the loop-back below stands in for RCCL, device to device)
 Lx = A_CU * cells
 
 
