@@ -96,16 +96,33 @@ def rdf_stream_check(s):
     assert np.array_equal(g0, g1)
 
 
+def fused_check(s):
+    """mdh_build_neighbor_fcna against mdh_build_neighbor followed by mdh_fcna: lists and labels bit for bit"""
+    r = np.random.default_rng(s["seed"] + 31)
+    x, y, z = T._xyz(s["pos"])
+    n = len(x)
+    rc = float(r.uniform(2.7, 3.9))
+    M = int(r.choice([12, 14, 16, 20, 30]))
+    va = np.full((n, M), -1, np.int32); da = np.full((n, M), rc + 1.0); na = np.zeros(n, np.int32); pa = np.zeros(n, np.int32)
+    T._neighbor.build_neighbor(x, y, z, s["box"], s["origin"], s["bnd"], rc, va, da, na, 1)
+    T._cna.fcna(x, y, z, s["box"], s["origin"], s["bnd"], va, na, pa, rc, 1)
+    vb = np.empty((n, M), np.int32); db = np.empty((n, M)); nb = np.empty(n, np.int32); pb = np.zeros(n, np.int32)
+    T._neighbor.build_neighbor_fcna(x, y, z, s["box"], s["origin"], s["bnd"], rc, vb, db, nb, pb, 1, fill_pads=True)
+    assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da) and np.array_equal(pb, pa)
+
+
 def checks(s):
     case = ("fuzz", s["pos"], s["box"], s["origin"], s["bnd"])
     if s["kind"] == "big":  # the tile kernels: neighbour rows bit for bit (fixed and exact width), pair counts
         rc_big = float(np.random.default_rng(s["seed"] + 7).uniform(2.8, 3.7))
         T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
-        return [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc_big)), ("rdf_stream", lambda: rdf_stream_check(s))]
+        return [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc_big)), ("rdf_stream", lambda: rdf_stream_check(s)),
+                ("fused_cna", lambda: fused_check(s))]
     T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
     rc = float(np.random.default_rng(s["seed"] + 7).uniform(2.6, 4.6))
     out = [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc)),
            ("rdf_stream", lambda: rdf_stream_check(s)),
+           ("fused_cna", lambda: fused_check(s)),
            ("sort_cna", lambda: T.test_sort_and_cna_vs_oracle(case)),
            ("overlap", lambda: T.test_filter_overlap_atom_vs_oracle("fuzz"))]
     if len(s["pos"]) >= 300 and s["kind"] in ("fcc", "bcc", "blob"):  # (the check also wants some atoms removed by its last cutoff set)

@@ -1207,6 +1207,7 @@ def test_voronoi_neighbors_vs_reference_library(case):
         v0, d0, f0, n0 = O.get_voronoi_neighbor(x, y, z, box, origin, bd, a_thr, r_thr)
         v1, d1, f1, n1 = _voronoi.get_voronoi_neighbor(x, y, z, box, origin, bd, a_thr, r_thr)
         assert np.array_equal(n1 - sl1, n0 - sl0)
+        v1_rows, d1_rows = v1, d1  # (as returned: the order checks at the end look at these)
         if a_thr < 0 and r_thr < 0 and (sl0.any() or sl1.any()):  # unfiltered rows list the slivers: make them look like pads
             drop = lambda v, d, f: tuple(np.where(f >= 1e-10, a, fill) for a, fill in ((v, -1), (d, 10000.0), (f, 0.0)))
             (v0, d0, f0), (v1, d1, f1) = drop(v0, d0, f0), drop(v1, d1, f1)
@@ -1225,6 +1226,7 @@ def test_voronoi_neighbors_vs_reference_library(case):
         # rows are ordered by the distance of the image that makes the face, pads last; the reported distance is the
         # reference's minimum-image one, so the two orders can only differ where a thin box makes a cell touch a
         # farther image of a neighbour
+        v1, d1 = v1_rows, d1_rows
         dd = np.where(v1 >= 0, d1, 1e9)
         L = np.diag(np.asarray(box, float)) if np.ndim(box) == 2 else np.asarray(box, float)
         vs = np.sort(np.where(v1 >= 0, v1, -np.arange(1, v1.shape[1] + 1)[None, :]), axis=1)
