@@ -72,6 +72,9 @@ int mdh_debug_set_neighbor_variant(int variant);
 int mdh_debug_neighbor_plan(int *plan8);
 /* test hook: 0 = LDS-tile kernel for the streaming RDF where it applies (default), 1 = thread-per-atom kernel everywhere */
 int mdh_debug_set_rdf_variant(int variant);
+/* k nearest neighbours: 0 = the near kernel (sorted list in registers, 27 cells) followed by the general kernel on the queries it
+ * lists; 1 = the general kernel for every query (A/B measurements, tests; results identical) */
+int mdh_debug_set_knn_variant(int variant);
 /* test hook: 0 = per-degree register-resident stage 1 of the Steinhardt parameters where compiled (default), 1 = generic kernel */
 int mdh_debug_set_sq_variant(int variant);
 /* test hook: vertex capacity of the first pass of the PTM neighbour ordering (10 default, 15; 5 sends most atoms through

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mdh_debug_set_neighbor_variant": [cint],
     "mdh_debug_neighbor_plan": [vp],
     "mdh_debug_set_rdf_variant": [cint],
+    "mdh_debug_set_knn_variant": [cint],
     "mdh_debug_set_sq_variant": [cint],
     "mdh_debug_set_ptm_order_cap": [cint],
     "mdh_debug_image_thresholds": [dbl, vp],

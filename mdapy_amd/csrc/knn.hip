@@ -20,6 +20,8 @@
 
 namespace mdh {
 
+int g_knn_variant = 0; // 0 = near kernel + general kernel, 1 = general kernel only (tests, A/B)
+
 struct KnnGeom {
     int nim[3];    // images per axis (0 on open axes)
     double wmin;   // smallest perpendicular cell width
@@ -57,19 +59,132 @@ __global__ __launch_bounds__(256) void k_knn_wrap(const double *__restrict__ x, 
 
 __device__ __forceinline__ int floordiv(int a, int n) { int q = a / n; return (a % n < 0) ? q - 1 : q; }
 
+// The common case — the k nearest all lie within one cell width, in the 27 cells around the query — with the sorted list in
+// REGISTERS (K slots, K >= k a template constant): an insertion is a fully unrolled count of the entries that stay in front
+// (the position) and one predicated move per slot, ~14 instructions per slot and no memory access, where the list in LDS
+// pays two dependent LDS round trips per shifted entry at two waves per SIMD (measured: 15 of 21 ms at k = 18 went into
+// shifting).  No LDS at all, so occupancy is set by the registers.  A query that does not find k candidates within one cell
+// width is appended to `todo` and finished by k_knn (any number of rings, list in LDS).
+template <bool TRI, int K>
+__global__ __launch_bounds__(256) void k_knn_near(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                  const double *__restrict__ zs, const int *__restrict__ order,
+                                                  const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg, Grid g,
+                                                  KnnGeom kg, int k, int *__restrict__ indices,
+                                                  double *__restrict__ distances, int *__restrict__ todo)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N)
+        return;
+    const int i = order[p];
+    const double qx = xs[p], qy = ys[p], qz = zs[p]; // wrapped query == stored wrapped self (bitwise)
+    int c0, c1, c2;
+    cell_coords<TRI>(bg, g, qx, qy, qz, c0, c1, c2);
+    double ld[K]; // the K best so far, sorted by (squared distance, id); free slots hold +inf
+    int li[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) { ld[e] = __builtin_huge_val(); li[e] = 0x7fffffff; }
+    const double one_cell = kg.wmin * (1.0 - 1e-9), bound = one_cell * one_cell;
+    auto fold_cell = [&](int d, int e, int &a, int &m) {
+        m = 0; a = e;
+        if (b.pbc[d]) { m = floordiv(e, g.nc[d]); a = e - m * g.nc[d]; return !(m > kg.nim[d] || m < -kg.nim[d]); }
+        return e >= 0 && e < g.nc[d];
+    };
+    for (int col9 = 0; col9 < 9; ++col9) { // nearest columns first: the k-th distance tightens early
+        const int da = (0x28161 >> (2 * col9) & 3) - 1, db = (0x22215 >> (2 * col9) & 3) - 1; // (0,0) (-1,0) (1,0) (0,-1) (0,1) (-1,-1) (-1,1) (1,-1) (1,1)
+        int a0, m0, a1, m1;
+        if (!fold_cell(0, c0 + da, a0, m0) || !fold_cell(1, c1 + db, a1, m1)) continue;
+        const int64_t col = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2];
+        for (int e2 = c2 - 1; e2 <= c2 + 1;) {
+            int a2, m2;
+            if (!fold_cell(2, e2, a2, m2)) { ++e2; continue; }
+            int len = 1; // cells of this column with the same image number: one contiguous piece of the sorted arrays
+            while (e2 + len <= c2 + 1 && a2 + len < g.nc[2]) ++len;
+            double s0, s1, s2; // image shift, fast_knn.cpp:822-833 (see k_knn)
+            if (TRI) {
+                s0 = m0 * b.h[0] + m1 * b.h[3] + m2 * b.h[6];
+                s1 = m0 * b.h[1] + m1 * b.h[4] + m2 * b.h[7];
+                s2 = m0 * b.h[2] + m1 * b.h[5] + m2 * b.h[8];
+            } else {
+                s0 = m0 * b.h[0]; s1 = m1 * b.h[4]; s2 = m2 * b.h[8];
+            }
+            const double w0 = qx - s0, w1 = qy - s1, w2 = qz - s2;
+            const int sb = cell_start[col + a2], se = cell_start[col + a2 + len];
+            for (int q0 = sb; q0 < se; q0 += 8) {
+                double d2s[8];
+                int cj[8];
+                unsigned todo_mask = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { // 32 loads in flight together
+                    const int q = min(q0 + u, se - 1);
+                    const double dx = xs[q] - w0, dy = ys[q] - w1, dz = zs[q] - w2;
+                    cj[u] = order[q];
+                    d2s[u] = dx * dx + dy * dy + dz * dz;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool live = q0 + u < se && !(cj[u] == i && d2s[u] == 0.0) && !(d2s[u] > bound) &&
+                                      (d2s[u] < ld[K - 1] || (d2s[u] == ld[K - 1] && cj[u] < li[K - 1]));
+                    todo_mask |= live ? 1u << u : 0u;
+                }
+                while (todo_mask) { // every lane inserts ITS next live candidate per round
+                    const int u = __builtin_ctz(todo_mask);
+                    todo_mask &= todo_mask - 1;
+                    double d2 = d2s[0];
+                    int j = cj[0];
+#pragma unroll
+                    for (int v = 1; v < 8; ++v)
+                        if (u == v) { d2 = d2s[v]; j = cj[v]; }
+                    int pos = 0; // entries that stay in front of the new one
+#pragma unroll
+                    for (int e = 0; e < K; ++e)
+                        pos += (ld[e] < d2 || (ld[e] == d2 && li[e] < j)) ? 1 : 0;
+#pragma unroll
+                    for (int e = K - 1; e >= 1; --e) {
+                        if (e > pos) { ld[e] = ld[e - 1]; li[e] = li[e - 1]; }
+                        else if (e == pos) { ld[e] = d2; li[e] = j; }
+                    }
+                    if (pos == 0) { ld[0] = d2; li[0] = j; }
+                }
+            }
+            e2 += len;
+        }
+    }
+    // k candidates within one cell width: nothing outside the 27 cells can be nearer (the stop test of ring 1)
+    bool full = true;
+#pragma unroll
+    for (int e = 0; e < K; ++e)
+        if (e < k && !(ld[e] <= bound)) full = false;
+    if (!full) {
+        todo[1 + atomicAdd(&todo[0], 1)] = (int)p;
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < K; ++e)
+        if (e < k) {
+            indices[(int64_t)i * k + e] = li[e];
+            distances[(int64_t)i * k + e] = sqrt(ld[e]); // :883
+        }
+}
+
 // top-k lists live in LDS: entry s of thread t at [s * blockDim + t]
 template <bool TRI>
 __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
                       const int *__restrict__ order, const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg,
-                      Grid g, KnnGeom kg, int k, int *__restrict__ indices, double *__restrict__ distances)
+                      Grid g, KnnGeom kg, int k, int *__restrict__ indices, double *__restrict__ distances,
+                      const int *__restrict__ todo)
 {
     extern __shared__ unsigned char smem[];
     const int bd = blockDim.x, t = threadIdx.x;
     double *td = reinterpret_cast<double *>(smem);                      // [k][bd]
     int *ti = reinterpret_cast<int *>(smem + sizeof(double) * (size_t)k * bd); // [k][bd]
-    const int64_t p = (int64_t)blockIdx.x * bd + t;
-    if (p >= N)
+    int64_t p = (int64_t)blockIdx.x * bd + t;
+    if (todo) { // the queries k_knn_near could not finish (todo[0] of them, positions in the cell-sorted arrays)
+        if (p >= todo[0])
+            return;
+        p = todo[1 + p];
+    } else if (p >= N) {
         return;
+    }
     const int i = order[p];
     const double qx = xs[p], qy = ys[p], qz = zs[p]; // wrapped query == stored wrapped self (bitwise)
     int c0, c1, c2;
@@ -77,112 +192,140 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
     int n = 0;
     double worst = __builtin_huge_val();
     int worst_id = 0x7fffffff;
-    // First try: rings 0 and 1 only, and only candidates within one cell width (the stop test after ring 1 demands
-    // k-th distance <= that width, so nothing farther can be in a result found there): a candidate beyond it costs one
-    // compare instead of a sorted insertion.  If fewer than k candidates are that close the search starts over without
-    // the bound and walks as many rings as it needs — the result is the same set in the same order either way.
+    // the candidates at positions [sb, se) of the cell-sorted arrays, seen from the shifted query w: into the sorted list
+    // (squared distance, then id; the k smallest are kept) unless farther than `bound`.  Batches of 8: the 32 loads of a
+    // batch are in flight together, and every lane then inserts ITS next live candidate per round — a wave runs
+    // max-over-lanes rounds (1-3 of 8) instead of walking all 8 slots with the insertion loop live whenever any lane needs it
+    auto scan_range = [&](int sb, int se, double w0, double w1, double w2, double bound) {
+        for (int q0 = sb; q0 < se; q0 += 8) {
+            double cx[8], cy[8], cz[8];
+            int cj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = min(q0 + u, se - 1);
+                cx[u] = xs[q]; cy[u] = ys[q]; cz[u] = zs[q]; cj[u] = order[q];
+            }
+            double d2s[8];
+            unsigned todo = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double dx = cx[u] - w0, dy = cy[u] - w1, dz = cz[u] - w2;
+                d2s[u] = dx * dx + dy * dy + dz * dz;
+                const bool live = q0 + u < se && !(cj[u] == i && d2s[u] == 0.0) && !(d2s[u] > bound);
+                todo |= live ? 1u << u : 0u;
+            }
+            while (todo) {
+                const int u = __builtin_ctz(todo);
+                todo &= todo - 1;
+                double d2 = d2s[0];
+                int j = cj[0];
+#pragma unroll
+                for (int v = 1; v < 8; ++v)
+                    if (u == v) { d2 = d2s[v]; j = cj[v]; }
+                if (n == k && !(d2 < worst || (d2 == worst && j < worst_id)))
+                    continue;
+                int pos = n < k ? n : k - 1;
+                while (pos > 0) {
+                    const double pd = td[(pos - 1) * bd + t];
+                    const int pi = ti[(pos - 1) * bd + t];
+                    if (!(pd > d2 || (pd == d2 && pi > j)))
+                        break;
+                    td[pos * bd + t] = pd;
+                    ti[pos * bd + t] = pi;
+                    --pos;
+                }
+                td[pos * bd + t] = d2;
+                ti[pos * bd + t] = j;
+                if (n < k) ++n;
+                if (n == k) { worst = td[(k - 1) * bd + t]; worst_id = ti[(k - 1) * bd + t]; }
+            }
+        }
+    };
+    // extended cell index e along axis d -> (stored cell a, image number m); false: no such cell (beyond an open face, or
+    // more images away than the reference looks, fast_knn.cpp:806-816)
+    auto fold_cell = [&](int d, int e, int &a, int &m) {
+        m = 0; a = e;
+        if (b.pbc[d]) { m = floordiv(e, g.nc[d]); a = e - m * g.nc[d]; return !(m > kg.nim[d] || m < -kg.nim[d]); }
+        return e >= 0 && e < g.nc[d];
+    };
+    // image shift, fast_knn.cpp:822-833.  An atom stored in cell (a0,a1,a2), seen through the extended cell e = a + m*nc, is
+    // the image a + m*L.  Its distance to the query is |a - (q - m*L)|: the reference's shifted query with shift = m*L (:759-763)
+    auto shifted = [&](int m0, int m1, int m2, double &w0, double &w1, double &w2) {
+        double s0, s1, s2;
+        if (TRI) {
+            s0 = m0 * b.h[0] + m1 * b.h[3] + m2 * b.h[6];
+            s1 = m0 * b.h[1] + m1 * b.h[4] + m2 * b.h[7];
+            s2 = m0 * b.h[2] + m1 * b.h[5] + m2 * b.h[8];
+        } else {
+            s0 = m0 * b.h[0]; s1 = m1 * b.h[4]; s2 = m2 * b.h[8];
+        }
+        w0 = qx - s0; w1 = qy - s1; w2 = qz - s2;
+    };
+    // First try: the 27 cells of rings 0 and 1, and only candidates within one cell width (the stop test after ring 1
+    // demands k-th distance <= that width, so nothing farther can be in a result found there): a candidate beyond it costs
+    // one compare instead of a sorted insertion.  The cells of a column that share an image number are one contiguous
+    // piece of the cell-sorted arrays (z runs fastest): 9 pieces of ~3 cells instead of 27 cells, a third of the dependent
+    // cell_start -> atoms load chains and batches that are mostly full.  If fewer than k candidates are that close the search
+    // starts over without the bound and walks as many rings as it needs — the result is the same set in the same order.
     const double one_cell = kg.wmin * (1.0 - 1e-9);
-    for (int attempt = kg.rmax >= 1 ? 0 : 1; attempt < 2; ++attempt) {
-    const double bound = attempt == 0 ? one_cell * one_cell : __builtin_huge_val();
-    const int last_ring = attempt == 0 ? 1 : kg.rmax;
-    n = 0;
-    worst = __builtin_huge_val();
-    worst_id = 0x7fffffff;
-    for (int R = 0; R <= last_ring; ++R) {
-        for (int da = -R; da <= R; ++da) {
-            const int e0 = c0 + da;
-            int m0 = 0, a0 = e0;
-            if (b.pbc[0]) { m0 = floordiv(e0, g.nc[0]); a0 = e0 - m0 * g.nc[0]; if (m0 > kg.nim[0] || m0 < -kg.nim[0]) continue; }
-            else if (e0 < 0 || e0 >= g.nc[0]) continue;
-            const int ada = da < 0 ? -da : da;
-            for (int db = -R; db <= R; ++db) {
-                const int e1 = c1 + db;
-                int m1 = 0, a1 = e1;
-                if (b.pbc[1]) { m1 = floordiv(e1, g.nc[1]); a1 = e1 - m1 * g.nc[1]; if (m1 > kg.nim[1] || m1 < -kg.nim[1]) continue; }
-                else if (e1 < 0 || e1 >= g.nc[1]) continue;
-                const int adb = db < 0 ? -db : db;
-                const bool shell_ab = (ada == R) || (adb == R);
-                for (int dc = -R; dc <= R; dc += (shell_ab || R == 0) ? 1 : 2 * R) { // interior of the cube was done by earlier rings
-                    const int e2 = c2 + dc;
-                    int m2 = 0, a2 = e2;
-                    if (b.pbc[2]) { m2 = floordiv(e2, g.nc[2]); a2 = e2 - m2 * g.nc[2]; if (m2 > kg.nim[2] || m2 < -kg.nim[2]) continue; }
-                    else if (e2 < 0 || e2 >= g.nc[2]) continue;
-                    // image shift, fast_knn.cpp:822-833
-                    double s0, s1, s2;
-                    if (TRI) {
-                        s0 = m0 * b.h[0] + m1 * b.h[3] + m2 * b.h[6];
-                        s1 = m0 * b.h[1] + m1 * b.h[4] + m2 * b.h[7];
-                        s2 = m0 * b.h[2] + m1 * b.h[5] + m2 * b.h[8];
-                    } else {
-                        s0 = m0 * b.h[0]; s1 = m1 * b.h[4]; s2 = m2 * b.h[8];
-                    }
-                    // An atom stored in cell (a0,a1,a2), seen through the extended cell e = a + m*nc, is the image
-                    // a + m*L.  Its distance to the query is |a - (q - m*L)|: the reference's shifted query with
-                    // shift = m*L (:759-763).
-                    const double w0 = qx - s0, w1 = qy - s1, w2 = qz - s2;
-                    const int64_t cell = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
-                    const int sb = cell_start[cell], se = cell_start[cell + 1];
-                    // candidates of a cell in batches of 8: the 32 loads of a batch are in flight together (one memory latency per
-                    // batch instead of one per candidate — the insertion below is data-dependent control flow, across which
-                    // the compiler does not move the next candidate's loads)
-                    for (int q0 = sb; q0 < se; q0 += 8) {
-                        double cx[8], cy[8], cz[8];
-                        int cj[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int q = min(q0 + u, se - 1);
-                            cx[u] = xs[q]; cy[u] = ys[q]; cz[u] = zs[q]; cj[u] = order[q];
-                        }
-                        // squared distances of the batch and a mask of the candidates that can still matter; then every lane
-                        // inserts ITS next such candidate per round: a wave runs max-over-lanes rounds (1-3 of 8) instead of
-                        // walking all 8 slots with the insertion loop live whenever any lane needs it
-                        double d2s[8];
-                        unsigned todo = 0;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const double dx = cx[u] - w0, dy = cy[u] - w1, dz = cz[u] - w2;
-                            d2s[u] = dx * dx + dy * dy + dz * dz;
-                            const bool live = q0 + u < se && !(cj[u] == i && d2s[u] == 0.0) && !(d2s[u] > bound);
-                            todo |= live ? 1u << u : 0u;
-                        }
-                        while (todo) {
-                            const int u = __builtin_ctz(todo);
-                            todo &= todo - 1;
-                            double d2 = d2s[0];
-                            int j = cj[0];
-#pragma unroll
-                            for (int v = 1; v < 8; ++v)
-                                if (u == v) { d2 = d2s[v]; j = cj[v]; }
-                            if (n == k && !(d2 < worst || (d2 == worst && j < worst_id)))
-                                continue;
-                            int pos = n < k ? n : k - 1;
-                            while (pos > 0) {
-                                const double pd = td[(pos - 1) * bd + t];
-                                const int pi = ti[(pos - 1) * bd + t];
-                                if (!(pd > d2 || (pd == d2 && pi > j)))
-                                    break;
-                                td[pos * bd + t] = pd;
-                                ti[pos * bd + t] = pi;
-                                --pos;
-                            }
-                            td[pos * bd + t] = d2;
-                            ti[pos * bd + t] = j;
-                            if (n < k) ++n;
-                            if (n == k) { worst = td[(k - 1) * bd + t]; worst_id = ti[(k - 1) * bd + t]; }
-                        }
-                    }
+    bool done = false;
+    if (kg.rmax >= 1 && !todo) { // (a query from the to-do list has been through this already)
+        const double bound = one_cell * one_cell;
+        // nearest columns first — the atom's own, the four that share a face with it, the four diagonal ones: candidates then
+        // arrive roughly by increasing distance, so most insertions land near the tail of the sorted list (few entries to
+        // shift) and the k-th distance tightens early (far candidates fail one compare instead of being inserted and pushed out
+        // again).  The result does not depend on the order: the list is sorted by (distance, id).
+        for (int col9 = 0; col9 < 9; ++col9) {
+            const int da = (0x28161 >> (2 * col9) & 3) - 1, db = (0x22215 >> (2 * col9) & 3) - 1; // (0,0) (-1,0) (1,0) (0,-1) (0,1) (-1,-1) (-1,1) (1,-1) (1,1)
+            {
+                int a0, m0, a1, m1;
+                if (!fold_cell(0, c0 + da, a0, m0) || !fold_cell(1, c1 + db, a1, m1)) continue;
+                const int64_t col = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2];
+                for (int e2 = c2 - 1; e2 <= c2 + 1;) {
+                    int a2, m2;
+                    if (!fold_cell(2, e2, a2, m2)) { ++e2; continue; }
+                    int len = 1; // cells of this column with the same image number
+                    while (e2 + len <= c2 + 1 && a2 + len < g.nc[2]) ++len;
+                    double w0, w1, w2;
+                    shifted(m0, m1, m2, w0, w1, w2);
+                    scan_range(cell_start[col + a2], cell_start[col + a2 + len], w0, w1, w2, bound);
+                    e2 += len;
                 }
             }
         }
-        // everything not yet visited lies at Chebyshev cell distance >= R+1, i.e. at least R cell widths away
-        if (n == k) {
-            const double reach = (double)R * kg.wmin * (1.0 - 1e-9);
-            if (worst <= reach * reach)
-                break;
-        }
+        done = n == k; // k candidates within one cell width: the stop test of ring 1 has passed
     }
-    if (attempt == 0 && n == k) // k candidates within one cell width after ring 1: the stop test above has passed
-        break;
+    if (!done) {
+        n = 0;
+        worst = __builtin_huge_val();
+        worst_id = 0x7fffffff;
+        for (int R = 0; R <= kg.rmax; ++R) {
+            for (int da = -R; da <= R; ++da) {
+                int a0, m0;
+                if (!fold_cell(0, c0 + da, a0, m0)) continue;
+                const int ada = da < 0 ? -da : da;
+                for (int db = -R; db <= R; ++db) {
+                    int a1, m1;
+                    if (!fold_cell(1, c1 + db, a1, m1)) continue;
+                    const int adb = db < 0 ? -db : db;
+                    const bool shell_ab = (ada == R) || (adb == R);
+                    for (int dc = -R; dc <= R; dc += (shell_ab || R == 0) ? 1 : 2 * R) { // interior of the cube was done by earlier rings
+                        int a2, m2;
+                        if (!fold_cell(2, c2 + dc, a2, m2)) continue;
+                        double w0, w1, w2;
+                        shifted(m0, m1, m2, w0, w1, w2);
+                        const int64_t cell = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
+                        scan_range(cell_start[cell], cell_start[cell + 1], w0, w1, w2, __builtin_huge_val());
+                    }
+                }
+            }
+            // everything not yet visited lies at Chebyshev cell distance >= R+1, i.e. at least R cell widths away
+            if (n == k) {
+                const double reach = (double)R * kg.wmin * (1.0 - 1e-9);
+                if (worst <= reach * reach)
+                    break;
+            }
+        }
     }
     for (int q = 0; q < n; ++q) {
         indices[(int64_t)i * k + q] = ti[q * bd + t];
@@ -197,6 +340,12 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
 } // namespace mdh
 
 using namespace mdh;
+
+extern "C" int mdh_debug_set_knn_variant(int v)
+{
+    g_knn_variant = v;
+    return MDH_OK;
+}
 
 extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                        const double *origin3, const int *boundary3, int k, int *indices, double *distances, int space,
@@ -269,12 +418,33 @@ extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_
     cg.g.mode = 1;
     MDH_TRY(build_cell_grid(sc, wx, wy, wz, N, bg, false, false, cg));
 
+    // the near kernel (list in registers) where it applies, then the general kernel on what it listed; larger k: the general
+    // kernel for every query
+    int *todo = nullptr;
+    if (k <= 24 && kg.rmax >= 1 && g_knn_variant == 0) {
+        todo = sc.alloc_n<int>((size_t)N + 1);
+        if (sc.failed())
+            return sc.error();
+        MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
+        const dim3 grid(grid_for(N, 256)), block(256);
+#define MDH_KNN_NEAR(K)                                                                                                                   \
+    do {                                                                                                                                  \
+        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo); \
+        else hipLaunchKernelGGL((k_knn_near<false, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo); \
+    } while (0)
+        if (k <= 12) MDH_KNN_NEAR(12);
+        else if (k <= 14) MDH_KNN_NEAR(14);
+        else if (k <= 18) MDH_KNN_NEAR(18);
+        else MDH_KNN_NEAR(24);
+#undef MDH_KNN_NEAR
+    }
     int bd = 256;
     while (bd > 64 && (size_t)bd * k * 12 > 65536) bd -= 64;
     const size_t lds = (size_t)bd * k * 12;
     if (b.tri)
-        hipLaunchKernelGGL(k_knn<true>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd);
+        hipLaunchKernelGGL(k_knn<true>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo);
     else
-        hipLaunchKernelGGL(k_knn<false>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd);
+        hipLaunchKernelGGL(k_knn<false>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo);
+    MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }

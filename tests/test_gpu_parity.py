@@ -334,6 +334,38 @@ def test_knn_general_vs_oracle(case):
         assert np.array_equal(i1, i0)
 
 
+def test_knn_near_kernel_equals_general_kernel():
+    """k <= 24: the near kernel (sorted list in registers, the 27 cells around the query) + the general kernel on what it
+    lists == the general kernel alone (rings until proven, list in LDS), bit for bit, for every list width the templates
+    serve (12 / 14 / 18 / 24 slots), systems where most queries finish near and systems where none does (gas with k above
+    the cell population, tiny boxes with periodic twins, open clusters), and against the brute-force oracle"""
+    from mdapy_amd import _lib
+
+    rng = np.random.default_rng(17)
+    systems = [c for c in CASES if c[0] in ("fcc_rattled", "fcc_unwrapped", "slab_open_z", "cluster_open", "triclinic_random",
+                                            "random_gas", "thin_box_3cells", "dense_blob")]
+    tiny = rng.random((40, 3)) * 7.0
+    systems.append(("tiny_periodic", tiny, np.eye(3) * 7.0, ORG0, PBC))
+    for name, pos, box, org, bnd in systems:
+        x, y, z = _xyz(pos[:2500])
+        n = len(x)
+        for k in (1, 5, 12, 13, 14, 17, 18, 19, 24, 25):
+            out = []
+            for variant in (0, 1):
+                _lib.lib().mdh_debug_set_knn_variant(variant)
+                try:
+                    idx = np.zeros((n, k), np.int32); dist = np.zeros((n, k))
+                    _fast_knn.knn(x, y, z, box, org, bnd, k, idx, dist, 1)
+                finally:
+                    _lib.lib().mdh_debug_set_knn_variant(0)
+                out.append((idx, dist))
+            assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0]), (name, k)
+            if k in (12, 18) and n <= 2500:
+                i0 = np.zeros((n, k), np.int32); q0 = np.zeros((n, k))
+                O.knn(x, y, z, box, org, bnd, k, i0, q0, 4)
+                assert np.array_equal(out[0][1], q0), (name, k)
+
+
 @pytest.mark.parametrize("case", [CASES[0], CASES[5]], ids=[CASES[0][0], CASES[5][0]])
 @pytest.mark.parametrize("mode", ["rc", "nnn"])
 def test_steinhardt_vs_oracle(case, mode):
