@@ -158,17 +158,39 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
         if (!use_voronoi && nnn > 0) // :329-333
             cnt = nnn;
         double wsum = 0.0;
+        // The row is read four entries at a time — ids, distances, weights, then the four neighbours' positions, each group of
+        // loads in flight together — and the entries are then taken in list order as before (same sums, bit for bit).  One
+        // entry per trip meant two dependent memory latencies per neighbour with nothing else to do at 2-3 waves per SIMD:
+        // 80 % of the wave-cycles were spent parked.
+        int cj[4];
+        double cr_[4], cw[4], cx[4], cy[4], cz[4];
         for (int jj = 0; jj < cnt; ++jj) {
-            const int64_t idx = i * M + jj;
-            const int j = NL[idx];
+            const int u = jj & 3;
+            if (u == 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t idx = i * M + min(jj + v, cnt - 1);
+                    cj[v] = NL[idx];
+                    cr_[v] = DL[idx];
+                    cw[v] = use_weight ? weight[idx] : 1.0;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int js = (unsigned)cj[v] < (unsigned)N ? cj[v] : (int)i; // (an index outside the system is skipped below)
+                    cx[v] = x[js]; cy[v] = y[js]; cz[v] = z[js];
+                }
+            }
+            int j = cj[0];
+            double r = cr_[0], w = cw[0], xj = cx[0], yj = cy[0], zj = cz[0];
+#pragma unroll
+            for (int v = 1; v < 4; ++v)
+                if (u == v) { j = cj[v]; r = cr_[v]; w = cw[v]; xj = cx[v]; yj = cy[v]; zj = cz[v]; }
             if ((unsigned)j >= (unsigned)N)
                 continue;
-            double dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1; // :346-350
+            double dx = xj - x1, dy = yj - y1, dz = zj - z1; // :346-350
             pbc<TRI>(b, dx, dy, dz);
-            const double r = DL[idx];
             if (!((r > EPS) && (r <= rc)))
                 continue;
-            const double w = use_weight ? weight[idx] : 1.0;
             wsum += w;
             const double rinv = 1.0 / r;
             const double ct = dz * rinv;
