@@ -76,6 +76,41 @@ __global__ __launch_bounds__(256) void k_aja(const double *__restrict__ x, const
     aja[i] = t;
 }
 
+// one neighbour j of atom i (common_neighbor_parameter.cpp:83-120), rows read entry by entry: the general form
+template <bool TRI>
+__device__ __forceinline__ double cnp_pair_rows(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                int64_t N, const DBox &b, const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                const int *__restrict__ nn, int64_t M, double rc, int64_t i, int j, int ni,
+                                                const int *__restrict__ vi, const double *__restrict__ di, double xi, double yi, double zi)
+{
+    const double xj = x[j], yj = y[j], zj = z[j];
+    double rx = 0, ry = 0, rz = 0;
+    const int nj = nn[j];
+    const int *vj = verlet + (int64_t)j * M;
+    const double *dj = dist + (int64_t)j * M;
+    for (int s = 0; s < nj; ++s) {
+        const int k = safe_id(vj[s], i, N);
+        for (int h = 0; h < ni; ++h)
+            if (k == vi[h]) { // first match only (:83-120)
+                if (dj[s] <= rc && di[h] <= rc) {
+                    const double xk = x[k], yk = y[k], zk = z[k];
+                    double ax = xi - xk, ay = yi - yk, az = zi - zk;
+                    double bx = xj - xk, by = yj - yk, bz = zj - zk;
+                    pbc<TRI>(b, ax, ay, az);
+                    pbc<TRI>(b, bx, by, bz);
+                    rx += ax + bx; ry += ay + by; rz += az + bz;
+                }
+                break;
+            }
+    }
+    return rx * rx + ry * ry + rz * rz;
+}
+
+// Rows of up to 16 entries (every cutoff list of a close-packed or bcc crystal) are handled from registers: the atom's own
+// ids are loaded once and compared with an unrolled chain (the general form re-reads them ni * nj times per neighbour), a
+// neighbour's row arrives as 32 loads in flight, and the positions of the common neighbours of a pair — four of them in
+// fcc — are gathered together instead of one dependent load chain per match.  Same sums in the same order as the general
+// form, which still takes wider rows (per neighbour) — 20.8 -> see DESIGN.md 3 for the measured effect.
 template <bool TRI>
 __global__ __launch_bounds__(128) void k_cnp(const double *__restrict__ x, const double *__restrict__ y,
                                              const double *__restrict__ z, int64_t N, DBox b,
@@ -91,29 +126,76 @@ __global__ __launch_bounds__(128) void k_cnp(const double *__restrict__ x, const
     const double xi = x[i], yi = y[i], zi = z[i];
     int cnt = 0;
     double acc = 0.0;
+    constexpr int W = 16;
+    const bool narrow = ni <= W && ni <= M;
+    int own[W];          // the atom's row (slots beyond ni: a value no id takes)
+    unsigned own_ok = 0; // bit h: di[h] <= rc
+    if (narrow) {
+#pragma unroll
+        for (int h = 0; h < W; ++h) {
+            const int hh = min(h, (int)M - 1);
+            const int v = vi[hh];
+            const double d = di[hh];
+            own[h] = h < ni ? v : -0x7fffffff;
+            own_ok |= (h < ni && d <= rc) ? 1u << h : 0u;
+        }
+    }
     for (int m = 0; m < ni; ++m) {
-        if (!(di[m] <= rc))
+        if (!(narrow ? (own_ok >> m & 1u) != 0 : di[m] <= rc))
             continue;
-        const int j = safe_id(vi[m], i, N);
+        int vim = narrow ? own[0] : vi[m];
+        if (narrow) {
+#pragma unroll
+            for (int h = 1; h < W; ++h)
+                if (m == h) vim = own[h];
+        }
+        const int j = safe_id(vim, i, N);
         ++cnt;
-        const double xj = x[j], yj = y[j], zj = z[j];
-        double rx = 0, ry = 0, rz = 0;
         const int nj = nn[j];
+        if (!narrow || nj > W || nj > M) {
+            acc += cnp_pair_rows<TRI>(x, y, z, N, b, verlet, dist, nn, M, rc, i, j, ni, vi, di, xi, yi, zi);
+            continue;
+        }
+        const double xj = x[j], yj = y[j], zj = z[j];
         const int *vj = verlet + (int64_t)j * M;
         const double *dj = dist + (int64_t)j * M;
-        for (int s = 0; s < nj; ++s) {
-            const int k = safe_id(vj[s], i, N);
-            for (int h = 0; h < ni; ++h)
-                if (k == vi[h]) { // first match only (:83-120)
-                    if (dj[s] <= rc && di[h] <= rc) {
-                        const double xk = x[k], yk = y[k], zk = z[k];
-                        double ax = xi - xk, ay = yi - yk, az = zi - zk;
-                        double bx = xj - xk, by = yj - yk, bz = zj - zk;
-                        pbc<TRI>(b, ax, ay, az);
-                        pbc<TRI>(b, bx, by, bz);
-                        rx += ax + bx; ry += ay + by; rz += az + bz;
-                    }
-                    break;
+        int ks[W];
+        unsigned take = 0; // bit s: entry s of j's row is a common neighbour that counts
+#pragma unroll
+        for (int s = 0; s < W; ++s) { // 32 loads in flight
+            const int ss = min(s, (int)M - 1);
+            ks[s] = safe_id(vj[ss], i, N);
+            const double d = dj[ss];
+            take |= (s < nj && d <= rc) ? 1u << s : 0u;
+        }
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            unsigned hit = 0; // own slots holding this id; the first one decides (:83-120)
+#pragma unroll
+            for (int h = 0; h < W; ++h)
+                hit |= ks[s] == own[h] ? 1u << h : 0u;
+            const bool counts = hit != 0 && (own_ok >> __builtin_ctz(hit | 0x10000u) & 1u) != 0;
+            if (!counts) take &= ~(1u << s);
+        }
+        double rx = 0, ry = 0, rz = 0;
+#pragma unroll
+        for (int half = 0; half < W; half += 8) {
+            if ((take >> half & 0xffu) == 0)
+                continue;
+            double px[8], py[8], pz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { // the positions of this half's common neighbours, requested together
+                const int k = (take >> (half + u) & 1u) ? ks[half + u] : (int)i;
+                px[u] = x[k]; py[u] = y[k]; pz[u] = z[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (take >> (half + u) & 1u) {
+                    double ax = xi - px[u], ay = yi - py[u], az = zi - pz[u];
+                    double bx = xj - px[u], by = yj - py[u], bz = zj - pz[u];
+                    pbc<TRI>(b, ax, ay, az);
+                    pbc<TRI>(b, bx, by, bz);
+                    rx += ax + bx; ry += ay + by; rz += az + bz;
                 }
         }
         acc += rx * rx + ry * ry + rz * rz;
