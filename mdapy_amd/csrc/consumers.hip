@@ -355,31 +355,46 @@ __global__ __launch_bounds__(256) void k_atomic_temp(const int *__restrict__ ver
     const double vxi = vx[i], vyi = vy[i], vzi = vz[i];
     double sx = vxi * mi, sy = vyi * mi, sz = vzi * mi, ms = mi;
     int n = 1;
-    for (int q = 0; q < M; ++q) { // mass-weighted mean velocity of the neighbourhood (:44-62)
-        const int j = vi[q];
-        if ((unsigned)j >= (unsigned)N) // pad (-1) or an index of another system
-            break;
-        if (j != i && di[q] <= rc) {
-            const double mj = mass[j];
-            sx += vx[j] * mj; sy += vy[j] * mj; sz += vz[j] * mj;
-            ++n;
-            ms += mj;
+    // Both sweeps read the row eight entries at a time — ids and distances, then the masses and velocities of the eight
+    // neighbours, each group of loads in flight together — and then take the entries in list order up to the first pad, as
+    // the entry-by-entry loop did (same sums, bit for bit): that loop paid two dependent memory latencies per neighbour.
+    auto sweep = [&](auto &&use) {
+        bool stop = false;
+        for (int q0 = 0; q0 < M && !stop; q0 += 8) {
+            int js[8];
+            double ds[8], mj[8], ux[8], uy[8], uz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int qq = min(q0 + u, (int)M - 1);
+                js[u] = vi[qq];
+                ds[u] = di[qq];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t jj = (unsigned)js[u] < (unsigned)N ? js[u] : i;
+                mj[u] = mass[jj]; ux[u] = vx[jj]; uy[u] = vy[jj]; uz[u] = vz[jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (!stop && q0 + u < M) {
+                    if ((unsigned)js[u] >= (unsigned)N) stop = true; // pad (-1) or an index of another system
+                    else if (js[u] != i && ds[u] <= rc) use(mj[u], ux[u], uy[u], uz[u]);
+                }
         }
-    }
+    };
+    sweep([&](double mj, double ux, double uy, double uz) { // mass-weighted mean velocity of the neighbourhood (:44-62)
+        sx += ux * mj; sy += uy * mj; sz += uz * mj;
+        ++n;
+        ms += mj;
+    });
     const double mx = sx / ms, my = sy / ms, mz = sz / ms;
     double dx = vxi - mx, dy = vyi - my, dz = vzi - mz;
     double ke = 0.0;
     ke += 0.5 * mi * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
-    for (int q = 0; q < M; ++q) { // kinetic energy relative to it (:78-101)
-        const int j = vi[q];
-        if ((unsigned)j >= (unsigned)N) // pad (-1) or an index of another system
-            break;
-        if (j != i && di[q] <= rc) {
-            const double mj = mass[j];
-            dx = vx[j] - mx; dy = vy[j] - my; dz = vz[j] - mz;
-            ke += 0.5 * mj * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
-        }
-    }
+    sweep([&](double mj, double ux, double uy, double uz) { // kinetic energy relative to it (:78-101)
+        dx = ux - mx; dy = uy - my; dz = uz - mz;
+        ke += 0.5 * mj * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
+    });
     T[i] = ke * 2.0 / (dim * n * kb);
 }
 
