@@ -207,20 +207,34 @@ static constexpr int ENT_MAXBINS = 512;
 
 // the per-bin tables of the reference (:27-38: r_j = j*step, r_j^2, r_j^2*factor with entry 0 := entry 1) are single
 // IEEE multiplications, recomputed here with identical results
-__global__ __launch_bounds__(128) void k_entropy(const double *__restrict__ dist, const int *__restrict__ nn, int64_t N,
-                                                 int64_t M, double rc, double sigma, int use_local, double gd, int nbins,
-                                                 double step, double factor, double *__restrict__ entropy)
+// STAGED: the 64 rows of the workgroup are one contiguous piece of the list: loaded with coalesced reads into LDS (entry k
+// of row t at [k * 65 + t]) and read from there nbins times.  Unstaged, every one of the nbins * n loads of a wave touches
+// 64 different cache lines (a lane's row is M * 8 bytes away from its neighbour's).  Rows too wide for LDS: unstaged.
+template <bool STAGED>
+__global__ __launch_bounds__(64) void k_entropy(const double *__restrict__ dist, const int *__restrict__ nn, int64_t N,
+                                                int64_t M, double rc, double sigma, int use_local, double gd, int nbins,
+                                                double step, double factor, double *__restrict__ entropy)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ double ent_rows[];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    if (STAGED) {
+        const int64_t total = (N - row0 < 64 ? N - row0 : 64) * M;
+        for (int64_t e = threadIdx.x; e < total; e += 64) {
+            const int r = (int)(e / M), c = (int)(e - (int64_t)r * M);
+            ent_rows[c * 65 + r] = dist[row0 * M + e];
+        }
+        __syncthreads();
+    }
     if (i >= N)
         return;
     const double PI = 3.14159265358979323846;
     const double s2 = sigma * sigma, lvol = 4. / 3. * PI * rc * rc * rc;
-    const double *di = dist + i * M;
-    const int n = nn[i];
+    const double *di = STAGED ? ent_rows + threadIdx.x : dist + i * M;
+    const int stride = STAGED ? 65 : 1;
+    const int n = STAGED ? min(nn[i], (int)M) : nn[i]; // (a count beyond the row width is the caller's error: the staged form stays inside the row)
     int nin = 0;
     for (int k = 0; k < n; ++k)
-        nin += di[k] <= rc ? 1 : 0;
+        nin += di[k * stride] <= rc ? 1 : 0;
     double density = gd, fac = 1.0;
     if (use_local) {
         density = nin / lvol;
@@ -232,7 +246,7 @@ __global__ __launch_bounds__(128) void k_entropy(const double *__restrict__ dist
         const double r = j * step, r2 = r * r;
         const double p = j == 0 ? (step * step) * factor : r2 * factor;
         for (int k = 0; k < n; ++k) {
-            const double d = di[k];
+            const double d = di[k * stride];
             if (d <= rc) {
                 const double dl = r - d;
                 g += exp(-(dl * dl) / (2.0 * s2)) / p;
@@ -326,8 +340,13 @@ extern "C" int mdh_structure_entropy(double rc, double sigma, int use_local_dens
     if (sc.failed())
         return sc.error();
     ProfRange pr("k_entropy", sc.stream());
-    hipLaunchKernelGGL(k_entropy, dim3(grid_for(N, 128)), dim3(128), 0, sc.stream(), dd, dn, N, M, rc, sigma, use_local_density ? 1 : 0,
-                       gd, nbins, step, factor, de);
+    const size_t lds = (size_t)M * 65 * sizeof(double);
+    if (lds <= 48 * 1024) // (the reference reads nn[i] entries of a row of M: a count beyond M is its caller's error, here as there)
+        hipLaunchKernelGGL(k_entropy<true>, dim3(grid_for(N, 64)), dim3(64), lds, sc.stream(), dd, dn, N, M, rc, sigma, use_local_density ? 1 : 0,
+                           gd, nbins, step, factor, de);
+    else
+        hipLaunchKernelGGL(k_entropy<false>, dim3(grid_for(N, 64)), dim3(64), 0, sc.stream(), dd, dn, N, M, rc, sigma, use_local_density ? 1 : 0,
+                           gd, nbins, step, factor, de);
     return sc.finish(space);
 }
 
