@@ -363,17 +363,42 @@ __global__ __launch_bounds__(256) void k_solid_bonds(int q6index, const double *
     int cnt = nn[i], nsb = 0;
     if (!use_voronoi && nnn > 0)
         cnt = nnn;
-    const double *ar = qlm_r + i * stride + q6index * nz, *ai = qlm_i + i * stride + q6index * nz;
-    for (int jj = 0; jj < cnt; ++jj) {
-        const int j = verlet[i * M + jj];
-        if ((unsigned)j >= (unsigned)N) continue;
-        if (dist[i * M + jj] > rc) continue;
-        const double *br = qlm_r + (int64_t)j * stride + q6index * nz, *bi = qlm_i + (int64_t)j * stride + q6index * nz;
-        double s = 0.0;
-        for (int m = 0; m < 13; ++m)
-            s += ar[m] * br[m] + ai[m] * bi[m];
-        s = s / Q6[i] / Q6[j] * 4 * MY_PI / 13;
-        if (s > threshold) ++nsb;
+    // the atom's own q_6m once, in registers; the row eight entries at a time (ids, distances, the neighbours' Q6 in flight
+    // together); a neighbour's 26 components are then one group of loads.  Entry by entry every neighbour cost three
+    // dependent memory latencies (id -> Q6 / components -> own components re-read).
+    double ar[13], ai[13];
+#pragma unroll
+    for (int m = 0; m < 13; ++m) {
+        ar[m] = qlm_r[i * stride + q6index * nz + m];
+        ai[m] = qlm_i[i * stride + q6index * nz + m];
+    }
+    const double q6i = Q6[i];
+    for (int j0 = 0; j0 < cnt; j0 += 8) {
+        int js[8];
+        double ds[8], qj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t idx = i * M + min(j0 + u, cnt - 1);
+            js[u] = verlet[idx];
+            ds[u] = dist[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            qj[u] = Q6[(unsigned)js[u] < (unsigned)N ? js[u] : (int)i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (j0 + u >= cnt) continue;
+            const int j = js[u];
+            if ((unsigned)j >= (unsigned)N) continue;
+            if (ds[u] > rc) continue;
+            const double *br = qlm_r + (int64_t)j * stride + q6index * nz, *bi = qlm_i + (int64_t)j * stride + q6index * nz;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < 13; ++m)
+                s += ar[m] * br[m] + ai[m] * bi[m];
+            s = s / q6i / qj[u] * 4 * MY_PI / 13;
+            if (s > threshold) ++nsb;
+        }
     }
     if (nsb >= n_bond) solid[i] = 1;
     nbond[i] = nsb;
