@@ -264,13 +264,26 @@ __global__ __launch_bounds__(256) void k_sq_average(int64_t N, const int *__rest
         cnt = nnn;
     double sr = qlm_r[g], si = qlm_i[g];
     int nb = 1;
-    for (int jj = 0; jj < cnt; ++jj) {
-        const int j = NL[i * M + jj];
-        if ((unsigned)j >= (unsigned)N)
-            continue;
-        sr += ar[(int64_t)j * stride + c];
-        si += ai[(int64_t)j * stride + c];
-        ++nb;
+    for (int j0 = 0; j0 < cnt; j0 += 4) { // four entries at a time: ids, then the four neighbours' components, in flight together
+        int js[4];
+        double br[4], bi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            js[u] = NL[i * M + min(j0 + u, cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t jj = (unsigned)js[u] < (unsigned)N ? js[u] : i;
+            br[u] = ar[jj * stride + c];
+            bi[u] = ai[jj * stride + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u >= cnt || (unsigned)js[u] >= (unsigned)N)
+                continue;
+            sr += br[u];
+            si += bi[u];
+            ++nb;
+        }
     }
     const double inv = 1.0 / nb;
     qlm_r[g] = sr * inv;
