@@ -3,7 +3,7 @@
 //
 // Same result, bit for bit, as the thread-per-atom kernel in neighbor.hip and therefore as src/neighbor.cpp:102-187 of
 // the reference (ids, order inside a row, counts, distances).  This is the fast path of mdh_build_neighbor /
-// mdh_neighbor_count for orthogonal boxes.
+// mdh_neighbor_count / mdh_build_neighbor_exact for orthogonal boxes and for triclinic ones periodic along all three vectors.
 //
 // A workgroup owns a tile of TXY x TXY x TZ cells and stages the atoms of the halo ((TXY+2)^2 x (TZ+2) cells, ONE CELL
 // PER THREAD, coalesced loads from the cell-sorted arrays) into LDS once: raw doubles for the values that are written,
@@ -15,12 +15,12 @@
 //
 // Scan (hand-written, scan_run_asm).  A thread walks its 9 runs in the reference's order (neighbor.cpp:147-151), four
 // candidates per trip: four 16-byte LDS reads in flight, then per candidate 3 subtractions, an FMA chain ending in
-// d' = d2 - rc^2, ONE compare whose VCC is shifted into a hit mask by an add-with-carry, and one v_min tracking the
-// smallest |d'| seen.  No per-candidate branch, ticket store or address arithmetic: 9 VALU instructions per candidate,
-// 7 of them register-only single-precision operations (2.7 cycles each on this chip against 4.4 for anything that
-// touches SGPRs / VCC or is double precision; tools/ubench).  |d'_f32 - d'_exact| <= T (host, from the tile extent): a pair
-// with d' < -T is a hit, d' > +T a miss; a thread that saw |d'| <= T redoes ITS masks with the reference's own
-// double-precision expression.  Single precision only prunes: every distance that is WRITTEN is recomputed in double
+// e = d2 - c (c a little below rc^2), v_alignbit shifting e's SIGN into the hit mask, and an unsigned v_min of e's bits that
+// tracks the smallest non-negative e seen.  No per-candidate branch, ticket store, address arithmetic or VCC traffic:
+// 8 VALU instructions per candidate, all register-only single-precision / integer operations (2.7 cycles each on this chip
+// against 4.4 for anything that touches SGPRs / VCC or is double precision; tools/ubench).  |e_f32 - e_exact| <= tol (host,
+// from the tile extent): e < 0 is a hit, e > W a miss; a thread that saw 0 <= e <= W redoes ITS masks with the reference's
+// own double-precision expression.  Single precision only prunes: every distance that is WRITTEN is recomputed in double
 // precision from the raw coordinates exactly as the reference does (raw x[j] - wrapped x[i], minimum image,
 // (dx*dx + dy*dy) + dz*dz, sqrt), so rows are bit-identical.
 //
@@ -28,16 +28,17 @@
 // writes rows cooperatively — MP adjacent lanes write the MP slots of one row, pads included — so a wave store covers whole
 // 64 B / 128 B row segments instead of 64 scattered rows.
 //
-// Tiles whose halo does not fit the LDS budget are listed and taken by a SECOND launch of the same kernel on one-cell
-// slices of those tiles; what is left after that (a dense blob, atoms far outside the box on an open axis, a run of more
-// than 32 atoms) is listed again for the thread-per-atom code (k_neighbor_tiles).  Not taken at all (thread-per-atom
-// kernel / round-1 tiled kernel, same results): triclinic boxes, fewer than 7 cells on a periodic axis or 4 on an open
-// one, unwrapped input (device flag), max_neigh > 64, cells so full that runs exceed 32 atoms.
+// One tile per workgroup, straight-line code (template LOOP = false); the form that walks a list of tiles (LOOP = true)
+// only for the second pass and for what a tile list longer than the host expected leaves over: its loop-carried uniform
+// state costs 140 scalar-register spills.  Tiles whose halo does not fit the LDS budget are listed and taken by a SECOND
+// launch of the same kernel on one-cell slices of those tiles; what is left after that (a dense blob, atoms far outside the
+// box on an open axis, a run of more than 32 atoms) is listed again for the thread-per-atom code (k_neighbor_tiles).  Not
+// taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): open triclinic boxes, fewer than 7 cells on
+// a periodic axis or 4 on an open one, unwrapped input (device flag), max_neigh > 64, cells so full that runs exceed 32 atoms.
 //
-// Measured alternatives (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16): round-1 tiled kernel (thread per
-// centre, double-precision scan, per-hit ticket stores) 1.80 ms; one WAVEFRONT per centre cell with one LANE per candidate
-// (packed-f32 distances, hit masks straight from VCC, v_mbcnt slots, hand-written body) 2.0 ms — fewer LDS reads but
-// ~50 wave-level instructions per centre, most of them scalar bookkeeping; this kernel 1.40 ms.
+// Measured (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16; DESIGN.md 3a has the counters, the per-phase time stamps of the
+// MDH_STAMPS build and the table of variants that were built and not kept): round-1 tiled kernel 1.78 ms, this kernel
+// 1.16 ms.
 #include "common.hpp"
 #include "grid.hpp"
 #include "cna_core.hpp"
