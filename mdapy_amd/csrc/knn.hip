@@ -14,7 +14,10 @@
 // Search structure: a uniform grid over the (wrapped) atoms; each query walks
 // Chebyshev rings of cells around its own cell — image cells beyond the box map
 // to (cell, shift) — and stops once the k-th best distance is no larger than
-// the distance to anything outside the rings visited so far.
+// the distance to anything outside the rings visited so far (k_knn, sorted list
+// in LDS).  For k <= 24 the common case — all k within one cell width, i.e. in
+// the 27 cells around the query — is served first by k_knn_near with the sorted
+// list in registers; the queries it cannot prove go to k_knn through a to-do list.
 #include "common.hpp"
 #include "grid.hpp"
 
