@@ -663,9 +663,9 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
     if (g_neighbor_variant == 0) { // tile kernel (orthogonal boxes, and triclinic ones periodic along all three vectors); the thread-per-atom code below then only mops up what it listed
         GridStats gs;
         MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
-        const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc);
+        const bool cna = pattern && mode != 0;
+        const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc, cna);
         if (lp.txy) {
-            const bool cna = pattern && mode != 0;
             if (cna) tf.cna_todo = todo;
             MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, mode == 0 ? 1 : M, mode == 2, mode == 0, dmax, tf, cna ? pattern : nullptr));
             done = true;

@@ -44,6 +44,7 @@
 #include "cna_core.hpp"
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -56,9 +57,36 @@ static constexpr int MAX_NH = 256;  // halo cells of a tile: one per thread
 static constexpr int CEN_CAP = 512; // centre atoms a tile may hold
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
 static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
-static constexpr long long ROW_MASK = (1ll << 57) - 1;   // id * M of a row (M <= 64, id < 2^31) under its 7-bit count
 
-struct Shape { int txy, tz; };
+// exact n / d for 32-bit n by multiply and shift (Granlund & Montgomery, "Division by invariant integers using
+// multiplication", fig. 4.1): the tile and halo-cell coordinates of a workgroup come from divisions by launch constants, and a
+// division is ~30 instructions in front of a tile's first load
+struct FastDiv {
+    unsigned mul, sh1, sh2, d;
+    __device__ __forceinline__ unsigned div(unsigned n) const
+    {
+        const unsigned t = __umulhi(mul, n);
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+};
+static FastDiv make_fastdiv(unsigned d)
+{
+    FastDiv f{0, 0, 0, d};
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l; // ceil(log2 d)
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+// txy, tz: tile shape in cells; by_nt2, by_nt1: divisions of a tile id by the tile counts along z and y of this launch;
+// mhz, mhxy: ceil(2^16 / (tz + 2)), ceil(2^16 / (txy + 2)) — thread id / HZ as (tid * mhz) >> 16, exact for tid < 512
+struct Shape { int txy, tz; FastDiv by_nt2, by_nt1; unsigned mhz, mhxy; };
+static Shape make_shape(int txy, int tz, int nt1, int nt2)
+{
+    return Shape{txy, tz, make_fastdiv((unsigned)nt2), make_fastdiv((unsigned)nt1), (65536u + (unsigned)tz + 1u) / ((unsigned)tz + 2u),
+                 (65536u + (unsigned)txy + 1u) / ((unsigned)txy + 2u)};
+}
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
 static int g_last_plan[8]; // test hook (mdh_debug_neighbor_plan)
@@ -124,7 +152,7 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
     return dx * dx + dy * dy + dz * dz;
 }
 
-// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v130-v148).  Four candidates per
+// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v100-v118).  Four candidates per
 // trip: four 16-byte LDS reads in flight, then per candidate 3 subtractions, an FMA chain that ends in e = d2 - c (c a little
 // below rc^2), v_alignbit shifting e's SIGN into the hit mask, and an unsigned v_min of e's bits that tracks the smallest
 // NON-NEGATIVE e the lane has seen (negative floats are the large unsigned numbers).  Eight instructions, none of which
@@ -136,14 +164,14 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
 // they are consumed were measured too: what counts is the number of candidate SLOTS a wave walks — 12 for the 10-atom runs
 // of the headline lattice with trips of 4 or 12, 16 with 8 or 16 — not the per-trip overhead)
 #define MDH_CAND(X, Y, Z)                                                                                                            \
-    "v_sub_f32 v146, " X ", %[sx]\n\t"                                                                                               \
-    "v_sub_f32 v147, " Y ", %[sy]\n\t"                                                                                               \
-    "v_sub_f32 v148, " Z ", %[sz]\n\t"                                                                                               \
-    "v_fma_f32 v146, v146, v146, %[negc]\n\t"                                                                                        \
-    "v_fmac_f32 v146, v147, v147\n\t"                                                                                                \
-    "v_fmac_f32 v146, v148, v148\n\t"                                                                                                \
-    "v_alignbit_b32 %[m], %[m], v146, 31\n\t"                                                                                        \
-    "v_min_u32 %[w], %[w], v146\n\t"
+    "v_sub_f32 v116, " X ", %[sx]\n\t"                                                                                               \
+    "v_sub_f32 v117, " Y ", %[sy]\n\t"                                                                                               \
+    "v_sub_f32 v118, " Z ", %[sz]\n\t"                                                                                               \
+    "v_fma_f32 v116, v116, v116, %[negc]\n\t"                                                                                        \
+    "v_fmac_f32 v116, v117, v117\n\t"                                                                                                \
+    "v_fmac_f32 v116, v118, v118\n\t"                                                                                                \
+    "v_alignbit_b32 %[m], %[m], v116, 31\n\t"                                                                                        \
+    "v_min_u32 %[w], %[w], v116\n\t"
 __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, float sy, float sz, float negc, unsigned &mask,
                                              unsigned &w)
 {
@@ -155,23 +183,23 @@ __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, floa
                  "v_cmp_lt_i32 vcc, 0, %[rem]\n\t"
                  "s_and_b64 exec, exec, vcc\n\t"
                  "s_cbranch_execz .Lscan_end_%=\n\t"
-                 "ds_read_b128 v[130:133], %[a]\n\t"
-                 "ds_read_b128 v[134:137], %[a] offset:16\n\t"
-                 "ds_read_b128 v[138:141], %[a] offset:32\n\t"
-                 "ds_read_b128 v[142:145], %[a] offset:48\n\t"
+                 "ds_read_b128 v[100:103], %[a]\n\t"
+                 "ds_read_b128 v[104:107], %[a] offset:16\n\t"
+                 "ds_read_b128 v[108:111], %[a] offset:32\n\t"
+                 "ds_read_b128 v[112:115], %[a] offset:48\n\t"
                  "v_add_u32 %[a], 64, %[a]\n\t"
                  "v_add_u32 %[rem], -4, %[rem]\n\t"
-                 "s_waitcnt lgkmcnt(3)\n\t" MDH_CAND("v130", "v131", "v132")
-                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND("v134", "v135", "v136")
-                 "s_waitcnt lgkmcnt(1)\n\t" MDH_CAND("v138", "v139", "v140")
-                 "s_waitcnt lgkmcnt(0)\n\t" MDH_CAND("v142", "v143", "v144")
+                 "s_waitcnt lgkmcnt(3)\n\t" MDH_CAND("v100", "v101", "v102")
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND("v104", "v105", "v106")
+                 "s_waitcnt lgkmcnt(1)\n\t" MDH_CAND("v108", "v109", "v110")
+                 "s_waitcnt lgkmcnt(0)\n\t" MDH_CAND("v112", "v113", "v114")
                  "s_branch .Lscan_top_%=\n"
                  ".Lscan_end_%=:\n\t"
                  "s_mov_b64 exec, %[save]\n\t"
                  : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)
                  : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [negc] "v"(negc)
-                 : "vcc", "scc", "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140",
-                   "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148");
+                 : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",
+                   "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118");
     mask = m;
 }
 #undef MDH_CAND
@@ -224,19 +252,19 @@ __device__ __forceinline__ unsigned scan_run_f64(const double2 *__restrict__ lxy
     return m;
 }
 
-// fixed-cutoff CNA of one centre (FixedCNA, cna.cpp:429-506) from the tile: its NN tickets are the LDS indices of the listed
-// neighbours in row order, their RAW positions are staged.  plain: no staged atom of this tile carries an image shift, and
+// fixed-cutoff CNA of one centre (FixedCNA, cna.cpp:429-506) from the tile: its NN tickets name the listed neighbours in row
+// order, their RAW positions are staged.  plain: no staged atom of this tile carries an image shift, and
 // two neighbours of one centre are less than 2 rc < L / 2 apart (>= 7 cells per periodic axis): the minimum image of every
 // pair is the plain difference, d - L * 0 == d as the reference computes it.  Tiles at a periodic face classify the spread
 // of the positions as k_fcna does; -1: spread too far (atoms handed in outside the box), the atom goes to the to-do list
-template <bool TRI, int NN>
-__device__ __forceinline__ int lane_fcna(const DBox &b, const unsigned short *__restrict__ my, const double2 *__restrict__ lxy,
+template <bool TRI, int NN, class Index>
+__device__ __forceinline__ int lane_fcna(const DBox &b, Index index_of, const double2 *__restrict__ lxy,
                                          const double *__restrict__ lz, bool plain, double cut2)
 {
     double px[NN], py[NN], pz[NN];
 #pragma unroll
     for (int a = 0; a < NN; ++a) {
-        const int k = my[a];
+        const int k = index_of(a); // LDS index of the a-th listed neighbour
         const double2 c = lxy[k];
         px[a] = c.x; py[a] = c.y; pz[a] = lz[k];
     }
@@ -264,8 +292,11 @@ __device__ __forceinline__ int lane_fcna(const DBox &b, const unsigned short *__
 // list longer than the host expected leaves over); false: one tile per workgroup, straight-line code (measurably faster:
 // 1.15 against 1.23 ms on the headline build — the loop-carried state costs scalar-register spills in every phase)
 // FCNA: the fixed-cutoff CNA label of every centre as well (mdh_build_neighbor_fcna)
-template <bool COUNT, bool TRI, bool LOOP, bool FCNA>
-__global__ __launch_bounds__(NT) void k_neighbor_lane(
+// TK8: one-byte tickets (runs of at most 16 candidate slots) and the kernel held to 128 VGPRs: together with the lean LDS
+// layout (no wrapped-centre table: orthogonal boxes recompute the wrap of a centre where its row is written) a workgroup
+// then needs under 40 KB and FOUR of them share a CU
+template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8>
+__global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
@@ -274,26 +305,31 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
     int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0)
 {
-    if (flags[0] != 0) // unwrapped input: the image codes are not valid, the thread-per-atom kernel takes the whole call
-        return;
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    // Tickets: (run r << JB) | position of the candidate in its run, decoded where a row is written through the run table hr
+    // (cell of the run = centre's cell + roff[r]).  Two bytes, or ONE: five bits of position (a run's mask has 32 slots) and
+    // three of run number — run 8 is the last of the walk, its tickets are the last of the row and the row word counts them.
+    typedef typename std::conditional<TK8, unsigned char, unsigned short>::type Ticket;
+    constexpr int JB = TK8 ? 5 : 8;
+    constexpr bool WCEN = TRI || FCNA; // wrapped centres tabulated by the centre's lane (the triclinic wrap is too long to redo per written slot)
     float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap+8] staged (ux, uy, uz, bits of the atom id)
     double2 *lxy = reinterpret_cast<double2 *>(f4 + cap + 8);       // [cap] staged raw x, y
-    double2 *rxy = lxy + cap;                                       // [NT] this pass's rows: wrapped centre x, y
-    double2 *rzc = rxy + NT;                                        // [NT] wrapped centre z, (first slot of the atom's row = id * M | min(count, M) << 57)
-    double *lz = reinterpret_cast<double *>(rzc + NT);              // [cap] staged raw z
-    unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 16
-    unsigned short *tk = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [NT][M+1] tickets (slot M swallows the hits past M)
-    unsigned short *lsh = tk + (size_t)NT * (M + 1) + (((size_t)NT * (M + 1)) & 1); // [cap] combined image code of a staged atom seen from this tile
+    double2 *rxy = lxy + cap;                                       // WCEN [NT] this pass's rows: wrapped centre x, y
+    double *rz = reinterpret_cast<double *>(rxy + (WCEN ? NT : 0)); // WCEN [NT] wrapped centre z
+    double *lz = rz + (WCEN ? NT : 0);                              // [cap] staged raw z
+    unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 11, later | min(count, M) << 20 | listed hits of run 8 << 27
+    unsigned short *lsh = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [cap] combined image code of a staged atom seen from this tile
+    Ticket *tk = reinterpret_cast<Ticket *>(lsh + cap + (cap & 1)); // [NT][M+1] tickets (slot M swallows the hits past M); wave w owns rows 64 w ...
     const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
-    __shared__ unsigned hc[MAX_NH + 2]; // halo cell: LDS offset | population << 16
+    __shared__ unsigned hc[MAX_NH + 2]; // halo cell: population
     __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
     __shared__ int scan_tmp[4];
     __shared__ int s_flag[3];
+    __shared__ int roff[16]; // halo cell of run r relative to the centre's cell
 
     const double rcsq = rc * rc, pad = rc + 1.0; // neighbor.cpp:127; pads neighbor.py:125-129
     const double cw = rc;                        // cell width of the rc-wide grid (neighbor.cpp:29-62)
@@ -316,7 +352,10 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
             t.id = (t0 * nt1 + t1) * nt2 + t2;
         } else {
             t.id = (list_mode && tile_list) ? tile_list[slot] : slot;
-            t2 = t.id % nt2; t1 = (t.id / nt2) % nt1; t0 = t.id / (nt2 * nt1);
+            const unsigned col = ts.by_nt2.div((unsigned)t.id);
+            t2 = t.id - (int)col * nt2;
+            t0 = (int)ts.by_nt1.div(col);
+            t1 = (int)col - t0 * nt1;
         }
         t.T0 = t0 * TXY; t.T1 = t1 * TXY; t.T2 = t2 * TZ;
         t.empty = t.T2 >= g.nc[2]; // (a slice beyond the grid: the parent tile was a clipped one)
@@ -326,9 +365,9 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
     auto halo_of = [&](const Tile &t) {
         Halo h{0, 0, NEUTRAL, 0, false, false}; // edge: first / last cell of an open axis (atoms outside the box are clamped into it, neighbor.cpp:58-61)
         if (tid < NH && !t.empty) {
-            const int hcol = tid / HZ;
+            const int hcol = (int)(((unsigned)tid * ts.mhz) >> 16); // tid / HZ
             h.hz = tid - hcol * HZ;
-            const int hx = hcol / HXY, hy = hcol - hx * HXY;
+            const int hx = (int)(((unsigned)hcol * ts.mhxy) >> 16), hy = hcol - hx * HXY;
             const int g0 = t.T0 + hx - 1, g1 = t.T1 + hy - 1, g2 = t.T2 + h.hz - 1;
             // a cell beyond an OPEN face is the far side of the box in the reference's modulo walk (neighbor.cpp:18-27); with
             // >= 4 cells on the axis its atoms are >= 2 rc from every centre of this tile: no hits, not staged
@@ -339,7 +378,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 const int a0 = g0 < 0 ? g0 + g.nc[0] : (g0 >= g.nc[0] ? g0 - g.nc[0] : g0);
                 const int a1 = g1 < 0 ? g1 + g.nc[1] : (g1 >= g.nc[1] ? g1 - g.nc[1] : g1);
                 const int a2 = g2 < 0 ? g2 + g.nc[2] : (g2 >= g.nc[2] ? g2 - g.nc[2] : g2);
-                const int64_t c = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2] + a2;
+                const int c = (a0 * g.nc[1] + a1) * g.nc[2] + a2; // (the host refuses grids of 2^31 cells or more)
                 h.src = cell_start[c];
                 h.cnt = cell_start[c + 1] - h.src;
                 // image of the candidate cell seen from an in-grid centre cell: below the box -> raw coordinates are ~+L
@@ -380,10 +419,14 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         int pd[4];
         unsigned char pm[4];
         request(cur, pa, pb, pc, pd, pm);
+        if (flags[0] != 0) // unwrapped input: the image codes are not valid, the thread-per-atom kernel takes the whole call (asked
+            return;        // here, behind the tile's first loads: the flag is two dependent scalar loads away)
         const int tile_id = tile.id, T0 = tile.T0, T1 = tile.T1, T2 = tile.T2;
         const int cnt = cur.cnt, src = cur.src, img = cur.img, hz = cur.hz;
         const bool edge = cur.edge, centre_cell = cur.centre;
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+        if (tid < 9) roff[tid] = ((tid / 3 - 1) * HXY + (tid % 3 - 1)) * HZ; // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
+        hc[tid] = (unsigned)cnt; // the neighbours in z need it for their run (published by the scan's barrier)
 
         int total2;
         const int off2 = excl_scan_block(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
@@ -391,7 +434,13 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         const int off0 = off2 & 0xffff, coff = off2 >> 16;
         bool ok = !(total > cap || ncentres > CEN_CAP); // else: listed for the next pass
         STAMP(2);
-        if (ok && tid < NH) hc[tid] = (unsigned)off0 | ((unsigned)cnt << 16);
+        // the 3-cell run around every cell that can be a column entry of a centre's walk (cells tid-1, tid, tid+1 are adjacent in z
+        // and in LDS)
+        if (ok && tid < NH && hz >= 1 && hz <= HZ - 2) {
+            const unsigned k0 = (unsigned)off0 - hc[tid - 1], len = hc[tid - 1] + (unsigned)cnt + hc[tid + 1];
+            hr[tid] = k0 | (len << 16);
+            if (len > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
+        }
         // ---- stage this cell's atoms
         if (ok && cnt > 0) {
             double X0, Y0, Z0, XS, YS, ZS;
@@ -453,22 +502,14 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                         lxy[p] = make_double2(a[v], bb[v]);
                         lz[p] = c[v];
                         lsh[p] = (unsigned short)code;
-                        if (centre_cell) cen[coff + k + v] = (unsigned)p | ((unsigned)tid << 16);
+                        if (centre_cell) cen[coff + k + v] = (unsigned)p | ((unsigned)tid << 11);
                     }
                 }
             }
             if (general) s_flag[0] = 1;
             if (far) s_flag[1] = 1;
         }
-        __syncthreads(); // publishes hc, the staged atoms, the centre list and the flags
-        // the 3-cell run around every cell that can be a column entry of a centre's walk
-        if (ok && tid < NH && hz >= 1 && hz <= HZ - 2) {
-            const unsigned lo_c = hc[tid - 1], hi_c = hc[tid + 1];
-            const unsigned k0 = lo_c & 0xffffu, k3 = (hi_c & 0xffffu) + (hi_c >> 16);
-            hr[tid] = k0 | ((k3 - k0) << 16);
-            if (k3 - k0 > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
-        }
-        __syncthreads();
+        __syncthreads(); // publishes the run table, the staged atoms, the centre list and the flags
         STAMP(3);
         if (ok && (s_flag[1] | s_flag[2]))
             ok = false;
@@ -478,11 +519,18 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
         }
         const bool general_tile = s_flag[0] != 0;
 
-        for (int base = 0; ok && base < ncentres; base += NT) {
-            const int q = base + tid;
-            if (q < ncentres) {
+        // ---- From here on the four waves do not meet again: a wave takes a contiguous quarter of the tile's centres, scans
+        // them, leaves their tickets in ITS rows of tk and writes those rows itself — LDS traffic inside one wave is ordered,
+        // no workgroup barrier — so one wave's scan overlaps another's write-out.
+        const int wv = tid >> 6;
+        const int per_w = (ncentres + (NT >> 6) - 1) / (NT >> 6);
+        const int wbeg = min(wv * per_w, ncentres), wend = min(wbeg + per_w, ncentres);
+        Ticket *tkw = tk + (size_t)(wv * 64) * (M + 1);
+        for (int cbase = wbeg; ok && cbase < wend; cbase += 64) {
+            const int q = cbase + lane;
+            if (q < wend) {
                 const unsigned cv = cen[q];
-                const int li = (int)(cv & 0xffffu), cb = (int)(cv >> 16);
+                const int li = (int)(cv & 2047u), cb = (int)(cv >> 11);
                 const float4 s = f4[li];
                 unsigned hv[9], mk[9];
 #pragma unroll
@@ -500,11 +548,20 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                     mk[4] &= ~(1u << (S - 1 - (li - (int)(hv[4] & 0xffffu))));
                 }
                 STAMP(4);
-                const double2 ci = lxy[li];
-                double xi = ci.x, yi = ci.y, zi = lz[li];
-                if (b.anypbc) // neighbor.cpp:139-142
-                    wrap<TRI>(b, xi, yi, zi);
+                double xi = 0, yi = 0, zi = 0;
+                if (WCEN) {
+                    const double2 ci = lxy[li];
+                    xi = ci.x; yi = ci.y; zi = lz[li];
+                    if (b.anypbc) // neighbor.cpp:139-142
+                        wrap<TRI>(b, xi, yi, zi);
+                }
                 if (__builtin_expect(w <= __float_as_uint(W), 0)) { // a pair inside the decision band: this centre again in double precision
+                    if (!WCEN) {
+                        const double2 ci = lxy[li];
+                        xi = ci.x; yi = ci.y; zi = lz[li];
+                        if (b.anypbc)
+                            wrap<TRI>(b, xi, yi, zi);
+                    }
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
                         if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
@@ -519,73 +576,143 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                 if (COUNT) {
                     vmax = max(vmax, hits);
                 } else {
-                    // masks -> tickets in walk order: bit (L4-1-j) of a run's mask is its candidate j.  A run rarely holds more
-                    // than a few hits: four predicated steps without a loop, then a loop for what is left
-                    unsigned short *my = tk + (size_t)tid * (M + 1);
+                    // masks -> tickets in walk order: bit (S-1-j) of a run's mask is its candidate j.  Branch-free steps: a step
+                    // of a run that has no hit left writes into the row's spare slot M (v_ffbh of 0 is -1: the slot index
+                    // saturates, the cleared bit is one of an empty mask).  Three steps per run cover nearly every run; a loop
+                    // takes what is left.  (With a branch per step — v_cmp, s_and_saveexec, s_cbranch — the 36 steps of a centre
+                    // were 13 % of a tile's time.)
+                    Ticket *my = tkw + (size_t)lane * (M + 1);
                     int sl = 0;
+                    auto step = [&](unsigned &m, int jb) {
+                        int z;
+                        asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(m)); // leading zeros; -1 for 0
+                        const int none = z >> 31;                      // -1: no hit left in this run
+                        const unsigned slot = min((unsigned)(sl | none), (unsigned)M);
+                        my[slot] = (Ticket)(jb + z);
+                        sl += none + 1;
+                        m &= ~(0x80000000u >> (z & 31));
+                    };
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        const int kend = (int)(hv[r] & 0xffffu) + (run_slots((int)(hv[r] >> 16)) - 32); // + clz(m) = LDS index of the hit
+                        const int jb = (((TK8 ? (r & 7) : r)) << JB) + (run_slots((int)(hv[r] >> 16)) - 32); // + clz(m) = the hit's ticket
                         unsigned m = mk[r];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            if (m) {
-                                const int z = __builtin_clz(m);
-                                my[min(sl, M)] = (unsigned short)(kend + z);
-                                ++sl;
-                                m &= ~(0x80000000u >> z);
-                            }
-                        }
-                        while (m) {
-                            const int z = __builtin_clz(m);
-                            my[min(sl, M)] = (unsigned short)(kend + z);
-                            ++sl;
-                            m &= ~(0x80000000u >> z);
-                        }
+                        step(m, jb);
+                        step(m, jb);
+                        step(m, jb);
+                        while (__builtin_amdgcn_ballot_w64(m != 0)) step(m, jb);
                     }
                     if (FCNA) { // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
+                        auto index_of = [&](int a) { // (FCNA instances have two-byte tickets)
+                            const unsigned t = my[a];
+                            return (int)(hr[cb + roff[t >> JB]] & 0xffffu) + (int)(t & ((1u << JB) - 1u));
+                        };
                         int label = 0;
-                        if (hits == 12 && M >= 12) label = lane_fcna<TRI, 12>(b, my, lxy, lz, !general_tile, rcsq);
-                        else if (hits == 14 && M >= 14) label = lane_fcna<TRI, 14>(b, my, lxy, lz, !general_tile, rcsq);
+                        if (hits == 12 && M >= 12) label = lane_fcna<TRI, 12>(b, index_of, lxy, lz, !general_tile, rcsq);
+                        else if (hits == 14 && M >= 14) label = lane_fcna<TRI, 14>(b, index_of, lxy, lz, !general_tile, rcsq);
                         if (label > 0) pattern[id] = label;
                         else if (label < 0) defer(cna_todo, id);
                     }
-                    rxy[tid] = make_double2(xi, yi);
-                    rzc[tid] = make_double2(zi, __longlong_as_double((long long)(((unsigned long long)(unsigned)(hits < M ? hits : M) << 57) | (unsigned long long)((int64_t)id * M))));
+                    {   // listed hits, and how many of them belong to run 8 (the last ones of the row)
+                        const int kept = hits < M ? hits : M, n8 = __builtin_popcount(mk[8]);
+                        const int kept8 = max(0, min(n8, kept - (hits - n8)));
+                        cen[q] = cv | ((unsigned)kept << 20) | ((unsigned)kept8 << 27);
+                    }
+                    if (WCEN) {
+                        rxy[tid] = make_double2(xi, yi);
+                        rz[tid] = zi;
+                    }
                 }
             }
             if (!COUNT) {
-                __syncthreads();
+                // the rows of this wave: written by the lanes of this wave, read below by other lanes of it.  The LDS unit serves
+                // one wave's instructions in order; the fence only keeps the compiler from moving accesses across it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 STAMP(5);
                 // ---- tickets -> rows: MP adjacent lanes serve the slots of one centre
-                const int nrows = min(NT, ncentres - base);
+                const int nrows = min(64, wend - cbase);
                 const int MP = 1 << mp_shift; // smallest power of two >= M
-                const int e = tid & (MP - 1);
+                const int e = lane & (MP - 1);
                 if (e < M) {
-                    const int step = NT >> mp_shift;
-                    for (int c0 = tid >> mp_shift; c0 < nrows; c0 += 2 * step) {
-                        // two rows per trip: their LDS reads are issued together, one wait serves both
-                        const int c1 = c0 + step;
-                        const bool two = c1 < nrows;
-                        const int ca = c0, cb2 = two ? c1 : c0;
-                        const double2 za = rzc[ca], zb = rzc[cb2];
-                        const long long ia = __double_as_longlong(za.y), ib = __double_as_longlong(zb.y);
-                        const bool ha = e < (int)((unsigned long long)ia >> 57), hb = e < (int)((unsigned long long)ib >> 57);
-                        const int ka = tk[ca * (M + 1) + (ha ? e : 0)], kb = tk[cb2 * (M + 1) + (hb ? e : 0)]; // (slot 0 of a row with no hit: any staged index, unused)
-                        const int kka = ha ? ka : 0, kkb = hb ? kb : 0;
-                        const double2 ja = lxy[kka], jb = lxy[kkb], wa = rxy[ca], wb = rxy[cb2];
+                    const int step = 64 >> mp_shift;
+                    const unsigned tself = 4u << JB; // first slot of the centre's own run: a valid ticket for lanes without a hit
+                    // Two rows per trip, and a three-deep pipeline over the trips: while the distances of trip i are worked out,
+                    // the run-table entries of trip i+1 and the row words and tickets of trip i+2 are on their way — every LDS
+                    // read of a trip's body is independent of the others, so a trip pays one LDS round trip instead of four
+                    // dependent ones.  Reads past the last row are clamped to it (never stored).
+                    auto words = [&](int c, unsigned &info, unsigned &t) { // row word and this lane's ticket of row c
+                        c = min(c, nrows - 1);
+                        info = cen[cbase + c];
+                        t = tkw[c * (M + 1) + e]; // (e < M: inside the row; slots past the hits hold leftovers)
+                    };
+                    auto settle = [&](unsigned info, unsigned &t) { // the ticket with its run number in place; a valid one for a slot without a hit
+                        const int kept = (int)((info >> 20) & 127u);
+                        if (TK8 && e >= kept - (int)(info >> 27)) t = (t & 31u) | (8u << JB);
+                        t = e < kept ? t : tself;
+                    };
+                    // cell of run r relative to the centre's: ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ, neighbor.cpp:147-151
+                    const int A2 = HXY * HZ;
+                    auto cell_of = [&](unsigned info, unsigned t) {
+                        const int r = (int)(t >> JB), r3 = (r * 11) >> 5;
+                        return (int)((info >> 11) & 511u) + __mul24(r3, A2 - 3 * HZ) + __mul24(r, HZ) - (A2 + HZ);
+                    };
+                    int c0 = lane >> mp_shift;
+                    unsigned ia, ib, ta, tb, na, nb, nta, ntb; // this trip's and the next trip's words
+                    words(c0, ia, ta); words(c0 + step, ib, tb);
+                    words(c0 + 2 * step, na, nta); words(c0 + 3 * step, nb, ntb);
+                    settle(ia, ta); settle(ib, tb);
+                    unsigned ra_ = hr[cell_of(ia, ta)], rb_ = hr[cell_of(ib, tb)];
+                    for (; c0 < nrows; c0 += 2 * step) {
+                        const bool two = c0 + step < nrows;
+                        const bool ha = e < (int)((ia >> 20) & 127u), hb = e < (int)((ib >> 20) & 127u);
+                        const int lia = (int)(ia & 2047u), lib = (int)(ib & 2047u);
+                        const int kka = (int)(ra_ & 0xffffu) + (int)(ta & ((1u << JB) - 1u));
+                        const int kkb = (int)(rb_ & 0xffffu) + (int)(tb & ((1u << JB) - 1u));
+                        const double2 ja = lxy[kka], jb2 = lxy[kkb];
                         const double jza = lz[kka], jzb = lz[kkb];
                         const int ida = __float_as_int(f4[kka].w), idb = __float_as_int(f4[kkb].w);
+                        const unsigned rowa = __float_as_uint(f4[lia].w), rowb = __float_as_uint(f4[lib].w);
+                        double2 wa, wb;
+                        double wza, wzb;
+                        if (WCEN) {
+                            wa = rxy[wv * 64 + c0]; wb = rxy[wv * 64 + (two ? c0 + step : c0)];
+                            wza = rz[wv * 64 + c0]; wzb = rz[wv * 64 + (two ? c0 + step : c0)];
+                        } else {
+                            wa = lxy[lia]; wb = lxy[lib];
+                            wza = lz[lia]; wzb = lz[lib];
+                        }
+                        // trip i+1: run-table entries; trip i+2: row words and tickets
+                        settle(na, nta); settle(nb, ntb);
+                        const unsigned nra = hr[cell_of(na, nta)], nrb = hr[cell_of(nb, ntb)];
+                        unsigned fa, fb, fta, ftb;
+                        words(c0 + 4 * step, fa, fta); words(c0 + 5 * step, fb, ftb);
+                        if (!WCEN && b.anypbc) { // the wrapped centre (neighbor.cpp:139-142), once per written slot
+                            if (general_tile) { // an atom may have been handed in outside the box: the whole expression
+                                wrap<false>(b, wa.x, wa.y, wza);
+                                wrap<false>(b, wb.x, wb.y, wzb);
+                            } else { // every staged atom lies inside the box: floor((x - o) / L) = 0, the wrap is o + (x - o) - L * 0 (box.h:158-176)
+                                if (b.pbc[0] && b.pbc[1] && b.pbc[2]) { // (one uniform branch instead of six selects)
+                                    wa.x = b.o[0] + (wa.x - b.o[0]); wb.x = b.o[0] + (wb.x - b.o[0]);
+                                    wa.y = b.o[1] + (wa.y - b.o[1]); wb.y = b.o[1] + (wb.y - b.o[1]);
+                                    wza = b.o[2] + (wza - b.o[2]); wzb = b.o[2] + (wzb - b.o[2]);
+                                } else {
+                                    if (b.pbc[0]) { wa.x = b.o[0] + (wa.x - b.o[0]); wb.x = b.o[0] + (wb.x - b.o[0]); }
+                                    if (b.pbc[1]) { wa.y = b.o[1] + (wa.y - b.o[1]); wb.y = b.o[1] + (wb.y - b.o[1]); }
+                                    if (b.pbc[2]) { wza = b.o[2] + (wza - b.o[2]); wzb = b.o[2] + (wzb - b.o[2]); }
+                                }
+                            }
+                        }
                         double d2a, d2b;
                         if (TRI) {
-                            d2a = exact_d2<2>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
-                            d2b = exact_d2<2>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
+                            d2a = exact_d2<2>(b, ja.x, ja.y, jza, wa.x, wa.y, wza, 0);
+                            d2b = exact_d2<2>(b, jb2.x, jb2.y, jzb, wb.x, wb.y, wzb, 0);
                         } else if (general_tile) {
-                            d2a = exact_d2<1>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, lsh[kka]);
-                            d2b = exact_d2<1>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, lsh[kkb]);
+                            d2a = exact_d2<1>(b, ja.x, ja.y, jza, wa.x, wa.y, wza, lsh[kka]);
+                            d2b = exact_d2<1>(b, jb2.x, jb2.y, jzb, wb.x, wb.y, wzb, lsh[kkb]);
                         } else {
-                            d2a = exact_d2<0>(b, ja.x, ja.y, jza, wa.x, wa.y, za.x, 0);
-                            d2b = exact_d2<0>(b, jb.x, jb.y, jzb, wb.x, wb.y, zb.x, 0);
+                            d2a = exact_d2<0>(b, ja.x, ja.y, jza, wa.x, wa.y, wza, 0);
+                            d2b = exact_d2<0>(b, jb2.x, jb2.y, jzb, wb.x, wb.y, wzb, 0);
                         }
                         // neighbor.cpp:174; pads neighbor.py:125-129.  Both roots for every lane (a lane without a hit holds the
                         // distance to some staged atom), then a select: straight-line code whose two chains interleave
@@ -599,7 +726,7 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                         }
                         ra = ha ? ra : pad;
                         rb = hb ? rb : pad;
-                        const int64_t oa = (ia & ROW_MASK) + e, ob = (ib & ROW_MASK) + e; // the row's first slot was worked out once, by the centre's lane
+                        const uint64_t oa = (uint64_t)rowa * (unsigned)M + (unsigned)e, ob = (uint64_t)rowb * (unsigned)M + (unsigned)e;
                         if (ha || write_pads) {
                             __builtin_nontemporal_store(ha ? ida : -1, &verlet[oa]); // rows are written once and not read back here
                             __builtin_nontemporal_store(ra, &dist[oa]);
@@ -608,10 +735,13 @@ __global__ __launch_bounds__(NT) void k_neighbor_lane(
                             __builtin_nontemporal_store(hb ? idb : -1, &verlet[ob]);
                             __builtin_nontemporal_store(rb, &dist[ob]);
                         }
+                        ia = na; ib = nb; ta = nta; tb = ntb; ra_ = nra; rb_ = nrb;
+                        na = fa; nb = fb; nta = fta; ntb = ftb;
                     }
                 }
                 STAMP(6);
-                lds_barrier(); // the row stores stay in flight
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 STAMP(7);
             }
         }
@@ -751,11 +881,12 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
 
 namespace lane {
 
-static size_t lds_bytes(int cap, int64_t M)
+// wcen: the wrapped-centre table (triclinic boxes, the fused CNA instance); tk8: one-byte tickets
+static size_t lds_bytes(int cap, int64_t M, bool wcen, bool tk8)
 {
-    size_t tk = (size_t)NT * (size_t)(M + 1);
-    tk += tk & 1;
-    return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (size_t)NT * 32 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + tk * 2 + (size_t)cap * 2;
+    const size_t tk = (size_t)NT * (size_t)(M + 1) * (tk8 ? 1 : 2);
+    return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (wcen ? (size_t)NT * 24 : 0) + (size_t)cap * 8 + (size_t)CEN_CAP * 4 +
+           (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }
 
 } // namespace lane
@@ -770,7 +901,7 @@ static int lane_refusal(const DBox &b, const Grid &g, int64_t M)
     return 0;
 }
 
-LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc)
+LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc, bool fcna)
 {
     using namespace lane;
     LanePlan p{};
@@ -785,22 +916,30 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
-    // LDS budget: three workgroups per CU if the tile that allows is not much worse than what two would get
+    static const int wgs_env = [] { const char *e = std::getenv("MDH_LANE_WGS"); return e ? std::atoi(e) : 0; }(); // A/B: workgroups per CU the LDS is cut for
+    // one-byte tickets, the lean LDS layout and the 128-VGPR instance: orthogonal boxes without the fused CNA
+    const bool wcen = b.tri || fcna;
+    static const int tk8_env = [] { const char *e = std::getenv("MDH_LANE_TK8"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = two-byte tickets always
+    const bool tk8 = tk8_env && !wcen;
+    // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, if the tile that allows is not much worse
+    // than what fewer would get
     Shape best{0, 0};
-    int best_cap = 0;
+    int best_cap = 0, best_wgs = 0;
     double best_score = -1.0;
-    for (int wgs = 3; wgs >= 2; --wgs) {
+    for (int wgs = tk8 ? 4 : 3; wgs >= 2; --wgs) {
+        if (wgs_env > 0 && wgs != std::min(wgs_env, tk8 ? 4 : 3))
+            continue;
         const long budget = 160 * 1024 / wgs - 3700; // static tables + allocation granularity (52.9 KB per workgroup still gives three per CU, 54.3 KB does not)
-        long fixed = (long)lds_bytes(0, M);
+        long fixed = (long)lds_bytes(0, M, wcen, tk8);
         int cap = (int)((budget - fixed) / 42) & ~7;
         if (cap_env > 0) cap = cap_env;
         if (cap < 64)
             continue;
-        cap = std::min(cap, 16384);
+        cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
         for (int txy = 1; txy <= 8; ++txy)
             for (int tz = 1; tz <= 24; ++tz) {
                 const int nh = (txy + 2) * (txy + 2) * (tz + 2);
-                if (nh > MAX_NH || nh * pop > 0.86 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
+                if (nh > MAX_NH || nh * pop > 0.875 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
                     continue;
                 const int ncc = txy * txy * tz;
                 const double c = ncc * pop;                                 // centre atoms per tile
@@ -809,8 +948,8 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
                     continue;
                 const double util = c / (passes * NT);                     // lane utilisation of the scan
                 const double reuse = (double)ncc / (double)nh;             // centre cells per staged cell
-                const double score = util * (0.35 + reuse) * (wgs == 3 ? 1.0 : 0.85);
-                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; }
+                const double score = util * (0.35 + reuse) * (wgs == 4 ? 1.1 : (wgs == 3 ? 1.0 : 0.85));
+                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; best_wgs = wgs; }
             }
         if (cap_env > 0)
             break;
@@ -851,10 +990,12 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.txy = best.txy;
     p.tz = best.tz;
     p.cap = best_cap;
+    p.tk8 = tk8;
+    p.wgs = best_wgs;
     p.occupied = occ;
     p.full = occ >= g.ncell;
-    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M);
-    g_last_plan[4] = p.full; g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
+    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, wcen, tk8);
+    g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
 
@@ -864,13 +1005,13 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
                          TileFilter &tf, int *pattern)
 {
     using namespace lane;
-    const Shape ts{plan.txy, plan.tz};
     int nt[3];
     for (int d = 0; d < 3; ++d) {
-        const int T = d == 2 ? ts.tz : ts.txy;
+        const int T = d == 2 ? plan.tz : plan.txy;
         nt[d] = (cg.g.nc[d] + T - 1) / T;
     }
     const int64_t ntiles = (int64_t)nt[0] * nt[1] * nt[2];
+    const Shape ts = make_shape(plan.txy, plan.tz, nt[1], nt[2]);
     const int nsub = ts.tz; // second pass: one-cell slices along z
     unsigned *live = sc.alloc_n<unsigned>((size_t)ntiles);
     int *slot = sc.alloc_n<int>((size_t)ntiles + 1);
@@ -894,37 +1035,38 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         list_mode = 1;
     }
     const dim3 grid((unsigned)(per * 8));
-    const size_t lds = lds_bytes(plan.cap, count ? 1 : M);
+    const bool wcen = b.tri || pattern != nullptr;
+    const size_t lds = lds_bytes(plan.cap, count ? 1 : M, wcen, plan.tk8);
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
     const float negc = -plan.mid;
-    const Shape ts2{ts.txy, 1};
     const int nt2b = nt[2] * nsub;
-#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, GRID, JT0, ...)                                                                                  \
+    const Shape ts2 = make_shape(ts.txy, 1, nt[1], nt2b);
+#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, TK8, GRID, JT0, ...)                                                                             \
     do {                                                                                                                                  \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
                            cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
     // otherwise); second pass: one-cell slices of what the first listed
-#define MDH_LANE_LAUNCH(COUNT, TRI, FCNA)                                                                                                 \
+#define MDH_LANE_LAUNCH(COUNT, TRI, FCNA, TK8)                                                                                            \
     do {                                                                                                                                  \
         if (list_mode) {                                                                                                                  \
-            MDH_LANE_PASS(COUNT, TRI, false, FCNA, grid, 0, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
             if ((int64_t)per * 8 < ntiles)                                                                                                \
-                MDH_LANE_PASS(COUNT, TRI, true, FCNA, dim3(512), per, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+                MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(512), per, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
         } else {                                                                                                                          \
-            MDH_LANE_PASS(COUNT, TRI, false, FCNA, grid, 0, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
         }                                                                                                                                 \
-        MDH_LANE_PASS(COUNT, TRI, true, FCNA, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
+        MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
-    if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false); else MDH_LANE_LAUNCH(true, false, false); }
-    else if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true); else MDH_LANE_LAUNCH(false, false, true); }
-    else { if (b.tri) MDH_LANE_LAUNCH(false, true, false); else MDH_LANE_LAUNCH(false, false, false); }
+    if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, false); else if (plan.tk8) MDH_LANE_LAUNCH(true, false, false, true); else MDH_LANE_LAUNCH(true, false, false, false); }
+    else if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true, false); else MDH_LANE_LAUNCH(false, false, true, false); }
+    else { if (b.tri) MDH_LANE_LAUNCH(false, true, false, false); else if (plan.tk8) MDH_LANE_LAUNCH(false, false, false, true); else MDH_LANE_LAUNCH(false, false, false, false); }
 #undef MDH_LANE_PASS
 #undef MDH_LANE_LAUNCH
     MDH_HIP(hipGetLastError());

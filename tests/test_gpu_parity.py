@@ -225,7 +225,7 @@ def test_neighbor_live_tile_list_longer_than_expected():
         vb = np.empty((n, M), np.int32); db = np.empty((n, M)); nb = np.empty(n, np.int32)
         _neighbor.build_neighbor(x, y, z, box, ORG0, bnd, rc, vb, db, nb, 1, fill_pads=True)
         _lib.lib().mdh_debug_neighbor_plan(plan.ctypes.data)
-        assert plan[0] > 0 and plan[4] == 0, plan  # the tile kernel ran, on a list of live tiles (vacuum around the atoms)
+        assert plan[0] > 0 and (plan[4] & 1) == 0, plan  # the tile kernel ran, on a list of live tiles (vacuum around the atoms)
         assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da), k
 
 

@@ -38,7 +38,7 @@ torch.cuda.synchronize()
 L.mdh_prof_enable(0)
 L.mdh_debug_neighbor_plan(plan)
 buf = ctypes.create_string_buffer(1 << 16); L.mdh_prof_report(buf, len(buf))
-print("plan txy,tz,cap,lds,full,pop*1000,occ,fresh:", list(plan))
+print("plan txy,tz,cap,lds,full|tk8<<1|wgs<<2,pop*1000,occ,fresh:", list(plan))
 print(buf.value.decode().strip(), "N", n, "env", {k: v for k, v in os.environ.items() if k.startswith("MDH_")}, flush=True)
 
 if hasattr(L, "mdh_debug_lane_stamps"):  # experiment builds only (-DMDH_STAMPS): phase stamps of the first 51200 tiles
