@@ -62,14 +62,14 @@ struct GridStats {
 struct LanePlan {
     int txy, tz;      // tile shape in cells; txy == 0: not applicable
     int cap;          // atoms a tile's halo may hold in LDS
-    bool tk8;         // one-byte tickets + the 128-VGPR instance (orthogonal boxes, runs of at most 16 slots)
+    bool tk8;         // rows of at most 16 slots: one-byte tickets, lean LDS layout, rows written by the centre's lane
     int wgs;          // workgroups per CU the LDS budget was cut for
     float mid, T;     // single-precision scan: the constant c subtracted from d2 (a little below rc^2) and the width W of the band above it
     bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live
     int64_t occupied; // cells of the occupied region (last known)
 };
 int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out);
-LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc, bool fcna);
+LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc, bool fcna, bool count);
 // pattern != nullptr: the fixed-cutoff CNA label (cna.cpp:429-506, same rc) of every centre the kernel takes is written too
 int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,

@@ -664,7 +664,7 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
         GridStats gs;
         MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
         const bool cna = pattern && mode != 0;
-        const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc, cna);
+        const LanePlan lp = plan_lane(b, cg.g, N, mode == 0 ? 1 : M, gs, rc, cna, mode == 0);
         if (lp.txy) {
             if (cna) tf.cna_todo = todo;
             MDH_TRY(launch_neighbor_lane(sc, cg, lp, N, b, rc, dv, dd, dn, mode == 0 ? 1 : M, mode == 2, mode == 0, dmax, tf, cna ? pattern : nullptr));

@@ -54,7 +54,7 @@ namespace lane {
 
 static constexpr int NT = 256;      // threads per workgroup
 static constexpr int MAX_NH = 256;  // halo cells of a tile: one per thread
-static constexpr int CEN_CAP = 512; // centre atoms a tile may hold
+static constexpr int CEN_CAP = 384; // centre atoms a tile may hold
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
 static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
 
@@ -88,6 +88,7 @@ static Shape make_shape(int txy, int tz, int nt1, int nt2)
                  (65536u + (unsigned)txy + 1u) / ((unsigned)txy + 2u)};
 }
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef int Int4 __attribute__((ext_vector_type(4))); // 16 bytes of a row (nontemporal vector stores take clang vector types)
 
 static int g_last_plan[8]; // test hook (mdh_debug_neighbor_plan)
 #ifdef MDH_STAMPS
@@ -280,6 +281,37 @@ __device__ __forceinline__ int lane_fcna(const DBox &b, Index index_of, const do
     return fcna_label<NN>(R);
 }
 
+// 4 x 4 transpose of 16-byte pieces among the four lanes of a quad: lane u's piece v <-> lane v's piece u.  Two butterfly
+// stages (partner lane u^1, then u^2), each a bitwise select (v_bfi_b32 with a lane-parity mask in a VGPR), one quad_perm DPP
+// move and two selects per dword: 64 register-only instructions.  odd1 / odd2: all ones in lanes with bit 0 / bit 1 set.
+__device__ __forceinline__ int bit_select(int m, int a, int b) // (a & m) | (b & ~m): one register-only instruction
+{
+    int d; // (spelled out: from the C expression the compiler derives v_cndmask with an SGPR-pair mask, ~23 cycles apiece here)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd2)
+{
+#pragma unroll
+    for (int pp = 0; pp < 4; pp += 2)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int x = bit_select(odd1, P[pp][w], P[pp + 1][w]);            // odd lanes hand over piece pp, even lanes piece pp+1
+            const int y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+            P[pp + 1][w] = bit_select(odd1, P[pp + 1][w], y);
+            P[pp][w] = bit_select(odd1, y, P[pp][w]);
+        }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int x = bit_select(odd2, P[pp][w], P[pp + 2][w]);
+            const int y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+            P[pp + 2][w] = bit_select(odd2, P[pp + 2][w], y);
+            P[pp][w] = bit_select(odd2, y, P[pp][w]);
+        }
+}
+
 // COUNT: nn and the largest count only (first pass of the exact-width variant)
 // parent != nullptr: second pass over the tiles the first pass listed (halo over the LDS budget): the same tiling cut into
 // nsub slices along z (this launch's TZ = parent's TZ / nsub); what still does not fit goes to `flagged` (counter
@@ -292,11 +324,11 @@ __device__ __forceinline__ int lane_fcna(const DBox &b, Index index_of, const do
 // list longer than the host expected leaves over); false: one tile per workgroup, straight-line code (measurably faster:
 // 1.15 against 1.23 ms on the headline build — the loop-carried state costs scalar-register spills in every phase)
 // FCNA: the fixed-cutoff CNA label of every centre as well (mdh_build_neighbor_fcna)
-// TK8: one-byte tickets (runs of at most 16 candidate slots) and the kernel held to 128 VGPRs: together with the lean LDS
-// layout (no wrapped-centre table: orthogonal boxes recompute the wrap of a centre where its row is written) a workgroup
-// then needs under 40 KB and FOUR of them share a CU
+// TK8 (rows of at most 16 slots): one-byte tickets, no row-word / wrapped-centre tables, rows written by the centre's own lane,
+// and (without the fused CNA) the kernel held to 128 VGPRs: a workgroup then needs under 40 KB of LDS and FOUR share a CU.
+// false: two-byte tickets and the slot-per-lane write-out (rows of up to 64 slots)
 template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8>
-__global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
+__global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
@@ -310,12 +342,13 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    // Tickets: (run r << JB) | position of the candidate in its run, decoded where a row is written through the run table hr
-    // (cell of the run = centre's cell + roff[r]).  Two bytes, or ONE: five bits of position (a run's mask has 32 slots) and
-    // three of run number — run 8 is the last of the walk, its tickets are the last of the row and the row word counts them.
+    // Tickets: (run r << JB) | position of the candidate in its run, decoded where a row is written through the run table hr.
+    // Two bytes, or ONE (TK8): five bits of position (a run's mask has 32 slots) and three of run number — run 8 is the last of
+    // the walk, so its tickets are the last of the row and a count of them says which they are.
     typedef typename std::conditional<TK8, unsigned char, unsigned short>::type Ticket;
     constexpr int JB = TK8 ? 5 : 8;
-    constexpr bool WCEN = TRI || FCNA; // wrapped centres tabulated by the centre's lane (the triclinic wrap is too long to redo per written slot)
+    constexpr bool ROWREG = TK8 && !COUNT;         // M <= 16: a centre's lane keeps its row in registers and writes it itself
+    constexpr bool WCEN = !TK8 && (TRI || FCNA);   // slot-per-lane write-out: wrapped centres tabulated by the centre's lane (the triclinic wrap is too long to redo per written slot)
     float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap+8] staged (ux, uy, uz, bits of the atom id)
     double2 *lxy = reinterpret_cast<double2 *>(f4 + cap + 8);       // [cap] staged raw x, y
     double2 *rxy = lxy + cap;                                       // WCEN [NT] this pass's rows: wrapped centre x, y
@@ -323,7 +356,7 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
     double *lz = rz + (WCEN ? NT : 0);                              // [cap] staged raw z
     unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 11, later | min(count, M) << 20 | listed hits of run 8 << 27
     unsigned short *lsh = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [cap] combined image code of a staged atom seen from this tile
-    Ticket *tk = reinterpret_cast<Ticket *>(lsh + cap + (cap & 1)); // [NT][M+1] tickets (slot M swallows the hits past M); wave w owns rows 64 w ...
+    Ticket *tk = reinterpret_cast<Ticket *>(lsh + cap + (cap & 1)); // [NT][TKS] tickets (slot M swallows the hits past M); wave w owns rows 64 w ...
     const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
     __shared__ unsigned hc[MAX_NH + 2]; // halo cell: population
     __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
@@ -518,19 +551,29 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
             flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
         }
         const bool general_tile = s_flag[0] != 0;
-
         // ---- From here on the four waves do not meet again: a wave takes a contiguous quarter of the tile's centres, scans
-        // them, leaves their tickets in ITS rows of tk and writes those rows itself — LDS traffic inside one wave is ordered,
+        // them, leaves their tickets in ITS rows of tk and writes their rows itself — LDS traffic inside one wave is ordered,
         // no workgroup barrier — so one wave's scan overlaps another's write-out.
         const int wv = tid >> 6;
         const int per_w = (ncentres + (NT >> 6) - 1) / (NT >> 6);
         const int wbeg = min(wv * per_w, ncentres), wend = min(wbeg + per_w, ncentres);
-        Ticket *tkw = tk + (size_t)(wv * 64) * (M + 1);
+        const int TKS = TK8 ? ((M + 4) & ~3) : (M + 1); // tickets of a row (one-byte rows are read back as whole words)
+        Ticket *tkw = tk + (size_t)(wv * 64) * TKS;
+        const int A2 = HXY * HZ;
+        // halo cell of run r relative to the centre's cell: ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ, neighbor.cpp:147-151
+        auto run_cell = [&](int cbv, int r) {
+            const int r3 = (r * 11) >> 5;
+            return cbv + __mul24(r3, A2 - 3 * HZ) + __mul24(r, HZ) - (A2 + HZ);
+        };
         for (int cbase = wbeg; ok && cbase < wend; cbase += 64) {
             const int q = cbase + lane;
+            int kept = 0, kept8 = 0, cb = 0, id = 0; // (lanes without a centre: no row)
+            double xi = 0, yi = 0, zi = 0;
+            Ticket *my = tkw + (size_t)lane * TKS;
             if (q < wend) {
                 const unsigned cv = cen[q];
-                const int li = (int)(cv & 2047u), cb = (int)(cv >> 11);
+                const int li = (int)(cv & 2047u);
+                cb = (int)(cv >> 11);
                 const float4 s = f4[li];
                 unsigned hv[9], mk[9];
 #pragma unroll
@@ -548,20 +591,13 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
                     mk[4] &= ~(1u << (S - 1 - (li - (int)(hv[4] & 0xffffu))));
                 }
                 STAMP(4);
-                double xi = 0, yi = 0, zi = 0;
-                if (WCEN) {
+                {
                     const double2 ci = lxy[li];
                     xi = ci.x; yi = ci.y; zi = lz[li];
                     if (b.anypbc) // neighbor.cpp:139-142
                         wrap<TRI>(b, xi, yi, zi);
                 }
                 if (__builtin_expect(w <= __float_as_uint(W), 0)) { // a pair inside the decision band: this centre again in double precision
-                    if (!WCEN) {
-                        const double2 ci = lxy[li];
-                        xi = ci.x; yi = ci.y; zi = lz[li];
-                        if (b.anypbc)
-                            wrap<TRI>(b, xi, yi, zi);
-                    }
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
                         if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
@@ -571,7 +607,7 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
                 int hits = 0;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]);
-                const int id = __float_as_int(s.w);
+                id = __float_as_int(s.w);
                 nn[id] = hits; // keeps counting past M (neighbor.cpp:172-177)
                 if (COUNT) {
                     vmax = max(vmax, hits);
@@ -581,7 +617,6 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
                     // saturates, the cleared bit is one of an empty mask).  Three steps per run cover nearly every run; a loop
                     // takes what is left.  (With a branch per step — v_cmp, s_and_saveexec, s_cbranch — the 36 steps of a centre
                     // were 13 % of a tile's time.)
-                    Ticket *my = tkw + (size_t)lane * (M + 1);
                     int sl = 0;
                     auto step = [&](unsigned &m, int jb) {
                         int z;
@@ -601,10 +636,16 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
                         step(m, jb);
                         while (__builtin_amdgcn_ballot_w64(m != 0)) step(m, jb);
                     }
+                    {   // listed hits, and how many of them belong to run 8 (the last ones of the row)
+                        const int n8 = __builtin_popcount(mk[8]);
+                        kept = hits < M ? hits : M;
+                        kept8 = max(0, min(n8, kept - (hits - n8)));
+                    }
                     if (FCNA) { // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
-                        auto index_of = [&](int a) { // (FCNA instances have two-byte tickets)
+                        auto index_of = [&](int a) {
                             const unsigned t = my[a];
-                            return (int)(hr[cb + roff[t >> JB]] & 0xffffu) + (int)(t & ((1u << JB) - 1u));
+                            const int r = (TK8 && a >= kept - kept8) ? 8 : (int)(t >> JB);
+                            return (int)(hr[run_cell(cb, r)] & 0xffffu) + (int)(t & ((1u << JB) - 1u));
                         };
                         int label = 0;
                         if (hits == 12 && M >= 12) label = lane_fcna<TRI, 12>(b, index_of, lxy, lz, !general_tile, rcsq);
@@ -612,18 +653,138 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
                         if (label > 0) pattern[id] = label;
                         else if (label < 0) defer(cna_todo, id);
                     }
-                    {   // listed hits, and how many of them belong to run 8 (the last ones of the row)
-                        const int kept = hits < M ? hits : M, n8 = __builtin_popcount(mk[8]);
-                        const int kept8 = max(0, min(n8, kept - (hits - n8)));
-                        cen[q] = cv | ((unsigned)kept << 20) | ((unsigned)kept8 << 27);
-                    }
-                    if (WCEN) {
-                        rxy[tid] = make_double2(xi, yi);
-                        rz[tid] = zi;
+                    if (!ROWREG) {
+                        cen[q] = cv | ((unsigned)kept << 20);
+                        if (WCEN) {
+                            rxy[tid] = make_double2(xi, yi);
+                            rz[tid] = zi;
+                        }
                     }
                 }
             }
-            if (!COUNT) {
+            if (ROWREG) {
+                // ---- M <= 16: the centre's lane works out its own row — every listed neighbour's distance, in registers — and
+                // writes it with 16-byte stores: no row word, no per-slot copy of the centre, a third of the instructions of the
+                // slot-per-lane write-out below.  The tickets go through LDS only to turn a per-lane slot number into a register
+                // number: written at slot `sl`, read back as the row's four words.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                STAMP(5);
+                int maxk = kept;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) maxk = max(maxk, __shfl_xor(maxk, d, 64));
+                const unsigned *myw = reinterpret_cast<const unsigned *>(my);
+                unsigned tw[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tw[v] = (4 * v < M) ? myw[v] : 0u;
+                int idv[16];
+                double dv[16];
+                // four slots at a time: their run-table reads go out together, then their twelve position reads, then four
+                // independent distance chains — two LDS round trips per group instead of two per slot
+#pragma unroll
+                for (int g0 = 0; g0 < 16; g0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        idv[g0 + u] = -1; // pads neighbor.py:125-129
+                        dv[g0 + u] = pad;
+                    }
+                    if (g0 < maxk) { // (uniform)
+                        int k[4];
+                        bool h[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sx = g0 + u;
+                            h[u] = sx < kept;
+                            const unsigned t = (tw[sx >> 2] >> (8 * (sx & 3))) & 255u;
+                            int r = (sx >= kept - kept8) ? 8 : (int)(t >> 5);
+                            r = h[u] ? r : 4; // a lane whose row is shorter: the first atom of its own run, result unused
+                            k[u] = (int)(hr[run_cell(cb, r)] & 0xffffu) + (h[u] ? (int)(t & 31u) : 0);
+                        }
+                        double2 cj[4];
+                        double zj[4], d2[4];
+                        int nid[4], sh[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            cj[u] = lxy[k[u]];
+                            zj[u] = lz[k[u]];
+                            nid[u] = __float_as_int(f4[k[u]].w);
+                            sh[u] = (!TRI && general_tile) ? (int)lsh[k[u]] : 0;
+                        }
+                        bool slow = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (TRI) d2[u] = exact_d2<2>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, 0);
+                            else if (general_tile) d2[u] = exact_d2<1>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, sh[u]);
+                            else d2[u] = exact_d2<0>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, 0);
+                            d2[u] = h[u] ? d2[u] : 1.0;
+                            slow = slow || !sqrt_fast_ok(d2[u]);
+                        }
+                        const bool fast = __builtin_amdgcn_ballot_w64(slow) == 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double rr = __builtin_expect(fast, 1) ? sqrt_fast(d2[u]) : sqrt(d2[u]); // neighbor.cpp:174
+                            idv[g0 + u] = h[u] ? nid[u] : -1;
+                            dv[g0 + u] = h[u] ? rr : pad;
+                        }
+                    }
+                }
+                // ---- the rows go out.  Whole rows in 16-byte pieces: first the four lanes of a quad exchange pieces (lane u gets
+                // piece u of each of the quad's four rows), so that one store instruction writes 64 consecutive bytes per quad —
+                // 16 line requests per instruction instead of 64: with every lane storing into its own row the address unit
+                // of the CU, at about two cycles per request, was a quarter of the kernel's time.
+                {
+                    const int rid = (q < wend) ? id : -1;
+                    if (write_pads && (M & 3) == 0) {
+                        const int odd1 = -(lane & 1), odd2 = -((lane >> 1) & 1), u4 = lane & 3;
+                        int P[4][4];
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) P[pp][w] = idv[4 * pp + w];
+                        quad_transpose(P, odd1, odd2);
+                        int rq[4]; // the quad's four row numbers
+                        rq[0] = __builtin_amdgcn_mov_dpp(rid, 0x00, 0xF, 0xF, true); // quad_perm [v,v,v,v]
+                        rq[1] = __builtin_amdgcn_mov_dpp(rid, 0x55, 0xF, 0xF, true);
+                        rq[2] = __builtin_amdgcn_mov_dpp(rid, 0xAA, 0xF, 0xF, true);
+                        rq[3] = __builtin_amdgcn_mov_dpp(rid, 0xFF, 0xF, 0xF, true);
+                        if (4 * u4 < M) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (rq[v] >= 0)
+                                    *reinterpret_cast<Int4 *>(verlet + (uint64_t)(unsigned)rq[v] * (unsigned)M + 4 * u4) = Int4{P[v][0], P[v][1], P[v][2], P[v][3]};
+                        }
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) { // distance pieces 0..3, then 4..7 (two doubles each)
+#pragma unroll
+                            for (int pp = 0; pp < 4; ++pp) {
+                                P[pp][0] = __double2loint(dv[8 * half + 2 * pp]); P[pp][1] = __double2hiint(dv[8 * half + 2 * pp]);
+                                P[pp][2] = __double2loint(dv[8 * half + 2 * pp + 1]); P[pp][3] = __double2hiint(dv[8 * half + 2 * pp + 1]);
+                            }
+                            quad_transpose(P, odd1, odd2);
+                            const int piece = 4 * half + u4;
+                            if (2 * piece < M) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v)
+                                    if (rq[v] >= 0)
+                                        *reinterpret_cast<Int4 *>(dist + (uint64_t)(unsigned)rq[v] * (unsigned)M + 2 * piece) = Int4{P[v][0], P[v][1], P[v][2], P[v][3]};
+                            }
+                        }
+                    } else if (rid >= 0) { // reference semantics (the caller's pads stay) or a row width that is no multiple of four
+                        const uint64_t row = (uint64_t)(unsigned)id * (unsigned)M;
+#pragma unroll
+                        for (int sx = 0; sx < 16; ++sx)
+                            if (sx < M && (sx < kept || write_pads)) {
+                                verlet[row + sx] = idv[sx];
+                                dist[row + sx] = dv[sx];
+                            }
+                    }
+                }
+                STAMP(6);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                STAMP(7);
+            } else if (!COUNT) {
                 // the rows of this wave: written by the lanes of this wave, read below by other lanes of it.  The LDS unit serves
                 // one wave's instructions in order; the fence only keeps the compiler from moving accesses across it
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -644,19 +805,12 @@ __global__ __launch_bounds__(NT, TK8 ? 4 : 1) void k_neighbor_lane(
                     auto words = [&](int c, unsigned &info, unsigned &t) { // row word and this lane's ticket of row c
                         c = min(c, nrows - 1);
                         info = cen[cbase + c];
-                        t = tkw[c * (M + 1) + e]; // (e < M: inside the row; slots past the hits hold leftovers)
+                        t = tkw[c * TKS + e]; // (e < M: inside the row; slots past the hits hold leftovers)
                     };
-                    auto settle = [&](unsigned info, unsigned &t) { // the ticket with its run number in place; a valid one for a slot without a hit
-                        const int kept = (int)((info >> 20) & 127u);
-                        if (TK8 && e >= kept - (int)(info >> 27)) t = (t & 31u) | (8u << JB);
-                        t = e < kept ? t : tself;
+                    auto settle = [&](unsigned info, unsigned &t) { // a valid ticket for a slot without a hit
+                        t = e < (int)((info >> 20) & 127u) ? t : tself;
                     };
-                    // cell of run r relative to the centre's: ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ, neighbor.cpp:147-151
-                    const int A2 = HXY * HZ;
-                    auto cell_of = [&](unsigned info, unsigned t) {
-                        const int r = (int)(t >> JB), r3 = (r * 11) >> 5;
-                        return (int)((info >> 11) & 511u) + __mul24(r3, A2 - 3 * HZ) + __mul24(r, HZ) - (A2 + HZ);
-                    };
+                    auto cell_of = [&](unsigned info, unsigned t) { return run_cell((int)((info >> 11) & 511u), (int)(t >> JB)); };
                     int c0 = lane >> mp_shift;
                     unsigned ia, ib, ta, tb, na, nb, nta, ntb; // this trip's and the next trip's words
                     words(c0, ia, ta); words(c0 + step, ib, tb);
@@ -881,10 +1035,11 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
 
 namespace lane {
 
-// wcen: the wrapped-centre table (triclinic boxes, the fused CNA instance); tk8: one-byte tickets
+// tk8: one-byte tickets in rows padded to whole words; else two-byte tickets and, with wcen (triclinic boxes, the fused CNA
+// instance), the wrapped-centre table
 static size_t lds_bytes(int cap, int64_t M, bool wcen, bool tk8)
 {
-    const size_t tk = (size_t)NT * (size_t)(M + 1) * (tk8 ? 1 : 2);
+    const size_t tk = tk8 ? (size_t)NT * (size_t)((M + 4) & ~(int64_t)3) : (size_t)NT * (size_t)(M + 1) * 2;
     return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (wcen ? (size_t)NT * 24 : 0) + (size_t)cap * 8 + (size_t)CEN_CAP * 4 +
            (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }
@@ -901,7 +1056,7 @@ static int lane_refusal(const DBox &b, const Grid &g, int64_t M)
     return 0;
 }
 
-LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc, bool fcna)
+LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc, bool fcna, bool count)
 {
     using namespace lane;
     LanePlan p{};
@@ -917,19 +1072,21 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
     static const int wgs_env = [] { const char *e = std::getenv("MDH_LANE_WGS"); return e ? std::atoi(e) : 0; }(); // A/B: workgroups per CU the LDS is cut for
-    // one-byte tickets, the lean LDS layout and the 128-VGPR instance: orthogonal boxes without the fused CNA
-    const bool wcen = b.tri || fcna;
-    static const int tk8_env = [] { const char *e = std::getenv("MDH_LANE_TK8"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = two-byte tickets always
-    const bool tk8 = tk8_env && !wcen;
+    // rows of at most 16 slots: one-byte tickets, the lean LDS layout, rows written by the centre's lane; four workgroups per CU
+    // where the instance keeps to 128 VGPRs (not the fused CNA)
+    static const int tk8_env = [] { const char *e = std::getenv("MDH_LANE_TK8"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = the slot-per-lane write-out always
+    const bool tk8 = count || (tk8_env && M <= 16);
+    const bool wcen = !tk8 && (b.tri || fcna);
+    const int max_wgs = (tk8 && !fcna) ? 4 : 3;
     // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, if the tile that allows is not much worse
     // than what fewer would get
     Shape best{0, 0};
     int best_cap = 0, best_wgs = 0;
     double best_score = -1.0;
-    for (int wgs = tk8 ? 4 : 3; wgs >= 2; --wgs) {
-        if (wgs_env > 0 && wgs != std::min(wgs_env, tk8 ? 4 : 3))
+    for (int wgs = max_wgs; wgs >= 2; --wgs) {
+        if (wgs_env > 0 && wgs != std::min(wgs_env, max_wgs))
             continue;
-        const long budget = 160 * 1024 / wgs - 3700; // static tables + allocation granularity (52.9 KB per workgroup still gives three per CU, 54.3 KB does not)
+        const long budget = 160 * 1024 / wgs - 2176 - (wgs == 4 ? 384 : 1600); // static tables (2176 B) and a margin.  Measured: 40 544 B in all still gives four workgroups per CU, 41 216 B does not; 52.9 KB three, 54.3 KB not
         long fixed = (long)lds_bytes(0, M, wcen, tk8);
         int cap = (int)((budget - fixed) / 42) & ~7;
         if (cap_env > 0) cap = cap_env;
@@ -1035,7 +1192,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         list_mode = 1;
     }
     const dim3 grid((unsigned)(per * 8));
-    const bool wcen = b.tri || pattern != nullptr;
+    const bool wcen = !plan.tk8 && (b.tri || pattern != nullptr);
     const size_t lds = lds_bytes(plan.cap, count ? 1 : M, wcen, plan.tk8);
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
@@ -1064,9 +1221,14 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         }                                                                                                                                 \
         MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
-    if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, false); else if (plan.tk8) MDH_LANE_LAUNCH(true, false, false, true); else MDH_LANE_LAUNCH(true, false, false, false); }
-    else if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true, false); else MDH_LANE_LAUNCH(false, false, true, false); }
-    else { if (b.tri) MDH_LANE_LAUNCH(false, true, false, false); else if (plan.tk8) MDH_LANE_LAUNCH(false, false, false, true); else MDH_LANE_LAUNCH(false, false, false, false); }
+    if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, true); else MDH_LANE_LAUNCH(true, false, false, true); }
+    else if (plan.tk8) {
+        if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true, true); else MDH_LANE_LAUNCH(false, false, true, true); }
+        else { if (b.tri) MDH_LANE_LAUNCH(false, true, false, true); else MDH_LANE_LAUNCH(false, false, false, true); }
+    } else {
+        if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true, false); else MDH_LANE_LAUNCH(false, false, true, false); }
+        else { if (b.tri) MDH_LANE_LAUNCH(false, true, false, false); else MDH_LANE_LAUNCH(false, false, false, false); }
+    }
 #undef MDH_LANE_PASS
 #undef MDH_LANE_LAUNCH
     MDH_HIP(hipGetLastError());
