@@ -19,6 +19,8 @@
 // compact kernel that evaluates the reference expression as is (GENERIC = true).
 #include "common.hpp"
 #include "cna_core.hpp"
+#include <cmath>
+#include <cstdlib>
 
 namespace mdh {
 
@@ -51,7 +53,7 @@ __device__ __forceinline__ bool bond_rows(const DBox &b, const double *__restric
 template <bool TRI, bool GENERIC, int NN>
 __device__ __forceinline__ int fcna_atom(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
                                          const double *__restrict__ z, const int *__restrict__ row, double cut2, int64_t i,
-                                         int64_t N)
+                                         int64_t N, unsigned short *lds_col)
 {
     int ids[NN];
 #pragma unroll
@@ -60,7 +62,7 @@ __device__ __forceinline__ int fcna_atom(const DBox &b, const double *__restrict
     Rows R;
     if (!bond_rows<TRI, GENERIC, NN>(b, x, y, z, ids, cut2, R))
         return -1;
-    return fcna_label<NN>(R);
+    return fcna_label<NN>(spill_rows<NN>(R, lds_col, 256));
 }
 
 template <bool TRI, bool GENERIC>
@@ -77,15 +79,134 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
     } else if (i >= N) {
         return;
     }
+    __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread (read back by the thread that wrote them)
     const int n = nn[i];
     const double cut2 = rc * rc; // cna.cpp:449
     const int *row = verlet + i * M;
     // atoms with nn not in {12,14} keep the caller's value (cna.cpp:456)
     int t = 0;
-    if (n == 12 && M >= 12) t = fcna_atom<TRI, GENERIC, 12>(b, x, y, z, row, cut2, i, N);
-    else if (n == 14 && M >= 14) t = fcna_atom<TRI, GENERIC, 14>(b, x, y, z, row, cut2, i, N);
+    if (n == 12 && M >= 12) t = fcna_atom<TRI, GENERIC, 12>(b, x, y, z, row, cut2, i, N, srows + threadIdx.x);
+    else if (n == 14 && M >= 14) t = fcna_atom<TRI, GENERIC, 14>(b, x, y, z, row, cut2, i, N, srows + threadIdx.x);
     if (t > 0) pattern[i] = t;
     else if (!GENERIC && t < 0) defer(todo, i);
+}
+
+// ------------------------------------------------------------------ fixed cutoff, single-precision pair tests
+// Orthogonal boxes with every periodic edge >= 10 rc.  The 66 (91) pair tests of an atom are what the kernel above spends its
+// time on, eleven double-precision instructions each.  Here the listed neighbours are held as single-precision vectors relative
+// to the first of them (minimum image taken in double precision, once per neighbour): a pair costs ten register-only
+// instructions — three subtractions, an FMA chain ending in e = d2 - c (c a little below rc^2), the sign of e shifted into
+// both bond rows, an unsigned minimum that tracks the smallest non-negative e.  |e - exact| <= tol: e < 0 is a bond for sure,
+// e > W none for sure; an atom that saw 0 <= e <= W, or whose list does not look like a neighbourhood (a neighbour more than
+// 2.5 rc from the first, an image number outside {-1,0,1}), goes to the to-do list and is finished by the GENERIC kernel with
+// the reference's expression — labels are the reference's, and no double-precision copy of the positions stays in registers
+// (36 instead of 72: the round-2 attempt kept both and lost to the register file).
+template <int NN>
+__device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
+                                             const double *__restrict__ z, const int (&ids)[NN], float negc, float W, double reach,
+                                             unsigned short *lds_col)
+{
+    float ux[NN], uy[NN], uz[NN];
+    const int j0 = ids[0];
+    const double x0 = x[j0], y0 = y[j0], z0 = z[j0];
+    ux[0] = 0.f; uy[0] = 0.f; uz[0] = 0.f;
+    // the plain differences first: away from the periodic faces (nearly every wavefront) nobody needs an image
+    float big = 0.f;
+#pragma unroll
+    for (int a = 1; a < NN; ++a) {
+        const int j = ids[a];
+        ux[a] = (float)(x[j] - x0); uy[a] = (float)(y[j] - y0); uz[a] = (float)(z[j] - z0);
+        big = fmaxf(big, fmaxf(fabsf(ux[a]), fmaxf(fabsf(uy[a]), fabsf(uz[a]))));
+    }
+    const float reachf = (float)reach;
+    if (__builtin_amdgcn_ballot_w64(!(big <= reachf * 0.999f)) != 0) { // (NaN counts as big) some lane's list crosses a face, or is no neighbourhood
+        bool ok = true;
+#pragma unroll
+        for (int a = 1; a < NN; ++a) {
+            const int j = ids[a];
+            double dx = x[j] - x0, dy = y[j] - y0, dz = z[j] - z0;
+            if (b.pbc[0]) { ok = ok && dx >= b.tn[0][0] && dx < b.tn[0][3]; dx = fold(dx, b.h[0], b.tn[0][1], b.tn[0][2]); }
+            if (b.pbc[1]) { ok = ok && dy >= b.tn[1][0] && dy < b.tn[1][3]; dy = fold(dy, b.h[4], b.tn[1][1], b.tn[1][2]); }
+            if (b.pbc[2]) { ok = ok && dz >= b.tn[2][0] && dz < b.tn[2][3]; dz = fold(dz, b.h[8], b.tn[2][1], b.tn[2][2]); }
+            ok = ok && fabs(dx) <= reach && fabs(dy) <= reach && fabs(dz) <= reach; // (false for NaN)
+            ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
+        }
+        if (!ok)
+            return -1;
+    }
+    unsigned adj[NN];
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+        adj[a] = 0;
+    unsigned w = 0x7f7fffffu; // bits of the smallest non-negative d2 - c seen
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+#pragma unroll
+        for (int c = a + 1; c < NN; ++c) {
+            // (spelled out: left to itself the compiler pairs the tests into packed-f32 instructions, which issue at the
+            // double-precision rate, and shuffles operands into place with hundreds of moves)
+            float t0, t1, t2;
+            asm("v_sub_f32 %[t0], %[xc], %[xa]\n\t"
+                "v_sub_f32 %[t1], %[yc], %[ya]\n\t"
+                "v_sub_f32 %[t2], %[zc], %[za]\n\t"
+                "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"
+                "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
+                "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
+                "v_min_u32 %[w], %[w], %[t0]\n\t"
+                "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"
+                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w] "+v"(w), [ra] "+v"(adj[a]), [rc] "+v"(adj[c])
+                : [xc] "v"(ux[c]), [xa] "v"(ux[a]), [yc] "v"(uy[c]), [ya] "v"(uy[a]), [zc] "v"(uz[c]), [za] "v"(uz[a]),
+                  [negc] "v"(negc), [sc] "n"(c), [sa] "n"(a));
+        }
+    if (w <= __float_as_uint(W))
+        return -1;
+#pragma unroll
+    for (int a = 0; a < NN; ++a) lds_col[a * 256] = (unsigned short)adj[a];
+    return fcna_label_words<NN>(adj, RowsLds{lds_col, 256});
+}
+
+// Held to 128 VGPRs (four waves per SIMD): the few spills that costs (the 14-neighbour branch) are cheaper than three waves;
+// at 96 VGPRs the pair tests spill and the kernel is a third slower.  (One kernel per list length — no spills at 128 — pays
+// a second pass over nn: measured 0.57 against 0.54 ms.)
+__global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ x, const double *__restrict__ y,
+                                                     const double *__restrict__ z, int64_t N, DBox b,
+                                                     const int *__restrict__ verlet, int64_t M, const int *__restrict__ nn,
+                                                     int *__restrict__ pattern, float negc, float W, double reach,
+                                                     int *__restrict__ todo)
+{
+    __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int n = nn[i];
+    const int *row = verlet + i * M;
+    int t = 0; // atoms with nn not in {12,14} keep the caller's value (cna.cpp:456)
+    if (n == 12 && M >= 12) {
+        int ids[12];
+        if ((M & 3) == 0) { // the row in three 16-byte loads
+            const int4 *r4 = reinterpret_cast<const int4 *>(row);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int4 v = r4[q];
+                ids[4 * q] = v.x; ids[4 * q + 1] = v.y; ids[4 * q + 2] = v.z; ids[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) ids[a] = row[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 12; ++a) ids[a] = safe_id(ids[a], i, N);
+        t = fcna_atom_f32<12>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
+    } else if (n == 14 && M >= 14) {
+        int ids[14];
+#pragma unroll
+        for (int a = 0; a < 14; ++a) ids[a] = safe_id(row[a], i, N);
+        t = fcna_atom_f32<14>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
+    }
+    if (t > 0) pattern[i] = t;
+    else if (t < 0) defer(todo, i);
 }
 
 // ------------------------------------------------------------------ adaptive (cna.cpp:289-427)
@@ -300,7 +421,23 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
     if (b.tri) {
         hipLaunchKernelGGL((k_fcna<true, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
     } else {
-        hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        // single-precision pair tests where the neighbourhood of an atom cannot reach its own image (|u_c - u_a| <= 5 rc < L / 2)
+        bool f32 = rc > 1e-12 && rc < 1e12;
+        for (int d = 0; d < 3; ++d)
+            if (b.pbc[d] && !(b.h[d * 4] >= 10.01 * rc)) f32 = false;
+        static const int f32_env = [] { const char *e = std::getenv("MDH_FCNA_F32"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = double precision always
+        if (f32 && f32_env) {
+            // |e_f32 - (d2 - c)| <= 2.4e-6 rc^2 for |u| <= 2.5 rc (derivation at fcna_atom_f32); the band is four times that
+            const double rcsq = rc * rc, tol = 1e-5 * rcsq;
+            float c = (float)(rcsq - tol);
+            while ((double)c > rcsq - tol) c = std::nextafterf(c, -INFINITY);
+            const double want = (rcsq - (double)c) + tol;
+            float W = (float)want;
+            while ((double)W < want) W = std::nextafterf(W, INFINITY);
+            hipLaunchKernelGGL(k_fcna_f32, grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo);
+        } else {
+            hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        }
         hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
     }
 }

@@ -31,9 +31,26 @@ __device__ __forceinline__ Rows pack_rows(const unsigned (&adj)[NN])
     return r;
 }
 
+// The same rows in LDS, one column per thread (row a of thread t at base[a * stride]): a row fetched by a dynamic index is one
+// ds_read_u16 instead of the ~8 select / shift instructions the packed registers need — the signatures of an atom fetch
+// ~60 rows, and the kernels that use this keep no other data in LDS.
+struct RowsLds {
+    const unsigned short *base;
+    int stride;
+    __device__ __forceinline__ unsigned row(int a) const { return base[a * stride]; }
+};
+template <int NN>
+__device__ __forceinline__ RowsLds spill_rows(const Rows &R, unsigned short *base, int stride)
+{
+#pragma unroll
+    for (int a = 0; a < NN; ++a) base[a * stride] = (unsigned short)R.row(a); // (static a: a shift and a mask)
+    return RowsLds{base, stride};
+}
+
 // (ncn, nb, chain) of the bond centre--neighbour ni.  Only neighbours in `limit_mask`
 // take part in the bond search (cna.cpp:69-92; the adaptive 12-neighbour pass hands 12, :344).
-__device__ __forceinline__ void signature(const Rows &R, int ni, unsigned limit_mask, int &ncn, int &nb, int &chain)
+template <class RT>
+__device__ __forceinline__ void signature(const RT &R, int ni, unsigned limit_mask, int &ncn, int &nb, int &chain)
 {
     const unsigned common = R.row(ni); // cna.cpp:52-64
     ncn = __popc(common);
@@ -180,13 +197,58 @@ __device__ __forceinline__ int span_class3(const DBox &b, const double (&px)[NN]
 }
 
 // fixed-cutoff label from the bond matrix of the NN listed neighbours (cna.cpp:471-503; no early exit): 0 = none
-template <int NN>
-__device__ __forceinline__ int fcna_label(const Rows &R)
+template <int NN, class RT>
+__device__ __forceinline__ int fcna_label(const RT &R)
 {
     int n421 = 0, n422 = 0, n555 = 0, n444 = 0, n666 = 0;
     for (int ni = 0; ni < NN; ++ni) {
         int ncn, nb, ch;
         signature(R, ni, (1u << NN) - 1u, ncn, nb, ch);
+        if (ncn == 4 && nb == 2) { n421 += (ch == 1); n422 += (ch == 2); }
+        else if (ncn == 5 && nb == 5 && ch == 5) ++n555;
+        else if (ncn == 4 && nb == 4 && ch == 4) ++n444;
+        else if (ncn == 6 && nb == 6 && ch == 6) ++n666;
+    }
+    if (n421 == 12) return 1; // cna.cpp:496-503
+    if (n421 == 6 && n422 == 6) return 2;
+    if (n555 == 12) return 4;
+    if (n666 == 8 && n444 == 6) return 3;
+    return 0;
+}
+
+// The same label from the bond rows held in registers, two 16-bit rows to a word, without fetching a row by a computed index:
+// for the bond centre--ni the rows of its common neighbours are selected by masks, so 2 * (bonds among them) is one popcount
+// per word and the atoms those bonds touch are the OR of the masked words.  That decides every signature with at most two
+// bonds (two bonds share an atom <=> they touch three atoms) and those of the shortcuts of signature(); the rest — six bonds
+// on six atoms, the (6,6,6) of bcc — walks the clusters through the LDS copy of the rows.
+template <int NN>
+__device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RowsLds &L)
+{
+    constexpr int NW = (NN + 1) / 2;
+    unsigned P[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) P[k] = adj[2 * k] | ((2 * k + 1 < NN) ? (adj[2 * k + 1] << 16) : 0u);
+    int n421 = 0, n422 = 0, n555 = 0, n444 = 0, n666 = 0;
+#pragma unroll
+    for (int ni = 0; ni < NN; ++ni) {
+        const unsigned common = adj[ni]; // cna.cpp:52-64
+        const int ncn = __popc(common);
+        const unsigned c2 = common | (common << 16);
+        unsigned twice = 0, touched = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const unsigned lo = (unsigned)(((int)(common << (31 - 2 * k))) >> 31) & 0xffffu;         // row 2k is a common neighbour
+            const unsigned hi = (unsigned)(((int)(common << (30 - 2 * k))) >> 31) & 0xffff0000u;     // row 2k+1
+            const unsigned xk = P[k] & c2 & (lo | hi);
+            twice += __popc(xk);
+            touched |= xk;
+        }
+        const int nb = (int)(twice >> 1);
+        int ch;
+        if (nb <= 1) ch = nb;
+        else if (nb == 2) ch = (__popc((touched | (touched >> 16)) & 0xffffu) == 3) ? 2 : 1;
+        else if (nb == ncn && (ncn == 4 || ncn == 5)) ch = nb;
+        else { int a, c; signature(L, ni, (1u << NN) - 1u, a, c, ch); }
         if (ncn == 4 && nb == 2) { n421 += (ch == 1); n422 += (ch == 2); }
         else if (ncn == 5 && nb == 5 && ch == 5) ++n555;
         else if (ncn == 4 && nb == 4 && ch == 4) ++n444;
