@@ -70,6 +70,10 @@ int mdh_debug_set_neighbor_variant(int variant);
  * plan8 = {tile cells in x/y, in z, halo atoms per tile, LDS bytes, box full of atoms, 1000 * atoms per cell,
  * cells of the occupied region, 1 if a plan was made since the last query}. */
 int mdh_debug_neighbor_plan(int *plan8);
+/* test hook: fixed-cutoff CNA (mdh_fcna, src/cna.cpp:429-506): 0 = single-precision pair tests with a decision band where the
+ * box allows (default; atoms inside the band are finished with the reference's double-precision expression), 1 = the
+ * double-precision kernel everywhere.  Labels are identical. */
+int mdh_debug_set_fcna_variant(int variant);
 /* test hook: 0 = LDS-tile kernel for the streaming RDF where it applies (default), 1 = thread-per-atom kernel everywhere */
 int mdh_debug_set_rdf_variant(int variant);
 /* k nearest neighbours: 0 = the near kernel (sorted list in registers, 27 cells) followed by the general kernel on the queries it

@@ -24,6 +24,8 @@
 
 namespace mdh {
 
+int g_fcna_variant = 0; // 0 = automatic, 1 = the double-precision kernel everywhere (mdh_debug_set_fcna_variant)
+
 // ---- bond matrix among NN listed neighbours: bit c of row a <=> pbcdis_sq(list[a], list[c]) <= cut2
 // (cna.cpp:459-466; both ends RAW coordinates, cna.cpp:149-161).  Returns false (orthogonal hot path only)
 // when the span test fails and the atom has to be redone by the GENERIC variant.
@@ -425,8 +427,7 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
         bool f32 = rc > 1e-12 && rc < 1e12;
         for (int d = 0; d < 3; ++d)
             if (b.pbc[d] && !(b.h[d * 4] >= 10.01 * rc)) f32 = false;
-        static const int f32_env = [] { const char *e = std::getenv("MDH_FCNA_F32"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = double precision always
-        if (f32 && f32_env) {
+        if (f32 && g_fcna_variant == 0) {
             // |e_f32 - (d2 - c)| <= 2.4e-6 rc^2 for |u| <= 2.5 rc (derivation at fcna_atom_f32); the band is four times that
             const double rcsq = rc * rc, tol = 1e-5 * rcsq;
             float c = (float)(rcsq - tol);
@@ -457,6 +458,12 @@ void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const do
 using namespace mdh;
 
 extern "C" {
+
+int mdh_debug_set_fcna_variant(int v)
+{
+    g_fcna_variant = v;
+    return MDH_OK;
+}
 
 int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
              const double *origin3, const int *boundary3, const int *verlet, int64_t M, const int *nn, int *pattern,

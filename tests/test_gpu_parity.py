@@ -287,6 +287,51 @@ def test_sort_and_cna_vs_oracle(case):
     assert np.array_equal(vb, va) and np.array_equal(db, da)
 
 
+def _fcna_cases():
+    """boxes of >= 10 cutoffs per periodic edge: the single-precision pair tests of k_fcna_f32 apply"""
+    rng = np.random.default_rng(5)
+    out = []
+    p, b = _fcc(11, 0.06, 21)
+    out.append(("fcc_rattled_seams", p, b, ORG0, PBC, 3.2))
+    org = np.array([-7.0, 2.5, 40.0])
+    p, b = _fcc(10, 0.15, 22)
+    p = p + org
+    p[::7] += rng.integers(-1, 2, (len(p[::7]), 3)) * np.diag(b)  # some atoms handed in a box length away
+    out.append(("fcc_hot_shifted_unwrapped", p, b, org, PBC, 3.2))
+    pb, bb = lattice_positions("bcc", 2.87, 13, 13, 13)
+    out.append(("bcc_rattled", pb + rng.normal(0, 0.04, pb.shape), bb, ORG0, PBC, 3.2))  # 14 listed neighbours: (6,6,6) signatures walk the clusters
+    ph, bh = lattice_positions("hcp", 2.95, 12, 7, 7)
+    out.append(("hcp_open_z", ph + rng.normal(0, 0.03, ph.shape), bh, ORG0, np.array([1, 1, 0], np.int32), 3.3))
+    out.append(("random_gas", rng.random((30000, 3)) * 40.0, np.eye(3) * 40.0, ORG0, PBC, 3.6))
+    # knife edge: the second shell of perfect fcc 1e-7 (relative) beyond the cutoff — every atom has a pair inside the band
+    p, b = _fcc(10)
+    out.append(("fcc_second_shell_in_band", p, b, ORG0, PBC, 3.615 * (1.0 - 1e-7)))
+    return out
+
+
+@pytest.mark.parametrize("case", _fcna_cases(), ids=lambda c: c[0])
+def test_fcna_single_precision_pair_tests_vs_oracle(case):
+    """mdh_fcna on boxes where the single-precision kernel runs: labels == oracle == the double-precision kernel"""
+    from mdapy_amd import _lib
+    _, pos, box, org, bnd, rc = case
+    x, y, z = _xyz(pos)
+    v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    want = np.zeros(len(x), np.int32)
+    O.fcna(x, y, z, box, org, bnd, v, n, want, rc, 4)
+    got = np.zeros(len(x), np.int32)
+    _cna.fcna(x, y, z, box, org, bnd, v, n, got, rc, 1)
+    assert np.array_equal(got, want)
+    try:
+        _lib.lib().mdh_debug_set_fcna_variant(1)
+        f64 = np.zeros(len(x), np.int32)
+        _cna.fcna(x, y, z, box, org, bnd, v, n, f64, rc, 1)
+    finally:
+        _lib.lib().mdh_debug_set_fcna_variant(0)
+    assert np.array_equal(f64, want)
+    if case[0].startswith("fcc") or case[0].startswith("bcc") or case[0].startswith("hcp"):
+        assert (want > 0).mean() > 0.5  # the case does exercise labelled atoms
+
+
 @pytest.mark.parametrize("name", ["fcc", "bcc", "hcp", "diamond"])
 @pytest.mark.parametrize("sigma", [0.0, 0.08])
 def test_knn_acna_csp_ids_vs_oracle(name, sigma):
