@@ -64,6 +64,7 @@ struct LanePlan {
     int cap;          // atoms a tile's halo may hold in LDS
     bool tk8;         // rows of at most 16 slots: one-byte tickets, lean LDS layout, rows written by the centre's lane
     int wgs;          // workgroups per CU the LDS budget was cut for
+    int rw;           // rows (centres) a wave works on at a time: 64, fewer for long rows in dense cells
     float mid, T;     // single-precision scan: the constant c subtracted from d2 (a little below rc^2) and the width W of the band above it
     bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live
     int64_t occupied; // cells of the occupied region (last known)

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     int M, int mp_shift, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
-    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0)
+    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw)
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         if (ok && tid < NH && hz >= 1 && hz <= HZ - 2) {
             const unsigned k0 = (unsigned)off0 - hc[tid - 1], len = hc[tid - 1] + (unsigned)cnt + hc[tid + 1];
             hr[tid] = k0 | (len << 16);
-            if (len > 32u) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4)
+            if (len > (TK8 ? 32u : 64u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4); two in the wide instance
         }
         // ---- stage this cell's atoms
         if (ok && cnt > 0) {
@@ -558,37 +558,50 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         const int per_w = (ncentres + (NT >> 6) - 1) / (NT >> 6);
         const int wbeg = min(wv * per_w, ncentres), wend = min(wbeg + per_w, ncentres);
         const int TKS = TK8 ? ((M + 4) & ~3) : (M + 1); // tickets of a row (one-byte rows are read back as whole words)
-        Ticket *tkw = tk + (size_t)(wv * 64) * TKS;
+        Ticket *tkw = tk + (size_t)(wv * rw) * TKS; // rw: rows a wave works on at a time (64; fewer where rows are long and centres few: dense cells)
         const int A2 = HXY * HZ;
         // halo cell of run r relative to the centre's cell: ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ, neighbor.cpp:147-151
         auto run_cell = [&](int cbv, int r) {
             const int r3 = (r * 11) >> 5;
             return cbv + __mul24(r3, A2 - 3 * HZ) + __mul24(r, HZ) - (A2 + HZ);
         };
-        for (int cbase = wbeg; ok && cbase < wend; cbase += 64) {
+        for (int cbase = wbeg; ok && cbase < wend; cbase += rw) {
             const int q = cbase + lane;
+            const bool mine = lane < rw && q < wend; // this lane holds a centre
             int kept = 0, kept8 = 0, cb = 0, id = 0; // (lanes without a centre: no row)
             double xi = 0, yi = 0, zi = 0;
             Ticket *my = tkw + (size_t)lane * TKS;
-            if (q < wend) {
+            if (mine) {
                 const unsigned cv = cen[q];
                 const int li = (int)(cv & 2047u);
                 cb = (int)(cv >> 11);
                 const float4 s = f4[li];
-                unsigned hv[9], mk[9];
+                // WIDE (the two-byte instance): runs of up to 64 candidates — cells of ten atoms and more — as two masks, the
+                // first 32 candidates of a run in mk, the rest in mk2
+                constexpr bool WIDE = !TK8;
+                unsigned hv[9], mk[9], mk2[WIDE ? 9 : 1];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
                     hv[r] = hr[cb + ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ];
                 unsigned w = 0x7f7fffffu; // bits of the smallest non-negative d2 - c this centre has seen
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
-                    const int len = (int)(hv[r] >> 16);
-                    scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), len, s.x, s.y, s.z, negc, mk[r], w);
-                    mk[r] &= ~0u << (run_slots(len) - len); // slots past the end of the run
+                    const int len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
+                    scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), la, s.x, s.y, s.z, negc, mk[r], w);
+                    mk[r] &= ~0u << (run_slots(la) - la); // slots past the end of the run
+                    if (WIDE) {
+                        const int lb = len - la;
+                        mk2[r] = 0;
+                        if (__builtin_amdgcn_ballot_w64(lb > 0)) {
+                            scan_run_asm(f4_lds + (((hv[r] & 0xffffu) + 32u) << 4), lb, s.x, s.y, s.z, negc, mk2[r], w);
+                            mk2[r] &= lb > 0 ? ~0u << (run_slots(lb) - lb) : 0u;
+                        }
+                    }
                 }
                 {   // the centre itself sits in run 4 with d2 = 0: not a neighbour (neighbor.cpp:162)
-                    const int S = run_slots((int)(hv[4] >> 16));
-                    mk[4] &= ~(1u << (S - 1 - (li - (int)(hv[4] & 0xffffu))));
+                    const int len = (int)(hv[4] >> 16), idx = li - (int)(hv[4] & 0xffffu);
+                    if (!WIDE || idx < 32) mk[4] &= ~(1u << (run_slots(WIDE ? min(len, 32) : len) - 1 - idx));
+                    else mk2[4] &= ~(1u << (run_slots(len - 32) - 1 - (idx - 32)));
                 }
                 STAMP(4);
                 {
@@ -600,13 +613,18 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 if (__builtin_expect(w <= __float_as_uint(W), 0)) { // a pair inside the decision band: this centre again in double precision
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
-                        else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, (int)(hv[r] & 0xffffu), (int)(hv[r] >> 16), li, xi, yi, zi);
+                        const int k0 = (int)(hv[r] & 0xffffu), len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
+                        if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0, la, li, xi, yi, zi);
+                        else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0, la, li, xi, yi, zi);
+                        if (WIDE) {
+                            if (r == 4) mk2[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, len - la, li, xi, yi, zi);
+                            else mk2[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, len - la, li, xi, yi, zi);
+                        }
                     }
                 }
                 int hits = 0;
 #pragma unroll
-                for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]);
+                for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]) + (WIDE ? __builtin_popcount(mk2[r]) : 0);
                 id = __float_as_int(s.w);
                 nn[id] = hits; // keeps counting past M (neighbor.cpp:172-177)
                 if (COUNT) {
@@ -629,12 +647,18 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                     };
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
-                        const int jb = (((TK8 ? (r & 7) : r)) << JB) + (run_slots((int)(hv[r] >> 16)) - 32); // + clz(m) = the hit's ticket
+                        const int len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
+                        const int jb = (((TK8 ? (r & 7) : r)) << JB) + (run_slots(la) - 32); // + clz(m) = the hit's ticket
                         unsigned m = mk[r];
                         step(m, jb);
                         step(m, jb);
                         step(m, jb);
                         while (__builtin_amdgcn_ballot_w64(m != 0)) step(m, jb);
+                        if (WIDE) { // candidates 32.. of the run: position 32 + j
+                            unsigned m2 = mk2[r];
+                            const int jb2 = (r << JB) + run_slots(len - la);
+                            while (__builtin_amdgcn_ballot_w64(m2 != 0)) step(m2, jb2);
+                        }
                     }
                     {   // listed hits, and how many of them belong to run 8 (the last ones of the row)
                         const int n8 = __builtin_popcount(mk[8]);
@@ -734,7 +758,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 // 16 line requests per instruction instead of 64: with every lane storing into its own row the address unit
                 // of the CU, at about two cycles per request, was a quarter of the kernel's time.
                 {
-                    const int rid = (q < wend) ? id : -1;
+                    const int rid = mine ? id : -1;
                     if (write_pads && (M & 3) == 0) {
                         const int odd1 = -(lane & 1), odd2 = -((lane >> 1) & 1), u4 = lane & 3;
                         int P[4][4];
@@ -792,7 +816,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 STAMP(5);
                 // ---- tickets -> rows: MP adjacent lanes serve the slots of one centre
-                const int nrows = min(64, wend - cbase);
+                const int nrows = min(rw, wend - cbase);
                 const int MP = 1 << mp_shift; // smallest power of two >= M
                 const int e = lane & (MP - 1);
                 if (e < M) {
@@ -1037,9 +1061,10 @@ namespace lane {
 
 // tk8: one-byte tickets in rows padded to whole words; else two-byte tickets and, with wcen (triclinic boxes, the fused CNA
 // instance), the wrapped-centre table
-static size_t lds_bytes(int cap, int64_t M, bool wcen, bool tk8)
+static size_t lds_bytes(int cap, int64_t M, bool wcen, bool tk8, int rw)
 {
-    const size_t tk = tk8 ? (size_t)NT * (size_t)((M + 4) & ~(int64_t)3) : (size_t)NT * (size_t)(M + 1) * 2;
+    const size_t rows = (size_t)(NT / 64) * (size_t)rw;
+    const size_t tk = tk8 ? rows * (size_t)((M + 4) & ~(int64_t)3) : rows * (size_t)(M + 1) * 2;
     return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (wcen ? (size_t)NT * 24 : 0) + (size_t)cap * 8 + (size_t)CEN_CAP * 4 +
            (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }
@@ -1064,49 +1089,55 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     if (N <= 0) { g_last_plan[6] = -1; return p; }
     if (const int why = lane_refusal(b, g, M)) { g_last_plan[6] = why; return p; }
     if (!(rc > 1e-12 && rc < 1e12)) { g_last_plan[6] = -4; return p; }
-    int64_t runs = 0, longer = 0;
+    int64_t runs = 0, over32 = 0, over64 = 0;
     for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
-    for (int len = 29; len <= 65; ++len) longer += gs.v[1 + len];
-    if (runs > 0 && (double)longer > 0.002 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)longer; g_last_plan[4] = (int)runs; return p; } // cells so full that many runs would not fit a 32-bit hit mask
+    for (int len = 29; len <= 65; ++len) over32 += gs.v[1 + len]; // (a little below the limits: the statistics are the previous call's)
+    for (int len = 59; len <= 65; ++len) over64 += gs.v[1 + len];
+    const bool long_runs = runs > 0 && (double)over32 > 0.002 * (double)runs; // many runs would not fit one 32-bit hit mask: the wide instance (two)
+    // cells so full that more than a few per cent of the runs would not fit two masks (fewer — the wider last cell of a small box — go to the mop-up kernel)
+    if (runs > 0 && (double)over64 > 0.05 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)over64; g_last_plan[4] = (int)runs; return p; }
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
     static const int wgs_env = [] { const char *e = std::getenv("MDH_LANE_WGS"); return e ? std::atoi(e) : 0; }(); // A/B: workgroups per CU the LDS is cut for
-    // rows of at most 16 slots: one-byte tickets, the lean LDS layout, rows written by the centre's lane; four workgroups per CU
-    // where the instance keeps to 128 VGPRs (not the fused CNA)
+    // rows of at most 16 slots in cells of a few atoms: one-byte tickets, the lean LDS layout, rows written by the centre's lane;
+    // four workgroups per CU where the instance keeps to 128 VGPRs (not the fused CNA)
     static const int tk8_env = [] { const char *e = std::getenv("MDH_LANE_TK8"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = the slot-per-lane write-out always
-    const bool tk8 = count || (tk8_env && M <= 16);
+    const bool tk8 = (count && !long_runs) || (tk8_env && M <= 16 && !long_runs);
     const bool wcen = !tk8 && (b.tri || fcna);
     const int max_wgs = (tk8 && !fcna) ? 4 : 3;
-    // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, if the tile that allows is not much worse
-    // than what fewer would get
+    // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, two, one, if the tile that allows is not
+    // much worse than what fewer would get.  Rows of many slots in cells of many atoms (rc = 5 A, 50 slots: the reference's
+    // own benchmark call) leave few centres per tile: the ticket rows are sized for them (rw rows per wave), not for 64.
     Shape best{0, 0};
-    int best_cap = 0, best_wgs = 0;
+    int best_cap = 0, best_wgs = 0, best_rw = 64;
     double best_score = -1.0;
-    for (int wgs = max_wgs; wgs >= 2; --wgs) {
+    for (int wgs = max_wgs; wgs >= 1; --wgs) {
         if (wgs_env > 0 && wgs != std::min(wgs_env, max_wgs))
             continue;
         const long budget = 160 * 1024 / wgs - 2176 - (wgs == 4 ? 384 : 1600); // static tables (2176 B) and a margin.  Measured: 40 544 B in all still gives four workgroups per CU, 41 216 B does not; 52.9 KB three, 54.3 KB not
-        long fixed = (long)lds_bytes(0, M, wcen, tk8);
-        int cap = (int)((budget - fixed) / 42) & ~7;
-        if (cap_env > 0) cap = cap_env;
-        if (cap < 64)
-            continue;
-        cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
         for (int txy = 1; txy <= 8; ++txy)
             for (int tz = 1; tz <= 24; ++tz) {
                 const int nh = (txy + 2) * (txy + 2) * (tz + 2);
-                if (nh > MAX_NH || nh * pop > 0.875 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
+                if (nh > MAX_NH)
                     continue;
                 const int ncc = txy * txy * tz;
                 const double c = ncc * pop;                                 // centre atoms per tile
-                const double passes = std::ceil(c * 1.15 / NT);             // (head-room: a second pass for a handful of centres is a waste)
                 if (c * 1.15 > CEN_CAP)
                     continue;
+                int rw = 64;
+                if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / (NT / 64)) + 7) & ~7));
+                const long fixed = (long)lds_bytes(0, M, wcen, tk8, rw);
+                int cap = (int)((budget - fixed) / 42) & ~7;
+                if (cap_env > 0) cap = cap_env;
+                cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
+                if (cap < 64 || nh * pop > 0.875 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
+                    continue;
+                const double passes = std::ceil(c * 1.15 / ((NT / 64) * rw)); // (head-room: a second pass for a handful of centres is a waste)
                 const double util = c / (passes * NT);                     // lane utilisation of the scan
                 const double reuse = (double)ncc / (double)nh;             // centre cells per staged cell
-                const double score = util * (0.35 + reuse) * (wgs == 4 ? 1.1 : (wgs == 3 ? 1.0 : 0.85));
-                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; best_wgs = wgs; }
+                const double score = util * (0.35 + reuse) * (wgs == 4 ? 1.1 : (wgs == 3 ? 1.0 : (wgs == 2 ? 0.85 : 0.6)));
+                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; best_wgs = wgs; best_rw = rw; }
             }
         if (cap_env > 0)
             break;
@@ -1149,9 +1180,10 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.cap = best_cap;
     p.tk8 = tk8;
     p.wgs = best_wgs;
+    p.rw = best_rw;
     p.occupied = occ;
     p.full = occ >= g.ncell;
-    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, wcen, tk8);
+    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, wcen, tk8, p.rw);
     g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
@@ -1193,7 +1225,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     }
     const dim3 grid((unsigned)(per * 8));
     const bool wcen = !plan.tk8 && (b.tri || pattern != nullptr);
-    const size_t lds = lds_bytes(plan.cap, count ? 1 : M, wcen, plan.tk8);
+    const size_t lds = lds_bytes(plan.cap, count ? 1 : M, wcen, plan.tk8, plan.rw);
     int mp_shift = 0;
     while ((1 << mp_shift) < M) ++mp_shift;
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
@@ -1205,7 +1237,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0); \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
@@ -1221,8 +1253,10 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         }                                                                                                                                 \
         MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
-    if (count) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, true); else MDH_LANE_LAUNCH(true, false, false, true); }
-    else if (plan.tk8) {
+    if (count) {
+        if (plan.tk8) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, true); else MDH_LANE_LAUNCH(true, false, false, true); }
+        else { if (b.tri) MDH_LANE_LAUNCH(true, true, false, false); else MDH_LANE_LAUNCH(true, false, false, false); }
+    } else if (plan.tk8) {
         if (pattern) { if (b.tri) MDH_LANE_LAUNCH(false, true, true, true); else MDH_LANE_LAUNCH(false, false, true, true); }
         else { if (b.tri) MDH_LANE_LAUNCH(false, true, false, true); else MDH_LANE_LAUNCH(false, false, false, true); }
     } else {

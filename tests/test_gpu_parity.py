@@ -144,6 +144,51 @@ def test_neighbor_tile_overflow_and_variants():
 
 
 
+@pytest.mark.parametrize("kind", ["fcc", "fcc_rattled_shifted", "fcc_narrow_rows", "gas", "triclinic"])
+def test_neighbor_dense_cells_take_the_wide_tile_kernel(kind):
+    """The reference's own benchmark call, build_neighbor(5.0, max_neigh=50) on fcc Cu (doc/gettingstarted/benchmark.ipynb):
+    ~11 atoms per cell, 3-cell runs of 32 and more -> the wide instance of the tile kernel (two hit masks per run, two-byte
+    tickets, row buffers sized by the tile's centres).  Rows bit for bit vs the oracle, and the tile kernel did take the call."""
+    from mdapy_amd import _lib
+    rng = np.random.default_rng(77)
+    rc, M = 5.0, 50
+    org, bnd = ORG0, PBC
+    if kind == "fcc":
+        pos, box = _fcc(20)
+    elif kind == "fcc_rattled_shifted":
+        pos, box = _fcc(18, 0.1, 5)
+        org = np.array([4.0, -11.0, 2.5])
+        pos = pos + org
+        pos[::11] += rng.integers(-1, 2, (len(pos[::11]), 3)) * np.diag(box)  # atoms a box length outside
+    elif kind == "fcc_narrow_rows":
+        pos, box = _fcc(16, 0.05, 6)
+        M = 20  # 42 neighbours per atom: every row overflows, the counts keep running
+    elif kind == "gas":
+        pos, box = rng.random((50000, 3)) * 80.0, np.eye(3) * 80.0  # ~12 atoms per cell: runs of 25 to 50 (open y: edge cells clamp outside atoms)
+        bnd = np.array([1, 0, 1], np.int32)
+    else:
+        box = np.array([[60.0, 0.0, 0.0], [7.0, 58.0, 0.0], [-4.0, 6.0, 61.0]])
+        pos = rng.random((14000, 3)) @ box
+    x, y, z = _xyz(pos)
+    va = np.full((len(x), M), -1, np.int32); da = np.full((len(x), M), rc + 1.0); na = np.zeros(len(x), np.int32)
+    O.build_neighbor(x, y, z, box, org, bnd, rc, va, da, na, 4)
+    vb = np.empty((len(x), M), np.int32); db = np.empty((len(x), M)); nb = np.empty(len(x), np.int32)
+    for _ in range(2):  # (the second call plans from the first call's run-length statistics)
+        _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vb, db, nb, 1, fill_pads=True)
+    plan = np.zeros(8, np.int32)
+    _lib.lib().mdh_debug_neighbor_plan(plan.ctypes.data)
+    assert plan[0] > 0 and plan[7] == 1 and (plan[4] & 2) == 0, plan  # a tile plan was made, and it is the wide (two-byte) instance
+    assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+    if kind == "fcc":
+        assert (na == 42).all()
+    if kind == "fcc_narrow_rows":
+        assert na.min() > M
+    # the exact-width call (counting pass of the same instance) and the reference-semantics call (caller's pads)
+    v2, d2, n2 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1)
+    vo, do, no = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    assert np.array_equal(n2, no) and np.array_equal(v2, vo) and np.array_equal(d2, do)
+
+
 def test_fused_neighbor_fcna_equals_the_two_calls():
     """mdh_build_neighbor_fcna == mdh_build_neighbor then mdh_fcna, bit for bit (lists AND labels), on every kind of tile the
     kernel meets: interior, periodic seam, open faces, atoms handed in outside the box / unwrapped (the stand-by kernel
