@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
     const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
-    int M, int mp_shift, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
+    int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
     int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw)
@@ -347,14 +347,10 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     // the walk, so its tickets are the last of the row and a count of them says which they are.
     typedef typename std::conditional<TK8, unsigned char, unsigned short>::type Ticket;
     constexpr int JB = TK8 ? 5 : 8;
-    constexpr bool ROWREG = TK8 && !COUNT;         // M <= 16: a centre's lane keeps its row in registers and writes it itself
-    constexpr bool WCEN = !TK8 && (TRI || FCNA);   // slot-per-lane write-out: wrapped centres tabulated by the centre's lane (the triclinic wrap is too long to redo per written slot)
     float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap+8] staged (ux, uy, uz, bits of the atom id)
     double2 *lxy = reinterpret_cast<double2 *>(f4 + cap + 8);       // [cap] staged raw x, y
-    double2 *rxy = lxy + cap;                                       // WCEN [NT] this pass's rows: wrapped centre x, y
-    double *rz = reinterpret_cast<double *>(rxy + (WCEN ? NT : 0)); // WCEN [NT] wrapped centre z
-    double *lz = rz + (WCEN ? NT : 0);                              // [cap] staged raw z
-    unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 11, later | min(count, M) << 20 | listed hits of run 8 << 27
+    double *lz = reinterpret_cast<double *>(lxy + cap);             // [cap] staged raw z
+    unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 11
     unsigned short *lsh = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [cap] combined image code of a staged atom seen from this tile
     Ticket *tk = reinterpret_cast<Ticket *>(lsh + cap + (cap & 1)); // [NT][TKS] tickets (slot M swallows the hits past M); wave w owns rows 64 w ...
     const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
@@ -557,7 +553,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         const int wv = tid >> 6;
         const int per_w = (ncentres + (NT >> 6) - 1) / (NT >> 6);
         const int wbeg = min(wv * per_w, ncentres), wend = min(wbeg + per_w, ncentres);
-        const int TKS = TK8 ? ((M + 4) & ~3) : (M + 1); // tickets of a row (one-byte rows are read back as whole words)
+        const int TKS = (M + 4) & ~3; // tickets of a row + the spare slot, rounded up: rows are read back four tickets at a time
         Ticket *tkw = tk + (size_t)(wv * rw) * TKS; // rw: rows a wave works on at a time (64; fewer where rows are long and centres few: dense cells)
         const int A2 = HXY * HZ;
         // halo cell of run r relative to the centre's cell: ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ, neighbor.cpp:147-151
@@ -677,16 +673,9 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                         if (label > 0) pattern[id] = label;
                         else if (label < 0) defer(cna_todo, id);
                     }
-                    if (!ROWREG) {
-                        cen[q] = cv | ((unsigned)kept << 20);
-                        if (WCEN) {
-                            rxy[tid] = make_double2(xi, yi);
-                            rz[tid] = zi;
-                        }
-                    }
                 }
             }
-            if (ROWREG) {
+            if (TK8 && !COUNT) {
                 // ---- M <= 16: the centre's lane works out its own row — every listed neighbour's distance, in registers — and
                 // writes it with 16-byte stores: no row word, no per-slot copy of the centre, a third of the instructions of the
                 // slot-per-lane write-out below.  The tickets go through LDS only to turn a per-lane slot number into a register
@@ -809,112 +798,78 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 __builtin_amdgcn_wave_barrier();
                 STAMP(7);
             } else if (!COUNT) {
-                // the rows of this wave: written by the lanes of this wave, read below by other lanes of it.  The LDS unit serves
-                // one wave's instructions in order; the fence only keeps the compiler from moving accesses across it
+                // ---- rows of up to 64 slots (and any row in cells of many atoms): the same lane-per-centre form, four slots at
+                // a time — tickets read back as one word pair, run-table reads, twelve position reads, four distance chains —
+                // each group's part of the row stored at once (16-byte stores where the row allows).
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 STAMP(5);
-                // ---- tickets -> rows: MP adjacent lanes serve the slots of one centre
-                const int nrows = min(rw, wend - cbase);
-                const int MP = 1 << mp_shift; // smallest power of two >= M
-                const int e = lane & (MP - 1);
-                if (e < M) {
-                    const int step = 64 >> mp_shift;
-                    const unsigned tself = 4u << JB; // first slot of the centre's own run: a valid ticket for lanes without a hit
-                    // Two rows per trip, and a three-deep pipeline over the trips: while the distances of trip i are worked out,
-                    // the run-table entries of trip i+1 and the row words and tickets of trip i+2 are on their way — every LDS
-                    // read of a trip's body is independent of the others, so a trip pays one LDS round trip instead of four
-                    // dependent ones.  Reads past the last row are clamped to it (never stored).
-                    auto words = [&](int c, unsigned &info, unsigned &t) { // row word and this lane's ticket of row c
-                        c = min(c, nrows - 1);
-                        info = cen[cbase + c];
-                        t = tkw[c * TKS + e]; // (e < M: inside the row; slots past the hits hold leftovers)
-                    };
-                    auto settle = [&](unsigned info, unsigned &t) { // a valid ticket for a slot without a hit
-                        t = e < (int)((info >> 20) & 127u) ? t : tself;
-                    };
-                    auto cell_of = [&](unsigned info, unsigned t) { return run_cell((int)((info >> 11) & 511u), (int)(t >> JB)); };
-                    int c0 = lane >> mp_shift;
-                    unsigned ia, ib, ta, tb, na, nb, nta, ntb; // this trip's and the next trip's words
-                    words(c0, ia, ta); words(c0 + step, ib, tb);
-                    words(c0 + 2 * step, na, nta); words(c0 + 3 * step, nb, ntb);
-                    settle(ia, ta); settle(ib, tb);
-                    unsigned ra_ = hr[cell_of(ia, ta)], rb_ = hr[cell_of(ib, tb)];
-                    for (; c0 < nrows; c0 += 2 * step) {
-                        const bool two = c0 + step < nrows;
-                        const bool ha = e < (int)((ia >> 20) & 127u), hb = e < (int)((ib >> 20) & 127u);
-                        const int lia = (int)(ia & 2047u), lib = (int)(ib & 2047u);
-                        const int kka = (int)(ra_ & 0xffffu) + (int)(ta & ((1u << JB) - 1u));
-                        const int kkb = (int)(rb_ & 0xffffu) + (int)(tb & ((1u << JB) - 1u));
-                        const double2 ja = lxy[kka], jb2 = lxy[kkb];
-                        const double jza = lz[kka], jzb = lz[kkb];
-                        const int ida = __float_as_int(f4[kka].w), idb = __float_as_int(f4[kkb].w);
-                        const unsigned rowa = __float_as_uint(f4[lia].w), rowb = __float_as_uint(f4[lib].w);
-                        double2 wa, wb;
-                        double wza, wzb;
-                        if (WCEN) {
-                            wa = rxy[wv * 64 + c0]; wb = rxy[wv * 64 + (two ? c0 + step : c0)];
-                            wza = rz[wv * 64 + c0]; wzb = rz[wv * 64 + (two ? c0 + step : c0)];
-                        } else {
-                            wa = lxy[lia]; wb = lxy[lib];
-                            wza = lz[lia]; wzb = lz[lib];
+                int maxk = kept;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) maxk = max(maxk, __shfl_xor(maxk, d, 64));
+                const uint64_t row = (uint64_t)(unsigned)id * (unsigned)M;
+                const int gend = write_pads ? M : min(M, maxk);
+                for (int g0 = 0; g0 < gend; g0 += 4) {
+                    int idv[4];
+                    double dv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        idv[u] = -1; // pads neighbor.py:125-129
+                        dv[u] = pad;
+                    }
+                    if (g0 < maxk) { // (uniform)
+                        const uint2 t4 = *reinterpret_cast<const uint2 *>(my + g0); // tickets g0 .. g0+3
+                        int k[4];
+                        bool h[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            h[u] = g0 + u < kept;
+                            const unsigned t = ((u < 2 ? t4.x : t4.y) >> (16 * (u & 1))) & 0xffffu;
+                            const int r = h[u] ? (int)(t >> JB) : 4; // a lane whose row is shorter: the first atom of its own run, result unused
+                            k[u] = (int)(hr[run_cell(cb, r)] & 0xffffu) + (h[u] ? (int)(t & ((1u << JB) - 1u)) : 0);
                         }
-                        // trip i+1: run-table entries; trip i+2: row words and tickets
-                        settle(na, nta); settle(nb, ntb);
-                        const unsigned nra = hr[cell_of(na, nta)], nrb = hr[cell_of(nb, ntb)];
-                        unsigned fa, fb, fta, ftb;
-                        words(c0 + 4 * step, fa, fta); words(c0 + 5 * step, fb, ftb);
-                        if (!WCEN && b.anypbc) { // the wrapped centre (neighbor.cpp:139-142), once per written slot
-                            if (general_tile) { // an atom may have been handed in outside the box: the whole expression
-                                wrap<false>(b, wa.x, wa.y, wza);
-                                wrap<false>(b, wb.x, wb.y, wzb);
-                            } else { // every staged atom lies inside the box: floor((x - o) / L) = 0, the wrap is o + (x - o) - L * 0 (box.h:158-176)
-                                if (b.pbc[0] && b.pbc[1] && b.pbc[2]) { // (one uniform branch instead of six selects)
-                                    wa.x = b.o[0] + (wa.x - b.o[0]); wb.x = b.o[0] + (wb.x - b.o[0]);
-                                    wa.y = b.o[1] + (wa.y - b.o[1]); wb.y = b.o[1] + (wb.y - b.o[1]);
-                                    wza = b.o[2] + (wza - b.o[2]); wzb = b.o[2] + (wzb - b.o[2]);
-                                } else {
-                                    if (b.pbc[0]) { wa.x = b.o[0] + (wa.x - b.o[0]); wb.x = b.o[0] + (wb.x - b.o[0]); }
-                                    if (b.pbc[1]) { wa.y = b.o[1] + (wa.y - b.o[1]); wb.y = b.o[1] + (wb.y - b.o[1]); }
-                                    if (b.pbc[2]) { wza = b.o[2] + (wza - b.o[2]); wzb = b.o[2] + (wzb - b.o[2]); }
+                        double2 cj[4];
+                        double zj[4], d2[4];
+                        int nid[4], sh[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            cj[u] = lxy[k[u]];
+                            zj[u] = lz[k[u]];
+                            nid[u] = __float_as_int(f4[k[u]].w);
+                            sh[u] = (!TRI && general_tile) ? (int)lsh[k[u]] : 0;
+                        }
+                        bool slow = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (TRI) d2[u] = exact_d2<2>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, 0);
+                            else if (general_tile) d2[u] = exact_d2<1>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, sh[u]);
+                            else d2[u] = exact_d2<0>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, 0);
+                            d2[u] = h[u] ? d2[u] : 1.0;
+                            slow = slow || !sqrt_fast_ok(d2[u]);
+                        }
+                        const bool fast = __builtin_amdgcn_ballot_w64(slow) == 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double rr = __builtin_expect(fast, 1) ? sqrt_fast(d2[u]) : sqrt(d2[u]); // neighbor.cpp:174
+                            idv[u] = h[u] ? nid[u] : -1;
+                            dv[u] = h[u] ? rr : pad;
+                        }
+                    }
+                    if (mine) {
+                        if (write_pads && g0 + 4 <= M) { // (any alignment: the hardware takes 16-byte stores at 4-byte addresses)
+                            *reinterpret_cast<Int4 *>(verlet + row + g0) = Int4{idv[0], idv[1], idv[2], idv[3]};
+                            Int4 *dp = reinterpret_cast<Int4 *>(dist + row + g0);
+                            dp[0] = Int4{__double2loint(dv[0]), __double2hiint(dv[0]), __double2loint(dv[1]), __double2hiint(dv[1])};
+                            dp[1] = Int4{__double2loint(dv[2]), __double2hiint(dv[2]), __double2loint(dv[3]), __double2hiint(dv[3])};
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (g0 + u < M && (g0 + u < kept || write_pads)) {
+                                    verlet[row + g0 + u] = idv[u];
+                                    dist[row + g0 + u] = dv[u];
                                 }
-                            }
                         }
-                        double d2a, d2b;
-                        if (TRI) {
-                            d2a = exact_d2<2>(b, ja.x, ja.y, jza, wa.x, wa.y, wza, 0);
-                            d2b = exact_d2<2>(b, jb2.x, jb2.y, jzb, wb.x, wb.y, wzb, 0);
-                        } else if (general_tile) {
-                            d2a = exact_d2<1>(b, ja.x, ja.y, jza, wa.x, wa.y, wza, lsh[kka]);
-                            d2b = exact_d2<1>(b, jb2.x, jb2.y, jzb, wb.x, wb.y, wzb, lsh[kkb]);
-                        } else {
-                            d2a = exact_d2<0>(b, ja.x, ja.y, jza, wa.x, wa.y, wza, 0);
-                            d2b = exact_d2<0>(b, jb2.x, jb2.y, jzb, wb.x, wb.y, wzb, 0);
-                        }
-                        // neighbor.cpp:174; pads neighbor.py:125-129.  Both roots for every lane (a lane without a hit holds the
-                        // distance to some staged atom), then a select: straight-line code whose two chains interleave
-                        double ra, rb;
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(sqrt_fast_ok(d2a) && sqrt_fast_ok(d2b))) == 0, 1)) {
-                            ra = sqrt_fast(d2a);
-                            rb = sqrt_fast(d2b);
-                        } else {
-                            ra = sqrt(d2a);
-                            rb = sqrt(d2b);
-                        }
-                        ra = ha ? ra : pad;
-                        rb = hb ? rb : pad;
-                        const uint64_t oa = (uint64_t)rowa * (unsigned)M + (unsigned)e, ob = (uint64_t)rowb * (unsigned)M + (unsigned)e;
-                        if (ha || write_pads) {
-                            __builtin_nontemporal_store(ha ? ida : -1, &verlet[oa]); // rows are written once and not read back here
-                            __builtin_nontemporal_store(ra, &dist[oa]);
-                        }
-                        if (two && (hb || write_pads)) {
-                            __builtin_nontemporal_store(hb ? idb : -1, &verlet[ob]);
-                            __builtin_nontemporal_store(rb, &dist[ob]);
-                        }
-                        ia = na; ib = nb; ta = nta; tb = ntb; ra_ = nra; rb_ = nrb;
-                        na = fa; nb = fb; nta = fta; ntb = ftb;
                     }
                 }
                 STAMP(6);
@@ -1059,14 +1014,13 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
 
 namespace lane {
 
-// tk8: one-byte tickets in rows padded to whole words; else two-byte tickets and, with wcen (triclinic boxes, the fused CNA
-// instance), the wrapped-centre table
-static size_t lds_bytes(int cap, int64_t M, bool wcen, bool tk8, int rw)
+// tk8: one-byte tickets, else two-byte ones; rows of (M + 1) tickets rounded up to a multiple of four; rw rows per wave
+static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw)
 {
     const size_t rows = (size_t)(NT / 64) * (size_t)rw;
-    const size_t tk = tk8 ? rows * (size_t)((M + 4) & ~(int64_t)3) : rows * (size_t)(M + 1) * 2;
-    return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (wcen ? (size_t)NT * 24 : 0) + (size_t)cap * 8 + (size_t)CEN_CAP * 4 +
-           (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
+    const size_t tk = rows * (size_t)((M + 4) & ~(int64_t)3) * (tk8 ? 1 : 2);
+    return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + (size_t)(cap + (cap & 1)) * 2 +
+           ((tk + 15) & ~(size_t)15);
 }
 
 } // namespace lane
@@ -1104,7 +1058,6 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     // four workgroups per CU where the instance keeps to 128 VGPRs (not the fused CNA)
     static const int tk8_env = [] { const char *e = std::getenv("MDH_LANE_TK8"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = the slot-per-lane write-out always
     const bool tk8 = (count && !long_runs) || (tk8_env && M <= 16 && !long_runs);
-    const bool wcen = !tk8 && (b.tri || fcna);
     const int max_wgs = (tk8 && !fcna) ? 4 : 3;
     // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, two, one, if the tile that allows is not
     // much worse than what fewer would get.  Rows of many slots in cells of many atoms (rc = 5 A, 50 slots: the reference's
@@ -1127,7 +1080,7 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
                     continue;
                 int rw = 64;
                 if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / (NT / 64)) + 7) & ~7));
-                const long fixed = (long)lds_bytes(0, M, wcen, tk8, rw);
+                const long fixed = (long)lds_bytes(0, M, tk8, rw);
                 int cap = (int)((budget - fixed) / 42) & ~7;
                 if (cap_env > 0) cap = cap_env;
                 cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
@@ -1183,7 +1136,7 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.rw = best_rw;
     p.occupied = occ;
     p.full = occ >= g.ncell;
-    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, wcen, tk8, p.rw);
+    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw);
     g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
@@ -1224,10 +1177,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         list_mode = 1;
     }
     const dim3 grid((unsigned)(per * 8));
-    const bool wcen = !plan.tk8 && (b.tri || pattern != nullptr);
-    const size_t lds = lds_bytes(plan.cap, count ? 1 : M, wcen, plan.tk8, plan.rw);
-    int mp_shift = 0;
-    while ((1 << mp_shift) < M) ++mp_shift;
+    const size_t lds = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw);
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
     const float negc = -plan.mid;
     const int nt2b = nt[2] * nsub;
@@ -1237,7 +1187,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, mp_shift, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw); \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
