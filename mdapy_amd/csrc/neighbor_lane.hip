@@ -603,8 +603,15 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 {
                     const double2 ci = lxy[li];
                     xi = ci.x; yi = ci.y; zi = lz[li];
-                    if (b.anypbc) // neighbor.cpp:139-142
-                        wrap<TRI>(b, xi, yi, zi);
+                    if (b.anypbc) { // neighbor.cpp:139-142
+                        if (TRI || general_tile) { // an atom may have been handed in outside the box: the whole expression
+                            wrap<TRI>(b, xi, yi, zi);
+                        } else { // every staged atom lies inside the box: floor((x - o) / L) = 0, the wrap is o + (x - o) - L * 0 (box.h:158-176)
+                            if (b.pbc[0]) xi = b.o[0] + (xi - b.o[0]);
+                            if (b.pbc[1]) yi = b.o[1] + (yi - b.o[1]);
+                            if (b.pbc[2]) zi = b.o[2] + (zi - b.o[2]);
+                        }
+                    }
                 }
                 if (__builtin_expect(w <= __float_as_uint(W), 0)) { // a pair inside the decision band: this centre again in double precision
 #pragma unroll

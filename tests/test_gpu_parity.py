@@ -1103,29 +1103,39 @@ def _fcc_system(cells, sigma=0.0, seed=0, binary=False):
     return s
 
 
-def test_config1_1M_neighbor_cna_csp_bit_exact_vs_cpu():
-    """configs[1]: 1 M-atom FCC Cu, neighbor + CNA + CSP; labels / rows checked bit for bit against the CPU oracle"""
-    s = _fcc_system(63, 0.2, 1)  # 1 000 188 atoms, rattled so that not every label is FCC
+@pytest.mark.parametrize("sigma,seed", [(0.05, 0), (0.05, 1), (0.20, 0), (0.20, 1)])
+def test_config1_1M_neighbor_cna_csp_bit_exact_vs_cpu(sigma, seed):
+    """configs[1] at its specification: 63^3 cells = 1 000 188 atoms of fcc Cu, pos += Normal(0, sigma) with
+    default_rng(seed); build_neighbor(rc = a = 3.615, max_neigh = 24) — the knife edge: the second shell sits ON the cutoff,
+    counts run from 12 to 18 and more — rows, counts and distances bit for bit against the CPU oracle; fixed-cutoff CNA at
+    rc = 0.854 a = 3.08721 from a list of that cutoff, labels bit for bit; CSP(12) <= 1e-6."""
+    s = _fcc_system(63, sigma, seed)
     x, y, z = (np.ascontiguousarray(s.data[c].to_numpy()) for c in "xyz")
-    rc = 0.854 * 3.615
-    s.build_neighbor(rc, max_neigh=20)
+    assert len(x) == 1000188
+    rc, M = 3.615, 24
+    s.build_neighbor(rc, max_neigh=M)
     v, d, n = (np.asarray(a) for a in (s.verlet_list, s.distance_list, s.neighbor_number))
     V = np.full_like(v, -1); D = np.full_like(d, rc + 1.0); N_ = np.zeros_like(n)
     O.build_neighbor(x, y, z, s.box.box, s.box.origin, s.box.boundary, rc, V, D, N_, 64)
     assert np.array_equal(n, N_) and np.array_equal(v, V) and np.array_equal(d, D)
-    s.cal_common_neighbor_analysis(rc=rc)
+    assert n.min() >= 10 and n.max() <= M and len(np.unique(n)) >= 4  # the knife edge spreads the counts; no row overflows
+    rcna = 0.854 * 3.615
+    s2 = _fcc_system(63, sigma, seed)
+    s2.cal_common_neighbor_analysis(rc=rcna)
+    Vc, Dc, Nc = O.build_neighbor_without_max_neigh(x, y, z, s.box.box, s.box.origin, s.box.boundary, rcna, 64)
     P = np.zeros(len(x), np.int32)
-    O.fcna(x, y, z, s.box.box, s.box.origin, s.box.boundary, V, N_, P, rc, 64)
-    assert np.array_equal(s.data["cna"].to_numpy(), P) and len(np.unique(P)) > 1
+    O.fcna(x, y, z, s.box.box, s.box.origin, s.box.boundary, Vc, Nc, P, rcna, 64)
+    assert np.array_equal(s2.data["cna"].to_numpy(), P)
+    assert (len(np.unique(P)) > 1) == (sigma > 0.1)  # sigma 0.05 leaves every atom fcc, 0.20 does not
     # CSP: the 12-neighbour search of the GPU (checked against the brute-force oracle at small sizes above; the oracle's
     # search is O(N^2)) feeds both implementations of the parameter itself
     from mdapy_amd import _fast_knn
     I = np.zeros((len(x), 12), np.int32); Dk = np.zeros((len(x), 12))
     _fast_knn.knn(x, y, z, s.box.box, s.box.origin, s.box.boundary, 12, I, Dk, 1)
-    s.cal_centro_symmetry_parameter(12)
+    s2.cal_centro_symmetry_parameter(12)
     C = np.zeros(len(x))
     O.get_csp(x, y, z, s.box.box, s.box.origin, s.box.boundary, I, 12, C, 64)
-    assert np.allclose(s.data["csp"].to_numpy(), C, rtol=1e-6, atol=1e-9)
+    assert np.allclose(s2.data["csp"].to_numpy(), C, rtol=1e-6, atol=1e-9)
     assert np.all(np.diff(Dk, axis=1) >= 0) and Dk[:, 0].min() > 1.0
 
 
