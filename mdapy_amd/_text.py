@@ -11,6 +11,16 @@ from . import _lib
 from .devarray import HArray, current_stream_ptr, torch
 
 FLOAT, INT, STR, SKIP = 0, 1, 2, 3
+
+
+class RedoOverflow(OverflowError):
+    """more fields need the host converter than the hand-back buffer holds (a column of long strings, of nan): the caller
+    reads the table with the host tokenizer instead"""
+
+    def __init__(self, n):
+        super().__init__(f"{n} fields need the host converter")
+        self.n = n
+
 _NP = {FLOAT: np.float64, INT: np.int32, STR: np.int64}
 CHUNK = 32 << 20
 
@@ -22,8 +32,10 @@ def stream_to_device(f, nbytes=None, chunk=CHUNK):
     pinned = [t.empty(chunk, dtype=t.uint8).pin_memory() for _ in range(2)]
     busy = [None, None]
     side = t.cuda.Stream()
+    cur = t.cuda.current_stream()
     pieces, total = [], 0
     whole = t.empty(int(nbytes), dtype=t.uint8, device="cuda") if nbytes is not None else None
+    side.wait_stream(cur)  # `whole` may be a block the current stream has only just released: the copies wait for that work
     k = 0
     while True:
         if busy[k] is not None:
@@ -38,7 +50,9 @@ def stream_to_device(f, nbytes=None, chunk=CHUNK):
             if whole is not None:
                 whole[total:total + got].copy_(pinned[k][:got], non_blocking=True)
             else:
-                pieces.append(pinned[k][:got].to("cuda", non_blocking=True))
+                piece = pinned[k][:got].to("cuda", non_blocking=True)
+                piece.record_stream(cur)  # allocated under the side stream, consumed (and freed) on the current one
+                pieces.append(piece)
             ev = t.cuda.Event()
             ev.record(side)
         busy[k] = ev
@@ -68,26 +82,37 @@ def parse_table(text, nrows, kinds, redo_cap=1 << 16):
                                     redo.data_ptr(), int(redo_cap), status.ctypes.data, _lib.DEVICE, current_stream_ptr())
     _lib.check(rc)
     nredo, short, bad, lines = (int(v) for v in status)
+    if lines < nrows and not short:  # (no kernel ran — an empty body — or the count fell short without a row noticing)
+        short = nrows - lines
     if short:
         raise ValueError(f"expected {nrows} atom rows with {ncol} fields each; {short} rows are missing or too short")
     if nredo > redo_cap:
-        raise OverflowError(f"{nredo} fields need the host converter (more than {redo_cap})")
+        raise RedoOverflow(nredo)
     long_strings = {}
     if nredo:
+        # the fields the device handed back (strings over 8 bytes, nan / inf, integers spelled 3.0, 20-digit mantissas):
+        # their bytes in ONE copy to the host, float() / int() there, the values back with one indexed write per column
         todo = redo.dev()[: 2 * nredo].cpu().numpy().reshape(-1, 2)
-        for where, packed in todo:
-            r, c = divmod(int(where), ncol)
-            off, ln = int(packed) >> 16, int(packed) & 0xFFFF
-            if ln == 0xFFFF:  # longer than the length field: take the field up to the next blank
-                tail = bytes(text[off:off + 4096].cpu().numpy())
-                ln = len(tail.split()[0])
-            tok = bytes(text[off:off + ln].cpu().numpy()).decode()
-            if kinds[c] == FLOAT:
-                cols[c].dev()[r] = float(tok)  # raises ValueError for what float() rejects, as the reference does
-            elif kinds[c] == INT:
-                cols[c].dev()[r] = int(tok)
-            else:
+        where = todo[:, 0].astype(np.int64)
+        off = (todo[:, 1] >> 16).astype(np.int64)
+        ln = (todo[:, 1] & 0xFFFF).astype(np.int64)
+        span = np.where(ln == 0xFFFF, 4096, ln)  # longer than the length field: up to the next blank, found on the host
+        starts = np.concatenate([[0], np.cumsum(span)])[:-1]
+        idx = (np.repeat(off - starts, span) + np.arange(int(span.sum()))).clip(max=max(nbytes - 1, 0))
+        blob = text[t.from_numpy(idx).to(text.device)].cpu().numpy().tobytes()
+        rows_of, vals_of = {}, {}
+        for q in range(nredo):
+            r, c = divmod(int(where[q]), ncol)
+            raw = blob[int(starts[q]): int(starts[q] + span[q])]
+            tok = (raw.split()[0] if ln[q] == 0xFFFF else raw).decode()
+            if kinds[c] == STR:
                 long_strings.setdefault(c, {})[r] = tok
+            else:  # float() / int() raise ValueError for what they reject, as the reference's conversion does
+                rows_of.setdefault(c, []).append(r)
+                vals_of.setdefault(c, []).append(float(tok) if kinds[c] == FLOAT else int(tok))
+        for c, rows in rows_of.items():
+            dev = cols[c].dev()
+            dev[t.as_tensor(rows, dtype=t.int64, device=dev.device)] = t.as_tensor(vals_of[c], dtype=dev.dtype, device=dev.device)
     out = [_unpack_strings(col, long_strings.get(c)) if k == STR else col for c, (k, col) in enumerate(zip(kinds, cols))]
     return out, lines
 

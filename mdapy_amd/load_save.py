@@ -72,8 +72,11 @@ def _table(path, offset: int, nrows: int, names: List[str], kinds: List[int]):
             else:
                 f.seek(offset)
             text, _ = _text.stream_to_device(f, size)
-        cols, lines = _text.parse_table(text, nrows, kinds)
-        return dict(zip(names, cols)), lines
+        try:
+            cols, lines = _text.parse_table(text, nrows, kinds)
+            return dict(zip(names, cols)), lines
+        except _text.RedoOverflow:  # e.g. a column of strings longer than 8 bytes on every atom: the host tokenizer reads it
+            del text
     with _open(path) as f:
         f.read(offset) if size is None else f.seek(offset)
         body = f.read()

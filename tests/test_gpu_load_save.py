@@ -114,3 +114,50 @@ def test_ten_million_atom_dump(tmp_path):
     with open(os.path.join(HERE, "..", "gpurun_out", "f2_reader.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)
+
+
+def test_many_host_converted_fields_and_truncated_tables(tmp_path, monkeypatch):
+    """(1) Fields the device hands back — strings over 8 bytes, nan — by the thousand: patched in one batch, same frame as the
+    host tokenizer; (2) more of them than the hand-back buffer holds (a long string on every one of 70 000 atoms): the reader
+    falls back to the host tokenizer instead of failing; (3) a table cut off right after its header raises the reference's
+    'expected N atom rows' error from both tokenizers, compressed or not."""
+    import gzip
+    import mdapy_amd._text as T
+    head = "ITEM: TIMESTEP\n0\nITEM: NUMBER OF ATOMS\n{n}\nITEM: BOX BOUNDS pp pp pp\n0 50\n0 50\n0 50\nITEM: ATOMS id type x y z typelabel\n"
+    rng = np.random.default_rng(3)
+
+    def write(n, label_of, name):
+        xyz = rng.random((n, 3)) * 50.0
+        xyz = xyz.tolist()
+        rows = [f"{i + 1} {1 + i % 2} {xyz[i][0]!r} {'nan' if i % 97 == 0 else repr(xyz[i][1])} {xyz[i][2]!r} {label_of(i)}" for i in range(n)]
+        p = tmp_path / name
+        p.write_text(head.format(n=n) + "\n".join(rows) + "\n")
+        return str(p)
+
+    few = write(5000, lambda i: "Copper-sixty-three" if i % 5 == 0 else "Cu", "few.dump")  # 1000 long strings + 52 nan
+    dev, host = _both(few, monkeypatch)
+    _same(dev, host)
+    assert list(dev[0]["typelabel"].to_numpy()[:6]) == ["Copper-sixty-three", "Cu", "Cu", "Cu", "Cu", "Copper-sixty-three"]
+    assert np.isnan(dev[0]["y"].to_numpy()[::97]).all()
+
+    calls = []
+    real = T.parse_table
+    monkeypatch.setattr(T, "parse_table", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    many = write(70000, lambda i: "Zirconium-ninety", "many.dump")  # 70 000 > the 65 536-entry hand-back buffer
+    dev, host = _both(many, monkeypatch)
+    assert calls  # the device tokenizer was tried
+    _same(dev, host)
+    assert set(dev[0]["typelabel"].to_numpy()) == {"Zirconium-ninety"}
+    monkeypatch.setattr(T, "parse_table", real)
+
+    for gz in (False, True):
+        p = tmp_path / ("cut.dump.gz" if gz else "cut.dump")
+        data = head.format(n=1000).encode()
+        p.write_bytes(gzip.compress(data) if gz else data)
+        for gpu in (True, False):
+            with monkeypatch.context() as m:
+                m.setattr(LS, "DEVICE_MIN_BYTES", 0)
+                if not gpu:
+                    m.setattr(LS, "have_gpu", lambda: False)
+                with pytest.raises(ValueError, match="expected 1000 atom rows"):
+                    LS.read_file(str(p))
