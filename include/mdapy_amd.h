@@ -272,7 +272,7 @@ int mdh_repeat_cell(double *new_pos, const double *old_box9_host, const double *
  * verlet (N,M) int32 rows sorted by distance (the caller passes the 18 nearest neighbours); types may be NULL.
  * output (N,ncol>=8) f64: type, alloy ordering, rmsd, interatomic distance, orientation quaternion w x y z;
  * ptm_indices (N,nind) i32: matched atoms in template order, -1 padded (:296-305).
- * Built: sc, fcc, hcp, ico, bcc.  Requesting dcub / dhex / graphene returns MDH_ERR_ARG (not built yet). */
+ * All eight structure types of the library are built: sc, fcc, hcp, ico, bcc, and the two-shell ones dcub, dhex, graphene. */
 int mdh_ptm(const char *structure, const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
             const double *origin3_host, const int *boundary3_host, const int *verlet, int64_t M, const int *types,
             double rmsd_threshold, double *output, int ncol, int *ptm_indices, int nind, int space, void *stream);

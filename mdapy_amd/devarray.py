@@ -97,7 +97,7 @@ class HArray:
         if self._host is None:
             h = self._dev.cpu().numpy()
             h.setflags(write=False)
-            self._host = h
+            self._host = mark_frozen(h)
         return self._host
 
     def __array__(self, dtype=None, copy=None):
@@ -228,27 +228,59 @@ def empty(shape, dtype):
 # ---------------------------------------------------------------------------
 # marshalling
 # ---------------------------------------------------------------------------
-_mirrors = []  # [(weak reference to an immutable host array, its copy in HBM)]
+import threading
+import weakref
+
+_cache_lock = threading.Lock()  # the C side takes mutexes for multi-threaded callers; so do the caches in front of it
+_frozen = {}  # id -> (weak reference, fingerprint): arrays THIS package copied and froze (frame columns, cached species codes)
+_mirrors = []  # [(weak reference to such an array, its copy in HBM)]
+
+
+def _fingerprint(arr):
+    """64 samples spread over the array: enough to notice that a frozen array was thawed, rewritten and frozen again"""
+    flat = arr.reshape(-1)
+    step = max(1, flat.shape[0] // 61)
+    return (arr.shape, arr.dtype.str, flat[::step][:64].tobytes())
+
+
+def mark_frozen(arr):
+    """register a read-only array that the package itself made (only those are trusted not to change: identity-keyed caches —
+    HBM mirrors here, species codes in policy — serve nobody else's arrays)"""
+    try:
+        with _cache_lock:
+            if len(_frozen) > 256:
+                for k in [k for k, (r, _) in _frozen.items() if r() is None]:
+                    del _frozen[k]
+            _frozen[id(arr)] = (weakref.ref(arr), _fingerprint(arr))
+    except TypeError:
+        pass
+    return arr
+
+
+def frozen_by_us(arr):
+    with _cache_lock:
+        hit = _frozen.get(id(arr))
+    return hit is not None and hit[0]() is arr and not arr.flags.writeable and hit[1] == _fingerprint(arr)
 
 
 def _mirror_of(arr):
-    """HBM copy of a host array.  Large READ-ONLY arrays (frame columns, the species codes policy.label_codes caches) cannot
-    change under us, so their copy is kept while the array lives and the next call that is handed the same array does not
-    cross PCIe again."""
-    if arr.flags.writeable or not arr.flags.owndata or arr.nbytes < (1 << 20):  # (a read-only VIEW may still change through its base)
+    """HBM copy of a host array.  Large read-only arrays that the package froze itself (frame columns, the species codes
+    policy.label_codes caches) do not change under us, so their copy is kept while the array lives and the next call that is
+    handed the same array does not cross PCIe again."""
+    if arr.nbytes < (1 << 20) or not arr.flags.owndata or not frozen_by_us(arr):  # (a read-only VIEW may still change through its base)
         return HArray.from_numpy(arr)
-    import weakref
-
-    for k in range(len(_mirrors) - 1, -1, -1):
-        ref, dev = _mirrors[k]
-        if ref() is None:
-            del _mirrors[k]
-        elif ref() is arr:
-            return dev
+    with _cache_lock:
+        for k in range(len(_mirrors) - 1, -1, -1):
+            ref, dev = _mirrors[k]
+            if ref() is None:
+                del _mirrors[k]
+            elif ref() is arr:
+                return dev
     dev = HArray.from_numpy(arr)
     try:
-        _mirrors.append((weakref.ref(arr), dev))
-        del _mirrors[:-16]
+        with _cache_lock:
+            _mirrors.append((weakref.ref(arr), dev))
+            del _mirrors[:-16]
     except TypeError:
         pass
     return dev

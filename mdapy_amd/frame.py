@@ -34,8 +34,11 @@ class Column:
         if a.dtype.kind in "iuf":
             a = np.ascontiguousarray(a)
         if a.flags.writeable:  # never freeze (or alias) the caller's own buffer
+            from .devarray import mark_frozen
+
             a = a.copy()
             a.setflags(write=False)
+            mark_frozen(a)
         self._host_arr = a
         self._dev = None
 

@@ -98,17 +98,22 @@ def label_codes(labels):
     raw = np.asarray(labels)
     if raw.size == 0:
         return [], np.zeros(0, np.int32)
-    if not raw.flags.writeable:
-        for ref, names, codes in _label_cache:
-            if ref() is raw:
-                return list(names), codes
+    from .devarray import _cache_lock, frozen_by_us, mark_frozen
+
+    if frozen_by_us(raw):  # a column the package froze itself: nobody else's array is trusted to stay what it was
+        with _cache_lock:
+            for ref, names, codes in _label_cache:
+                if ref() is raw:
+                    return list(names), codes
         names, codes = _label_codes(raw)
         codes.setflags(write=False)  # shared by every later call on the same column (and mirrored in HBM once, devarray._mirror_of)
+        mark_frozen(codes)
         import weakref
 
         try:
-            _label_cache.append((weakref.ref(raw), names, codes))
-            del _label_cache[:-4]
+            with _cache_lock:
+                _label_cache.append((weakref.ref(raw), names, codes))
+                del _label_cache[:-4]
         except TypeError:
             pass
         return list(names), codes
@@ -117,7 +122,7 @@ def label_codes(labels):
 
 def label_population(codes, kinds):
     """atoms per species code; cached with the codes of an immutable column"""
-    for ref, names, cached in _label_cache:
+    for ref, names, cached in list(_label_cache):
         if cached is codes:
             if len(_population) > 8:
                 _population.clear()

@@ -285,7 +285,7 @@ class System:
             if name in cells.__dict__:
                 setattr(self, name, getattr(cells, name))
 
-    def cal_structure_factor(self, k_min, k_max, nbins, cal_partial=False, atomic_form_factors=False, mode="debye",
+    def cal_structure_factor(self, k_min, k_max, nbins, cal_partial=False, atomic_form_factors=False, mode="direct",
                              rc=None, nbin_rdf=200, window=False):
         """-> StructureFactor with ``k``, ``Sk``, ``Sk_partial``"""
         job = StructureFactor(self.data, self.box, k_min, k_max, nbins, cal_partial, atomic_form_factors, mode, rc,

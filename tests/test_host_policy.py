@@ -96,3 +96,27 @@ def test_host_layer_is_not_a_transcription_of_the_reference():
     reference file stays below 0.35 (tools/overlap_check.py)"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "overlap_check.py"), "0.35"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
+
+
+def test_identity_caches_serve_only_arrays_the_package_froze():
+    """devarray.frozen_by_us / policy.label_codes: a caller's own read-only array is never cached by identity (it may be
+    thawed and rewritten); a column the package froze is, and a thaw-rewrite-freeze of even that one is noticed."""
+    import numpy as np
+    from mdapy_amd import devarray, policy
+    from mdapy_amd.frame import Frame
+
+    mine = np.arange(300000, dtype=np.int32) % 3
+    mine.setflags(write=False)
+    assert not devarray.frozen_by_us(mine)
+    names, codes = policy.label_codes(mine)
+    mine.setflags(write=True); mine[:] = 7; mine.setflags(write=False)
+    assert policy.label_codes(mine)[0] == [7]  # recomputed, not served from a cache keyed by the array's identity
+
+    col = Frame({"type": np.arange(300000, dtype=np.int32) % 3})["type"].to_numpy()
+    assert devarray.frozen_by_us(col)
+    n1, c1 = policy.label_codes(col)
+    n2, c2 = policy.label_codes(col)
+    assert c2 is c1 and n1 == [0, 1, 2]  # the cached codes
+    col.setflags(write=True); col[:] = 5; col.setflags(write=False)  # (reaching into the frame's own array)
+    assert not devarray.frozen_by_us(col)
+    assert policy.label_codes(col)[0] == [5]
