@@ -231,6 +231,8 @@ def main():
     box = mp.Box(np.diag([A_CU * cells * world, A_CU * cells, A_CU * cells]))
     dec = SlabDecomposition(box, rank, world, axis=0)
     bx = (box.box, box.origin, box.boundary)
+    if world > 1:  # room behind the owned atoms: the ghosts of every step are appended there, no concatenation of the slab's arrays
+        x, y, z, gid = (dec.with_room(a, 0.05) for a in (x, y, z, gid))
 
     def sync():
         torch.cuda.synchronize()

@@ -147,6 +147,13 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
                             const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                             int64_t max_neigh, int fill_pads, int *pattern, const int64_t *key, int space, void *stream);
 
+/* Decomposed systems (multi-GPU extension): a promise that every atom of the NEXT neighbor build of this thread —
+ * a rank's slab and its halo, in the global box — has its wrapped fractional coordinate along `axis` in [frac_lo, frac_hi]
+ * (the interval may leave [0,1): a slab at the periodic seam).  The passes over ALL cells of the global grid then run over the
+ * window's planes only; results are the same.  Only axis 0 of orthogonal boxes is taken (otherwise ignored).  An atom outside
+ * the window breaks the promise: detected on the device, reported as MDH_ERR_ARG by this thread's next build. */
+int mdh_hint_cell_window(int axis, double frac_lo, double frac_hi);
+
 /* Halo selection of the slab decomposition (multi-GPU extension): one pass over the owned atoms; up / down (n) i32
  * receive the indices of the atoms whose wrapped fractional coordinate f along the decomposed axis (hi3 = that column of the
  * inverse box) satisfies f >= up_from / f < down_below, counts_host[2] their numbers.  Order of the indices: unspecified.
@@ -156,6 +163,14 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
 int mdh_slab_halo_select(const double *x, const double *y, const double *z, int64_t n, const double *origin3_host,
                          const double *hi3_host, double up_from, double down_below, int *up, int *down, int64_t *counts_host,
                          const int64_t *gid, double *up_pack, double *down_pack, int64_t capacity, int space, void *stream);
+/* The same selection packed into the two messages of the halo exchange, without a word to the host: msg_up / msg_down are
+ * device buffers of 1 + (4 + nextra) * cap doubles — [0] the number of selected atoms, then rows x, y, z, the nextra (<= 4)
+ * extra f64 columns, the global id, `cap` columns each.  A count above cap: the message holds the first cap atoms only
+ * (both ends see it in the header).  Device memory only; nothing synchronises. */
+int mdh_slab_halo_messages(const double *x, const double *y, const double *z, int64_t n, const double *origin3_host,
+                           const double *hi3_host, double up_from, double down_below, const int64_t *gid,
+                           const double *const *extras_host_array_of_device_pointers, int nextra, double *msg_up,
+                           double *msg_down, int64_t cap, void *stream);
 
 /*
  * first half of _neighbor.build_neighbor_without_max_neigh  src/neighbor.cpp:189-349:

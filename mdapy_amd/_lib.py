@@ -48,6 +48,8 @@ _SIGNATURES = {
     "mdh_debug_parse_double": [C.c_char_p, i64, vp],
     "mdh_build_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, cint, vp],
     "mdh_slab_halo_select": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, cint, vp],
+    "mdh_hint_cell_window": [cint, dbl, dbl],
+    "mdh_slab_halo_messages": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, cint, vp, vp, i64, vp],
     "mdh_build_neighbor_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, cint, vp],
     "mdh_build_neighbor_fcna": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, vp, cint, vp],
     "mdh_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, cint, vp],

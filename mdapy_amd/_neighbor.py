@@ -27,6 +27,13 @@ def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_lis
     c.done(rc_)
 
 
+def hint_cell_window(axis, frac_lo, frac_hi):
+    """promise to the next ``build_neighbor`` of this thread: every atom's wrapped fractional coordinate along ``axis`` lies in
+    [frac_lo, frac_hi] (a rank's slab and halo in the global box): the passes over all cells of the global grid run over that
+    window's planes only (mdh_hint_cell_window).  Same results."""
+    _lib.check(_lib.lib().mdh_hint_cell_window(int(axis), float(frac_lo), float(frac_hi)))
+
+
 def build_neighbor_fcna(x, y, z, box, origin, boundary, rc, verlet_list, distance_list, neighbor_number, pattern, num_t=1,
                         fill_pads=False, key=None):
     """``build_neighbor`` (src/neighbor.cpp:351) and ``fcna`` (src/cna.cpp:429) with the same ``rc`` in one pass over the

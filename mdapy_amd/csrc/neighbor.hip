@@ -238,6 +238,53 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
     mvs[p] = mv[i];
 }
 
+// ----------------------------------------------------------------------------
+// Cell window (decomposed systems).  A rank's atoms — its slab and the halo — occupy a few planes of the GLOBAL cell grid the
+// neighbor build works on (global box, global cells: the rows equal the undivided system's), and the passes over ALL cells
+// (bin counters zeroed, three scan kernels, the in-cell sort) then cost more than the passes over the atoms.  The caller, who
+// knows where its atoms are, promises a window of fractional coordinates along one axis (mdh_hint_cell_window, consumed by
+// the next build on this thread); those passes run over the window's planes (one more on each side) only, and the prefix
+// array outside them is filled with the constants a full scan would have left there, so that every reader of cell_start is
+// served as before.  An atom binned outside the promised window breaks the promise: counted on the device, reported by
+// the next call of this thread that builds a grid.
+// ----------------------------------------------------------------------------
+struct CellWindow { int axis; double lo, hi; bool set; };
+static thread_local CellWindow g_window{0, 0.0, 0.0, false};
+static thread_local int *g_window_violations = nullptr; // pinned host word of the previous windowed build
+
+__global__ __launch_bounds__(256) void k_fill_range(int *__restrict__ out, int64_t a, int64_t b, int v)
+{
+    const int64_t i = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b) out[i] = v;
+}
+
+// out[a..b) = *v (a value that is on the device only)
+__global__ __launch_bounds__(256) void k_fill_from(int *__restrict__ out, int64_t a, int64_t b, const int *__restrict__ v)
+{
+    const int64_t i = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b) out[i] = *v;
+}
+
+// out[a..b) += *v  (v outside [a, b)); the entry `skip`, if in range, is left alone
+__global__ __launch_bounds__(256) void k_add_from(int *__restrict__ out, int64_t a, int64_t b, const int *__restrict__ v, int64_t skip)
+{
+    const int64_t i = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b && i != skip) out[i] += *v;
+}
+
+// atoms binned outside planes [p0, p1) u [p2, p3) of axis 0 (cells are a0-major)
+__global__ __launch_bounds__(256) void k_window_check(const int *__restrict__ cell_id, int64_t N, int64_t plane, int p0, int p1, int p2,
+                                                      int p3, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool out = false;
+    if (i < N) {
+        const int a0 = (int)(cell_id[i] / plane);
+        out = !((a0 >= p0 && a0 < p1) || (a0 >= p2 && a0 < p3));
+    }
+    if (__any(out) && (threadIdx.x & 63) == 0) atomicAdd(bad, 1);
+}
+
 int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
 {
     double nc_total = 1.0;
@@ -280,7 +327,37 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     if (sc.failed())
         return sc.error();
 
-    MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * (size_t)g.ncell, st));
+    // window of planes along axis 0 (orthogonal boxes, rc-wide cells): [p0, p1) and, when it wraps around the ring, [p2, p3)
+    int p0 = 0, p1 = g.nc[0], p2 = 0, p3 = 0;
+    bool windowed = false;
+    if (g_window_violations && *(volatile int *)g_window_violations != 0) {
+        *g_window_violations = 0;
+        g_window.set = false;
+        set_error("an earlier neighbor build on this thread found atoms outside the cell window it had been promised (mdh_hint_cell_window)");
+        return MDH_ERR_ARG;
+    }
+    if (g_window.set) {
+        const CellWindow w = g_window;
+        g_window.set = false; // one build
+        if (w.axis == 0 && !b.tri && g.mode == 0 && g.nc[0] >= 16 && w.hi > w.lo && w.hi - w.lo < 0.75) {
+            const double L = b.h[0];
+            int lo = (int)std::floor(w.lo * L * g.rc_inv) - 1, hi = (int)std::ceil(w.hi * L * g.rc_inv) + 1; // one plane of margin
+            if (hi - lo < g.nc[0] - 2) {
+                windowed = true;
+                if (lo < 0) { p0 = 0; p1 = std::min(hi, g.nc[0]); p2 = g.nc[0] + lo; p3 = g.nc[0]; }         // wraps below
+                else if (hi > g.nc[0]) { p0 = 0; p1 = hi - g.nc[0]; p2 = lo; p3 = g.nc[0]; }                   // wraps above
+                else { p0 = lo; p1 = hi; p2 = p3 = 0; }
+                if (p2 < p1 && p3 > p2) { windowed = false; p0 = 0; p1 = g.nc[0]; p2 = p3 = 0; }               // (the pieces meet: everything)
+            }
+        }
+    }
+    const int64_t plane = (int64_t)g.nc[1] * g.nc[2];
+    if (windowed) {
+        MDH_HIP(hipMemsetAsync(cell_count + p0 * plane, 0, sizeof(unsigned) * (size_t)((p1 - p0) * plane), st));
+        if (p3 > p2) MDH_HIP(hipMemsetAsync(cell_count + p2 * plane, 0, sizeof(unsigned) * (size_t)((p3 - p2) * plane), st));
+    } else {
+        MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * (size_t)g.ncell, st));
+    }
     MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 4, st));
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
@@ -288,12 +365,51 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv);
     else
         hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv);
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
+    if (!windowed) {
+        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
+    } else {
+        // the pieces in index order: [p0, p1) then [p2, p3); a piece is scanned on its own, the atoms before it added by the
+        // fill / by a second add pass; cell_start elsewhere = what a full scan leaves: the atoms binned so far
+        int *cnt2 = sc.alloc_n<int>(2);
+        if (sc.failed())
+            return sc.error();
+        const int64_t a0 = p0 * plane, a1 = p1 * plane, b0 = p2 * plane, b1 = p3 * plane;
+        auto scan_piece = [&](int64_t from, int64_t to) {
+            const int64_t n = to - from, nb = (n + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+            hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, cell_count + from, cg.cell_start + from, block_sum, n);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nb);
+            hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, cg.cell_start + from, block_sum, n, -1); // [to] = the piece's total
+        };
+        if (a0 > 0) hipLaunchKernelGGL(k_fill_range, dim3(grid_for(a0, 256)), dim3(256), 0, st, cg.cell_start, (int64_t)0, a0, 0);
+        scan_piece(a0, a1);
+        if (b1 > b0) {
+            // second piece: offsets start at the first piece's total, which sits on the device in cell_start[a1]
+            hipLaunchKernelGGL(k_fill_from, dim3(grid_for(b0 - a1 - 1, 256) + 1), dim3(256), 0, st, cg.cell_start, a1 + 1, b0, cg.cell_start + a1);
+            scan_piece(b0, b1);
+            hipLaunchKernelGGL(k_add_from, dim3(grid_for(b1 - b0 + 1, 256)), dim3(256), 0, st, cg.cell_start, b0, b1 + 1, cg.cell_start + a1, (int64_t)-1);
+            if (b1 < g.ncell) hipLaunchKernelGGL(k_fill_range, dim3(grid_for(g.ncell - b1, 256)), dim3(256), 0, st, cg.cell_start, b1 + 1, g.ncell + 1, (int)N);
+        } else if (a1 < g.ncell) {
+            hipLaunchKernelGGL(k_fill_range, dim3(grid_for(g.ncell - a1, 256)), dim3(256), 0, st, cg.cell_start, a1 + 1, g.ncell + 1, (int)N);
+        }
+        // the promise is checked on the device and read back by the next build of this thread
+        if (!g_window_violations) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_window_violations), sizeof(int), hipHostMallocDefault));
+        *g_window_violations = 0;
+        MDH_HIP(hipMemsetAsync(cnt2, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_window_check, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, N, plane, p0, p1, p2, p3, cnt2);
+        MDH_HIP(hipMemcpyAsync(g_window_violations, cnt2, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
-    if (sort_desc)
-        hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, sort_key);
+    if (sort_desc) {
+        if (!windowed) {
+            hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, sort_key);
+        } else {
+            hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p1 - p0) * plane, 256)), dim3(256), 0, st, cg.cell_start + p0 * plane, cg.order, (p1 - p0) * plane, sort_key);
+            if (p3 > p2)
+                hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key);
+        }
+    }
     hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
@@ -771,6 +887,12 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
         MDH_HIP(hipGetLastError());
     }
     return sc.finish(space);
+}
+
+int mdh_hint_cell_window(int axis, double frac_lo, double frac_hi)
+{
+    g_window = CellWindow{axis, frac_lo, frac_hi, true};
+    return MDH_OK;
 }
 
 int mdh_debug_set_neighbor_variant(int v)

@@ -51,9 +51,84 @@ __global__ __launch_bounds__(256) void k_slab_select(const double *__restrict__ 
     }
 }
 
+// The same selection written straight into the two messages of the exchange (device memory, wire layout: [0] = number of
+// atoms as a double, then `width` rows of `cap` columns — x, y, z, the extra per-atom columns, the global id last), and no
+// word goes to the host: the receiver reads the count out of the message it gets.
+struct SlabExtras { const double *p[4]; int n; };
+__global__ __launch_bounds__(256) void k_slab_messages(const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ z, int64_t n, double o0, double o1, double o2,
+                                                       double h0, double h1, double h2, double up_from, double down_below,
+                                                       int *__restrict__ counts, const int64_t *__restrict__ gid, SlabExtras ex,
+                                                       double *__restrict__ msg_up, double *__restrict__ msg_down, int cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_up = false, is_down = false;
+    if (i < n) {
+        double f = (x[i] - o0) * h0 + (y[i] - o1) * h1 + (z[i] - o2) * h2;
+        f = f - floor(f);
+        if (f >= 1.0) f = f - 1.0;
+        is_up = f >= up_from;
+        is_down = f < down_below;
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mu = __ballot(is_up), md = __ballot(is_down);
+    int bu = 0, bd = 0;
+    if (lane == 0) {
+        if (mu) bu = atomicAdd(&counts[0], __popcll(mu));
+        if (md) bd = atomicAdd(&counts[1], __popcll(md));
+    }
+    bu = __shfl(bu, 0, 64);
+    bd = __shfl(bd, 0, 64);
+    auto put = [&](double *msg, int s) {
+        if (s >= cap) // (the counter keeps running: the count in the header tells both ends that the message was too small)
+            return;
+        double *o = msg + 1 + s;
+        o[0] = x[i];
+        o[(int64_t)cap] = y[i];
+        o[2 * (int64_t)cap] = z[i];
+        for (int k = 0; k < ex.n; ++k) o[(3 + k) * (int64_t)cap] = ex.p[k][i];
+        o[(3 + ex.n) * (int64_t)cap] = (double)gid[i];
+    };
+    if (is_up) put(msg_up, bu + __popcll(mu & ((1ull << lane) - 1ull)));
+    if (is_down) put(msg_down, bd + __popcll(md & ((1ull << lane) - 1ull)));
+}
+
+__global__ void k_slab_headers(const int *__restrict__ counts, double *__restrict__ msg_up, double *__restrict__ msg_down)
+{
+    msg_up[0] = (double)counts[0];
+    msg_down[0] = (double)counts[1];
+}
+
 } // namespace mdh
 
 using namespace mdh;
+
+// msg_up / msg_down: device memory, 1 + (4 + nextra) * cap doubles each.  extras: nextra (<= 4) device pointers to f64 columns
+// of the owned atoms.  Everything stays on the stream: no synchronisation.
+extern "C" int mdh_slab_halo_messages(const double *x, const double *y, const double *z, int64_t n, const double *origin3,
+                                      const double *hi3, double up_from, double down_below, const int64_t *gid,
+                                      const double *const *extras, int nextra, double *msg_up, double *msg_down, int64_t cap,
+                                      void *stream)
+{
+    if (n < 0 || n >= 2147483647LL || cap < 0 || cap >= 2147483647LL || nextra < 0 || nextra > 4 || !gid || !msg_up || !msg_down) {
+        set_error("mdh_slab_halo_messages: bad arguments");
+        return MDH_ERR_ARG;
+    }
+    Scope sc(stream);
+    hipStream_t st = sc.stream();
+    int *dc = sc.alloc_n<int>(2);
+    if (sc.failed())
+        return sc.error();
+    MDH_HIP(hipMemsetAsync(dc, 0, 2 * sizeof(int), st));
+    SlabExtras ex{{nullptr, nullptr, nullptr, nullptr}, nextra};
+    for (int k = 0; k < nextra; ++k) ex.p[k] = extras[k];
+    if (n > 0)
+        hipLaunchKernelGGL(k_slab_messages, dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, z, n, origin3[0], origin3[1], origin3[2],
+                           hi3[0], hi3[1], hi3[2], up_from, down_below, dc, gid, ex, msg_up, msg_down, (int)cap);
+    hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, st, dc, msg_up, msg_down);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
 
 // up / down: (capacity) i32 each; counts_host[0..1] receive the numbers of selected atoms — if one of them exceeds `capacity`
 // the buffers hold the first `capacity` selections only and the caller repeats the call with larger ones (a slab's halo is a

@@ -51,6 +51,10 @@ class SlabDecomposition:
         self.left = (rank - 1) % world
         self.right = (rank + 1) % world
         self._cap = 0  # rows of the halo pack buffers (grown on demand, sized from the last exchange)
+        self._msg_cap = {}   # (halo, columns) -> atoms a halo message holds, agreed by all ranks (fast exchange)
+        self._msg_buf = {}   # (columns, cap, device) -> the four message buffers
+        self._roomy = {}     # data_ptr -> (weak reference, rows of spare room) of tensors made by with_room()
+        self._own_mask = None
 
     # -- wire -----------------------------------------------------------------
     def _host_staged(self):
@@ -150,6 +154,115 @@ class SlabDecomposition:
             raise ValueError(f"slab thickness {thick / self.world:.3f} is smaller than the halo {halo}: use fewer ranks")
         return h
 
+    # -- the fast exchange: one message per direction, one host read -------------------------------------------------
+    def with_room(self, tensor, fraction: float = 0.25):
+        """a copy of a 1-D tensor of owned atoms with spare rows behind it: exchange_halo(sort=False) then appends the ghosts
+        in place instead of concatenating (a copy of every owned column per step otherwise).  Only tensors made here are
+        ever written behind their end."""
+        import weakref
+
+        t = _torch()
+        n = int(tensor.shape[0])
+        room = max(1024, int(n * fraction))
+        buf = t.empty(n + room, dtype=tensor.dtype, device=tensor.device)
+        buf[:n].copy_(tensor)
+        out = buf[:n]
+        self._roomy[out.data_ptr()] = (weakref.ref(out), room)
+        return out
+
+    def _room_behind(self, tensor):
+        hit = self._roomy.get(tensor.data_ptr())
+        return hit[1] if hit is not None and hit[0]() is tensor else 0
+
+    def _owned_mask(self, n_tot, n_owned, dev):
+        t = _torch()
+        key = (n_tot, n_owned, str(dev))
+        if self._own_mask is None or self._own_mask[0] != key:
+            self._own_mask = (key, t.arange(n_tot, device=dev) < n_owned)
+        return self._own_mask[1]
+
+    def reset_halo_capacity(self):
+        """forget the agreed message sizes (call on all ranks; the next exchange agrees on new ones)"""
+        self._msg_cap.clear()
+        self._msg_buf.clear()
+
+    def _exchange_fast(self, x, y, z, gid, cols, h, halo):
+        """device tensors, ghosts appended behind the owned atoms.  The layers are selected and packed into the two outgoing
+        messages on the device (slab.hip), each message carries its atom count in its first word, and the host reads the four
+        counts — sent and received — in ONE copy after the ring: no count round trip, no second synchronisation.  The message
+        size is agreed by all ranks (largest layer + 25 %) the first time a (halo, columns) pair is seen."""
+        import ctypes
+
+        from . import _lib
+
+        t = _torch()
+        dev = x.device
+        n_owned = int(x.shape[0])
+        width = len(cols) + 1
+        lo, hi = self.rank / self.world, (self.rank + 1) / self.world
+        sig = (float(halo), width)  # (the same on every rank: all ranks agree on a size in the same call)
+        cap = self._msg_cap.get(sig)
+        if cap is None:  # agree on a size: every rank's largest layer, one all-reduce, once per signature
+            up, down = self._select_device(x, y, z, hi - h, lo + h)
+            need = t.tensor([max(int(up.shape[0]), int(down.shape[0]))], dtype=t.int64, device=dev)
+            import torch.distributed as dist
+
+            if need.is_cuda and self._host_staged():
+                need = need.cpu()
+            dist.all_reduce(need, op=dist.ReduceOp.MAX, group=self.group)
+            cap = int(need.item())
+            cap = cap + cap // 4 + 64
+            self._msg_cap[sig] = cap
+        key = (width, cap, str(dev))
+        bufs = self._msg_buf.get(key)
+        if bufs is None:
+            if len(self._msg_buf) > 4:
+                self._msg_buf.clear()
+            bufs = tuple(t.empty(1 + width * cap, dtype=t.float64, device=dev) for _ in range(4))
+            self._msg_buf[key] = bufs
+        send_r, send_l, recv_l, recv_r = bufs
+        o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
+        hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
+        ex = [c.contiguous() for c in cols[3:]]
+        exp = (ctypes.c_void_p * max(len(ex), 1))(*[e.data_ptr() for e in ex]) if ex else None
+        g = gid.contiguous()
+        _lib.check(_lib.lib().mdh_slab_halo_messages(x.data_ptr(), y.data_ptr(), z.data_ptr(), n_owned, o.ctypes.data, hi3.ctypes.data,
+                                                     float(hi - h), float(lo + h), g.data_ptr(), exp, len(ex), send_r.data_ptr(),
+                                                     send_l.data_ptr(), cap, int(t.cuda.current_stream().cuda_stream)))
+        self._ring(send_r, send_l, recv_l, recv_r)
+        heads = t.stack([send_r[0], send_l[0], recv_l[0], recv_r[0]]).cpu().tolist()  # the one device-to-host read
+        if max(heads) > cap:
+            self._msg_cap.pop(sig, None)
+            raise RuntimeError(f"halo message of {int(max(heads))} atoms does not fit the agreed {cap}: the system changed since the "
+                               "size was agreed — call reset_halo_capacity() on all ranks and repeat the step")
+        nl, nr = int(heads[2]), int(heads[3])
+        n_ghost = nl + nr
+        n_tot = n_owned + n_ghost
+
+        def row(msg, r, cnt):
+            return msg[1 + r * cap: 1 + r * cap + cnt]
+
+        full = []
+        for k, c in enumerate(list(cols) + [gid]):
+            last = k == len(cols)
+            if self._room_behind(c) >= n_ghost:  # ghosts written behind the owned atoms, in place
+                whole = t.empty(0, dtype=c.dtype, device=dev).set_(c.untyped_storage(), c.storage_offset(), (n_tot,), (1,))
+            else:
+                whole = t.empty(n_tot, dtype=c.dtype, device=dev)
+                whole[:n_owned].copy_(c)
+            whole[n_owned:n_owned + nl].copy_(row(recv_l, k, nl))  # (the id row converts f64 -> i64 in the copy)
+            whole[n_owned + nl:].copy_(row(recv_r, k, nr))
+            full.append(whole)
+            del last
+        return LocalDomain(full[0], full[1], full[2], full[-1], self._owned_mask(n_tot, n_owned, dev), n_owned, tuple(full[3:-1]))
+
+    def hint_window(self, halo: float, like=None):
+        """tell the next neighbor build where this rank's atoms are (slab + halo along the decomposed axis): its passes over the
+        cells of the GLOBAL grid then cover that window only"""
+        if self.world > 2 and (like is None or getattr(like, "is_cuda", False)) and hasattr(kernels.neighbor, "hint_cell_window"):
+            h = self.halo_fraction(halo)
+            kernels.neighbor.hint_cell_window(self.axis, self.rank / self.world - h, (self.rank + 1) / self.world + h)
+
     # -- halo exchange --------------------------------------------------------
     def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True, extra=()) -> LocalDomain:
         """x,y,z (f64) and gid (i64) of the OWNED atoms (1-D tensors on this rank's device).
@@ -170,6 +283,8 @@ class SlabDecomposition:
             return LocalDomain(cols[0], cols[1], cols[2], gid, t.ones(n_owned, dtype=t.bool, device=dev), n_owned, tuple(cols[3:]))
         h = self.halo_fraction(halo)
         lo, hi = self.rank / self.world, (self.rank + 1) / self.world
+        if x.is_cuda and not sort and self.world > 2 and len(extra) <= 4:
+            return self._exchange_fast(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, h, halo)
         if x.is_cuda:  # selection and packing in one fused pass (slab.hip); the torch expressions below are its definition
             up, down, rows_r, rows_l = self._select_device(x, y, z, hi - h, lo + h, gid)
             send_r, send_l = rows_r.t(), rows_l.t()  # rows x, y, z, id
@@ -263,6 +378,7 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     dist = t.empty((n, max_neigh), dtype=t.float64, device=dom.x.device)
     nn = t.empty((n,), dtype=t.int32, device=dom.x.device)
     pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
+    dec.hint_window(rc, dom.x)
     kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
                              key=dom.gid if dec.world > 1 else None)
     kernels.cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
@@ -379,6 +495,7 @@ def steinhardt_step(dec: SlabDecomposition, x, y, z, gid, llist, rc: float, max_
     verlet = t.empty((n, max_neigh), dtype=t.int32, device=dev)
     dist = t.empty((n, max_neigh), dtype=t.float64, device=dev)
     nn = t.empty((n,), dtype=t.int32, device=dev)
+    dec.hint_window((2.0 if average else 1.0) * rc, dom.x)
     kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
                              key=dom.gid if dec.world > 1 else None)
     ll = np.ascontiguousarray(np.asarray(llist), dtype=np.int32)
