@@ -522,6 +522,29 @@ def rdf_counts_step(dec: SlabDecomposition, dom: LocalDomain, verlet, dist, nn, 
     return dec.all_reduce_(g)
 
 
+def rdf_streaming_step(dec: SlabDecomposition, x, y, z, gid, types, ntype: int, rc: float, nbin: int):
+    """Pair counts (Nt,Nt,nbin) of the WHOLE system from the streaming kernel (`_rdf._rdf_streaming`,
+    radial_distribution_function.cpp:143-317 — the practical one at cutoffs where a list would be a hundred columns wide):
+    owned centres x owned + ghost candidates.  One halo of rc carries the ghosts and their types; the ghosts are given the
+    species codes Nt .. 2 Nt - 1, the kernel runs once with 2 Nt species, and of its (2 Nt, 2 Nt, nbin) integer counts the rows
+    of owned centres are kept and the two column halves added — no change to the kernel, every ordered pair with an owned
+    centre counted exactly once in the whole job; one all-reduce of the integers (exact in f64 below 2^53).
+    ``types`` int32 0-based per OWNED atom.  Returns the counts; the normalisation is the caller's, as for the list kernels."""
+    t = _torch()
+    if dec.world == 1:
+        g = t.zeros((ntype, ntype, nbin), dtype=t.float64, device=x.device)
+        b = dec.box
+        kernels.rdf._rdf_streaming(x, y, z, types.to(t.int32).contiguous(), b.box, b.origin, b.boundary, g, rc, nbin)
+        return g
+    dom = dec.exchange_halo(x, y, z, gid, rc, sort=False, extra=(types,))
+    b = dec.box
+    ty2 = (dom.extra[0].to(t.int32) + t.where(dom.owned, 0, ntype).to(t.int32)).contiguous()
+    g2 = t.zeros((2 * ntype, 2 * ntype, nbin), dtype=t.float64, device=dom.x.device)
+    kernels.rdf._rdf_streaming(dom.x, dom.y, dom.z, ty2, b.box, b.origin, b.boundary, g2, rc, nbin)
+    g = (g2[:ntype, :ntype] + g2[:ntype, ntype:]).contiguous()
+    return dec.all_reduce_(g)
+
+
 def wcp_step(dec: SlabDecomposition, dom: LocalDomain, verlet, nn, types, ntype: int):
     """Warren-Cowley matrix of the whole system: Z_mn / Z_m / atoms-per-type counted over owned rows
     (`mdh_wcp_counts`), one int64 all-reduce, then warren_cowley_parameter.cpp:57-75."""

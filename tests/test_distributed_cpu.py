@@ -180,7 +180,9 @@ def _worker_analyses(rank, world, port, q):
         K.csp = _types.SimpleNamespace(get_csp=wrap(lambda x, y, z, b, o, p, v, n, out, nt=1: O.get_csp(x, y, z, b, o, p, v, n, out, 2)).__func__)
         K.ptm = _types.SimpleNamespace(get_ptm=wrap(lambda st, x, y, z, b, o, p, v, ty, thr, out, ind, nt=1:
                                                      O.get_ptm(st, x, y, z, b, o, p, v, ty, thr, out, ind)).__func__)
-        K.rdf = _types.SimpleNamespace(_rdf=wrap(lambda v, d, nn, ty, g, rc, nbin: O._rdf(v, d, nn, ty, g, rc, nbin)).__func__)
+        K.rdf = _types.SimpleNamespace(_rdf=wrap(lambda v, d, nn, ty, g, rc, nbin: O._rdf(v, d, nn, ty, g, rc, nbin)).__func__,
+                                       _rdf_streaming=wrap(lambda x, y, z, ty, b, o, p, g, rc, nbin, nt=1:
+                                                           O._rdf_streaming(x, y, z, ty, b, o, p, g, rc, nbin, 2)).__func__)
         K.wcp = _types.SimpleNamespace(get_wcp_counts=wrap(wcp_counts).__func__)
 
         a = 3.6
@@ -237,6 +239,11 @@ def _worker_analyses(rank, world, port, q):
         W = np.zeros((2, 2)); O.get_wcp(V, NN, types_all, 2, W, 2)
         msgs.append(("rdf_counts", np.array_equal(g.numpy(), G) and G.sum() > 0))
         msgs.append(("wcp", np.array_equal(w, W)))
+        # ---- the streaming g(r) at a cutoff beyond the list's: owned centres x owned + ghost candidates
+        rcs = 2.1 * rc
+        gs = D.rdf_streaming_step(dec, *own_args, t(types_all[owned_ids]), 2, rcs, 30)
+        GS = np.zeros((2, 2, 30)); O._rdf_streaming(x, y, z, types_all, boxm, org, bnd, GS, rcs, 30, 2)
+        msgs.append(("rdf_streaming", np.array_equal(gs.numpy(), GS) and GS.sum() > 0))
         q.put((rank, all(ok for _, ok in msgs), [m for m, ok in msgs if not ok], int(dom.owned.sum())))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -64,7 +64,9 @@ def _undivided(torch, K, pos, types, boxm, rc, M, ll):
     g = torch.zeros((2, 2, 40), dtype=torch.float64, device=dev)
     K.rdf._rdf(v, d, nn, t0, g, rc, 40)
     W = np.zeros((2, 2)); K.wcp.get_wcp(v, nn, t0, 2, W, 1)
-    out.update(rdf=g, wcp=W)
+    gs = torch.zeros((2, 2, 50), dtype=torch.float64, device=dev)
+    K.rdf._rdf_streaming(x, y, z, t0, boxm, org, bnd, gs, 2.2 * rc, 50)  # a cutoff no list is built for: the streaming kernel's case
+    out.update(rdf=g, wcp=W, rdf_stream=gs)
     return {k: (a.cpu().numpy() if hasattr(a, "cpu") else a) for k, a in out.items()}
 
 
@@ -127,6 +129,8 @@ def _run_rank(rank, world, torch, dist_ready=True):
     w = D.wcp_step(dec, dom, v, nn, ty, 2)
     check("rdf counts", np.array_equal(g.cpu().numpy(), ref["rdf"]) and ref["rdf"].sum() > 0)
     check("wcp", np.array_equal(w, ref["wcp"]))
+    gs = D.rdf_streaming_step(dec, *own_args, t((types - 1)[owned_ids]), 2, 2.2 * rc, 50)
+    check("streaming rdf counts", np.array_equal(gs.cpu().numpy(), ref["rdf_stream"]) and ref["rdf_stream"].sum() > 0)
     return bad, int(own.sum()), int((~own).sum())
 
 
