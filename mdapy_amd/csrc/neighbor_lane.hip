@@ -740,12 +740,18 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                             d2[u] = h[u] ? d2[u] : 1.0;
                             slow = slow || !sqrt_fast_ok(d2[u]);
                         }
-                        const bool fast = __builtin_amdgcn_ballot_w64(slow) == 0;
+                        double rr[4]; // neighbor.cpp:174 — the four roots as one straight-line block: their dependent chains interleave
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) == 0, 1)) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) rr[u] = sqrt_fast(d2[u]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) rr[u] = sqrt(d2[u]);
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const double rr = __builtin_expect(fast, 1) ? sqrt_fast(d2[u]) : sqrt(d2[u]); // neighbor.cpp:174
                             idv[g0 + u] = h[u] ? nid[u] : -1;
-                            dv[g0 + u] = h[u] ? rr : pad;
+                            dv[g0 + u] = h[u] ? rr[u] : pad;
                         }
                     }
                 }
@@ -855,12 +861,18 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                             d2[u] = h[u] ? d2[u] : 1.0;
                             slow = slow || !sqrt_fast_ok(d2[u]);
                         }
-                        const bool fast = __builtin_amdgcn_ballot_w64(slow) == 0;
+                        double rr[4]; // neighbor.cpp:174
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) == 0, 1)) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) rr[u] = sqrt_fast(d2[u]);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) rr[u] = sqrt(d2[u]);
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const double rr = __builtin_expect(fast, 1) ? sqrt_fast(d2[u]) : sqrt(d2[u]); // neighbor.cpp:174
                             idv[u] = h[u] ? nid[u] : -1;
-                            dv[u] = h[u] ? rr : pad;
+                            dv[u] = h[u] ? rr[u] : pad;
                         }
                     }
                     if (mine) {
