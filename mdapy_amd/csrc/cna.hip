@@ -211,6 +211,128 @@ __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ 
     else if (t < 0) defer(todo, i);
 }
 
+// ------------------------------------------------------------------ adaptive, single-precision pair tests (cna.cpp:289-427)
+// bond rows of the first NN of the vectors u (relative to the centre atom, minimum image): bit c of row a <=> |u_c - u_a|^2 -
+// c < 0; `w` tracks the smallest non-negative value seen (the same ten register-only instructions per pair as fcna_atom_f32)
+template <int NN, int NV>
+__device__ __forceinline__ void pair_rows_f32(const float (&ux)[NV], const float (&uy)[NV], const float (&uz)[NV], float negc,
+                                              unsigned (&adj)[NN], unsigned &w)
+{
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+        adj[a] = 0;
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+#pragma unroll
+        for (int c = a + 1; c < NN; ++c) {
+            float t0, t1, t2;
+            asm("v_sub_f32 %[t0], %[xc], %[xa]\n\t"
+                "v_sub_f32 %[t1], %[yc], %[ya]\n\t"
+                "v_sub_f32 %[t2], %[zc], %[za]\n\t"
+                "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"
+                "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
+                "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
+                "v_min_u32 %[w], %[w], %[t0]\n\t"
+                "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"
+                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w] "+v"(w), [ra] "+v"(adj[a]), [rc] "+v"(adj[c])
+                : [xc] "v"(ux[c]), [xa] "v"(ux[a]), [yc] "v"(uy[c]), [ya] "v"(uy[a]), [zc] "v"(uz[c]), [za] "v"(uz[a]),
+                  [negc] "v"(negc), [sc] "n"(c), [sa] "n"(a));
+        }
+}
+
+// The adaptive analysis with the pair tests of both passes in single precision.  The 14 neighbour vectors are evaluated once,
+// with the reference's double-precision expression (pbcdis of centre and neighbour: their lengths give the two local cutoffs
+// exactly as the reference computes them, cna.cpp:309-319,372-385), and kept as single-precision vectors; the bond tests
+// among neighbours then compare |u_c - u_a|^2 with a threshold a little below lc^2 and a band above it (tolerance 1e-5 lc^2
+// against a rounding bound of 2e-6 lc^2 for |u| <= 2 lc).  -1: the atom is finished by the GENERIC kernel — a pair inside the
+// band, a neighbour farther than 2 lc, a box edge shorter than 8 lc (the difference of two folded vectors would not be a
+// minimum image).
+__device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restrict__ pos, int64_t i, const int *__restrict__ row,
+                                             int label, int64_t N, unsigned short *lds_col)
+{
+    const Pos4 pi = pos[i];
+    const double xi = pi.x, yi = pi.y, zi = pi.z;
+    float ux[14], uy[14], uz[14];
+    double d2[14];
+    float far2 = 0.f;
+    int ids[14];
+    load_row<14>(row, ids);
+#pragma unroll
+    for (int a = 0; a < 14; ++a) {
+        const Pos4 pj = pos[safe_id(ids[a], i, N)];
+        double dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi; // pair_d2(i, j): cna.cpp:149-161
+        pbc<false>(b, dx, dy, dz);
+        d2[a] = dx * dx + dy * dy + dz * dz;
+        ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
+        far2 = fmaxf(far2, fmaxf(fabsf(ux[a]), fmaxf(fabsf(uy[a]), fabsf(uz[a]))));
+    }
+    const double Lmin = fmin(b.pbc[0] ? b.h[0] : 1e300, fmin(b.pbc[1] ? b.h[4] : 1e300, b.pbc[2] ? b.h[8] : 1e300));
+    const RowsLds L{lds_col, 256};
+    // ---- 12 nearest neighbours: FCC / HCP / ICO (cna.cpp:309-370)
+    {
+        double rs = 0.0;
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+            rs += sqrt(d2[m]);
+        const double lc = rs / 12 * (1.0 + sqrt(2.0)) * 0.5; // :319
+        const double lc2 = lc * lc, tol = 1e-5 * lc2;
+        if (!(far2 <= (float)(2.0 * lc) && 8.0 * lc < Lmin && lc2 > 0.0)) // (false for NaN)
+            return -1;
+        const float cf = (float)(lc2 - 2.0 * tol); // a float at least tol below lc^2 (its own rounding is 6e-8 lc^2)
+        const float Wf = (float)(4.0 * tol);       // the band ends at least tol above lc^2
+        unsigned adj[12], w = 0x7f7fffffu;
+        pair_rows_f32<12, 14>(ux, uy, uz, -cf, adj, w);
+        if (w <= __float_as_uint(Wf))
+            return -1;
+#pragma unroll
+        for (int a = 0; a < 12; ++a) lds_col[a * 256] = (unsigned short)adj[a];
+        const CnaCounts c = cna_counts_words<12>(adj, L); // (the reference's loop stops at the first signature of another kind;
+        if (c.n421 == 12) label = 1;                      //  every label needs all twelve to be of the listed kinds: same result)
+        else if (c.n421 == 6 && c.n422 == 6) label = 2;
+        else if (c.n555 == 12) label = 4;
+    }
+    // ---- 14 nearest neighbours: BCC (cna.cpp:372-425), only if still unlabelled
+    if (label == 0) {
+        double rs = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            rs += sqrt(d2[m] / (3.0 / 4.0));
+#pragma unroll
+        for (int m = 8; m < 14; ++m)
+            rs += sqrt(d2[m]);
+        const double lc = rs / 14 * (1.0 + sqrt(2.0)) * 0.5;
+        const double lc2 = lc * lc, tol = 1e-5 * lc2;
+        if (!(far2 <= (float)(2.0 * lc) && 8.0 * lc < Lmin && lc2 > 0.0))
+            return -1;
+        const float cf = (float)(lc2 - 2.0 * tol);
+        const float Wf = (float)(4.0 * tol);
+        unsigned adj[14], w = 0x7f7fffffu;
+        pair_rows_f32<14, 14>(ux, uy, uz, -cf, adj, w);
+        if (w <= __float_as_uint(Wf))
+            return -1;
+#pragma unroll
+        for (int a = 0; a < 14; ++a) lds_col[a * 256] = (unsigned short)adj[a];
+        const CnaCounts c = cna_counts_words<14>(adj, L);
+        if (c.n666 == 8 && c.n444 == 6) label = 3;
+    }
+    return label;
+}
+
+__global__ __launch_bounds__(256, 4) void k_acna_f32(const Pos4 *__restrict__ pos, int64_t N, DBox b,
+                                                     const int *__restrict__ verlet, int64_t M, int *__restrict__ pattern,
+                                                     int *__restrict__ todo)
+{
+    __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int t = acna_atom_f32(b, pos, i, verlet + i * M, pattern[i], N, srows + threadIdx.x);
+    if (t >= 0) pattern[i] = t;
+    else defer(todo, i);
+}
+
 // ------------------------------------------------------------------ adaptive (cna.cpp:289-427)
 template <bool TRI>
 __device__ __forceinline__ double dist2_to(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
@@ -513,7 +635,13 @@ int mdh_acna(const double *x, const double *y, const double *z, int64_t N, const
     if (b.tri) {
         hipLaunchKernelGGL((k_acna<true, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
     } else {
-        hipLaunchKernelGGL((k_acna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        if (g_fcna_variant == 0) {
+            const Pos4 *pos = pack_positions(sc, dx, dy, dz, N);
+            if (!pos)
+                return sc.error();
+            hipLaunchKernelGGL(k_acna_f32, grid, block, 0, st, pos, N, b, dv, M, dp, todo);
+        }
+        else hipLaunchKernelGGL((k_acna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
         hipLaunchKernelGGL((k_acna<false, true>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
     }
     return sc.finish(space);

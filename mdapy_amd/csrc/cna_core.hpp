@@ -221,8 +221,9 @@ __device__ __forceinline__ int fcna_label(const RT &R)
 // per word and the atoms those bonds touch are the OR of the masked words.  That decides every signature with at most two
 // bonds (two bonds share an atom <=> they touch three atoms) and those of the shortcuts of signature(); the rest — six bonds
 // on six atoms, the (6,6,6) of bcc — walks the clusters through the LDS copy of the rows.
+struct CnaCounts { int n421, n422, n555, n444, n666; };
 template <int NN>
-__device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RowsLds &L)
+__device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN], const RowsLds &L)
 {
     constexpr int NW = (NN + 1) / 2;
     unsigned P[NW];
@@ -254,10 +255,16 @@ __device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const
         else if (ncn == 4 && nb == 4 && ch == 4) ++n444;
         else if (ncn == 6 && nb == 6 && ch == 6) ++n666;
     }
-    if (n421 == 12) return 1; // cna.cpp:496-503
-    if (n421 == 6 && n422 == 6) return 2;
-    if (n555 == 12) return 4;
-    if (n666 == 8 && n444 == 6) return 3;
+    return CnaCounts{n421, n422, n555, n444, n666};
+}
+template <int NN>
+__device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RowsLds &L)
+{
+    const CnaCounts c = cna_counts_words<NN>(adj, L);
+    if (c.n421 == 12) return 1; // cna.cpp:496-503
+    if (c.n421 == 6 && c.n422 == 6) return 2;
+    if (c.n555 == 12) return 4;
+    if (c.n666 == 8 && c.n444 == 6) return 3;
     return 0;
 }
 

@@ -14,17 +14,19 @@
 namespace mdh {
 
 template <bool TRI, int K>
-__device__ __forceinline__ double csp_atom_static(const DBox &b, const double *__restrict__ x,
-                                                  const double *__restrict__ y, const double *__restrict__ z,
+__device__ __forceinline__ double csp_atom_static(const DBox &b, const Pos4 *__restrict__ pos,
                                                   int64_t i, const int *__restrict__ row, int64_t N)
 {
     constexpr int H = K / 2;
-    const double xi = x[i], yi = y[i], zi = z[i]; // RAW centre (:46-48)
+    const Pos4 pi = pos[i]; // RAW centre (:46-48)
+    const double xi = pi.x, yi = pi.y, zi = pi.z;
     double rx[K], ry[K], rz[K];
+    int ids[K];
+    load_row<K>(row, ids);
 #pragma unroll
     for (int a = 0; a < K; ++a) {
-        const int j = safe_id(row[a], i, N);
-        double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
+        const Pos4 pj = pos[safe_id(ids[a], i, N)];
+        double dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi;
         pbc<TRI>(b, dx, dy, dz);
         rx[a] = dx; ry[a] = dy; rz[a] = dz;
     }
@@ -92,15 +94,15 @@ template <bool TRI>
 __global__ __launch_bounds__(256) void k_csp(const double *__restrict__ x, const double *__restrict__ y,
                                              const double *__restrict__ z, int64_t N, DBox b,
                                              const int *__restrict__ verlet, int64_t M, int K,
-                                             double *__restrict__ csp)
+                                             double *__restrict__ csp, const Pos4 *__restrict__ pos)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
     const int *row = verlet + i * M;
     double v;
-    if (K == 12) v = csp_atom_static<TRI, 12>(b, x, y, z, i, row, N);
-    else if (K == 8) v = csp_atom_static<TRI, 8>(b, x, y, z, i, row, N);
+    if (K == 12) v = csp_atom_static<TRI, 12>(b, pos, i, row, N);
+    else if (K == 8) v = csp_atom_static<TRI, 8>(b, pos, i, row, N);
     else v = csp_atom_dynamic<TRI>(b, x, y, z, i, row, K, N);
     csp[i] = v;
 }
@@ -127,9 +129,12 @@ extern "C" int mdh_csp(const double *x, const double *y, const double *z, int64_
     double *dc = sc.stage(csp, (size_t)N, space, false, true);
     if (sc.failed())
         return sc.error();
+    const Pos4 *pos = pack_positions(sc, dx, dy, dz, N);
+    if (!pos)
+        return sc.error();
     if (b.tri)
-        hipLaunchKernelGGL(k_csp<true>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc);
+        hipLaunchKernelGGL(k_csp<true>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc, pos);
     else
-        hipLaunchKernelGGL(k_csp<false>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc);
+        hipLaunchKernelGGL(k_csp<false>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc, pos);
     return sc.finish(space);
 }

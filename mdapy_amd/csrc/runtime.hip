@@ -156,6 +156,22 @@ void *Scope::stage_raw(void *p, size_t bytes, int space, bool in, bool out)
     return d;
 }
 
+__global__ __launch_bounds__(256) void k_pack_positions(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ z, int64_t N, Pos4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = Pos4{x[i], y[i], z[i], 0.0};
+}
+
+const Pos4 *pack_positions(Scope &sc, const double *x, const double *y, const double *z, int64_t N)
+{
+    Pos4 *out = sc.alloc_n<Pos4>((size_t)N);
+    if (!out)
+        return nullptr;
+    hipLaunchKernelGGL(k_pack_positions, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), x, y, z, N, out);
+    return out;
+}
+
 int Scope::finish(int space)
 {
     if (failed_)

@@ -377,6 +377,32 @@ def test_fcna_single_precision_pair_tests_vs_oracle(case):
         assert (want > 0).mean() > 0.5  # the case does exercise labelled atoms
 
 
+@pytest.mark.parametrize("case", [c for c in _fcna_cases() if c[0] != "fcc_second_shell_in_band"], ids=lambda c: c[0])
+def test_acna_single_precision_pair_tests_vs_oracle(case):
+    """adaptive CNA on boxes large enough for the single-precision kernel (edges > 8 local cutoffs): labels == oracle == the
+    double-precision kernel; lattices, unwrapped atoms, an open axis, a gas (every atom unlabelled, many through the to-do list)"""
+    from mdapy_amd import _lib
+    name, pos, box, org, bnd, _ = case
+    x, y, z = _xyz(pos)
+    N, k = len(x), 14
+    idx = np.zeros((N, k), np.int32); dk = np.zeros((N, k))
+    _fast_knn.knn(x, y, z, box, org, bnd, k, idx, dk, 1)
+    want = np.zeros(N, np.int32)
+    O.acna(x, y, z, box, org, bnd, idx, want, 4)
+    got = np.zeros(N, np.int32)
+    _cna.acna(x, y, z, box, org, bnd, idx, got, 1)
+    assert np.array_equal(got, want)
+    try:
+        _lib.lib().mdh_debug_set_fcna_variant(1)
+        f64 = np.zeros(N, np.int32)
+        _cna.acna(x, y, z, box, org, bnd, idx, f64, 1)
+    finally:
+        _lib.lib().mdh_debug_set_fcna_variant(0)
+    assert np.array_equal(f64, want)
+    if name != "random_gas":
+        assert (want > 0).mean() > 0.5
+
+
 @pytest.mark.parametrize("name", ["fcc", "bcc", "hcp", "diamond"])
 @pytest.mark.parametrize("sigma", [0.0, 0.08])
 def test_knn_acna_csp_ids_vs_oracle(name, sigma):
