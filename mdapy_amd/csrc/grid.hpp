@@ -26,7 +26,25 @@ struct CellGrid {
     //   flags[1]      : largest cell population
     int *flags;
     unsigned char *mvs; // [N] per-atom image code (raw vs wrapped coordinate), in `order`
+    // [N] the same five values as one 32-byte record per atom (neighbor builds): the tile kernel stages an atom with two
+    // 16-byte requests instead of five small ones
+    struct Packed { double x, y, z; int id, code; };
+    Packed *pk; // when set, xs / ys / zs / mvs are NOT filled (ensure_unpacked() does that for the kernels that want them)
 };
+// a cell-sorted atom, from either representation
+struct SortedView {
+    const double *xs, *ys, *zs;
+    const int *order;
+    const CellGrid::Packed *pk;
+    __device__ __forceinline__ void get(int64_t q, double &x, double &y, double &z, int &id) const
+    {
+        if (pk) { const CellGrid::Packed r = pk[q]; x = r.x; y = r.y; z = r.z; id = r.id; }
+        else { x = xs[q]; y = ys[q]; z = zs[q]; id = order[q]; }
+    }
+    __device__ __forceinline__ int id_of(int64_t q) const { return pk ? pk[q].id : order[q]; }
+};
+inline SortedView view_of(const CellGrid &cg) { return SortedView{cg.xs, cg.ys, cg.zs, cg.order, cg.pk}; }
+int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N); // xs, ys, zs, mvs from pk (no-op when they exist)
 
 // neighbor_tiled.hip: the round-1 LDS-tiled kernel (double-precision scan, any run length); serves the cells too full for neighbor_lane.hip
 struct TiledPlan {
@@ -135,7 +153,7 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g);
 //   sort_desc  : order every cell's atoms by descending id (reference row order); otherwise the
 //                order inside a cell is whatever the atomic counters produced
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
-                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key = nullptr);
+                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key = nullptr, bool packed = false);
 
 // neighbor.hip: out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
 int exclusive_scan_u32(Scope &sc, const unsigned *in, int *out, int64_t n);

@@ -226,16 +226,48 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
                                                 const double *__restrict__ z, const int *__restrict__ order,
                                                 double *__restrict__ xs, double *__restrict__ ys,
                                                 double *__restrict__ zs, int64_t N,
-                                                const unsigned char *__restrict__ mv, unsigned char *__restrict__ mvs)
+                                                const unsigned char *__restrict__ mv, unsigned char *__restrict__ mvs,
+                                                CellGrid::Packed *__restrict__ pk)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N)
         return;
     const int i = order[p];
-    xs[p] = x[i];
-    ys[p] = y[i];
-    zs[p] = z[i];
-    mvs[p] = mv[i];
+    const double a = x[i], b = y[i], c = z[i];
+    const unsigned char m = mv[i];
+    if (pk) {
+        pk[p] = CellGrid::Packed{a, b, c, i, (int)m};
+        return;
+    }
+    xs[p] = a;
+    ys[p] = b;
+    zs[p] = c;
+    mvs[p] = m;
+}
+
+__global__ __launch_bounds__(256) void k_unpack(const CellGrid::Packed *__restrict__ pk, int64_t N, double *__restrict__ xs,
+                                                double *__restrict__ ys, double *__restrict__ zs, unsigned char *__restrict__ mvs)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N)
+        return;
+    const CellGrid::Packed r = pk[p];
+    xs[p] = r.x; ys[p] = r.y; zs[p] = r.z; mvs[p] = (unsigned char)r.code;
+}
+
+int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N)
+{
+    if (!cg.pk || cg.xs)
+        return MDH_OK;
+    cg.xs = sc.alloc_n<double>((size_t)N);
+    cg.ys = sc.alloc_n<double>((size_t)N);
+    cg.zs = sc.alloc_n<double>((size_t)N);
+    cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
+    if (sc.failed())
+        return sc.error();
+    hipLaunchKernelGGL(k_unpack, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.pk, N, cg.xs, cg.ys, cg.zs, cg.mvs);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
 }
 
 // ----------------------------------------------------------------------------
@@ -306,7 +338,7 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
 }
 
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
-                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key)
+                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key, bool packed)
 {
     const Grid &g = cg.g;
     hipStream_t st = sc.stream();
@@ -316,11 +348,18 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     int *cell_id = sc.alloc_n<int>((size_t)N);
     int *rank = sc.alloc_n<int>((size_t)N);
     cg.order = sc.alloc_n<int>((size_t)N);
-    cg.xs = sc.alloc_n<double>((size_t)N);
-    cg.ys = sc.alloc_n<double>((size_t)N);
-    cg.zs = sc.alloc_n<double>((size_t)N);
     unsigned char *mv = sc.alloc_n<unsigned char>((size_t)N);
-    cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
+    cg.xs = cg.ys = cg.zs = nullptr;
+    cg.mvs = nullptr;
+    cg.pk = nullptr;
+    if (packed) {
+        cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
+    } else {
+        cg.xs = sc.alloc_n<double>((size_t)N);
+        cg.ys = sc.alloc_n<double>((size_t)N);
+        cg.zs = sc.alloc_n<double>((size_t)N);
+        cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
+    }
     const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
     unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk + 1);
     cg.flags = sc.alloc_n<int>(4);
@@ -410,7 +449,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
                 hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key);
         }
     }
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs);
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
@@ -424,14 +463,13 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
 // ----------------------------------------------------------------------------
 // one centre atom (position p of the cell-sorted arrays): the reference's 27-cell walk, neighbor.cpp:139-177
 template <bool TRI, int MODE>
-__device__ __forceinline__ int neighbor_one(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
-                                            const int *__restrict__ order, const int *__restrict__ cell_start, const DBox &b,
+__device__ __forceinline__ int neighbor_one(const SortedView &sv, const int *__restrict__ cell_start, const DBox &b,
                                             const Grid &g, double rc, int *__restrict__ verlet, double *__restrict__ dist,
                                             int *__restrict__ nn, int64_t M, int64_t p, double xi, double yi, double zi, int c0, int c1,
                                             int c2)
 {
     int cnt = 0;
-    const int i = order[p];
+    const int i = sv.id_of(p);
     const double rcsq = rc * rc; // neighbor.cpp:127
     const int64_t row = (int64_t)i * M;
     const bool zrun = (c2 >= 1) && (c2 + 1 < g.nc[2]); // the three z-cells are one contiguous run
@@ -450,10 +488,12 @@ __device__ __forceinline__ int neighbor_one(const double *__restrict__ xs, const
                     e = cell_start[base + cc + 1];
                 }
                 for (int q = s; q < e; ++q) {
-                    const int j = order[q];
+                    double xq, yq, zq;
+                    int j;
+                    sv.get(q, xq, yq, zq, j);
                     if (j == i)
                         continue;
-                    double dx = xs[q] - xi, dy = ys[q] - yi, dz = zs[q] - zi; // raw x[j] - wrapped centre, :164-166
+                    double dx = xq - xi, dy = yq - yi, dz = zq - zi; // raw x[j] - wrapped centre, :164-166
                     pbc<TRI>(b, dx, dy, dz);
                     const double d2 = dx * dx + dy * dy + dz * dz;
                     if (d2 <= rcsq) {
@@ -479,8 +519,7 @@ __device__ __forceinline__ int neighbor_one(const double *__restrict__ xs, const
 }
 
 template <bool TRI, int MODE>
-__global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs, const double *__restrict__ ys,
-                                                  const double *__restrict__ zs, const int *__restrict__ order,
+__global__ __launch_bounds__(256) void k_neighbor(SortedView sv,
                                                   const int *__restrict__ cell_start, int64_t N, DBox b, Grid g,
                                                   double rc, int *__restrict__ verlet, double *__restrict__ dist,
                                                   int *__restrict__ nn, int64_t M, int *__restrict__ max_count,
@@ -498,7 +537,7 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
         int c0 = 0, c1 = 0, c2 = 0;
         double xi = 0, yi = 0, zi = 0;
         if (mine) {
-            xi = xs[p]; yi = ys[p]; zi = zs[p];
+            { int idp; sv.get(p, xi, yi, zi, idp); }
             if (b.anypbc) // neighbor.cpp:139-142
                 wrap<TRI>(b, xi, yi, zi);
             cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
@@ -508,8 +547,8 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
             }
         }
         if (mine) {
-            cnt = max(cnt, neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
-            if (tf.cna_todo) defer(tf.cna_todo, order[p]);
+            cnt = max(cnt, neighbor_one<TRI, MODE>(sv, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+            if (tf.cna_todo) defer(tf.cna_todo, sv.id_of(p));
         }
     }
     if (MODE == 0) {
@@ -527,8 +566,7 @@ __global__ __launch_bounds__(256) void k_neighbor(const double *__restrict__ xs,
 // mop-up of the tiles the wave kernel listed (halo over the LDS budget, atoms far outside the box): a workgroup per listed
 // tile, its threads over the tile's centre atoms — the cost follows the number of listed tiles, not N
 template <bool TRI, int MODE>
-__global__ __launch_bounds__(256) void k_neighbor_tiles(const double *__restrict__ xs, const double *__restrict__ ys,
-                                                        const double *__restrict__ zs, const int *__restrict__ order,
+__global__ __launch_bounds__(256) void k_neighbor_tiles(SortedView sv,
                                                         const int *__restrict__ cell_start, DBox b, Grid g, double rc,
                                                         int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
                                                         int64_t M, int *__restrict__ max_count, TileFilter tf)
@@ -552,13 +590,14 @@ __global__ __launch_bounds__(256) void k_neighbor_tiles(const double *__restrict
                 const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
                 const int s = cell_start[col + z0], e = cell_start[col + z1]; // the z-run of a column is contiguous
                 for (int p = s + sub; p < e; p += tpc) {
-                    double xi = xs[p], yi = ys[p], zi = zs[p];
+                    double xi, yi, zi;
+                    { int idp; sv.get(p, xi, yi, zi, idp); }
                     if (b.anypbc)
                         wrap<TRI>(b, xi, yi, zi);
                     int c0, c1, c2;
                     cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
-                    best = max(best, neighbor_one<TRI, MODE>(xs, ys, zs, order, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
-                    if (tf.cna_todo) defer(tf.cna_todo, order[p]);
+                    best = max(best, neighbor_one<TRI, MODE>(sv, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+                    if (tf.cna_todo) defer(tf.cna_todo, sv.id_of(p));
                 }
             }
         }
@@ -579,13 +618,13 @@ static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const
     // then, whose workgroups stride over the atoms if they do have to take the call (10 -> 3 us when they leave at once)
     dim3 grid(std::min(grid_for(N, 256), tf.list ? 2048 : 8192)), block(256);
     if (b.tri)
-        hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+        hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, view_of(cg), cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else
-        hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+        hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, view_of(cg), cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     if (tf.list && b.tri) // the listed tiles (at most list_cap; a longer list falls back to the flag scan above via tf.list == nullptr)
-        hipLaunchKernelGGL((k_neighbor_tiles<true, MODE>), dim3(512), block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+        hipLaunchKernelGGL((k_neighbor_tiles<true, MODE>), dim3(512), block, 0, st, view_of(cg), cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else if (tf.list)
-        hipLaunchKernelGGL((k_neighbor_tiles<false, MODE>), dim3(512), block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+        hipLaunchKernelGGL((k_neighbor_tiles<false, MODE>), dim3(512), block, 0, st, view_of(cg), cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
 }
 
 // ----------------------------------------------------------------------------
@@ -792,8 +831,10 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
         int64_t occ = 0;
         MDH_TRY(occupied_cells_hint(sc, cg, N, &occ));
         const TiledPlan plan = plan_tiled(b, cg.g, N, M, occ);
-        if (plan.tile)
+        if (plan.tile) {
+            MDH_TRY(ensure_unpacked(sc, const_cast<CellGrid &>(cg), N));
             MDH_TRY(launch_neighbor_tiled(sc, cg, plan, N, b, rc, dv, dd, dn, M, mode == 2, tf));
+        }
     }
     if (mode == 0) launch_neighbor<0>(st, cg, N, b, rc, nullptr, nullptr, dn, 1, dmax, tf);
     else if (mode == 2) launch_neighbor<2>(st, cg, N, b, rc, dv, dd, dn, M, nullptr, tf);
@@ -839,7 +880,7 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", sc.stream());
-        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey));
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
     {
         ProfRange pr("k_neighbor", sc.stream());
@@ -873,7 +914,7 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", sc.stream());
-        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey));
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
     bool fused = false;
     {
@@ -920,7 +961,7 @@ int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_
     MDH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), sc.stream()));
     CellGrid cg;
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
-    MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
+    MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, nullptr, true));
     MDH_TRY(neighbor_pass(sc, cg, b, N, rc, nullptr, nullptr, dn, 1, 0, dmax));
     MDH_HIP(hipMemcpyAsync(max_count, dmax, sizeof(int), hipMemcpyDeviceToHost, sc.stream()));
     MDH_TRY(sc.finish(space));
@@ -955,7 +996,7 @@ int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, 
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", st);
-        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg));
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, nullptr, true));
     }
     // Width hint: the largest count the previous call with the same (N, grid) found.  A sequence of calls on one system (a
     // trajectory, the same analysis repeated) almost always finds the same maximum again, so the rows are built at that

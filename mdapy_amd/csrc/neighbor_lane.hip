@@ -6,7 +6,7 @@
 // mdh_neighbor_count / mdh_build_neighbor_exact for orthogonal boxes and for triclinic ones periodic along all three vectors.
 //
 // A workgroup owns a tile of TXY x TXY x TZ cells and stages the atoms of the halo ((TXY+2)^2 x (TZ+2) cells, ONE CELL
-// PER THREAD, coalesced loads from the cell-sorted arrays) into LDS once: raw doubles for the values that are written,
+// PER THREAD, two 16-byte loads per atom from the cell-sorted 32-byte records) into LDS once: raw doubles for the values that are written,
 // and single-precision coordinates relative to the tile corner with the periodic image shift folded in
 // (u = x - (X0 + L n), n = image number of the candidate's cell as seen from the tile + the atom's own image code) for the
 // values that only decide.  The staging pass also lists the tile's centre atoms and tabulates, per halo cell, the LDS range
@@ -329,8 +329,7 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
 // false: two-byte tickets and the slot-per-lane write-out (rows of up to 64 slots)
 template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8>
 __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
-    const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
-    const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
+    const CellGrid::Packed *__restrict__ pk, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int q = h.src + min(v, max(h.cnt - 1, 0));
-            if (h.cnt > 0) { ra[v] = xs[q]; rb[v] = ys[q]; rc4[v] = zs[q]; rd[v] = order[q]; rm[v] = mvs[q]; }
+            if (h.cnt > 0) { const CellGrid::Packed a = pk[q]; ra[v] = a.x; rb[v] = a.y; rc4[v] = a.z; rd[v] = a.id; rm[v] = (unsigned char)a.code; }
             else { ra[v] = 0; rb[v] = 0; rc4[v] = 0; rd[v] = 0; rm[v] = NEUTRAL; }
         }
     };
@@ -500,7 +499,8 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                     if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = pm[v]; }
                     else {
                         const int q = src + min(k + v, cnt - 1);
-                        a[v] = xs[q]; bb[v] = ys[q]; c[v] = zs[q]; d[v] = order[q]; m[v] = mvs[q];
+                        const CellGrid::Packed r = pk[q];
+                        a[v] = r.x; bb[v] = r.y; c[v] = r.z; d[v] = r.id; m[v] = (unsigned char)r.code;
                     }
                 }
 #pragma unroll
@@ -1205,7 +1205,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     do {                                                                                                                                  \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.mvs, cg.cell_start, b, \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.pk, cg.cell_start, b, \
                            cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
