@@ -547,12 +547,10 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
             flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
         }
         const bool general_tile = s_flag[0] != 0;
-        // ---- From here on the four waves do not meet again: a wave takes a contiguous quarter of the tile's centres, scans
+        // ---- From here on the four waves do not meet again: a wave takes whole chunks of the tile's centres, scans
         // them, leaves their tickets in ITS rows of tk and writes their rows itself — LDS traffic inside one wave is ordered,
         // no workgroup barrier — so one wave's scan overlaps another's write-out.
         const int wv = tid >> 6;
-        const int per_w = (ncentres + (NT >> 6) - 1) / (NT >> 6);
-        const int wbeg = min(wv * per_w, ncentres), wend = min(wbeg + per_w, ncentres);
         const int TKS = (M + 4) & ~3; // tickets of a row + the spare slot, rounded up: rows are read back four tickets at a time
         Ticket *tkw = tk + (size_t)(wv * rw) * TKS; // rw: rows a wave works on at a time (64; fewer where rows are long and centres few: dense cells)
         const int A2 = HXY * HZ;
@@ -561,9 +559,12 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
             const int r3 = (r * 11) >> 5;
             return cbv + __mul24(r3, A2 - 3 * HZ) + __mul24(r, HZ) - (A2 + HZ);
         };
-        for (int cbase = wbeg; ok && cbase < wend; cbase += rw) {
+        // Centres go out in chunks of rw (a full wave of them); chunk c is taken by wave (c + jt) mod 4 — a tile of 150 centres
+        // keeps three waves busy with full registers and leaves the fourth free, and the rotation spreads the free one over the
+        // CU's four SIMDs from tile to tile (an even split, 38 lanes in each of four waves, costs four chunk passes for three)
+        for (int cbase = (int)((unsigned)(wv - jt) & (unsigned)((NT >> 6) - 1)) * rw; ok && cbase < ncentres; cbase += (NT >> 6) * rw) {
             const int q = cbase + lane;
-            const bool mine = lane < rw && q < wend; // this lane holds a centre
+            const bool mine = lane < rw && q < ncentres; // this lane holds a centre
             int kept = 0, kept8 = 0, cb = 0, id = 0; // (lanes without a centre: no row)
             double xi = 0, yi = 0, zi = 0;
             Ticket *my = tkw + (size_t)lane * TKS;
