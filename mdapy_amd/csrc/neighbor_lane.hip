@@ -153,7 +153,7 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
     return dx * dx + dy * dy + dz * dz;
 }
 
-// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v100-v118).  Four candidates per
+// One run of candidates for one centre per lane, hand-scheduled (fixed scratch registers v100-v121).  Four candidates per
 // trip: four 16-byte LDS reads in flight, then per candidate 3 subtractions, an FMA chain that ends in e = d2 - c (c a little
 // below rc^2), v_alignbit shifting e's SIGN into the hit mask, and an unsigned v_min of e's bits that tracks the smallest
 // NON-NEGATIVE e the lane has seen (negative floats are the large unsigned numbers).  Eight instructions, none of which
@@ -164,15 +164,22 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
 // e of theirs only costs a redundant double-precision pass.  (Trips of 8, 12 and 16 candidates with the reads re-issued as
 // they are consumed were measured too: what counts is the number of candidate SLOTS a wave walks — 12 for the 10-atom runs
 // of the headline lattice with trips of 4 or 12, 16 with 8 or 16 — not the per-trip overhead)
-#define MDH_CAND(X, Y, Z)                                                                                                            \
-    "v_sub_f32 v116, " X ", %[sx]\n\t"                                                                                               \
-    "v_sub_f32 v117, " Y ", %[sy]\n\t"                                                                                               \
-    "v_sub_f32 v118, " Z ", %[sz]\n\t"                                                                                               \
+#define MDH_CAND2(X1, Y1, Z1, X2, Y2, Z2)                                                                                            \
+    "v_sub_f32 v116, " X1 ", %[sx]\n\t"                                                                                              \
+    "v_sub_f32 v119, " X2 ", %[sx]\n\t"                                                                                              \
+    "v_sub_f32 v117, " Y1 ", %[sy]\n\t"                                                                                              \
+    "v_sub_f32 v120, " Y2 ", %[sy]\n\t"                                                                                              \
+    "v_sub_f32 v118, " Z1 ", %[sz]\n\t"                                                                                              \
+    "v_sub_f32 v121, " Z2 ", %[sz]\n\t"                                                                                              \
     "v_fma_f32 v116, v116, v116, %[negc]\n\t"                                                                                        \
+    "v_fma_f32 v119, v119, v119, %[negc]\n\t"                                                                                        \
     "v_fmac_f32 v116, v117, v117\n\t"                                                                                                \
+    "v_fmac_f32 v119, v120, v120\n\t"                                                                                                \
     "v_fmac_f32 v116, v118, v118\n\t"                                                                                                \
+    "v_fmac_f32 v119, v121, v121\n\t"                                                                                                \
     "v_alignbit_b32 %[m], %[m], v116, 31\n\t"                                                                                        \
-    "v_min_u32 %[w], %[w], v116\n\t"
+    "v_alignbit_b32 %[m], %[m], v119, 31\n\t"                                                                                        \
+    "v_min3_u32 %[w], %[w], v116, v119\n\t"
 __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, float sy, float sz, float negc, unsigned &mask,
                                              unsigned &w)
 {
@@ -190,20 +197,18 @@ __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, floa
                  "ds_read_b128 v[112:115], %[a] offset:48\n\t"
                  "v_add_u32 %[a], 64, %[a]\n\t"
                  "v_add_u32 %[rem], -4, %[rem]\n\t"
-                 "s_waitcnt lgkmcnt(3)\n\t" MDH_CAND("v100", "v101", "v102")
-                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND("v104", "v105", "v106")
-                 "s_waitcnt lgkmcnt(1)\n\t" MDH_CAND("v108", "v109", "v110")
-                 "s_waitcnt lgkmcnt(0)\n\t" MDH_CAND("v112", "v113", "v114")
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND2("v100", "v101", "v102", "v104", "v105", "v106")
+                 "s_waitcnt lgkmcnt(0)\n\t" MDH_CAND2("v108", "v109", "v110", "v112", "v113", "v114")
                  "s_branch .Lscan_top_%=\n"
                  ".Lscan_end_%=:\n\t"
                  "s_mov_b64 exec, %[save]\n\t"
                  : [m] "=&v"(m), [w] "+v"(w), [a] "+v"(a), [rem] "+v"(rem), [save] "=&s"(save)
                  : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [negc] "v"(negc)
                  : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110",
-                   "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118");
+                   "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121");
     mask = m;
 }
-#undef MDH_CAND
+#undef MDH_CAND2
 // slots a run of `len` candidates takes in its hit mask: whole trips of four
 __device__ __forceinline__ int run_slots(int len)
 {
