@@ -40,11 +40,11 @@ template <bool TRI> __device__ __forceinline__ void fold(const DBox &b, double &
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int ORD_THREADS = 128, ORD_APB = ORD_THREADS / NROW; // 7 atoms per workgroup
 
-template <int CAP_> struct PolyStripe {
+template <int CAP_, int DIM> struct PolyStripe { // DIM 2: vertices in the coordinates of the face's plane (ptm_core.hpp face_solid_angle_2d)
     static constexpr int CAP = CAP_;
     double *base;
-    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 3 + c) * ORD_THREADS]; }
-    __device__ __forceinline__ void set(int i, int c, double v) { base[(i * 3 + c) * ORD_THREADS] = v; }
+    __device__ __forceinline__ double get(int i, int c) const { return base[(i * DIM + c) * ORD_THREADS]; }
+    __device__ __forceinline__ void set(int i, int c, double v) { base[(i * DIM + c) * ORD_THREADS] = v; }
 };
 
 struct OrderShared { // per workgroup
@@ -56,11 +56,11 @@ struct OrderShared { // per workgroup
     int cnt[ORD_APB];
     int overflow[ORD_APB];
 };
-template <int CAP> constexpr size_t order_lds_bytes() { return sizeof(OrderShared) + (size_t)ORD_THREADS * CAP * 24; }
+template <int CAP, int DIM> constexpr size_t order_lds_bytes() { return sizeof(OrderShared) + (size_t)ORD_THREADS * CAP * DIM * 8; }
 
 // REDO = second pass over the atoms whose polygons outgrew the first pass's storage (flag set), with room for 28 vertices
-template <bool TRI, int CAP, bool REDO>
-__global__ __launch_bounds__(ORD_THREADS) void k_ptm_order_faces(const double *__restrict__ x, const double *__restrict__ y,
+template <bool TRI, int CAP, bool REDO, int DIM>
+__global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_faces(const double *__restrict__ x, const double *__restrict__ y,
                                                                  const double *__restrict__ z, int64_t N, DBox b,
                                                                  const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders,
                                                                  int *__restrict__ nbr, unsigned char *__restrict__ redo,
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(ORD_THREADS) void k_ptm_order_faces(const double *_
 {
     extern __shared__ unsigned char lds[];
     OrderShared &S = *reinterpret_cast<OrderShared *>(lds);
-    PolyStripe<CAP> poly{reinterpret_cast<double *>(lds + sizeof(OrderShared)) + threadIdx.x};
+    PolyStripe<CAP, DIM> poly{reinterpret_cast<double *>(lds + sizeof(OrderShared)) + threadIdx.x};
     const int t = threadIdx.x, slot = t / NROW, f = t - slot * NROW;
     if (REDO && *redo_count == 0) // the usual case: a small grid that leaves at once
         return;
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(ORD_THREADS) void k_ptm_order_faces(const double *_
         for (int i = 0; i < cnt; ++i) maxn = fmax(maxn, S.nsq[slot][i]);
         const double k = 10 * sqrt(maxn);
         double a = 0;
-        if (!ptmc::face_solid_angle(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a))
+        if (!(DIM == 2 ? ptmc::face_solid_angle_2d(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a)
+                       : ptmc::face_solid_angle(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a)))
             S.overflow[slot] = 1;
         S.area[slot][f] = a;
     }
@@ -1241,46 +1242,54 @@ void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
     }
 }
 
-static int g_order_cap = 10; // polygon vertices in the first pass: 10 -> 4 workgroups per CU (15 -> 3, 22 % slower); larger faces take the second pass
-void ptm_debug_order_cap(int cap) { g_order_cap = cap <= 5 ? 5 : cap <= 10 ? 10 : 15; }
+static int g_order_cap = 10; // polygon vertices in the first pass (10: faces of up to ten corners — all of a crystal's — stay in it); larger faces take the second pass
+static int g_order_dim = 2;  // 2: polygons in the coordinates of their own plane; 3: in space (the form of rounds 1-2, kept for A/B)
+// test / measurement hook (mdh_debug_set_ptm_order_cap): |cap| -> 5, 10 or 15 vertices; a NEGATIVE value selects the 3-D polygons
+void ptm_debug_order_cap(int cap)
+{
+    g_order_dim = cap < 0 ? 3 : 2;
+    const int c = cap < 0 ? -cap : cap;
+    g_order_cap = c <= 5 ? 5 : c <= 8 ? 8 : c <= 10 ? 10 : 15;
+}
+
+template <bool TRI, int CAP, int DIM>
+static int launch_ptm_order_as(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
+                               int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st)
+{
+    using namespace ptms;
+    const dim3 grid((unsigned)((N + ORD_APB - 1) / ORD_APB)), block(ORD_THREADS);
+    const dim3 small(grid.x < 1024u ? grid.x : 1024u);
+    // the second pass may ask for more than the 64 KB of dynamic LDS a launch gets by default
+    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<TRI, 28, true, DIM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(order_lds_bytes<28, DIM>())));
+    const size_t lds1 = order_lds_bytes<CAP, DIM>(), lds2 = order_lds_bytes<28, DIM>();
+    hipLaunchKernelGGL((k_ptm_order_faces<TRI, CAP, false, DIM>), grid, block, lds1, st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    hipLaunchKernelGGL((k_ptm_order_faces<TRI, 28, true, DIM>), small, block, lds2, st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
 
 int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
                      int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st)
 {
-    using namespace ptms;
     ProfRange pr("k_ptm_order", st);
-    const dim3 grid((unsigned)((N + ORD_APB - 1) / ORD_APB)), block(ORD_THREADS);
-    // the second pass asks for more than the 64 KB of dynamic LDS a launch gets by default
-    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<true, 28, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds_bytes<28>()));
-    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<false, 28, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds_bytes<28>()));
     MDH_HIP(hipMemsetAsync(redo_count, 0, sizeof(int), st));
-    const dim3 small(grid.x < 1024u ? grid.x : 1024u);
-    if (g_order_cap == 5) { // test hook: a first pass so small that most atoms take the second one
-        if (b.tri)
-            hipLaunchKernelGGL((k_ptm_order_faces<true, 5, false>), grid, block, order_lds_bytes<5>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        else
-            hipLaunchKernelGGL((k_ptm_order_faces<false, 5, false>), grid, block, order_lds_bytes<5>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        if (b.tri)
-            hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        else
-            hipLaunchKernelGGL((k_ptm_order_faces<false, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-    } else if (g_order_cap == 10) {
-        if (b.tri)
-            hipLaunchKernelGGL((k_ptm_order_faces<true, 10, false>), grid, block, order_lds_bytes<10>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        else
-            hipLaunchKernelGGL((k_ptm_order_faces<false, 10, false>), grid, block, order_lds_bytes<10>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        if (b.tri)
-            hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        else
-            hipLaunchKernelGGL((k_ptm_order_faces<false, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-    } else if (b.tri) {
-        hipLaunchKernelGGL((k_ptm_order_faces<true, 15, false>), grid, block, order_lds_bytes<15>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        hipLaunchKernelGGL((k_ptm_order_faces<true, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-    } else {
-        hipLaunchKernelGGL((k_ptm_order_faces<false, 15, false>), grid, block, order_lds_bytes<15>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-        hipLaunchKernelGGL((k_ptm_order_faces<false, 28, true>), small, block, order_lds_bytes<28>(), st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+#define MDH_ORD(TRI, CAP, DIM) return launch_ptm_order_as<TRI, CAP, DIM>(dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count, st)
+#define MDH_ORD_CAP(TRI, DIM)                                                                                                                  \
+    do {                                                                                                                                       \
+        if (g_order_cap == 5) MDH_ORD(TRI, 5, DIM); /* test hook: a first pass so small that most atoms take the second one */                 \
+        if (g_order_cap == 8) MDH_ORD(TRI, 8, DIM);                                                                                            \
+        if (g_order_cap == 10) MDH_ORD(TRI, 10, DIM);                                                                                          \
+        MDH_ORD(TRI, 15, DIM);                                                                                                                 \
+    } while (0)
+    if (g_order_dim == 2) {
+        if (b.tri) MDH_ORD_CAP(true, 2);
+        MDH_ORD_CAP(false, 2);
     }
-    return MDH_OK;
+    if (b.tri) MDH_ORD_CAP(true, 3);
+    MDH_ORD_CAP(false, 3);
+#undef MDH_ORD_CAP
+#undef MDH_ORD
 }
 
 size_t ptm_stage_bytes(int64_t N)

@@ -852,7 +852,7 @@ def test_ptm_ordering_second_pass_gives_the_same_rows():
     idx, dist = np.zeros((N, 18), np.int32), np.zeros((N, 18))
     _fast_knn.knn(x, y, z, box, ORG0, PBC, 18, idx, dist, 1)
     outs = []
-    for cap in (15, 10, 5):
+    for cap in (15, 10, 5, -15, -10, -5): # negative: the polygons in space instead of in their plane's coordinates (A/B form)
         _lib.lib().mdh_debug_set_ptm_order_cap(cap)
         try:
             o, i = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
@@ -860,8 +860,13 @@ def test_ptm_ordering_second_pass_gives_the_same_rows():
             outs.append((o, i))
         finally:
             _lib.lib().mdh_debug_set_ptm_order_cap(10)
-    for o, i in outs[1:]:
+    for o, i in outs[1:3]:
         assert np.array_equal(outs[0][0], o) and np.array_equal(outs[0][1], i)
+    for o, i in outs[4:]:
+        assert np.array_equal(outs[3][0], o) and np.array_equal(outs[3][1], i)
+    # 2-D against 3-D polygons: the same faces up to rounding; on a rattled lattice no two areas are that close, so the order
+    # of the rows — and with it every output — is the same
+    assert np.array_equal(outs[0][1], outs[3][1]) and np.array_equal(outs[0][0], outs[3][0])
     assert (outs[0][0][:, 0] == 1).mean() > 0.9
 
 

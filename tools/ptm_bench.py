@@ -7,8 +7,11 @@ from mdapy_amd import _ptm, _lib
 from mdapy_amd.build_lattice import lattice_positions
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-pos, box = lattice_positions("fcc", 3.615, n, n, n)
-pos = pos + np.random.default_rng(0).normal(0, 0.08, pos.shape)
+lat = os.environ.get("PTM_LATTICE", "fcc")  # fcc / bcc / hcp lattice, or "gas" (uniform random points)
+pos, box = lattice_positions("fcc" if lat == "gas" else lat, 3.615 if lat != "bcc" else 2.87, n, n, n)
+if lat == "gas":
+    pos = np.random.default_rng(1).random(pos.shape) * np.diag(np.asarray(box, float) if np.ndim(box) == 2 else np.diag(box))
+pos = pos + np.random.default_rng(0).normal(0, float(os.environ.get("PTM_SIGMA", "0.08")), pos.shape)
 s = mp.System(pos=pos, box=box)
 t0 = time.time(); s.build_nearest_neighbor(18) if hasattr(s, "build_nearest_neighbor") else None
 torch.cuda.synchronize(); print("knn s", time.time() - t0)
