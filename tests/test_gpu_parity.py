@@ -870,6 +870,50 @@ def test_ptm_ordering_second_pass_gives_the_same_rows():
     assert (outs[0][0][:, 0] == 1).mean() > 0.9
 
 
+@pytest.mark.parametrize("kind", ["gas", "fcc_hot", "bcc_rattled", "hcp_perfect", "fcc_perfect", "liquid_like"])
+def test_ptm_plane_polygons_against_space_polygons_on_random_systems(kind):
+    """the ordering kernel keeps a face's polygon in the 2-D coordinates of the face's plane; the 3-D form of rounds 1-2 stays
+    selectable (negative cap).  Same cell, same faces, different rounding: structure types must agree everywhere and the
+    rows everywhere but at exact-tie neighbourhoods (perfect lattices: equal areas, whose order is decided by the last bit —
+    the same class of difference the reference's voro++ has against either form)"""
+    from mdapy_amd import _lib
+
+    rng = np.random.default_rng(97)
+    if kind == "gas":
+        box = np.diag([40.0, 38.0, 42.0]); pos = rng.random((6000, 3)) * np.diag(box)
+    elif kind == "liquid_like": # jittered grid: no close pairs, wide spread of face sizes
+        g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3) * 2.6
+        pos = g + rng.uniform(-1.0, 1.0, g.shape); box = np.diag([16 * 2.6] * 3)
+    elif kind == "fcc_hot":
+        pos, box = _fcc(9, 0.25, 5)
+    elif kind == "bcc_rattled":
+        pos, box = lattice_positions("bcc", 2.87, 11, 11, 11); pos = pos + rng.normal(0, 0.07, pos.shape)
+    elif kind == "hcp_perfect":
+        pos, box = lattice_positions("hcp", 3.2, 8, 8, 8)
+    else:
+        pos, box = _fcc(8)
+    x, y, z = _xyz(pos)
+    N = len(x)
+    idx, dist = np.zeros((N, 18), np.int32), np.zeros((N, 18))
+    _fast_knn.knn(x, y, z, box, ORG0, PBC, 18, idx, dist, 1)
+    res = {}
+    for cap in (10, -10):
+        _lib.lib().mdh_debug_set_ptm_order_cap(cap)
+        try:
+            o, i = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
+            _ptm.get_ptm("all", x, y, z, box, ORG0, PBC, idx, None, 0.1, o, i)
+            res[cap] = (o, i)
+        finally:
+            _lib.lib().mdh_debug_set_ptm_order_cap(10)
+    (o2, i2), (o3, i3) = res[10], res[-10]
+    assert np.array_equal(o2[:, 0], o3[:, 0])  # structure type
+    same = (i2 == i3).all(axis=1)
+    if "perfect" not in kind:
+        assert same.mean() > 0.999, same.mean()
+    assert np.allclose(o2[same], o3[same], rtol=0, atol=1e-6)  # (the contract of the PTM floats; a perfect lattice has rmsd = sqrt(rounding noise) ~ 1e-8)
+    assert np.allclose(o2[:, 2], o3[:, 2], rtol=0, atol=1e-6)  # rmsd, whatever the labelling
+
+
 PTM_PATHS = fixtures_with("ptm")
 
 
