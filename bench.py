@@ -273,7 +273,9 @@ def main():
             return nn, pattern, None
     else:
         def step():
-            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M)
+            # every step: one halo exchange, one build, one CNA.  The exchange of the NEXT step (the next frame of a trajectory
+            # does not depend on this one) is started on a side stream before this step's kernels are enqueued.
+            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M, next_frame=(x, y, z, gid))
             return nn_, pat_, dom
 
     elapsed, out, prof = timed(step, args.steps, args.warmup)

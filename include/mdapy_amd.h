@@ -171,6 +171,12 @@ int mdh_slab_halo_messages(const double *x, const double *y, const double *z, in
                            const double *hi3_host, double up_from, double down_below, const int64_t *gid,
                            const double *const *extras_host_array_of_device_pointers, int nextra, double *msg_up,
                            double *msg_down, int64_t cap, void *stream);
+/* The receiving side: the nl + nr atoms of the two incoming messages (same layout, ncol = 3 + nextra f64 columns) are written
+ * behind the owned atoms, columns[k][n_owned ...] and gid[n_owned ...] (the id row converted back to i64), the left
+ * neighbour's atoms first.  One launch; the caller has read nl and nr from the message headers.  Device memory only. */
+int mdh_slab_append_ghosts(const double *msg_from_left, const double *msg_from_right, int64_t cap, int64_t nl, int64_t nr,
+                           double *const *columns_host_array_of_device_pointers, int ncol, int64_t *gid, int64_t n_owned,
+                           void *stream);
 
 /*
  * first half of _neighbor.build_neighbor_without_max_neigh  src/neighbor.cpp:189-349:

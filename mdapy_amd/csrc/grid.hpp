@@ -17,6 +17,7 @@ struct Grid {
 // device buffers produced by build_cell_grid (owned by the Scope that built them)
 struct CellGrid {
     Grid g;
+    int win_lo = 0, win_hi = 0; // planes [win_lo, win_hi) of axis 0 the grid was built over (a promised window, neighbor.hip); 0, 0: all
     int *cell_start; // [ncell+1] exclusive prefix of the per-cell populations
     int *order;      // [N] atom ids, cell-major, DESCENDING id inside a cell
     double *xs, *ys, *zs; // [N] raw positions in `order`

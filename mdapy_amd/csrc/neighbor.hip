@@ -391,6 +391,8 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         }
     }
     const int64_t plane = (int64_t)g.nc[1] * g.nc[2];
+    cg.win_lo = cg.win_hi = 0;
+    if (windowed && p3 <= p2) { cg.win_lo = p0; cg.win_hi = p1; } // one piece: the tile kernel runs over its range of tiles
     if (windowed) {
         MDH_HIP(hipMemsetAsync(cell_count + p0 * plane, 0, sizeof(unsigned) * (size_t)((p1 - p0) * plane), st));
         if (p3 > p2) MDH_HIP(hipMemsetAsync(cell_count + p2 * plane, 0, sizeof(unsigned) * (size_t)((p3 - p2) * plane), st));

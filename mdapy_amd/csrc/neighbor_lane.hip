@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
-    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw)
+    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw, int tile_base)
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
             t0 = pt / (parent_nt2 * nt1);
             t.id = (t0 * nt1 + t1) * nt2 + t2;
         } else {
-            t.id = (list_mode && tile_list) ? tile_list[slot] : slot;
+            t.id = (list_mode && tile_list) ? tile_list[slot] : slot + tile_base; // (tile_base: first tile of a window of the grid, else 0)
             const unsigned col = ts.by_nt2.div((unsigned)t.id);
             t2 = t.id - (int)col * nt2;
             t0 = (int)ts.by_nt1.div(col);
@@ -1189,9 +1189,18 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         return sc.error();
     hipStream_t st = sc.stream();
     int per = (int)((ntiles + 7) / 8);
-    int list_mode = 0;
+    int list_mode = 0, tile_base = 0, nt0_run = nt[0];
     if (plan.full) { // the statistics say that no 4x4x4 block of cells is empty: all tiles are live, workgroup b owns tile b
         tile_list = nullptr;
+    } else if (cg.win_hi > cg.win_lo) {
+        // the caller promised a window of planes along axis 0 (a slab of a decomposed system, mdh_hint_cell_window) and the cell
+        // grid was built over it: the tiles that can hold atoms are ONE range of tile numbers (axis 0 is the slowest index) —
+        // no list, no pass over the tiles of the global grid to make one
+        tile_list = nullptr;
+        const int t_lo = cg.win_lo / ts.txy, t_hi = (cg.win_hi - 1) / ts.txy;
+        tile_base = t_lo * nt[1] * nt[2];
+        nt0_run = t_hi - t_lo + 1;
+        per = (int)(((int64_t)nt0_run * nt[1] * nt[2] + 7) / 8);
     } else {
         hipLaunchKernelGGL(k_tile_live, dim3(grid_for(ntiles, 256)), dim3(256), 0, st, cg.cell_start, cg.g, nt[0], nt[1], nt[2], ts, live);
         MDH_TRY(exclusive_scan_u32(sc, live, slot, ntiles)); // slot[ntiles] = number of live tiles
@@ -1212,7 +1221,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.pk, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw); \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
@@ -1224,7 +1233,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
             if ((int64_t)per * 8 < ntiles)                                                                                                \
                 MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(512), per, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
         } else {                                                                                                                          \
-            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt[0], nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt0_run, nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
         }                                                                                                                                 \
         MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)

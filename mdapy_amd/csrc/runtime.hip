@@ -101,12 +101,23 @@ void *Scope::alloc(size_t bytes)
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes == 0) bytes = 256;
     std::lock_guard<std::mutex> lk(g_mu);
-    int best = -1;
+    // Best fit among the idle blocks this stream used last (or nobody did): no waiting.  A block last used on ANOTHER stream
+    // costs a wait for that stream's call to end — the caller's side stream packing halo messages would hold up the neighbor
+    // build on the main stream for a few counters' worth of scratch — so small requests get a block of their own instead
+    // (once per stream and size), and only large ones share across streams.
+    int best = -1, best_any = -1;
     for (size_t i = 0; i < g_blocks.size(); ++i) {
         const Block &b = g_blocks[i];
-        if (!b.busy && b.device == device_ && b.bytes >= bytes && (best < 0 || b.bytes < g_blocks[best].bytes))
+        if (b.busy || b.device != device_ || b.bytes < bytes)
+            continue;
+        if (best_any < 0 || b.bytes < g_blocks[best_any].bytes)
+            best_any = (int)i;
+        if ((!b.done || b.done->stream == stream_) && (best < 0 || b.bytes < g_blocks[best].bytes))
             best = (int)i;
     }
+    const bool fits = best >= 0 && g_blocks[best].bytes <= 2 * bytes + (1u << 20);
+    if (!fits && bytes > (size_t(4) << 20))
+        best = best_any;
     // reuse only if the block is not grossly oversized (keeps big list buffers from being pinned by tiny requests)
     if (best >= 0 && g_blocks[best].bytes <= 2 * bytes + (1u << 20)) {
         Block &b = g_blocks[best];

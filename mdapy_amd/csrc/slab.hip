@@ -130,6 +130,41 @@ extern "C" int mdh_slab_halo_messages(const double *x, const double *y, const do
     return MDH_OK;
 }
 
+// The receiving side of the same messages: the nl + nr atoms of the two incoming messages (layout of mdh_slab_halo_messages:
+// [count, row 0, row 1, ..., id row], rows `cap` long) are written behind the owned atoms — column k of the message to
+// cols[k][n_owned ...] (f64), the id row to gid[n_owned ...] (i64; ids < 2^53 are exact in f64) — left message first.  One
+// launch instead of two copies per column; nl and nr are the counts the caller has already read from the headers.
+namespace mdh {
+struct SlabColumns { double *p[7]; int n; };
+__global__ __launch_bounds__(256) void k_slab_append(const double *__restrict__ msg_l, const double *__restrict__ msg_r, int64_t cap, int64_t nl,
+                                                     int64_t nr, SlabColumns cols, int64_t *__restrict__ gid, int64_t n_owned)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nl + nr)
+        return;
+    const double *m = i < nl ? msg_l : msg_r;
+    const int64_t j = i < nl ? i : i - nl;
+    for (int k = 0; k < cols.n; ++k) cols.p[k][n_owned + i] = m[1 + (int64_t)k * cap + j];
+    gid[n_owned + i] = (int64_t)m[1 + (int64_t)cols.n * cap + j];
+}
+} // namespace mdh
+
+extern "C" int mdh_slab_append_ghosts(const double *msg_left, const double *msg_right, int64_t cap, int64_t nl, int64_t nr,
+                                      double *const *columns, int ncol, int64_t *gid, int64_t n_owned, void *stream)
+{
+    if (!msg_left || !msg_right || !columns || !gid || ncol < 3 || ncol > 7 || cap < 0 || nl < 0 || nr < 0 || nl > cap || nr > cap || n_owned < 0) {
+        set_error("mdh_slab_append_ghosts: bad arguments");
+        return MDH_ERR_ARG;
+    }
+    SlabColumns c{{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ncol};
+    for (int k = 0; k < ncol; ++k) c.p[k] = columns[k];
+    if (nl + nr > 0)
+        hipLaunchKernelGGL(k_slab_append, dim3(grid_for(nl + nr, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), msg_left, msg_right, cap, nl, nr, c,
+                           gid, n_owned);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
+
 // up / down: (capacity) i32 each; counts_host[0..1] receive the numbers of selected atoms — if one of them exceeds `capacity`
 // the buffers hold the first `capacity` selections only and the caller repeats the call with larger ones (a slab's halo is a
 // few per cent of its atoms: buffers sized for all of them would be ~72 B per owned atom of transient memory per step).  hi3 = column `axis` of the

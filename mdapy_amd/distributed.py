@@ -55,6 +55,8 @@ class SlabDecomposition:
         self._msg_buf = {}   # (columns, cap, device) -> the four message buffers
         self._roomy = {}     # data_ptr -> (weak reference, rows of spare room) of tensors made by with_room()
         self._own_mask = None
+        self._side = None    # HIP stream the next frame's halo travels on while this frame's kernels run (start_halo)
+        self._pending = {}   # (data_ptr of x, halo, columns) -> a halo exchange under way
 
     # -- wire -----------------------------------------------------------------
     def _host_staged(self):
@@ -191,6 +193,31 @@ class SlabDecomposition:
         messages on the device (slab.hip), each message carries its atom count in its first word, and the host reads the four
         counts — sent and received — in ONE copy after the ring: no count round trip, no second synchronisation.  The message
         size is agreed by all ranks (largest layer + 25 %) the first time a (halo, columns) pair is seen."""
+        key = (x.data_ptr(), float(halo), len(cols))
+        state = self._pending.pop(key, None)
+        if state is None or state["n_owned"] != int(x.shape[0]):
+            state = self._fast_begin(x, y, z, gid, cols, h, halo, side=False)
+        return self._fast_end(state)
+
+    def start_halo(self, x, y, z, gid, halo: float, extra=()):
+        """Begin the halo exchange of a frame — selection, packing, the ring, the read of the counts — on a side stream, and
+        return at once: the kernels of the frame before keep the device busy meanwhile (frames of a trajectory do not depend
+        on each other).  The exchange_halo(x, y, z, gid, halo, sort=False, extra=...) that follows with the SAME tensors picks
+        the messages up; until then the owned atoms must not change.  Without the single-message exchange (two ranks, host
+        tensors) this does nothing and exchange_halo does the whole exchange; with a host-staged ring (gloo) the exchange is
+        complete when this returns."""
+        t = _torch()
+        if self.world <= 2 or not x.is_cuda or len(extra) > 4:
+            return
+        cols = [x, y, z] + [e.to(t.float64) for e in extra]
+        key = (x.data_ptr(), float(halo), len(cols))
+        if key in self._pending:
+            return
+        if len(self._pending) > 2:
+            self._pending.clear()
+        self._pending[key] = self._fast_begin(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, self.halo_fraction(halo), halo, side=True)
+
+    def _fast_begin(self, x, y, z, gid, cols, h, halo, side):
         import ctypes
 
         from . import _lib
@@ -218,21 +245,42 @@ class SlabDecomposition:
         if bufs is None:
             if len(self._msg_buf) > 4:
                 self._msg_buf.clear()
-            bufs = tuple(t.empty(1 + width * cap, dtype=t.float64, device=dev) for _ in range(4))
+            bufs = tuple(t.empty(1 + width * cap, dtype=t.float64, device=dev) for _ in range(4)) + (t.empty(4, dtype=t.float64).pin_memory(),)
             self._msg_buf[key] = bufs
-        send_r, send_l, recv_l, recv_r = bufs
+        send_r, send_l, recv_l, recv_r, heads = bufs
         o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
         hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
         ex = [c.contiguous() for c in cols[3:]]
         exp = (ctypes.c_void_p * max(len(ex), 1))(*[e.data_ptr() for e in ex]) if ex else None
         g = gid.contiguous()
-        _lib.check(_lib.lib().mdh_slab_halo_messages(x.data_ptr(), y.data_ptr(), z.data_ptr(), n_owned, o.ctypes.data, hi3.ctypes.data,
-                                                     float(hi - h), float(lo + h), g.data_ptr(), exp, len(ex), send_r.data_ptr(),
-                                                     send_l.data_ptr(), cap, int(t.cuda.current_stream().cuda_stream)))
-        self._ring(send_r, send_l, recv_l, recv_r)
-        heads = t.stack([send_r[0], send_l[0], recv_l[0], recv_r[0]]).cpu().tolist()  # the one device-to-host read
+        main = t.cuda.current_stream()
+        if side:
+            if self._side is None:
+                self._side = t.cuda.Stream(device=dev)
+            stream = self._side
+            stream.wait_stream(main)  # the owned atoms are ready, and the previous frame's ghosts have been read out of the receive buffers
+        else:
+            stream = main
+        with t.cuda.stream(stream):
+            _lib.check(_lib.lib().mdh_slab_halo_messages(x.data_ptr(), y.data_ptr(), z.data_ptr(), n_owned, o.ctypes.data, hi3.ctypes.data,
+                                                         float(hi - h), float(lo + h), g.data_ptr(), exp, len(ex), send_r.data_ptr(),
+                                                         send_l.data_ptr(), cap, int(stream.cuda_stream)))
+            self._ring(send_r, send_l, recv_l, recv_r)
+            heads.copy_(t.stack([send_r[0], send_l[0], recv_l[0], recv_r[0]]), non_blocking=True)  # the one device-to-host read
+            done = t.cuda.Event()
+            done.record(stream)
+        return dict(cols=cols, gid=gid, ex=ex, g=g, n_owned=n_owned, cap=cap, sig=sig, bufs=bufs, done=done, side=side, dev=dev)
+
+    def _fast_end(self, st):
+        t = _torch()
+        st["done"].synchronize()  # (waits for the exchange only: kernels of the previous frame on the main stream keep running)
+        if st["side"]:
+            t.cuda.current_stream().wait_event(st["done"])
+        send_r, send_l, recv_l, recv_r, heads_pinned = st["bufs"]
+        heads = heads_pinned.tolist()
+        cap, dev, n_owned, cols, gid = st["cap"], st["dev"], st["n_owned"], st["cols"], st["gid"]
         if max(heads) > cap:
-            self._msg_cap.pop(sig, None)
+            self._msg_cap.pop(st["sig"], None)
             raise RuntimeError(f"halo message of {int(max(heads))} atoms does not fit the agreed {cap}: the system changed since the "
                                "size was agreed — call reset_halo_capacity() on all ranks and repeat the step")
         nl, nr = int(heads[2]), int(heads[3])
@@ -242,9 +290,20 @@ class SlabDecomposition:
         def row(msg, r, cnt):
             return msg[1 + r * cap: 1 + r * cap + cnt]
 
+        every = list(cols) + [gid]
+        if all(self._room_behind(c) >= n_ghost for c in every) and all(c.dtype == t.float64 for c in cols) and gid.dtype == t.int64 and len(cols) <= 7:
+            # every column has room behind its owned atoms: one kernel writes all ghosts in place
+            import ctypes
+
+            from . import _lib
+
+            ptrs = (ctypes.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+            _lib.check(_lib.lib().mdh_slab_append_ghosts(recv_l.data_ptr(), recv_r.data_ptr(), cap, nl, nr, ptrs, len(cols), gid.data_ptr(), n_owned,
+                                                         int(t.cuda.current_stream().cuda_stream)))
+            full = [t.empty(0, dtype=c.dtype, device=dev).set_(c.untyped_storage(), c.storage_offset(), (n_tot,), (1,)) for c in every]
+            return LocalDomain(full[0], full[1], full[2], full[-1], self._owned_mask(n_tot, n_owned, dev), n_owned, tuple(full[3:-1]))
         full = []
-        for k, c in enumerate(list(cols) + [gid]):
-            last = k == len(cols)
+        for k, c in enumerate(every):
             if self._room_behind(c) >= n_ghost:  # ghosts written behind the owned atoms, in place
                 whole = t.empty(0, dtype=c.dtype, device=dev).set_(c.untyped_storage(), c.storage_offset(), (n_tot,), (1,))
             else:
@@ -253,7 +312,6 @@ class SlabDecomposition:
             whole[n_owned:n_owned + nl].copy_(row(recv_l, k, nl))  # (the id row converts f64 -> i64 in the copy)
             whole[n_owned + nl:].copy_(row(recv_r, k, nr))
             full.append(whole)
-            del last
         return LocalDomain(full[0], full[1], full[2], full[-1], self._owned_mask(n_tot, n_owned, dev), n_owned, tuple(full[3:-1]))
 
     def hint_window(self, halo: float, like=None):
@@ -363,15 +421,20 @@ def partition_atoms(pos: np.ndarray, box: Box, world: int, axis: int = 0):
     return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
 
 
-def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh: int):
+def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh: int, next_frame=None):
     """One pass of the distributed hot path: halo exchange -> neighbor build -> fixed-cutoff CNA.
 
     Returns (dom, verlet, dist, nn, pattern): neighbor arrays / labels for ALL local atoms in `dom`
     order (rows of ghost atoms are incomplete; select with ``dom.owned``).  ``verlet`` holds local
     indices; ``dom.gid[verlet]`` maps them to global ids.
+
+    next_frame = (x, y, z, gid) of the frame the NEXT call will be given: its halo exchange is started on a side stream
+    before this frame's kernels are enqueued and travels while they run (SlabDecomposition.start_halo).
     """
     t = _torch()
     dom = dec.exchange_halo(x, y, z, gid, rc, sort=False)
+    if next_frame is not None:
+        dec.start_halo(*next_frame, rc)
     n = int(dom.x.shape[0])
     b = dec.box
     verlet = t.empty((n, max_neigh), dtype=t.int32, device=dom.x.device)

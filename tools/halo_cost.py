@@ -88,10 +88,27 @@ def prof(fn):
 
 ms_halo, dom = timed(lambda: dec.exchange_halo(x, y, z, gid, RC))
 ms_step, out = timed(lambda: D.neighbor_cna_step(dec, x, y, z, gid, RC, 16))
+ms_pipe, out = timed(lambda: D.neighbor_cna_step(dec, x, y, z, gid, RC, 16, next_frame=(x, y, z, gid)), reps=20)
+dec._pending.clear(); torch.cuda.synchronize()
+dom_p, v_p, d_p, nn_p, pat_p = out
+ok_pipe = bool((nn_p[dom_p.owned] == 12).all()) and bool((pat_p[dom_p.owned] == 1).all()) and int(dom_p.x.shape[0]) > n
 dom2, v, d, nn, pat = out
 ok = bool((nn[dom2.owned] == 12).all()) and bool((pat[dom2.owned] == 1).all())
 print("kernels (ms):", prof(lambda: D.neighbor_cna_step(dec, x, y, z, gid, RC, 16)))
-print(f"owned {n}, ghosts {int(dom.x.shape[0]) - n}; exchange_halo (loop-back) {ms_halo:.2f} ms; whole step {ms_step:.2f} ms; owned atoms all FCC with 12 neighbours: {ok}")
+print(f"owned {n}, ghosts {int(dom.x.shape[0]) - n}; exchange_halo (loop-back) {ms_halo:.2f} ms; whole step {ms_step:.2f} ms; "
+      f"with the next frame's exchange under way on a side stream {ms_pipe:.2f} ms; owned atoms all FCC with 12 neighbours: {ok} / {ok_pipe}")
+# the undivided step on the same box, for the ratio
+xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, 0.0)
+ubox = mp.Box(np.diag([A_CU * cells] * 3))
+from mdapy_amd import _neighbor as _nb, _cna as _cn
+uv, ud = torch.empty((n, 16), dtype=torch.int32, device=dev), torch.empty((n, 16), dtype=torch.float64, device=dev)
+un, up = torch.empty((n,), dtype=torch.int32, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev)
+def undivided():
+    up.zero_()
+    _nb.build_neighbor(xs, ys, zs, ubox.box, ubox.origin, ubox.boundary, RC, uv, ud, un, 1, fill_pads=True)
+    _cn.fcna(xs, ys, zs, ubox.box, ubox.origin, ubox.boundary, uv, un, up, RC, 1)
+ms_und, _ = timed(undivided, reps=20)
+print(f"undivided step of {n} atoms on the same box {ms_und:.2f} ms: loop-back slab step = {ms_step / ms_und:.3f}x, pipelined {ms_pipe / ms_und:.3f}x")
 
 import time as _t
 def lap(label, fn, reps=5):
