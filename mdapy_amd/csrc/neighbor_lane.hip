@@ -15,30 +15,39 @@
 //
 // Scan (hand-written, scan_run_asm).  A thread walks its 9 runs in the reference's order (neighbor.cpp:147-151), four
 // candidates per trip: four 16-byte LDS reads in flight, then per candidate 3 subtractions, an FMA chain ending in
-// e = d2 - c (c a little below rc^2), v_alignbit shifting e's SIGN into the hit mask, and an unsigned v_min of e's bits that
-// tracks the smallest non-negative e seen.  No per-candidate branch, ticket store, address arithmetic or VCC traffic:
-// 8 VALU instructions per candidate, all register-only single-precision / integer operations (2.7 cycles each on this chip
-// against 4.4 for anything that touches SGPRs / VCC or is double precision; tools/ubench).  |e_f32 - e_exact| <= tol (host,
-// from the tile extent): e < 0 is a hit, e > W a miss; a thread that saw 0 <= e <= W redoes ITS masks with the reference's
-// own double-precision expression.  Single precision only prunes: every distance that is WRITTEN is recomputed in double
-// precision from the raw coordinates exactly as the reference does (raw x[j] - wrapped x[i], minimum image,
-// (dx*dx + dy*dy) + dz*dz, sqrt), so rows are bit-identical.
+// e = d2 - c (c a little below rc^2), v_alignbit shifting e's SIGN into the hit mask, and — for two candidates at a time —
+// an unsigned v_min3 of e's bits that tracks the smallest non-negative e seen.  No per-candidate branch, ticket store,
+// address arithmetic or VCC traffic: 7.5 VALU instructions per candidate, all register-only single-precision / integer
+// operations (2.7 cycles each on this chip against 4.4 for anything that touches SGPRs / VCC or is double precision;
+// tools/ubench).  |e_f32 - e_exact| <= tol (host, from the tile extent): e < 0 is a hit, e > W a miss; a thread that saw
+// 0 <= e <= W redoes ITS masks with the reference's own double-precision expression.  Single precision only prunes: every
+// distance that is WRITTEN is recomputed in double precision from the raw coordinates exactly as the reference does (raw
+// x[j] - wrapped x[i], minimum image, (dx*dx + dy*dy) + dz*dz, sqrt), so rows are bit-identical.
 //
-// Output.  The masks are expanded into 2-byte tickets (LDS index of the candidate) in walk order; then the workgroup
-// writes rows cooperatively — MP adjacent lanes write the MP slots of one row, pads included — so a wave store covers whole
-// 64 B / 128 B row segments instead of 64 scattered rows.
+// Centres and waves.  The tile's centres go out in chunks of 64 (one per lane); chunk c is taken by wave (c + tile) mod 4,
+// which scans it, expands its masks into tickets in ITS rows of LDS and writes its rows — no workgroup barrier behind the
+// staging.
+//
+// Output, two instances (template TK8).  TK8 (rows of <= 16 slots, runs of <= 32 candidates; <= 128 VGPRs and ~38 KB of LDS:
+// FOUR workgroups per CU): one-byte tickets (run << 5 | position in the run; run 8 is the last of the walk, so its tickets
+// are the last of the row and a count says which they are); the centre's own lane decodes them, recomputes the distances
+// in double precision and holds its whole row in registers; the four lanes of a quad exchange 16-byte pieces (quad_transpose)
+// and store 16 bytes each: a quad writes 64 contiguous bytes of every row array.  Wide (!TK8: dense cells, rows of up to 64
+// slots, runs of up to 64 candidates as two masks): two-byte tickets, rows streamed four slots at a time, fewer rows per
+// wave (rw) where LDS is short.
 //
 // One tile per workgroup, straight-line code (template LOOP = false); the form that walks a list of tiles (LOOP = true)
 // only for the second pass and for what a tile list longer than the host expected leaves over: its loop-carried uniform
 // state costs 140 scalar-register spills.  Tiles whose halo does not fit the LDS budget are listed and taken by a SECOND
 // launch of the same kernel on one-cell slices of those tiles; what is left after that (a dense blob, atoms far outside the
-// box on an open axis, a run of more than 32 atoms) is listed again for the thread-per-atom code (k_neighbor_tiles).  Not
-// taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): open triclinic boxes, fewer than 7 cells on
-// a periodic axis or 4 on an open one, unwrapped input (device flag), max_neigh > 64, cells so full that runs exceed 32 atoms.
+// box on an open axis, a run longer than the instance's masks) is listed again for the thread-per-atom code
+// (k_neighbor_tiles).  Not taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): open triclinic
+// boxes, fewer than 7 cells on a periodic axis or 4 on an open one, unwrapped input (device flag), max_neigh > 64, grids
+// where more than 5 % of the runs hold 59 atoms or more.
 //
 // Measured (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16; DESIGN.md 3a has the counters, the per-phase time stamps of the
-// MDH_STAMPS build and the table of variants that were built and not kept): round-1 tiled kernel 1.78 ms, this kernel
-// 1.16 ms.
+// MDH_STAMPS build and the tables of what moved the kernel and what was built and not kept): round-1 tiled kernel 1.78 ms,
+// round 2 of this kernel 1.14 ms, now 0.92 ms.
 #include "common.hpp"
 #include "grid.hpp"
 #include "cna_core.hpp"
