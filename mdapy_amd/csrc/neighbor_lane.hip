@@ -217,6 +217,39 @@ __device__ __forceinline__ void scan_run_asm(unsigned a, int rem, float sx, floa
                    "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121");
     mask = m;
 }
+// TWELVE candidate slots of a run, straight-line: no trip counter, no EXEC mask, addresses as instruction offsets; the reads
+// of the later slots are issued as the registers of the earlier ones are consumed.  Bit (11 - j) of `mask` is candidate j.
+// For tiles whose runs all hold <= 12 candidates (the headline lattice: cells of 1, 2 or 4 atoms, runs of 2 ... 12, and
+// with 64 centres in a wave some lane always has a run of 10 or 12: the trip loop of scan_run_asm ran three trips for every
+// run anyway and paid a compare, two address updates and the EXEC bookkeeping for each).
+__device__ __forceinline__ void scan_run12_asm(unsigned a, float sx, float sy, float sz, float negc, unsigned &mask, unsigned &w)
+{
+    unsigned m;
+    asm volatile("v_mov_b32 %[m], 0\n\t"
+                 "ds_read_b128 v[100:103], %[a]\n\t"
+                 "ds_read_b128 v[104:107], %[a] offset:16\n\t"
+                 "ds_read_b128 v[108:111], %[a] offset:32\n\t"
+                 "ds_read_b128 v[112:115], %[a] offset:48\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND2("v100", "v101", "v102", "v104", "v105", "v106")
+                 "ds_read_b128 v[100:103], %[a] offset:64\n\t"
+                 "ds_read_b128 v[104:107], %[a] offset:80\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND2("v108", "v109", "v110", "v112", "v113", "v114")
+                 "ds_read_b128 v[108:111], %[a] offset:96\n\t"
+                 "ds_read_b128 v[112:115], %[a] offset:112\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND2("v100", "v101", "v102", "v104", "v105", "v106")
+                 "ds_read_b128 v[100:103], %[a] offset:128\n\t"
+                 "ds_read_b128 v[104:107], %[a] offset:144\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND2("v108", "v109", "v110", "v112", "v113", "v114")
+                 "ds_read_b128 v[108:111], %[a] offset:160\n\t"
+                 "ds_read_b128 v[112:115], %[a] offset:176\n\t"
+                 "s_waitcnt lgkmcnt(2)\n\t" MDH_CAND2("v100", "v101", "v102", "v104", "v105", "v106")
+                 "s_waitcnt lgkmcnt(0)\n\t" MDH_CAND2("v108", "v109", "v110", "v112", "v113", "v114")
+                 : [m] "=&v"(m), [w] "+v"(w)
+                 : [a] "v"(a), [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [negc] "v"(negc)
+                 : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",
+                   "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121");
+    mask = m;
+}
 #undef MDH_CAND2
 // slots a run of `len` candidates takes in its hit mask: whole trips of four
 __device__ __forceinline__ int run_slots(int len)
@@ -370,7 +403,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     __shared__ unsigned hc[MAX_NH + 2]; // halo cell: population
     __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
     __shared__ int scan_tmp[4];
-    __shared__ int s_flag[3];
+    __shared__ int s_flag[4];
     __shared__ int roff[16]; // halo cell of run r relative to the centre's cell
 
     const double rcsq = rc * rc, pad = rc + 1.0; // neighbor.cpp:127; pads neighbor.py:125-129
@@ -466,7 +499,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         const int tile_id = tile.id, T0 = tile.T0, T1 = tile.T1, T2 = tile.T2;
         const int cnt = cur.cnt, src = cur.src, img = cur.img, hz = cur.hz;
         const bool edge = cur.edge, centre_cell = cur.centre;
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; }
         if (tid < 9) roff[tid] = ((tid / 3 - 1) * HXY + (tid % 3 - 1)) * HZ; // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
         hc[tid] = (unsigned)cnt; // the neighbours in z need it for their run (published by the scan's barrier)
 
@@ -482,6 +515,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
             const unsigned k0 = (unsigned)off0 - hc[tid - 1], len = hc[tid - 1] + (unsigned)cnt + hc[tid + 1];
             hr[tid] = k0 | (len << 16);
             if (len > (TK8 ? 32u : 64u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4); two in the wide instance
+            if (TK8 && len > 12u) s_flag[3] = 1;        // no short-run scan for this tile (eight slots + up to four leftovers per run)
         }
         // ---- stage this cell's atoms
         if (ok && cnt > 0) {
@@ -561,6 +595,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
             flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
         }
         const bool general_tile = s_flag[0] != 0;
+        const bool short_runs = TK8 && s_flag[3] == 0; // every run of the tile holds <= 12 candidates
         // ---- From here on the four waves do not meet again: a wave takes whole chunks of the tile's centres, scans
         // them, leaves their tickets in ITS rows of tk and writes their rows itself — LDS traffic inside one wave is ordered,
         // no workgroup barrier — so one wave's scan overlaps another's write-out.
@@ -595,23 +630,35 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 for (int r = 0; r < 9; ++r) // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
                     hv[r] = hr[cb + ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ];
                 unsigned w = 0x7f7fffffu; // bits of the smallest non-negative d2 - c this centre has seen
+                // TK8: the masks are kept TOP-ALIGNED (bit 31 - j = candidate j of the run)
+                if (TK8 && short_runs) {
 #pragma unroll
-                for (int r = 0; r < 9; ++r) {
-                    const int len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
-                    scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), la, s.x, s.y, s.z, negc, mk[r], w);
-                    mk[r] &= ~0u << (run_slots(la) - la); // slots past the end of the run
-                    if (WIDE) {
-                        const int lb = len - la;
-                        mk2[r] = 0;
-                        if (__builtin_amdgcn_ballot_w64(lb > 0)) {
-                            scan_run_asm(f4_lds + (((hv[r] & 0xffffu) + 32u) << 4), lb, s.x, s.y, s.z, negc, mk2[r], w);
-                            mk2[r] &= lb > 0 ? ~0u << (run_slots(lb) - lb) : 0u;
+                    for (int r = 0; r < 9; ++r) {
+                        const int len = (int)(hv[r] >> 16);
+                        scan_run12_asm(f4_lds + ((hv[r] & 0xffffu) << 4), s.x, s.y, s.z, negc, mk[r], w);
+                        mk[r] = (mk[r] << 20) & (~0u << ((32 - len) & 31)) & (len > 0 ? ~0u : 0u); // slots past the end of the run
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) {
+                        const int len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
+                        scan_run_asm(f4_lds + ((hv[r] & 0xffffu) << 4), la, s.x, s.y, s.z, negc, mk[r], w);
+                        mk[r] &= ~0u << (run_slots(la) - la); // slots past the end of the run
+                        if (TK8) mk[r] <<= (32 - run_slots(la)) & 31; // (an empty run: mask 0, shift 0)
+                        if (WIDE) {
+                            const int lb = len - la;
+                            mk2[r] = 0;
+                            if (__builtin_amdgcn_ballot_w64(lb > 0)) {
+                                scan_run_asm(f4_lds + (((hv[r] & 0xffffu) + 32u) << 4), lb, s.x, s.y, s.z, negc, mk2[r], w);
+                                mk2[r] &= lb > 0 ? ~0u << (run_slots(lb) - lb) : 0u;
+                            }
                         }
                     }
                 }
                 {   // the centre itself sits in run 4 with d2 = 0: not a neighbour (neighbor.cpp:162)
                     const int len = (int)(hv[4] >> 16), idx = li - (int)(hv[4] & 0xffffu);
-                    if (!WIDE || idx < 32) mk[4] &= ~(1u << (run_slots(WIDE ? min(len, 32) : len) - 1 - idx));
+                    if (TK8) mk[4] &= ~(0x80000000u >> idx);
+                    else if (idx < 32) mk[4] &= ~(1u << (run_slots(min(len, 32)) - 1 - idx));
                     else mk2[4] &= ~(1u << (run_slots(len - 32) - 1 - (idx - 32)));
                 }
                 STAMP(4);
@@ -634,6 +681,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                         const int k0 = (int)(hv[r] & 0xffffu), len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
                         if (r == 4) mk[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0, la, li, xi, yi, zi);
                         else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0, la, li, xi, yi, zi);
+                        if (TK8) mk[r] <<= (32 - run_slots(la)) & 31;
                         if (WIDE) {
                             if (r == 4) mk2[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, len - la, li, xi, yi, zi);
                             else mk2[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, len - la, li, xi, yi, zi);
@@ -648,7 +696,8 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 if (COUNT) {
                     vmax = max(vmax, hits);
                 } else {
-                    // masks -> tickets in walk order: bit (S-1-j) of a run's mask is its candidate j.  Branch-free steps: a step
+                    // masks -> tickets in walk order: bit (S-1-j) of a run's mask is its candidate j (S = 32 in the one-byte
+                    // instance: top-aligned).  Branch-free steps: a step
                     // of a run that has no hit left writes into the row's spare slot M (v_ffbh of 0 is -1: the slot index
                     // saturates, the cleared bit is one of an empty mask).  Three steps per run cover nearly every run; a loop
                     // takes what is left.  (With a branch per step — v_cmp, s_and_saveexec, s_cbranch — the 36 steps of a centre
@@ -666,7 +715,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
 #pragma unroll
                     for (int r = 0; r < 9; ++r) {
                         const int len = (int)(hv[r] >> 16), la = WIDE ? min(len, 32) : len;
-                        const int jb = (((TK8 ? (r & 7) : r)) << JB) + (run_slots(la) - 32); // + clz(m) = the hit's ticket
+                        const int jb = TK8 ? ((r & 7) << JB) : (r << JB) + (run_slots(la) - 32); // + clz(m) = the hit's ticket
                         unsigned m = mk[r];
                         step(m, jb);
                         step(m, jb);
