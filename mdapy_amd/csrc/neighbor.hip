@@ -30,15 +30,16 @@ int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kern
 // ----------------------------------------------------------------------------
 // cell assignment: wrap, bin, take a slot from the cell's atomic counter
 // ----------------------------------------------------------------------------
+struct CellPlanes { int p0, p1, p2, p3; int *bad; }; // planes [p0, p1) and [p2, p3) of axis 0 hold every atom (bad == nullptr: not promised)
 template <bool TRI>
 __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
                                                 unsigned *__restrict__ cell_count, int *__restrict__ flags,
-                                                double slack, unsigned char *__restrict__ mv)
+                                                double slack, unsigned char *__restrict__ mv, CellPlanes win)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool moved = false;
+    bool moved = false, outside = false;
     int cell = -1 - (int)(threadIdx.x & 63); // lanes past the end: distinct negative values, no run, no atomic
     if (i < N) {
         const double xr = x[i], yr = y[i], zr = z[i];
@@ -67,6 +68,8 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
         cell_id[i] = cell;
+        if (win.bad && !((c0 >= win.p0 && c0 < win.p1) || (c0 >= win.p2 && c0 < win.p3)))
+            outside = true; // an atom outside the window of planes the caller promised (mdh_hint_cell_window)
     }
     // One returning atomic per RUN of adjacent lanes in the same cell instead of one per atom: atoms usually arrive in some
     // spatial order (a lattice builder, a file written cell by cell, a previous sort), so neighbouring lanes share cells;
@@ -89,6 +92,8 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
     }
     if (__any(moved) && (threadIdx.x & 63) == 0)
         flags[0] = 1;
+    if (__any(outside) && (threadIdx.x & 63) == 0)
+        atomicAdd(win.bad, 1);
 }
 
 // ----------------------------------------------------------------------------
@@ -305,18 +310,6 @@ __global__ __launch_bounds__(256) void k_add_from(int *__restrict__ out, int64_t
 }
 
 // atoms binned outside planes [p0, p1) u [p2, p3) of axis 0 (cells are a0-major)
-__global__ __launch_bounds__(256) void k_window_check(const int *__restrict__ cell_id, int64_t N, int64_t plane, int p0, int p1, int p2,
-                                                      int p3, int *__restrict__ bad)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool out = false;
-    if (i < N) {
-        const int a0 = (int)(cell_id[i] / plane);
-        out = !((a0 >= p0 && a0 < p1) || (a0 >= p2 && a0 < p3));
-    }
-    if (__any(out) && (threadIdx.x & 63) == 0) atomicAdd(bad, 1);
-}
-
 int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
 {
     double nc_total = 1.0;
@@ -402,10 +395,24 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 4, st));
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
+    // the promise is checked where the atoms are binned and read back by the next build of this thread
+    CellPlanes win{p0, p1, p2, p3, nullptr};
+    int *cnt2 = nullptr;
+    if (windowed) {
+        cnt2 = sc.alloc_n<int>(2);
+        if (sc.failed())
+            return sc.error();
+        if (!g_window_violations) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_window_violations), sizeof(int), hipHostMallocDefault));
+        *g_window_violations = 0;
+        MDH_HIP(hipMemsetAsync(cnt2, 0, sizeof(int), st));
+        win.bad = cnt2;
+    }
     if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv, win);
     else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv);
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv, win);
+    if (windowed)
+        MDH_HIP(hipMemcpyAsync(g_window_violations, cnt2, sizeof(int), hipMemcpyDeviceToHost, st));
     if (!windowed) {
         hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
@@ -413,9 +420,6 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     } else {
         // the pieces in index order: [p0, p1) then [p2, p3); a piece is scanned on its own, the atoms before it added by the
         // fill / by a second add pass; cell_start elsewhere = what a full scan leaves: the atoms binned so far
-        int *cnt2 = sc.alloc_n<int>(2);
-        if (sc.failed())
-            return sc.error();
         const int64_t a0 = p0 * plane, a1 = p1 * plane, b0 = p2 * plane, b1 = p3 * plane;
         auto scan_piece = [&](int64_t from, int64_t to) {
             const int64_t n = to - from, nb = (n + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
@@ -434,12 +438,6 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         } else if (a1 < g.ncell) {
             hipLaunchKernelGGL(k_fill_range, dim3(grid_for(g.ncell - a1, 256)), dim3(256), 0, st, cg.cell_start, a1 + 1, g.ncell + 1, (int)N);
         }
-        // the promise is checked on the device and read back by the next build of this thread
-        if (!g_window_violations) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_window_violations), sizeof(int), hipHostMallocDefault));
-        *g_window_violations = 0;
-        MDH_HIP(hipMemsetAsync(cnt2, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_window_check, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, N, plane, p0, p1, p2, p3, cnt2);
-        MDH_HIP(hipMemcpyAsync(g_window_violations, cnt2, sizeof(int), hipMemcpyDeviceToHost, st));
     }
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc) {

@@ -817,6 +817,47 @@ def test_system_flow_perfect_crystals_and_errors():
 
 
 # ------------------------------------------------------------------ PTM (a13): HIP kernel vs oracle/_ref, the reference's own library
+def test_neighbor_cell_window_hint_same_rows_and_broken_promise_is_reported():
+    """mdh_hint_cell_window (a rank's slab of a decomposed system): the build's passes over the cells of the global grid and
+    the tile kernel's range cover the promised planes only — rows, counts, distances bit-identical to the build without the
+    hint, with and without an ordering key; an atom outside the promised window is counted where the atoms are binned and the
+    NEXT build of the thread refuses loudly."""
+    import torch
+
+    pos, box = lattice_positions("fcc", 3.615, 40, 6, 6)
+    pos = pos + np.random.default_rng(8).normal(0, 0.05, pos.shape)
+    L = box[0][0] if np.ndim(box) == 2 else box[0]
+    f = (pos[:, 0] / L) % 1.0
+    pos = pos[(f >= 0.30) & (f < 0.52)]
+    N = len(pos)
+    rc, M = 0.854 * 3.615, 18
+    dev = torch.device("cuda", 0)
+    x, y, z = (torch.from_numpy(np.ascontiguousarray(pos[:, k])).to(dev) for k in range(3))
+    key = torch.from_numpy(np.random.default_rng(3).permutation(N).astype(np.int64) + 7).to(dev)
+
+    def build(hint, k=None):
+        v = torch.empty((N, M), dtype=torch.int32, device=dev)
+        d = torch.empty((N, M), dtype=torch.float64, device=dev)
+        n = torch.empty((N,), dtype=torch.int32, device=dev)
+        if hint is not None:
+            _neighbor.hint_cell_window(0, *hint)
+        _neighbor.build_neighbor(x, y, z, box, ORG0, PBC, rc, v, d, n, 1, fill_pads=True, key=k)
+        torch.cuda.synchronize()
+        return v.cpu().numpy(), d.cpu().numpy(), n.cpu().numpy()
+
+    for k in (None, key):
+        ref = build(None, k)
+        assert ref[2].max() >= 12
+        for _ in range(2):
+            got = build((0.28, 0.54), k)
+            assert all(np.array_equal(a, b_) for a, b_ in zip(got, ref))
+    build((0.40, 0.54))  # a third of the atoms lie below the promised window: counted on the device ...
+    with pytest.raises(ValueError, match="outside the cell window"):
+        build(None)      # ... and reported by the next build
+    got = build((0.28, 0.54))  # the thread is usable again
+    assert all(np.array_equal(a, b_) for a, b_ in zip(got, build(None)))
+
+
 from _ptm_cases import compare_ptm, ptm_cases
 from mdapy_amd import _ptm
 
