@@ -86,7 +86,7 @@ ALG = [
     ("k_knn_near<false, 12>", N3, 24 + 12 * 12, "k = 12"),
     ("k_knn_near<false, 14>", N3, 24 + 12 * 14, "k = 14"),
     ("k_knn<false>", N3, 24 + 12 * 18, "the general kernel on the to-do list of the near kernel (empty here: it leaves at once)"),
-    ("ptms::k_ptm_order_faces<false, 10, false>", N3, 24 + 72 + 18 + 72, "positions, row 4*18 in; order 18 B + ordered ids 4*18 out"),
+    ("ptms::k_ptm_order_faces<false, 10, false, 2>", N3, 24 + 72 + 18 + 72, "positions, row 4*18 in; order 18 B + ordered ids 4*18 out"),
     ("ptms::k_ptm_hull<false>", N3, 24 + 72 + 2 * (56 + 1), "positions + ordered ids in; 2 hulls x (28 facets x 2 B + status) out (fcc-hcp-bcc)"),
     ("ptms::k_ptm_canon<12, false>", N3, 57 + 8 + 17 + 1, "facets in; hash, labelling, flag out"),
     ("ptms::k_ptm_canon<14, false>", N3, 57 + 8 + 17 + 1, "same, 15-point cluster"),
@@ -95,7 +95,7 @@ ALG = [
     ("k_sq_stage1_l<false, 6>", N3, 24 + 4 + 12 * 12 + 2 * 16 * 13, "same, q_6m (13 x re,im)"),
     ("k_sq_final<true>", N3, 16 * 2 * 13 + 16, "q_lm rows in (416 B); q4, q6 out"),
     ("k_csp<false>", N3, 24 + 4 * 12 + 8, "positions, 12 ids in; csp out"),
-    ("k_acna<false, false>", N3, 24 + 4 * 14 + 4, "positions, 14 ids in; label out"),
+    ("k_acna_f32", N3, 24 + 4 * 14 + 4, "positions, 14 ids in; label out (single-precision pair tests; the double-precision kernel finishes its to-do list)"),
     ("ptms::k_ptm_shell<false, 4, 3>", N3, 24 + 72 + 18 + 17 * 28 + 1, '"all": positions, ordered ids + ranks in; 17-point cluster (ids, points) out'),
     ("ptms::k_ptm_hull_shell", N3, 17 * 24 + 1 + 57, '"all": cluster points in; 28 facets + status out'),
     ("ptms::k_ptm_canon<16, true>", N3, 57 + 8 + 17 + 1, '"all": facets in; hash, labelling, flag out'),
