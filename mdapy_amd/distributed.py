@@ -156,6 +156,12 @@ class SlabDecomposition:
             raise ValueError(f"slab thickness {thick / self.world:.3f} is smaller than the halo {halo}: use fewer ranks")
         return h
 
+    def _single_message(self, h: float) -> bool:
+        """may the single-message exchange serve this halo?  Three ranks and more: always.  Two ranks: the one neighbour is
+        both the left and the right one, and an atom within `halo` of BOTH faces of its slab would arrive twice (the general
+        path removes such duplicates); a slab at least four halos thick has no such atom."""
+        return self.world > 2 or (self.world == 2 and h <= 0.125)
+
     # -- the fast exchange: one message per direction, one host read -------------------------------------------------
     def with_room(self, tensor, fraction: float = 0.25):
         """a copy of a 1-D tensor of owned atoms with spare rows behind it: exchange_halo(sort=False) then appends the ghosts
@@ -207,7 +213,7 @@ class SlabDecomposition:
         tensors) this does nothing and exchange_halo does the whole exchange; with a host-staged ring (gloo) the exchange is
         complete when this returns."""
         t = _torch()
-        if self.world <= 2 or not x.is_cuda or len(extra) > 4:
+        if self.world < 2 or not x.is_cuda or len(extra) > 4 or not self._single_message(self.halo_fraction(halo)):
             return
         cols = [x, y, z] + [e.to(t.float64) for e in extra]
         key = (x.data_ptr(), float(halo), len(cols))
@@ -317,8 +323,10 @@ class SlabDecomposition:
     def hint_window(self, halo: float, like=None):
         """tell the next neighbor build where this rank's atoms are (slab + halo along the decomposed axis): its passes over the
         cells of the GLOBAL grid then cover that window only"""
-        if self.world > 2 and (like is None or getattr(like, "is_cuda", False)) and hasattr(kernels.neighbor, "hint_cell_window"):
+        if self.world >= 2 and (like is None or getattr(like, "is_cuda", False)) and hasattr(kernels.neighbor, "hint_cell_window"):
             h = self.halo_fraction(halo)
+            if not self._single_message(h):
+                return
             kernels.neighbor.hint_cell_window(self.axis, self.rank / self.world - h, (self.rank + 1) / self.world + h)
 
     # -- halo exchange --------------------------------------------------------
@@ -341,7 +349,7 @@ class SlabDecomposition:
             return LocalDomain(cols[0], cols[1], cols[2], gid, t.ones(n_owned, dtype=t.bool, device=dev), n_owned, tuple(cols[3:]))
         h = self.halo_fraction(halo)
         lo, hi = self.rank / self.world, (self.rank + 1) / self.world
-        if x.is_cuda and not sort and self.world > 2 and len(extra) <= 4:
+        if x.is_cuda and not sort and len(extra) <= 4 and self._single_message(h):
             return self._exchange_fast(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, h, halo)
         if x.is_cuda:  # selection and packing in one fused pass (slab.hip); the torch expressions below are its definition
             up, down, rows_r, rows_l = self._select_device(x, y, z, hi - h, lo + h, gid)

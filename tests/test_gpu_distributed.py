@@ -110,7 +110,7 @@ def _run_rank(rank, world, torch, dist_ready=True):
     # later calls consume the exchange the one before began (the order of the ghosts inside a message is not fixed)
     for it in range(3):
         check_step(f"prefetched halo {it}: ", *D.neighbor_cna_step(dec, *own_args, rc, M, next_frame=own_args))
-        check("an exchange is under way after the step", world <= 2 or len(dec._pending) == 1)
+        check("an exchange is under way after the step", world < 2 or len(dec._pending) == 1)
     dec._pending.clear()
     # ---- Steinhardt over the cutoff list, plain and neighbour-averaged (halo 2 rc)
     for average in (False, True):
