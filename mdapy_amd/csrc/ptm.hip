@@ -146,7 +146,7 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     int8_t *dord = sc.alloc_n<int8_t>((size_t)N * 18);
     int *dnbr = sc.alloc_n<int>((size_t)N * 18);
     unsigned char *dredo = sc.alloc_n<unsigned char>((size_t)N);
-    int *dcount = sc.alloc_n<int>(1);
+    int *dcount = sc.alloc_n<int>(2); // atoms for the second ordering pass; atoms with a face of more than eight vertices
     unsigned char *work = sc.alloc_n<unsigned char>(ptm_stage_bytes(N));
     if (sc.failed())
         return sc.error();

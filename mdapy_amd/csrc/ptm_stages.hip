@@ -18,6 +18,7 @@
 // Stages hand over through HBM in lane-major (structure-of-arrays) buffers: ~500 B per atom, read and written once.
 #include "common.hpp"
 #include "ptm_core.hpp"
+#include <type_traits>
 
 namespace mdh {
 namespace ptms {
@@ -55,6 +56,7 @@ struct OrderShared { // per workgroup
     int raw[ORD_APB][NROW];
     int cnt[ORD_APB];
     int overflow[ORD_APB];
+    int big[ORD_APB]; // a face of the atom had more than eight vertices at some point (statistic for the choice of the first pass)
 };
 template <int CAP, int DIM> constexpr size_t order_lds_bytes() { return sizeof(OrderShared) + (size_t)ORD_THREADS * CAP * DIM * 8; }
 
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_f
     const int scan = M < NROW ? (int)M : NROW;
     if (lane_on) {
         S.raw[slot][f] = f < scan ? verlet[atom * M + f] : -1;
-        if (f == 0) S.overflow[slot] = 0;
+        if (f == 0) { S.overflow[slot] = 0; S.big[slot] = 0; }
     }
     __syncthreads();
     int pos = -1; // this lane's place in the compacted row
@@ -125,9 +127,11 @@ __global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_f
         for (int i = 0; i < cnt; ++i) maxn = fmax(maxn, S.nsq[slot][i]);
         const double k = 10 * sqrt(maxn);
         double a = 0;
-        if (!(DIM == 2 ? ptmc::face_solid_angle_2d(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a)
+        int peak = 0;
+        if (!(DIM == 2 ? ptmc::face_solid_angle_2d(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a, (CAP > 8 && !REDO) ? &peak : nullptr)
                        : ptmc::face_solid_angle(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a)))
             S.overflow[slot] = 1;
+        if (CAP > 8 && !REDO && peak > 8) S.big[slot] = 1;
         S.area[slot][f] = a;
     }
     __syncthreads();
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_f
             }
             if (!REDO && f == 0) redo[atom] = 0;
         }
+        if (CAP > 8 && !REDO && f == 0 && (S.big[slot] | S.overflow[slot])) atomicAdd(redo_count + 1, 1);
     }
     if (REDO) __syncthreads(); // the shared arrays are reused by the next group
   }
@@ -154,15 +159,22 @@ __global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_f
 // ---------------------------------------------------------------------------------------------------------------------
 // stage 1: convex hulls of the first 7 / 13 / 15 points (ptm_core.hpp convex_hull / hull_init / add_facet)
 // ---------------------------------------------------------------------------------------------------------------------
-// facet word: bits 0-14 the oriented triangle with its smallest index first (5 bits each), bits 15-16 how far the
-// oriented triple was rotated to get there, bit 17 whether the creation order (a,b,c) was swapped to (b,a,c).  The extra
+// facet word: the oriented triangle with its smallest index first (IB bits each), then two bits for how far the
+// oriented triple was rotated to get there, then one for whether the creation order (a,b,c) was swapped to (b,a,c).  The extra
 // bits let a later test rebuild the normal from the very operands the facet was created with.
+// Up to 16 points (the single-shell hulls: 7, 13, 15 points) a vertex index takes 4 bits: the facet word fits 16 bits, a
+// horizon edge 8, and the stripe of a lane 500 bytes instead of 584 — five workgroups per CU instead of four for a kernel
+// that runs one wave per SIMD and waits on LDS most of the time.  The 17-point hull of the diamond clusters keeps 5 bits.
 template <int NP> struct HullMem {
+    static constexpr int IB = NP <= 16 ? 4 : 5;          // bits of a vertex index in a facet word
+    static constexpr uint32_t IM = (1u << IB) - 1u;
+    typedef typename std::conditional<(NP <= 16), uint16_t, uint32_t>::type FW;
+    typedef typename std::conditional<(NP <= 16), uint8_t, uint16_t>::type AW;
     double *P;   // [NP][3]
-    uint32_t *F; // [MAXF]
+    FW *F;       // [MAXF]
     uint32_t *E; // [NP-1]: edge marks of the current insertion, row = smaller endpoint, bit hi-1 seen in a visible facet, bit 16+hi-1 in a hidden one
-    uint16_t *A; // [MAXF]: horizon edges waiting to become facets
-    static constexpr size_t BYTES = (size_t)BLK * (NP * 3 * 8 + MAXF * 4 + (NP - 1) * 4 + MAXF * 2);
+    AW *A;       // [MAXF]: horizon edges waiting to become facets
+    static constexpr size_t BYTES = (size_t)BLK * (NP * 3 * 8 + MAXF * sizeof(FW) + (NP - 1) * 4 + MAXF * sizeof(AW));
     __device__ __forceinline__ void pt(int i, double *v) const
     {
         v[0] = P[(i * 3 + 0) * BLK];
@@ -224,18 +236,21 @@ template <int NP> __device__ uint32_t make_facet(const HullMem<NP> &m, int a, in
     if (o2 < o0 && o2 < o1) r = 2;
     if (r == 1 && o2 < o1) r = 2; // (unreachable for distinct indices; keeps the smallest-first rule explicit)
     const int c0 = r == 0 ? o0 : r == 1 ? o1 : o2, c1 = r == 0 ? o1 : r == 1 ? o2 : o0, c2 = r == 0 ? o2 : r == 1 ? o0 : o1;
-    const uint32_t w = (uint32_t)c0 | ((uint32_t)c1 << 5) | ((uint32_t)c2 << 10);
+    constexpr int IB = HullMem<NP>::IB;
+    const uint32_t w = (uint32_t)c0 | ((uint32_t)c1 << IB) | ((uint32_t)c2 << (2 * IB));
     bool dup = false;
     for (int j = 0; j < nf; ++j)
-        dup = dup || (m.F[j * BLK] & 0x7FFFu) == w;
-    return dup ? 0xFFFFFFFFu : (w | ((uint32_t)r << 15) | ((uint32_t)flip << 17));
+        dup = dup || ((uint32_t)m.F[j * BLK] & ((1u << (3 * IB)) - 1u)) == w;
+    return dup ? 0xFFFFFFFFu : (w | ((uint32_t)r << (3 * IB)) | ((uint32_t)flip << (3 * IB + 2)));
 }
 
 // is point q (coordinates) strictly outside facet word w ?
 template <int NP> __device__ __forceinline__ bool facet_sees(const HullMem<NP> &m, uint32_t w, const double *q)
 {
-    const int c0 = w & 31, c1 = (w >> 5) & 31, c2 = (w >> 10) & 31, r = (w >> 15) & 3;
-    const bool flip = (w >> 17) & 1;
+    constexpr int IB = HullMem<NP>::IB;
+    constexpr uint32_t IM = HullMem<NP>::IM;
+    const int c0 = w & IM, c1 = (w >> IB) & IM, c2 = (w >> (2 * IB)) & IM, r = (w >> (3 * IB)) & 3;
+    const bool flip = (w >> (3 * IB + 2)) & 1;
     const int o0 = r == 0 ? c0 : r == 1 ? c2 : c1, o1 = r == 0 ? c1 : r == 1 ? c0 : c2, o2 = r == 0 ? c2 : r == 1 ? c1 : c0;
     const int a = flip ? o1 : o0, b = flip ? o0 : o1;
     double N[3], pa[3], pp[3];
@@ -320,16 +335,21 @@ template <int NP> __device__ int hull_start(const HullMem<NP> &m, int num, HullS
         h.bary[0] += p[0]; h.bary[1] += p[1]; h.bary[2] += p[2];
     }
     h.bary[0] /= 4; h.bary[1] /= 4; h.bary[2] /= 4;
-    m.F[0 * BLK] = make_facet(m, a, b, c, h.bary, 0);
-    m.F[1 * BLK] = make_facet(m, a, b, d4, h.bary, 0);
-    m.F[2 * BLK] = make_facet(m, a, c, d4, h.bary, 0);
-    m.F[3 * BLK] = make_facet(m, b, c, d4, h.bary, 0);
+    typedef typename HullMem<NP>::FW FW;
+    m.F[0 * BLK] = (FW)make_facet(m, a, b, c, h.bary, 0);
+    m.F[1 * BLK] = (FW)make_facet(m, a, b, d4, h.bary, 0);
+    m.F[2 * BLK] = (FW)make_facet(m, a, c, d4, h.bary, 0);
+    m.F[3 * BLK] = (FW)make_facet(m, b, c, d4, h.bary, 0);
     return 0;
 }
 
 // hull of points [0,num); continues the hull of fewer points when h.ok.  0 ok, 1 the centre is on the hull, <0 failure
 template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullState &h)
 {
+    constexpr int IB = HullMem<NP>::IB;
+    constexpr uint32_t IM = HullMem<NP>::IM;
+    typedef typename HullMem<NP>::FW FW;
+    typedef typename HullMem<NP>::AW AW;
     int num_prev = h.num_prev;
     h.num_prev = num;
     if (!h.ok) {
@@ -349,7 +369,7 @@ template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullSt
         int nadd = 0;
         for (int j = 0; j < h.num_facets; ++j) {
             const uint32_t w = m.F[j * BLK];
-            const int a = w & 31, b = (w >> 5) & 31, c = (w >> 10) & 31;
+            const int a = w & IM, b = (w >> IB) & IM, c = (w >> (2 * IB)) & IM;
             const bool vis = facet_sees(m, w, q);
             const uint32_t side = vis ? 0u : 16u;
             // the three marks are independent LDS read-modify-writes (ds_or_rtn): issued back to back
@@ -366,25 +386,25 @@ template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullSt
                 --h.num_facets;
                 --j;
             }
-            if (u && nadd < MAXF) { m.A[nadd * BLK] = (uint16_t)(a | (b << 5)); ++nadd; }
-            if (v && nadd < MAXF) { m.A[nadd * BLK] = (uint16_t)(b | (c << 5)); ++nadd; }
-            if (x && nadd < MAXF) { m.A[nadd * BLK] = (uint16_t)(c | (a << 5)); ++nadd; }
+            if (u && nadd < MAXF) { m.A[nadd * BLK] = (AW)(a | (b << IB)); ++nadd; }
+            if (v && nadd < MAXF) { m.A[nadd * BLK] = (AW)(b | (c << IB)); ++nadd; }
+            if (x && nadd < MAXF) { m.A[nadd * BLK] = (AW)(c | (a << IB)); ++nadd; }
         }
         for (int j = 0; j < nadd; ++j) {
             if (h.num_facets >= MAXF)
                 return -4;
             const int e = m.A[j * BLK];
-            const uint32_t w = make_facet(m, i, e & 31, (e >> 5) & 31, h.bary, h.num_facets);
+            const uint32_t w = make_facet(m, i, e & IM, (e >> IB) & IM, h.bary, h.num_facets);
             if (w == 0xFFFFFFFFu)
                 return -5;
-            m.F[h.num_facets * BLK] = w;
+            m.F[h.num_facets * BLK] = (FW)w;
             ++h.num_facets;
         }
     }
     bool centre = false;
     for (int j = 0; j < h.num_facets; ++j) {
         const uint32_t w = m.F[j * BLK];
-        centre = centre || (w & 31) == 0; // the smallest index comes first
+        centre = centre || (w & IM) == 0; // the smallest index comes first
     }
     return centre ? 1 : 0;
 }
@@ -452,9 +472,10 @@ __global__ __launch_bounds__(BLK) void k_ptm_hull(const double *__restrict__ x, 
         return;
     HullMem<NP> m;
     m.P = reinterpret_cast<double *>(lds) + threadIdx.x;
-    m.F = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
-    m.E = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * 4)) + threadIdx.x;
-    m.A = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * 4 + (NP - 1) * 4)) + threadIdx.x;
+    typedef HullMem<NP> HM;
+    m.F = reinterpret_cast<HM::FW *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
+    m.E = reinterpret_cast<uint32_t *>(lds + (size_t)BLK * (NP * 24 + MAXF * sizeof(HM::FW))) + threadIdx.x;
+    m.A = reinterpret_cast<HM::AW *>(lds + (size_t)BLK * (NP * 24 + MAXF * sizeof(HM::FW) + (NP - 1) * 4)) + threadIdx.x;
     const int num = load_normalized<TRI, NP>(x, y, z, b, nbr, N, atom, m);
     HullState h;
     h.ok = false; h.num_prev = 0; h.num_facets = 0; h.processed = 0;
@@ -480,7 +501,8 @@ __global__ __launch_bounds__(BLK) void k_ptm_hull(const double *__restrict__ x, 
                 st = (int8_t)h.num_facets;
                 for (int j = 0; j < h.num_facets; ++j) {
                     const uint32_t w = m.F[j * BLK];
-                    out.facets[kind][(int64_t)j * N + atom] = (uint16_t)(((w & 31) - 1) | ((((w >> 5) & 31) - 1) << 5) | ((((w >> 10) & 31) - 1) << 10));
+                    out.facets[kind][(int64_t)j * N + atom] =
+                        (uint16_t)(((w & HM::IM) - 1) | ((((w >> HM::IB) & HM::IM) - 1) << 5) | ((((w >> (2 * HM::IB)) & HM::IM) - 1) << 10)); // (5 bits each on the way out)
                 }
             }
         }
@@ -1244,12 +1266,21 @@ void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
 
 static int g_order_cap = 10; // polygon vertices in the first pass (10: faces of up to ten corners — all of a crystal's — stay in it); larger faces take the second pass
 static int g_order_dim = 2;  // 2: polygons in the coordinates of their own plane; 3: in space (the form of rounds 1-2, kept for A/B)
-// test / measurement hook (mdh_debug_set_ptm_order_cap): |cap| -> 5, 10 or 15 vertices; a NEGATIVE value selects the 3-D polygons
+static bool g_order_auto = true;
+// Automatic choice of the first pass: eight-vertex polygons run at four waves per SIMD (128 VGPRs, 22 KB of LDS) and are 5 %
+// faster on crystals, whose faces stay small; a gas or a glass sends half its atoms to the second pass with them (2.2x
+// slower).  Every call counts the atoms that had a face of more than eight vertices; the count of the previous call with the
+// same number of atoms — read from pinned memory, never waited for, like the occupancy word of the neighbor build — picks
+// eight when fewer than 2 % of the atoms did, else ten (and ten for a first call).
+static int *g_order_stat = nullptr; // pinned: [0] atoms with a face of > 8 vertices in the last finished call
+static int64_t g_order_stat_n = -1; // ... which had this many atoms
+// test / measurement hook (mdh_debug_set_ptm_order_cap): 0 -> automatic; |cap| -> 5, 8, 10 or 15 vertices; a NEGATIVE value selects the 3-D polygons
 void ptm_debug_order_cap(int cap)
 {
+    g_order_auto = cap == 0;
     g_order_dim = cap < 0 ? 3 : 2;
     const int c = cap < 0 ? -cap : cap;
-    g_order_cap = c <= 5 ? 5 : c <= 8 ? 8 : c <= 10 ? 10 : 15;
+    g_order_cap = cap == 0 ? 10 : c <= 5 ? 5 : c <= 8 ? 8 : c <= 10 ? 10 : 15;
 }
 
 template <bool TRI, int CAP, int DIM>
@@ -1273,7 +1304,18 @@ int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64
                      int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st)
 {
     ProfRange pr("k_ptm_order", st);
-    MDH_HIP(hipMemsetAsync(redo_count, 0, sizeof(int), st));
+    MDH_HIP(hipMemsetAsync(redo_count, 0, 2 * sizeof(int), st));
+    if (!g_order_stat) {
+        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_order_stat), sizeof(int), hipHostMallocDefault));
+        *g_order_stat = 0;
+    }
+    if (g_order_auto)
+        g_order_cap = (g_order_stat_n == N && (int64_t)(*(volatile int *)g_order_stat) * 50 < N) ? 8 : 10;
+    const int ran_cap = g_order_cap;
+    struct Note { // after the passes: the statistic of this call on its way to the host
+        int *count; int cap; int64_t n; hipStream_t st;
+        ~Note() { (void)hipMemcpyAsync(g_order_stat, cap > 8 ? count + 1 : count, sizeof(int), hipMemcpyDeviceToHost, st); g_order_stat_n = n; }
+    } note{redo_count, ran_cap, N, st};
 #define MDH_ORD(TRI, CAP, DIM) return launch_ptm_order_as<TRI, CAP, DIM>(dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count, st)
 #define MDH_ORD_CAP(TRI, DIM)                                                                                                                  \
     do {                                                                                                                                       \
