@@ -907,12 +907,19 @@ struct MatchIn {
     ShellSet dc, gr;
 };
 
+// The single-shell instance (15 points) keeps a point's identity as its SLOT in the atom's ordered row (0 the atom itself,
+// k + 1 its k-th neighbour, -1 none: one byte, resolved through `nbr` where an atom id is wanted) instead of the id: 392
+// instead of 448 bytes per lane, six workgroups per CU instead of five for a stage that runs one wave per SIMD and is parked
+// on LDS and memory half of the time.  The two-shell instance (17 points of a cluster) keeps ids.
 template <int NPM> struct MatchMem {
     static constexpr int NP = NPM;
+    static constexpr bool SLOTS = NPM <= 15;
+    typedef typename std::conditional<SLOTS, int8_t, int>::type IdT;
+    static constexpr int NI = SLOTS ? 16 : 17, NV = SLOTS ? 16 : 20;
     double *P;  // [NP][3] raw separations (centre first)
-    int *I;     // [17] atom ids in the same order, later the matched ids in template order
-    int8_t *V;  // [20] inverse canonical labelling of the kind at hand
-    static constexpr size_t BYTES = (size_t)BLK * (NP * 24 + 17 * 4 + 20);
+    IdT *I;     // [NI] the points' slots / atom ids in the same order, later those of the matched atoms in template order
+    int8_t *V;  // [NV] inverse canonical labelling of the kind at hand
+    static constexpr size_t BYTES = (size_t)BLK * (NP * 24 + NI * sizeof(IdT) + NV);
 };
 
 struct GraphMap { // template point i -> cluster point V[autc[i]]
@@ -1022,7 +1029,8 @@ __device__ __forceinline__ void load_neighbourhood(const Mem &m, const double *_
 {
     const double xi = x[atom], yi = y[atom], zi = z[atom];
     m.P[0 * BLK] = 0; m.P[1 * BLK] = 0; m.P[2 * BLK] = 0;
-    m.I[0 * BLK] = (int)atom;
+    typedef typename Mem::IdT IdT;
+    m.I[0 * BLK] = Mem::SLOTS ? (IdT)0 : (IdT)atom;
     bool open = true;
 #pragma unroll
     for (int k = 0; k < 14; ++k) { // 15 points serve the largest single-shell template
@@ -1034,7 +1042,7 @@ __device__ __forceinline__ void load_neighbourhood(const Mem &m, const double *_
             fold<TRI>(b, dx, dy, dz);
         }
         m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
-        m.I[(k + 1) * BLK] = open ? j : -1;
+        m.I[(k + 1) * BLK] = open ? (Mem::SLOTS ? (IdT)(k + 1) : (IdT)j) : (IdT)-1;
     }
 }
 
@@ -1061,8 +1069,10 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
         return;
     Mem m;
     m.P = reinterpret_cast<double *>(lds) + threadIdx.x;
-    m.I = reinterpret_cast<int *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
-    m.V = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (NP * 24 + 17 * 4)) + threadIdx.x;
+    m.I = reinterpret_cast<typename Mem::IdT *>(lds + (size_t)BLK * NP * 24) + threadIdx.x;
+    m.V = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (NP * 24 + Mem::NI * sizeof(typename Mem::IdT))) + threadIdx.x;
+    // a stored identity -> atom id (MatchMem)
+    auto id_of = [&](int v) { return !Mem::SLOTS ? v : v < 0 ? -1 : v == 0 ? (int)atom : nbr[(int64_t)(v - 1) * N + atom]; };
     const Tables &T = *tables;
     load_neighbourhood<TRI>(m, x, y, z, b, nbr, N, atom);
     Best best;
@@ -1152,11 +1162,11 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
         // alloy ordering (ptm_core.hpp alloy_type); without a type column every atom is the same species
         ordering = ptmc::ALLOY_PURE;
         if (types) {
-            const int n0 = types[m.I[0]];
+            const int n0 = types[id_of(m.I[0])];
             bool pure = true, none = n0 == -1, binary = true;
             int other = -1;
             for (int i = 1; i < np; ++i) {
-                const int ni = types[m.I[i * BLK]];
+                const int ni = types[id_of(m.I[i * BLK])];
                 none = none || ni == -1;
                 if (ni != n0) {
                     pure = false;
@@ -1171,7 +1181,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
                 uint32_t bin = 0; // bit i: template point i holds the other species
 #pragma unroll
                 for (int i = 0; i < ptmc::MAX_PTS; ++i)
-                    if (i < np && types[m.I[pick[i] * BLK]] != n0) bin |= 1u << i;
+                    if (i < np && types[id_of(m.I[pick[i] * BLK])] != n0) bin |= 1u << i;
                 uint32_t lowest = 0xFFFFFFFFu;
                 for (int r = 0; r < s.num_maps; ++r) {
                     const int8_t *mp = T.maps[s.map_begin + r];
@@ -1216,11 +1226,11 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
             const int8_t *perm = T.maps[s.conv_begin + bi];
 #pragma unroll
             for (int i = 0; i < ptmc::MAX_PTS; ++i)
-                if (i < np) m.I[perm[i] * BLK] = ids_local[i];
+                if (i < np) m.I[perm[i] * BLK] = (typename Mem::IdT)ids_local[i];
         } else {
 #pragma unroll
             for (int i = 0; i < ptmc::MAX_PTS; ++i)
-                if (i < np) m.I[i * BLK] = ids_local[i];
+                if (i < np) m.I[i * BLK] = (typename Mem::IdT)ids_local[i];
         }
         type = best.type;
         o_rmsd = best.rmsd;
@@ -1238,7 +1248,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
         o[k] = k < 8 ? vals[k] : 0.0;
     int *pi = ptm_indices + atom * nind;
     for (int k = 0; k < nind; ++k)
-        pi[k] = k < num_out ? m.I[k * BLK] : -1;
+        pi[k] = k < num_out ? id_of(m.I[k * BLK]) : -1;
 }
 
 } // namespace ptms
