@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_rdf_cells(const double *__restrict__ xs
     hist_flush(lds, hist, use_lds, hsize);
 }
 
-// ---- streaming, cell-list path on LDS tiles (orthogonal boxes).  A workgroup takes one centre cell at a time and pairs its
+// ---- streaming, cell-list path on LDS tiles (orthogonal boxes, and triclinic ones periodic along all three vectors).  A workgroup takes one centre cell at a time and pairs its
 // atoms with those of the cell itself and of the 13 cells "ahead" of it in the walk order — every unordered pair of atoms
 // in neighbouring cells is met exactly once and counted in both directions, (ti, tj) and (tj, ti), which is what the
 // reference's full 27-cell walk over ordered pairs adds up to (:223-251), at half the distance evaluations.  The atoms are
@@ -102,14 +102,15 @@ __global__ __launch_bounds__(256) void k_rdf_cells(const double *__restrict__ xs
 // to f32 of magnitudes <= 2.7 rc, the subtractions, the FMA chain.
 constexpr int RDF_CEN = 256, RDF_QUEUE = 1024, RDF_NB = 14;
 
+template <bool TRI>
 __device__ __forceinline__ void rdf_exact_pair(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
                                                const DBox &b, int qi, int qj, int ti, int tj, int ntype, int nbin, double dr, double rcsq,
                                                unsigned *lds)
 {
     double xi = xs[qi], yi = ys[qi], zi = zs[qi];
-    if (b.anypbc) wrap<false>(b, xi, yi, zi);      // :213-214
+    if (b.anypbc) wrap<TRI>(b, xi, yi, zi);        // :213-214
     double ex = xs[qj] - xi, ey = ys[qj] - yi, ez = zs[qj] - zi;
-    pbc<false>(b, ex, ey, ez);
+    pbc<TRI>(b, ex, ey, ez);
     const double e2 = ex * ex + ey * ey + ez * ez;
     if (e2 < rcsq) {                               // strict, :246
         const int kk = (int)(sqrt(e2) / dr);
@@ -117,10 +118,15 @@ __device__ __forceinline__ void rdf_exact_pair(const double *__restrict__ xs, co
     }
 }
 
+// TRI: fully periodic triclinic boxes.  The same walk over the cells of the fractional grid; a cell's corner and the shift
+// to a neighbouring cell are sums of the cell's edge VECTORS (box vector d over nc[d]), the atoms are wrapped through the
+// fractional coordinates, and the band is widened by tol_scale = (extent of the 3x3x3-cell frame along the worst Cartesian
+// axis) / (2.7 rc): the single-precision error of a coordinate grows with the frame, which a sheared cell stretches.
+template <bool TRI>
 __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
                                                   const int *__restrict__ order, const int *__restrict__ cell_start,
                                                   const int *__restrict__ type, DBox b, Grid g, double rc, int nbin, int ntype,
-                                                  unsigned long long *__restrict__ hist)
+                                                  unsigned long long *__restrict__ hist, float tol_scale)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rdf_lds[];
     float4 *cen = reinterpret_cast<float4 *>(rdf_lds);               // [RDF_CEN] ux, uy, uz, bits of the position in the sorted arrays
@@ -136,7 +142,10 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
     for (int64_t q = tid; q < hsize; q += 256) lds[q] = 0u;
     const double dr = rc / nbin, rcsq = rc * rc; // :158-159
     const float drf = (float)dr, inv_dr = (float)(1.0 / dr), rc2f = (float)rcsq;
-    const double w[3] = {b.h[0] / g.nc[0], b.h[4] / g.nc[1], b.h[8] / g.nc[2]};
+    // edge vectors of a cell: ev[d][c] = component c of box vector d over nc[d] (orthogonal box: the diagonal only)
+    double ev[3][3];
+    for (int d = 0; d < 3; ++d)
+        for (int c = 0; c < 3; ++c) ev[d][c] = (TRI || d == c) ? b.h[3 * d + c] / g.nc[d] : 0.0;
     for (int64_t cell = blockIdx.x; cell < g.ncell; cell += gridDim.x) {
         const int c2 = (int)(cell % g.nc[2]), c1 = (int)((cell / g.nc[2]) % g.nc[1]), c0 = (int)(cell / ((int64_t)g.nc[1] * g.nc[2]));
         const int cs = cell_start[cell], ncen_all = cell_start[cell + 1] - cs;
@@ -156,8 +165,10 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
             }
             s_src[tid] = src;
             s_start[tid + 1] = n; // turned into a prefix below
-            s_lo[tid][0] = b.o[0] + a * w[0]; s_lo[tid][1] = b.o[1] + bb * w[1]; s_lo[tid][2] = b.o[2] + cc * w[2];
-            s_shift[tid][0] = (float)(da * w[0]); s_shift[tid][1] = (float)(db * w[1]); s_shift[tid][2] = (float)(dc * w[2]);
+            for (int c = 0; c < 3; ++c) {
+                s_lo[tid][c] = b.o[c] + a * ev[0][c] + bb * ev[1][c] + cc * ev[2][c];
+                s_shift[tid][c] = (float)(da * ev[0][c] + db * ev[1][c] + dc * ev[2][c]);
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                 const int q = cs + cbase + tid;
                 double xi = xs[q], yi = ys[q], zi = zs[q];
                 if (b.anypbc)
-                    wrap<false>(b, xi, yi, zi);
+                    wrap<TRI>(b, xi, yi, zi);
                 cen[tid] = make_float4((float)(xi - s_lo[0][0]), (float)(yi - s_lo[0][1]), (float)(zi - s_lo[0][2]), __int_as_float(q));
                 etype[tid] = (unsigned char)type[order[q]];
             }
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                 const int qj = s_src[k] + (gv - s_start[k]);
                 double xj = xs[qj], yj = ys[qj], zj = zs[qj];
                 if (b.anypbc)
-                    wrap<false>(b, xj, yj, zj);
+                    wrap<TRI>(b, xj, yj, zj);
                 const float ux = (float)(xj - s_lo[k][0]) + s_shift[k][0], uy = (float)(yj - s_lo[k][1]) + s_shift[k][1],
                             uz = (float)(zj - s_lo[k][2]) + s_shift[k][2];
                 const int tj = type[order[qj]];
@@ -194,13 +205,13 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                     const float4 ce = cen[c]; // one address for the whole wavefront: a broadcast read
                     const float dx = ux - ce.x, dy = uy - ce.y, dz = uz - ce.z;
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    if (r2 < rc2f * 1.0001f) {
+                    if (r2 < rc2f * (1.0f + 1.0e-4f * tol_scale)) {
                         const int qi = __float_as_int(ce.w);
                         if (same_cell && qj <= qi)
                             continue; // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
                         const int kb = (int)(__builtin_sqrtf(r2) * inv_dr);
                         const float lo = (float)kb * drf, hi = lo + drf;
-                        const float tol = 4.0e-6f * (rc2f + r2);
+                        const float tol = 4.0e-6f * tol_scale * (rc2f + r2);
                         const int ti = etype[c];
                         if (r2 - lo * lo > tol && hi * hi - r2 > tol) {
                             if (kb < nbin) {
@@ -217,8 +228,8 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                                 queue[2 * slot] = (unsigned)qi;
                                 queue[2 * slot + 1] = (unsigned)qj;
                             } else { // (a full list: this pair right away)
-                                rdf_exact_pair(xs, ys, zs, b, qi, qj, ti, tj, ntype, nbin, dr, rcsq, lds);
-                                rdf_exact_pair(xs, ys, zs, b, qj, qi, tj, ti, ntype, nbin, dr, rcsq, lds);
+                                rdf_exact_pair<TRI>(xs, ys, zs, b, qi, qj, ti, tj, ntype, nbin, dr, rcsq, lds);
+                                rdf_exact_pair<TRI>(xs, ys, zs, b, qj, qi, tj, ti, ntype, nbin, dr, rcsq, lds);
                             }
                         }
                     }
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
         const int nq = (int)min(s_nq, (unsigned)RDF_QUEUE);
         for (int e = tid; e < 2 * nq; e += 256) { // the pairs near a shell boundary, each direction as the reference bins it
             const int qa = (int)queue[2 * (e >> 1) + (e & 1)], qb = (int)queue[2 * (e >> 1) + 1 - (e & 1)];
-            rdf_exact_pair(xs, ys, zs, b, qa, qb, type[order[qa]], type[order[qb]], ntype, nbin, dr, rcsq, lds);
+            rdf_exact_pair<TRI>(xs, ys, zs, b, qa, qb, type[order[qa]], type[order[qb]], ntype, nbin, dr, rcsq, lds);
         }
     }
     __syncthreads();
@@ -373,10 +384,23 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         cg.g.mode = 1;
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, false, cg));
         const size_t tile_lds = (size_t)RDF_CEN * 17 + (size_t)RDF_QUEUE * 8 + (size_t)hsize * 4;
-        if (!b.tri && ntype <= 255 && hsize <= RDF_LDS_BINS && g_rdf_variant == 0) {
+        // the frame of 3x3x3 cells along the worst Cartesian axis, in units of the orthogonal kernel's 2.7 rc
+        double tol_scale = 1.0;
+        const bool tri_tile = b.tri && b.pbc[0] && b.pbc[1] && b.pbc[2];
+        if (tri_tile) {
+            for (int c = 0; c < 3; ++c) {
+                double ext = 0;
+                for (int d = 0; d < 3; ++d) ext += 2.0 * std::fabs(b.h[3 * d + c]) / cg.g.nc[d];
+                tol_scale = std::max(tol_scale, ext / (2.7 * rc));
+            }
+        }
+        if ((!b.tri || (tri_tile && tol_scale < 64.0)) && ntype <= 255 && hsize <= RDF_LDS_BINS && g_rdf_variant == 0) {
             ProfRange pr("k_rdf_tile", st);
             const unsigned blocks = (unsigned)std::min<int64_t>(cg.g.ncell, 256 * 8);
-            hipLaunchKernelGGL(k_rdf_tile, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist);
+            if (b.tri)
+                hipLaunchKernelGGL(k_rdf_tile<true>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, (float)tol_scale);
+            else
+                hipLaunchKernelGGL(k_rdf_tile<false>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, 1.0f);
         } else if (b.tri)
             hipLaunchKernelGGL(k_rdf_cells<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, N, b, cg.g, rc, nbin, ntype, hist);
         else

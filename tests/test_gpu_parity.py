@@ -667,6 +667,15 @@ def test_streaming_rdf_tile_kernel_edge_cases():
     jobs.append(("dense_gas", dense, np.eye(3) * 30.0, ORG0, PBC, rng.integers(0, 2, 9000).astype(np.int32), 9.9, 500))  # ~330 atoms per cell
     edge = np.concatenate([np.arange(0, 200)[:, None] * np.array([[0.04, 0, 0]]) + 10.0, [[10.0, 10.0, 10.0]]])      # distances exactly on shell boundaries
     jobs.append(("on_the_boundaries", edge, np.eye(3) * 40.0, ORG0, PBC, np.zeros(len(edge), np.int32), 8.0, 200))
+    # triclinic boxes periodic along all three vectors take the tile kernel too (cell edge vectors instead of widths, a band
+    # widened with the shear); an open triclinic box keeps the thread-per-atom kernel — same counts either way
+    for tag, shear in (("tri_mild", 0.15), ("tri_strong", 0.45)):
+        H = np.array([[36.0, 0, 0], [shear * 36.0, 36.0, 0], [-0.5 * shear * 36.0, shear * 36.0, 36.0]])
+        frac = pos / 36.0
+        ptri = frac @ H + rng.integers(-1, 2, pos.shape) @ H * (tag == "tri_strong")  # (the strong one also handed in unwrapped)
+        jobs.append((tag, ptri + 2.0, H, np.array([2.0, 2.0, 2.0]), PBC, ty3, 6.5, 120))
+    jobs.append(("tri_open_x", (pos / 36.0) @ np.array([[36.0, 0, 0], [7.0, 36.0, 0], [0, 5.0, 36.0]]), np.array([[36.0, 0, 0], [7.0, 36.0, 0], [0, 5.0, 36.0]]),
+                 ORG0, np.array([0, 1, 1], np.int32), ty3, 6.0, 60))
     for name, p, bx, org, bd, ty, rc, nbin in jobs:
         x, y, z = _xyz(p)
         nt = int(ty.max()) + 1
