@@ -66,10 +66,11 @@ __device__ __forceinline__ int floordiv(int a, int n) { int q = a / n; return (a
 // REGISTERS (K slots, K >= k a template constant): an insertion is a fully unrolled count of the entries that stay in front
 // (the position) and one predicated move per slot, ~14 instructions per slot and no memory access, where the list in LDS
 // pays two dependent LDS round trips per shifted entry at two waves per SIMD (measured: 15 of 21 ms at k = 18 went into
-// shifting).  No LDS at all, so occupancy is set by the registers.  A query that does not find k candidates within one cell
+// shifting).  No LDS at all, so occupancy is set by the registers: k <= 18 is held to 128 VGPRs (four waves per SIMD; 9 - 26
+// values spill) — 6.7 -> 6.0 ms at k = 12, 11.5 -> 10.1 ms at k = 18 for 10 M atoms; k = 24 loses with it (20 -> 26 ms) and keeps three.  A query that does not find k candidates within one cell
 // width is appended to `todo` and finished by k_knn (any number of rings, list in LDS).
 template <bool TRI, int K>
-__global__ __launch_bounds__(256) void k_knn_near(const double *__restrict__ xs, const double *__restrict__ ys,
+__global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const double *__restrict__ xs, const double *__restrict__ ys,
                                                   const double *__restrict__ zs, const int *__restrict__ order,
                                                   const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg, Grid g,
                                                   KnnGeom kg, int k, int *__restrict__ indices,
