@@ -18,11 +18,11 @@ namespace mdh {
 static constexpr int VORO_MAXC = 250;  // neighbours one cell may consider
 static constexpr int VORO_LANES = 64;
 
-struct PolyLdsV { // vertex i, coordinate c of lane l at [(i*3 + c) * 64 + l]
-    static constexpr int CAP = 16;
+struct PolyLdsV { // vertex i, plane coordinate c (voro_core.hpp voronoi_face_2d) of lane l at [(i*2 + c) * 64 + l]
+    static constexpr int CAP = 12;
     double *base;
-    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 3 + c) * VORO_LANES]; }
-    __device__ __forceinline__ void set(int i, int c, double x) { base[(i * 3 + c) * VORO_LANES] = x; }
+    __device__ __forceinline__ double get(int i, int c) const { return base[(i * 2 + c) * VORO_LANES]; }
+    __device__ __forceinline__ void set(int i, int c, double x) { base[(i * 2 + c) * VORO_LANES] = x; }
 };
 
 // optional per-face output of the cell-info call: polygons relative to the atom
@@ -62,10 +62,15 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
             }
         return;
     }
-    __shared__ double nrm[VORO_MAXC + 6][3];
-    __shared__ double off[VORO_MAXC + 6], dist[VORO_MAXC + 6];
-    __shared__ double poly_lds[PolyLdsV::CAP * 3 * VORO_LANES];
-    __shared__ double farea[VORO_MAXC + 6]; // area of face f (0: no face)
+    // LDS of the wave, sized by the launch for the rows it was given (ncap = min(M, VORO_MAXC) + 6 constraints): polygons 12 KB
+    // + 48 bytes per constraint — 16 KB and eight waves per CU at the usual 80-neighbour rows (36.9 KB and four waves with
+    // 16-vertex polygons in space and tables for 256 constraints)
+    extern __shared__ __attribute__((aligned(16))) double voro_lds[];
+    const int ncap = (int)(M < VORO_MAXC ? M : VORO_MAXC) + 6;
+    double *poly_lds = voro_lds;                                         // [CAP * 2 * 64]
+    double (*nrm)[3] = reinterpret_cast<double (*)[3]>(poly_lds + PolyLdsV::CAP * 2 * VORO_LANES); // [ncap][3]
+    double *off = reinterpret_cast<double *>(nrm + ncap), *dist = off + ncap; // [ncap] each
+    double *farea = dist + ncap;                                         // [ncap] area of face f (0: no face)
     const double xi = x[i], yi = y[i], zi = z[i];
     // rows are sorted by distance: a crowded atom uses its VORO_MAXC nearest neighbours and is complete within THEIR reach
     const int n = min(min(nn[i], (int)M), VORO_MAXC);
@@ -102,16 +107,17 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
     for (int f0 = 0; f0 < nc; f0 += VORO_LANES) {
         const int f = f0 + lane;
         bool have = false;
-        voroc::FaceResult r{0.0, 0.0, false, 0};
+        voroc::FaceResult2 r;
+        r.area = 0.0; r.maxr2 = 0.0; r.overflow = false; r.nv = 0;
         PolyLdsV fast{poly_lds + lane};
         ptmc::PolyLocal slow;
         bool in_slow = false;
         if (f < nc) {
             farea[f] = 0.0;
             if (!(f < 6 && (TRI || b.pbc[f >> 1]))) { // the bounding cube is not a face
-                r = voroc::voronoi_face(fast, f, nc, nrm, off, dist, 6, big);
-                if (r.overflow) { // a face with more than 16 vertices: private storage holds 28
-                    r = voroc::voronoi_face(slow, f, nc, nrm, off, dist, 6, big);
+                r = voroc::voronoi_face_2d(fast, f, nc, nrm, off, dist, 6, big);
+                if (r.overflow) { // a face with more than 12 vertices: private storage holds 28
+                    r = voroc::voronoi_face_2d(slow, f, nc, nrm, off, dist, 6, big);
                     in_slow = true;
                 }
                 if (!r.overflow && r.area > voroc::AREA_TOL * dist[f] * dist[f]) {
@@ -133,9 +139,11 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                     co.nv[o] = r.nv;
                     co.area[o] = r.area;
                     if (r.nv > co.V) atomicMax(co.need_v, r.nv);
-                    for (int c = 0; c < r.nv && c < co.V; ++c)
-                        for (int d = 0; d < 3; ++d)
-                            co.vert[(o * co.V + c) * 3 + d] = in_slow ? slow.get(c, d) : fast.get(c, d);
+                    for (int c = 0; c < r.nv && c < co.V; ++c) {
+                        double p3[3];
+                        if (in_slow) r.vertex(slow, c, p3); else r.vertex(fast, c, p3);
+                        for (int d = 0; d < 3; ++d) co.vert[(o * co.V + c) * 3 + d] = p3[d];
+                    }
                 }
             }
             co_base += __popcll(m);
@@ -288,10 +296,11 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         if (dmaxf) MDH_HIP(hipMemsetAsync(dmaxf, 0, sizeof(int), st));
         {
             ProfRange pr("k_voronoi", st);
+            const size_t voro_lds_bytes = ((size_t)PolyLdsV::CAP * 2 * VORO_LANES + (size_t)((M < VORO_MAXC ? M : VORO_MAXC) + 6) * 6) * sizeof(double);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), 0, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));

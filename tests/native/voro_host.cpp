@@ -40,7 +40,7 @@ extern "C" int voroh_run(const double *x, const double *y, const double *z, int6
         for (int f = 0; f < nc; ++f) {
             if (f < 6 && pbc3[f / 2]) continue; // the cube is not a face
             ptmc::PolyLocal poly;
-            FaceResult r = voronoi_face(poly, f, nc, (const double(*)[3])nrm.data(), off.data(), dist.data(), first_sorted, big);
+            FaceResult2 r = voronoi_face_2d(poly, f, nc, (const double(*)[3])nrm.data(), off.data(), dist.data(), first_sorted, big); // the form the device runs
             if (r.overflow) return -2;
             if (r.area > AREA_TOL * dist[f] * dist[f]) { vol += r.area * dist[f] / 3.0; ++nf; mr2 = std::max(mr2, r.maxr2); }
         }
