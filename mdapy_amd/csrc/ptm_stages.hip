@@ -710,11 +710,16 @@ __global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x,
     const int64_t atom = (int64_t)blockIdx.x * BLK + threadIdx.x;
     if (atom >= N)
         return;
-    double *OP = reinterpret_cast<double *>(lds) + threadIdx.x;                       // [NPT][3]
-    int *OI = reinterpret_cast<int *>(lds + (size_t)BLK * NPT * 24) + threadIdx.x;    // [NPT]
+    // Only the ids of the cluster live in LDS (68 bytes per lane).  The centre and the inner atoms' positions are registers;
+    // an outer atom's position goes straight to its place in the output and is read back only in the rare case that the same
+    // atom id turns up again (an image of it in a small periodic box).  With ids AND positions in LDS (476 bytes per lane)
+    // the kernel — a chain of dependent row and position reads per outer atom — ran 1.25 waves per SIMD and was parked 61 %
+    // of the time.
+    int *OI = reinterpret_cast<int *>(lds) + threadIdx.x; // [NPT]
     const double xi = x[atom], yi = y[atom], zi = z[atom];
+    double rp[INNER + 1][3]; // centre, inner atoms: relative to the centre
     OI[0] = (int)atom;
-    OP[0] = 0; OP[1 * BLK] = 0; OP[2 * BLK] = 0;
+    rp[0][0] = rp[0][1] = rp[0][2] = 0;
     int m = 1;
     for (int k = 0; k < NROW && m < INNER + 1; ++k) {
         int j;
@@ -723,7 +728,9 @@ __global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x,
         double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
         fold<TRI>(b, dx, dy, dz);
         OI[m * BLK] = j;
-        OP[(m * 3 + 0) * BLK] = dx; OP[(m * 3 + 1) * BLK] = dy; OP[(m * 3 + 2) * BLK] = dz;
+#pragma unroll
+        for (int i = 1; i <= INNER; ++i)
+            if (i == m) { rp[i][0] = dx; rp[i][1] = dy; rp[i][2] = dz; }
         ++m;
     }
     bool good = m == INNER + 1;
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x,
     if (good) {
         double tol;
         {
-            const double d[3] = {OP[0] - OP[3 * BLK], OP[1 * BLK] - OP[4 * BLK], OP[2 * BLK] - OP[5 * BLK]};
+            const double d[3] = {rp[0][0] - rp[1][0], rp[0][1] - rp[1][1], rp[0][2] - rp[1][2]};
             tol = 1E-5 * sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             tol = tol > 1E-5 ? tol : 1E-5;
         }
@@ -764,14 +771,17 @@ __global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x,
                         continue;
                     double dx = x[id] - ix[i], dy = y[id] - iy[i], dz = z[id] - iz[i];
                     fold<TRI>(b, dx, dy, dz);
-                    const double px = dx + OP[((1 + i) * 3 + 0) * BLK], py = dy + OP[((1 + i) * 3 + 1) * BLK], pz = dz + OP[((1 + i) * 3 + 2) * BLK];
+                    const double px = dx + rp[1 + i][0], py = dy + rp[1 + i][1], pz = dz + rp[1 + i][2];
                     bool claimed = false;
 #pragma unroll
                     for (int k = 0; k < NPT; ++k) {
                         if (k > INNER && !((filled >> k) & 1u))
                             continue;
                         if (id == OI[k * BLK]) {
-                            const double d[3] = {px - OP[(k * 3 + 0) * BLK], py - OP[(k * 3 + 1) * BLK], pz - OP[(k * 3 + 2) * BLK]};
+                            double q[3];
+                            if (k <= INNER) { q[0] = rp[k <= INNER ? k : 0][0]; q[1] = rp[k <= INNER ? k : 0][1]; q[2] = rp[k <= INNER ? k : 0][2]; }
+                            else { q[0] = out.pts[(int64_t)(k * 3 + 0) * N + atom]; q[1] = out.pts[(int64_t)(k * 3 + 1) * N + atom]; q[2] = out.pts[(int64_t)(k * 3 + 2) * N + atom]; }
+                            const double d[3] = {px - q[0], py - q[1], pz - q[2]};
                             if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < tol) claimed = true;
                         }
                     }
@@ -779,7 +789,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x,
                         continue;
                     const int slot = 1 + INNER + OUTER * i + counts[i];
                     OI[slot * BLK] = id;
-                    OP[(slot * 3 + 0) * BLK] = px; OP[(slot * 3 + 1) * BLK] = py; OP[(slot * 3 + 2) * BLK] = pz;
+                    out.pts[(int64_t)(slot * 3 + 0) * N + atom] = px; out.pts[(int64_t)(slot * 3 + 1) * N + atom] = py; out.pts[(int64_t)(slot * 3 + 2) * N + atom] = pz;
                     filled |= 1u << slot;
                     ++counts[i];
                     ++found;
@@ -792,9 +802,11 @@ __global__ __launch_bounds__(BLK) void k_ptm_shell(const double *__restrict__ x,
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             out.ids[(int64_t)k * N + atom] = OI[k * BLK];
-            out.pts[(int64_t)(k * 3 + 0) * N + atom] = OP[(k * 3 + 0) * BLK];
-            out.pts[(int64_t)(k * 3 + 1) * N + atom] = OP[(k * 3 + 1) * BLK];
-            out.pts[(int64_t)(k * 3 + 2) * N + atom] = OP[(k * 3 + 2) * BLK];
+            if (k <= INNER) {
+                out.pts[(int64_t)(k * 3 + 0) * N + atom] = rp[k <= INNER ? k : 0][0];
+                out.pts[(int64_t)(k * 3 + 1) * N + atom] = rp[k <= INNER ? k : 0][1];
+                out.pts[(int64_t)(k * 3 + 2) * N + atom] = rp[k <= INNER ? k : 0][2];
+            }
         }
     }
 }
@@ -1393,7 +1405,7 @@ int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int6
     }
     if (flags & want[K_DC]) {
         ProfRange pr("k_ptm_shell", st);
-        const size_t lds = (size_t)BLK * 17 * 28;
+        const size_t lds = (size_t)BLK * 17 * 4;
         if (b.tri)
             hipLaunchKernelGGL((k_ptm_shell<true, 4, 3>), grid, block, lds, st, dx, dy, dz, N, b, nbr, orders, dc);
         else
@@ -1402,7 +1414,7 @@ int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int6
     }
     if (flags & ptmc::CHECK_GRAPHENE) {
         ProfRange pr("k_ptm_shell", st);
-        const size_t lds = (size_t)BLK * 10 * 28;
+        const size_t lds = (size_t)BLK * 10 * 4;
         if (b.tri)
             hipLaunchKernelGGL((k_ptm_shell<true, 3, 2>), grid, block, lds, st, dx, dy, dz, N, b, nbr, orders, gr);
         else
