@@ -19,6 +19,7 @@
 // compact kernel that evaluates the reference expression as is (GENERIC = true).
 #include "common.hpp"
 #include "cna_core.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -73,24 +74,25 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
                                               const int *__restrict__ verlet, int64_t M, const int *__restrict__ nn,
                                               int *__restrict__ pattern, double rc, int *__restrict__ todo)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (GENERIC) {
-        if (i >= todo[0])
-            return;
-        i = todo[1 + i];
-    } else if (i >= N) {
-        return;
-    }
     __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread (read back by the thread that wrote them)
-    const int n = nn[i];
     const double cut2 = rc * rc; // cna.cpp:449
-    const int *row = verlet + i * M;
-    // atoms with nn not in {12,14} keep the caller's value (cna.cpp:456)
-    int t = 0;
-    if (n == 12 && M >= 12) t = fcna_atom<TRI, GENERIC, 12>(b, x, y, z, row, cut2, i, N, srows + threadIdx.x);
-    else if (n == 14 && M >= 14) t = fcna_atom<TRI, GENERIC, 14>(b, x, y, z, row, cut2, i, N, srows + threadIdx.x);
-    if (t > 0) pattern[i] = t;
-    else if (!GENERIC && t < 0) defer(todo, i);
+    auto one = [&](int64_t i) {
+        const int n = nn[i];
+        const int *row = verlet + i * M;
+        // atoms with nn not in {12,14} keep the caller's value (cna.cpp:456)
+        int t = 0;
+        if (n == 12 && M >= 12) t = fcna_atom<TRI, GENERIC, 12>(b, x, y, z, row, cut2, i, N, srows + threadIdx.x);
+        else if (n == 14 && M >= 14) t = fcna_atom<TRI, GENERIC, 14>(b, x, y, z, row, cut2, i, N, srows + threadIdx.x);
+        if (t > 0) pattern[i] = t;
+        else if (!GENERIC && t < 0) defer(todo, i);
+    };
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (GENERIC) { // the to-do list of the single-precision kernel: its length is on the device, the grid is a fixed small one
+        const int64_t total = todo[0];
+        for (int64_t q = first; q < total; q += (int64_t)gridDim.x * blockDim.x) one(todo[1 + q]);
+    } else if (first < N) {
+        one(first);
+    }
 }
 
 // ------------------------------------------------------------------ fixed cutoff, single-precision pair tests
@@ -417,17 +419,18 @@ __global__ __launch_bounds__(256) void k_acna(const double *__restrict__ x, cons
                                               const int *__restrict__ verlet, int64_t M, int *__restrict__ pattern,
                                               int *__restrict__ todo)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (GENERIC) {
-        if (i >= todo[0])
-            return;
-        i = todo[1 + i];
-    } else if (i >= N) {
-        return;
+    auto one = [&](int64_t i) {
+        const int t = acna_atom<TRI, GENERIC>(b, x, y, z, i, verlet + i * M, pattern[i], N);
+        if (t >= 0) pattern[i] = t;
+        else if (!GENERIC) defer(todo, i);
+    };
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (GENERIC) { // the to-do list (length on the device, usually zero) walked by a fixed small grid
+        const int64_t total = todo[0];
+        for (int64_t q = first; q < total; q += (int64_t)gridDim.x * blockDim.x) one(todo[1 + q]);
+    } else if (first < N) {
+        one(first);
     }
-    const int t = acna_atom<TRI, GENERIC>(b, x, y, z, i, verlet + i * M, pattern[i], N);
-    if (t >= 0) pattern[i] = t;
-    else if (!GENERIC) defer(todo, i);
 }
 
 // ------------------------------------------------------------------ diamond, per-atom classification (cna.cpp:184-251)
@@ -561,14 +564,18 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
         } else {
             hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
         }
-        hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        // the to-do list (length on the device, usually zero) walked by a grid that fills the chip once: an empty one costs 5 us
+        // instead of the 17 us that N / 256 workgroups take to leave
+        hipLaunchKernelGGL((k_fcna<false, true>), dim3(std::min<unsigned>(grid.x, 2048u)), block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
     }
 }
 
 void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
                         int64_t M, const int *nn, int *pattern, double rc, int *todo)
 {
-    dim3 grid(grid_for(N, 256)), block(256); // (the list's length is on the device: threads beyond it leave at once)
+    // the list's length is on the device and usually zero: a grid that fills the chip once walks a long list, and an empty one
+    // costs 5 us instead of the 17 us that N / 256 workgroups take to leave
+    dim3 grid(std::min<unsigned>(grid_for(N, 256), 2048u)), block(256);
     if (b.tri)
         hipLaunchKernelGGL((k_fcna<true, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
     else
@@ -642,7 +649,7 @@ int mdh_acna(const double *x, const double *y, const double *z, int64_t N, const
             hipLaunchKernelGGL(k_acna_f32, grid, block, 0, st, pos, N, b, dv, M, dp, todo);
         }
         else hipLaunchKernelGGL((k_acna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
-        hipLaunchKernelGGL((k_acna<false, true>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        hipLaunchKernelGGL((k_acna<false, true>), dim3(std::min<unsigned>(grid.x, 2048u)), block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
     }
     return sc.finish(space);
 }

@@ -77,6 +77,8 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
 struct GridStats {
     static constexpr int NBIN = 67; // v[0] = cells of the occupied region; v[1 + len] = 3-cell z-runs of that length (66: longer than 64)
     int v[NBIN];
+    int last_listed = -1;   // tiles the first pass of the previous build with this (N, grid) listed for the second (-1: not known)
+    int *listed_sink = nullptr; // pinned host word the second pass of THIS build writes its count to (device-visible)
 };
 struct LanePlan {
     int txy, tz;      // tile shape in cells; txy == 0: not applicable
@@ -85,6 +87,7 @@ struct LanePlan {
     int wgs;          // workgroups per CU the LDS budget was cut for
     int rw;           // rows (centres) a wave works on at a time: 64, fewer for long rows in dense cells
     float mid, T;     // single-precision scan: the constant c subtracted from d2 (a little below rc^2) and the width W of the band above it
+    int last_listed = -1; int *listed_sink = nullptr; // GridStats: sizes the second pass's grid
     bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live
     int64_t occupied; // cells of the occupied region (last known)
 };

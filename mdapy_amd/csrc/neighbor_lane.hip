@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
-    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw, int tile_base)
+    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw, int tile_base, int *__restrict__ listed_sink)
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
@@ -414,6 +414,8 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     // (neighbouring tiles share halo cells through the same L2; vacuum leaves no XCD idle)
     const int nlive = parent ? min(*n_live, nt0 * nt1 * parent_nt2) * nsub : ((list_mode && tile_list) ? *n_live : nt0 * nt1 * nt2);
     const int per = (nlive + 7) / 8;
+    if (parent && listed_sink && blockIdx.x == 0 && tid == 0)
+        *listed_sink = min(*n_live, nt0 * nt1 * parent_nt2); // (pinned host memory: the next build sizes this pass's grid with it)
     struct Tile { int id, T0, T1, T2; bool empty; };
     struct Halo { int cnt, src, img, hz; bool edge, centre; };
     auto tile_of = [&](int slot) {
@@ -1073,6 +1075,8 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
         // the copy may be landing right now: a torn read mixes two generations of a slowly drifting statistic
         for (int k = 0; k < GridStats::NBIN; ++k) out->v[k] = ((const volatile int *)host)[k];
         if (out->v[0] <= 0) out->v[0] = (int)std::min<int64_t>(cg.g.ncell, 2147483647);
+        out->last_listed = ((const volatile int *)host)[GridStats::NBIN];
+        out->listed_sink = const_cast<int *>(host) + GridStats::NBIN;
     };
     for (auto &e : g_stat)
         if (e.N == N && e.ncell == cg.g.ncell && e.device == device) {
@@ -1086,8 +1090,9 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
         host = g_stat.front().host; // enqueued on some other stream may still land in it — a wrong hint at worst)
         g_stat.erase(g_stat.begin());
     } else {
-        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int) * GridStats::NBIN, hipHostMallocDefault));
+        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(int) * (GridStats::NBIN + 1), hipHostMallocDefault));
     }
+    host[GridStats::NBIN] = -1; // tiles listed for the second pass: written by the device (k_neighbor_lane, second pass)
     MDH_TRY(count(host));
     MDH_HIP(hipStreamSynchronize(st));
     read(host);
@@ -1218,6 +1223,8 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.wgs = best_wgs;
     p.rw = best_rw;
     p.occupied = occ;
+    p.last_listed = gs.last_listed;
+    p.listed_sink = gs.listed_sink;
     p.full = occ >= g.ncell;
     g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw);
     g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
@@ -1273,13 +1280,17 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
     const float negc = -plan.mid;
     const int nt2b = nt[2] * nsub;
+    // second pass: workgroups walk the listed tiles' slices.  Nothing was listed by the previous build with this (N, grid)
+    // (a lattice, nearly always): a small stand-by grid — it walks whatever turns up this time, slowly but correctly; 22 us of
+    // every build went into 1024 workgroups that found an empty list
+    const dim3 grid2(plan.last_listed == 0 ? 64u : 1024u);
     const Shape ts2 = make_shape(ts.txy, 1, nt[1], nt2b);
 #define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, TK8, GRID, JT0, ...)                                                                             \
     do {                                                                                                                                  \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.pk, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base); \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base, plan.listed_sink); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
@@ -1293,7 +1304,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         } else {                                                                                                                          \
             MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt0_run, nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
         }                                                                                                                                 \
-        MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(1024), 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
+        MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, grid2, 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
     if (count) {
         if (plan.tk8) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, true); else MDH_LANE_LAUNCH(true, false, false, true); }
