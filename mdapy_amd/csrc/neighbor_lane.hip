@@ -63,7 +63,7 @@ namespace lane {
 
 static constexpr int NT = 256;      // threads per workgroup
 static constexpr int MAX_NH = 256;  // halo cells of a tile: one per thread
-static constexpr int CEN_CAP = 384; // centre atoms a tile may hold
+static constexpr int CEN_CAP = 320; // centre atoms a tile may hold
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
 static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
 
@@ -393,18 +393,22 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     // the walk, so its tickets are the last of the row and a count of them says which they are.
     typedef typename std::conditional<TK8, unsigned char, unsigned short>::type Ticket;
     constexpr int JB = TK8 ? 5 : 8;
-    float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap+8] staged (ux, uy, uz, bits of the atom id)
-    double2 *lxy = reinterpret_cast<double2 *>(f4 + cap + 8);       // [cap] staged raw x, y
+    float4 *f4 = reinterpret_cast<float4 *>(smem);                  // [cap] staged (ux, uy, uz, bits of the atom id); the scan reads up to 11 entries past a run's end: into lxy, masked
+    double2 *lxy = reinterpret_cast<double2 *>(f4 + cap);           // [cap] staged raw x, y
     double *lz = reinterpret_cast<double *>(lxy + cap);             // [cap] staged raw z
     unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 11
     unsigned short *lsh = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [cap] combined image code of a staged atom seen from this tile
     Ticket *tk = reinterpret_cast<Ticket *>(lsh + cap + (cap & 1)); // [NT][TKS] tickets (slot M swallows the hits past M); wave w owns rows 64 w ...
     const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
-    __shared__ unsigned hc[MAX_NH + 2]; // halo cell: population
+    // halo cell: population — needed from the block scan's barrier to the run table only, so it lives in the ticket rows, cell t
+    // in the rows of wave t / 64 (the wave that writes it: a wave walking a list of tiles may be a tile ahead of the others,
+    // whose tickets it must not touch)
+    const int TKS = (M + 4) & ~3; // tickets of a row + the spare slot, rounded up: rows are read back four tickets at a time
+    const int wstride = max(rw * TKS, 256 / (int)sizeof(Ticket)); // tickets of one wave's rows (at least its 64 populations)
+    auto hc = [&](int t) -> unsigned & { return reinterpret_cast<unsigned *>(tk + (size_t)(t >> 6) * wstride)[t & 63]; };
     __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
     __shared__ int scan_tmp[4];
     __shared__ int s_flag[4];
-    __shared__ int roff[16]; // halo cell of run r relative to the centre's cell
 
     const double rcsq = rc * rc, pad = rc + 1.0; // neighbor.cpp:127; pads neighbor.py:125-129
     const double cw = rc;                        // cell width of the rc-wide grid (neighbor.cpp:29-62)
@@ -502,8 +506,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         const int cnt = cur.cnt, src = cur.src, img = cur.img, hz = cur.hz;
         const bool edge = cur.edge, centre_cell = cur.centre;
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; }
-        if (tid < 9) roff[tid] = ((tid / 3 - 1) * HXY + (tid % 3 - 1)) * HZ; // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
-        hc[tid] = (unsigned)cnt; // the neighbours in z need it for their run (published by the scan's barrier)
+        hc(tid) = (unsigned)cnt; // the neighbours in z need it for their run (published by the scan's barrier)
 
         int total2;
         const int off2 = excl_scan_block(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         // the 3-cell run around every cell that can be a column entry of a centre's walk (cells tid-1, tid, tid+1 are adjacent in z
         // and in LDS)
         if (ok && tid < NH && hz >= 1 && hz <= HZ - 2) {
-            const unsigned k0 = (unsigned)off0 - hc[tid - 1], len = hc[tid - 1] + (unsigned)cnt + hc[tid + 1];
+            const unsigned k0 = (unsigned)off0 - hc(tid - 1), len = hc(tid - 1) + (unsigned)cnt + hc(tid + 1);
             hr[tid] = k0 | (len << 16);
             if (len > (TK8 ? 32u : 64u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4); two in the wide instance
             if (TK8 && len > 12u) s_flag[3] = 1;        // no short-run scan for this tile (eight slots + up to four leftovers per run)
@@ -602,8 +605,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         // them, leaves their tickets in ITS rows of tk and writes their rows itself — LDS traffic inside one wave is ordered,
         // no workgroup barrier — so one wave's scan overlaps another's write-out.
         const int wv = tid >> 6;
-        const int TKS = (M + 4) & ~3; // tickets of a row + the spare slot, rounded up: rows are read back four tickets at a time
-        Ticket *tkw = tk + (size_t)(wv * rw) * TKS; // rw: rows a wave works on at a time (64; fewer where rows are long and centres few: dense cells)
+        Ticket *tkw = tk + (size_t)wv * wstride; // rw: rows a wave works on at a time (64; fewer where rows are long and centres few: dense cells)
         const int A2 = HXY * HZ;
         // halo cell of run r relative to the centre's cell: ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ, neighbor.cpp:147-151
         auto run_cell = [&](int cbv, int r) {
@@ -1105,10 +1107,9 @@ namespace lane {
 // tk8: one-byte tickets, else two-byte ones; rows of (M + 1) tickets rounded up to a multiple of four; rw rows per wave
 static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw)
 {
-    const size_t rows = (size_t)(NT / 64) * (size_t)rw;
-    const size_t tk = rows * (size_t)((M + 4) & ~(int64_t)3) * (tk8 ? 1 : 2);
-    return (size_t)(cap + 8) * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + (size_t)(cap + (cap & 1)) * 2 +
-           ((tk + 15) & ~(size_t)15);
+    const size_t wave = std::max<size_t>((size_t)rw * (size_t)((M + 4) & ~(int64_t)3) * (tk8 ? 1 : 2), 256); // (the kernel's wstride)
+    const size_t tk = (size_t)(NT / 64) * wave;
+    return (size_t)cap * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }
 
 } // namespace lane
@@ -1156,7 +1157,9 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     for (int wgs = max_wgs; wgs >= 1; --wgs) {
         if (wgs_env > 0 && wgs != std::min(wgs_env, max_wgs))
             continue;
-        const long budget = 160 * 1024 / wgs - 2176 - (wgs == 4 ? 384 : 1600); // static tables (2176 B) and a margin.  Measured: 40 544 B in all still gives four workgroups per CU, 41 216 B does not; 52.9 KB three, 54.3 KB not
+        // static tables (1.1 KB: the run table, scan scratch, flags) and a margin.  LDS is handed out in 512-byte granules: 40 960 B
+        // in all give four workgroups per CU (measured: 40 544 do, 41 216 do not; 52.9 KB three, 54.3 KB not)
+        const long budget = 160 * 1024 / wgs - 1088 - (wgs == 4 ? 64 : 1600);
         for (int txy = 1; txy <= 8; ++txy)
             for (int tz = 1; tz <= 24; ++tz) {
                 const int nh = (txy + 2) * (txy + 2) * (tz + 2);
@@ -1169,7 +1172,7 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
                 int rw = 64;
                 if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / (NT / 64)) + 7) & ~7));
                 const long fixed = (long)lds_bytes(0, M, tk8, rw);
-                int cap = (int)((budget - fixed) / 42) & ~7;
+                int cap = (int)((budget - fixed - 2) / 42);
                 if (cap_env > 0) cap = cap_env;
                 cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
                 if (cap < 64 || nh * pop > 0.875 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
