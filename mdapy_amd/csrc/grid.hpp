@@ -18,6 +18,7 @@ struct Grid {
 struct CellGrid {
     Grid g;
     int win_lo = 0, win_hi = 0; // planes [win_lo, win_hi) of axis 0 the grid was built over (a promised window, neighbor.hip); 0, 0: all
+    mutable bool flags_fresh = false; // flags[] were zeroed by build_cell_grid and nobody has used them yet (the first neighbor pass skips its own memset: every hipMemsetAsync is a 5 us launch)
     int *cell_start; // [ncell+1] exclusive prefix of the per-cell populations
     int *order;      // [N] atom ids, cell-major, DESCENDING id inside a cell
     double *xs, *ys, *zs; // [N] raw positions in `order`

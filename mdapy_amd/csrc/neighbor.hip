@@ -348,7 +348,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     const Grid &g = cg.g;
     hipStream_t st = sc.stream();
 
-    unsigned *cell_count = sc.alloc_n<unsigned>((size_t)g.ncell);
+    unsigned *cell_count = sc.alloc_n<unsigned>((size_t)g.ncell + 4); // + the four flags: one memset for both
     cg.cell_start = sc.alloc_n<int>((size_t)g.ncell + 1);
     int *cell_id = sc.alloc_n<int>((size_t)N);
     int *rank = sc.alloc_n<int>((size_t)N);
@@ -367,7 +367,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     }
     const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
     unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk + 1);
-    cg.flags = sc.alloc_n<int>(4);
+    cg.flags = reinterpret_cast<int *>(cell_count + g.ncell);
     if (sc.failed())
         return sc.error();
 
@@ -402,9 +402,10 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         MDH_HIP(hipMemsetAsync(cell_count + p0 * plane, 0, sizeof(unsigned) * (size_t)((p1 - p0) * plane), st));
         if (p3 > p2) MDH_HIP(hipMemsetAsync(cell_count + p2 * plane, 0, sizeof(unsigned) * (size_t)((p3 - p2) * plane), st));
     } else {
-        MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * (size_t)g.ncell, st));
+        MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * ((size_t)g.ncell + 4), st)); // counters and flags
     }
-    MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 4, st));
+    if (windowed) MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 4, st));
+    cg.flags_fresh = true;
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
     // the promise is checked where the atoms are binned and read back by the next build of this thread
@@ -824,7 +825,8 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
                          int64_t M, int mode, int *dmax, int *pattern = nullptr, int *todo = nullptr, bool *fused = nullptr)
 {
     hipStream_t st = sc.stream();
-    MDH_HIP(hipMemsetAsync(cg.flags + 2, 0, sizeof(int) * 2, st)); // the tile lists of this pass (flags[0], unwrapped input, stays)
+    if (!cg.flags_fresh) MDH_HIP(hipMemsetAsync(cg.flags + 2, 0, sizeof(int) * 2, st)); // the tile lists of this pass (flags[0], unwrapped input, stays)
+    cg.flags_fresh = false;
     TileFilter tf{};
     bool done = false;
     if (g_neighbor_variant == 0) { // tile kernel (orthogonal boxes, and triclinic ones periodic along all three vectors); the thread-per-atom code below then only mops up what it listed
