@@ -56,7 +56,8 @@ int mdh_release_workspace(void);
 int64_t mdh_workspace_bytes(void);
 /*
  * Per-kernel timing with HIP events recorded on the stream each kernel is launched on
- * (used by bench.py for the roofline figure).  mdh_prof_enable(1) starts collecting,
+ * (used by bench.py for the roofline figure).  mdh_prof_enable(1) starts collecting (2: the
+ * range "k_neighbor" only — an event pair costs ~8 us of stream time per range and call),
  * mdh_prof_reset() drops what was collected, mdh_prof_report() synchronises the recorded
  * events and writes lines "name count total_ms\n" into buf (returns bytes written, <0 on error).
  */

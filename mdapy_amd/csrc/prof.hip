@@ -8,13 +8,13 @@
 
 namespace mdh {
 
-static bool g_prof_on = false;
+static int g_prof_on = 0; // 0 off, 1 every range, 2 the k_neighbor range only (an event pair costs ~8 us of stream time per range)
 static std::mutex g_prof_mu;
 struct Rec { const char *name; hipEvent_t a, b; };
 static std::vector<Rec> g_recs;
 static std::vector<hipEvent_t> g_free;
 
-bool prof_enabled() { return g_prof_on; }
+bool prof_enabled() { return g_prof_on != 0; }
 
 static hipEvent_t get_event()
 {
@@ -26,7 +26,7 @@ static hipEvent_t get_event()
 
 ProfRange::ProfRange(const char *name, hipStream_t st) : name_(name), st_(st), a_(nullptr)
 {
-    if (!g_prof_on) return;
+    if (!g_prof_on || (g_prof_on == 2 && std::strcmp(name, "k_neighbor") != 0)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     a_ = get_event();
     if (a_) (void)hipEventRecord(a_, st_);
@@ -49,7 +49,7 @@ extern "C" {
 
 int mdh_prof_enable(int on)
 {
-    g_prof_on = on != 0;
+    g_prof_on = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return MDH_OK;
 }
 
