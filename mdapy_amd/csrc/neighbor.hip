@@ -532,11 +532,11 @@ __device__ __forceinline__ int neighbor_one(const SortedView &sv, const int *__r
 }
 
 template <bool TRI, int MODE>
-__global__ __launch_bounds__(256) void k_neighbor(SortedView sv,
-                                                  const int *__restrict__ cell_start, int64_t N, DBox b, Grid g,
+__device__ __forceinline__ void neighbor_atoms_body(const SortedView &sv,
+                                                  const int *__restrict__ cell_start, int64_t N, const DBox &b, const Grid &g,
                                                   double rc, int *__restrict__ verlet, double *__restrict__ dist,
                                                   int *__restrict__ nn, int64_t M, int *__restrict__ max_count,
-                                                  TileFilter tf)
+                                                  const TileFilter &tf)
 {
     const bool take_all = tf.moved && *tf.moved != 0; // the tiled kernel stood down: this kernel does the whole call
     if (tf.flag && !take_all && (tf.list || *tf.any == 0)) // nothing to mop up here (flagged tiles go to k_neighbor_tiles when listed)
@@ -579,10 +579,18 @@ __global__ __launch_bounds__(256) void k_neighbor(SortedView sv,
 // mop-up of the tiles the wave kernel listed (halo over the LDS budget, atoms far outside the box): a workgroup per listed
 // tile, its threads over the tile's centre atoms — the cost follows the number of listed tiles, not N
 template <bool TRI, int MODE>
-__global__ __launch_bounds__(256) void k_neighbor_tiles(SortedView sv,
-                                                        const int *__restrict__ cell_start, DBox b, Grid g, double rc,
+__global__ __launch_bounds__(256) void k_neighbor(SortedView sv, const int *__restrict__ cell_start, int64_t N, DBox b, Grid g, double rc,
+                                                  int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int64_t M,
+                                                  int *__restrict__ max_count, TileFilter tf)
+{
+    neighbor_atoms_body<TRI, MODE>(sv, cell_start, N, b, g, rc, verlet, dist, nn, M, max_count, tf);
+}
+
+template <bool TRI, int MODE>
+__device__ __forceinline__ void neighbor_tiles_body(const SortedView &sv,
+                                                        const int *__restrict__ cell_start, const DBox &b, const Grid &g, double rc,
                                                         int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
-                                                        int64_t M, int *__restrict__ max_count, TileFilter tf)
+                                                        int64_t M, int *__restrict__ max_count, const TileFilter &tf)
 {
     if (tf.moved && *tf.moved != 0) // k_neighbor takes the whole call
         return;
@@ -623,6 +631,25 @@ __global__ __launch_bounds__(256) void k_neighbor_tiles(SortedView sv,
     }
 }
 
+template <bool TRI, int MODE>
+__global__ __launch_bounds__(256) void k_neighbor_tiles(SortedView sv, const int *__restrict__ cell_start, DBox b, Grid g, double rc,
+                                                        int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int64_t M,
+                                                        int *__restrict__ max_count, TileFilter tf)
+{
+    neighbor_tiles_body<TRI, MODE>(sv, cell_start, b, g, rc, verlet, dist, nn, M, max_count, tf);
+}
+
+// the two stand-bys behind a tile kernel that lists its leftovers, as ONE launch (a launch that finds nothing to do costs
+// ~4 us): the whole call atom by atom if the tile kernel stood down (unwrapped input), else the listed tiles
+template <bool TRI, int MODE>
+__global__ __launch_bounds__(256) void k_neighbor_mop(SortedView sv, const int *__restrict__ cell_start, int64_t N, DBox b, Grid g, double rc,
+                                                      int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int64_t M,
+                                                      int *__restrict__ max_count, TileFilter tf)
+{
+    if (tf.moved && *tf.moved != 0) neighbor_atoms_body<TRI, MODE>(sv, cell_start, N, b, g, rc, verlet, dist, nn, M, max_count, tf);
+    else neighbor_tiles_body<TRI, MODE>(sv, cell_start, b, g, rc, verlet, dist, nn, M, max_count, tf);
+}
+
 template <int MODE>
 static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const DBox &b, double rc, int *verlet,
                             double *dist, int *nn, int64_t M, int *max_count, TileFilter tf = TileFilter{})
@@ -630,14 +657,17 @@ static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const
     // behind a tile kernel that lists its leftovers this launch only stands by for unwrapped input (device flag): a small grid
     // then, whose workgroups stride over the atoms if they do have to take the call (10 -> 3 us when they leave at once)
     dim3 grid(std::min(grid_for(N, 256), tf.list ? 2048 : 8192)), block(256);
+    if (tf.list) { // behind a tile kernel with a list (at most list_cap entries): both stand-bys in one launch
+        if (b.tri)
+            hipLaunchKernelGGL((k_neighbor_mop<true, MODE>), grid, block, 0, st, view_of(cg), cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+        else
+            hipLaunchKernelGGL((k_neighbor_mop<false, MODE>), grid, block, 0, st, view_of(cg), cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
+        return;
+    }
     if (b.tri)
         hipLaunchKernelGGL((k_neighbor<true, MODE>), grid, block, 0, st, view_of(cg), cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
     else
         hipLaunchKernelGGL((k_neighbor<false, MODE>), grid, block, 0, st, view_of(cg), cg.cell_start, N, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
-    if (tf.list && b.tri) // the listed tiles (at most list_cap; a longer list falls back to the flag scan above via tf.list == nullptr)
-        hipLaunchKernelGGL((k_neighbor_tiles<true, MODE>), dim3(512), block, 0, st, view_of(cg), cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
-    else if (tf.list)
-        hipLaunchKernelGGL((k_neighbor_tiles<false, MODE>), dim3(512), block, 0, st, view_of(cg), cg.cell_start, b, cg.g, rc, verlet, dist, nn, M, max_count, tf);
 }
 
 // ----------------------------------------------------------------------------
