@@ -519,20 +519,22 @@ struct CanonOut {
     int8_t *ok;     // [N]
 };
 
+// (The facets themselves are not kept: they are read from the stage's lane-major input where a start edge is looked up — one
+// coalesced load per start edge — and the tables have NN rows, not 16: 212 instead of 280 bytes per lane for the 14-neighbour
+// kinds, twelve workgroups per CU instead of eight for a stage that runs a serial traversal per lane.)
 template <int NN> struct CanonMem {
     static constexpr int NF = 2 * NN - 4, NE = 3 * NN - 6;
-    uint64_t *C; // [16]: row a, nibble b = third vertex of the facet left of a->b
-    uint16_t *M; // [16]: first the "edge defined" bits, then the walked bits of a traversal
-    uint16_t *F; // [NF]
+    uint64_t *C; // [NN]: row a, nibble b = third vertex of the facet left of a->b
+    uint16_t *M; // [NN]: first the "edge defined" bits, then the walked bits of a traversal
     int8_t *B;   // [2 NE]: best code
-    static constexpr size_t BYTES = (size_t)BLK * (16 * 8 + 16 * 2 + NF * 2 + 2 * NE);
+    static constexpr size_t BYTES = (size_t)BLK * (NN * 8 + NN * 2 + 2 * NE);
     __device__ __forceinline__ int cm(int a, int b) const { return (int)((C[a * BLK] >> (4 * b)) & 15u); }
 };
 
 // COL: the first four vertices carry colour 1 (the inner atoms of the diamond cluster): a vertex's code is colour * NN + its
 // visiting number, so that inner atoms only map onto inner atoms
 template <int NN, bool COL>
-__global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__restrict__ facets, const int8_t *__restrict__ status,
+__global__ __launch_bounds__(BLK, (NN >= 12 && NN <= 14 ? 3 : 1)) void k_ptm_canon(int64_t N, const uint16_t *__restrict__ facets, const int8_t *__restrict__ status,
                                                    int max_degree, int all_degree, CanonOut out)
 {
     using Mem = CanonMem<NN>;
@@ -543,16 +545,15 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
         return;
     Mem m;
     m.C = reinterpret_cast<uint64_t *>(lds) + threadIdx.x;
-    m.M = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * 128) + threadIdx.x;
-    m.F = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * 160) + threadIdx.x;
-    m.B = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (160 + NF * 2)) + threadIdx.x;
+    m.M = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * NN * 8) + threadIdx.x;
+    m.B = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (NN * 8 + NN * 2)) + threadIdx.x;
+    auto facet = [&](int j) { return (int)facets[(int64_t)j * N + atom]; };
     bool good = status[atom] == NF;
     uint64_t deg = 0; // nibble v = degree of vertex v
     if (good) {
-        for (int a = 0; a < 16; ++a) { m.C[a * BLK] = 0; m.M[a * BLK] = 0; }
+        for (int a = 0; a < NN; ++a) { m.C[a * BLK] = 0; m.M[a * BLK] = 0; }
         for (int j = 0; j < NF; ++j) {
-            const int w = facets[(int64_t)j * N + atom];
-            m.F[j * BLK] = (uint16_t)w;
+            const int w = facet(j);
             const int a = w & 31, b = (w >> 5) & 31, c = (w >> 10) & 31;
             deg += (1ull << (4 * a)) + (1ull << (4 * b)) + (1ull << (4 * c));
             // every directed edge may appear once (an oriented closed surface)
@@ -586,14 +587,14 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
             } else {
                 uint32_t bestd = 0;
                 for (int j = 0; j < NF; ++j) {
-                    const int w = m.F[j * BLK];
+                    const int w = facet(j);
                     const uint32_t da = (uint32_t)((deg >> (4 * (w & 31))) & 15u), db = (uint32_t)((deg >> (4 * ((w >> 5) & 31))) & 15u),
                                    dc = (uint32_t)((deg >> (4 * ((w >> 10) & 31))) & 15u);
                     const uint32_t k0 = (da << 16) | (db << 8) | dc, k1 = da | (db << 16) | (dc << 8), k2 = (da << 8) | db | (dc << 16);
                     bestd = max(bestd, max(k0, max(k1, k2)));
                 }
                 for (int j = 0; j < NF; ++j) {
-                    const int w = m.F[j * BLK];
+                    const int w = facet(j);
                     const uint32_t da = (uint32_t)((deg >> (4 * (w & 31))) & 15u), db = (uint32_t)((deg >> (4 * ((w >> 5) & 31))) & 15u),
                                    dc = (uint32_t)((deg >> (4 * ((w >> 10) & 31))) & 15u);
                     const uint32_t k0 = (da << 16) | (db << 8) | dc, k1 = da | (db << 16) | (dc << 8), k2 = (da << 8) | db | (dc << 16);
@@ -621,11 +622,11 @@ __global__ __launch_bounds__(BLK) void k_ptm_canon(int64_t N, const uint16_t *__
             if (s_lo) { pos = __builtin_ctzll(s_lo); s_lo &= s_lo - 1; }
             else { pos = 64 + __builtin_ctz(s_hi); s_hi &= s_hi - 1; }
             const int j = pos / 3, r = pos - 3 * j;
-            const int w = m.F[j * BLK];
+            const int w = facet(j);
             const int v0 = w & 31, v1 = (w >> 5) & 31, v2 = (w >> 10) & 31;
             int a = r == 0 ? v0 : r == 1 ? v1 : v2, bq = r == 0 ? v1 : r == 1 ? v2 : v0;
             // one traversal (colours are all 0 for these kinds: a vertex's code is its visiting number)
-            for (int v = 0; v < 16; ++v) m.M[v * BLK] = 0;
+            for (int v = 0; v < NN; ++v) m.M[v * BLK] = 0;
             uint64_t index = 0;   // nibble v = visiting number
             uint32_t seen = 1u << a;
             int n = 1;            // index[a] = 0
