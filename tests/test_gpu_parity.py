@@ -274,6 +274,32 @@ def test_neighbor_live_tile_list_longer_than_expected():
         assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da), k
 
 
+def test_neighbor_second_pass_grid_from_a_stale_count():
+    """the tile kernel's second pass (one-cell slices of the tiles whose halo outgrew LDS) gets a small stand-by grid when the
+    previous build with the same (N, grid) listed nothing — the count travels through pinned memory.  Same N and box: first an
+    even crystal (nothing listed), then the same atoms with half of them squeezed into a slab three times as dense (most of
+    its tiles are listed): the stand-by grid walks the whole list, rows equal the oracle's, and again with the count updated."""
+    a = 3.615
+    pos0, box = lattice_positions("fcc", a, 24, 24, 24)
+    box = np.asarray(box, float)
+    rng = np.random.default_rng(17)
+    pos0 = pos0 + rng.normal(0, 0.04, pos0.shape)
+    L = box[0][0]
+    dense = pos0.copy()
+    lower = dense[:, 2] < 0.5 * L
+    dense[lower, 2] = dense[lower, 2] / 3.0  # the lower half of the box into its lowest sixth: ~7.5 atoms per cell there
+    rc, M = 0.854 * a, 40
+    for k, pos in enumerate((pos0, dense, dense)):
+        x, y, z = _xyz(pos)
+        n = len(x)
+        va = np.full((n, M), -1, np.int32); da = np.full((n, M), rc + 1.0); na = np.zeros(n, np.int32)
+        O.build_neighbor(x, y, z, box, ORG0, PBC, rc, va, da, na, 4)
+        vb = np.empty((n, M), np.int32); db = np.empty((n, M)); nb = np.empty(n, np.int32)
+        _neighbor.build_neighbor(x, y, z, box, ORG0, PBC, rc, vb, db, nb, 1, fill_pads=True)
+        assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da), k
+        assert k == 0 or na.max() > 16
+
+
 def test_neighbor_device_space_and_pads():
     """HBM-resident path (torch tensors in, HArray out) == host-space path; kernel-written pads == -1 / rc+1."""
     import torch
@@ -909,7 +935,7 @@ def test_ptm_ordering_second_pass_gives_the_same_rows():
             _ptm.get_ptm("all", x, y, z, box, ORG0, PBC, idx, None, 0.1, o, i)
             outs.append((o, i))
         finally:
-            _lib.lib().mdh_debug_set_ptm_order_cap(10)
+            _lib.lib().mdh_debug_set_ptm_order_cap(0)  # back to the automatic choice
     for o, i in outs[1:3]:
         assert np.array_equal(outs[0][0], o) and np.array_equal(outs[0][1], i)
     for o, i in outs[4:]:
@@ -954,7 +980,7 @@ def test_ptm_plane_polygons_against_space_polygons_on_random_systems(kind):
             _ptm.get_ptm("all", x, y, z, box, ORG0, PBC, idx, None, 0.1, o, i)
             res[cap] = (o, i)
         finally:
-            _lib.lib().mdh_debug_set_ptm_order_cap(10)
+            _lib.lib().mdh_debug_set_ptm_order_cap(0)  # back to the automatic choice
     (o2, i2), (o3, i3) = res[10], res[-10]
     assert np.array_equal(o2[:, 0], o3[:, 0])  # structure type
     same = (i2 == i3).all(axis=1)
@@ -962,6 +988,38 @@ def test_ptm_plane_polygons_against_space_polygons_on_random_systems(kind):
         assert same.mean() > 0.999, same.mean()
     assert np.allclose(o2[same], o3[same], rtol=0, atol=1e-6)  # (the contract of the PTM floats; a perfect lattice has rmsd = sqrt(rounding noise) ~ 1e-8)
     assert np.allclose(o2[:, 2], o3[:, 2], rtol=0, atol=1e-6)  # rmsd, whatever the labelling
+
+
+def test_ptm_first_ordering_pass_chosen_from_a_stale_count():
+    """the first ordering pass uses eight-vertex polygons when the previous call with the same number of atoms counted few
+    atoms with larger faces (a crystal), ten otherwise; the count travels through pinned memory.  A crystal twice (the second
+    call runs with eight), then a gas of the same size (still eight, by the stale count: half its atoms take the second
+    pass), then the gas again (ten): every result equals the one with the pass size forced."""
+    from mdapy_amd import _lib
+
+    rng = np.random.default_rng(23)
+    cry, box = _fcc(9, 0.05, 6)
+    gas = rng.random(cry.shape) * np.diag(np.asarray(box, float) if np.ndim(box) == 2 else np.diag(box))
+    L = _lib.lib()
+
+    def run(pos, cap):
+        L.mdh_debug_set_ptm_order_cap(cap)
+        x, y, z = _xyz(pos)
+        N = len(x)
+        idx, dist = np.zeros((N, 18), np.int32), np.zeros((N, 18))
+        _fast_knn.knn(x, y, z, box, ORG0, PBC, 18, idx, dist, 1)
+        o, i = np.zeros((N, 8)), np.zeros((N, 18), np.int32)
+        _ptm.get_ptm("fcc-hcp-bcc", x, y, z, box, ORG0, PBC, idx, None, 0.1, o, i)
+        return o, i
+
+    try:
+        ref_c, ref_g = run(cry, 10), run(gas, 10)
+        L.mdh_debug_set_ptm_order_cap(0)
+        for pos, ref in ((cry, ref_c), (cry, ref_c), (gas, ref_g), (gas, ref_g), (cry, ref_c)):
+            o, i = run(pos, 0)
+            assert np.array_equal(o, ref[0]) and np.array_equal(i, ref[1])
+    finally:
+        L.mdh_debug_set_ptm_order_cap(0)
 
 
 PTM_PATHS = fixtures_with("ptm")
