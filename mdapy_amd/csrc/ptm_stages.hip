@@ -962,16 +962,12 @@ __device__ double stage_rmsd(const Mem &m, const ptmc::TypeInfo &s, int np, cons
     double nrmsdsq, rot[9];
     ptmc::qcp_quaternion(A, E0, &nrmsdsq, q);
     ptmc::quat_to_matrix(q, rot);
+    // k0 = sum_i (R s_i) . p_i = sum_{j,c} R[j][c] A[c][j]  (A[c][j] = sum_i s_i[c] p_i[j] is the matrix just accumulated): the
+    // reference's second pass over the points (ptm_polar.cpp calc_rmsd) is nine multiplications here — the same number up to the
+    // order of summation
     double k0 = 0;
-    for (int i = 0; i < np; ++i) {
-        const int k = map(i);
-        const double p[3] = {m.P[(k * 3 + 0) * BLK] - bary[0], m.P[(k * 3 + 1) * BLK] - bary[1], m.P[(k * 3 + 2) * BLK] - bary[2]};
-        for (int j = 0; j < 3; ++j) {
-            double v = 0.0;
-            for (int c = 0; c < 3; ++c) v += rot[j * 3 + c] * s.points[i][c];
-            k0 += v * p[j];
-        }
-    }
+    for (int j = 0; j < 3; ++j)
+        for (int c = 0; c < 3; ++c) k0 += rot[j * 3 + c] * A[c * 3 + j];
     const double scale = k0 / G2;
     *p_scale = scale;
     return sqrt(fabs(G1 - scale * k0) / np);
