@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_rdf_cells(const double *__restrict__ xs
 // sqrt(r2)/dr, :236-251 — the two directions may round differently), so the counts are the reference's bit for bit.
 // |r2_f32 - r2| <= 1.8e-6 (rc^2 + r2) for coordinates inside the 3x3x3-cell frame (cell width < 1.34 rc): three roundings
 // to f32 of magnitudes <= 2.7 rc, the subtractions, the FMA chain.
-constexpr int RDF_CEN = 256, RDF_QUEUE = 1024, RDF_NB = 14;
+constexpr int RDF_CEN = 256, RDF_QUEUE = 1024, RDF_NB = 14, RDF_HITS = 128; // RDF_HITS: a wave's list of hits (< 64 left over + 64 new ones)
+__host__ __device__ inline int64_t hsize_of(int ntype, int nbin) { return (int64_t)ntype * ntype * nbin; }
 
 template <bool TRI>
 __device__ __forceinline__ void rdf_exact_pair(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
@@ -133,6 +134,12 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
     unsigned *queue = reinterpret_cast<unsigned *>(cen + RDF_CEN);   // [RDF_QUEUE][2] sorted positions of a pair to bin exactly
     unsigned char *etype = reinterpret_cast<unsigned char *>(queue + 2 * RDF_QUEUE); // [RDF_CEN]
     unsigned *lds = reinterpret_cast<unsigned *>(etype + RDF_CEN);   // [ntype^2 nbin]
+    // Pairs inside the cutoff are ~15 % of the pairs tested; binning one (square root, shell bounds, band test, LDS atomics) is
+    // ~40 instructions.  Taken on the spot they ran for every trip of the centre loop with a seventh of the lanes active (some
+    // lane of the 64 nearly always has a hit): 55 instructions per 64 pair tests.  Instead a hit is pushed — ballot, mbcnt, one
+    // 16-byte LDS store — onto the wave's own list, and the list is binned 64 hits at a time with every lane busy.
+    struct Hit { float r2; unsigned qi, qj, tt; }; // tt = type of the centre | type of the candidate << 8
+    Hit *hitq = reinterpret_cast<Hit *>(lds + ((hsize_of(ntype, nbin) + 3) & ~(int64_t)3)) + (size_t)(threadIdx.x >> 6) * RDF_HITS; // [4][RDF_HITS]
     __shared__ int s_start[RDF_NB + 1], s_src[RDF_NB];
     __shared__ float s_shift[RDF_NB][3];
     __shared__ double s_lo[RDF_NB][3];
@@ -146,6 +153,34 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
     double ev[3][3];
     for (int d = 0; d < 3; ++d)
         for (int c = 0; c < 3; ++c) ev[d][c] = (TRI || d == c) ? b.h[3 * d + c] / g.nc[d] : 0.0;
+    const int lane = tid & 63;
+    int nhit = 0; // hits on this wave's list (the same number in every lane)
+    auto bin_hit = [&](const Hit h) { // one pair inside the cutoff, both directions (what the centre loop used to do on the spot)
+        const float r2 = h.r2;
+        const int qi = (int)h.qi, qj = (int)h.qj, ti = (int)(h.tt & 255u), tj = (int)(h.tt >> 8);
+        const int kb = (int)(__builtin_sqrtf(r2) * inv_dr);
+        const float lo = (float)kb * drf, hi = lo + drf;
+        const float tol = 4.0e-6f * tol_scale * (rc2f + r2);
+        if (r2 - lo * lo > tol && hi * hi - r2 > tol) {
+            if (kb < nbin) {
+                if (ti == tj) {
+                    atomicAdd(&lds[(ti * ntype + tj) * nbin + kb], 2u);
+                } else {
+                    atomicAdd(&lds[(ti * ntype + tj) * nbin + kb], 1u);
+                    atomicAdd(&lds[(tj * ntype + ti) * nbin + kb], 1u);
+                }
+            }
+        } else {
+            const unsigned slot = atomicAdd(&s_nq, 1u);
+            if (slot < (unsigned)RDF_QUEUE) {
+                queue[2 * slot] = (unsigned)qi;
+                queue[2 * slot + 1] = (unsigned)qj;
+            } else { // (a full list: this pair right away)
+                rdf_exact_pair<TRI>(xs, ys, zs, b, qi, qj, ti, tj, ntype, nbin, dr, rcsq, lds);
+                rdf_exact_pair<TRI>(xs, ys, zs, b, qj, qi, tj, ti, ntype, nbin, dr, rcsq, lds);
+            }
+        }
+    };
     for (int64_t cell = blockIdx.x; cell < g.ncell; cell += gridDim.x) {
         const int c2 = (int)(cell % g.nc[2]), c1 = (int)((cell / g.nc[2]) % g.nc[1]), c0 = (int)(cell / ((int64_t)g.nc[1] * g.nc[2]));
         const int cs = cell_start[cell], ncen_all = cell_start[cell + 1] - cs;
@@ -190,52 +225,58 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                 etype[tid] = (unsigned char)type[order[q]];
             }
             __syncthreads();
-            for (int gv = tid; gv < ncand_all; gv += 256) { // this lane's candidate: atom gv of the 14 cells laid end to end
+            for (int gbase = 0; gbase < ncand_all; gbase += 256) { // (wave-uniform trips: the hit list is kept by the whole wave)
+                const int gv = gbase + tid; // this lane's candidate: atom gv of the 14 cells laid end to end
+                const bool valid = gv < ncand_all;
                 int k = 0;
-                while (gv >= s_start[k + 1]) ++k;
-                const int qj = s_src[k] + (gv - s_start[k]);
+                if (valid)
+                    while (gv >= s_start[k + 1]) ++k;
+                const int qj = valid ? s_src[k] + (gv - s_start[k]) : s_src[0];
                 double xj = xs[qj], yj = ys[qj], zj = zs[qj];
                 if (b.anypbc)
                     wrap<TRI>(b, xj, yj, zj);
                 const float ux = (float)(xj - s_lo[k][0]) + s_shift[k][0], uy = (float)(yj - s_lo[k][1]) + s_shift[k][1],
                             uz = (float)(zj - s_lo[k][2]) + s_shift[k][2];
-                const int tj = type[order[qj]];
+                const unsigned tj = (unsigned)type[order[qj]];
                 const bool same_cell = k == 0;
                 for (int c = 0; c < ncen; ++c) {
                     const float4 ce = cen[c]; // one address for the whole wavefront: a broadcast read
                     const float dx = ux - ce.x, dy = uy - ce.y, dz = uz - ce.z;
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    if (r2 < rc2f * (1.0f + 1.0e-4f * tol_scale)) {
-                        const int qi = __float_as_int(ce.w);
-                        if (same_cell && qj <= qi)
-                            continue; // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
-                        const int kb = (int)(__builtin_sqrtf(r2) * inv_dr);
-                        const float lo = (float)kb * drf, hi = lo + drf;
-                        const float tol = 4.0e-6f * tol_scale * (rc2f + r2);
-                        const int ti = etype[c];
-                        if (r2 - lo * lo > tol && hi * hi - r2 > tol) {
-                            if (kb < nbin) {
-                                if (ti == tj) {
-                                    atomicAdd(&lds[(ti * ntype + tj) * nbin + kb], 2u);
-                                } else {
-                                    atomicAdd(&lds[(ti * ntype + tj) * nbin + kb], 1u);
-                                    atomicAdd(&lds[(tj * ntype + ti) * nbin + kb], 1u);
-                                }
-                            }
-                        } else {
-                            const unsigned slot = atomicAdd(&s_nq, 1u);
-                            if (slot < (unsigned)RDF_QUEUE) {
-                                queue[2 * slot] = (unsigned)qi;
-                                queue[2 * slot + 1] = (unsigned)qj;
-                            } else { // (a full list: this pair right away)
-                                rdf_exact_pair<TRI>(xs, ys, zs, b, qi, qj, ti, tj, ntype, nbin, dr, rcsq, lds);
-                                rdf_exact_pair<TRI>(xs, ys, zs, b, qj, qi, tj, ti, ntype, nbin, dr, rcsq, lds);
-                            }
-                        }
+                    const int qi = __float_as_int(ce.w);
+                    // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
+                    const bool hit = valid && r2 < rc2f * (1.0f + 1.0e-4f * tol_scale) && !(same_cell && qj <= qi);
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm == 0)
+                        continue;
+                    if (hit) {
+                        const int at = nhit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                        hitq[at] = Hit{r2, (unsigned)qi, (unsigned)qj, (unsigned)etype[c] | (tj << 8)};
+                    }
+                    nhit += __popcll(hm);
+                    if (nhit >= 64) { // a full wave of hits: bin them, move the rest down
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        bin_hit(hitq[lane]);
+                        const int rest = nhit - 64;
+                        Hit mv = hitq[lane];
+                        if (lane < rest) mv = hitq[64 + lane];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < rest) hitq[lane] = mv;
+                        nhit = rest;
                     }
                 }
             }
         }
+        // what is left on the wave's list
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < nhit) bin_hit(hitq[lane]);
+        nhit = 0;
         __syncthreads();
         const int nq = (int)min(s_nq, (unsigned)RDF_QUEUE);
         for (int e = tid; e < 2 * nq; e += 256) { // the pairs near a shell boundary, each direction as the reference bins it
@@ -383,7 +424,7 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         cg.g.rc_inv = 1.0 / rc;
         cg.g.mode = 1;
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, false, cg));
-        const size_t tile_lds = (size_t)RDF_CEN * 17 + (size_t)RDF_QUEUE * 8 + (size_t)hsize * 4;
+        const size_t tile_lds = (size_t)RDF_CEN * 17 + (size_t)RDF_QUEUE * 8 + (((size_t)hsize + 3) & ~(size_t)3) * 4 + (size_t)4 * RDF_HITS * 16;
         // the frame of 3x3x3 cells along the worst Cartesian axis, in units of the orthogonal kernel's 2.7 rc
         double tol_scale = 1.0;
         const bool tri_tile = b.tri && b.pbc[0] && b.pbc[1] && b.pbc[2];
