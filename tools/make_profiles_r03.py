@@ -100,7 +100,7 @@ ALG = [
     ("ptms::k_ptm_hull_shell", N3, 17 * 24 + 1 + 57, '"all": cluster points in; 28 facets + status out'),
     ("ptms::k_ptm_canon<16, true>", N3, 57 + 8 + 17 + 1, '"all": facets in; hash, labelling, flag out'),
     ("ptms::k_ptm_match<false, true>", N3, 24 + 72 + 3 * 26 + 17 * 28 + 10 * 28 + 64 + 72, '"all": + both clusters in'),
-    ("k_rdf_tile", N5, 28, "positions 24 + type 4 (the histogram is 6.4 kB)"),
+    ("k_rdf_tile<false>", N5, 28, "positions 24 + type 4 (the histogram is 6.4 kB)"),
     ("k_wcp_count", N5, 8 + 4 * 27, "count, type, row of the rc = 3.6 list (width 27)"),
 ]
 with open(os.path.join(P, "r03_analyses_roofline.md"), "w") as f:
