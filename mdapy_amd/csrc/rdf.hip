@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_rdf_cells(const double *__restrict__ xs
 // sqrt(r2)/dr, :236-251 — the two directions may round differently), so the counts are the reference's bit for bit.
 // |r2_f32 - r2| <= 1.8e-6 (rc^2 + r2) for coordinates inside the 3x3x3-cell frame (cell width < 1.34 rc): three roundings
 // to f32 of magnitudes <= 2.7 rc, the subtractions, the FMA chain.
-constexpr int RDF_CEN = 256, RDF_QUEUE = 1024, RDF_NB = 14, RDF_HITS = 128; // RDF_HITS: a wave's list of hits (< 64 left over + 64 new ones)
+constexpr int RDF_NB = 14, RDF_HITS = 128; // RDF_HITS: a wave's list of hits (< 64 left over + 64 new ones)
 __host__ __device__ inline int64_t hsize_of(int ntype, int nbin) { return (int64_t)ntype * ntype * nbin; }
 
 template <bool TRI>
@@ -123,6 +123,23 @@ __device__ __forceinline__ void rdf_exact_pair(const double *__restrict__ xs, co
 // to a neighbouring cell are sums of the cell's edge VECTORS (box vector d over nc[d]), the atoms are wrapped through the
 // fractional coordinates, and the band is widened by tol_scale = (extent of the 3x3x3-cell frame along the worst Cartesian
 // axis) / (2.7 rc): the single-precision error of a coordinate grows with the frame, which a sheared cell stretches.
+// One WAVEFRONT per centre cell (four cells in flight per workgroup, sixteen per CU): a cell's set-up — its 14 cell ranges, the
+// centre atoms, the first candidates: three dependent trips to memory — is a few microseconds for ~170 wave-trips of pair
+// tests, and with a whole workgroup per cell (four barriers per cell, four cells in flight per CU) 69 % of the wave-cycles were
+// parked.  A wave needs no workgroup barrier for its own cell; only the histogram is shared.
+struct RdfHit { float r2; unsigned qi, qj, tt; }; // tt = type of the centre | type of the candidate << 8
+struct RdfWave { // LDS of one wave
+    float4 cen[64];          // centre atoms: ux, uy, uz, bits of the position in the sorted arrays
+    RdfHit hitq[RDF_HITS];   // pairs inside the cutoff waiting to be binned
+    unsigned xq[2 * 128];    // sorted positions of the pairs to bin exactly
+    double lo[RDF_NB][3];    // corner of each of the 14 cells
+    float shift[RDF_NB][3];  // its offset from the centre cell
+    int start[RDF_NB + 2], src[RDF_NB];
+    unsigned nq, pad;
+    unsigned char etype[64];
+};
+static_assert(sizeof(RdfWave) % 16 == 0, "RdfWave keeps float4 alignment");
+
 template <bool TRI>
 __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
                                                   const int *__restrict__ order, const int *__restrict__ cell_start,
@@ -130,32 +147,29 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                                                   unsigned long long *__restrict__ hist, float tol_scale)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rdf_lds[];
-    float4 *cen = reinterpret_cast<float4 *>(rdf_lds);               // [RDF_CEN] ux, uy, uz, bits of the position in the sorted arrays
-    unsigned *queue = reinterpret_cast<unsigned *>(cen + RDF_CEN);   // [RDF_QUEUE][2] sorted positions of a pair to bin exactly
-    unsigned char *etype = reinterpret_cast<unsigned char *>(queue + 2 * RDF_QUEUE); // [RDF_CEN]
-    unsigned *lds = reinterpret_cast<unsigned *>(etype + RDF_CEN);   // [ntype^2 nbin]
-    // Pairs inside the cutoff are ~15 % of the pairs tested; binning one (square root, shell bounds, band test, LDS atomics) is
-    // ~40 instructions.  Taken on the spot they ran for every trip of the centre loop with a seventh of the lanes active (some
-    // lane of the 64 nearly always has a hit): 55 instructions per 64 pair tests.  Instead a hit is pushed — ballot, mbcnt, one
-    // 16-byte LDS store — onto the wave's own list, and the list is binned 64 hits at a time with every lane busy.
-    struct Hit { float r2; unsigned qi, qj, tt; }; // tt = type of the centre | type of the candidate << 8
-    Hit *hitq = reinterpret_cast<Hit *>(lds + ((hsize_of(ntype, nbin) + 3) & ~(int64_t)3)) + (size_t)(threadIdx.x >> 6) * RDF_HITS; // [4][RDF_HITS]
-    __shared__ int s_start[RDF_NB + 1], s_src[RDF_NB];
-    __shared__ float s_shift[RDF_NB][3];
-    __shared__ double s_lo[RDF_NB][3];
-    __shared__ unsigned s_nq;
-    const int tid = threadIdx.x;
-    const int64_t hsize = (int64_t)ntype * ntype * nbin;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t hsize = hsize_of(ntype, nbin);
+    unsigned *lds = reinterpret_cast<unsigned *>(rdf_lds); // [ntype^2 nbin] the workgroup's histogram
+    RdfWave &W = reinterpret_cast<RdfWave *>(rdf_lds + (((size_t)hsize * 4 + 15) & ~(size_t)15))[wv];
     for (int64_t q = tid; q < hsize; q += 256) lds[q] = 0u;
+    __syncthreads();
     const double dr = rc / nbin, rcsq = rc * rc; // :158-159
     const float drf = (float)dr, inv_dr = (float)(1.0 / dr), rc2f = (float)rcsq;
     // edge vectors of a cell: ev[d][c] = component c of box vector d over nc[d] (orthogonal box: the diagonal only)
     double ev[3][3];
     for (int d = 0; d < 3; ++d)
         for (int c = 0; c < 3; ++c) ev[d][c] = (TRI || d == c) ? b.h[3 * d + c] / g.nc[d] : 0.0;
-    const int lane = tid & 63;
-    int nhit = 0; // hits on this wave's list (the same number in every lane)
-    auto bin_hit = [&](const Hit h) { // one pair inside the cutoff, both directions (what the centre loop used to do on the spot)
+    auto wsync = [] { // LDS written by some lanes of this wave is read by others
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // Pairs inside the cutoff are ~15 % of the pairs tested; binning one (square root, shell bounds, band test, LDS atomics) is
+    // ~40 instructions.  Taken on the spot they ran for every trip of the centre loop with a seventh of the lanes active (some
+    // lane of the 64 nearly always has a hit): 55 instructions per 64 pair tests.  Instead a hit is pushed — ballot, mbcnt, one
+    // 16-byte LDS store — onto the wave's list, and the list is binned 64 hits at a time with every lane busy.
+    int nhit = 0; // hits on the wave's list (the same number in every lane)
+    auto bin_hit = [&](const RdfHit h) { // one pair inside the cutoff, both directions
         const float r2 = h.r2;
         const int qi = (int)h.qi, qj = (int)h.qj, ti = (int)(h.tt & 255u), tj = (int)(h.tt >> 8);
         const int kb = (int)(__builtin_sqrtf(r2) * inv_dr);
@@ -171,76 +185,80 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                 }
             }
         } else {
-            const unsigned slot = atomicAdd(&s_nq, 1u);
-            if (slot < (unsigned)RDF_QUEUE) {
-                queue[2 * slot] = (unsigned)qi;
-                queue[2 * slot + 1] = (unsigned)qj;
+            const unsigned slot = atomicAdd(&W.nq, 1u);
+            if (slot < 128u) {
+                W.xq[2 * slot] = (unsigned)qi;
+                W.xq[2 * slot + 1] = (unsigned)qj;
             } else { // (a full list: this pair right away)
                 rdf_exact_pair<TRI>(xs, ys, zs, b, qi, qj, ti, tj, ntype, nbin, dr, rcsq, lds);
                 rdf_exact_pair<TRI>(xs, ys, zs, b, qj, qi, tj, ti, ntype, nbin, dr, rcsq, lds);
             }
         }
     };
-    for (int64_t cell = blockIdx.x; cell < g.ncell; cell += gridDim.x) {
+    for (int64_t cell = (int64_t)blockIdx.x * 4 + wv; cell < g.ncell; cell += (int64_t)gridDim.x * 4) {
         const int c2 = (int)(cell % g.nc[2]), c1 = (int)((cell / g.nc[2]) % g.nc[1]), c0 = (int)(cell / ((int64_t)g.nc[1] * g.nc[2]));
         const int cs = cell_start[cell], ncen_all = cell_start[cell + 1] - cs;
         if (ncen_all == 0)
             continue;
-        __syncthreads(); // the tables below are reused
-        if (tid < RDF_NB) { // the cell itself (entry 0) and the 13 cells after it in the reference's walk order (:223-235)
-            const int o = tid == 0 ? 13 : 13 + tid; // position in the 27-cell walk
+        wsync(); // the tables below are reused
+        int n = 0;
+        if (lane < RDF_NB) { // the cell itself (entry 0) and the 13 cells after it in the reference's walk order (:223-235)
+            const int o = lane == 0 ? 13 : 13 + lane; // position in the 27-cell walk
             const int da = o / 9 - 1, db = (o / 3) % 3 - 1, dc = o % 3 - 1;
             const int a = b.pbc[0] ? pmod(c0 + da, g.nc[0]) : c0 + da, bb = b.pbc[1] ? pmod(c1 + db, g.nc[1]) : c1 + db,
                       cc = b.pbc[2] ? pmod(c2 + dc, g.nc[2]) : c2 + dc;
-            int n = 0, src = 0;
+            int src = 0;
             if (a >= 0 && a < g.nc[0] && bb >= 0 && bb < g.nc[1] && cc >= 0 && cc < g.nc[2]) { // open axes are not wrapped
                 const int64_t nb = ((int64_t)a * g.nc[1] + bb) * g.nc[2] + cc;
                 src = cell_start[nb];
                 n = cell_start[nb + 1] - src;
             }
-            s_src[tid] = src;
-            s_start[tid + 1] = n; // turned into a prefix below
+            W.src[lane] = src;
             for (int c = 0; c < 3; ++c) {
-                s_lo[tid][c] = b.o[c] + a * ev[0][c] + bb * ev[1][c] + cc * ev[2][c];
-                s_shift[tid][c] = (float)(da * ev[0][c] + db * ev[1][c] + dc * ev[2][c]);
+                W.lo[lane][c] = b.o[c] + a * ev[0][c] + bb * ev[1][c] + cc * ev[2][c];
+                W.shift[lane][c] = (float)(da * ev[0][c] + db * ev[1][c] + dc * ev[2][c]);
             }
         }
-        __syncthreads();
-        if (tid == 0) {
-            s_start[0] = 0;
-            for (int k = 0; k < RDF_NB; ++k) s_start[k + 1] += s_start[k];
-            s_nq = 0;
+        { // prefix of the 14 populations across the lanes
+            int inc = n;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            if (lane < RDF_NB) W.start[lane + 1] = inc;
+            if (lane == 0) { W.start[0] = 0; W.nq = 0; }
         }
-        __syncthreads();
-        const int ncand_all = s_start[RDF_NB];
-        for (int cbase = 0; cbase < ncen_all; cbase += RDF_CEN) {
-            const int ncen = min(RDF_CEN, ncen_all - cbase);
-            __syncthreads();
-            if (tid < ncen) { // centre atoms
-                const int q = cs + cbase + tid;
+        wsync();
+        const int ncand_all = W.start[RDF_NB];
+        for (int cbase = 0; cbase < ncen_all; cbase += 64) {
+            const int ncen = min(64, ncen_all - cbase);
+            wsync();
+            if (lane < ncen) { // centre atoms
+                const int q = cs + cbase + lane;
                 double xi = xs[q], yi = ys[q], zi = zs[q];
                 if (b.anypbc)
                     wrap<TRI>(b, xi, yi, zi);
-                cen[tid] = make_float4((float)(xi - s_lo[0][0]), (float)(yi - s_lo[0][1]), (float)(zi - s_lo[0][2]), __int_as_float(q));
-                etype[tid] = (unsigned char)type[order[q]];
+                W.cen[lane] = make_float4((float)(xi - W.lo[0][0]), (float)(yi - W.lo[0][1]), (float)(zi - W.lo[0][2]), __int_as_float(q));
+                W.etype[lane] = (unsigned char)type[order[q]];
             }
-            __syncthreads();
-            for (int gbase = 0; gbase < ncand_all; gbase += 256) { // (wave-uniform trips: the hit list is kept by the whole wave)
-                const int gv = gbase + tid; // this lane's candidate: atom gv of the 14 cells laid end to end
+            wsync();
+            for (int gbase = 0; gbase < ncand_all; gbase += 64) {
+                const int gv = gbase + lane; // this lane's candidate: atom gv of the 14 cells laid end to end
                 const bool valid = gv < ncand_all;
                 int k = 0;
                 if (valid)
-                    while (gv >= s_start[k + 1]) ++k;
-                const int qj = valid ? s_src[k] + (gv - s_start[k]) : s_src[0];
+                    while (gv >= W.start[k + 1]) ++k;
+                const int qj = valid ? W.src[k] + (gv - W.start[k]) : W.src[0];
                 double xj = xs[qj], yj = ys[qj], zj = zs[qj];
                 if (b.anypbc)
                     wrap<TRI>(b, xj, yj, zj);
-                const float ux = (float)(xj - s_lo[k][0]) + s_shift[k][0], uy = (float)(yj - s_lo[k][1]) + s_shift[k][1],
-                            uz = (float)(zj - s_lo[k][2]) + s_shift[k][2];
+                const float ux = (float)(xj - W.lo[k][0]) + W.shift[k][0], uy = (float)(yj - W.lo[k][1]) + W.shift[k][1],
+                            uz = (float)(zj - W.lo[k][2]) + W.shift[k][2];
                 const unsigned tj = (unsigned)type[order[qj]];
                 const bool same_cell = k == 0;
                 for (int c = 0; c < ncen; ++c) {
-                    const float4 ce = cen[c]; // one address for the whole wavefront: a broadcast read
+                    const float4 ce = W.cen[c]; // one address for the whole wavefront: a broadcast read
                     const float dx = ux - ce.x, dy = uy - ce.y, dz = uz - ce.z;
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const int qi = __float_as_int(ce.w);
@@ -251,36 +269,29 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                         continue;
                     if (hit) {
                         const int at = nhit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                        hitq[at] = Hit{r2, (unsigned)qi, (unsigned)qj, (unsigned)etype[c] | (tj << 8)};
+                        W.hitq[at] = RdfHit{r2, (unsigned)qi, (unsigned)qj, (unsigned)W.etype[c] | (tj << 8)};
                     }
                     nhit += __popcll(hm);
                     if (nhit >= 64) { // a full wave of hits: bin them, move the rest down
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        bin_hit(hitq[lane]);
+                        wsync();
+                        bin_hit(W.hitq[lane]);
                         const int rest = nhit - 64;
-                        Hit mv = hitq[lane];
-                        if (lane < rest) mv = hitq[64 + lane];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (lane < rest) hitq[lane] = mv;
+                        RdfHit mv = W.hitq[lane];
+                        if (lane < rest) mv = W.hitq[64 + lane];
+                        wsync();
+                        if (lane < rest) W.hitq[lane] = mv;
                         nhit = rest;
                     }
                 }
             }
         }
-        // what is left on the wave's list
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < nhit) bin_hit(hitq[lane]);
+        wsync(); // what is left on the wave's list
+        if (lane < nhit) bin_hit(W.hitq[lane]);
         nhit = 0;
-        __syncthreads();
-        const int nq = (int)min(s_nq, (unsigned)RDF_QUEUE);
-        for (int e = tid; e < 2 * nq; e += 256) { // the pairs near a shell boundary, each direction as the reference bins it
-            const int qa = (int)queue[2 * (e >> 1) + (e & 1)], qb = (int)queue[2 * (e >> 1) + 1 - (e & 1)];
+        wsync();
+        const int nq = (int)min(W.nq, 128u);
+        for (int e = lane; e < 2 * nq; e += 64) { // the pairs near a shell boundary, each direction as the reference bins it
+            const int qa = (int)W.xq[2 * (e >> 1) + (e & 1)], qb = (int)W.xq[2 * (e >> 1) + 1 - (e & 1)];
             rdf_exact_pair<TRI>(xs, ys, zs, b, qa, qb, type[order[qa]], type[order[qb]], ntype, nbin, dr, rcsq, lds);
         }
     }
@@ -424,7 +435,7 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         cg.g.rc_inv = 1.0 / rc;
         cg.g.mode = 1;
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, false, cg));
-        const size_t tile_lds = (size_t)RDF_CEN * 17 + (size_t)RDF_QUEUE * 8 + (((size_t)hsize + 3) & ~(size_t)3) * 4 + (size_t)4 * RDF_HITS * 16;
+        const size_t tile_lds = (((size_t)hsize * 4 + 15) & ~(size_t)15) + 4 * sizeof(RdfWave);
         // the frame of 3x3x3 cells along the worst Cartesian axis, in units of the orthogonal kernel's 2.7 rc
         double tol_scale = 1.0;
         const bool tri_tile = b.tri && b.pbc[0] && b.pbc[1] && b.pbc[2];
@@ -437,7 +448,7 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         }
         if ((!b.tri || (tri_tile && tol_scale < 64.0)) && ntype <= 255 && hsize <= RDF_LDS_BINS && g_rdf_variant == 0) {
             ProfRange pr("k_rdf_tile", st);
-            const unsigned blocks = (unsigned)std::min<int64_t>(cg.g.ncell, 256 * 8);
+            const unsigned blocks = (unsigned)std::min<int64_t>((cg.g.ncell + 3) / 4, 256 * 8); // a wave per cell, four to a workgroup
             if (b.tri)
                 hipLaunchKernelGGL(k_rdf_tile<true>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, (float)tol_scale);
             else
