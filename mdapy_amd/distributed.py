@@ -441,8 +441,15 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     """
     t = _torch()
     dom = dec.exchange_halo(x, y, z, gid, rc, sort=False)
-    if next_frame is not None:
-        dec.start_halo(*next_frame, rc)
+    if next_frame is not None and not getattr(dec, "_no_prefetch", False):
+        try:
+            dec.start_halo(*next_frame, rc)
+        except Exception as e:  # the overlap is an optimisation: without it the next call exchanges inside the step
+            import sys
+
+            dec._no_prefetch = True
+            dec._pending.clear()
+            print(f"mdapy_amd.distributed: halo prefetch switched off on rank {dec.rank} ({type(e).__name__}: {e})", file=sys.stderr)
     n = int(dom.x.shape[0])
     b = dec.box
     verlet = t.empty((n, max_neigh), dtype=t.int32, device=dom.x.device)
