@@ -477,12 +477,15 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     };
     // the first four atoms of a cell (twenty independent loads), requested BEFORE the workgroup scan: their latency overlaps
     // the scan's two barriers instead of following them (the loads do not need the LDS offsets, only the stores do)
-    auto request = [&](const Halo &h, double (&ra)[4], double (&rb)[4], double (&rc4)[4], int (&rd)[4], unsigned char (&rm)[4]) {
+    // (unconditional loads, nothing computed from them here: a branch around them, or a narrowing of the code, makes the compiler
+    // copy registers behind an s_waitcnt right after the loads, and the latency is paid before the scan after all; a thread
+    // without atoms loads record 0 and never looks at it)
+    auto request = [&](const Halo &h, double (&ra)[4], double (&rb)[4], double (&rc4)[4], int (&rd)[4], int (&rm)[4]) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int q = h.src + min(v, max(h.cnt - 1, 0));
-            if (h.cnt > 0) { const CellGrid::Packed a = pk[q]; ra[v] = a.x; rb[v] = a.y; rc4[v] = a.z; rd[v] = a.id; rm[v] = (unsigned char)a.code; }
-            else { ra[v] = 0; rb[v] = 0; rc4[v] = 0; rd[v] = 0; rm[v] = NEUTRAL; }
+            const int q = h.cnt > 0 ? h.src + min(v, h.cnt - 1) : 0;
+            const CellGrid::Packed a = pk[q];
+            ra[v] = a.x; rb[v] = a.y; rc4[v] = a.z; rd[v] = a.id; rm[v] = a.code;
         }
     };
     for (int jt = jt0 + (int)(blockIdx.x >> 3); jt < per; jt += (int)(gridDim.x >> 3)) {
@@ -497,8 +500,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         STAMP(1);
 #endif
         double pa[4], pb[4], pc[4];
-        int pd[4];
-        unsigned char pm[4];
+        int pd[4], pm[4];
         request(cur, pa, pb, pc, pd, pm);
         if (flags[0] != 0) // unwrapped input: the image codes are not valid, the thread-per-atom kernel takes the whole call (asked
             return;        // here, behind the tile's first loads: the flag is two dependent scalar loads away)
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 unsigned char m[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) { // twenty independent loads in flight
-                    if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = pm[v]; }
+                    if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = (unsigned char)pm[v]; }
                     else {
                         const int q = src + min(k + v, cnt - 1);
                         const CellGrid::Packed r = pk[q];
