@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
                                                     int64_t N, DBox b, const int *__restrict__ NL, const double *__restrict__ DL, int64_t M,
                                                     const int *__restrict__ NN, const double *__restrict__ weight, int il, int stride, int nz,
                                                     int lmax, int nnn, int use_voronoi, double rc, int use_weight,
-                                                    const double *__restrict__ norm, double *__restrict__ qlm_r, double *__restrict__ qlm_i)
+                                                    const double *__restrict__ norm, double *__restrict__ qlm_r, double *__restrict__ qlm_i,
+                                                    double *__restrict__ qn, int ncol, int lrt)
 {
     constexpr int NM = 2 * L + 1;
     __shared__ double sr[NM][65], si[NM][65];
@@ -216,6 +217,15 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
         const double f = 1.0 / wsum; // :422 (no guard: NaN/inf for an atom without neighbours)
 #pragma unroll
         for (int m = 0; m < NM; ++m) { sr[m][t] = ar[m] * f; si[m][t] = ai[m] * f; }
+        if (qn) { // q_l of a call without averaging and without w_l: the row is in registers, stage 3 (:520-531) would re-read it
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const double vr = ar[m] * f, vi = ai[m] * f; // the stored values
+                s += vr * vr + vi * vi;
+            }
+            qn[i * ncol + il] = sqrt(4 * MY_PI / (2 * lrt + 1)) * sqrt(s); // (lrt = L at run time: the factor as the kernel of stage 3 computes it)
+        }
     }
     __syncthreads();
     for (int e = t; e < rows * NM; e += 64) {
@@ -228,12 +238,12 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
 template <bool TRI>
 static bool launch_stage1_l(int l, dim3 grid, hipStream_t st, const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b,
                             const int *dv, const double *dd, int64_t M, const int *dn, const double *dw, int il, int stride, int nz, int lmax,
-                            int nnn, int use_voronoi, double rc, int use_weight, const double *dnorm, double *dqr, double *dqi)
+                            int nnn, int use_voronoi, double rc, int use_weight, const double *dnorm, double *dqr, double *dqi, double *dqn, int ncol)
 {
 #define MDH_SQ_L(LL)                                                                                                                     \
     case LL:                                                                                                                             \
         hipLaunchKernelGGL((k_sq_stage1_l<TRI, LL>), grid, dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, il, stride, nz, lmax, nnn, \
-                           use_voronoi, rc, use_weight, dnorm, dqr, dqi);                                                                \
+                           use_voronoi, rc, use_weight, dnorm, dqr, dqi, dqn, ncol, LL);                                                 \
         return true;
     switch (l) {
         MDH_SQ_L(2) MDH_SQ_L(3) MDH_SQ_L(4) MDH_SQ_L(5) MDH_SQ_L(6) MDH_SQ_L(7) MDH_SQ_L(8) MDH_SQ_L(10) MDH_SQ_L(12)
@@ -551,13 +561,16 @@ int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, con
         const int l = ll.l[k];
         special = (l >= 2 && l <= 8) || l == 10 || l == 12;
     }
+    // no averaging, no w_l: q_l leaves the stage-1 kernels, stage 3 is not launched (2.1 of 8.2 ms for q4 + q6 of 10 M atoms)
+    const bool fused_final = special && !average && !wl && !wlhat;
+    double *fq = fused_final ? dqn : nullptr;
     if (special) {
         const dim3 grid(grid_for(N, 64));
         for (int k = 0; k < nl; ++k) {
             if (b.tri)
-                launch_stage1_l<true>(ll.l[k], grid, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, k, (int)stride, 2 * lmax + 1, lmax, nnn, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+                launch_stage1_l<true>(ll.l[k], grid, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, k, (int)stride, 2 * lmax + 1, lmax, nnn, use_voronoi, rc, use_weight, dnorm, dqr, dqi, fq, ncol);
             else
-                launch_stage1_l<false>(ll.l[k], grid, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, k, (int)stride, 2 * lmax + 1, lmax, nnn, use_voronoi, rc, use_weight, dnorm, dqr, dqi);
+                launch_stage1_l<false>(ll.l[k], grid, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, k, (int)stride, 2 * lmax + 1, lmax, nnn, use_voronoi, rc, use_weight, dnorm, dqr, dqi, fq, ncol);
         }
     } else {
     // block size so that 2*stride doubles per thread fit in 64 KiB of LDS
@@ -581,7 +594,9 @@ int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, con
         MDH_HIP(hipMemcpyAsync(ai, dqi, sizeof(double) * (size_t)(N * stride), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_sq_average, dim3(grid_for(N * stride, 256)), dim3(256), 0, st, N, dv, M, dn, ll, nnn, lmax, use_voronoi, ar, ai, dqr, dqi);
     }
-    if ((size_t)65 * 16 * (size_t)stride <= 60 * 1024)
+    if (fused_final)
+        ;
+    else if ((size_t)65 * 16 * (size_t)stride <= 60 * 1024)
         hipLaunchKernelGGL(k_sq_final<true>, dim3(grid_for(N, 64)), dim3(64), (size_t)65 * 16 * (size_t)stride, st, N, ll, lmax, wl, wlhat, dcg, dqr, dqi, dqn, ncol);
     else
         hipLaunchKernelGGL(k_sq_final<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, N, ll, lmax, wl, wlhat, dcg, dqr, dqi, dqn, ncol);

@@ -537,6 +537,15 @@ def test_steinhardt_vs_oracle(case, mode):
         assert np.array_equal(ok, np.isfinite(outs[1][2]).all(axis=1))
         for a, b in zip(outs[0], outs[1]):
             assert np.allclose(b[ok], a[ok], rtol=1e-6, atol=1e-12)
+    # q_l alone (no w_l, no averaging): the stage-1 kernels write it themselves
+    plain = []
+    for be in (O, _sbo):
+        qr = np.zeros((N, 3, 2 * lmax + 1)); qi = np.zeros_like(qr); qn = np.zeros((N, 3))
+        be.get_sq(x, y, z, box, org, bnd, v, d, n, np.zeros((2, 2)), ll, nnn, lmax, False, False, False, False, rc, False, qr, qi, qn, 4)
+        plain.append(qn)
+    ok = np.isfinite(plain[0]).all(axis=1)
+    assert np.array_equal(ok, np.isfinite(plain[1]).all(axis=1))
+    assert np.allclose(plain[1][ok], plain[0][ok], rtol=1e-6, atol=1e-12)
     # solid / liquid bond counting on the averaged-off q6m
     qr, qi, qn = outs[1]
     Q6 = np.ascontiguousarray(qn[:, 1])
@@ -562,19 +571,21 @@ def test_steinhardt_per_degree_kernels_equal_the_generic_one():
     for ls, nnn, use_w in (([4, 6], 0, False), ([2, 3, 5, 7, 8, 10, 12], 0, True), ([6], 10, False), ([4, 9], 0, False)):
         ll = np.array(ls, np.int32)
         lmax = int(ll.max())
-        outs = []
-        for variant in (0, 1):
-            _lib.lib().mdh_debug_set_sq_variant(variant)
-            try:
-                qr = np.zeros((N, len(ls), 2 * lmax + 1)); qi = np.zeros_like(qr); qn = np.zeros((N, 3 * len(ls)))
-                _sbo.get_sq(x, y, z, box, org, bnd, v, d, n, w if use_w else np.zeros((2, 2)), ll, nnn, lmax, True, True, True, False,
-                            3.4 if nnn == 0 else 1e9, use_w, qr, qi, qn, 1)
-                outs.append((qr, qi, qn))
-            finally:
-                _lib.lib().mdh_debug_set_sq_variant(0)
-        for a, b_ in zip(*outs):
-            assert a.tobytes() == b_.tobytes(), ls
-        assert np.isfinite(outs[0][2]).any()
+        # (w_l, w-hat_l, averaging) all on; all off: q_l then leaves the stage-1 kernels themselves and stage 3 is not launched
+        for full in (True, False):
+            outs = []
+            for variant in (0, 1):
+                _lib.lib().mdh_debug_set_sq_variant(variant)
+                try:
+                    qr = np.zeros((N, len(ls), 2 * lmax + 1)); qi = np.zeros_like(qr); qn = np.zeros((N, (3 if full else 1) * len(ls)))
+                    _sbo.get_sq(x, y, z, box, org, bnd, v, d, n, w if use_w else np.zeros((2, 2)), ll, nnn, lmax, full, full, full, False,
+                                3.4 if nnn == 0 else 1e9, use_w, qr, qi, qn, 1)
+                    outs.append((qr, qi, qn))
+                finally:
+                    _lib.lib().mdh_debug_set_sq_variant(0)
+            for a, b_ in zip(*outs):
+                assert a.tobytes() == b_.tobytes(), (ls, full)
+            assert np.isfinite(outs[0][2]).any()
 
 
 def _solid_liquid_serial(v, d, n, q, thr, n_bond, rc):
