@@ -261,14 +261,25 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
     float far2 = 0.f;
     int ids[14];
     load_row<14>(row, ids);
+    // seven gathers in flight, then their minimum images (one loop body for both keeps every load behind the branches of the
+    // previous neighbour's pbc: fourteen dependent memory latencies)
 #pragma unroll
-    for (int a = 0; a < 14; ++a) {
-        const Pos4 pj = pos[safe_id(ids[a], i, N)];
-        double dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi; // pair_d2(i, j): cna.cpp:149-161
-        pbc<false>(b, dx, dy, dz);
-        d2[a] = dx * dx + dy * dy + dz * dz;
-        ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
-        far2 = fmaxf(far2, fmaxf(fabsf(ux[a]), fmaxf(fabsf(uy[a]), fabsf(uz[a]))));
+    for (int a0 = 0; a0 < 14; a0 += 7) {
+        double gx[7], gy[7], gz[7];
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const Pos4 pj = pos[safe_id(ids[a0 + v], i, N)];
+            gx[v] = pj.x - xi; gy[v] = pj.y - yi; gz[v] = pj.z - zi; // pair_d2(i, j): cna.cpp:149-161
+        }
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const int a = a0 + v;
+            double dx = gx[v], dy = gy[v], dz = gz[v];
+            pbc<false>(b, dx, dy, dz);
+            d2[a] = dx * dx + dy * dy + dz * dz;
+            ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
+            far2 = fmaxf(far2, fmaxf(fabsf(ux[a]), fmaxf(fabsf(uy[a]), fabsf(uz[a]))));
+        }
     }
     const double Lmin = fmin(b.pbc[0] ? b.h[0] : 1e300, fmin(b.pbc[1] ? b.h[4] : 1e300, b.pbc[2] ? b.h[8] : 1e300));
     const RowsLds L{lds_col, 256};
@@ -336,13 +347,6 @@ __global__ __launch_bounds__(256, 4) void k_acna_f32(const Pos4 *__restrict__ po
 }
 
 // ------------------------------------------------------------------ adaptive (cna.cpp:289-427)
-template <bool TRI>
-__device__ __forceinline__ double dist2_to(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
-                                           const double *__restrict__ z, double xi, double yi, double zi, int j)
-{
-    return pair_d2<TRI>(b, xi, yi, zi, x[j], y[j], z[j]); // pbcdis_sq(i, j): exact reference expression
-}
-
 // returns the label, or -1 (redo with the generic variant)
 template <bool TRI, bool GENERIC>
 __device__ __forceinline__ int acna_atom(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
@@ -354,11 +358,21 @@ __device__ __forceinline__ int acna_atom(const DBox &b, const double *__restrict
 #pragma unroll
     for (int a = 0; a < 14; ++a)
         ids[a] = safe_id(row[a], i, N);
+    // the fourteen gathers go out together and pbcdis_sq(i, j) is evaluated once per neighbour (the reference evaluates it in
+    // both passes, from identical operands); gather and minimum image in one loop body would be fourteen dependent latencies
+    double d2[14];
+    {
+        double px[14], py[14], pz[14];
+#pragma unroll
+        for (int a = 0; a < 14; ++a) { px[a] = x[ids[a]]; py[a] = y[ids[a]]; pz[a] = z[ids[a]]; }
+#pragma unroll
+        for (int a = 0; a < 14; ++a) d2[a] = pair_d2<TRI>(b, xi, yi, zi, px[a], py[a], pz[a]);
+    }
     // ---- 12 nearest neighbours: FCC / HCP / ICO (cna.cpp:309-370)
     double rs = 0.0;
 #pragma unroll
     for (int m = 0; m < 12; ++m)
-        rs += sqrt(dist2_to<TRI>(b, x, y, z, xi, yi, zi, ids[m]));
+        rs += sqrt(d2[m]);
     double lc = rs / 12 * (1.0 + sqrt(2.0)) * 0.5; // :319
     {
         int ids12[12];
@@ -390,10 +404,10 @@ __device__ __forceinline__ int acna_atom(const DBox &b, const double *__restrict
         rs = 0.0;
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-            rs += sqrt(dist2_to<TRI>(b, x, y, z, xi, yi, zi, ids[m]) / (3.0 / 4.0));
+            rs += sqrt(d2[m] / (3.0 / 4.0));
 #pragma unroll
         for (int m = 8; m < 14; ++m)
-            rs += sqrt(dist2_to<TRI>(b, x, y, z, xi, yi, zi, ids[m]));
+            rs += sqrt(d2[m]);
         lc = rs / 14 * (1.0 + sqrt(2.0)) * 0.5;
         Rows R;
         if (!bond_rows<TRI, GENERIC, 14>(b, x, y, z, ids, lc * lc, R))
@@ -477,8 +491,8 @@ __global__ __launch_bounds__(256) void k_ids_classify(const double *__restrict__
     const double xi = x[i], yi = y[i], zi = z[i];
     double rs = 0.0;
 #pragma unroll
-    for (int m = 0; m < 12; ++m)
-        rs += sqrt(dist2_to<TRI>(b, x, y, z, xi, yi, zi, ids[m]));
+    for (int m = 0; m < 12; ++m) // (gathers batched in front as in acna_atom: 190 VGPRs against 158, the kernel 4 % slower)
+        rs += sqrt(pair_d2<TRI>(b, xi, yi, zi, x[ids[m]], y[ids[m]], z[ids[m]]));
     rs /= 12.0;
     const double lc = rs * 1.2071068; // :212
     Rows R;

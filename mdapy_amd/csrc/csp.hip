@@ -23,13 +23,16 @@ __device__ __forceinline__ double csp_atom_static(const DBox &b, const Pos4 *__r
     double rx[K], ry[K], rz[K];
     int ids[K];
     load_row<K>(row, ids);
+    // all K gathers first, the minimum image afterwards: with both in one loop body the compiler keeps every load behind the
+    // branches of the previous neighbour's pbc (it does not hoist loads over control flow) — K dependent memory latencies
 #pragma unroll
     for (int a = 0; a < K; ++a) {
         const Pos4 pj = pos[safe_id(ids[a], i, N)];
-        double dx = pj.x - xi, dy = pj.y - yi, dz = pj.z - zi;
-        pbc<TRI>(b, dx, dy, dz);
-        rx[a] = dx; ry[a] = dy; rz[a] = dz;
+        rx[a] = pj.x - xi; ry[a] = pj.y - yi; rz[a] = pj.z - zi;
     }
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+        pbc<TRI>(b, rx[a], ry[a], rz[a]);
     double top[H];
 #pragma unroll
     for (int q = 0; q < H; ++q)
