@@ -39,16 +39,17 @@ __global__ __launch_bounds__(256) void k_aja(const double *__restrict__ x, const
     // rows are sorted by distance, so the n0 bonds below 1.45 r0^2 are the first n0 entries (as the reference assumes)
     double rx[14], ry[14], rz[14];
     const double xi = x[i], yi = y[i], zi = z[i];
+    // all fourteen gathers first (a slot past n0 reads a valid atom and is zeroed below), the minimum images afterwards: in one
+    // loop body each gather waits behind the branches of the previous neighbour's pbc
 #pragma unroll
     for (int j = 0; j < 14; ++j) {
-        if (j < n0) {
-            const int q = safe_id(vi[j], i, N);
-            double ax = x[q] - xi, ay = y[q] - yi, az = z[q] - zi;
-            pbc<TRI>(b, ax, ay, az);
-            rx[j] = ax; ry[j] = ay; rz[j] = az;
-        } else {
-            rx[j] = ry[j] = rz[j] = 0.0;
-        }
+        const int q = safe_id(vi[j], i, N);
+        rx[j] = x[q] - xi; ry[j] = y[q] - yi; rz[j] = z[q] - zi;
+    }
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        if (j < n0) pbc<TRI>(b, rx[j], ry[j], rz[j]);
+        else rx[j] = ry[j] = rz[j] = 0.0;
     }
     int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
 #pragma unroll

@@ -425,23 +425,41 @@ __device__ int load_normalized(const double *__restrict__ x, const double *__res
     double ex[NROW + 1 - NP][3]; // points beyond the hull's reach only count in the barycentre and the scale
     int num = 1;
     bool open = true;
+    // Six neighbours at a time: their ids, then their positions, requested together; the minimum images afterwards.  With id,
+    // position and fold in one loop body every gather waited behind the branches of the previous neighbour's fold — eighteen
+    // dependent memory latencies per atom in a kernel that runs five waves per CU.
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        const int j = nbr[(int64_t)k * N + atom];
-        open = open && j >= 0;
-        double dx = 0, dy = 0, dz = 0;
-        if (open) {
-            dx = x[j] - xi; dy = y[j] - yi; dz = z[j] - zi;
-            fold<TRI>(b, dx, dy, dz);
-            sum[0] += dx; sum[1] += dy; sum[2] += dz;
-            ++num;
+    for (int k0 = 0; k0 < NROW; k0 += 6) {
+        int jj[6];
+        bool op[6];
+        double gx[6], gy[6], gz[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) jj[u] = nbr[(int64_t)(k0 + u) * N + atom];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            open = open && jj[u] >= 0;
+            op[u] = open;
+            const int64_t q = open ? (int64_t)jj[u] : atom; // (a closed slot reads the centre: never used)
+            gx[u] = x[q] - xi; gy[u] = y[q] - yi; gz[u] = z[q] - zi;
         }
-        if (k + 1 < NP) {
-            m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
-        } else {
-            ex[k + 1 - NP][0] = dx; ex[k + 1 - NP][1] = dy; ex[k + 1 - NP][2] = dz;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = k0 + u;
+            double dx = 0, dy = 0, dz = 0;
+            if (op[u]) {
+                dx = gx[u]; dy = gy[u]; dz = gz[u];
+                fold<TRI>(b, dx, dy, dz);
+                sum[0] += dx; sum[1] += dy; sum[2] += dz;
+                ++num;
+            }
+            if (k + 1 < NP) {
+                m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
+            } else {
+                ex[k + 1 - NP][0] = dx; ex[k + 1 - NP][1] = dy; ex[k + 1 - NP][2] = dz;
+            }
         }
     }
+    static_assert(NROW % 6 == 0, "batches of six");
     const double s[3] = {sum[0] / num, sum[1] / num, sum[2] / num};
     double scale = 0.0;
     m.P[0 * BLK] = 0.0 - s[0]; m.P[1 * BLK] = 0.0 - s[1]; m.P[2 * BLK] = 0.0 - s[2];
@@ -1041,17 +1059,33 @@ __device__ __forceinline__ void load_neighbourhood(const Mem &m, const double *_
     typedef typename Mem::IdT IdT;
     m.I[0 * BLK] = Mem::SLOTS ? (IdT)0 : (IdT)atom;
     bool open = true;
+    // 15 points serve the largest single-shell template; seven neighbours at a time, ids then positions requested together, the
+    // minimum images afterwards (see load_normalized)
 #pragma unroll
-    for (int k = 0; k < 14; ++k) { // 15 points serve the largest single-shell template
-        const int j = nbr[(int64_t)k * N + atom];
-        open = open && j >= 0;
-        double dx = 0, dy = 0, dz = 0;
-        if (open) {
-            dx = x[j] - xi; dy = y[j] - yi; dz = z[j] - zi;
-            fold<TRI>(b, dx, dy, dz);
+    for (int k0 = 0; k0 < 14; k0 += 7) {
+        int jj[7];
+        bool op[7];
+        double gx[7], gy[7], gz[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) jj[u] = nbr[(int64_t)(k0 + u) * N + atom];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            open = open && jj[u] >= 0;
+            op[u] = open;
+            const int64_t q = open ? (int64_t)jj[u] : atom;
+            gx[u] = x[q] - xi; gy[u] = y[q] - yi; gz[u] = z[q] - zi;
         }
-        m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
-        m.I[(k + 1) * BLK] = open ? (Mem::SLOTS ? (IdT)(k + 1) : (IdT)j) : (IdT)-1;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int k = k0 + u;
+            double dx = 0, dy = 0, dz = 0;
+            if (op[u]) {
+                dx = gx[u]; dy = gy[u]; dz = gz[u];
+                fold<TRI>(b, dx, dy, dz);
+            }
+            m.P[((k + 1) * 3 + 0) * BLK] = dx; m.P[((k + 1) * 3 + 1) * BLK] = dy; m.P[((k + 1) * 3 + 2) * BLK] = dz;
+            m.I[(k + 1) * BLK] = op[u] ? (Mem::SLOTS ? (IdT)(k + 1) : (IdT)jj[u]) : (IdT)-1;
+        }
     }
 }
 
