@@ -1122,16 +1122,28 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
     best.type = ptmc::T_NONE; best.aut = -1; best.kind = -1;
     best.rmsd = INFINITY; best.scale = 0;
     best.q[0] = best.q[1] = best.q[2] = best.q[3] = 0;
+    // the canonical forms' flags of all kinds are requested together, and a kind's labelling as one batch of loads: one flag,
+    // then one label per trip of a run-time loop, was a chain of up to sixteen dependent memory latencies per kind
+    bool live_of[NKIND];
+#pragma unroll
+    for (int kind = 0; kind < NKIND; ++kind) live_of[kind] = in.ok[kind] != nullptr && in.ok[kind][atom] != 0;
     for (int kind = 0; kind < NKIND; ++kind) {
         const int np = kind_points(kind);
-        const bool live = in.ok[kind] != nullptr && in.ok[kind][atom] != 0;
+        bool live = live_of[0];
+#pragma unroll
+        for (int k = 1; k < NKIND; ++k) live = kind == k ? live_of[k] : live;
         if (__ballot(live) == 0)
             continue;
         double bary[3] = {0, 0, 0}, G2 = 0;
         uint64_t hash = 0;
         if (live) {
             hash = in.hash[kind][atom];
-            for (int i = 0; i < np; ++i) m.V[in.label[kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+            int lab[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) lab[i] = in.label[kind][(int64_t)min(i, np - 1) * N + atom];
+#pragma unroll
+            for (int i = 0; i < 15; ++i)
+                if (i < np) m.V[lab[i] * BLK] = (int8_t)i;
             barycentre(m, np, bary, &G2);
         }
         const int ntypes = kind == K_FCC ? 3 : 1;
