@@ -1091,9 +1091,26 @@ __device__ __forceinline__ void load_neighbourhood(const Mem &m, const double *_
 
 template <class Mem> __device__ __forceinline__ void load_cluster(const Mem &m, const ShellSet &set, int npt, int64_t N, int64_t atom)
 {
-    for (int k = 0; k < npt; ++k) {
-        m.I[k * BLK] = set.ids[(int64_t)k * N + atom];
-        for (int c = 0; c < 3; ++c) m.P[(k * 3 + c) * BLK] = set.pts[(int64_t)(k * 3 + c) * N + atom];
+    // six points per trip, their 24 loads together (one point per trip of a run-time loop: 17 x 4 dependent latencies)
+    for (int k0 = 0; k0 < npt; k0 += 6) {
+        int id[6];
+        double p[6][3];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = min(k0 + u, npt - 1);
+            id[u] = set.ids[(int64_t)k * N + atom];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[u][c] = set.pts[(int64_t)(k * 3 + c) * N + atom];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = k0 + u;
+            if (k < npt) {
+                m.I[k * BLK] = id[u];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) m.P[(k * 3 + c) * BLK] = p[u][c];
+            }
+        }
     }
 }
 
@@ -1210,7 +1227,15 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
             for (int i = 0; i < ptmc::MAX_PTS; ++i) pick[i] = (int8_t)(i < 10 ? map(i) : 0);
         } else {
             const int8_t *ac = autc + (size_t)best.aut * ptmc::MAX_PTS;
-            for (int i = 0; i < np; ++i) m.V[in.label[best.kind][(int64_t)i * N + atom] * BLK] = (int8_t)i;
+            {
+                const auto *lp = in.label[best.kind];
+                int lab[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) lab[i] = lp[(int64_t)min(i, np - 1) * N + atom];
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    if (i < np) m.V[lab[i] * BLK] = (int8_t)i;
+            }
 #pragma unroll
             for (int i = 0; i < ptmc::MAX_PTS; ++i) pick[i] = (int8_t)(i < np ? m.V[ac[i] * BLK] : 0);
         }
