@@ -351,12 +351,6 @@ struct CellWindow { int axis; double lo, hi; bool set; };
 static thread_local CellWindow g_window{0, 0.0, 0.0, false};
 static thread_local int *g_window_violations = nullptr; // pinned host word of the previous windowed build
 
-__global__ __launch_bounds__(256) void k_fill_range(int *__restrict__ out, int64_t a, int64_t b, int v)
-{
-    const int64_t i = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < b) out[i] = v;
-}
-
 // out[a..b) = *v (a value that is on the device only)
 __global__ __launch_bounds__(256) void k_fill_from(int *__restrict__ out, int64_t a, int64_t b, const int *__restrict__ v)
 {
@@ -490,17 +484,24 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nb);
             hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, cg.cell_start + from, block_sum, n, -1); // [to] = the piece's total
         };
-        if (a0 > 0) hipLaunchKernelGGL(k_fill_range, dim3(grid_for(a0, 256)), dim3(256), 0, st, cg.cell_start, (int64_t)0, a0, 0);
+        // (constant fills through the runtime's fill kernel: 16-byte stores, 5 us per 10 MB against 15 of a store per thread)
+        hipError_t fill_err = hipSuccess;
+        auto fill_const = [&](int64_t from, int64_t to, int v) {
+            if (to > from && fill_err == hipSuccess)
+                fill_err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cg.cell_start + from), v, (size_t)(to - from), st);
+        };
+        fill_const(0, a0, 0);
         scan_piece(a0, a1);
         if (b1 > b0) {
             // second piece: offsets start at the first piece's total, which sits on the device in cell_start[a1]
             hipLaunchKernelGGL(k_fill_from, dim3(grid_for(b0 - a1 - 1, 256) + 1), dim3(256), 0, st, cg.cell_start, a1 + 1, b0, cg.cell_start + a1);
             scan_piece(b0, b1);
             hipLaunchKernelGGL(k_add_from, dim3(grid_for(b1 - b0 + 1, 256)), dim3(256), 0, st, cg.cell_start, b0, b1 + 1, cg.cell_start + a1, (int64_t)-1);
-            if (b1 < g.ncell) hipLaunchKernelGGL(k_fill_range, dim3(grid_for(g.ncell - b1, 256)), dim3(256), 0, st, cg.cell_start, b1 + 1, g.ncell + 1, (int)N);
+            if (b1 < g.ncell) fill_const(b1 + 1, g.ncell + 1, (int)N);
         } else if (a1 < g.ncell) {
-            hipLaunchKernelGGL(k_fill_range, dim3(grid_for(g.ncell - a1, 256)), dim3(256), 0, st, cg.cell_start, a1 + 1, g.ncell + 1, (int)N);
+            fill_const(a1 + 1, g.ncell + 1, (int)N);
         }
+        MDH_HIP(fill_err);
     }
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc) {
