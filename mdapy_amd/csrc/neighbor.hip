@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                                                 double slack, unsigned char *__restrict__ mv, CellPlanes win)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool moved = false, outside = false;
+    bool moved = false, outside = false, coded = false;
     int cell = -1 - (int)(threadIdx.x & 63); // lanes past the end: distinct negative values, no run, no atomic
     if (i < N) {
         const double xr = x[i], yr = y[i], zr = z[i];
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
             }
         }
         if (mv) mv[i] = (unsigned char)code;
+        coded = code != (1 | (1 << 2) | (1 << 4));
         int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
     }
     if (__any(moved) && (threadIdx.x & 63) == 0)
         flags[0] = 1;
+    if (__any(coded) && (threadIdx.x & 63) == 0)
+        flags[4] = 1; // some atom was handed in outside the box: the gather has to read the image codes (else they are all neutral)
     if (__any(outside) && (threadIdx.x & 63) == 0)
         atomicAdd(win.bad, 1);
 }
@@ -294,14 +297,15 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
                                                 double *__restrict__ xs, double *__restrict__ ys,
                                                 double *__restrict__ zs, int64_t N,
                                                 const unsigned char *__restrict__ mv, unsigned char *__restrict__ mvs,
-                                                CellGrid::Packed *__restrict__ pk)
+                                                CellGrid::Packed *__restrict__ pk, const int *__restrict__ any_code)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N)
         return;
     const int i = order[p];
     const double a = x[i], b = y[i], c = z[i];
-    const unsigned char m = mv[i];
+    // the image codes are a fourth scattered read per atom (one byte each); k_assign says whether any of them is not neutral
+    const unsigned char m = *any_code ? mv[i] : (unsigned char)(1 | (1 << 2) | (1 << 4));
     if (pk) {
         pk[p] = CellGrid::Packed{a, b, c, i, (int)m};
         return;
@@ -392,7 +396,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     const Grid &g = cg.g;
     hipStream_t st = sc.stream();
 
-    unsigned *cell_count = sc.alloc_n<unsigned>((size_t)g.ncell + 4); // + the four flags: one memset for both
+    unsigned *cell_count = sc.alloc_n<unsigned>((size_t)g.ncell + 8); // + the flags (five used): one memset for both
     cg.cell_start = sc.alloc_n<int>((size_t)g.ncell + 1);
     int *cell_id = sc.alloc_n<int>((size_t)N);
     int *rank = sc.alloc_n<int>((size_t)N);
@@ -446,9 +450,9 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         MDH_HIP(hipMemsetAsync(cell_count + p0 * plane, 0, sizeof(unsigned) * (size_t)((p1 - p0) * plane), st));
         if (p3 > p2) MDH_HIP(hipMemsetAsync(cell_count + p2 * plane, 0, sizeof(unsigned) * (size_t)((p3 - p2) * plane), st));
     } else {
-        MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * ((size_t)g.ncell + 4), st)); // counters and flags
+        MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * ((size_t)g.ncell + 8), st)); // counters and flags
     }
-    if (windowed) MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 4, st));
+    if (windowed) MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 8, st));
     cg.flags_fresh = true;
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
@@ -513,7 +517,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
                 hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key);
         }
     }
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk);
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
