@@ -23,8 +23,33 @@ __global__ __launch_bounds__(256) void k_wcp_count(const int *__restrict__ verle
         const int ti = type[i], n = nn[i];
         atomicAdd(&lds[T * T + T + ti], 1u);
         atomicAdd(&lds[T * T + ti], (unsigned)n);
-        for (int q = 0; q < n; ++q)
-            atomicAdd(&lds[ti * T + type[safe_id(verlet[i * M + q], i, N)]], 1u);
+        // eight entries of the row at a time: their ids, then their types, requested together (entry by entry it was two
+        // dependent memory latencies per neighbour: 94 % of the wave-cycles parked); with up to four types the counts stay in
+        // registers until the row is done — 256 threads adding into T*T LDS words serialise on them
+        unsigned c[4] = {0u, 0u, 0u, 0u};
+        const bool few = T <= 4;
+        for (int q0 = 0; q0 < n; q0 += 8) {
+            int tj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tj[u] = safe_id(verlet[i * M + min(q0 + u, n - 1)], i, N);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tj[u] = type[tj[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (q0 + u >= n) continue;
+                if (few) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) c[k] += tj[u] == k ? 1u : 0u;
+                } else {
+                    atomicAdd(&lds[ti * T + tj[u]], 1u);
+                }
+            }
+        }
+        if (few) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < T && c[k]) atomicAdd(&lds[ti * T + k], c[k]);
+        }
     }
     __syncthreads();
     for (int q = threadIdx.x; q < words; q += blockDim.x) {
