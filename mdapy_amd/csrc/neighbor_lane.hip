@@ -545,19 +545,8 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
             const float flo = (float)(-1.5 * cw);
             const float fhx = (float)(((double)HXY + 1.5) * cw), fhz = (float)(((double)HZ + 1.5) * cw);
             bool general = code0 != NEUTRAL3, far = false;
-            for (int k = 0; k < cnt; k += 4) {
-                double a[4], bb[4], c[4];
-                int d[4];
-                unsigned char m[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { // twenty independent loads in flight
-                    if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = (unsigned char)pm[v]; }
-                    else {
-                        const int q = src + min(k + v, cnt - 1);
-                        const CellGrid::Packed r = pk[q];
-                        a[v] = r.x; bb[v] = r.y; c[v] = r.z; d[v] = r.id; m[v] = (unsigned char)r.code;
-                    }
-                }
+            // four atoms of the cell: into the staging arrays
+            auto stage4 = [&](int k, const double (&a)[4], const double (&bb)[4], const double (&c)[4], const int (&d)[4], const int (&m)[4]) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     if (k + v < cnt) {
@@ -588,6 +577,41 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                         lsh[p] = (unsigned short)code;
                         if (centre_cell) cen[coff + k + v] = (unsigned)p | ((unsigned)tid << 11);
                     }
+                }
+            };
+            if (TK8) { // cells of the one-byte instance rarely hold more than the four atoms requested in front of the scan
+                for (int k = 0; k < cnt; k += 4) {
+                    double a[4], bb[4], c[4];
+                    int d[4], m[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { // twenty independent loads in flight
+                        if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = pm[v]; }
+                        else {
+                            const int q = src + min(k + v, cnt - 1);
+                            const CellGrid::Packed r = pk[q];
+                            a[v] = r.x; bb[v] = r.y; c[v] = r.z; d[v] = r.id; m[v] = r.code;
+                        }
+                    }
+                    stage4(k, a, bb, c, d, m);
+                }
+            } else { // dense cells (ten atoms and more): the next four atoms travel while these four are staged (the wide instance
+                     // runs two workgroups per CU: registers to spare)
+                double a[4], bb[4], c[4];
+                int d[4], m[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = pm[v]; }
+                for (int k = 0; k < cnt; k += 4) {
+                    double na[4], nb[4], nc[4];
+                    int nd[4], nm[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { // (unconditional: past the cell's end the last atom again, never staged)
+                        const int q = src + min(k + 4 + v, cnt - 1);
+                        const CellGrid::Packed r = pk[q];
+                        na[v] = r.x; nb[v] = r.y; nc[v] = r.z; nd[v] = r.id; nm[v] = r.code;
+                    }
+                    stage4(k, a, bb, c, d, m);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { a[v] = na[v]; bb[v] = nb[v]; c[v] = nc[v]; d[v] = nd[v]; m[v] = nm[v]; }
                 }
             }
             if (general) s_flag[0] = 1;
