@@ -24,7 +24,7 @@ from .centro_symmetry_parameter import CentroSymmetryParameter
 from .cluster_analysis import ClusterAnalysis
 from .common_neighbor_analysis import CommonNeighborAnalysis
 from .common_neighbor_parameter import CommonNeighborParameter
-from .devarray import HArray, as_numpy
+from .devarray import HArray, as_numpy, full
 from .frame import Frame
 from .identify_diamond_structure import IdentifyDiamondStructure
 from .identify_fcc_planar_faults import IdentifyFccPlanarFaults
@@ -162,7 +162,8 @@ class System:
         """k nearest neighbours as the current list (no ``rc``; every count is k)"""
         search = NearestNeighbor(self.data, self.box, k)
         search.compute()
-        self._remember(search, search.indices_py, search.distances_py, np.full(search.indices_py.shape[0], k, np.int32))
+        # (the counts live where the rows live: a host array here was 40 MB over PCIe in front of every analysis that takes the list)
+        self._remember(search, search.indices_py, search.distances_py, full((search.indices_py.shape[0],), k, np.int32))
         self._sorted_columns = (id(self.verlet_list), k)
 
     def _require_cutoff_list(self, rc, max_neigh):
