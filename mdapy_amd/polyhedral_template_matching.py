@@ -7,7 +7,7 @@ caller or from a search of its own (replica when a periodic direction is thinner
 import numpy as np
 
 from . import kernels, policy
-from .devarray import zeros
+from .devarray import HArray, full, zeros
 from .parallel import get_num_threads
 
 DEPTH = 18
@@ -17,10 +17,14 @@ KNOWN = ("fcc", "hcp", "bcc", "ico", "sc", "dcub", "dhex", "graphene", "all", "d
 def _alloy_types(frame):
     """1-based species codes for the alloy orderings: the ``type`` column, else elements in sorted order, else one species"""
     if "type" in frame.columns:
-        return np.ascontiguousarray(frame["type"].to_numpy(), dtype=np.int32)
+        column = frame["type"]
+        held = getattr(column, "_dev", None)
+        if isinstance(held, HArray) and held.dtype == np.int32:
+            return held  # already in HBM (a file reader's column), as the kernel reads it
+        return np.ascontiguousarray(column.to_numpy(), dtype=np.int32)
     if "element" in frame.columns:
         return policy.label_codes(frame["element"].to_numpy())[1] + 1
-    return np.ones(frame.shape[0], np.int32)
+    return full((frame.shape[0],), 1, np.int32)  # (made where the kernel reads it: a host array is 40 MB over PCIe per 10 M atoms)
 
 
 class PolyhedralTemplateMatching:
