@@ -120,3 +120,34 @@ def test_identity_caches_serve_only_arrays_the_package_froze():
     col.setflags(write=True); col[:] = 5; col.setflags(write=False)  # (reaching into the frame's own array)
     assert not devarray.frozen_by_us(col)
     assert policy.label_codes(col)[0] == [5]
+
+
+def test_fixed_cutoff_cna_is_lent_a_remembered_list_of_the_same_cutoff(oracle_backend, monkeypatch):
+    """cal_common_neighbor_analysis(rc) right after build_neighbor(rc): the reference lends nothing and the analysis builds a
+    list of its own with this very cutoff (src/mdapy/system.py:2038-2058) — the same rows; here the remembered one is lent
+    (no second build), a list with a LARGER cutoff is not (its rows hold more neighbours), and the labels are those of a
+    fresh System either way"""
+    from mdapy_amd import system as S
+    from mdapy_amd.build_lattice import lattice_positions
+
+    pos, box = lattice_positions("fcc", 3.615, 6, 6, 6)
+    pos = pos + np.random.default_rng(5).normal(0, 0.05, pos.shape)
+    rc = 0.854 * 3.615
+    fresh = mp.System(pos=pos, box=mp.Box(box))
+    fresh.cal_common_neighbor_analysis(rc)
+    want = fresh.data["cna"].to_numpy()
+    lent = []
+    real = S.CommonNeighborAnalysis
+
+    def spy(frame, cell, rows, counts, cutoff):
+        lent.append(rows is not None)
+        return real(frame, cell, rows, counts, cutoff)
+
+    monkeypatch.setattr(S, "CommonNeighborAnalysis", spy)
+    s = mp.System(pos=pos, box=mp.Box(box))
+    s.build_neighbor(rc, max_neigh=20)
+    s.cal_common_neighbor_analysis(rc)
+    assert lent == [True] and np.array_equal(s.data["cna"].to_numpy(), want)
+    s.build_neighbor(rc + 0.5, max_neigh=40)
+    s.cal_common_neighbor_analysis(rc)
+    assert lent == [True, False] and np.array_equal(s.data["cna"].to_numpy(), want)
