@@ -119,6 +119,20 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argt
             fn.restype = _RESTYPES.get(name, C.c_int)
+        # MDAPY_HIP_DEVICE ("Config / flags"): the device the library's calls of this process go to, chosen
+        # once at load; mdh_set_device() switches it later (bench.py: one process per GPU, LOCAL_RANK)
+        want = os.environ.get("MDAPY_HIP_DEVICE", "").strip()
+        if want:
+            try:
+                index = int(want)
+            except ValueError:
+                raise ValueError(f"MDAPY_HIP_DEVICE must be a device index, got {want!r}") from None
+            count = int(L.mdh_device_count())
+            if count > 0:  # (a CPU-only box: nothing to select; compute calls raise on their own)
+                if not 0 <= index < count:
+                    raise ValueError(f"MDAPY_HIP_DEVICE={index}: this process sees {count} HIP device(s)")
+                if L.mdh_set_device(index) != 0:
+                    raise RuntimeError(L.mdh_last_error().decode("utf-8", "replace"))
         _lib = L
     return _lib
 

@@ -127,7 +127,7 @@ class CreatePolycrystal:
             return None
         return np.asarray(kept, bool)
 
-    def compute(self, verbose=False):
+    def compute(self, verbose=True):
         """-> System with columns (element,) x, y, z, grain_id, type"""
         from .system import System
 

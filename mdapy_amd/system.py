@@ -39,7 +39,7 @@ from .voronoi import Voronoi
 from .warren_cowley_parameter import WarrenCowleyParameter
 
 _REPLICA = ("_enlarge_box", "_enlarge_data")
-_LIST = ("verlet_list", "neighbor_number", "distance_list", "rc", "_sorted_columns") + _REPLICA
+_LIST = ("verlet_list", "neighbor_number", "distance_list", "rc", "_sorted_columns", "_list_cutoff") + _REPLICA
 
 
 def _position_columns(xyz):
@@ -62,8 +62,60 @@ def _position_columns(xyz):
     return dict(zip("xyz", xyz.T))
 
 
+def _from_ase(atoms):
+    """frame and box of an ASE ``Atoms`` (load_save.py:508-545): cell rows, ``pbc``, positions, chemical symbols.  Duck-typed:
+    ase itself is not needed, only the four getters the reference calls."""
+    for needed in ("get_cell", "get_pbc", "get_positions", "get_chemical_symbols"):
+        if not hasattr(atoms, needed):
+            raise TypeError("Only accept an ASE Atoms object")
+    cell = Box(np.array(atoms.get_cell(), dtype=np.float64), [1 if p else 0 for p in atoms.get_pbc()])
+    xyz = np.asarray(atoms.get_positions(), dtype=np.float64)
+    cols = _position_columns(xyz)
+    cols["element"] = np.array(atoms.get_chemical_symbols())
+    return Frame(cols), cell
+
+
+def _from_ovito(collection):
+    """frame, box and attributes of an OVITO ``DataCollection`` (load_save.py:413-505): the cell's 3x3 block transposed,
+    ``Position`` -> x y z, ``Particle Type`` -> type, ``Particle Identifier`` -> id, ``Velocity`` / ``Force`` -> three columns,
+    ``Velocity Magnitude`` dropped, every other property under its name without blanks (vectors as name_0, name_1, ...);
+    an ``element`` column when every particle type carries a name.  Duck-typed: ``.cell`` (array-like with ``.pbc``),
+    ``.particles`` (mapping), ``.attributes`` (mapping)."""
+    for needed in ("cell", "particles", "attributes"):
+        if not hasattr(collection, needed):
+            raise TypeError("Only accept an Ovito DataCollection object")
+    cell = Box(np.array(collection.cell[...], dtype=np.float64)[:, :3].T, [1 if p else 0 for p in collection.cell.pbc])
+    info = {key: value for key, value in collection.attributes.items()}
+    three = {"Position": ("x", "y", "z"), "Velocity": ("vx", "vy", "vz"), "Force": ("fx", "fy", "fz")}
+    one = {"Particle Type": "type", "Particle Identifier": "id"}
+    cols = {}
+    for key in collection.particles.keys():
+        values = np.array(collection.particles[key][...])
+        if key in three:
+            for k, name in enumerate(three[key]):
+                cols[name] = np.ascontiguousarray(values[:, k])
+        elif key in one:
+            cols[one[key]] = values
+        elif key == "Velocity Magnitude":
+            continue
+        else:
+            name = "".join(key.split())
+            if values.ndim == 1:
+                cols[name] = values
+            else:
+                for k in range(values.shape[1]):
+                    cols[f"{name}_{k}"] = np.ascontiguousarray(values[:, k])
+    table = getattr(collection.particles, "particle_type", None)
+    if table is not None and "type" in cols:
+        names = {t.id: t.name for t in table.types}
+        if names and all(isinstance(n, str) and len(n) > 0 for n in names.values()):
+            cols["element"] = np.array([names[t] for t in cols["type"].tolist()])
+    return Frame(cols), cell, info
+
+
 class System:
-    def __init__(self, filename=None, data=None, pos=None, box=None, format=None, global_info=None):
+    def __init__(self, filename=None, data=None, pos=None, box=None, ase_atom=None, ovito_atom=None, format=None,
+                 global_info=None):
         self._info = {}
         if isinstance(filename, str):
             from .load_save import read_file
@@ -81,8 +133,12 @@ class System:
                 raise AssertionError("pos must have shape (N, 3).")
             self._frame = Frame(_position_columns(xyz))
             self.box = box
+        elif ase_atom is not None:
+            self._frame, self.box = _from_ase(ase_atom)
+        elif ovito_atom is not None:
+            self._frame, self.box, self._info = _from_ovito(ovito_atom)
         else:
-            raise RuntimeError("One must at least provide filename or [data, box] or [pos, box].")
+            raise RuntimeError("One must at least provide filename or [data, box] or [pos, box] or ase_atom or ovito_atom.")
         if global_info is not None and not self._info:
             self._info = dict(global_info)
 
@@ -108,8 +164,15 @@ class System:
     def __repr__(self):
         return f"Atom Number: {self.N}\n{self.box}\nParticle Information:\n{self.data}"
 
-    def update_data(self, data, reset_calculator=False, reset_neighbor=False):
-        """replace the per-atom frame; ``reset_neighbor`` also forgets the neighbor list"""
+    def update_data(self, data, reset_calculator=False, reset_neighbor=False, reset_calcolator=None):
+        """replace the per-atom frame; ``reset_neighbor`` also forgets the neighbor list.  ``reset_calcolator`` is the
+        reference's deprecated misspelling of ``reset_calculator`` (system.py:686-744), accepted with the same warning; there
+        is no calculator on this path, so neither flag has anything to clear."""
+        if reset_calcolator is not None:
+            import warnings
+
+            warnings.warn("`reset_calcolator` is a misspelling and is deprecated; use `reset_calculator` instead.",
+                          DeprecationWarning, stacklevel=2)
         self._frame = Frame.from_any(data)
         if reset_neighbor:
             self._forget(_LIST)
@@ -157,6 +220,9 @@ class System:
         search.compute()
         self.rc = rc
         self._remember(search, search.verlet_list, search.distance_list, search.neighbor_number)
+        # provenance of the CURRENT list: a cutoff list of exactly this reach, complete (an overflow of max_neigh raises).
+        # `rc` alone does not say so — like the reference's, it survives build_nearest_neighbor (system.py:1256-1263)
+        self._list_cutoff = float(rc)
 
     def build_nearest_neighbor(self, k):
         """k nearest neighbours as the current list (no ``rc``; every count is k)"""
@@ -164,6 +230,7 @@ class System:
         search.compute()
         # (the counts live where the rows live: a host array here was 40 MB over PCIe in front of every analysis that takes the list)
         self._remember(search, search.indices_py, search.distances_py, full((search.indices_py.shape[0],), k, np.int32))
+        self._forget(("_list_cutoff",))  # the current list is no cutoff list any more (`rc` stays, as in the reference)
         self._sorted_columns = (id(self.verlet_list), k)
 
     def _require_cutoff_list(self, rc, max_neigh):
@@ -204,9 +271,10 @@ class System:
         elif policy.is_single(self._safe_repeat()) and not ("rc" in self.__dict__ and self.rc >= rc):
             self.build_neighbor(rc, max_neigh)
             rows, counts = self.verlet_list, self.neighbor_number
-        elif policy.is_single(self._safe_repeat()) and self.rc == rc:
+        elif policy.is_single(self._safe_repeat()) and self.__dict__.get("_list_cutoff") == float(rc):
             # the reference lends nothing here and the analysis builds a list of its own with this very cutoff: the same
-            # rows and counts as the remembered one, which is lent instead (one neighbour build less per call)
+            # rows and counts as the CURRENT list when that is a cutoff list of exactly this reach, which is lent instead
+            # (one neighbour build less per call).  A stale `rc` beside a k-nearest list lends nothing.
             rows, counts = self.verlet_list, self.neighbor_number
         cell, frame = self._get_compute_view()
         job = CommonNeighborAnalysis(frame, cell, rows, counts, rc)

@@ -151,3 +151,124 @@ def test_fixed_cutoff_cna_is_lent_a_remembered_list_of_the_same_cutoff(oracle_ba
     s.build_neighbor(rc + 0.5, max_neigh=40)
     s.cal_common_neighbor_analysis(rc)
     assert lent == [True, False] and np.array_equal(s.data["cna"].to_numpy(), want)
+
+
+def test_stale_rc_beside_a_k_nearest_list_lends_nothing(oracle_backend, monkeypatch):
+    """build_neighbor(rc), build_nearest_neighbor(8), cal_common_neighbor_analysis(rc): `rc` survives the k-nearest search (as in
+    the reference, src/mdapy/system.py:1256-1263) but the current list is a k-nearest list — the analysis must build its own
+    (the remembered rows were lent and every fcc atom came out 0)."""
+    from mdapy_amd import system as S
+    from mdapy_amd.build_lattice import lattice_positions
+
+    pos, box = lattice_positions("fcc", 3.615, 6, 6, 6)
+    rc = 0.854 * 3.615
+    lent = []
+    real = S.CommonNeighborAnalysis
+
+    def spy(frame, cell, rows, counts, cutoff):
+        lent.append(rows is not None)
+        return real(frame, cell, rows, counts, cutoff)
+
+    monkeypatch.setattr(S, "CommonNeighborAnalysis", spy)
+    s = mp.System(pos=pos, box=mp.Box(box))
+    s.build_neighbor(rc)
+    s.build_nearest_neighbor(8)
+    assert "rc" in s.__dict__ and "_list_cutoff" not in s.__dict__
+    s.cal_common_neighbor_analysis(rc)
+    assert lent == [False]
+    assert (s.data["cna"].to_numpy() == 1).all()  # 864 fcc atoms, as a fresh System says
+    # a box assignment forgets the provenance with the list
+    s.build_neighbor(rc)
+    assert s._list_cutoff == rc
+    s.box = mp.Box(box)
+    assert "_list_cutoff" not in s.__dict__ and "rc" not in s.__dict__
+
+
+class _FakeAtoms:
+    """the four getters of ase.Atoms that BuildSystem.from_ase calls (src/mdapy/load_save.py:537-541)"""
+
+    def __init__(self, cell, pbc, pos, symbols):
+        self._c, self._p, self._x, self._s = cell, pbc, pos, symbols
+
+    def get_cell(self): return self._c
+    def get_pbc(self): return self._p
+    def get_positions(self): return self._x
+    def get_chemical_symbols(self): return self._s
+
+
+class _FakeCell:
+    def __init__(self, m34, pbc):
+        self._m, self.pbc = m34, pbc
+
+    def __getitem__(self, key): return self._m[key]
+
+
+class _FakeParticles(dict):
+    particle_type = None
+
+
+def test_system_from_ase_and_ovito_like_objects():
+    """System(ase_atom=...) / System(ovito_atom=...) (src/mdapy/system.py:181-203), duck-typed: neither package is installed
+    here, and the reference only uses the getters / mappings the fakes provide.  Positional order is the reference's:
+    filename, data, pos, box, ase_atom, ovito_atom, format, global_info."""
+    import inspect
+
+    assert list(inspect.signature(mp.System.__init__).parameters)[1:] == [
+        "filename", "data", "pos", "box", "ase_atom", "ovito_atom", "format", "global_info"]
+    rng = np.random.default_rng(3)
+    cell = np.array([[10.0, 0, 0], [2.0, 9.0, 0], [0, 0, 8.0]])
+    pos = rng.random((7, 3)) * 8
+    s = mp.System(ase_atom=_FakeAtoms(cell, [True, False, True], pos, ["Cu"] * 4 + ["Zr"] * 3))
+    assert s.N == 7 and np.array_equal(s.box.box, cell) and s.box.boundary.tolist() == [1, 0, 1]
+    assert np.array_equal(np.column_stack([s.data[c].to_numpy() for c in "xyz"]), pos)
+    assert s.data["element"].to_numpy().tolist() == ["Cu"] * 4 + ["Zr"] * 3
+    with pytest.raises(TypeError, match="ASE Atoms"):
+        mp.System(ase_atom=object())
+
+    m34 = np.zeros((3, 4)); m34[:, :3] = cell.T; m34[:, 3] = [1.0, 2.0, 3.0]  # OVITO: cell vectors as columns + origin column
+    class T:  # particle types with names
+        def __init__(self, i, n): self.id, self.name = i, n
+    class Table:
+        types = [T(1, "Cu"), T(2, "Zr")]
+    parts = _FakeParticles({"Position": pos, "Particle Type": np.array([1, 1, 2, 2, 1, 2, 1]), "Particle Identifier": np.arange(1, 8),
+                            "Velocity": pos * 0.1, "Velocity Magnitude": np.ones(7), "Potential Energy": np.arange(7.0),
+                            "Stress Tensor": np.ones((7, 6))})
+    parts.particle_type = Table()
+
+    class Coll:
+        pass
+    c = Coll(); c.cell = _FakeCell(m34, (True, True, False)); c.particles = parts; c.attributes = {"Timestep": 100}
+    s = mp.System(ovito_atom=c)
+    assert s.N == 7 and np.array_equal(s.box.box, cell) and s.box.boundary.tolist() == [1, 1, 0]
+    assert s.global_info == {"Timestep": 100}
+    cols = set(s.data.columns)
+    assert {"x", "y", "z", "type", "id", "vx", "vy", "vz", "PotentialEnergy", "StressTensor_0", "StressTensor_5", "element"} <= cols
+    assert "VelocityMagnitude" not in cols and "Velocity Magnitude" not in cols
+    assert s.data["element"].to_numpy().tolist() == ["Cu", "Cu", "Zr", "Zr", "Cu", "Zr", "Cu"]
+    with pytest.raises(RuntimeError, match="ase_atom or ovito_atom"):
+        mp.System()
+
+
+def test_update_data_accepts_the_misspelled_alias_with_a_warning():
+    pos = np.random.default_rng(0).random((5, 3)) * 4
+    s = mp.System(pos=pos, box=mp.Box(5.0))
+    with pytest.warns(DeprecationWarning, match="reset_calcolator"):
+        s.update_data(s.data.with_columns(e=np.arange(5.0)), reset_calcolator=True)
+    assert "e" in s.data.columns
+    import inspect
+    from mdapy_amd.create_polycrystal import CreatePolycrystal
+
+    assert list(inspect.signature(mp.System.update_data).parameters)[1:] == ["data", "reset_calculator", "reset_neighbor", "reset_calcolator"]
+    assert inspect.signature(CreatePolycrystal.compute).parameters["verbose"].default is True
+
+
+def test_mdapy_hip_device_is_validated_at_load():
+    """MDAPY_HIP_DEVICE: a non-integer is refused when the library loads; on a CPU-only box an index is accepted
+    (there is nothing to select) and compute calls still raise on their own"""
+    code = "import mdapy_amd._lib as L; L.lib(); print('ok')"
+    env = dict(os.environ, MDAPY_HIP_DEVICE="zero")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode != 0 and "MDAPY_HIP_DEVICE must be a device index" in out.stderr
+    env["MDAPY_HIP_DEVICE"] = "0"
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
