@@ -152,8 +152,13 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
  * a rank's slab and its halo, in the global box — has its wrapped fractional coordinate along `axis` in [frac_lo, frac_hi]
  * (the interval may leave [0,1): a slab at the periodic seam).  The passes over ALL cells of the global grid then run over the
  * window's planes only; results are the same.  Only axis 0 of orthogonal boxes is taken (otherwise ignored).  An atom outside
- * the window breaks the promise: detected on the device, reported as MDH_ERR_ARG by this thread's next build. */
+ * the window breaks the promise: detected on the device, the atom is left out of the grid (nothing is written out of bounds),
+ * and the broken promise is reported as MDH_ERR_ARG by this thread's next build or by mdh_cell_window_check(). */
 int mdh_hint_cell_window(int axis, double frac_lo, double frac_hi);
+/* Waits for `stream` and returns MDH_ERR_ARG if the last windowed build of this thread found atoms outside its window (the
+ * build itself stays memory-safe: such atoms take no slot and are left out, so its rows are incomplete); MDH_OK otherwise.
+ * For callers that want the CURRENT step to fail instead of the next build (one stream synchronisation). */
+int mdh_cell_window_check(void *stream);
 
 /* Halo selection of the slab decomposition (multi-GPU extension): one pass over the owned atoms; up / down (n) i32
  * receive the indices of the atoms whose wrapped fractional coordinate f along the decomposed axis (hi3 = that column of the

@@ -34,6 +34,16 @@ def hint_cell_window(axis, frac_lo, frac_hi):
     _lib.check(_lib.lib().mdh_hint_cell_window(int(axis), float(frac_lo), float(frac_hi)))
 
 
+def cell_window_check(stream=None):
+    """wait for the stream and raise ValueError if the last windowed build of this thread left atoms out (broken promise);
+    without this the NEXT build of the thread raises"""
+    if stream is None:
+        from .devarray import torch
+
+        stream = int(torch().cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().mdh_cell_window_check(stream))
+
+
 def build_neighbor_fcna(x, y, z, box, origin, boundary, rc, verlet_list, distance_list, neighbor_number, pattern, num_t=1,
                         fill_pads=False, key=None):
     """``build_neighbor`` (src/neighbor.cpp:351) and ``fcna`` (src/cna.cpp:429) with the same ``rc`` in one pass over the

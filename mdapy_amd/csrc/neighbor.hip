@@ -68,9 +68,14 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
         int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
+        if (win.bad && !((c0 >= win.p0 && c0 < win.p1) || (c0 >= win.p2 && c0 < win.p3))) {
+            // an atom outside the window of planes the caller promised (mdh_hint_cell_window): the counters out there were
+            // never zeroed — it takes no slot and is not scattered (cell -1); the build is reported broken (win.bad), its
+            // rows are not to be used, and nothing is written out of bounds
+            outside = true;
+            cell = -1 - (int)(threadIdx.x & 63);
+        }
         cell_id[i] = cell;
-        if (win.bad && !((c0 >= win.p0 && c0 < win.p1) || (c0 >= win.p2 && c0 < win.p3)))
-            outside = true; // an atom outside the window of planes the caller promised (mdh_hint_cell_window)
     }
     // One returning atomic per RUN of adjacent lanes in the same cell instead of one per atom: atoms usually arrive in some
     // spatial order (a lattice builder, a file written cell by cell, a previous sort), so neighbouring lanes share cells;
@@ -215,7 +220,9 @@ __global__ __launch_bounds__(256) void k_scatter(const int *__restrict__ cell_id
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    order[cell_start[cell_id[i]] + rank[i]] = (int)i;
+    const int c = cell_id[i];
+    if (c >= 0) // (< 0: an atom outside a promised cell window, k_assign)
+        order[cell_start[c] + rank[i]] = (int)i;
 }
 
 // The atomic counters hand out slots in arbitrary order; put every cell's
@@ -297,10 +304,13 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
                                                 double *__restrict__ xs, double *__restrict__ ys,
                                                 double *__restrict__ zs, int64_t N,
                                                 const unsigned char *__restrict__ mv, unsigned char *__restrict__ mvs,
-                                                CellGrid::Packed *__restrict__ pk, const int *__restrict__ any_code)
+                                                CellGrid::Packed *__restrict__ pk, const int *__restrict__ any_code,
+                                                const int *__restrict__ n_binned)
 {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N)
+        return;
+    if (n_binned && p >= *n_binned) // a windowed build that dropped atoms outside its window: order[] ends at the atoms binned
         return;
     const int i = order[p];
     const double a = x[i], b = y[i], c = z[i];
@@ -517,7 +527,9 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
                 hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key);
         }
     }
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4);
+    // (windowed: the atoms binned = the prefix behind the last piece, on the device; all N unless the promise was broken)
+    const int *n_binned = windowed ? cg.cell_start + (p3 > p2 ? p3 : p1) * plane : nullptr;
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4, n_binned);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
@@ -1032,6 +1044,19 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
 int mdh_hint_cell_window(int axis, double frac_lo, double frac_hi)
 {
     g_window = CellWindow{axis, frac_lo, frac_hi, true};
+    return MDH_OK;
+}
+
+int mdh_cell_window_check(void *stream)
+{
+    if (!g_window_violations)
+        return MDH_OK;
+    MDH_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    if (*(volatile int *)g_window_violations != 0) {
+        *g_window_violations = 0;
+        set_error("the last neighbor build on this thread found atoms outside the cell window it had been promised (mdh_hint_cell_window): its rows are incomplete");
+        return MDH_ERR_ARG;
+    }
     return MDH_OK;
 }
 

@@ -49,6 +49,14 @@ def current_stream_ptr() -> int:
     return int(torch().cuda.current_stream().cuda_stream)
 
 
+PINNED_BUDGET = 1 << 30  # page-locked bytes HArray.numpy() may have handed out at any time (host arrays that are still alive)
+_pinned_out = [0]
+
+
+def _pinned_release(nbytes):
+    _pinned_out[0] -= nbytes
+
+
 class HArray:
     """An array that lives in HBM; the host copy is made on demand and is read-only."""
 
@@ -96,14 +104,21 @@ class HArray:
     def numpy(self) -> np.ndarray:
         if self._host is None:
             d = self._dev
-            if d.is_cuda and d.is_contiguous() and (1 << 20) <= d.numel() * d.element_size() <= (1 << 28):
+            nbytes = d.numel() * d.element_size()
+            locked = 1 << max(nbytes - 1, 1).bit_length()  # (torch's pinned allocator rounds a block up to a power of two)
+            if d.is_cuda and d.is_contiguous() and (1 << 20) <= nbytes <= (1 << 28) and _pinned_out[0] + locked <= PINNED_BUDGET:
                 # into page-locked memory (recycled by torch's host allocator) and handed out as it is: 0.7 instead of 5 ms for the
-                # 40 MB label column of a 10 M-atom system
+                # 40 MB label column of a 10 M-atom system.  The block stays locked while the host array lives, so the bytes
+                # handed out this way are counted and capped (PINNED_BUDGET); beyond the cap a result is an ordinary pageable copy
+                import weakref
+
                 t = torch()
                 pinned = t.empty(d.shape, dtype=d.dtype, pin_memory=True)
                 pinned.copy_(d, non_blocking=True)
                 t.cuda.current_stream().synchronize()
                 h = pinned.numpy()
+                _pinned_out[0] += locked
+                weakref.finalize(pinned, _pinned_release, locked)
             else:
                 h = d.cpu().numpy()
             h.setflags(write=False)

@@ -52,7 +52,8 @@ class SlabDecomposition:
         self.right = (rank + 1) % world
         self._cap = 0  # rows of the halo pack buffers (grown on demand, sized from the last exchange)
         self._msg_cap = {}   # (halo, columns) -> atoms a halo message holds, agreed by all ranks (fast exchange)
-        self._msg_buf = {}   # (columns, cap, device) -> the four message buffers
+        self._msg_buf = {}   # (columns, cap, device) -> list of buffer sets (four messages + pinned heads); one set per exchange in flight
+        self._busy = set()   # id() of the buffer sets an exchange under way (a prefetched one included) is using
         self._roomy = {}     # data_ptr -> (weak reference, rows of spare room) of tensors made by with_room()
         self._own_mask = None
         self._side = None    # HIP stream the next frame's halo travels on while this frame's kernels run (start_halo)
@@ -191,8 +192,20 @@ class SlabDecomposition:
 
     def reset_halo_capacity(self):
         """forget the agreed message sizes (call on all ranks; the next exchange agrees on new ones)"""
+        self._drop_pending()
         self._msg_cap.clear()
         self._msg_buf.clear()
+
+    def _drop_pending(self):
+        """forget exchanges that were started and never picked up; their buffer sets are free again once the streams that
+        filled them are waited for (the next exchange on either stream is ordered behind them)"""
+        t = _torch()
+        for st in self._pending.values():
+            st["done"].synchronize()
+            if st["side"]:
+                t.cuda.current_stream().wait_event(st["done"])
+            self._busy.discard(id(st["bufs"]))
+        self._pending.clear()
 
     def _exchange_fast(self, x, y, z, gid, cols, h, halo):
         """device tensors, ghosts appended behind the owned atoms.  The layers are selected and packed into the two outgoing
@@ -220,7 +233,7 @@ class SlabDecomposition:
         if key in self._pending:
             return
         if len(self._pending) > 2:
-            self._pending.clear()
+            self._drop_pending()
         self._pending[key] = self._fast_begin(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, self.halo_fraction(halo), halo, side=True)
 
     def _fast_begin(self, x, y, z, gid, cols, h, halo, side):
@@ -247,12 +260,18 @@ class SlabDecomposition:
             cap = cap + cap // 4 + 64
             self._msg_cap[sig] = cap
         key = (width, cap, str(dev))
-        bufs = self._msg_buf.get(key)
+        if key not in self._msg_buf and len(self._msg_buf) > 4:
+            for k in [k for k, sets in self._msg_buf.items() if not any(id(b) in self._busy for b in sets)]:
+                del self._msg_buf[k]
+        pool = self._msg_buf.setdefault(key, [])
+        # an exchange owns its buffer set — the four messages and the pinned heads — from here until _fast_end has read it: a
+        # prefetched exchange (start_halo) that is still waiting to be picked up keeps its set, and any other exchange with
+        # the same (halo, columns) in between takes another one
+        bufs = next((b for b in pool if id(b) not in self._busy), None)
         if bufs is None:
-            if len(self._msg_buf) > 4:
-                self._msg_buf.clear()
             bufs = tuple(t.empty(1 + width * cap, dtype=t.float64, device=dev) for _ in range(4)) + (t.empty(4, dtype=t.float64).pin_memory(),)
-            self._msg_buf[key] = bufs
+            pool.append(bufs)
+        self._busy.add(id(bufs))
         send_r, send_l, recv_l, recv_r, heads = bufs
         o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
         hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
@@ -284,9 +303,11 @@ class SlabDecomposition:
             t.cuda.current_stream().wait_event(st["done"])
         send_r, send_l, recv_l, recv_r, heads_pinned = st["bufs"]
         heads = heads_pinned.tolist()
+        self._busy.discard(id(st["bufs"]))  # (what reads the receive buffers below is enqueued before any later exchange refills them)
         cap, dev, n_owned, cols, gid = st["cap"], st["dev"], st["n_owned"], st["cols"], st["gid"]
         if max(heads) > cap:
-            self._msg_cap.pop(st["sig"], None)
+            # only the two ranks of the overflowing link see this: the agreed size is NOT dropped here (a subset of ranks
+            # re-agreeing would enter an all-reduce the others never join); the job stops, or every rank resets together
             raise RuntimeError(f"halo message of {int(max(heads))} atoms does not fit the agreed {cap}: the system changed since the "
                                "size was agreed — call reset_halo_capacity() on all ranks and repeat the step")
         nl, nr = int(heads[2]), int(heads[3])
@@ -429,7 +450,7 @@ def partition_atoms(pos: np.ndarray, box: Box, world: int, axis: int = 0):
     return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
 
 
-def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh: int, next_frame=None):
+def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh: int, next_frame=None, strict: bool = False):
     """One pass of the distributed hot path: halo exchange -> neighbor build -> fixed-cutoff CNA.
 
     Returns (dom, verlet, dist, nn, pattern): neighbor arrays / labels for ALL local atoms in `dom`
@@ -438,6 +459,8 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
 
     next_frame = (x, y, z, gid) of the frame the NEXT call will be given: its halo exchange is started on a side stream
     before this frame's kernels are enqueued and travels while they run (SlabDecomposition.start_halo).
+    strict: wait for the build and raise if an atom lay outside the slab + halo window the build was promised (atoms that
+    drifted across a face without re-partitioning); without it the build is still memory-safe and the NEXT build raises.
     """
     t = _torch()
     dom = dec.exchange_halo(x, y, z, gid, rc, sort=False)
@@ -448,7 +471,7 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
             import sys
 
             dec._no_prefetch = True
-            dec._pending.clear()
+            dec._drop_pending()
             print(f"mdapy_amd.distributed: halo prefetch switched off on rank {dec.rank} ({type(e).__name__}: {e})", file=sys.stderr)
     n = int(dom.x.shape[0])
     b = dec.box
@@ -459,6 +482,8 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     dec.hint_window(rc, dom.x)
     kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
                              key=dom.gid if dec.world > 1 else None)
+    if strict and dom.x.is_cuda and hasattr(kernels.neighbor, "cell_window_check"):
+        kernels.neighbor.cell_window_check()
     kernels.cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
     return dom, verlet, dist, nn, pattern
 

@@ -111,12 +111,25 @@ def _run_rank(rank, world, torch, dist_ready=True):
     for it in range(3):
         check_step(f"prefetched halo {it}: ", *D.neighbor_cna_step(dec, *own_args, rc, M, next_frame=own_args))
         check("an exchange is under way after the step", world < 2 or len(dec._pending) == 1)
-    dec._pending.clear()
-    # ---- Steinhardt over the cutoff list, plain and neighbour-averaged (halo 2 rc)
+    dec._drop_pending()
+    # ---- a prefetched exchange keeps its own message buffers: frame B's halo is started, then ANOTHER exchange
+    # with the same (halo, columns) runs for frame A on the main stream, then B's is picked up — and must hold B's ghosts
+    yB = pos[:, 1] + 0.25
+    frame_b = (own_args[0].clone(), t(yB[owned_ids]), own_args[2].clone(), own_args[3].clone())
+    D.neighbor_cna_step(dec, *own_args, rc, M, next_frame=frame_b)
+    check("frame B's exchange is under way", world < 2 or len(dec._pending) == 1)
+    # ---- Steinhardt over the cutoff list, plain and neighbour-averaged (halo 2 rc); the first one exchanges frame A again
+    own_a2 = tuple(a.clone() for a in own_args)  # (other tensors: not the pending key)
     for average in (False, True):
-        dq, qloc = D.steinhardt_step(dec, *own_args, ll, rc, M, average=average, wl=True)
+        dq, qloc = D.steinhardt_step(dec, *own_a2, ll, rc, M, average=average, wl=True)
         oq = dq.owned.cpu().numpy()
         check(f"steinhardt average={average}", np.array_equal(qloc.cpu().numpy()[oq], ref[f"q{int(average)}"][dq.gid.cpu().numpy()[oq]]))
+    check("frame B's exchange is still waiting", world < 2 or len(dec._pending) == 1)
+    dom_b = dec.exchange_halo(*frame_b, rc, sort=False)
+    gb, ob = dom_b.gid.cpu().numpy(), dom_b.owned.cpu().numpy()
+    check("frame B's ghosts are frame B's", np.array_equal(dom_b.y.cpu().numpy(), yB[gb]) and np.array_equal(dom_b.x.cpu().numpy(), pos[gb, 0])
+          and (world < 2 or (~ob).sum() > 0))
+    check("no exchange is left over", len(dec._pending) == 0 and len(dec._busy) == 0)
     # ---- verified-halo kNN analyses; the types of the ghosts travel with the halo
     dk, res = D.knn_analysis_step(dec, *own_args, what=("acna", "csp", "ptm"), types=t(types[owned_ids]))
     ok_, gk = dk.owned.cpu().numpy(), dk.gid.cpu().numpy()

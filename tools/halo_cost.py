@@ -89,7 +89,7 @@ def prof(fn):
 ms_halo, dom = timed(lambda: dec.exchange_halo(x, y, z, gid, RC))
 ms_step, out = timed(lambda: D.neighbor_cna_step(dec, x, y, z, gid, RC, 16))
 ms_pipe, out = timed(lambda: D.neighbor_cna_step(dec, x, y, z, gid, RC, 16, next_frame=(x, y, z, gid)), reps=20)
-dec._pending.clear(); torch.cuda.synchronize()
+dec._drop_pending(); torch.cuda.synchronize()
 dom_p, v_p, d_p, nn_p, pat_p = out
 ok_pipe = bool((nn_p[dom_p.owned] == 12).all()) and bool((pat_p[dom_p.owned] == 1).all()) and int(dom_p.x.shape[0]) > n
 dom2, v, d, nn, pat = out
