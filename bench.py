@@ -59,25 +59,26 @@ def parse():
     return p.parse_args()
 
 
-def slab_positions(torch, dev, cells, rank, sigma):
-    """FCC Cu slab of rank `rank`: cells ix in [cells*rank, cells*(rank+1)), cell-major order, basis innermost —
-    same expression as build_crystal / repeat_cell (basis@cell + (ix*a1 + iy*a2 + iz*a3))."""
+def slab_positions(torch, dev, cells, rank, sigma, cells_x=None):
+    """FCC Cu slab of rank `rank`: cells ix in [cx*rank, cx*(rank+1)) x cells x cells (cx = cells unless cells_x is given: the
+    slab of a box split along x), cell-major order, basis innermost — same expression as build_crystal / repeat_cell
+    (basis@cell + (ix*a1 + iy*a2 + iz*a3))."""
     a = A_CU
+    cx = cells if cells_x is None else cells_x
     basis = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]], dtype=torch.float64, device=dev) * a
-    ix = torch.arange(cells * rank, cells * (rank + 1), dtype=torch.float64, device=dev) * a
+    ix = torch.arange(cx * rank, cx * (rank + 1), dtype=torch.float64, device=dev) * a
     iy = torch.arange(cells, dtype=torch.float64, device=dev) * a
     out = []
-    for k, (sx, sy, sz) in enumerate(((ix, None, None), (None, iy, None), (None, None, iy))):
-        s = sx if sx is not None else (sy if sy is not None else sz)
+    for k, s in enumerate((ix, iy, iy)):
         shape = [1, 1, 1, 1]
-        shape[k] = cells
+        shape[k] = cx if k == 0 else cells
         comp = basis[:, k].view(1, 1, 1, 4) + s.view(shape)
-        out.append(comp.expand(cells, cells, cells, 4).reshape(-1).contiguous())
+        out.append(comp.expand(cx, cells, cells, 4).reshape(-1).contiguous())
     if sigma > 0:
         g = torch.Generator(device=dev)
         g.manual_seed(1234 + rank)
         out = [c + torch.randn(c.shape, generator=g, dtype=torch.float64, device=dev) * sigma for c in out]
-    n = cells ** 3 * 4
+    n = cx * cells * cells * 4
     gid = torch.arange(n * rank, n * (rank + 1), dtype=torch.int64, device=dev)
     return out[0], out[1], out[2], gid
 
