@@ -4,8 +4,9 @@
 A "step" is one pass of the hot path over the whole (synthetic) system, positions already resident in HBM: cell-list
 neighbor build (rc = 0.854 a, max_neigh = 16: the `System.cal_common_neighbor_analysis(rc)` configuration the reference's
 own CNA tests and SURVEY.md 6 use) followed by fixed-cutoff CNA, all through the C ABI of libmdapy_amd.so with device
-pointers.  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling) and exchanges a
-one-cutoff ghost halo with its two ring neighbours over RCCL each step.
+pointers.  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling, the default) — or,
+with --scaling strong, a 136/N-cell slab of the one 136^3 box — and exchanges a one-cutoff ghost halo with its two ring
+neighbours over RCCL each step.
 
 Prints ONE JSON line (rank 0):
 * `roofline` is for the dominant kernel of the step (the neighbor kernel, `k_neighbor` = everything between the cell grid
@@ -13,10 +14,14 @@ Prints ONE JSON line (rank 0):
   HBM byte count of that kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) taken by THIS run when rocprofv3 is
   on PATH (`traffic_source: "live"`), else the committed measurement under profiles/ (`"committed"`); FETCH_SIZE is
   doubled as MI355X_MICROARCH.md prescribes for gfx950 (the raw sum is reported beside it).
-* `extra` times, on the same box, the two other ways the step is reached through the API: `max_neigh=None` (exact-width
-  rows: counting pass + build on one cell grid, mdh_build_neighbor_exact) and a thermally rattled lattice (sigma = 0.05 A).
+* `extra` times, on the same box, other ways the step is reached and other inputs: `max_neigh=None` (exact-width rows:
+  counting pass + build on one cell grid, mdh_build_neighbor_exact); thermally rattled lattices (sigma = 0.05 and 0.20 A) and a
+  polycrystal of the headline's size (BASELINE config 3's construction), each with the fraction of atoms the CNA finished in
+  double precision (`todo_fraction`) and the tiles that went to the neighbour kernel's slice pass; `strong_1of8`: the slab of
+  rank 1 of 8 of the SAME box with the exchange in loop-back on this one GPU (the wire is not measured).
 * `cpu_baseline` is the CPU oracle (a parity-checked port of the reference's OpenMP C++, oracle/mdapy_oracle.c) timed on
-  this box's host cores on a 1 M-atom sample, best thread count of a sweep.
+  this box's host cores on the headline's own input; a sweep on a 1 M-atom lattice picks the thread count.
+* `--scaling strong` (N > 1): the ONE --cells^3 box cut into N slabs along x instead of one --cells^3 slab per rank.
 """
 import argparse
 import ctypes
@@ -53,7 +58,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the max_neigh=None / rattled-lattice timings")
     p.add_argument("--no-pmc", action="store_true", help="do not take the live rocprofv3 PMC passes for roofline.traffic")
-    p.add_argument("--cpu-cells", type=int, default=63, help="cells per axis of the CPU-baseline sample (63 -> 1 000 188 atoms)")
+    p.add_argument("--cpu-cells", type=int, default=63, help="cells per axis of the CPU-baseline thread sweep (63 -> 1 000 188 atoms)")
+    p.add_argument("--cpu-full-cells", type=int, default=0, help="cells per axis of the CPU-baseline run proper (0: --cells, the headline input)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="N > 1: weak = a --cells^3 slab per rank (default); strong = the ONE --cells^3 box cut into N slabs along x")
     p.add_argument("--pmc-child", choices=["fetch", "write"], help=argparse.SUPPRESS)
     p.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)
     return p.parse_args()
@@ -85,19 +93,26 @@ def slab_positions(torch, dev, cells, rank, sigma, cells_x=None):
 
 def cpu_baseline_child(args):
     """the timed sample itself (a process of its own: OpenMP reads its binding when the runtime starts, and the parent has
-    long started one with torch)"""
+    long started one with torch): a thread sweep on a 1 M-atom lattice picks the thread count, the figure is then measured on
+    the HEADLINE input (--cpu-full-cells, 10 061 824 atoms) at that count and its two neighbours"""
     from mdapy_amd.build_lattice import lattice_positions
     from oracle import oracle as O
 
-    n = args.cpu_cells
-    pos, box = lattice_positions("fcc", A_CU, n, n, n)
-    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
-    N, M = len(x), args.max_neigh
+    M = args.max_neigh
     org, bnd = np.zeros(3), np.array([1, 1, 1], np.int32)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
-    def one(threads):
-        v = np.full((N, M), -1, np.int32); d = np.full((N, M), RC + 1.0); nn = np.zeros(N, np.int32); pat = np.zeros(N, np.int32)
+    def setup(n):
+        pos, box = lattice_positions("fcc", A_CU, n, n, n)
+        x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+        N = len(x)
+        del pos
+        bufs = (np.full((N, M), -1, np.int32), np.full((N, M), RC + 1.0), np.zeros(N, np.int32), np.zeros(N, np.int32))
+        return x, y, z, box, N, bufs
+
+    def one(inp, threads):
+        x, y, z, box, N, (v, d, nn, pat) = inp
+        v[...] = -1; d[...] = RC + 1.0; nn[...] = 0; pat[...] = 0  # what the reference's Python does before the call (neighbor.py:125-129)
         t0 = time.perf_counter()
         O.build_neighbor(x, y, z, box, org, bnd, RC, v, d, nn, threads)
         O.fcna(x, y, z, box, org, bnd, v, nn, pat, RC, threads)
@@ -105,37 +120,73 @@ def cpu_baseline_child(args):
         assert int((pat == 1).sum()) == N
         return dt
 
-    one(min(cores, 16))  # first touch of the pages
-    sweep = {}
     t_all = time.perf_counter()
-    for threads in sorted({t for t in (8, 16, 32, 64, 128, 256, cores) if t <= cores}):
-        sweep[threads] = min(one(threads) for _ in range(5))
-        if time.perf_counter() - t_all > 25.0:
+    small = setup(args.cpu_cells)
+    one(small, min(cores, 16))  # first touch of the pages
+    grid = sorted({t for t in (8, 16, 32, 64, 128, 256, cores) if t <= cores})
+    sweep = {}
+    for threads in grid:
+        sweep[threads] = min(one(small, threads) for _ in range(3))
+        if time.perf_counter() - t_all > 10.0:
             break
-    print(json.dumps({"N": N, "cores": cores, "sweep": {str(k): v for k, v in sweep.items()}}))
+    best_small = min(sweep, key=sweep.get)
+    n_small = small[4]
+    del small
+    full_cells = args.cpu_full_cells or args.cells
+    out = {"N_sweep": n_small, "cores": cores, "sweep": {str(k): v for k, v in sweep.items()}}
+    if full_cells != args.cpu_cells:
+        big = setup(full_cells)
+        k = grid.index(best_small)
+        cand = [grid[j] for j in (k, k - 1, k + 1) if 0 <= j < len(grid)]
+        full = {}
+        for threads in cand:
+            runs = []
+            for _ in range(3):
+                runs.append(one(big, threads))
+                if time.perf_counter() - t_all > 28.0 and len(runs) >= 1:
+                    break
+            full[threads] = min(runs)
+            if time.perf_counter() - t_all > 28.0:
+                break
+        out.update(N=big[4], full={str(k): v for k, v in full.items()})
+    else:
+        out.update(N=n_small, full={str(best_small): sweep[best_small]})
+    nodes = 0
+    try:
+        nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        pass
+    out["numa_nodes"] = nodes
+    print(json.dumps(out))
 
 
 def cpu_baseline(args):
-    """the OpenMP port of the oracle on the host cores: threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores), best of 5 per
-    thread count, so that two boxes of the pool agree"""
+    """the OpenMP port of the oracle on the host cores: threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores), the thread
+    count picked by a sweep on a 1 M-atom lattice, the figure taken on the headline's own input (best of <= 3 runs)"""
     import subprocess
 
     env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "--cpu-cells", str(args.cpu_cells), "--max-neigh", str(args.max_neigh)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "--cpu-cells", str(args.cpu_cells), "--max-neigh", str(args.max_neigh),
+           "--cells", str(args.cells), "--cpu-full-cells", str(args.cpu_full_cells)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     if out.returncode != 0:
         raise RuntimeError("cpu baseline child failed: " + out.stderr[-2000:])
     got = json.loads(out.stdout.strip().splitlines()[-1])
-    N, cores, n, M = got["N"], got["cores"], args.cpu_cells, args.max_neigh
+    N, cores, M = got["N"], got["cores"], args.max_neigh
+    full = {int(k): v for k, v in got["full"].items()}
     sweep = {int(k): v for k, v in got["sweep"].items()}
-    best_threads = min(sweep, key=sweep.get)
-    best = sweep[best_threads]
+    best_threads = min(full, key=full.get)
+    best = full[best_threads]
     return {"value": N / best, "unit": "atoms/s", "cores": best_threads, "kind": "port",
-            "sample": f"{N}-atom FCC Cu ({n}^3 cells), neighbor(rc={RC:.5f}, max_neigh={M}) + fixed CNA, OpenMP oracle port, threads pinned "
-                      f"(OMP_PROC_BIND=close, OMP_PLACES=cores), best of 5 at the best thread count of the sweep {sorted(sweep)} on {cores} "
-                      f"host cores; on the build container's 8 cores the port runs {PORT_OVER_REFERENCE:.2f}x as fast as the reference's own "
-                      f"C++ on this input (0.315 s vs 0.40 s)",
-            "threads_sweep_atoms_per_s": {str(k): N / v for k, v in sweep.items()}}
+            "sample": f"{N}-atom FCC Cu (the headline input), neighbor(rc={RC:.5f}, max_neigh={M}) + fixed CNA, OpenMP oracle port "
+                      f"(oracle/mdapy_oracle.c), best of <= 3 runs at {sorted(full)} threads (picked by a sweep {sorted(sweep)} on "
+                      f"{got['N_sweep']} atoms), {cores} host cores, {got.get('numa_nodes', 0)} NUMA node(s)",
+            "placement": "OMP_PROC_BIND=close OMP_PLACES=cores OMP_DYNAMIC=false, a process of its own",
+            "reference_estimate": {"value": N / best / PORT_OVER_REFERENCE, "unit": "atoms/s",
+                                   "how": f"port / {PORT_OVER_REFERENCE:.2f}: on the build container's 8 cores the port runs 0.315 s where the "
+                                          "reference's own C++ runs 0.40 s (1 000 188 atoms, BASELINE.md 2)"},
+            "threads_full_atoms_per_s": {str(k): N / v for k, v in full.items()},
+            "threads_sweep_atoms_per_s": {str(k): got["N_sweep"] / v for k, v in sweep.items()}}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -227,13 +278,20 @@ def main():
     L = _lib.lib()
     _lib.check(L.mdh_set_device(local_rank))
     cells, M = args.cells, args.max_neigh
-    x, y, z, gid = slab_positions(torch, dev, cells, rank, args.sigma)
+    strong = args.scaling == "strong" and world > 1
+    if strong:  # the ONE cells^3 box (BASELINE.json's 10 M atoms) cut into `world` slabs along x
+        if cells % world != 0:
+            raise SystemExit(f"--scaling strong: {cells} cells do not split into {world} equal slabs")
+        x, y, z, gid = slab_positions(torch, dev, cells, rank, args.sigma, cells_x=cells // world)
+        box = mp.Box(np.diag([A_CU * cells] * 3))
+    else:
+        x, y, z, gid = slab_positions(torch, dev, cells, rank, args.sigma)
+        box = mp.Box(np.diag([A_CU * cells * world, A_CU * cells, A_CU * cells]))
     n_local = int(x.shape[0])
-    box = mp.Box(np.diag([A_CU * cells * world, A_CU * cells, A_CU * cells]))
     dec = SlabDecomposition(box, rank, world, axis=0)
     bx = (box.box, box.origin, box.boundary)
     if world > 1:  # room behind the owned atoms: the ghosts of every step are appended there, no concatenation of the slab's arrays
-        x, y, z, gid = (dec.with_room(a, 0.05) for a in (x, y, z, gid))
+        x, y, z, gid = (dec.with_room(a, 0.25 if strong else 0.05) for a in (x, y, z, gid))
 
     def sync():
         torch.cuda.synchronize()
@@ -312,8 +370,10 @@ def main():
             "value": n_total / (elapsed / args.steps),
             "unit": "atoms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"FCC Cu a={A_CU}, {cells}^3 cells per GPU ({n_local} atoms/GPU, {n_total} total), "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f64 (CNA pair tests: f32 filter + f64 finish, labels exact)", "data": "synthetic",
+            "config": {"workload": (f"FCC Cu a={A_CU}, ONE {cells}^3-cell box cut into {world} slabs along x ({n_local} atoms/GPU, {n_total} total), "
+                                    if strong else f"FCC Cu a={A_CU}, {cells}^3 cells per GPU ({n_local} atoms/GPU, {n_total} total), ") +
                                    f"build_neighbor(rc=0.854a={RC:.5f}, max_neigh={M}) + fixed-cutoff CNA, positions resident in HBM",
                        "atoms_per_gpu": n_local, "rc": RC, "max_neigh": M, "sigma": args.sigma,
                        "parallelism": f"slab{world}" if world > 1 else "single", "world_size_checked": world},
@@ -356,19 +416,75 @@ def main():
             extra["max_neigh_none"] = {"ms_per_step": e2 / max(3, args.steps // 4) * 1e3, "row_width": int(o2[2].shape[1]),
                                        "kernels_ms": {k: v[1] / v[0] for k, v in p2.items()}}
             del o2
-            # (b) a thermally rattled lattice (sigma = 0.05 A), same box, max_neigh = 16
-            xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, 0.05)
+            # (b) steps on inputs that are not the kernels' best case: thermally rattled lattices and a polycrystal — the CNA's
+            # double-precision to-do list and the neighbour kernel's slice pass are not empty there (counts reported)
             v3 = torch.empty((n_local, M), dtype=torch.int32, device=dev); d3 = torch.empty((n_local, M), dtype=torch.float64, device=dev)
+            cnt4 = (ctypes.c_int64 * 4)()
 
-            def step_rattled():
-                pattern.zero_()
-                _neighbor.build_neighbor(xs, ys, zs, *bx, RC, v3, d3, nn, 1, fill_pads=True)
-                _cna.fcna(xs, ys, zs, *bx, v3, nn, pattern, RC, 1)
-                return nn, pattern, None
+            def other_input(xs, ys, zs, bxs, n_at):
+                nn_, pat_ = nn[:n_at], pattern[:n_at]
+                v_, d_ = v3[:n_at], d3[:n_at]
 
-            e3, o3, p3 = timed(step_rattled, max(3, args.steps // 4), 2)
-            extra["sigma_0.05"] = {"ms_per_step": e3 / max(3, args.steps // 4) * 1e3, "fcc_fraction": float((o3[1] == 1).float().mean().item()),
-                                   "kernels_ms": {k: v[1] / v[0] for k, v in p3.items()}}
+                def step_other():
+                    pat_.zero_()
+                    _neighbor.build_neighbor(xs, ys, zs, *bxs, RC, v_, d_, nn_, 1, fill_pads=True)
+                    _cna.fcna(xs, ys, zs, *bxs, v_, nn_, pat_, RC, 1)
+                    return nn_, pat_, None
+
+                k = max(3, args.steps // 4)
+                e_, o_, p_ = timed(step_other, k, 2)
+                L.mdh_debug_track_counters(1)
+                step_other(); step_other(); torch.cuda.synchronize()
+                L.mdh_debug_counters(cnt4)
+                L.mdh_debug_track_counters(0)
+                lab = torch.bincount(o_[1], minlength=5).tolist()
+                return {"atoms": n_at, "ms_per_step": e_ / k * 1e3, "atoms_per_s": n_at / (e_ / k), "fcc_fraction": lab[1] / n_at,
+                        "labels_other_fcc_hcp_bcc_ico": lab[:5], "max_neighbors": int(o_[0].max().item()),
+                        "todo_fraction": max(int(cnt4[0]), 0) / n_at, "cna_todo_atoms": int(cnt4[0]), "tiles_to_slice_pass": int(cnt4[1]),
+                        "kernels_ms": {k_: v_[1] / v_[0] for k_, v_ in p_.items()}}
+
+            for sg in (0.05, 0.20):
+                xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, sg)
+                extra[f"sigma_{sg:.2f}"] = other_input(xs, ys, zs, bx, n_local)
+                del xs, ys, zs
+            try:  # (c) a polycrystal of the headline's size: BASELINE config 3's construction (Voronoi grains, 2.0 A overlap filter) in the same box
+                rng = np.random.default_rng(2024)
+                grains = max(4, int(round((A_CU * cells) ** 3 / 2.3e6)))
+                unit = mp.build_crystal("Cu", "fcc", A_CU)
+                poly = mp.CreatePolycrystal(unit, box=A_CU * cells, seed_number=grains, seed_position=rng.random((grains, 3)) * A_CU * cells,
+                                            theta_list=rng.uniform(-180, 180, (grains, 3)), metal_overlap_dis=2.0).compute(verbose=False)
+                n_poly = min(int(poly.N), n_local)
+                cols = [torch.from_numpy(np.ascontiguousarray(poly.data[c].to_numpy()[:n_poly])).to(dev) for c in "xyz"]
+                pb = (poly.box.box, poly.box.origin, poly.box.boundary)
+                if n_poly < int(poly.N):  # (the buffers are the headline's: a box that came out fuller is cut to its first atoms, open along x)
+                    pb = (poly.box.box, poly.box.origin, np.array([0, 1, 1], np.int32))
+                extra["polycrystal"] = dict(other_input(*cols, pb, n_poly), grains=grains, atoms_built=int(poly.N))
+                del cols, poly
+            except Exception as e:  # an extra, not the headline
+                extra["polycrystal"] = {"error": f"{type(e).__name__}: {e}"}
+            # (d) strong scaling, one rank's share: the slab of rank 1 of 8 of the SAME box, exchange in loop-back on this GPU
+            # (tools/_loopback.py: the product's exchange code with the wire replaced by a device copy; never ran on RCCL)
+            try:
+                from tools import _loopback
+
+                w8 = 8
+                cx = cells // w8
+                if cells % w8 == 0 and cx >= 2:
+                    sx, sy, sz, sg_ = slab_positions(torch, dev, cells, 1, 0.0, cells_x=cx)
+                    n_slab = int(sx.shape[0])
+                    dec8 = SlabDecomposition(mp.Box(np.diag([A_CU * cells] * 3)), 1, w8, axis=0)
+                    _loopback.install(dec8, A_CU * cx, n_slab)
+                    sx, sy, sz, sg_ = (dec8.with_room(a, 0.25) for a in (sx, sy, sz, sg_))
+                    k = max(10, args.steps)
+                    e_a, o_a, _ = timed(lambda: neighbor_cna_step(dec8, sx, sy, sz, sg_, RC, M)[3:] + (None,), k, 3, ranges=0)
+                    e_b, o_b, _ = timed(lambda: neighbor_cna_step(dec8, sx, sy, sz, sg_, RC, M, next_frame=(sx, sy, sz, sg_))[3:] + (None,), k, 3, ranges=0)
+                    dec8._drop_pending(); torch.cuda.synchronize()
+                    extra["strong_1of8"] = {"slab_atoms": n_slab, "slab_cells": f"{cx}x{cells}x{cells}", "ms_per_step": e_a / k * 1e3,
+                                            "ms_per_step_next_halo_prefetched": e_b / k * 1e3, "undivided_ms_over_8": ms_per_step / 8.0,
+                                            "ratio": (e_a / k * 1e3) / (ms_per_step / 8.0), "ratio_prefetched": (e_b / k * 1e3) / (ms_per_step / 8.0),
+                                            "transport": "loop-back on one GPU (device copy instead of RCCL): the wire is NOT measured"}
+            except Exception as e:
+                extra["strong_1of8"] = {"error": f"{type(e).__name__}: {e}"}
             res["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args)

@@ -75,6 +75,13 @@ int mdh_debug_neighbor_plan(int *plan8);
  * box allows (default; atoms inside the band are finished with the reference's double-precision expression), 1 = the
  * double-precision kernel everywhere.  Labels are identical. */
 int mdh_debug_set_fcna_variant(int variant);
+/* measurement hook (bench.py `extra.*.todo_fraction`): mdh_debug_track_counters(1) makes every mdh_fcna copy the length of its
+ * to-do list (atoms with a pair inside the single-precision decision band, finished in double precision) into pinned memory
+ * (one 4-byte copy per call, off by default); mdh_debug_counters(out4) — after the caller synchronised the stream — returns
+ * {to-do atoms of the last tracked mdh_fcna or -1, tiles the previous neighbor build with the last plan's (N, grid) listed for
+ * the one-cell-slice pass or -1, 0, 0}. */
+int mdh_debug_track_counters(int on);
+int mdh_debug_counters(int64_t *out4);
 /* test hook: 0 = LDS-tile kernel for the streaming RDF where it applies (default), 1 = thread-per-atom kernel everywhere */
 int mdh_debug_set_rdf_variant(int variant);
 /* k nearest neighbours: 0 = the near kernel (sorted list in registers, 27 cells) followed by the general kernel on the queries it

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "mdh_debug_set_neighbor_variant": [cint],
     "mdh_debug_neighbor_plan": [vp],
     "mdh_debug_set_fcna_variant": [cint],
+    "mdh_debug_track_counters": [cint],
+    "mdh_debug_counters": [vp],
     "mdh_debug_set_rdf_variant": [cint],
     "mdh_debug_set_knn_variant": [cint],
     "mdh_debug_set_sq_variant": [cint],

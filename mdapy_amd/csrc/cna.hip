@@ -608,6 +608,28 @@ int mdh_debug_set_fcna_variant(int v)
     return MDH_OK;
 }
 
+namespace mdh { int lane_last_listed(); } // neighbor_lane.hip
+static int g_track_counters = 0;
+static int *g_todo_probe = nullptr; // pinned: the to-do length of the last tracked mdh_fcna
+
+int mdh_debug_track_counters(int on)
+{
+    if (on && !g_todo_probe) {
+        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_todo_probe), sizeof(int), hipHostMallocDefault));
+        *g_todo_probe = -1;
+    }
+    g_track_counters = on;
+    return MDH_OK;
+}
+
+int mdh_debug_counters(int64_t *out4)
+{
+    out4[0] = g_todo_probe ? (int64_t)*(volatile int *)g_todo_probe : -1;
+    out4[1] = (int64_t)mdh::lane_last_listed();
+    out4[2] = out4[3] = 0;
+    return MDH_OK;
+}
+
 int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
              const double *origin3, const int *boundary3, const int *verlet, int64_t M, const int *nn, int *pattern,
              double rc, int space, void *stream)
@@ -631,6 +653,8 @@ int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const
         ProfRange pr("k_fcna", st);
         launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
     }
+    if (g_track_counters && g_todo_probe)
+        MDH_HIP(hipMemcpyAsync(g_todo_probe, todo, sizeof(int), hipMemcpyDeviceToHost, st));
     return sc.finish(space);
 }
 

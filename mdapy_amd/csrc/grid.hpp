@@ -94,6 +94,7 @@ struct LanePlan {
 };
 int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out);
 LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const GridStats &gs, double rc, bool fcna, bool count);
+int lane_last_listed(); // tiles listed for the slice pass as last seen when a plan was made (mdh_debug_counters)
 // pattern != nullptr: the fixed-cutoff CNA label (cna.cpp:429-506, same rc) of every centre the kernel takes is written too
 int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,

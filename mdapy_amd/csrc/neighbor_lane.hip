@@ -100,6 +100,7 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef int Int4 __attribute__((ext_vector_type(4))); // 16 bytes of a row (nontemporal vector stores take clang vector types)
 
 static int g_last_plan[8]; // test hook (mdh_debug_neighbor_plan)
+static int g_last_listed = -1; // tiles the previous build with the last plan's (N, grid) listed for the slice pass (mdh_debug_counters)
 #ifdef MDH_STAMPS
 __device__ unsigned long long g_stamps[65536 * 8];
 #define STAMP(k) do { if (tid == 0 && !parent && tile.id < 65536) g_stamps[tile.id * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1254,6 +1255,7 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.occupied = occ;
     p.last_listed = gs.last_listed;
     p.listed_sink = gs.listed_sink;
+    g_last_listed = gs.listed_sink ? *(volatile int *)gs.listed_sink : gs.last_listed; // (the freshest value the device has delivered)
     p.full = occ >= g.ncell;
     g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw);
     g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
@@ -1368,6 +1370,7 @@ extern "C" int mdh_debug_lane_stamps(unsigned long long *out, int n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(mdh::lane::g_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 1;
 }
 #endif
+namespace mdh { int lane_last_listed() { return lane::g_last_listed; } }
 extern "C" int mdh_debug_neighbor_plan(int *plan8)
 {
     for (int k = 0; k < 8; ++k) plan8[k] = mdh::lane::g_last_plan[k];
