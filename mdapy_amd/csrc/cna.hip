@@ -72,7 +72,8 @@ template <bool TRI, bool GENERIC>
 __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, const double *__restrict__ y,
                                               const double *__restrict__ z, int64_t N, DBox b,
                                               const int *__restrict__ verlet, int64_t M, const int *__restrict__ nn,
-                                              int *__restrict__ pattern, double rc, int *__restrict__ todo)
+                                              int *__restrict__ pattern, double rc, int *__restrict__ todo,
+                                              int *__restrict__ done = nullptr)
 {
     __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread (read back by the thread that wrote them)
     const double cut2 = rc * rc; // cna.cpp:449
@@ -90,6 +91,15 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
     if (GENERIC) { // the to-do list of the single-precision kernel: its length is on the device, the grid is a fixed small one
         const int64_t total = todo[0];
         for (int64_t q = first; q < total; q += (int64_t)gridDim.x * blockDim.x) one(todo[1 + q]);
+        // done != nullptr: the list lives in a kept block (Scope::KEEP_TODO) whose counters are zero whenever it is idle — the
+        // workgroup that leaves last (every workgroup has read the length by then) clears them: no memset in front of the next call
+        if (done) {
+            __syncthreads();
+            if (threadIdx.x == 0 && atomicAdd(done, 1) == (int)gridDim.x - 1) {
+                todo[0] = 0;
+                *done = 0;
+            }
+        }
     } else if (first < N) {
         one(first);
     }
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(256) void k_fill_int(int *__restrict__ p, int64_t n
 }
 
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
-                     int64_t M, const int *nn, int *pattern, double rc, int *todo)
+                     int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done)
 {
     dim3 grid(grid_for(N, 256)), block(256);
     if (b.tri) {
@@ -580,7 +590,7 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
         }
         // the to-do list (length on the device, usually zero) walked by a grid that fills the chip once: an empty one costs 5 us
         // instead of the 17 us that N / 256 workgroups take to leave
-        hipLaunchKernelGGL((k_fcna<false, true>), dim3(std::min<unsigned>(grid.x, 2048u)), block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        hipLaunchKernelGGL((k_fcna<false, true>), dim3(std::min<unsigned>(grid.x, 2048u)), block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
     }
 }
 
@@ -598,6 +608,7 @@ void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const do
 
 } // namespace mdh
 
+namespace mdh { int lane_last_listed(); } // neighbor_lane.hip
 using namespace mdh;
 
 extern "C" {
@@ -608,7 +619,6 @@ int mdh_debug_set_fcna_variant(int v)
     return MDH_OK;
 }
 
-namespace mdh { int lane_last_listed(); } // neighbor_lane.hip
 static int g_track_counters = 0;
 static int *g_todo_probe = nullptr; // pinned: the to-do length of the last tracked mdh_fcna
 
@@ -645,14 +655,24 @@ int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const
     const int *dv = sc.stage_in(verlet, (size_t)(N * M), space);
     const int *dn = sc.stage_in(nn, (size_t)N, space);
     int *dp = sc.stage(pattern, (size_t)N, space, true, true);
-    int *todo = sc.alloc_n<int>((size_t)N + 1);
+    // the to-do list (count first).  Orthogonal boxes: in a kept block whose two counters — workgroups done (word 0), length
+    // (word 64) — are zero whenever it is idle (the list's last reader clears them): no hipMemsetAsync per call.  Triclinic
+    // boxes (one kernel, nobody walks a list): plain scratch, cleared here.
+    int *todo, *done = nullptr;
+    if (!b.tri && !g_track_counters) { // (tracking the length for bench.py: the plain list, whose count survives the call)
+        done = static_cast<int *>(sc.alloc_kept(sizeof(int) * ((size_t)N + 1 + 64), Scope::KEEP_TODO));
+        todo = done ? done + 64 : nullptr;
+    } else {
+        todo = sc.alloc_n<int>((size_t)N + 1);
+    }
     if (sc.failed())
         return sc.error();
-    MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
+    if (!done) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
     {
         ProfRange pr("k_fcna", st);
-        launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
+        launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo, done);
     }
+    if (done) sc.keep_confirm(done);
     if (g_track_counters && g_todo_probe)
         MDH_HIP(hipMemcpyAsync(g_todo_probe, todo, sizeof(int), hipMemcpyDeviceToHost, st));
     return sc.finish(space);

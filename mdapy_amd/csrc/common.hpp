@@ -140,6 +140,18 @@ class Scope {
     // device scratch, 256-byte aligned; nullptr + error set on failure
     void *alloc(size_t bytes);
     template <class T> T *alloc_n(size_t n) { return static_cast<T *>(alloc((n ? n : 1) * sizeof(T))); }
+    // Kept blocks: device memory with an invariant that holds whenever the block is idle, so that a call needs no
+    // hipMemsetAsync (a ~7 us node of its own on the stream) to bring it into its starting state.  A kept block is only ever
+    // handed out for its own tag, zero-filled when it is created.
+    //   KEEP_ZERO : all zero when idle (the bin counters of a cell grid: the scan that reads them writes the zeros back)
+    //   KEEP_SCAN : control words of the single-pass scan (a ticket that its last block resets, generation-stamped status
+    //               words: a stale one is never mistaken for a fresh one)
+    //   KEEP_TODO : word 0 (blocks done) and word 64 (length of a to-do list) zero when idle (reset by the list's last reader)
+    // keep_confirm(p): the kernels that restore p's invariant have been enqueued; a KEEP_ZERO / KEEP_TODO block that leaves
+    // its Scope unconfirmed (an error path) is zero-filled on the stream before it returns to the cache.
+    enum Keep { KEEP_NONE = 0, KEEP_ZERO = 1, KEEP_SCAN = 2, KEEP_TODO = 3 };
+    void *alloc_kept(size_t bytes, Keep tag);
+    void keep_confirm(void *p);
 
     // Stage a caller array.  space==MDH_DEVICE: returns the pointer itself.
     // space==MDH_HOST: returns a device copy (uploaded when `in`), and remembers
@@ -167,10 +179,14 @@ class Scope {
     static const int kMaxHeld = 64;
     void *held_[kMaxHeld];
     size_t held_bytes_[kMaxHeld];
+    unsigned char held_keep_[kMaxHeld]; // Keep tag | 0x80 once confirmed
     int nheld_ = 0;
+    void *alloc_impl(size_t bytes, int tag);
     Out outs_[16];
     int nouts_ = 0;
 };
+
+void reset_kept_blocks(int tag); // runtime.hip
 
 // Positions as one 32-byte record per atom (x, y, z, unused): a neighbour's position is then two 16-byte requests instead of
 // three 8-byte ones — the list consumers that gather 12 - 18 neighbours per atom are bound by the number of lane requests their

@@ -101,8 +101,9 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
                          TileFilter &tf, int *pattern = nullptr);
 // cna.hip: fixed-cutoff CNA from finished lists on the caller's stream — of all atoms, or of the atoms listed in todo
 // (todo[0] = count, device side) with the reference expression
+// done != nullptr: todo sits in a kept block (Scope::KEEP_TODO) — the kernel that walks the list clears its counters when it leaves
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
-                     int64_t M, const int *nn, int *pattern, double rc, int *todo);
+                     int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done = nullptr);
 void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
                         int64_t M, const int *nn, int *pattern, double rc, int *todo);
 

@@ -20,6 +20,7 @@
 #include "grid.hpp"
 #include "cna_core.hpp"
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -30,12 +31,12 @@ int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kern
 // ----------------------------------------------------------------------------
 // cell assignment: wrap, bin, take a slot from the cell's atomic counter
 // ----------------------------------------------------------------------------
-struct CellPlanes { int p0, p1, p2, p3; int *bad; }; // planes [p0, p1) and [p2, p3) of axis 0 hold every atom (bad == nullptr: not promised)
+struct CellPlanes { int p0, p1, p2, p3; int *bad; }; // planes [p0, p1) and [p2, p3) of axis 0 hold every atom (bad == nullptr: not promised; else a pinned host word)
 template <bool TRI>
 __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
-                                                unsigned *__restrict__ cell_count, int *__restrict__ flags,
+                                                unsigned *__restrict__ cell_count, unsigned *__restrict__ ctl, unsigned gen,
                                                 double slack, unsigned char *__restrict__ mv, CellPlanes win)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,12 +97,14 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
         if (cell >= 0)
             rank[i] = (int)(base + (unsigned)(lane - first));
     }
+    // what this kernel finds out about the input goes into generation-stamped control words (no memset per build): the scan
+    // that follows turns them into the build's flags[0] (unwrapped input) and flags[4] (image codes present)
     if (__any(moved) && (threadIdx.x & 63) == 0)
-        flags[0] = 1;
+        ctl[1] = gen;
     if (__any(coded) && (threadIdx.x & 63) == 0)
-        flags[4] = 1; // some atom was handed in outside the box: the gather has to read the image codes (else they are all neutral)
+        ctl[2] = gen; // some atom was handed in outside the box: the gather has to read the image codes (else they are all neutral)
     if (__any(outside) && (threadIdx.x & 63) == 0)
-        atomicAdd(win.bad, 1);
+        *win.bad = 1; // (pinned host memory: read by the next build of the thread / mdh_cell_window_check)
 }
 
 // ----------------------------------------------------------------------------
@@ -139,76 +142,134 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *tot)
     return off + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(const unsigned *__restrict__ in, int *__restrict__ out,
-                                                           unsigned *__restrict__ block_sum, int64_t n)
+// ----------------------------------------------------------------------------
+// Single-pass exclusive scan (decoupled look-back: Merrill & Garland, "Single-pass parallel prefix scan with decoupled
+// look-back", NVIDIA NVR-2016-002) — ONE launch instead of three: at a few thousand atoms a build is a chain of dependent
+// launches of ~4 us each, whatever they do.  A block takes a ticket (so that every predecessor it waits for is already
+// running), scans its 1024 items, publishes its total, and wave 0 collects the totals / inclusive prefixes of the blocks
+// before it, 64 at a time.  Control words live in a kept block (Scope::KEEP_SCAN): ctl[0] the ticket counter (reset by
+// the block that takes the last ticket), ctl[1], ctl[2] the stamps of k_assign, status words from byte 256 on:
+// generation (30 bits) | state (2: 1 = block total, 2 = inclusive prefix) | value (32) — a word of an earlier launch
+// carries an older generation and reads as "not there yet", so nothing is cleared between launches.
+// REZERO: the input is a build's bin counters in a KEEP_ZERO block: every counter is cleared as it is read.
+// flags != nullptr: the first block also writes the build's eight device flags (grid.hpp) from the stamps.
+// ----------------------------------------------------------------------------
+static std::atomic<unsigned> g_scan_gen{0};
+static unsigned next_scan_gen()
 {
-    const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
-    unsigned v[SCAN_ITEMS], s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0u;
-        s += v[k];
+    unsigned g = (++g_scan_gen) & 0x3fffffffu;
+    if (g == 0) { // 2^30 launches: old status words could repeat a generation — start over from clean control blocks
+        reset_kept_blocks(Scope::KEEP_SCAN);
+        g = (++g_scan_gen) & 0x3fffffffu;
     }
+    return g;
+}
+
+template <bool REZERO>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_onepass(unsigned *__restrict__ in, int *__restrict__ out, int64_t n,
+                                                             unsigned *__restrict__ ctl, unsigned gen, int *__restrict__ flags)
+{
+    __shared__ unsigned s_blk, s_excl;
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl + 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_blk = atomicAdd(&ctl[0], 1u);
+    __syncthreads();
+    const unsigned blk = s_blk, nblk = gridDim.x;
+    if (tid == 0) {
+        if (blk == nblk - 1) ctl[0] = 0; // every ticket has been taken: ready for the next launch
+        if (blk == 0 && flags) {
+            flags[0] = ctl[1] == gen ? 1 : 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
+            flags[4] = ctl[2] == gen ? 1 : 0; flags[5] = 0; flags[6] = 0; flags[7] = 0;
+        }
+    }
+    const int64_t base = ((int64_t)blk * SCAN_BLOCK + tid) * SCAN_ITEMS;
+    unsigned v[SCAN_ITEMS], s = 0;
+    const bool vec = base + SCAN_ITEMS <= n && ((reinterpret_cast<uintptr_t>(in + base) | reinterpret_cast<uintptr_t>(out + base)) & 15u) == 0;
+    if (vec) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(in + base);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        if (REZERO) *reinterpret_cast<uint4 *>(in + base) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            v[k] = (base + k < n) ? in[base + k] : 0u;
+            if (REZERO && base + k < n) in[base + k] = 0u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += v[k];
     unsigned tot;
     unsigned ex = block_excl_scan(s, &tot);
+    const unsigned long long stamp = (unsigned long long)gen << 34;
+    if (tid == 0) // this block's total (block 0: its inclusive prefix) for the blocks behind it
+        __hip_atomic_store(&status[blk], stamp | ((unsigned long long)(blk == 0 ? 2u : 1u) << 32) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        unsigned excl = 0;
+        if (blk > 0) {
+            int64_t j = (int64_t)blk - 1; // nearest predecessor
+            for (;;) {
+                const int64_t idx = j - lane;
+                unsigned long long st;
+                for (;;) {
+                    st = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (stamp | (2ull << 32));
+                    const bool there = (st >> 34) == gen && ((st >> 32) & 3u) != 0;
+                    if (__all(there))
+                        break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                const unsigned long long pm = __ballot(((st >> 32) & 3u) == 2u);
+                const int first = pm ? __builtin_ctzll(pm) : 64; // nearest block that already knows its inclusive prefix
+                unsigned val = lane <= first ? (unsigned)(st & 0xffffffffull) : 0u;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[base + k] = (int)ex;
-        ex += v[k];
-    }
-    if (threadIdx.x == 0) block_sum[blockIdx.x] = tot;
-}
-
-// one block scans the per-block totals in place (exclusive)
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(unsigned *__restrict__ block_sum, int64_t nb)
-{
-    // a thread takes SUMS_PER consecutive totals per trip (one trip for up to 8192 blocks = 8.4 M cells; with one total per thread
-    // and trip the 4096 blocks of the headline grid were sixteen serial block scans: 10 us of every build)
-    constexpr int SUMS_PER = 32;
-    unsigned carry = 0;
-    for (int64_t base = 0; base < nb; base += (int64_t)SCAN_BLOCK * SUMS_PER) {
-        const int64_t first = base + (int64_t)threadIdx.x * SUMS_PER;
-        unsigned v[SUMS_PER], s = 0;
-#pragma unroll
-        for (int k = 0; k < SUMS_PER; ++k) {
-            v[k] = first + k < nb ? block_sum[first + k] : 0u;
-            s += v[k];
+                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+                excl += val;
+                if (pm)
+                    break;
+                j -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&status[blk], stamp | (2ull << 32) | (unsigned long long)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        unsigned tot;
-        unsigned ex = carry + block_excl_scan(s, &tot);
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    ex += s_excl;
+    if (vec) {
+        int4 o;
+        o.x = (int)ex; o.y = (int)(ex + v[0]); o.z = (int)(ex + v[0] + v[1]); o.w = (int)(ex + v[0] + v[1] + v[2]);
+        *reinterpret_cast<int4 *>(out + base) = o;
+    } else {
 #pragma unroll
-        for (int k = 0; k < SUMS_PER; ++k) {
-            if (first + k < nb) block_sum[first + k] = ex;
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (base + k < n) out[base + k] = (int)ex;
             ex += v[k];
         }
-        carry += tot;
     }
-    if (threadIdx.x == 0) block_sum[nb] = carry; // grand total (slot nb is always allocated)
+    if (blk == nblk - 1 && tid == 0) out[n] = (int)(s_excl + tot); // grand total
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int *__restrict__ out, const unsigned *__restrict__ block_sum,
-                                                         int64_t n, int total)
+static size_t scan_ctl_bytes(int64_t n)
 {
-    const int64_t base = ((int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
-    const unsigned off = block_sum[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) out[base + k] += (int)off;
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total >= 0 ? total : (int)block_sum[gridDim.x];
+    const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
+    return 256 + (size_t)((n + per - 1) / per) * 8;
+}
+// out[0..n] = exclusive prefix of in[0..n), out[n] = total; rezero: clear in[] on the way (bin counters of a kept block)
+static void launch_scan(hipStream_t st, unsigned *in, int *out, int64_t n, unsigned *ctl, bool rezero, int *flags)
+{
+    const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
+    const unsigned nblk = (unsigned)std::max<int64_t>(1, (n + per - 1) / per);
+    const unsigned gen = next_scan_gen();
+    if (rezero) hipLaunchKernelGGL(k_scan_onepass<true>, dim3(nblk), dim3(SCAN_BLOCK), 0, st, in, out, n, ctl, gen, flags);
+    else hipLaunchKernelGGL(k_scan_onepass<false>, dim3(nblk), dim3(SCAN_BLOCK), 0, st, in, out, n, ctl, gen, flags);
 }
 
 // out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); for other translation units (grid.hpp)
 int exclusive_scan_u32(Scope &sc, const unsigned *in, int *out, int64_t n)
 {
-    const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
-    const int64_t nblk = (n + per - 1) / per;
-    unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk + 1);
+    unsigned *ctl = static_cast<unsigned *>(sc.alloc_kept(scan_ctl_bytes(n), Scope::KEEP_SCAN));
     if (sc.failed())
         return sc.error();
-    hipStream_t st = sc.stream();
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, in, out, block_sum, n);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, out, block_sum, n, -1);
+    launch_scan(sc.stream(), const_cast<unsigned *>(in), out, n, ctl, false, nullptr);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
@@ -406,7 +467,11 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     const Grid &g = cg.g;
     hipStream_t st = sc.stream();
 
-    unsigned *cell_count = sc.alloc_n<unsigned>((size_t)g.ncell + 8); // + the flags (five used): one memset for both
+    // bin counters in a kept block (all zero whenever idle: the scan clears what it reads), the scan's control words in
+    // another; the eight device flags are plain scratch, written by the scan — a build enqueues no hipMemsetAsync
+    unsigned *cell_count = static_cast<unsigned *>(sc.alloc_kept(sizeof(unsigned) * (size_t)g.ncell, Scope::KEEP_ZERO));
+    unsigned *ctl = static_cast<unsigned *>(sc.alloc_kept(scan_ctl_bytes(g.ncell), Scope::KEEP_SCAN));
+    cg.flags = sc.alloc_n<int>(8);
     cg.cell_start = sc.alloc_n<int>((size_t)g.ncell + 1);
     int *cell_id = sc.alloc_n<int>((size_t)N);
     int *rank = sc.alloc_n<int>((size_t)N);
@@ -423,9 +488,6 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         cg.zs = sc.alloc_n<double>((size_t)N);
         cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
     }
-    const int64_t nblk = (g.ncell + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-    unsigned *block_sum = sc.alloc_n<unsigned>((size_t)nblk + 1);
-    cg.flags = reinterpret_cast<int *>(cell_count + g.ncell);
     if (sc.failed())
         return sc.error();
 
@@ -456,48 +518,34 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     const int64_t plane = (int64_t)g.nc[1] * g.nc[2];
     cg.win_lo = cg.win_hi = 0;
     if (windowed && p3 <= p2) { cg.win_lo = p0; cg.win_hi = p1; } // one piece: the tile kernel runs over its range of tiles
-    if (windowed) {
-        MDH_HIP(hipMemsetAsync(cell_count + p0 * plane, 0, sizeof(unsigned) * (size_t)((p1 - p0) * plane), st));
-        if (p3 > p2) MDH_HIP(hipMemsetAsync(cell_count + p2 * plane, 0, sizeof(unsigned) * (size_t)((p3 - p2) * plane), st));
-    } else {
-        MDH_HIP(hipMemsetAsync(cell_count, 0, sizeof(unsigned) * ((size_t)g.ncell + 8), st)); // counters and flags
-    }
-    if (windowed) MDH_HIP(hipMemsetAsync(cg.flags, 0, sizeof(int) * 8, st));
     cg.flags_fresh = true;
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
-    // the promise is checked where the atoms are binned and read back by the next build of this thread
+    // the promise is checked where the atoms are binned (a word of pinned host memory the kernel writes) and read by the next
+    // build of this thread or by mdh_cell_window_check
     CellPlanes win{p0, p1, p2, p3, nullptr};
-    int *cnt2 = nullptr;
     if (windowed) {
-        cnt2 = sc.alloc_n<int>(2);
-        if (sc.failed())
-            return sc.error();
         if (!g_window_violations) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_window_violations), sizeof(int), hipHostMallocDefault));
         *g_window_violations = 0;
-        MDH_HIP(hipMemsetAsync(cnt2, 0, sizeof(int), st));
-        win.bad = cnt2;
+        win.bad = g_window_violations;
     }
+    const unsigned gen = next_scan_gen(); // stamps of this build's k_assign; the (first) scan below is launched with the same value
     if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv, win);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win);
     else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, cg.flags, slack, mv, win);
-    if (windowed)
-        MDH_HIP(hipMemcpyAsync(g_window_violations, cnt2, sizeof(int), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win);
+    auto scan_piece = [&](int64_t from, int64_t to, unsigned use_gen, int *flags) {
+        const int64_t n = to - from, per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
+        hipLaunchKernelGGL(k_scan_onepass<true>, dim3((unsigned)std::max<int64_t>(1, (n + per - 1) / per)), dim3(SCAN_BLOCK), 0, st,
+                           cell_count + from, cg.cell_start + from, n, ctl, use_gen, flags); // [to] = the piece's total
+    };
     if (!windowed) {
-        hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cell_count, cg.cell_start, block_sum, g.ncell);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nblk);
-        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nblk), dim3(SCAN_BLOCK), 0, st, cg.cell_start, block_sum, g.ncell, (int)N);
+        scan_piece(0, g.ncell, gen, cg.flags);
     } else {
         // the pieces in index order: [p0, p1) then [p2, p3); a piece is scanned on its own, the atoms before it added by the
-        // fill / by a second add pass; cell_start elsewhere = what a full scan leaves: the atoms binned so far
+        // fill / by a second add pass; cell_start elsewhere = what a full scan leaves: the atoms binned so far.  The counters
+        // outside the window are zero (kept block; atoms out there take no slot) and stay untouched.
         const int64_t a0 = p0 * plane, a1 = p1 * plane, b0 = p2 * plane, b1 = p3 * plane;
-        auto scan_piece = [&](int64_t from, int64_t to) {
-            const int64_t n = to - from, nb = (n + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-            hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, cell_count + from, cg.cell_start + from, block_sum, n);
-            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sum, nb);
-            hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, cg.cell_start + from, block_sum, n, -1); // [to] = the piece's total
-        };
         // (constant fills through the runtime's fill kernel: 16-byte stores, 5 us per 10 MB against 15 of a store per thread)
         hipError_t fill_err = hipSuccess;
         auto fill_const = [&](int64_t from, int64_t to, int v) {
@@ -505,11 +553,11 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
                 fill_err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cg.cell_start + from), v, (size_t)(to - from), st);
         };
         fill_const(0, a0, 0);
-        scan_piece(a0, a1);
+        scan_piece(a0, a1, gen, cg.flags);
         if (b1 > b0) {
             // second piece: offsets start at the first piece's total, which sits on the device in cell_start[a1]
             hipLaunchKernelGGL(k_fill_from, dim3(grid_for(b0 - a1 - 1, 256) + 1), dim3(256), 0, st, cg.cell_start, a1 + 1, b0, cg.cell_start + a1);
-            scan_piece(b0, b1);
+            scan_piece(b0, b1, next_scan_gen(), nullptr);
             hipLaunchKernelGGL(k_add_from, dim3(grid_for(b1 - b0 + 1, 256)), dim3(256), 0, st, cg.cell_start, b0, b1 + 1, cg.cell_start + a1, (int64_t)-1);
             if (b1 < g.ncell) fill_const(b1 + 1, g.ncell + 1, (int)N);
         } else if (a1 < g.ncell) {
@@ -517,6 +565,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         }
         MDH_HIP(fill_err);
     }
+    sc.keep_confirm(cell_count); // every counter a binned atom touched has been read and cleared by a scan enqueued above
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc) {
         if (!windowed) {

@@ -1,6 +1,7 @@
 // runtime.hip — error reporting, per-device scratch cache, host<->HBM staging,
 // and the host-side construction of the kernel-visible box.
 #include "common.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -27,7 +28,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 // event, and a later Scope on a different stream makes its stream wait for it before touching the block.
 // ----------------------------------------------------------------------------
 struct DoneEvent { hipEvent_t ev; hipStream_t stream; int refs; };
-struct Block { void *p; size_t bytes; bool busy; int device; DoneEvent *done; };
+struct Block { void *p; size_t bytes; bool busy; int device; DoneEvent *done; int tag; }; // tag: Scope::Keep (0: plain scratch)
 static std::mutex g_mu;
 static std::vector<Block> g_blocks;
 static std::vector<DoneEvent *> g_event_pool;
@@ -71,6 +72,11 @@ Scope::~Scope()
 {
     if (nheld_ == 0)
         return;
+    // a kept block whose invariant was not restored (an error path between its first and its last kernel): zero-fill it, in
+    // stream order, before the event that marks the end of this call
+    for (int i = 0; i < nheld_; ++i)
+        if (held_keep_[i] == KEEP_ZERO || held_keep_[i] == KEEP_TODO)
+            (void)hipMemsetAsync(held_[i], 0, held_keep_[i] == KEEP_TODO ? std::min<size_t>(512, held_bytes_[i]) : held_bytes_[i], stream_);
     std::lock_guard<std::mutex> lk(g_mu);
     DoneEvent *done = event_acquire(stream_);
     if (done && hipEventRecord(done->ev, stream_) != hipSuccess) { // cannot mark the end of this call's work: wait for it instead
@@ -93,7 +99,17 @@ Scope::~Scope()
         g_event_pool.push_back(done);
 }
 
-void *Scope::alloc(size_t bytes)
+void *Scope::alloc(size_t bytes) { return alloc_impl(bytes, KEEP_NONE); }
+
+void *Scope::alloc_kept(size_t bytes, Keep tag) { return alloc_impl(bytes, (int)tag); }
+
+void Scope::keep_confirm(void *p)
+{
+    for (int i = 0; i < nheld_; ++i)
+        if (held_[i] == p) held_keep_[i] |= 0x80;
+}
+
+void *Scope::alloc_impl(size_t bytes, int tag)
 {
     if (failed_)
         return nullptr;
@@ -108,7 +124,7 @@ void *Scope::alloc(size_t bytes)
     int best = -1, best_any = -1;
     for (size_t i = 0; i < g_blocks.size(); ++i) {
         const Block &b = g_blocks[i];
-        if (b.busy || b.device != device_ || b.bytes < bytes)
+        if (b.busy || b.device != device_ || b.bytes < bytes || b.tag != tag)
             continue;
         if (best_any < 0 || b.bytes < g_blocks[best_any].bytes)
             best_any = (int)i;
@@ -118,16 +134,21 @@ void *Scope::alloc(size_t bytes)
     const bool fits = best >= 0 && g_blocks[best].bytes <= 2 * bytes + (1u << 20);
     if (!fits && bytes > (size_t(4) << 20))
         best = best_any;
+    if (tag != KEEP_NONE && best < 0)
+        best = best_any; // kept blocks: any idle one of the tag that is large enough (only the part a call touches matters)
     // reuse only if the block is not grossly oversized (keeps big list buffers from being pinned by tiny requests)
-    if (best >= 0 && g_blocks[best].bytes <= 2 * bytes + (1u << 20)) {
+    if (best >= 0 && (tag != KEEP_NONE || g_blocks[best].bytes <= 2 * bytes + (1u << 20))) {
         Block &b = g_blocks[best];
         if (b.done && b.done->stream != stream_) // last used on another stream: its work there comes first
             (void)hipStreamWaitEvent(stream_, b.done->ev, 0);
         b.busy = true;
         held_[nheld_] = b.p;
+        held_keep_[nheld_] = (unsigned char)tag;
         held_bytes_[nheld_++] = b.bytes;
         return b.p;
     }
+    if (tag != KEEP_NONE) // a new kept block: with head-room, so that a slowly growing system does not make one per size
+        bytes = (bytes + bytes / 8 + 4095) & ~size_t(4095);
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
@@ -143,10 +164,24 @@ void *Scope::alloc(size_t bytes)
         failed_ = true;
         return nullptr;
     }
-    g_blocks.push_back(Block{p, bytes, true, device_, nullptr});
+    if (tag != KEEP_NONE) { // every kept block starts zero-filled (stream-ordered: its first user is this call)
+        e = hipMemsetAsync(p, 0, bytes, stream_);
+        if (e != hipSuccess) { (void)hipFree(p); hip_fail(e, "hipMemsetAsync(kept block)", __FILE__, __LINE__); failed_ = true; err_ = MDH_ERR_HIP; return nullptr; }
+    }
+    g_blocks.push_back(Block{p, bytes, true, device_, nullptr, tag});
     held_[nheld_] = p;
+    held_keep_[nheld_] = (unsigned char)tag;
     held_bytes_[nheld_++] = bytes;
     return p;
+}
+
+// every cached block of one Keep tag back to all-zero (waits for the device; for the rare generation wrap of the scan)
+void reset_kept_blocks(int tag)
+{
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &b : g_blocks)
+        if (b.tag == tag) (void)hipMemset(b.p, 0, b.bytes);
 }
 
 void *Scope::stage_raw(void *p, size_t bytes, int space, bool in, bool out)
