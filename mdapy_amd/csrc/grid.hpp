@@ -87,6 +87,7 @@ struct LanePlan {
     bool tk8;         // rows of at most 16 slots: one-byte tickets, lean LDS layout, rows written by the centre's lane
     int wgs;          // workgroups per CU the LDS budget was cut for
     int rw;           // rows (centres) a wave works on at a time: 64, fewer for long rows in dense cells
+    int nw = 4;       // waves per workgroup: 4, or 8 (tiles of up to 512 halo cells, two workgroups per CU)
     float mid, T;     // single-precision scan: the constant c subtracted from d2 (a little below rc^2) and the width W of the band above it
     int last_listed = -1; int *listed_sink = nullptr; // GridStats: sizes the second pass's grid
     bool full;        // every 4x4x4 block of cells holds atoms (last known statistics): all tiles are live

@@ -61,9 +61,9 @@
 namespace mdh {
 namespace lane {
 
-static constexpr int NT = 256;      // threads per workgroup
-static constexpr int MAX_NH = 256;  // halo cells of a tile: one per thread
-static constexpr int CEN_CAP = 320; // centre atoms a tile may hold
+// A workgroup is NW waves (template parameter of the kernel): 4 — 256 threads, four workgroups per CU — or 8 for the big-tile
+// instance — 512 threads, two per CU.  A tile has at most one halo cell per thread.
+constexpr int cen_cap(int nw) { return 80 * nw; } // centre atoms a tile may hold
 static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
 static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
 
@@ -115,6 +115,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+template <int NW>
 __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -128,7 +129,7 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < (NT >> 6); ++k) {
+    for (int k = 0; k < NW; ++k) {
         if (k < w) off += scratch[k];
         tot += scratch[k];
     }
@@ -375,8 +376,12 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
 // TK8 (rows of at most 16 slots): one-byte tickets, no row-word / wrapped-centre tables, rows written by the centre's own lane,
 // and (without the fused CNA) the kernel held to 128 VGPRs: a workgroup then needs under 40 KB of LDS and FOUR share a CU.
 // false: two-byte tickets and the slot-per-lane write-out (rows of up to 64 slots)
-template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8>
-__global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
+// NW: waves per workgroup.  4: tiles of up to 256 halo cells, four workgroups per CU.  8 (one-byte instance without the fused CNA
+// only): tiles of up to 512 halo cells, two workgroups per CU — the same sixteen waves per CU, but a tile of 6 x 6 x 5 cells
+// stages 2.5 halo cells per centre cell instead of 3.15, its per-wave front phases serve twice the centres, and its ~440 centres
+// fill seven chunks of 64 better than ~196 fill three or four
+template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neighbor_lane(
     const CellGrid::Packed *__restrict__ pk, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
+    constexpr int CENC = cen_cap(NW);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     double2 *lxy = reinterpret_cast<double2 *>(f4 + cap);           // [cap] staged raw x, y
     double *lz = reinterpret_cast<double *>(lxy + cap);             // [cap] staged raw z
     unsigned *cen = reinterpret_cast<unsigned *>(lz + cap);         // [CEN_CAP] centre atoms: LDS index | halo cell << 11
-    unsigned short *lsh = reinterpret_cast<unsigned short *>(cen + CEN_CAP); // [cap] combined image code of a staged atom seen from this tile
+    unsigned short *lsh = reinterpret_cast<unsigned short *>(cen + CENC); // [cap] combined image code of a staged atom seen from this tile
     Ticket *tk = reinterpret_cast<Ticket *>(lsh + cap + (cap & 1)); // [NT][TKS] tickets (slot M swallows the hits past M); wave w owns rows 64 w ...
     const unsigned f4_lds = (unsigned)(unsigned long)(lds_byte *)smem;
     // halo cell: population — needed from the block scan's barrier to the run table only, so it lives in the ticket rows, cell t
@@ -407,8 +413,8 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
     const int TKS = (M + 4) & ~3; // tickets of a row + the spare slot, rounded up: rows are read back four tickets at a time
     const int wstride = max(rw * TKS, 256 / (int)sizeof(Ticket)); // tickets of one wave's rows (at least its 64 populations)
     auto hc = [&](int t) -> unsigned & { return reinterpret_cast<unsigned *>(tk + (size_t)(t >> 6) * wstride)[t & 63]; };
-    __shared__ unsigned hr[MAX_NH + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
-    __shared__ int scan_tmp[4];
+    __shared__ unsigned hr[NW * 64 + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
+    __shared__ int scan_tmp[NW];
     __shared__ int s_flag[4];
 
     const double rcsq = rc * rc, pad = rc + 1.0; // neighbor.cpp:127; pads neighbor.py:125-129
@@ -512,10 +518,10 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         hc(tid) = (unsigned)cnt; // the neighbours in z need it for their run (published by the scan's barrier)
 
         int total2;
-        const int off2 = excl_scan_block(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
+        const int off2 = excl_scan_block<NW>(cnt | (centre_cell ? cnt << 16 : 0), scan_tmp, &total2); // both prefixes in one scan (each < 2^15)
         const int total = total2 & 0xffff, ncentres = total2 >> 16;
         const int off0 = off2 & 0xffff, coff = off2 >> 16;
-        bool ok = !(total > cap || ncentres > CEN_CAP); // else: listed for the next pass
+        bool ok = !(total > cap || ncentres > CENC); // else: listed for the next pass
         STAMP(2);
         // the 3-cell run around every cell that can be a column entry of a centre's walk (cells tid-1, tid, tid+1 are adjacent in z
         // and in LDS)
@@ -572,7 +578,11 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                         if (edge)
                             far = far || !(ux >= flo && ux <= fhx && uy >= flo && uy <= fhx && uz >= flo && uz <= fhz);
                         const int p = off0 + k + v;
+#ifdef MDH_EXP_GATHER // measuring build (make gather): the staged atom carries its record's index, not its id
+                        f4[p] = make_float4(ux, uy, uz, __int_as_float(src + k + v));
+#else
                         f4[p] = make_float4(ux, uy, uz, __int_as_float(d[v]));
+#endif
                         lxy[p] = make_double2(a[v], bb[v]);
                         lz[p] = c[v];
                         lsh[p] = (unsigned short)code;
@@ -642,7 +652,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
         // Centres go out in chunks of rw (a full wave of them); chunk c is taken by wave (c + jt) mod 4 — a tile of 150 centres
         // keeps three waves busy with full registers and leaves the fourth free, and the rotation spreads the free one over the
         // CU's four SIMDs from tile to tile (an even split, 38 lanes in each of four waves, costs four chunk passes for three)
-        for (int cbase = (int)((unsigned)(wv - jt) & (unsigned)((NT >> 6) - 1)) * rw; ok && cbase < ncentres; cbase += (NT >> 6) * rw) {
+        for (int cbase = (int)((unsigned)(wv - jt) & (unsigned)(NW - 1)) * rw; ok && cbase < ncentres; cbase += NW * rw) {
             const int q = cbase + lane;
             const bool mine = lane < rw && q < ncentres; // this lane holds a centre
             int kept = 0, kept8 = 0, cb = 0, id = 0; // (lanes without a centre: no row)
@@ -722,7 +732,11 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                 int hits = 0;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]) + (WIDE ? __builtin_popcount(mk2[r]) : 0);
+#ifdef MDH_EXP_GATHER
+                id = pk[__float_as_int(s.w)].id;
+#else
                 id = __float_as_int(s.w);
+#endif
                 nn[id] = hits; // keeps counting past M (neighbor.cpp:172-177)
                 if (COUNT) {
                     vmax = max(vmax, hits);
@@ -819,6 +833,19 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                         double2 cj[4];
                         double zj[4], d2[4];
                         int nid[4], sh[4];
+#ifdef MDH_EXP_GATHER // the hits' raw doubles through L2 in one batched gather per group of four
+                        int qx[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) qx[u] = mine ? __float_as_int(f4[k[u]].w) : 0; // (a lane without a centre reads whatever LDS holds)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const CellGrid::Packed rj = pk[qx[u]];
+                            cj[u] = make_double2(rj.x, rj.y);
+                            zj[u] = rj.z;
+                            nid[u] = rj.id;
+                            sh[u] = (!TRI && general_tile) ? (int)lsh[k[u]] : 0;
+                        }
+#else
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             cj[u] = lxy[k[u]];
@@ -826,6 +853,7 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                             nid[u] = __float_as_int(f4[k[u]].w);
                             sh[u] = (!TRI && general_tile) ? (int)lsh[k[u]] : 0;
                         }
+#endif
                         bool slow = false;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -944,7 +972,11 @@ __global__ __launch_bounds__(NT, (TK8 && !FCNA) ? 4 : 1) void k_neighbor_lane(
                         for (int u = 0; u < 4; ++u) {
                             cj[u] = lxy[k[u]];
                             zj[u] = lz[k[u]];
+#ifdef MDH_EXP_GATHER
+                            nid[u] = mine ? pk[__float_as_int(f4[k[u]].w)].id : 0;
+#else
                             nid[u] = __float_as_int(f4[k[u]].w);
+#endif
                             sh[u] = (!TRI && general_tile) ? (int)lsh[k[u]] : 0;
                         }
                         bool slow = false;
@@ -1132,11 +1164,11 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
 namespace lane {
 
 // tk8: one-byte tickets, else two-byte ones; rows of (M + 1) tickets rounded up to a multiple of four; rw rows per wave
-static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw)
+static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw, int nw = 4)
 {
     const size_t wave = std::max<size_t>((size_t)rw * (size_t)((M + 4) & ~(int64_t)3) * (tk8 ? 1 : 2), 256); // (the kernel's wstride)
-    const size_t tk = (size_t)(NT / 64) * wave;
-    return (size_t)cap * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)CEN_CAP * 4 + (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
+    const size_t tk = (size_t)nw * wave;
+    return (size_t)cap * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)cen_cap(nw) * 4 + (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }
 
 } // namespace lane
@@ -1178,40 +1210,60 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, two, one, if the tile that allows is not
     // much worse than what fewer would get.  Rows of many slots in cells of many atoms (rc = 5 A, 50 slots: the reference's
     // own benchmark call) leave few centres per tile: the ticket rows are sized for them (rw rows per wave), not for 64.
+    // eight waves per workgroup (tiles of up to 512 halo cells, two workgroups per CU): the one-byte instance without the fused
+    // CNA, where four workgroups of four waves would share the CU anyway
+#ifdef MDH_LANE_NW8
+    static const int nw_env = [] { const char *e = std::getenv("MDH_LANE_NW"); return e ? std::atoi(e) : 0; }(); // A/B: 4 or 8
+#else
+    constexpr int nw_env = 0;
+#endif
     Shape best{0, 0};
-    int best_cap = 0, best_wgs = 0, best_rw = 64;
+    int best_cap = 0, best_wgs = 0, best_rw = 64, best_nw = 4;
     double best_score = -1.0;
-    for (int wgs = max_wgs; wgs >= 1; --wgs) {
-        if (wgs_env > 0 && wgs != std::min(wgs_env, max_wgs))
+    bool stop = false;
+    for (int nw = 8; nw >= 4 && !stop; nw -= 4)
+    for (int wgs = (nw == 8 ? 2 : max_wgs); wgs >= 1; --wgs) {
+        if (nw == 8 && (!(tk8 && !fcna) || nw_env != 8 || wgs < 2)) // measured 3 % slower than four waves: on request only
             continue;
+        if (nw == 4 && nw_env == 8 && tk8 && !fcna)
+            continue;
+        if (wgs_env > 0 && nw == 4 && wgs != std::min(wgs_env, max_wgs))
+            continue;
+        const int nthr = nw * 64;
         // static tables (1.1 KB: the run table, scan scratch, flags) and a margin.  LDS is handed out in 512-byte granules: 40 960 B
         // in all give four workgroups per CU (measured: 40 544 do, 41 216 do not; 52.9 KB three, 54.3 KB not)
-        const long budget = 160 * 1024 / wgs - 1088 - (wgs == 4 ? 64 : 1600);
+        const long budget = nw == 8 ? 160 * 1024 / 2 - 2112 - 64 : 160 * 1024 / wgs - 1088 - (wgs == 4 ? 64 : 1600);
         for (int txy = 1; txy <= 8; ++txy)
             for (int tz = 1; tz <= 24; ++tz) {
                 const int nh = (txy + 2) * (txy + 2) * (tz + 2);
-                if (nh > MAX_NH)
+                if (nh > nthr)
                     continue;
                 const int ncc = txy * txy * tz;
                 const double c = ncc * pop;                                 // centre atoms per tile
-                if (c * 1.15 > CEN_CAP)
+                if (c * 1.15 > cen_cap(nw))
                     continue;
                 int rw = 64;
-                if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / (NT / 64)) + 7) & ~7));
-                const long fixed = (long)lds_bytes(0, M, tk8, rw);
+                if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / nw) + 7) & ~7));
+                const long fixed = (long)lds_bytes(0, M, tk8, rw, nw);
                 int cap = (int)((budget - fixed - 2) / 42);
                 if (cap_env > 0) cap = cap_env;
                 cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
                 if (cap < 64 || nh * pop > 0.875 * cap) // head-room for density fluctuations; what overflows goes to the slice pass
                     continue;
-                const double passes = std::ceil(c * 1.15 / ((NT / 64) * rw)); // (head-room: a second pass for a handful of centres is a waste)
-                const double util = c / (passes * NT);                     // lane utilisation of the scan
+                const double passes = std::ceil(c * 1.15 / (nw * rw)); // (head-room: a second pass for a handful of centres is a waste)
+                const double util = c / (passes * nthr);                   // lane utilisation of the scan
                 const double reuse = (double)ncc / (double)nh;             // centre cells per staged cell
-                const double score = util * (0.35 + reuse) * (wgs == 4 ? 1.1 : (wgs == 3 ? 1.0 : (wgs == 2 ? 0.85 : 0.6)));
-                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; best_wgs = wgs; best_rw = rw; }
+                const int wpc = wgs * nw;                                  // waves per CU
+                const double score = util * (0.35 + reuse) * (wpc == 16 ? 1.1 : (wpc == 12 ? 1.0 : (wpc == 8 ? 0.85 : 0.6)));
+                // the big tile must leave the chip full: at least four workgroups' worth of tiles per CU
+                if (nw == 8 && (double)occ / ncc < 4.0 * 256.0)
+                    continue;
+                if (score > best_score) { best_score = score; best = Shape{txy, tz}; best_cap = cap; best_wgs = wgs; best_rw = rw; best_nw = nw; }
             }
-        if (cap_env > 0)
+        if (cap_env > 0) {
+            stop = true;
             break;
+        }
     }
     if (!best.txy) { g_last_plan[6] = -6; return p; }
     // Decision band of the single-precision scan (file header).  E bounds the staged coordinates (far-atom check of the
@@ -1252,13 +1304,14 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.tk8 = tk8;
     p.wgs = best_wgs;
     p.rw = best_rw;
+    p.nw = best_nw;
     p.occupied = occ;
     p.last_listed = gs.last_listed;
     p.listed_sink = gs.listed_sink;
     g_last_listed = gs.listed_sink ? *(volatile int *)gs.listed_sink : gs.last_listed; // (the freshest value the device has delivered)
     p.full = occ >= g.ncell;
-    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw);
-    g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
+    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw, p.nw);
+    g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2) | (p.nw == 8 ? 32 : 0); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
 
@@ -1307,7 +1360,8 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         list_mode = 1;
     }
     const dim3 grid((unsigned)(per * 8));
-    const size_t lds = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw);
+    const size_t lds1 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, plan.nw); // first pass (four or eight waves per workgroup)
+    const size_t lds2 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, 4);       // slice pass: always four
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
     const float negc = -plan.mid;
     const int nt2b = nt[2] * nsub;
@@ -1316,27 +1370,35 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     // every build went into 1024 workgroups that found an empty list
     const dim3 grid2(plan.last_listed == 0 ? 64u : 1024u);
     const Shape ts2 = make_shape(ts.txy, 1, nt[1], nt2b);
-#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, TK8, GRID, JT0, ...)                                                                             \
+#define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, TK8, NW, GRID, JT0, ...)                                                                         \
     do {                                                                                                                                  \
+        const size_t lds = (NW) == 8 ? lds1 : lds2;                                                                                       \
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8>), GRID, dim3(NT), lds, st, cg.pk, cg.cell_start, b, \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW>), GRID, dim3((NW) * 64), lds, st, cg.pk, cg.cell_start, b, \
                            cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base, plan.listed_sink); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
     // otherwise); second pass: one-cell slices of what the first listed
-#define MDH_LANE_LAUNCH(COUNT, TRI, FCNA, TK8)                                                                                            \
+#define MDH_LANE_LAUNCH_NW(COUNT, TRI, FCNA, TK8, NW)                                                                                     \
     do {                                                                                                                                  \
         if (list_mode) {                                                                                                                  \
-            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, NW, grid, 0, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
             if ((int64_t)per * 8 < ntiles)                                                                                                \
-                MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, dim3(512), per, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
+                MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, NW, dim3(512), per, nt[0], nt[1], nt[2], ts, tile_list, slot + ntiles, 1, max_count, flagged, nullptr, 0, 1, 2); \
         } else {                                                                                                                          \
-            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, grid, 0, nt0_run, nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
+            MDH_LANE_PASS(COUNT, TRI, false, FCNA, TK8, NW, grid, 0, nt0_run, nt[1], nt[2], ts, nullptr, slot + ntiles, 0, max_count, flagged, nullptr, 0, 1, 2); \
         }                                                                                                                                 \
-        MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, grid2, 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
+        MDH_LANE_PASS(COUNT, TRI, true, FCNA, TK8, 4, grid2, 0, nt[0], nt[1], nt2b, ts2, nullptr, cg.flags + 2, 1, max_count, flagged2, flagged, nt[2], nsub, 3); \
     } while (0)
+#define MDH_LANE_LAUNCH(COUNT, TRI, FCNA, TK8) MDH_LANE_LAUNCH_NW(COUNT, TRI, FCNA, TK8, 4)
+#ifdef MDH_LANE_NW8 // measuring build (make nw8): the eight-wave instances are compiled in and MDH_LANE_NW=8 selects them
+    if (plan.nw == 8) { // (one-byte instance without the fused CNA: plan_lane)
+        if (count) { if (b.tri) MDH_LANE_LAUNCH_NW(true, true, false, true, 8); else MDH_LANE_LAUNCH_NW(true, false, false, true, 8); }
+        else { if (b.tri) MDH_LANE_LAUNCH_NW(false, true, false, true, 8); else MDH_LANE_LAUNCH_NW(false, false, false, true, 8); }
+    } else
+#endif
     if (count) {
         if (plan.tk8) { if (b.tri) MDH_LANE_LAUNCH(true, true, false, true); else MDH_LANE_LAUNCH(true, false, false, true); }
         else { if (b.tri) MDH_LANE_LAUNCH(true, true, false, false); else MDH_LANE_LAUNCH(true, false, false, false); }
@@ -1349,6 +1411,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     }
 #undef MDH_LANE_PASS
 #undef MDH_LANE_LAUNCH
+#undef MDH_LANE_LAUNCH_NW
     MDH_HIP(hipGetLastError());
     // what the two passes listed for the thread-per-atom code (k_neighbor_tiles), in the tiling of the second pass
     tf.flag = reinterpret_cast<const unsigned char *>(flagged2); // (non-null: "a tiled kernel ran"; the per-tile byte flags are not used with a list)
