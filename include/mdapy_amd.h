@@ -49,7 +49,22 @@ const char *mdh_last_error(void);
 int mdh_version(void);
 /* number of visible HIP devices (0 when there is no GPU; never an error) */
 int mdh_device_count(void);
+/* select the device of this thread's later calls and load the library's code objects on it (mdh_warm) */
 int mdh_set_device(int device);
+/*
+ * Load every code object of the library on the current device, once per device and process (an empty launch per
+ * translation unit; ~30-100 ms in a fresh process): afterwards the FIRST mdh_build_neighbor / mdh_csp / ... of the
+ * process costs about what the following ones do.  The reference has no counterpart: a CPU extension module is
+ * mapped as a whole at import (CMakeLists.txt:71-100).  mdapy_amd/_lib.py calls it when it loads the library on a
+ * box with a GPU.  No-op when the device has been warmed before.
+ */
+int mdh_warm(void);
+/*
+ * min_max2[0] / [1] (host memory) = smallest / largest entry of an int32 array of n > 0 entries; waits for the stream.
+ * Host policy of src/mdapy/system.py:1262-1263, 1987-1988 ("does every atom have k neighbours in the list I hold?" is
+ * `neighbor_number.min() >= k` there, a numpy reduction): with the counts resident in HBM the reduction runs there.
+ */
+int mdh_min_max_i32(const int *v, int64_t n, int *min_max2, int space, void *stream);
 /* free the cached per-device scratch buffers */
 int mdh_release_workspace(void);
 /* bytes currently held by the scratch cache of the current device */

@@ -30,6 +30,8 @@ _SIGNATURES = {
     "mdh_version": [],
     "mdh_device_count": [],
     "mdh_set_device": [cint],
+    "mdh_warm": [],
+    "mdh_min_max_i32": [vp, i64, vp, cint, vp],
     "mdh_release_workspace": [],
     "mdh_workspace_bytes": [],
     "mdh_prof_enable": [cint],
@@ -136,6 +138,11 @@ def lib():
                     raise ValueError(f"MDAPY_HIP_DEVICE={index}: this process sees {count} HIP device(s)")
                 if L.mdh_set_device(index) != 0:
                     raise RuntimeError(L.mdh_last_error().decode("utf-8", "replace"))
+        # code objects of all kernel families on the device this process uses, now: the set-up cost of a process belongs to
+        # its first touch of the library, not to its first build_neighbor / cal_* (tools/cold_path.py).  MDAPY_HIP_WARM=0 skips it.
+        if os.environ.get("MDAPY_HIP_WARM", "1") != "0" and int(L.mdh_device_count()) > 0:
+            if L.mdh_warm() != 0:
+                raise RuntimeError(L.mdh_last_error().decode("utf-8", "replace"))
         _lib = L
     return _lib
 

@@ -750,3 +750,5 @@ int mdh_ids(const double *x, const double *y, const double *z, int64_t N, const 
     return sc.finish(space);
 }
 }
+
+MDH_WARM_UNIT(cna)

@@ -215,6 +215,16 @@ __device__ __forceinline__ int safe_id(int j, int64_t fallback, int64_t n) { ret
 
 inline int grid_for(int64_t n, int block) { return (int)((n + block - 1) / block); }
 
+// Every translation unit of the library is one code object, loaded by the HIP runtime at the first launch of one of its
+// kernels (1-2.5 ms apiece on an MI355X box, 65 ms for the first of the process).  MDH_WARM_UNIT(name) gives a unit an empty
+// kernel; mdh_warm() (runtime.hip) launches them all, so that the loading happens where a caller expects set-up cost — the
+// first use of a device — and not inside its first build_neighbor, cal_centro_symmetry_parameter, ...
+#define MDH_WARM_UNIT(name)                                                                                                    \
+    namespace mdh {                                                                                                            \
+    __global__ void k_warm_##name() {}                                                                                         \
+    void warm_##name(hipStream_t st) { hipLaunchKernelGGL(k_warm_##name, dim3(1), dim3(64), 0, st); }                          \
+    }
+
 // Scoped HIP-event pair around a kernel launch (no-op unless mdh_prof_enable(1)); prof.hip
 class ProfRange {
   public:

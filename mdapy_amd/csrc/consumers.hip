@@ -729,3 +729,5 @@ extern "C" int mdh_filter_by_type(int *verlet, const double *dist, const int *nn
     MDH_HIP(hipStreamSynchronize(sc.stream())); // t1/t2/r are staged from caller memory
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(consumers)

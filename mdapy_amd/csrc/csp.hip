@@ -93,21 +93,28 @@ __device__ double csp_atom_dynamic(const DBox &b, const double *__restrict__ x, 
     return s;
 }
 
-template <bool TRI>
-__global__ __launch_bounds__(256) void k_csp(const double *__restrict__ x, const double *__restrict__ y,
-                                             const double *__restrict__ z, int64_t N, DBox b,
-                                             const int *__restrict__ verlet, int64_t M, int K,
+// Two kernels, not one with a branch on K: the general path keeps its pair vectors in scratch memory (1.8 KB per lane), and a
+// kernel reserves its scratch whether a launch takes that path or not — the first such launch of a process pays the queue's
+// scratch allocation (24 ms for ~1 GB on this chip) and every launch runs at scratch-limited occupancy.
+template <bool TRI, int K>
+__global__ __launch_bounds__(256) void k_csp(int64_t N, DBox b, const int *__restrict__ verlet, int64_t M,
                                              double *__restrict__ csp, const Pos4 *__restrict__ pos)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    const int *row = verlet + i * M;
-    double v;
-    if (K == 12) v = csp_atom_static<TRI, 12>(b, pos, i, row, N);
-    else if (K == 8) v = csp_atom_static<TRI, 8>(b, pos, i, row, N);
-    else v = csp_atom_dynamic<TRI>(b, x, y, z, i, row, K, N);
-    csp[i] = v;
+    csp[i] = csp_atom_static<TRI, K>(b, pos, i, verlet + i * M, N);
+}
+
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_csp_any(const double *__restrict__ x, const double *__restrict__ y,
+                                                 const double *__restrict__ z, int64_t N, DBox b,
+                                                 const int *__restrict__ verlet, int64_t M, int K, double *__restrict__ csp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    csp[i] = csp_atom_dynamic<TRI>(b, x, y, z, i, verlet + i * M, K, N);
 }
 
 } // namespace mdh
@@ -132,12 +139,24 @@ extern "C" int mdh_csp(const double *x, const double *y, const double *z, int64_
     double *dc = sc.stage(csp, (size_t)N, space, false, true);
     if (sc.failed())
         return sc.error();
-    const Pos4 *pos = pack_positions(sc, dx, dy, dz, N);
-    if (!pos)
-        return sc.error();
-    if (b.tri)
-        hipLaunchKernelGGL(k_csp<true>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc, pos);
-    else
-        hipLaunchKernelGGL(k_csp<false>, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc, pos);
+    const dim3 grid(grid_for(N, 256)), block(256);
+    if (num_neigh == 12 || num_neigh == 8) {
+        const Pos4 *pos = pack_positions(sc, dx, dy, dz, N);
+        if (!pos)
+            return sc.error();
+        if (num_neigh == 12) {
+            if (b.tri) hipLaunchKernelGGL((k_csp<true, 12>), grid, block, 0, sc.stream(), N, b, dv, M, dc, pos);
+            else hipLaunchKernelGGL((k_csp<false, 12>), grid, block, 0, sc.stream(), N, b, dv, M, dc, pos);
+        } else {
+            if (b.tri) hipLaunchKernelGGL((k_csp<true, 8>), grid, block, 0, sc.stream(), N, b, dv, M, dc, pos);
+            else hipLaunchKernelGGL((k_csp<false, 8>), grid, block, 0, sc.stream(), N, b, dv, M, dc, pos);
+        }
+    } else if (b.tri) {
+        hipLaunchKernelGGL(k_csp_any<true>, grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc);
+    } else {
+        hipLaunchKernelGGL(k_csp_any<false>, grid, block, 0, sc.stream(), dx, dy, dz, N, b, dv, M, num_neigh, dc);
+    }
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(csp)

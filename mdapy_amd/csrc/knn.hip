@@ -452,3 +452,5 @@ extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_
     MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(knn)

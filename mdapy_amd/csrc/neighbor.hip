@@ -1291,3 +1291,5 @@ int mdh_average_by_neighbor(double rc, const int *verlet, const double *dist, co
     return sc.finish(space);
 }
 }
+
+MDH_WARM_UNIT(neighbor)

@@ -1440,3 +1440,5 @@ extern "C" int mdh_debug_neighbor_plan(int *plan8)
     mdh::lane::g_last_plan[7] = 0; // [7] = 1: the plan was made since the last query
     return MDH_OK;
 }
+
+MDH_WARM_UNIT(neighbor_lane)

@@ -594,3 +594,5 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
 }
 
 } // namespace mdh
+
+MDH_WARM_UNIT(neighbor_tiled)

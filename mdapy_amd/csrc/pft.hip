@@ -206,3 +206,5 @@ extern "C" int mdh_identify_sftb_fcc(const int *hcp_indices, int64_t n_hcp, int 
     MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(pft)

@@ -229,3 +229,5 @@ extern "C" int mdh_filter_overlap_atom_with_grain(const double *x, const double 
     MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(polycrystal)

@@ -82,3 +82,5 @@ int mdh_prof_report(char *buf, int buflen)
     return (int)out.size();
 }
 }
+
+MDH_WARM_UNIT(prof)

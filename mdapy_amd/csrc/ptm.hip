@@ -154,3 +154,5 @@ extern "C" int mdh_ptm(const char *structure, const double *x, const double *y, 
     MDH_TRY(launch_ptm_stages(dx, dy, dz, N, b, dnbr, dord, dtp, dt, dautc, flags, rmsd_threshold, dout, ncol, dind, nind, work, sc.stream()));
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(ptm)

@@ -1522,3 +1522,5 @@ int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int6
 }
 
 } // namespace mdh
+
+MDH_WARM_UNIT(ptm_stages)

@@ -502,3 +502,5 @@ int mdh_rdf_single_species(const int *verlet, const double *dist, const int *nn,
     return rdf_from_list(verlet, dist, nn, nullptr, N, M, g, 1, rc, nbin, 1, space, stream);
 }
 }
+
+MDH_WARM_UNIT(rdf)

@@ -45,3 +45,5 @@ extern "C" int mdh_repeat_cell(double *new_pos, const double *old_box9_host, con
     hipLaunchKernelGGL(k_repeat, dim3(grid_for(total, 256)), dim3(256), 0, sc.stream(), dnew, bx, dold, n_old, ny, nz, total);
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(repeat)

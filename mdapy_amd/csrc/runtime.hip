@@ -332,6 +332,61 @@ int make_box(DBox &b, const double *box9, const double *origin3, const int *boun
 
 } // namespace mdh
 
+namespace mdh {
+void warm_prof(hipStream_t st);
+void warm_neighbor(hipStream_t st);
+void warm_neighbor_tiled(hipStream_t st);
+void warm_neighbor_lane(hipStream_t st);
+void warm_cna(hipStream_t st);
+void warm_csp(hipStream_t st);
+void warm_sbo(hipStream_t st);
+void warm_rdf(hipStream_t st);
+void warm_wcp(hipStream_t st);
+void warm_knn(hipStream_t st);
+void warm_repeat(hipStream_t st);
+void warm_ptm(hipStream_t st);
+void warm_ptm_stages(hipStream_t st);
+void warm_consumers(hipStream_t st);
+void warm_pft(hipStream_t st);
+void warm_voronoi(hipStream_t st);
+void warm_sfc(hipStream_t st);
+void warm_polycrystal(hipStream_t st);
+void warm_slab(hipStream_t st);
+void warm_text(hipStream_t st);
+}
+namespace mdh {
+__global__ void k_warm_runtime() {}
+// a launch that needs 256 bytes of private (scratch) memory per lane: the queue's scratch area is allocated at the first launch
+// that needs one, and again when a later kernel needs more per lane (1-17 ms on this chip); the stand-by kernels of the
+// fixed-cutoff CNA (244 B: its double-precision to-do pass) and the k-nearest search (up to 120 B of spills) are such kernels
+__global__ void k_warm_scratch(int n, int *out)
+{
+    volatile int a[64];
+    for (int i = 0; i < n; ++i) a[(i * 7) & 63] = i;
+    if (n > 0) out[0] = a[n & 63];
+}
+// smallest and largest entry of an int32 array: out[0], out[1] preset to INT_MAX / INT_MIN
+__global__ __launch_bounds__(256) void k_min_max_i32(const int *__restrict__ v, int64_t n, int *__restrict__ out)
+{
+    int lo = 2147483647, hi = -2147483647 - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = v[i];
+        lo = min(lo, x);
+        hi = max(hi, x);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (lo < __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out, lo);
+        if (hi > __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out + 1, hi);
+    }
+}
+__global__ void k_min_max_init(int *out) { out[0] = 2147483647; out[1] = -2147483647 - 1; }
+}
+
 // ----------------------------------------------------------------------------
 // C ABI: runtime
 // ----------------------------------------------------------------------------
@@ -349,10 +404,68 @@ int mdh_device_count(void)
     return n;
 }
 
+int mdh_warm(void)
+{
+    static std::mutex mu;
+    static unsigned long long done = 0; // one bit per device
+    int device = 0;
+    MDH_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 64 && ((done >> device) & 1ull))
+        return MDH_OK;
+    hipLaunchKernelGGL(mdh::k_warm_runtime, dim3(1), dim3(64), 0, nullptr);
+    hipLaunchKernelGGL(mdh::k_warm_scratch, dim3(1), dim3(64), 0, nullptr, 0, static_cast<int *>(nullptr));
+    mdh::warm_prof(nullptr);
+    mdh::warm_neighbor(nullptr);
+    mdh::warm_neighbor_tiled(nullptr);
+    mdh::warm_neighbor_lane(nullptr);
+    mdh::warm_cna(nullptr);
+    mdh::warm_csp(nullptr);
+    mdh::warm_sbo(nullptr);
+    mdh::warm_rdf(nullptr);
+    mdh::warm_wcp(nullptr);
+    mdh::warm_knn(nullptr);
+    mdh::warm_repeat(nullptr);
+    mdh::warm_ptm(nullptr);
+    mdh::warm_ptm_stages(nullptr);
+    mdh::warm_consumers(nullptr);
+    mdh::warm_pft(nullptr);
+    mdh::warm_voronoi(nullptr);
+    mdh::warm_sfc(nullptr);
+    mdh::warm_polycrystal(nullptr);
+    mdh::warm_slab(nullptr);
+    mdh::warm_text(nullptr);
+    MDH_HIP(hipGetLastError());
+    MDH_HIP(hipStreamSynchronize(nullptr));
+    if (device < 64) done |= 1ull << device;
+    return MDH_OK;
+}
+
+int mdh_min_max_i32(const int *v, int64_t n, int *min_max2, int space, void *stream)
+{
+    if (n <= 0 || !min_max2) { mdh::set_error("mdh_min_max_i32: empty array"); return MDH_ERR_ARG; }
+    mdh::Scope sc(stream);
+    const int *dv = sc.stage_in(v, (size_t)n, space);
+    int *out = sc.alloc_n<int>(2);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    // the answer lands in page-locked memory of this thread (a copy into pageable memory goes through the runtime's staging path)
+    static thread_local int *pinned = nullptr;
+    if (!pinned) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 2 * sizeof(int), hipHostMallocDefault));
+    hipLaunchKernelGGL(mdh::k_min_max_init, dim3(1), dim3(1), 0, st, out);
+    hipLaunchKernelGGL(mdh::k_min_max_i32, dim3((unsigned)std::min<int64_t>(1024, (n + 1023) / 1024)), dim3(256), 0, st, dv, n, out);
+    MDH_HIP(hipMemcpyAsync(pinned, out, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    MDH_HIP(hipStreamSynchronize(st));
+    min_max2[0] = pinned[0];
+    min_max2[1] = pinned[1];
+    return MDH_OK;
+}
+
 int mdh_set_device(int device)
 {
     MDH_HIP(hipSetDevice(device));
-    return MDH_OK;
+    return mdh_warm();
 }
 
 int mdh_release_workspace(void)

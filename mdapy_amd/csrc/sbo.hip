@@ -631,3 +631,5 @@ int mdh_identify_solid_liquid(int q6index, const double *Q6, const int *verlet, 
     return sc.finish(space);
 }
 }
+
+MDH_WARM_UNIT(sbo)

@@ -258,3 +258,5 @@ extern "C" int mdh_sfc_direct_partial(const double *x, const double *y, const do
         }
     return MDH_OK;
 }
+
+MDH_WARM_UNIT(sfc)

@@ -205,3 +205,5 @@ extern "C" int mdh_slab_halo_select(const double *x, const double *y, const doub
     counts_host[1] = c[1];
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(slab)

@@ -335,3 +335,5 @@ extern "C" int mdh_parse_table(const char *text, int64_t nbytes, int text_space,
     status4[3] = nlines;
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(text)

@@ -563,3 +563,5 @@ extern "C" int mdh_voronoi_row_distance(const int *verlet, int64_t N, int width,
         hipLaunchKernelGGL(k_row_distance<false>, grid, block, 0, sc.stream(), dv, N, width, dx, dy, dz, b, dd);
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(voronoi)

@@ -117,3 +117,5 @@ extern "C" int mdh_wcp_counts(const int *verlet, const int *nn, const int *type,
         hipLaunchKernelGGL(k_wcp_count, dim3(grid_for(N, 256)), dim3(256), sizeof(unsigned) * (size_t)words, st, dv, dn, dt, dr, N, M, ntype, dc);
     return sc.finish(space);
 }
+
+MDH_WARM_UNIT(wcp)

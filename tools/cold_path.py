@@ -48,6 +48,9 @@ print(f"# {N} atoms ({cells}^3 fcc cells, sigma 0.05), import torch + mdapy_amd 
 if "apis" in what:
     t_ctx, _ = lap(lambda: torch.zeros(1, device="cuda"))
     print(f"# first touch of the device (context, torch allocator): {t_ctx:.1f} ms")
+    from mdapy_amd import _lib
+    t_lib, _ = lap(_lib.lib)
+    print(f"# library load + its code objects on the device (mdh_warm; MDAPY_HIP_WARM={os.environ.get('MDAPY_HIP_WARM', '1')}): {t_lib:.1f} ms")
     rounds = []
     for rnd in range(3):
         row = []
