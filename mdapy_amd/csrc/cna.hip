@@ -609,6 +609,7 @@ void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const do
 } // namespace mdh
 
 namespace mdh { int lane_last_listed(); } // neighbor_lane.hip
+namespace mdh { int moved_probe(int enable); } // neighbor.hip
 using namespace mdh;
 
 extern "C" {
@@ -629,6 +630,7 @@ int mdh_debug_track_counters(int on)
         *g_todo_probe = -1;
     }
     g_track_counters = on;
+    (void)mdh::moved_probe(on ? 1 : 0);
     return MDH_OK;
 }
 
@@ -636,7 +638,8 @@ int mdh_debug_counters(int64_t *out4)
 {
     out4[0] = g_todo_probe ? (int64_t)*(volatile int *)g_todo_probe : -1;
     out4[1] = (int64_t)mdh::lane_last_listed();
-    out4[2] = out4[3] = 0;
+    out4[2] = (int64_t)mdh::moved_probe(-1); // 1: the last tracked neighbor build found input it has no image codes for (thread-per-atom kernel)
+    out4[3] = 0;
     return MDH_OK;
 }
 

@@ -14,6 +14,25 @@ struct Grid {
     int mode;
 };
 
+// Image codes (orthogonal boxes).  An atom handed in outside the box on a periodic axis has raw = wrapped + m L, m a whole number
+// of box lengths (an unwrapped trajectory: atoms that have diffused through the faces); the cell grid sees the wrapped atom, the
+// reference's distances are computed from the raw one (neighbor.cpp:164-166) and then folded by L * floor(d / L + 0.5)
+// (box.h:120-124).  The tile kernels take that image number from codes instead of a division per pair:
+//   atom code      (m + 15) per axis, 5 bits each, m in [-14, 14] (more: the build's flags[0], the thread-per-atom kernel)
+//   cell code      (n + 1) per axis, 2 bits each: the candidate's cell seen from the tile, n in {-1, 0, 1}
+//   combined code  (n + m + 16) per axis, 5 bits each — fits the 16-bit LDS entry of a staged atom
+namespace img {
+constexpr int MAX_M = 14;
+constexpr int ATOM_NEUTRAL = 15 | (15 << 5) | (15 << 10);
+constexpr int CELL_NEUTRAL = 1 | (1 << 2) | (1 << 4);
+constexpr int NEUTRAL = 16 | (16 << 5) | (16 << 10); // combined code "no shift"
+__host__ __device__ __forceinline__ int combine(int cc, int ca)
+{
+    return ((cc & 3) + (ca & 31)) | ((((cc >> 2) & 3) + ((ca >> 5) & 31)) << 5) | ((((cc >> 4) & 3) + ((ca >> 10) & 31)) << 10);
+}
+__host__ __device__ __forceinline__ int axis(int code, int d) { return ((code >> (5 * d)) & 31) - 16; } // image number of a combined code
+} // namespace img
+
 // device buffers produced by build_cell_grid (owned by the Scope that built them)
 struct CellGrid {
     Grid g;
@@ -27,7 +46,7 @@ struct CellGrid {
     //                   periodic axis (unwrapped input) -> per-cell image shifts are not valid
     //   flags[1]      : largest cell population
     int *flags;
-    unsigned char *mvs; // [N] per-atom image code (raw vs wrapped coordinate), in `order`
+    unsigned short *mvs; // [N] per-atom image code (raw vs wrapped coordinate; img::), in `order`
     // [N] the same five values as one 32-byte record per atom (neighbor builds): the tile kernel stages an atom with two
     // 16-byte requests instead of five small ones
     struct Packed { double x, y, z; int id, code; };

@@ -26,6 +26,7 @@
 
 namespace mdh {
 
+static int *g_moved_probe = nullptr; // pinned: flags[0] of the last tracked neighbor pass (mdh_debug_track_counters)
 int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel, 2 = force the round-1 LDS-tiled kernel (A/B measurements, tests)
 
 // ----------------------------------------------------------------------------
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
                                                 unsigned *__restrict__ cell_count, unsigned *__restrict__ ctl, unsigned gen,
-                                                double slack, unsigned char *__restrict__ mv, CellPlanes win)
+                                                double slack, unsigned short *__restrict__ mv, CellPlanes win)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false, outside = false, coded = false;
@@ -45,12 +46,13 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
     if (i < N) {
         const double xr = x[i], yr = y[i], zr = z[i];
         double xi = xr, yi = yr, zi = zr;
-        int code = 1 | (1 << 2) | (1 << 4); // (m+1) per axis: raw = wrapped + m*L
+        int code = img::ATOM_NEUTRAL; // (m + 15) per axis: raw = wrapped + m*L
         if (wrap_first && b.anypbc) { // neighbor.cpp:88-91
             wrap<TRI>(b, xi, yi, zi);
             if (!TRI) {
-                // whole box lengths between the raw and the wrapped coordinate; anything that is not a clean
-                // -1/0/+1 (far-unwrapped input) invalidates the image codes for this call (flags[0])
+                // whole box lengths between the raw and the wrapped coordinate (an unwrapped trajectory: a few); more than
+                // img::MAX_M of them, or a coordinate that is not wrapped + m L to within `slack`, invalidates the image codes
+                // for this call (flags[0])
                 const double raw[3] = {xr, yr, zr}, wrp[3] = {xi, yi, zi};
                 code = 0;
 #pragma unroll
@@ -58,14 +60,14 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                     double m = 0.0;
                     if (b.pbc[d] && raw[d] != wrp[d]) { // already wrapped (the common case): m = 0, no division
                         m = rint((raw[d] - wrp[d]) / b.h[d * 4]);
-                        if (!(fabs(m) <= 1.0) || !(fabs(raw[d] - m * b.h[d * 4] - wrp[d]) <= slack)) { moved = true; m = 0.0; }
+                        if (!(fabs(m) <= (double)img::MAX_M) || !(fabs(raw[d] - m * b.h[d * 4] - wrp[d]) <= slack)) { moved = true; m = 0.0; }
                     }
-                    code |= ((int)m + 1) << (2 * d);
+                    code |= ((int)m + 15) << (5 * d);
                 }
             }
         }
-        if (mv) mv[i] = (unsigned char)code;
-        coded = code != (1 | (1 << 2) | (1 << 4));
+        if (mv) mv[i] = (unsigned short)code;
+        coded = code != img::ATOM_NEUTRAL;
         int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
         cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
                                                 const double *__restrict__ z, const int *__restrict__ order,
                                                 double *__restrict__ xs, double *__restrict__ ys,
                                                 double *__restrict__ zs, int64_t N,
-                                                const unsigned char *__restrict__ mv, unsigned char *__restrict__ mvs,
+                                                const unsigned short *__restrict__ mv, unsigned short *__restrict__ mvs,
                                                 CellGrid::Packed *__restrict__ pk, const int *__restrict__ any_code,
                                                 const int *__restrict__ n_binned)
 {
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
     const int i = order[p];
     const double a = x[i], b = y[i], c = z[i];
     // the image codes are a fourth scattered read per atom (one byte each); k_assign says whether any of them is not neutral
-    const unsigned char m = *any_code ? mv[i] : (unsigned char)(1 | (1 << 2) | (1 << 4));
+    const unsigned short m = *any_code ? mv[i] : (unsigned short)img::ATOM_NEUTRAL;
     if (pk) {
         pk[p] = CellGrid::Packed{a, b, c, i, (int)m};
         return;
@@ -388,13 +390,13 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
 }
 
 __global__ __launch_bounds__(256) void k_unpack(const CellGrid::Packed *__restrict__ pk, int64_t N, double *__restrict__ xs,
-                                                double *__restrict__ ys, double *__restrict__ zs, unsigned char *__restrict__ mvs)
+                                                double *__restrict__ ys, double *__restrict__ zs, unsigned short *__restrict__ mvs)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N)
         return;
     const CellGrid::Packed r = pk[p];
-    xs[p] = r.x; ys[p] = r.y; zs[p] = r.z; mvs[p] = (unsigned char)r.code;
+    xs[p] = r.x; ys[p] = r.y; zs[p] = r.z; mvs[p] = (unsigned short)r.code;
 }
 
 int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N)
@@ -404,7 +406,7 @@ int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N)
     cg.xs = sc.alloc_n<double>((size_t)N);
     cg.ys = sc.alloc_n<double>((size_t)N);
     cg.zs = sc.alloc_n<double>((size_t)N);
-    cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
+    cg.mvs = sc.alloc_n<unsigned short>((size_t)N);
     if (sc.failed())
         return sc.error();
     hipLaunchKernelGGL(k_unpack, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.pk, N, cg.xs, cg.ys, cg.zs, cg.mvs);
@@ -476,7 +478,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     int *cell_id = sc.alloc_n<int>((size_t)N);
     int *rank = sc.alloc_n<int>((size_t)N);
     cg.order = sc.alloc_n<int>((size_t)N);
-    unsigned char *mv = sc.alloc_n<unsigned char>((size_t)N);
+    unsigned short *mv = sc.alloc_n<unsigned short>((size_t)N);
     cg.xs = cg.ys = cg.zs = nullptr;
     cg.mvs = nullptr;
     cg.pk = nullptr;
@@ -486,7 +488,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         cg.xs = sc.alloc_n<double>((size_t)N);
         cg.ys = sc.alloc_n<double>((size_t)N);
         cg.zs = sc.alloc_n<double>((size_t)N);
-        cg.mvs = sc.alloc_n<unsigned char>((size_t)N);
+        cg.mvs = sc.alloc_n<unsigned short>((size_t)N);
     }
     if (sc.failed())
         return sc.error();
@@ -999,8 +1001,24 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
     if (mode == 0) launch_neighbor<0>(st, cg, N, b, rc, nullptr, nullptr, dn, 1, dmax, tf);
     else if (mode == 2) launch_neighbor<2>(st, cg, N, b, rc, dv, dd, dn, M, nullptr, tf);
     else launch_neighbor<1>(st, cg, N, b, rc, dv, dd, dn, M, nullptr, tf);
+    if (g_moved_probe) // mdh_debug_track_counters(1): the build's "image codes not valid" flag, for mdh_debug_counters
+        MDH_HIP(hipMemcpyAsync(g_moved_probe, cg.flags, sizeof(int), hipMemcpyDeviceToHost, st));
     MDH_HIP(hipGetLastError());
     return MDH_OK;
+}
+
+int moved_probe(int enable) // enable > 0: start tracking; 0: stop; < 0: the last value (-1: none)
+{
+    if (enable > 0 && !g_moved_probe) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&g_moved_probe), sizeof(int), hipHostMallocDefault) != hipSuccess) { g_moved_probe = nullptr; return -1; }
+        *g_moved_probe = -1;
+    } else if (enable == 0 && g_moved_probe) {
+        int *p = g_moved_probe;
+        g_moved_probe = nullptr;
+        (void)hipDeviceSynchronize();
+        (void)hipHostFree(p);
+    }
+    return g_moved_probe ? *(volatile int *)g_moved_probe : -1;
 }
 
 } // namespace mdh

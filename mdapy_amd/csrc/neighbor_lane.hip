@@ -64,8 +64,8 @@ namespace lane {
 // A workgroup is NW waves (template parameter of the kernel): 4 — 256 threads, four workgroups per CU — or 8 for the big-tile
 // instance — 512 threads, two per CU.  A tile has at most one halo cell per thread.
 constexpr int cen_cap(int nw) { return 80 * nw; } // centre atoms a tile may hold
-static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4);   // image code "no shift": (n+1) per axis, 2 bits each
-static constexpr int NEUTRAL3 = 2 | (2 << 3) | (2 << 6);  // combined code "no shift": (n+2) per axis, 3 bits each
+static constexpr int NEUTRAL = img::CELL_NEUTRAL;  // a halo cell's image code "no shift" (grid.hpp img::)
+static constexpr int NEUTRAL3 = img::NEUTRAL;      // combined code "no shift"
 
 // exact n / d for 32-bit n by multiply and shift (Granlund & Montgomery, "Division by invariant integers using
 // multiplication", fig. 4.1): the tile and halo-cell coordinates of a workgroup come from divisions by launch constants, and a
@@ -138,11 +138,8 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
     return off + inc - v;
 }
 
-// cell code cc and atom code ca (each (n+1) per axis in 2 bits) -> combined code ((n_cell + m_atom) + 2 per axis in 3 bits)
-__device__ __forceinline__ int combine_codes(int cc, int ca)
-{
-    return ((cc & 3) + (ca & 3)) | ((((cc >> 2) & 3) + ((ca >> 2) & 3)) << 3) | ((((cc >> 4) & 3) + ((ca >> 4) & 3)) << 6);
-}
+// cell code cc and atom code ca -> combined code (grid.hpp img::)
+__device__ __forceinline__ int combine_codes(int cc, int ca) { return img::combine(cc, ca); }
 
 // the reference's squared distance of one pair: raw x[j] - wrapped x[i] (neighbor.cpp:164-166), minimum image
 // d - L*floor(d/L+0.5) with the image number n taken from the code (box.h:120-124; L*n exact, d - L*0 == d), then
@@ -155,9 +152,9 @@ __device__ __forceinline__ double exact_d2(const DBox &b, double xj, double yj, 
 {
     double dx = xj - xi, dy = yj - yi, dz = zj - zi;
     if (KIND == 1) {
-        dx = dx - b.h[0] * (double)((code & 7) - 2);
-        dy = dy - b.h[4] * (double)(((code >> 3) & 7) - 2);
-        dz = dz - b.h[8] * (double)(((code >> 6) & 7) - 2);
+        dx = dx - b.h[0] * (double)img::axis(code, 0);
+        dy = dy - b.h[4] * (double)img::axis(code, 1);
+        dz = dz - b.h[8] * (double)img::axis(code, 2);
     }
     if (KIND == 2)
         pbc<true>(b, dx, dy, dz);
@@ -534,20 +531,20 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
         // ---- stage this cell's atoms
         if (ok && cnt > 0) {
             double X0, Y0, Z0, XS, YS, ZS;
-            const int code0 = combine_codes(img, NEUTRAL); // an atom inside the box (image code 0): the cell's own shift
+            const int code0 = combine_codes(img, img::ATOM_NEUTRAL); // an atom inside the box (image number 0): the cell's own shift
             if (TRI) { // corner of the tile's halo and the cell's lattice shift, through the cell vectors (rows of h)
                 // (cell k of axis d starts at the fraction k * rc / thickness_d: cells of perpendicular width rc, grid.hpp)
-                const double f0 = (double)(T0 - 1) * (cw / b.thick[0]) + (double)((code0 & 7) - 2);
-                const double f1 = (double)(T1 - 1) * (cw / b.thick[1]) + (double)(((code0 >> 3) & 7) - 2);
-                const double f2 = (double)(T2 - 1) * (cw / b.thick[2]) + (double)(((code0 >> 6) & 7) - 2);
+                const double f0 = (double)(T0 - 1) * (cw / b.thick[0]) + (double)img::axis(code0, 0);
+                const double f1 = (double)(T1 - 1) * (cw / b.thick[1]) + (double)img::axis(code0, 1);
+                const double f2 = (double)(T2 - 1) * (cw / b.thick[2]) + (double)img::axis(code0, 2);
                 XS = b.o[0] + f0 * b.h[0] + f1 * b.h[3] + f2 * b.h[6];
                 YS = b.o[1] + f0 * b.h[1] + f1 * b.h[4] + f2 * b.h[7];
                 ZS = b.o[2] + f0 * b.h[2] + f1 * b.h[5] + f2 * b.h[8];
                 X0 = XS; Y0 = YS; Z0 = ZS;
             } else {
                 X0 = b.o[0] + (double)(T0 - 1) * cw; Y0 = b.o[1] + (double)(T1 - 1) * cw; Z0 = b.o[2] + (double)(T2 - 1) * cw;
-                XS = X0 + b.h[0] * (double)((code0 & 7) - 2); YS = Y0 + b.h[4] * (double)(((code0 >> 3) & 7) - 2);
-                ZS = Z0 + b.h[8] * (double)(((code0 >> 6) & 7) - 2);
+                XS = X0 + b.h[0] * (double)img::axis(code0, 0); YS = Y0 + b.h[4] * (double)img::axis(code0, 1);
+                ZS = Z0 + b.h[8] * (double)img::axis(code0, 2);
             }
             const float flo = (float)(-1.5 * cw);
             const float fhx = (float)(((double)HXY + 1.5) * cw), fhz = (float)(((double)HZ + 1.5) * cw);
@@ -566,11 +563,11 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                         } else {
                             ux = (float)(a[v] - XS); uy = (float)(bb[v] - YS); uz = (float)(c[v] - ZS);
                         }
-                        if (!TRI && m[v] != NEUTRAL) { // an atom handed in outside the box on a periodic axis: its own image number on top
+                        if (!TRI && m[v] != img::ATOM_NEUTRAL) { // an atom handed in outside the box on a periodic axis: its own image number on top
                             code = combine_codes(img, m[v]);
-                            ux = (float)((a[v] - b.h[0] * (double)((code & 7) - 2)) - X0);
-                            uy = (float)((bb[v] - b.h[4] * (double)(((code >> 3) & 7) - 2)) - Y0);
-                            uz = (float)((c[v] - b.h[8] * (double)(((code >> 6) & 7) - 2)) - Z0);
+                            ux = (float)((a[v] - b.h[0] * (double)img::axis(code, 0)) - X0);
+                            uy = (float)((bb[v] - b.h[4] * (double)img::axis(code, 1)) - Y0);
+                            uz = (float)((c[v] - b.h[8] * (double)img::axis(code, 2)) - Z0);
                             general = true;
                         }
                         // the decision band assumes coordinates inside the tile's halo; an atom clamped into an edge cell from
@@ -1284,7 +1281,8 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
         for (int d = 0; d < 3; ++d) big += std::fabs(b.o[d]);
         big *= 4.0; // the wrap and the frame shift go through the fractional coordinates: a few more roundings
     } else {
-        for (int d = 0; d < 3; ++d) big = std::max(big, std::fabs(b.o[d]) + 2.0 * std::fabs(b.h[d * 4]) + E);
+        // (a raw coordinate may be img::MAX_M + 1 box lengths away from the box: the shift L * n loses at most an ulp of THAT)
+        for (int d = 0; d < 3; ++d) big = std::max(big, std::fabs(b.o[d]) + (double)(img::MAX_M + 2) * std::fabs(b.h[d * 4]) + E);
     }
     const double du = std::ldexp(E, -24) * 1.01 + std::ldexp(big, -49);
     const double rcsq = rc * rc;

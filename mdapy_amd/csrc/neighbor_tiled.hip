@@ -55,7 +55,7 @@ static constexpr int NT = 256;        // threads per workgroup
 static constexpr int MAX_NH = MDH_MAX_NH;    // halo cells a tile may have
 static constexpr int MAX_COLS = 64;   // (x,y) columns of centre cells a tile may have
 static constexpr int TICK_STRIDE = NT + 2; // ticket slot stride (u16 units): 516 B -> consecutive slots shift by one bank
-static constexpr int NEUTRAL = 1 | (1 << 2) | (1 << 4); // image code of "no shift": (n+1) per axis, 2 bits each
+static constexpr int NEUTRAL = img::CELL_NEUTRAL; // a halo cell's image code "no shift" (grid.hpp img::)
 
 // Tile shape (cells): TXY x TXY x TZ
 struct TileShape { int txy, tz; };
@@ -83,12 +83,8 @@ __device__ __forceinline__ int excl_scan_block(int v, int *scratch, int *total)
 }
 
 // L * n for a staged atom's combined image number n = n_cell + m_atom in [-2, 2], stored as n + 2 in three bits per axis
-__device__ __forceinline__ double img_shift(double L, int code) { return L * (double)(code - 2); }
-// cell code cc and atom code ca (each (n+1) per axis in 2 bits) -> combined code ((n_cell + m_atom) + 2 per axis in 3 bits)
-__device__ __forceinline__ int combine_codes(int cc, int ca)
-{
-    return ((cc & 3) + (ca & 3)) | ((((cc >> 2) & 3) + ((ca >> 2) & 3)) << 3) | ((((cc >> 4) & 3) + ((ca >> 4) & 3)) << 6);
-}
+// cell code cc and atom code ca -> combined code (grid.hpp img::)
+__device__ __forceinline__ int combine_codes(int cc, int ca) { return img::combine(cc, ca); }
 
 // squared distance of one (centre, candidate) pair.
 //   PBCMODE 0: no shift at all (tile away from the seam, all atoms wrapped): d - L*0 == d
@@ -100,9 +96,9 @@ __device__ __forceinline__ double pair_d2_tiled(const DBox &b, double xj, double
 {
     double dx = xj - xi, dy = yj - yi, dz = zj - zi; // raw x[j] - wrapped centre (neighbor.cpp:164-166)
     if (PBCMODE == 1) {
-        dx = dx - img_shift(b.h[0], sh & 7); // == xij - L*floor(xij/L+0.5)   (box.h:120-124)
-        dy = dy - img_shift(b.h[4], (sh >> 3) & 7);
-        dz = dz - img_shift(b.h[8], (sh >> 6) & 7);
+        dx = dx - b.h[0] * (double)img::axis(sh, 0); // == xij - L*floor(xij/L+0.5)   (box.h:120-124)
+        dy = dy - b.h[4] * (double)img::axis(sh, 1);
+        dz = dz - b.h[8] * (double)img::axis(sh, 2);
     } else if (PBCMODE == 2) {
         pbc<false>(b, dx, dy, dz);
     }
@@ -176,7 +172,7 @@ __device__ __forceinline__ int scan_centre(const DBox &b, const TileLds &L, cons
 template <bool CELLSHIFT, int MODE, bool LIST>
 __global__ __launch_bounds__(NT) void k_neighbor_tiled(
     const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
-    const int *__restrict__ order, const unsigned char *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
+    const int *__restrict__ order, const unsigned short *__restrict__ mvs, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn, int M, int mp_shift,
     int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0, int nt1, int nt2, int want_moved,
     TileShape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live)
@@ -278,21 +274,21 @@ __global__ __launch_bounds__(NT) void k_neighbor_tiled(
         for (; k + 4 <= cnt; k += 4) { // four independent loads in flight per array
             double a[4], bb[4], c[4];
             int d[4];
-            unsigned char m[4];
+            int m[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) { a[v] = xs[src + k + v]; bb[v] = ys[src + k + v]; c[v] = zs[src + k + v]; d[v] = order[src + k + v]; m[v] = mvs[src + k + v]; }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 L.lx[off + k + v] = a[v]; L.ly[off + k + v] = bb[v]; L.lz[off + k + v] = c[v]; L.lid[off + k + v] = d[v];
                 L.lsh[off + k + v] = (unsigned short)combine_codes(img2[u], m[v]);
-                general = general || (m[v] != NEUTRAL);
+                general = general || (m[v] != img::ATOM_NEUTRAL);
             }
         }
         for (; k < cnt; ++k) {
-            const unsigned char m = mvs[src + k];
+            const int m = mvs[src + k];
             L.lx[off + k] = xs[src + k]; L.ly[off + k] = ys[src + k]; L.lz[off + k] = zs[src + k]; L.lid[off + k] = order[src + k];
             L.lsh[off + k] = (unsigned short)combine_codes(img2[u], m);
-            general = general || (m != NEUTRAL);
+            general = general || (m != img::ATOM_NEUTRAL);
         }
     }
     const int tile_general = __syncthreads_or(general ? 1 : 0); // also publishes h_off / staged atoms

@@ -44,6 +44,8 @@ def _cases():
     p, b = _fcc(6, 0.1, 3)
     p2 = p + rng.integers(-2, 3, p.shape) * np.diag(b)  # unwrapped input: atoms whole box lengths away
     out.append(("fcc_unwrapped", p2, b, ORG0, PBC))
+    p3 = p + rng.integers(-13, 14, p.shape) * np.diag(b)  # an unwrapped trajectory after a long run: up to 13 box lengths away
+    out.append(("fcc_unwrapped_far", p3 + np.array([4.0, -2.5, 9.0]), b, np.array([4.0, -2.5, 9.0]), PBC))
     out.append(("slab_open_z", p, b, ORG0, np.array([1, 1, 0], np.int32)))
     out.append(("cluster_open", p, b * 1.0, ORG0, np.array([0, 0, 0], np.int32)))
     tri = np.array([[22.0, 0.0, 0.0], [4.0, 21.0, 0.0], [-3.0, 5.0, 20.0]])
@@ -92,6 +94,35 @@ def test_neighbor_bit_exact_vs_oracle(case, rc):
     O.build_neighbor(x, y, z, box, org, bnd, rc, va, da, na, 4)
     _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vb, db, nb, 1)
     assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+
+
+def test_unwrapped_input_takes_the_tile_kernel():
+    """atoms handed in up to 14 box lengths outside an orthogonal periodic box (an unwrapped trajectory) carry their image number
+    in the cell-sorted record and go through the LDS-tile kernel (asserted through the build's device flag); farther out the
+    thread-per-atom kernel takes the whole call.  Rows bit for bit the oracle's either way (src/neighbor.cpp:139-177: raw
+    x[j] - wrapped x[i], then box.h:120-124)."""
+    import ctypes
+    from mdapy_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(23)
+    pos, box = _fcc(9, 0.08, 4)  # 32.5 A: ten cells of 3.2 A per axis
+    org, rc = np.array([-1.0, 2.0, 0.25]), 3.2
+    out4 = (ctypes.c_int64 * 4)()
+    L.mdh_debug_track_counters(1)
+    try:
+        for reach, moved in ((1, 0), (14, 0), (15, 1), (40, 1)):
+            shift = rng.integers(-reach, reach + 1, pos.shape)
+            shift[0] = reach; shift[1] = -reach  # the extremes are there
+            p = pos % np.diag(box) + shift * np.diag(box) + org
+            x, y, z = _xyz(p)
+            v0, d0, n0 = O.build_neighbor_without_max_neigh(x, y, z, box, org, PBC, rc, 4)
+            v1, d1, n1 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, PBC, rc, 1)
+            L.mdh_debug_counters(out4)
+            assert int(out4[2]) == moved, (reach, list(out4))
+            assert np.array_equal(n1, n0) and np.array_equal(v1, v0) and np.array_equal(d1, d0), reach
+    finally:
+        L.mdh_debug_track_counters(0)
 
 
 def test_neighbor_tile_overflow_and_variants():

@@ -22,6 +22,12 @@ if len(sys.argv) > 6:  # sheared box: the same fractional coordinates in a tricl
     Hm = np.array([[Lb, 0, 0], [sh * Lb, Lb, 0], [0.5 * sh * Lb, sh * Lb, Lb]])
     x, y, z = x + sh * y + 0.5 * sh * z, y + sh * z, z
     box = mp.Box(Hm)
+if os.environ.get('NB_UNWRAP'):  # an unwrapped trajectory: every atom handed in a few whole box lengths away (orthogonal box)
+    k = int(os.environ['NB_UNWRAP']); Lb = A_CU * cells
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    x = x + Lb * torch.randint(-k, k + 1, (n,), device=dev, generator=gen).double()
+    y = y + Lb * torch.randint(-k, k + 1, (n,), device=dev, generator=gen).double()
+    z = z + Lb * torch.randint(-k, k + 1, (n,), device=dev, generator=gen).double()
 if os.environ.get('NB_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['NB_LIB'])  # A/B against another build of the library
 L = _lib.lib()
 if os.environ.get('NB_VARIANT'): L.mdh_debug_set_neighbor_variant(int(os.environ['NB_VARIANT']))
