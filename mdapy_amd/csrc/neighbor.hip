@@ -977,7 +977,7 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
     cg.flags_fresh = false;
     TileFilter tf{};
     bool done = false;
-    if (g_neighbor_variant == 0) { // tile kernel (orthogonal boxes, and triclinic ones periodic along all three vectors); the thread-per-atom code below then only mops up what it listed
+    if (g_neighbor_variant == 0) { // tile kernel (orthogonal and triclinic boxes); the thread-per-atom code below then only mops up what it listed
         GridStats gs;
         MDH_TRY(grid_stats_hint(sc, cg, N, &gs));
         const bool cna = pattern && mode != 0;

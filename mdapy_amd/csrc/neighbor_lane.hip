@@ -3,7 +3,7 @@
 //
 // Same result, bit for bit, as the thread-per-atom kernel in neighbor.hip and therefore as src/neighbor.cpp:102-187 of
 // the reference (ids, order inside a row, counts, distances).  This is the fast path of mdh_build_neighbor /
-// mdh_neighbor_count / mdh_build_neighbor_exact for orthogonal boxes and for triclinic ones periodic along all three vectors.
+// mdh_neighbor_count / mdh_build_neighbor_exact for orthogonal and triclinic boxes, periodic or open along any of their vectors.
 //
 // A workgroup owns a tile of TXY x TXY x TZ cells and stages the atoms of the halo ((TXY+2)^2 x (TZ+2) cells, ONE CELL
 // PER THREAD, two 16-byte loads per atom from the cell-sorted 32-byte records) into LDS once: raw doubles for the values that are written,
@@ -41,9 +41,10 @@
 // state costs 140 scalar-register spills.  Tiles whose halo does not fit the LDS budget are listed and taken by a SECOND
 // launch of the same kernel on one-cell slices of those tiles; what is left after that (a dense blob, atoms far outside the
 // box on an open axis, a run longer than the instance's masks) is listed again for the thread-per-atom code
-// (k_neighbor_tiles).  Not taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): open triclinic
-// boxes, fewer than 7 cells on a periodic axis or 4 on an open one, unwrapped input (device flag), max_neigh > 64, grids
-// where more than 5 % of the runs hold 59 atoms or more.
+// (k_neighbor_tiles).  Not taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): fewer than 7 cells on
+// a periodic axis or 4 on an open one, atoms more than 14 box lengths outside an orthogonal periodic box (device flag; nearer
+// ones carry their image number in their record, grid.hpp img::), max_neigh > 64, grids where more than 5 % of the runs hold 59
+// atoms or more.
 //
 // Measured (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16; DESIGN.md 3a has the counters, the per-phase time stamps of the
 // MDH_STAMPS build and the tables of what moved the kernel and what was built and not kept): round-1 tiled kernel 1.78 ms,
@@ -362,7 +363,8 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
 // parent != nullptr: second pass over the tiles the first pass listed (halo over the LDS budget): the same tiling cut into
 // nsub slices along z (this launch's TZ = parent's TZ / nsub); what still does not fit goes to `flagged` (counter
 // flags[flag_slot]) and from there to the thread-per-atom code
-// TRI: triclinic box, periodic along all three vectors.  Cells are parallelepipeds in fractional coordinates; the staged
+// TRI: triclinic box (open vectors as in the orthogonal case: no cell beyond the face is staged, atoms outside the box sit in the
+// edge cells and are checked against the halo in cell units).  Cells are parallelepipeds in fractional coordinates; the staged
 // single-precision coordinates are Cartesian, relative to the tile's corner, of the WRAPPED atom shifted by the lattice
 // vectors its cell is away from the tile; every decision inside the band and every written distance goes through the
 // reference's fractional fold.
@@ -556,10 +558,18 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                     if (k + v < cnt) {
                         int code = code0;
                         float ux, uy, uz;
-                        if (TRI) { // the atom as the cell grid saw it (wrapped), in the tile's frame
+                        if (TRI) { // the atom as the cell grid saw it (wrapped along the periodic vectors), in the tile's frame
                             double wx = a[v], wy = bb[v], wz = c[v];
                             wrap<true>(b, wx, wy, wz);
-                            ux = (float)(wx - XS); uy = (float)(wy - YS); uz = (float)(wz - ZS);
+                            const double rx = wx - XS, ry = wy - YS, rz = wz - ZS;
+                            ux = (float)rx; uy = (float)ry; uz = (float)rz;
+                            if (edge) { // first / last cell of an OPEN vector: an atom clamped into it from outside the box may be anywhere —
+                                // its place in units of cells along the three vectors, counted from the halo's corner
+                                const double s0 = (rx * b.hi[0] + ry * b.hi[3] + rz * b.hi[6]) * (b.thick[0] / cw);
+                                const double s1 = (rx * b.hi[1] + ry * b.hi[4] + rz * b.hi[7]) * (b.thick[1] / cw);
+                                const double s2 = (rx * b.hi[2] + ry * b.hi[5] + rz * b.hi[8]) * (b.thick[2] / cw);
+                                far = far || !(s0 >= -1.5 && s0 <= (double)HXY + 1.5 && s1 >= -1.5 && s1 <= (double)HXY + 1.5 && s2 >= -1.5 && s2 <= (double)HZ + 1.5);
+                            }
                         } else {
                             ux = (float)(a[v] - XS); uy = (float)(bb[v] - YS); uz = (float)(c[v] - ZS);
                         }
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                         }
                         // the decision band assumes coordinates inside the tile's halo; an atom clamped into an edge cell from
                         // far outside the box (open axis) sends the tile to the thread-per-atom code
-                        if (edge)
+                        if (!TRI && edge)
                             far = far || !(ux >= flo && ux <= fhx && uy >= flo && uy <= fhx && uz >= flo && uz <= fhz);
                         const int p = off0 + k + v;
 #ifdef MDH_EXP_GATHER // measuring build (make gather): the staged atom carries its record's index, not its id
@@ -1174,7 +1184,6 @@ static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw, int nw = 4)
 static int lane_refusal(const DBox &b, const Grid &g, int64_t M)
 {
     if (g.mode != 0 || M <= 0 || M > 64) return -1;
-    if (b.tri && !(b.pbc[0] && b.pbc[1] && b.pbc[2])) return -2; // open triclinic boxes: thread-per-atom kernel
     for (int d = 0; d < 3; ++d)
         if (g.nc[d] < (b.pbc[d] ? 7 : 4)) return -3; // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
     return 0;

@@ -67,6 +67,14 @@ def _cases():
     fr = fr + (rng.random(fr.shape) < 0.02) * rng.integers(-1, 2, fr.shape)
     org = np.array([2.0, -7.5, 11.0])
     out.append(("triclinic_fcc_sheared", fr @ shear + org, shear, org, PBC))
+    # the same sheared box OPEN along one / two vectors (a slab, a wire): the tile kernel clamps instead of wrapping there; a few
+    # atoms handed in outside the box along the open vectors (clamped into the edge cells, box.h:131-156 leaves them where they
+    # are), two of them far outside (their tiles go to the thread-per-atom code)
+    fo = fr.copy()
+    fo[:40] += rng.normal(0.0, 0.08, (40, 3)) * np.array([0, 1, 0]) + np.array([0, 1.0, 0]) * (rng.random((40, 1)) < 0.5)
+    fo[40] += np.array([0, 7.5, 0]); fo[41] -= np.array([0, 3.25, 0])
+    out.append(("triclinic_fcc_sheared_open_b", fo @ shear + org, shear, org, np.array([1, 0, 1], np.int32)))
+    out.append(("triclinic_fcc_sheared_open_ac", fr @ shear + org, shear, org, np.array([0, 1, 0], np.int32)))
     big = np.array([[60.0, 0.0, 0.0], [6.0, 60.0, 0.0], [3.0, -6.0, 60.0]])
     fr = np.concatenate([rng.random((2500, 3)) * 0.41 + 0.3, rng.random((2500, 3))])  # ~6 atoms per cell in the blob: tiles overflow, runs fit
     out.append(("triclinic_dense_blob", fr @ big, big, ORG0, PBC))
@@ -157,7 +165,7 @@ def test_neighbor_tile_overflow_and_variants():
             _lib.lib().mdh_debug_set_neighbor_variant(variant)
             try:
                 outs.append(_neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, 3.3, 1))
-                if name in ("triclinic_fcc_sheared", "triclinic_dense_blob"):  # fixed rows (narrow ones overflow inside the blob)
+                if name.startswith("triclinic_fcc_sheared") or name == "triclinic_dense_blob":  # fixed rows (narrow ones overflow inside the blob)
                     M = 20
                     va = np.full((len(x), M), -1, np.int32); da = np.full((len(x), M), 4.3); na = np.zeros(len(x), np.int32)
                     O.build_neighbor(x, y, z, box, org, bnd, 3.3, va, da, na, 4)

@@ -22,6 +22,8 @@ if len(sys.argv) > 6:  # sheared box: the same fractional coordinates in a tricl
     Hm = np.array([[Lb, 0, 0], [sh * Lb, Lb, 0], [0.5 * sh * Lb, sh * Lb, Lb]])
     x, y, z = x + sh * y + 0.5 * sh * z, y + sh * z, z
     box = mp.Box(Hm)
+if os.environ.get('NB_PBC'):  # e.g. 101: open along the second box vector
+    box = mp.Box(box.box, boundary=[int(ch) for ch in os.environ['NB_PBC']], origin=box.origin)
 if os.environ.get('NB_UNWRAP'):  # an unwrapped trajectory: every atom handed in a few whole box lengths away (orthogonal box)
     k = int(os.environ['NB_UNWRAP']); Lb = A_CU * cells
     gen = torch.Generator(device=dev); gen.manual_seed(5)
