@@ -65,6 +65,13 @@ int mdh_warm(void);
  * `neighbor_number.min() >= k` there, a numpy reduction): with the counts resident in HBM the reduction runs there.
  */
 int mdh_min_max_i32(const int *v, int64_t n, int *min_max2, int space, void *stream);
+/*
+ * Dense species codes of a numeric label column (host policy of src/mdapy/radial_distribution_function.py:83-110 and
+ * warren_cowley_parameter.py:76-112: `type - 1` / element -> sorted index, a numpy pass over N labels there): every value of
+ * [low, low + span), span <= 4096, that occurs gets the next code in ascending order; codes[i] = code of v[i] (0 for a value
+ * outside the range), counts_span[k] (host memory, span entries) = how often low + k occurs.  Waits for the stream.
+ */
+int mdh_dense_codes_i32(const int *v, int64_t n, int low, int span, int *codes, int64_t *counts_span, int space, void *stream);
 /* free the cached per-device scratch buffers */
 int mdh_release_workspace(void);
 /* bytes currently held by the scratch cache of the current device */

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "mdh_set_device": [cint],
     "mdh_warm": [],
     "mdh_min_max_i32": [vp, i64, vp, cint, vp],
+    "mdh_dense_codes_i32": [vp, i64, cint, cint, vp, vp, cint, vp],
     "mdh_release_workspace": [],
     "mdh_workspace_bytes": [],
     "mdh_prof_enable": [cint],

@@ -385,6 +385,28 @@ __global__ __launch_bounds__(256) void k_min_max_i32(const int *__restrict__ v, 
     }
 }
 __global__ void k_min_max_init(int *out) { out[0] = 2147483647; out[1] = -2147483647 - 1; }
+// how often each value of [low, low + span) occurs (span <= 4096: a workgroup counts in LDS)
+__global__ __launch_bounds__(256) void k_value_counts(const int *__restrict__ v, int64_t n, int low, int span, unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned h[4096];
+    for (int k = threadIdx.x; k < span; k += blockDim.x) h[k] = 0u;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned d = (unsigned)(v[i] - low);
+        if (d < (unsigned)span) atomicAdd(&h[d], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < span; k += blockDim.x)
+        if (h[k]) atomicAdd(&counts[k], (unsigned long long)h[k]);
+}
+__global__ __launch_bounds__(256) void k_apply_lut(const int *__restrict__ v, int64_t n, int low, int span, const int *__restrict__ lut, int *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const unsigned d = (unsigned)(v[i] - low);
+    out[i] = d < (unsigned)span ? lut[d] : 0;
+}
 }
 
 // ----------------------------------------------------------------------------
@@ -460,6 +482,36 @@ int mdh_min_max_i32(const int *v, int64_t n, int *min_max2, int space, void *str
     min_max2[0] = pinned[0];
     min_max2[1] = pinned[1];
     return MDH_OK;
+}
+
+int mdh_dense_codes_i32(const int *v, int64_t n, int low, int span, int *codes, int64_t *counts_span, int space, void *stream)
+{
+    if (n <= 0 || span <= 0 || span > 4096 || !codes || !counts_span) { mdh::set_error("mdh_dense_codes_i32: need n > 0 and 0 < span <= 4096"); return MDH_ERR_ARG; }
+    mdh::Scope sc(stream);
+    const int *dv = sc.stage_in(v, (size_t)n, space);
+    int *dc = sc.stage(codes, (size_t)n, space, false, true);
+    unsigned long long *dcnt = sc.alloc_n<unsigned long long>((size_t)span);
+    int *dlut = sc.alloc_n<int>((size_t)span);
+    if (sc.failed())
+        return sc.error();
+    hipStream_t st = sc.stream();
+    static thread_local unsigned long long *pinned = nullptr; // counts down, lut up: page-locked, one block per thread
+    if (!pinned) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 4096 * (sizeof(unsigned long long) + sizeof(int)), hipHostMallocDefault));
+    int *lut = reinterpret_cast<int *>(pinned + 4096);
+    MDH_HIP(hipMemsetAsync(dcnt, 0, sizeof(unsigned long long) * (size_t)span, st));
+    hipLaunchKernelGGL(mdh::k_value_counts, dim3((unsigned)std::min<int64_t>(2048, (n + 2047) / 2048)), dim3(256), 0, st, dv, n, low, span, dcnt);
+    MDH_HIP(hipMemcpyAsync(pinned, dcnt, sizeof(unsigned long long) * (size_t)span, hipMemcpyDeviceToHost, st));
+    MDH_HIP(hipStreamSynchronize(st));
+    int next = 0;
+    for (int k = 0; k < span; ++k) {
+        counts_span[k] = (int64_t)pinned[k];
+        lut[k] = pinned[k] ? next++ : 0;
+    }
+    MDH_HIP(hipMemcpyAsync(dlut, lut, sizeof(int) * (size_t)span, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mdh::k_apply_lut, dim3(mdh::grid_for(n, 256)), dim3(256), 0, st, dv, n, low, span, dlut, dc);
+    if (space == MDH_DEVICE)
+        MDH_HIP(hipStreamSynchronize(st)); // (the pinned lut block is reused by this thread's next call)
+    return sc.finish(space);
 }
 
 int mdh_set_device(int device)

@@ -60,7 +60,7 @@ def _pinned_release(nbytes):
 class HArray:
     """An array that lives in HBM; the host copy is made on demand and is read-only."""
 
-    __slots__ = ("_dev", "_host")
+    __slots__ = ("_dev", "_host", "__weakref__")
     __array_priority__ = 100
 
     def __init__(self, dev):

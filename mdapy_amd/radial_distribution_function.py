@@ -30,7 +30,7 @@ class RadialDistributionFunction:
             self.verlet_list, self.distance_list, self.neighbor_number = verlet_list, distance_list, neighbor_number
             self.N = int(verlet_list.shape[0])
         labels = np.zeros(self.N, dtype=np.int32) if type_list is None else np.asarray(type_list)
-        self.elements, self.type_list = policy.label_codes(labels)
+        self.elements, self.type_list = policy.label_codes(labels, device_ok=self.streaming)  # (streaming: the codes only ever go to the kernel)
         self.Ntype = len(self.elements)
 
     def _pair_counts(self):

@@ -77,7 +77,7 @@ class StructureFactor:
         atoms = frame.shape[0]
         self._set_density(atoms, cell.volume)
         self._uniele = list(pairs.elements)
-        self._concentrations = np.bincount(pairs.type_list, minlength=len(self._uniele)) / atoms
+        self._concentrations = policy.label_population(pairs.type_list, len(self._uniele)) / atoms
         damp = np.sinc(2.0 * pairs.r / longest) if self.window else np.ones_like(pairs.r)
         phase = np.sin(np.outer(self.k, pairs.r))
         scale = 4.0 * np.pi * self._density / self.k

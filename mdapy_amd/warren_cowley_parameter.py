@@ -16,7 +16,7 @@ class WarrenCowleyParameter:
             self.Ntype = len(names)
             return
         assert "type" in data.columns
-        present, codes = policy.label_codes(data["type"].to_numpy())  # (cached per immutable column, with its copy in HBM)
+        present, codes = policy.label_codes(data["type"].to_numpy(), device_ok=True)  # (cached per immutable column, with its copy in HBM)
         kinds = len(present)
         assert present == list(range(1, kinds + 1))  # types must be 1..Ntype without gaps: then code == type - 1
         self.type_list, self.Ntype = codes, kinds
