@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.environ.get("MDAPY_ORACLE_SO") or os.path.join(_HERE, "libmdapy_oracle.so")  # (MDAPY_ORACLE_SO: a sanitizer build, `make -C oracle asan`)
+_SO = os.environ.get("MDAPY_ORACLE_SO") or os.path.join(_HERE, "libmdapy_oracle.so")  # (MDAPY_ORACLE_SO: the sanitizer build, `make -C oracle asan`)
 
 
 def build(force: bool = False) -> str:
