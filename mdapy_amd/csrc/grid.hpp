@@ -95,7 +95,7 @@ int launch_neighbor_tiled(Scope &sc, const CellGrid &cg, const TiledPlan &plan, 
 
 // neighbor_lane.hip: LDS tiles, one thread per centre atom, single-precision pruning (see the file header)
 struct GridStats {
-    static constexpr int NBIN = 67; // v[0] = cells of the occupied region; v[1 + len] = 3-cell z-runs of that length (66: longer than 64)
+    static constexpr int NBIN = 99; // v[0] = cells of the occupied region; v[1 + len] = 3-cell z-runs of that length (98: longer than 96)
     int v[NBIN];
     int last_listed = -1;   // tiles the first pass of the previous build with this (N, grid) listed for the second (-1: not known)
     int *listed_sink = nullptr; // pinned host word the second pass of THIS build writes its count to (device-visible)

@@ -33,7 +33,7 @@
 // are the last of the row and a count says which they are); the centre's own lane decodes them, recomputes the distances
 // in double precision and holds its whole row in registers; the four lanes of a quad exchange 16-byte pieces (quad_transpose)
 // and store 16 bytes each: a quad writes 64 contiguous bytes of every row array.  Wide (!TK8: dense cells, rows of up to 64
-// slots, runs of up to 64 candidates as two masks): two-byte tickets, rows streamed four slots at a time, fewer rows per
+// slots, runs of up to 96 candidates as three masks): two-byte tickets, rows streamed four slots at a time, fewer rows per
 // wave (rw) where LDS is short.
 //
 // One tile per workgroup, straight-line code (template LOOP = false); the form that walks a list of tiles (LOOP = true)
@@ -43,7 +43,7 @@
 // box on an open axis, a run longer than the instance's masks) is listed again for the thread-per-atom code
 // (k_neighbor_tiles).  Not taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): fewer than 7 cells on
 // a periodic axis or 4 on an open one, atoms more than 14 box lengths outside an orthogonal periodic box (device flag; nearer
-// ones carry their image number in their record, grid.hpp img::), max_neigh > 64, grids where more than 5 % of the runs hold 59
+// ones carry their image number in their record, grid.hpp img::), max_neigh > 64, grids where more than 5 % of the runs hold 89
 // atoms or more.
 //
 // Measured (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16; DESIGN.md 3a has the counters, the per-phase time stamps of the
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
         if (ok && tid < NH && hz >= 1 && hz <= HZ - 2) {
             const unsigned k0 = (unsigned)off0 - hc(tid - 1), len = hc(tid - 1) + (unsigned)cnt + hc(tid + 1);
             hr[tid] = k0 | (len << 16);
-            if (len > (TK8 ? 32u : 64u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4); two in the wide instance
+            if (len > (TK8 ? 32u : 96u)) s_flag[2] = 1; // a run's hit mask is one 32-bit register (length rounded up to 4); three in the wide instance
             if (TK8 && len > 12u) s_flag[3] = 1;        // no short-run scan for this tile (eight slots + up to four leftovers per run)
         }
         // ---- stage this cell's atoms
@@ -670,10 +670,13 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                 const int li = (int)(cv & 2047u);
                 cb = (int)(cv >> 11);
                 const float4 s = f4[li];
-                // WIDE (the two-byte instance): runs of up to 64 candidates — cells of ten atoms and more — as two masks, the
-                // first 32 candidates of a run in mk, the rest in mk2
+                // WIDE (the two-byte instance): runs of up to 96 candidates — cells of ten atoms and more — as three masks, the
+                // first 32 candidates of a run in mk, the next 32 in mk2, the rest in mk3 (the last cell of an axis takes the
+                // remainder of the box, neighbor.cpp:58-61, and holds up to twice the atoms of the others: with two masks the
+                // tiles along three faces of a 3.4 M-atom box at rc = 5 A went to the slice pass and on to the thread-per-atom
+                // code, 0.35 of 1.98 ms)
                 constexpr bool WIDE = !TK8;
-                unsigned hv[9], mk[9], mk2[WIDE ? 9 : 1];
+                unsigned hv[9], mk[9], mk2[WIDE ? 9 : 1], mk3[WIDE ? 9 : 1];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) // neighbor.cpp:147-151: r = (da+1)*3 + (db+1)
                     hv[r] = hr[cb + ((r / 3 - 1) * HXY + (r % 3 - 1)) * HZ];
@@ -694,11 +697,16 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                         mk[r] &= ~0u << (run_slots(la) - la); // slots past the end of the run
                         if (TK8) mk[r] <<= (32 - run_slots(la)) & 31; // (an empty run: mask 0, shift 0)
                         if (WIDE) {
-                            const int lb = len - la;
+                            const int lb = min(len - la, 32), lc = len - la - lb;
                             mk2[r] = 0;
+                            mk3[r] = 0;
                             if (__builtin_amdgcn_ballot_w64(lb > 0)) {
                                 scan_run_asm(f4_lds + (((hv[r] & 0xffffu) + 32u) << 4), lb, s.x, s.y, s.z, negc, mk2[r], w);
                                 mk2[r] &= lb > 0 ? ~0u << (run_slots(lb) - lb) : 0u;
+                                if (__builtin_amdgcn_ballot_w64(lc > 0)) {
+                                    scan_run_asm(f4_lds + (((hv[r] & 0xffffu) + 64u) << 4), lc, s.x, s.y, s.z, negc, mk3[r], w);
+                                    mk3[r] &= lc > 0 ? ~0u << (run_slots(lc) - lc) : 0u;
+                                }
                             }
                         }
                     }
@@ -707,7 +715,8 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                     const int len = (int)(hv[4] >> 16), idx = li - (int)(hv[4] & 0xffffu);
                     if (TK8) mk[4] &= ~(0x80000000u >> idx);
                     else if (idx < 32) mk[4] &= ~(1u << (run_slots(min(len, 32)) - 1 - idx));
-                    else mk2[4] &= ~(1u << (run_slots(len - 32) - 1 - (idx - 32)));
+                    else if (idx < 64) mk2[4] &= ~(1u << (run_slots(min(len - 32, 32)) - 1 - (idx - 32)));
+                    else mk3[4] &= ~(1u << (run_slots(len - 64) - 1 - (idx - 64)));
                 }
                 STAMP(4);
                 {
@@ -731,14 +740,17 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                         else mk[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0, la, li, xi, yi, zi);
                         if (TK8) mk[r] <<= (32 - run_slots(la)) & 31;
                         if (WIDE) {
-                            if (r == 4) mk2[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, len - la, li, xi, yi, zi);
-                            else mk2[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, len - la, li, xi, yi, zi);
+                            const int lb = min(len - la, 32), lc = len - la - lb;
+                            if (r == 4) mk2[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, lb, li, xi, yi, zi);
+                            else mk2[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0 + 32, lb, li, xi, yi, zi);
+                            if (r == 4) mk3[r] = scan_run_f64<true, TRI>(lxy, lz, lsh, b, rcsq, k0 + 64, lc, li, xi, yi, zi);
+                            else mk3[r] = scan_run_f64<false, TRI>(lxy, lz, lsh, b, rcsq, k0 + 64, lc, li, xi, yi, zi);
                         }
                     }
                 }
                 int hits = 0;
 #pragma unroll
-                for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]) + (WIDE ? __builtin_popcount(mk2[r]) : 0);
+                for (int r = 0; r < 9; ++r) hits += __builtin_popcount(mk[r]) + (WIDE ? __builtin_popcount(mk2[r]) + __builtin_popcount(mk3[r]) : 0);
 #ifdef MDH_EXP_GATHER
                 id = pk[__float_as_int(s.w)].id;
 #else
@@ -773,10 +785,12 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                         step(m, jb);
                         step(m, jb);
                         while (__builtin_amdgcn_ballot_w64(m != 0)) step(m, jb);
-                        if (WIDE) { // candidates 32.. of the run: position 32 + j
-                            unsigned m2 = mk2[r];
-                            const int jb2 = (r << JB) + run_slots(len - la);
+                        if (WIDE) { // candidates 32.. of the run: position 32 + j; 64..: position 64 + j
+                            const int lb = min(len - la, 32), lc = len - la - lb;
+                            unsigned m2 = mk2[r], m3 = mk3[r];
+                            const int jb2 = (r << JB) + run_slots(lb), jb3 = (r << JB) + 32 + run_slots(lc);
                             while (__builtin_amdgcn_ballot_w64(m2 != 0)) step(m2, jb2);
+                            while (__builtin_amdgcn_ballot_w64(m3 != 0)) step(m3, jb3);
                         }
                     }
                     {   // listed hits, and how many of them belong to run 8 (the last ones of the row)
@@ -1076,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_tile_compact(const unsigned *__restrict
 // 3-cell z-runs — a run's hit mask is one 32-bit register.  Counted on the device; the host uses the values the previous call
 // with the same (N, grid) left in pinned memory — an MD-style sequence of calls never waits — and waits only the first
 // time it sees a new (N, grid).  A stale value costs speed, never correctness.
-// out[0] = occupied cells; out[1 + len] = number of runs of that length (len 0..64; out[66] = longer)
+// out[0] = occupied cells; out[1 + len] = number of runs of that length (len 0..96; out[98] = longer)
 __global__ __launch_bounds__(256) void k_grid_stats(const int *__restrict__ cell_start, Grid g, int *__restrict__ out)
 {
     __shared__ int hist[GridStats::NBIN];
@@ -1101,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_grid_stats(const int *__restrict__ cell
                     const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
                     for (int k = z0; k < z1; ++k) {
                         const int len = cell_start[col + min(k + 2, g.nc[2])] - cell_start[col + max(k - 1, 0)];
-                        atomicAdd(&hist[1 + min(len, 65)], 1);
+                        atomicAdd(&hist[1 + min(len, 97)], 1);
                     }
                 }
         }
@@ -1197,13 +1211,13 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     if (N <= 0) { g_last_plan[6] = -1; return p; }
     if (const int why = lane_refusal(b, g, M)) { g_last_plan[6] = why; return p; }
     if (!(rc > 1e-12 && rc < 1e12)) { g_last_plan[6] = -4; return p; }
-    int64_t runs = 0, over32 = 0, over64 = 0;
+    int64_t runs = 0, over32 = 0, over96 = 0;
     for (int k = 1; k < GridStats::NBIN; ++k) runs += gs.v[k];
-    for (int len = 29; len <= 65; ++len) over32 += gs.v[1 + len]; // (a little below the limits: the statistics are the previous call's)
-    for (int len = 59; len <= 65; ++len) over64 += gs.v[1 + len];
-    const bool long_runs = runs > 0 && (double)over32 > 0.002 * (double)runs; // many runs would not fit one 32-bit hit mask: the wide instance (two)
-    // cells so full that more than a few per cent of the runs would not fit two masks (fewer — the wider last cell of a small box — go to the mop-up kernel)
-    if (runs > 0 && (double)over64 > 0.05 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)over64; g_last_plan[4] = (int)runs; return p; }
+    for (int len = 29; len <= 97; ++len) over32 += gs.v[1 + len]; // (a little below the limits: the statistics are the previous call's)
+    for (int len = 89; len <= 97; ++len) over96 += gs.v[1 + len];
+    const bool long_runs = runs > 0 && (double)over32 > 0.002 * (double)runs; // many runs would not fit one 32-bit hit mask: the wide instance (three)
+    // cells so full that more than a few per cent of the runs would not fit three masks (fewer — the wider last cell of a small box — go to the mop-up kernel)
+    if (runs > 0 && (double)over96 > 0.05 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)over96; g_last_plan[4] = (int)runs; return p; }
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
@@ -1249,7 +1263,7 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
                 if (c * 1.15 > cen_cap(nw))
                     continue;
                 int rw = 64;
-                if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / nw) + 7) & ~7));
+                if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / nw) + 3) & ~3)); // (a row is a multiple of eight bytes: any count keeps the waves' blocks aligned)
                 const long fixed = (long)lds_bytes(0, M, tk8, rw, nw);
                 int cap = (int)((budget - fixed - 2) / 42);
                 if (cap_env > 0) cap = cap_env;
