@@ -1330,7 +1330,10 @@ LanePlan plan_lane(const DBox &b, const Grid &g, int64_t N, int64_t M, const Gri
     p.last_listed = gs.last_listed;
     p.listed_sink = gs.listed_sink;
     g_last_listed = gs.listed_sink ? *(volatile int *)gs.listed_sink : gs.last_listed; // (the freshest value the device has delivered)
-    p.full = occ >= g.ncell;
+    // "full": (nearly) every 4x4x4 block of cells holds atoms — all tiles are launched, no list of live ones is made.  A couple of
+    // per cent of empty blocks (the corner cell of a 100^3-cell fcc box holds no lattice site) cost a workgroup each that finds no
+    // centre and leaves; the list costs three launches
+    p.full = (double)occ >= 0.98 * (double)g.ncell;
     g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw, p.nw);
     g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2) | (p.nw == 8 ? 32 : 0); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;

@@ -94,7 +94,7 @@ ALG = [
     ("k_sq_stage1_l<false, 4>", N3, 24 + 4 + 12 * 12 + 2 * 16 * 9, "positions, count, 12 ids + distances in; q_4m (9 x re,im) read and written"),
     ("k_sq_stage1_l<false, 6>", N3, 24 + 4 + 12 * 12 + 2 * 16 * 13, "same, q_6m (13 x re,im)"),
     ("k_sq_final<true>", N3, 16 * 2 * 13 + 16, "q_lm rows in (416 B); q4, q6 out"),
-    ("k_csp<false>", N3, 24 + 4 * 12 + 8, "positions, 12 ids in; csp out"),
+    ("k_csp<false, 12>", N3, 24 + 4 * 12 + 8, "positions, 12 ids in; csp out"),
     ("k_acna_f32", N3, 24 + 4 * 14 + 4, "positions, 14 ids in; label out (single-precision pair tests; the double-precision kernel finishes its to-do list)"),
     ("ptms::k_ptm_shell<false, 4, 3>", N3, 24 + 72 + 18 + 17 * 28 + 1, '"all": positions, ordered ids + ranks in; 17-point cluster (ids, points) out'),
     ("ptms::k_ptm_hull_shell", N3, 17 * 24 + 1 + 57, '"all": cluster points in; 28 facets + status out'),
