@@ -55,8 +55,9 @@ int mdh_set_device(int device);
  * Load every code object of the library on the current device, once per device and process (an empty launch per
  * translation unit; ~30-100 ms in a fresh process): afterwards the FIRST mdh_build_neighbor / mdh_csp / ... of the
  * process costs about what the following ones do.  The reference has no counterpart: a CPU extension module is
- * mapped as a whole at import (CMakeLists.txt:71-100).  mdapy_amd/_lib.py calls it when it loads the library on a
- * box with a GPU.  No-op when the device has been warmed before.
+ * mapped as a whole at import (CMakeLists.txt:71-100).  The library calls it by itself at its first compute
+ * call on a device (MDAPY_HIP_WARM=0 in the environment switches that off) and in mdh_set_device; a binding may call it
+ * earlier.  No-op when the device has been warmed before.
  */
 int mdh_warm(void);
 /*

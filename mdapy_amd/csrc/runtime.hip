@@ -2,10 +2,14 @@
 // and the host-side construction of the kernel-visible box.
 #include "common.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
+
+extern "C" int mdh_warm(void);
 
 namespace mdh {
 
@@ -66,6 +70,14 @@ Scope::Scope(void *stream) : stream_(static_cast<hipStream_t>(stream))
         return;
     }
     (void)hipGetDevice(&device_);
+    // the first call of the process on this device loads every code object of the library (mdh_warm): the set-up cost of a
+    // process belongs to its first touch of a device, wherever the caller selected it, not to whichever kernels come first
+    static std::atomic<unsigned long long> warmed{0};
+    static const bool want = [] { const char *e = std::getenv("MDAPY_HIP_WARM"); return !(e && e[0] == '0'); }();
+    if (want && device_ < 64 && !((warmed.load(std::memory_order_relaxed) >> device_) & 1ull)) {
+        warmed.fetch_or(1ull << device_, std::memory_order_relaxed);
+        (void)mdh_warm();
+    }
 }
 
 Scope::~Scope()
