@@ -588,9 +588,10 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
         } else {
             hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
         }
-        // the to-do list (length on the device, usually zero) walked by a grid that fills the chip once: an empty one costs 5 us
-        // instead of the 17 us that N / 256 workgroups take to leave
-        hipLaunchKernelGGL((k_fcna<false, true>), dim3(std::min<unsigned>(grid.x, 2048u)), block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
+        // the to-do list (length on the device, usually zero, a few per 10^4 atoms in a hot crystal) walked by a SMALL grid: the
+        // double-precision kernel holds 512 VGPRs and 7 KB of LDS per workgroup, and 2048 of them took 25 us to find an empty
+        // list at 10 M atoms (rocprofv3, round 4) where 256 take 5; a list of 10^5 atoms is two trips per thread
+        hipLaunchKernelGGL((k_fcna<false, true>), dim3(std::min<unsigned>(grid.x, 256u)), block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
     }
 }
 
@@ -599,7 +600,7 @@ void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const do
 {
     // the list's length is on the device and usually zero: a grid that fills the chip once walks a long list, and an empty one
     // costs 5 us instead of the 17 us that N / 256 workgroups take to leave
-    dim3 grid(std::min<unsigned>(grid_for(N, 256), 2048u)), block(256);
+    dim3 grid(std::min<unsigned>(grid_for(N, 256), 256u)), block(256);
     if (b.tri)
         hipLaunchKernelGGL((k_fcna<true, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
     else
@@ -710,7 +711,7 @@ int mdh_acna(const double *x, const double *y, const double *z, int64_t N, const
             hipLaunchKernelGGL(k_acna_f32, grid, block, 0, st, pos, N, b, dv, M, dp, todo);
         }
         else hipLaunchKernelGGL((k_acna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
-        hipLaunchKernelGGL((k_acna<false, true>), dim3(std::min<unsigned>(grid.x, 2048u)), block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        hipLaunchKernelGGL((k_acna<false, true>), dim3(std::min<unsigned>(grid.x, 256u)), block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
     }
     return sc.finish(space);
 }
