@@ -139,9 +139,14 @@ def lib():
                     raise ValueError(f"MDAPY_HIP_DEVICE={index}: this process sees {count} HIP device(s)")
                 if L.mdh_set_device(index) != 0:
                     raise RuntimeError(L.mdh_last_error().decode("utf-8", "replace"))
-        # (the code objects of all kernel families are loaded by the library itself at its first call on a device — mdh_warm,
-        # runtime.hip Scope — or by mdh_set_device: on the device the caller selected, not on whatever is current at import;
-        # MDAPY_HIP_WARM=0 switches it off)
+        # The code objects of all kernel families, loaded now (mdh_warm): the set-up cost of a process belongs to its first
+        # touch of the library — System(...) — not to its first build_neighbor / cal_* (tools/cold_path.py).  Not under a
+        # multi-process launcher (LOCAL_RANK set, no MDAPY_HIP_DEVICE): the process has not selected its GPU yet, and the
+        # library warms the right one by itself at its first call there (runtime.hip Scope) or in mdh_set_device.
+        # MDAPY_HIP_WARM=0 switches all of it off.
+        if os.environ.get("MDAPY_HIP_WARM", "1") != "0" and (want or "LOCAL_RANK" not in os.environ) and int(L.mdh_device_count()) > 0:
+            if L.mdh_warm() != 0:
+                raise RuntimeError(L.mdh_last_error().decode("utf-8", "replace"))
         _lib = L
     return _lib
 

@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
 // exclusive prefix sum of the bin counters (three small kernels)
 // ----------------------------------------------------------------------------
 static constexpr int SCAN_BLOCK = 256;
-static constexpr int SCAN_ITEMS = 4; // per thread -> 1024 per block
+static constexpr int SCAN_ITEMS = 4; // per thread -> 1024 per block (small inputs); SCAN_ITEMS_BIG for large ones
+static constexpr int SCAN_ITEMS_BIG = 32; // 8192 per block: every block takes a ticket from ONE word, ~90 of them per microsecond —
+                                          // with 1024 per block the 3 925 tickets of a 4 M-cell grid were 43 of the scan's 62 us
+static constexpr int64_t SCAN_BIG_FROM = 1 << 19; // items from which the big blocks are used
 
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane)
 {
@@ -167,10 +170,11 @@ static unsigned next_scan_gen()
     return g;
 }
 
-template <bool REZERO>
+template <bool REZERO, int ITEMS = SCAN_ITEMS>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_onepass(unsigned *__restrict__ in, int *__restrict__ out, int64_t n,
                                                              unsigned *__restrict__ ctl, unsigned gen, int *__restrict__ flags)
 {
+    constexpr int SCAN_ITEMS = ITEMS; // (shadows the namespace constant: the body below is written for any multiple of four)
     __shared__ unsigned s_blk, s_excl;
     unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl + 64);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,9 +192,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_onepass(unsigned *__restric
     unsigned v[SCAN_ITEMS], s = 0;
     const bool vec = base + SCAN_ITEMS <= n && ((reinterpret_cast<uintptr_t>(in + base) | reinterpret_cast<uintptr_t>(out + base)) & 15u) == 0;
     if (vec) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(in + base);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        if (REZERO) *reinterpret_cast<uint4 *>(in + base) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int c = 0; c < SCAN_ITEMS / 4; ++c) {
+            const uint4 q = reinterpret_cast<const uint4 *>(in + base)[c];
+            v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+        }
+        if (REZERO) {
+#pragma unroll
+            for (int c = 0; c < SCAN_ITEMS / 4; ++c) reinterpret_cast<uint4 *>(in + base)[c] = make_uint4(0u, 0u, 0u, 0u);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -237,9 +247,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_onepass(unsigned *__restric
     __syncthreads();
     ex += s_excl;
     if (vec) {
-        int4 o;
-        o.x = (int)ex; o.y = (int)(ex + v[0]); o.z = (int)(ex + v[0] + v[1]); o.w = (int)(ex + v[0] + v[1] + v[2]);
-        *reinterpret_cast<int4 *>(out + base) = o;
+#pragma unroll
+        for (int c = 0; c < SCAN_ITEMS / 4; ++c) {
+            int4 o;
+            o.x = (int)ex; o.y = (int)(ex + v[4 * c]); o.z = (int)(ex + v[4 * c] + v[4 * c + 1]); o.w = (int)(ex + v[4 * c] + v[4 * c + 1] + v[4 * c + 2]);
+            reinterpret_cast<int4 *>(out + base)[c] = o;
+            ex += v[4 * c] + v[4 * c + 1] + v[4 * c + 2] + v[4 * c + 3];
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; ++k) {
@@ -256,13 +270,22 @@ static size_t scan_ctl_bytes(int64_t n)
     return 256 + (size_t)((n + per - 1) / per) * 8;
 }
 // out[0..n] = exclusive prefix of in[0..n), out[n] = total; rezero: clear in[] on the way (bin counters of a kept block)
+static void launch_scan_gen(hipStream_t st, unsigned *in, int *out, int64_t n, unsigned *ctl, unsigned gen, bool rezero, int *flags)
+{
+    const bool big = n >= SCAN_BIG_FROM;
+    const int64_t per = (int64_t)SCAN_BLOCK * (big ? SCAN_ITEMS_BIG : SCAN_ITEMS);
+    const dim3 grid((unsigned)std::max<int64_t>(1, (n + per - 1) / per)), block(SCAN_BLOCK);
+    if (big) {
+        if (rezero) hipLaunchKernelGGL((k_scan_onepass<true, SCAN_ITEMS_BIG>), grid, block, 0, st, in, out, n, ctl, gen, flags);
+        else hipLaunchKernelGGL((k_scan_onepass<false, SCAN_ITEMS_BIG>), grid, block, 0, st, in, out, n, ctl, gen, flags);
+    } else {
+        if (rezero) hipLaunchKernelGGL((k_scan_onepass<true, SCAN_ITEMS>), grid, block, 0, st, in, out, n, ctl, gen, flags);
+        else hipLaunchKernelGGL((k_scan_onepass<false, SCAN_ITEMS>), grid, block, 0, st, in, out, n, ctl, gen, flags);
+    }
+}
 static void launch_scan(hipStream_t st, unsigned *in, int *out, int64_t n, unsigned *ctl, bool rezero, int *flags)
 {
-    const int64_t per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
-    const unsigned nblk = (unsigned)std::max<int64_t>(1, (n + per - 1) / per);
-    const unsigned gen = next_scan_gen();
-    if (rezero) hipLaunchKernelGGL(k_scan_onepass<true>, dim3(nblk), dim3(SCAN_BLOCK), 0, st, in, out, n, ctl, gen, flags);
-    else hipLaunchKernelGGL(k_scan_onepass<false>, dim3(nblk), dim3(SCAN_BLOCK), 0, st, in, out, n, ctl, gen, flags);
+    launch_scan_gen(st, in, out, n, ctl, next_scan_gen(), rezero, flags);
 }
 
 // out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); for other translation units (grid.hpp)
@@ -537,9 +560,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     else
         hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win);
     auto scan_piece = [&](int64_t from, int64_t to, unsigned use_gen, int *flags) {
-        const int64_t n = to - from, per = (int64_t)SCAN_BLOCK * SCAN_ITEMS;
-        hipLaunchKernelGGL(k_scan_onepass<true>, dim3((unsigned)std::max<int64_t>(1, (n + per - 1) / per)), dim3(SCAN_BLOCK), 0, st,
-                           cell_count + from, cg.cell_start + from, n, ctl, use_gen, flags); // [to] = the piece's total
+        launch_scan_gen(st, cell_count + from, cg.cell_start + from, to - from, ctl, use_gen, true, flags); // [to] = the piece's total
     };
     if (!windowed) {
         scan_piece(0, g.ncell, gen, cg.flags);

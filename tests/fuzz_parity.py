@@ -76,7 +76,8 @@ def draw(seed):
         pos, box, origin = pos @ q, box @ q, origin @ q
     unwrapped = rng.random() < 0.2
     if unwrapped:
-        pos = pos + (rng.integers(-2, 3, pos.shape) * bnd) @ box
+        far = int(rng.choice([2, 2, 13, 20]))  # (up to 14 box lengths the tile kernel keeps the call, beyond the thread-per-atom one takes it)
+        pos = pos + (rng.integers(-far, far + 1, pos.shape) * bnd) @ box
     return dict(seed=seed, sigma=sigma, kind=kind, tri=tri, unwrapped=unwrapped, pos=pos, box=box, origin=origin, bnd=bnd)
 
 

@@ -50,7 +50,7 @@ if "apis" in what:
     print(f"# first touch of the device (context, torch allocator): {t_ctx:.1f} ms")
     from mdapy_amd import _lib
     t_lib, _ = lap(_lib.lib)
-    print(f"# library load: {t_lib:.1f} ms (MDAPY_HIP_WARM={os.environ.get('MDAPY_HIP_WARM', '1')}: its code objects are loaded by its first call on the device — mdh_warm, inside System(pos, box) below — or, with 0, by the first launch that needs each)")
+    print(f"# library load + its code objects on the device (mdh_warm; MDAPY_HIP_WARM={os.environ.get('MDAPY_HIP_WARM', '1')}; with 0 every code object is loaded by the first launch that needs it): {t_lib:.1f} ms")
     rounds = []
     for rnd in range(3):
         row = []

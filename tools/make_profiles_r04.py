@@ -211,8 +211,8 @@ if os.path.exists(svn):
 with open(os.path.join(P, "r04_cold_path.md"), "w") as f:
     f.write("# The first calls of a process, and an NPT-like trajectory (round 4, one MI355X; `tools/cold_path.py`)\n\n"
             "Fresh process, rattled fcc Cu as host numpy arrays, every API called once on a new `System` (first), then on a second and a third `System` of the "
-            "same atoms.  With `mdh_warm` (the default: every code object of the library and the queue's scratch area are loaded by the library's first call on a "
-            "device — here inside `System(pos, box)`) and with `MDAPY_HIP_WARM=0` (the round-3 behaviour: each translation unit's code object is loaded by the first launch that needs it).\n")
+            "same atoms.  With `mdh_warm` (the default: every code object of the library and the queue's scratch area are loaded when the package loads the library, "
+            "i.e. at the first `System`) and with `MDAPY_HIP_WARM=0` (the round-3 behaviour: each translation unit's code object is loaded by the first launch that needs it).\n")
     for tag, title in (("63", "1 000 188 atoms"), ("63_nowarm", "1 000 188 atoms, MDAPY_HIP_WARM=0"), ("136", "10 061 824 atoms"), ("136_nowarm", "10 061 824 atoms, MDAPY_HIP_WARM=0")):
         pth = os.path.join(G, f"r04_cold_path_{tag}.txt")
         if os.path.exists(pth):
