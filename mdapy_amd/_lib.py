@@ -180,10 +180,25 @@ def same_rows(what: str, n_atoms: int, **arrays) -> None:
             raise ValueError(f"{what}: {name} has {rows} rows for {int(n_atoms)} atoms")
 
 
+_box_memo = {}  # bytes of (box, origin, boundary) -> the converted copies and their pointers (a trajectory asks for the same box again and again)
+
+
 def host_box(box, origin, boundary):
     """(box9, origin3, boundary3) as C-contiguous host arrays + their pointers (kept alive by the caller)."""
-    b = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3, 3))
-    o = np.ascontiguousarray(np.asarray(origin, dtype=np.float64).reshape(3))
+    if type(box) is np.ndarray and type(origin) is np.ndarray and type(boundary) is np.ndarray and box.dtype == np.float64 and origin.dtype == np.float64:
+        key = (box.tobytes(), origin.tobytes(), boundary.tobytes(), boundary.dtype.str)
+        hit = _box_memo.get(key)
+        if hit is not None:
+            return hit
+    else:
+        key = None
+    b = np.array(np.asarray(box, dtype=np.float64).reshape(3, 3), order="C", copy=True)
+    o = np.array(np.asarray(origin, dtype=np.float64).reshape(3), order="C", copy=True)
     # the reference accepts int64 boundary through nanobind's implicit conversion (SURVEY §8b)
     p = np.ascontiguousarray(np.asarray(boundary).astype(np.int32).reshape(3))
-    return (b, o, p), (b.ctypes.data, o.ctypes.data, p.ctypes.data)
+    out = ((b, o, p), (b.ctypes.data, o.ctypes.data, p.ctypes.data))
+    if key is not None and len(key[0]) == 72 and len(key[1]) == 24:
+        if len(_box_memo) > 64:
+            _box_memo.clear()
+        _box_memo[key] = out  # (private copies: the caller's arrays may change under us, the memo is keyed by content)
+    return out
