@@ -54,9 +54,16 @@ def lattice_positions(structure, a, nx=1, ny=1, nz=1, c=None):
     return np.ascontiguousarray(pos), _supercell(cell, nx, ny, nz)
 
 
-def build_crystal(name, structure, a, nx=1, ny=1, nz=1, c=None):
-    """``System`` holding an nx x ny x nz supercell of one element (standard orientation)"""
+def build_crystal(name, structure, a, miller1=None, miller2=None, miller3=None, nx=1, ny=1, nz=1, c=None):
+    """``System`` holding an nx x ny x nz supercell of one element, the reference's positional order
+    (src/mdapy/build_lattice.py:657-668).  The generator of this package's benchmarks and tests: standard orientation only
+    (``miller1..3`` None or the unit vectors) — re-oriented cells, multi-species structures and the HEA / dislocation builders
+    of the reference are outside the hot path (out of scope)."""
     from .system import System
+
+    for k, (m, unit) in enumerate(zip((miller1, miller2, miller3), ((1, 0, 0), (0, 1, 0), (0, 0, 1)))):
+        if m is not None and tuple(int(v) for v in m) != unit:
+            raise ValueError(f"mdapy_amd.build_crystal builds the standard orientation only (miller{k + 1}={m!r})")
 
     if not isinstance(name, str):
         raise TypeError("only single-element crystals are supported here; pass one element symbol")

@@ -193,6 +193,82 @@ class System:
     def wrap_pos(self):
         self.update_data(tool.wrap_pos(self._frame, self.box), reset_neighbor=True)
 
+    # ---- small host helpers of the reference's System (src/mdapy/system.py:333-500, 786-850, 1414-1490): no kernel behind them
+    def set_element(self, element):
+        """element names: one string for every atom, or one name per atom (system.py:333-364)"""
+        if isinstance(element, str):
+            names = np.full(self.N, element, dtype=object)
+        else:
+            assert len(element) == self.N, f"Length of element ({len(element)}) must equal the atom number ({self.N})."
+            names = np.array(element, dtype=object)
+        self.update_data(self._frame.with_columns(element=names), True)
+
+    def set_type_by_element(self, element_list):
+        """column ``type`` = 1-based position of an atom's element in ``element_list`` (system.py:379-431)"""
+        assert "element" in self.data.columns, "Data must contain element column."
+        names = self.data["element"].to_numpy()
+        order = {name: k for k, name in enumerate(element_list, start=1)}
+        for name in np.unique(names):
+            assert name in order, f"element_list must include element {name!r} (seen in data['element'])."
+        present, codes = policy.label_codes(names)
+        lut = np.array([order[name] for name in present], dtype=np.int32)
+        self.update_data(self._frame.with_columns(type=lut[np.asarray(codes)]), True)
+
+    def get_positions(self, reduced=False):
+        """frame of x, y, z — or, reduced, of r_x, r_y, r_z = positions @ inverse box (system.py:433-477; like the reference the
+        origin is not subtracted)"""
+        if not reduced:
+            return self.data.select("x", "y", "z")
+        inv = self.box.inverse_box
+        x, y, z = (self.data[c].to_numpy() for c in ("x", "y", "z"))
+        return Frame({"r_x": x * inv[0, 0] + y * inv[1, 0] + z * inv[2, 0], "r_y": x * inv[0, 1] + y * inv[1, 1] + z * inv[2, 1],
+                      "r_z": x * inv[0, 2] + y * inv[1, 2] + z * inv[2, 2]})
+
+    def get_velocities(self):
+        for name in ("vx", "vy", "vz"):
+            assert name in self.data.columns
+        return self.data.select("vx", "vy", "vz")
+
+    def update_box(self, box, scale_pos=False):
+        """a new box; ``scale_pos`` moves the atoms affinely with it (system.py:786-846: all three axes periodic)"""
+        new_box = box if isinstance(box, Box) else Box(box)
+        if scale_pos:
+            assert sum(new_box.boundary) == 3, "only support all periodic boundary condition."
+            m = np.linalg.solve(self.box.box, new_box.box)
+            x, y, z = (self.data[c].to_numpy() - self.box.origin[k] for k, c in enumerate(("x", "y", "z")))
+            self._frame = self._frame.with_columns(x=x * m[0, 0] + y * m[1, 0] + z * m[2, 0] + new_box.origin[0],
+                                                   y=x * m[0, 1] + y * m[1, 1] + z * m[2, 1] + new_box.origin[1],
+                                                   z=x * m[0, 2] + y * m[1, 2] + z * m[2, 2] + new_box.origin[2])
+        self.box = new_box  # (the setter forgets the neighbor list)
+
+    def delete_overlap(self, rc, max_neigh=None):
+        """remove every atom that has a SURVIVING neighbour of smaller index closer than ``rc``; returns how many went
+        (system.py:1414-1490: a sweep in index order).  The sweep's answer is the unique solution of
+        gone[j] = any(not gone[i] for the neighbours i < j within rc); it is reached here by repeating that rule over all
+        atoms at once until nothing changes (a chain of k overlapping atoms takes k rounds)."""
+        rc = float(rc)
+        assert rc > 0, "rc should be larger than 0."
+        n = self.N
+        if not (hasattr(self, "rc") and self.rc >= rc):
+            self.build_neighbor(rc, max_neigh)
+        rows, dist = as_numpy(self.verlet_list), as_numpy(self.distance_list)
+        if "_enlarge_data" in self.__dict__:
+            rows = np.where(rows >= 0, rows % n, -1)  # replica indices back to the atoms they copy
+        rows, dist = rows[:n], dist[:n]
+        own = np.arange(n)[:, None]
+        smaller = (rows >= 0) & (rows < own) & (dist < rc)
+        gone = np.zeros(n, dtype=bool)
+        cols = np.where(smaller, rows, 0)
+        while True:
+            nxt = (smaller & ~gone[cols]).any(axis=1)
+            if np.array_equal(nxt, gone):
+                break
+            gone = nxt
+        removed = int(gone.sum())
+        if removed:
+            self.update_data(self.data.filter(~gone), reset_calculator=True, reset_neighbor=True)
+        return removed
+
     def replicate(self, nx, ny, nz):
         self._frame, self.box = tool.replicate(self._frame, self.box, nx, ny, nz)
 
@@ -477,7 +553,7 @@ class System:
     def average_by_neighbor(self, average_rc, property_name, include_self=True, output_name=None, max_neigh=None):
         """column ``<property>_ave`` (or ``output_name``): neighbourhood mean of a column within ``average_rc``"""
         self._require_cutoff_list(average_rc, max_neigh)
-        averaged = tool.average_by_neighbor(average_rc, self._get_compute_view()[1], self.verlet_list, self.distance_list,
-                                            self.neighbor_number, property_name, include_self, output_name)
+        averaged = tool.average_by_neighbor(average_rc, self._get_compute_view()[1], property_name, self.verlet_list, self.distance_list,
+                                            self.neighbor_number, include_self, output_name)
         name = f"{property_name}_ave" if output_name is None else output_name
         self._store(**{name: averaged[name].to_numpy()})

@@ -35,8 +35,8 @@ def _replicate_pos(data, box, nx, ny, nz):
     return policy.replica(data, box, (nx, ny, nz), all_columns=False)
 
 
-def average_by_neighbor(average_rc, data, verlet_list, distance_list, neighbor_number, property_name, include_self=True,
-                        output_name=None):
+def average_by_neighbor(average_rc, data, property_name, verlet_list, distance_list, neighbor_number, include_self=True,
+                        output_name=None):  # (src/mdapy/tool_function.py:14-23: this positional order)
     """frame with ``<property>_ave`` (or ``output_name``): mean of a column over the neighbours within ``average_rc``"""
     assert property_name in data.columns
     mean = zeros(data.shape[0], np.float64)

@@ -272,3 +272,57 @@ def test_mdapy_hip_device_is_validated_at_load():
     env["MDAPY_HIP_DEVICE"] = "0"
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_system_small_helpers_follow_the_reference(oracle_backend):
+    """set_element / set_type_by_element / get_positions / get_velocities / update_box / delete_overlap and the positional order
+    of tool_function.average_by_neighbor and build_lattice.build_crystal (src/mdapy/system.py:333-500, 786-846, 1414-1490;
+    tool_function.py:14-23; build_lattice.py:657-668)"""
+    import inspect
+
+    from mdapy_amd import build_lattice, tool_function
+
+    assert list(inspect.signature(tool_function.average_by_neighbor).parameters)[:6] == [
+        "average_rc", "data", "property_name", "verlet_list", "distance_list", "neighbor_number"]
+    assert list(inspect.signature(build_lattice.build_crystal).parameters) == [
+        "name", "structure", "a", "miller1", "miller2", "miller3", "nx", "ny", "nz", "c"]
+    rng = np.random.default_rng(3)
+    pos = rng.random((400, 3)) * 12.0
+    s = mp.System(pos=pos, box=np.diag([12.0, 12.0, 12.0]))
+    s.set_element("Cu")
+    assert set(s.data["element"].to_numpy()) == {"Cu"}
+    names = np.where(np.arange(400) % 3 == 0, "Zr", "Cu")
+    s.set_element(list(names))
+    with pytest.raises(AssertionError, match="must equal the atom number"):
+        s.set_element(["Cu"] * 3)
+    s.set_type_by_element(["Zr", "Cu"])
+    assert s.data["type"].to_numpy().tolist() == np.where(names == "Zr", 1, 2).tolist() and s.data["type"].to_numpy().dtype == np.int32
+    with pytest.raises(AssertionError, match="element_list must include element"):
+        s.set_type_by_element(["Zr"])
+    assert np.array_equal(s.get_positions().to_numpy(), pos)
+    assert np.allclose(s.get_positions(reduced=True).to_numpy(), pos / 12.0) and s.get_positions(reduced=True).columns == ["r_x", "r_y", "r_z"]
+    with pytest.raises(AssertionError):
+        s.get_velocities()
+    s.build_neighbor(3.0)
+    s.update_box(np.diag([13.2, 12.0, 12.0]), scale_pos=True)
+    assert not hasattr(s, "verlet_list")  # the box setter forgot the list
+    assert np.allclose(s.data["x"].to_numpy(), pos[:, 0] * 1.1) and np.array_equal(s.data["y"].to_numpy(), pos[:, 1])
+    with pytest.raises(AssertionError, match="all periodic"):
+        s.update_box(mp.Box(np.diag([13.2, 12.0, 12.0]), boundary=[1, 1, 0]), scale_pos=True)
+    # delete_overlap against the reference's sweep in index order, on a gas with chains of close atoms
+    gas = rng.random((600, 3)) * 14.0
+    gas[100:160] = gas[40:100] + rng.normal(0, 0.25, (60, 3))
+    gas[160:200] = gas[100:140] + rng.normal(0, 0.25, (40, 3))
+    t = mp.System(pos=gas, box=np.diag([14.0] * 3))
+    rc = 0.6
+    t.build_neighbor(rc)
+    v, d, nn = (np.asarray(a) for a in (t.verlet_list, t.distance_list, t.neighbor_number))
+    gone = np.zeros(600, bool)
+    for j in range(600):
+        near = v[j, :nn[j]][(v[j, :nn[j]] < j) & (d[j, :nn[j]] < rc)]
+        if near.size and not gone[near].all():
+            gone[j] = True
+    assert gone.sum() > 40
+    assert t.delete_overlap(rc) == int(gone.sum())
+    assert t.N == 600 - int(gone.sum()) and np.array_equal(t.data.to_numpy()[:, :3], gas[~gone]) and not hasattr(t, "verlet_list")
+    assert t.delete_overlap(rc) == 0
