@@ -165,3 +165,35 @@ class StructureFactor:
     def get_electron_structure_factor(self):
         self.Sk_electron = self._weighted_total("electron")
         return self.Sk_electron
+
+    # ------------------------------------------------------- back to real space
+    def _real_space(self, kind, r=None):
+        """(r, g, G, R) from a weighted total S(k): G(r) = 2/pi * integral of k (S - 1) sin(k r) dk (trapezoid rule over the k
+        points), g = 1 + G / (4 pi r rho) with g(0) = 0, R = 4 pi r^2 rho g   (src/mdapy/structure_factor.py:560-588)"""
+        if kind not in _WEIGHTS:
+            raise ValueError(f"unknown weighting kind: {kind!r}")
+        total = getattr(self, f"get_{kind}_structure_factor")()
+        if r is None:
+            r = self.r if hasattr(self, "r") else np.linspace(0.0, np.pi / (self.k[1] - self.k[0]), 200)
+        r = np.asarray(r, dtype=float)
+        rho = self._density
+        reduced = (2.0 / np.pi) * np.trapezoid(np.sin(np.outer(r, self.k)) * self.k * (total - 1.0), x=self.k, axis=1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pair = np.where(r > 0, reduced / (4.0 * np.pi * r * rho) + 1.0, 0.0)
+        return r, pair, reduced, 4.0 * np.pi * r ** 2 * rho * pair
+
+
+def _real_space_getter(kind, pick, what):
+    def getter(self, r=None):
+        out = self._real_space(kind, r)
+        return out[0], out[pick]
+
+    getter.__doc__ = f"(r, {what}) reconstructed from the {kind}-weighted total S(k)"
+    return getter
+
+
+for _kind in ("xray", "neutron", "electron"):  # the nine accessors of the reference (structure_factor.py:590-653)
+    setattr(StructureFactor, f"get_{_kind}_pair_distribution_function", _real_space_getter(_kind, 1, "g(r)"))
+    setattr(StructureFactor, f"get_{_kind}_reduced_pair_distribution_function", _real_space_getter(_kind, 2, "G(r) = 4 pi r rho (g - 1)"))
+    setattr(StructureFactor, f"get_{_kind}_radial_distribution_function", _real_space_getter(_kind, 3, "R(r) = 4 pi r^2 rho g"))
+del _kind

@@ -326,3 +326,25 @@ def test_system_small_helpers_follow_the_reference(oracle_backend):
     assert t.delete_overlap(rc) == int(gone.sum())
     assert t.N == 600 - int(gone.sum()) and np.array_equal(t.data.to_numpy()[:, :3], gas[~gone]) and not hasattr(t, "verlet_list")
     assert t.delete_overlap(rc) == 0
+
+
+def test_structure_factor_back_to_real_space():
+    """the nine (r, g / G / R) accessors (src/mdapy/structure_factor.py:560-653) on an exactly known pair:
+    g(r) = 1 + A exp(-r^2 / 2 s^2)  <->  S(k) - 1 = rho A (2 pi s^2)^(3/2) exp(-k^2 s^2 / 2)"""
+    sf = StructureFactor.__new__(StructureFactor)
+    sf.k = np.linspace(0.05, 25.0, 500)
+    rho, amp, s = 0.05, -1.0, 0.8
+    sf._density = rho
+    total = 1 + rho * amp * (2 * np.pi * s * s) ** 1.5 * np.exp(-sf.k ** 2 * s * s / 2)
+    for kind in ("xray", "neutron", "electron"):
+        setattr(sf, f"get_{kind}_structure_factor", lambda total=total: total)
+        grid = np.linspace(0, 6, 61)
+        r, g = getattr(sf, f"get_{kind}_pair_distribution_function")(grid)
+        assert g[0] == 0.0 and np.abs(g[1:] - (1 + amp * np.exp(-r[1:] ** 2 / (2 * s * s)))).max() < 1e-4
+        _, red = getattr(sf, f"get_{kind}_reduced_pair_distribution_function")(grid)
+        _, rad = getattr(sf, f"get_{kind}_radial_distribution_function")(grid)
+        assert np.allclose(red[1:], 4 * np.pi * r[1:] * rho * (g[1:] - 1)) and np.allclose(rad, 4 * np.pi * r ** 2 * rho * g)
+    r, _ = sf.get_xray_pair_distribution_function()  # default grid: 200 points out to pi / dk
+    assert len(r) == 200 and np.isclose(r[-1], np.pi / (sf.k[1] - sf.k[0]))
+    with pytest.raises(ValueError, match="unknown weighting kind"):
+        sf._real_space("muon")
