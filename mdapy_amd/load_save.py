@@ -316,3 +316,57 @@ def read_file(path: str, fmt: Optional[str] = None):
     if fmt == "mp":
         return read_mp(p)
     raise ValueError(f"unsupported file format {fmt!r} (supported: xyz, dump, mp)")
+
+
+class BuildSystem:
+    """The reference's entry points for the input side (src/mdapy/load_save.py:356-1374) over this package's readers: the same
+    names and return tuples ``(frame, box[, global_info])``.  Formats: LAMMPS dump, (ext)XYZ, ``.mp`` — the rows of SURVEY 8f.2;
+    ``data`` / ``lmp`` / ``poscar`` files, which the reference also reads, are refused by name."""
+
+    _SUPPORTED = ["data", "lmp", "dump", "poscar", "xyz", "mp"]
+
+    @classmethod
+    def from_file(cls, filename, format=None):
+        if format is None:
+            parts = os.path.basename(str(filename)).split(".")
+            if parts[-1] == "gz":
+                if len(parts) < 2:
+                    raise ValueError("Cannot infer format from filename")
+                format = parts[-2]
+            else:
+                format = parts[-1]
+        format = format.lower()
+        if format.endswith(".gz"):
+            format = format[:-3]
+        if format not in cls._SUPPORTED:
+            raise ValueError(f"Format '{format}' not supported. Supported formats: {cls._SUPPORTED}")
+        if format == "dump":
+            return cls.read_dump(filename)
+        if format == "xyz":
+            return cls.read_xyz(filename)
+        if format == "mp":
+            return cls.read_mp(filename)
+        raise ValueError(f"mdapy_amd reads dump, xyz and mp files; '{format}' files are outside its input side (SURVEY 8f.2)")
+
+    @staticmethod
+    def from_array(pos, box):
+        if not isinstance(pos, np.ndarray):
+            raise TypeError("pos must be numpy array")
+        if pos.ndim != 2 or pos.shape[1] != 3:
+            raise ValueError("pos must be N x 3 array")
+        xyz = np.asarray(pos, dtype=np.float64)
+        return Frame({"x": np.ascontiguousarray(xyz[:, 0]), "y": np.ascontiguousarray(xyz[:, 1]), "z": np.ascontiguousarray(xyz[:, 2])}), \
+            (box if isinstance(box, Box) else Box(box))
+
+    @staticmethod
+    def from_data(data, box):
+        frame = Frame.from_any(data)
+        for name in ("x", "y", "z"):
+            if name not in frame.columns:
+                raise ValueError(f"Data must contain {name} column")
+        frame = frame.with_columns(**{name: frame[name].to_numpy().astype(np.float64, copy=False) for name in ("x", "y", "z")})
+        return frame, (box if isinstance(box, Box) else Box(box))
+
+    read_dump = staticmethod(read_dump)
+    read_xyz = staticmethod(read_xyz)
+    read_mp = staticmethod(read_mp)

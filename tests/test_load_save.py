@@ -102,3 +102,28 @@ def test_mp_round_trip(tmp_path):
     for c in fr.columns:
         assert list(got[c].to_numpy()) == list(fr[c].to_numpy())
     assert np.array_equal(gbox.box, box.box) and np.array_equal(gbox.origin, box.origin) and list(gbox.boundary) == [1, 0, 1]
+
+
+def test_build_system_facade(tmp_path):
+    """the reference's entry-point names (src/mdapy/load_save.py:356-410, 547-607) over this package's readers"""
+    from mdapy_amd.load_save import BuildSystem
+
+    frame, box = BuildSystem.from_array(np.arange(12.0).reshape(4, 3), [10.0, 11.0, 12.0])
+    assert frame.columns == ["x", "y", "z"] and frame["y"].to_numpy().tolist() == [1.0, 4.0, 7.0, 10.0] and box.box[1, 1] == 11.0
+    with pytest.raises(TypeError, match="numpy array"):
+        BuildSystem.from_array([[0, 0, 0]], 5.0)
+    with pytest.raises(ValueError, match="N x 3"):
+        BuildSystem.from_array(np.zeros((3, 2)), 5.0)
+    frame2, _ = BuildSystem.from_data({"x": np.array([1, 2]), "y": np.array([0, 0]), "z": np.array([3, 4]), "type": np.array([1, 2])}, 9.0)
+    assert frame2["x"].to_numpy().dtype == np.float64 and "type" in frame2.columns
+    with pytest.raises(ValueError, match="must contain z"):
+        BuildSystem.from_data({"x": np.zeros(2), "y": np.zeros(2)}, 9.0)
+    path = tmp_path / "two.xyz"
+    path.write_text('2\nLattice="5 0 0 0 5 0 0 0 5" Properties=species:S:1:pos:R:3\nCu 0.5 0.5 0.5\nZr 1.5 2.5 3.5\n')
+    got = BuildSystem.from_file(str(path))
+    assert got[0].shape[0] == 2 and got[1].box[2, 2] == 5.0
+    assert BuildSystem.from_file(str(path), format="XYZ")[0]["z"].to_numpy().tolist() == [0.5, 3.5]
+    with pytest.raises(ValueError, match="not supported"):
+        BuildSystem.from_file("frame.cfg")
+    with pytest.raises(ValueError, match="outside its input side"):
+        BuildSystem.from_file("POSCAR.poscar")
