@@ -354,8 +354,12 @@ __device__ __forceinline__ void sort_cell_net(int *__restrict__ order, int s, in
         if (u < n) order[s + u] = id[u];
 }
 
+// tmp: N ints of scratch indexed like `order` (the rank array of k_assign, free once the atoms are scattered), for cells of
+// more than eight atoms without a key: the ids are copied there and every atom is PLACED at the number of larger ids of its
+// cell — n^2 independent, cached reads instead of the insertion sort's chain of dependent ones (dense cells, rc = 5 A: 11 atoms
+// per cell, up to 50 in the fat last cells: 239 -> 204 us at 10 M atoms, 131 -> 94 us at 3.4 M)
 __global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell_start, int *__restrict__ order,
-                                                    int64_t ncell, const int64_t *__restrict__ key)
+                                                    int64_t ncell, const int64_t *__restrict__ key, int *__restrict__ tmp)
 {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell)
@@ -372,6 +376,16 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell
     if (n <= 8) {
         if (key) sort_cell_net<8, int64_t>(order, s, n, key);
         else sort_cell_net<8, int>(order, s, n, nullptr);
+        return;
+    }
+    if (!key && tmp) {
+        for (int a = s; a < e; ++a) tmp[a] = order[a];
+        for (int a = s; a < e; ++a) {
+            const int mine = tmp[a];
+            int larger = 0;
+            for (int q = s; q < e; ++q) larger += tmp[q] > mine ? 1 : 0;
+            order[s + larger] = mine; // (ids are distinct: every slot of the cell is written once)
+        }
         return;
     }
     for (int a = s + 1; a < e; ++a) {
@@ -592,11 +606,11 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc) {
         if (!windowed) {
-            hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, sort_key);
+            hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, sort_key, rank);
         } else {
-            hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p1 - p0) * plane, 256)), dim3(256), 0, st, cg.cell_start + p0 * plane, cg.order, (p1 - p0) * plane, sort_key);
+            hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p1 - p0) * plane, 256)), dim3(256), 0, st, cg.cell_start + p0 * plane, cg.order, (p1 - p0) * plane, sort_key, rank);
             if (p3 > p2)
-                hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key);
+                hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key, rank);
         }
     }
     // (windowed: the atoms binned = the prefix behind the last piece, on the device; all N unless the promise was broken)
