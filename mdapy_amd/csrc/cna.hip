@@ -311,7 +311,7 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
             return -1;
 #pragma unroll
         for (int a = 0; a < 12; ++a) lds_col[a * 256] = (unsigned short)adj[a];
-        const CnaCounts c = cna_counts_words<12>(adj, L); // (the reference's loop stops at the first signature of another kind;
+        const CnaCounts c = cna_counts_words<12, 0>(adj, L); // (the reference's loop stops at the first signature of another kind;
         if (c.n421 == 12) label = 1;                      //  every label needs all twelve to be of the listed kinds: same result)
         else if (c.n421 == 6 && c.n422 == 6) label = 2;
         else if (c.n555 == 12) label = 4;
@@ -337,7 +337,7 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
             return -1;
 #pragma unroll
         for (int a = 0; a < 14; ++a) lds_col[a * 256] = (unsigned short)adj[a];
-        const CnaCounts c = cna_counts_words<14>(adj, L);
+        const CnaCounts c = cna_counts_words<14, 0>(adj, L);
         if (c.n666 == 8 && c.n444 == 6) label = 3;
     }
     return label;

@@ -222,16 +222,23 @@ __device__ __forceinline__ int fcna_label(const RT &R)
 // bonds (two bonds share an atom <=> they touch three atoms) and those of the shortcuts of signature(); the rest — six bonds
 // on six atoms, the (6,6,6) of bcc — walks the clusters through the LDS copy of the rows.
 struct CnaCounts { int n421, n422, n555, n444, n666; };
-template <int NN>
+// MAXO: signatures of none of the five kinds after which no label is possible any more — every label asks for 12 (14) bonds of
+// the listed kinds: one stray bond decides a 12-neighbour atom, three a 14-neighbour one (n421 == 12 needs 12 of the 14).  A lane
+// past that number skips the rest of its bonds; the counts it returns are then incomplete, and every caller's label tests fail on
+// them as they would on the complete ones.  On a lattice nothing is skipped; in a liquid nearly every atom is decided by its
+// first bonds and a wave leaves once its last lane is (the general cluster walks below were most of the kernel's time there).
+template <int NN, int MAXO = NN>
 __device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN], const RowsLds &L)
 {
     constexpr int NW = (NN + 1) / 2;
     unsigned P[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) P[k] = adj[2 * k] | ((2 * k + 1 < NN) ? (adj[2 * k + 1] << 16) : 0u);
-    int n421 = 0, n422 = 0, n555 = 0, n444 = 0, n666 = 0;
+    int n421 = 0, n422 = 0, n555 = 0, n444 = 0, n666 = 0, others = 0;
 #pragma unroll
     for (int ni = 0; ni < NN; ++ni) {
+        if (MAXO < NN && others > MAXO)
+            continue;
         const unsigned common = adj[ni]; // cna.cpp:52-64
         const int ncn = __popc(common);
         const unsigned c2 = common | (common << 16);
@@ -254,13 +261,14 @@ __device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN],
         else if (ncn == 5 && nb == 5 && ch == 5) ++n555;
         else if (ncn == 4 && nb == 4 && ch == 4) ++n444;
         else if (ncn == 6 && nb == 6 && ch == 6) ++n666;
+        else ++others;
     }
     return CnaCounts{n421, n422, n555, n444, n666};
 }
 template <int NN>
 __device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RowsLds &L)
 {
-    const CnaCounts c = cna_counts_words<NN>(adj, L);
+    const CnaCounts c = cna_counts_words<NN, NN - 12>(adj, L); // (12 neighbours: no stray bond; 14: two, n421 == 12 of 14)
     if (c.n421 == 12) return 1; // cna.cpp:496-503
     if (c.n421 == 6 && c.n422 == 6) return 2;
     if (c.n555 == 12) return 4;
