@@ -447,6 +447,28 @@ def main():
                 xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, sg)
                 extra[f"sigma_{sg:.2f}"] = other_input(xs, ys, zs, bx, n_local)
                 del xs, ys, zs
+            # (b') the inputs that used to leave the tile kernel (round 4): an unwrapped trajectory frame — every atom a few whole box
+            # lengths outside the box — and the same crystal in a sheared box open along its second vector; the build's device flag says
+            # whether the thread-per-atom kernel had to take the call
+            try:
+                xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, 0.05)
+                gen = torch.Generator(device=dev); gen.manual_seed(5)
+                Lb = A_CU * cells
+                far = [c + Lb * torch.randint(-3, 4, (n_local,), device=dev, generator=gen).double() for c in (xs, ys, zs)]
+                got = other_input(*far, bx, n_local)
+                extra["unwrapped_pm3_boxes"] = {k_: got[k_] for k_ in ("atoms", "ms_per_step", "fcc_fraction", "kernels_ms")}
+                extra["unwrapped_pm3_boxes"]["thread_per_atom_kernel_took_the_call"] = int(cnt4[2])
+                del far
+                sh = 0.1
+                tri = np.array([[Lb, 0, 0], [sh * Lb, Lb, 0], [0.5 * sh * Lb, sh * Lb, Lb]])
+                tb = mp.Box(tri, boundary=[1, 0, 1])
+                got = other_input(xs + sh * ys + 0.5 * sh * zs, ys + sh * zs, zs, (tb.box, tb.origin, tb.boundary), n_local)
+                extra["sheared_open_b"] = {k_: got[k_] for k_ in ("atoms", "ms_per_step", "fcc_fraction", "kernels_ms")}
+                plan8 = (ctypes.c_int * 8)(); L.mdh_debug_neighbor_plan(plan8)
+                extra["sheared_open_b"]["tile_plan"] = list(plan8)[:3]
+                del xs, ys, zs
+            except Exception as e:  # an extra, not the headline
+                extra["unwrapped_pm3_boxes"] = {"error": f"{type(e).__name__}: {e}"}
             try:  # (c) a polycrystal of the headline's size: BASELINE config 3's construction (Voronoi grains, 2.0 A overlap filter) in the same box
                 rng = np.random.default_rng(2024)
                 grains = max(4, int(round((A_CU * cells) ** 3 / 2.3e6)))

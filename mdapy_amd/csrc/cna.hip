@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
 // instructions — three subtractions, an FMA chain ending in e = d2 - c (c a little below rc^2), the sign of e shifted into
 // both bond rows, an unsigned minimum that tracks the smallest non-negative e.  |e - exact| <= tol: e < 0 is a bond for sure,
 // e > W none for sure; an atom that saw 0 <= e <= W, or whose list does not look like a neighbourhood (a neighbour more than
-// 2.5 rc from the first, an image number outside {-1,0,1}), goes to the to-do list and is finished by the GENERIC kernel with
+// 2.5 rc from the first after the fold), goes to the to-do list and is finished by the GENERIC kernel with
 // the reference's expression — labels are the reference's, and no double-precision copy of the positions stays in registers
 // (36 instead of 72: the round-2 attempt kept both and lost to the register file).
 template <int NN>
@@ -139,9 +139,12 @@ __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__rest
         for (int a = 1; a < NN; ++a) {
             const int j = ids[a];
             double dx = x[j] - x0, dy = y[j] - y0, dz = z[j] - z0;
-            if (b.pbc[0]) { ok = ok && dx >= b.tn[0][0] && dx < b.tn[0][3]; dx = fold(dx, b.h[0], b.tn[0][1], b.tn[0][2]); }
-            if (b.pbc[1]) { ok = ok && dy >= b.tn[1][0] && dy < b.tn[1][3]; dy = fold(dy, b.h[4], b.tn[1][1], b.tn[1][2]); }
-            if (b.pbc[2]) { ok = ok && dz >= b.tn[2][0] && dz < b.tn[2][3]; dz = fold(dz, b.h[8], b.tn[2][1], b.tn[2][2]); }
+            // (the reference's fold for ANY image number — pbc_axis: two exact thresholds for -1 / 0 / 1, the division beyond — so
+            // that an unwrapped trajectory frame, every atom whole box lengths away from its neighbours' raw coordinates, stays in
+            // this kernel: with the thresholds alone all 10 M atoms of such a frame went to the double-precision to-do kernel, 5.9 ms)
+            if (b.pbc[0]) dx = pbc_axis(dx, b.h[0], b.tn[0]);
+            if (b.pbc[1]) dy = pbc_axis(dy, b.h[4], b.tn[1]);
+            if (b.pbc[2]) dz = pbc_axis(dz, b.h[8], b.tn[2]);
             ok = ok && fabs(dx) <= reach && fabs(dy) <= reach && fabs(dz) <= reach; // (false for NaN)
             ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
         }
