@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
 // 2.5 rc from the first after the fold), goes to the to-do list and is finished by the GENERIC kernel with
 // the reference's expression — labels are the reference's, and no double-precision copy of the positions stays in registers
 // (36 instead of 72: the round-2 attempt kept both and lost to the register file).
-template <int NN>
+template <int NN, bool TRI = false>
 __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
                                              const double *__restrict__ z, const int (&ids)[NN], float negc, float W, double reach,
                                              unsigned short *lds_col)
@@ -142,9 +142,14 @@ __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__rest
             // (the reference's fold for ANY image number — pbc_axis: two exact thresholds for -1 / 0 / 1, the division beyond — so
             // that an unwrapped trajectory frame, every atom whole box lengths away from its neighbours' raw coordinates, stays in
             // this kernel: with the thresholds alone all 10 M atoms of such a frame went to the double-precision to-do kernel, 5.9 ms)
-            if (b.pbc[0]) dx = pbc_axis(dx, b.h[0], b.tn[0]);
-            if (b.pbc[1]) dy = pbc_axis(dy, b.h[4], b.tn[1]);
-            if (b.pbc[2]) dz = pbc_axis(dz, b.h[8], b.tn[2]);
+            // (TRI: through fractional coordinates, box.h:99-114 — once per neighbour; the pair tests are Cartesian either way)
+            if (TRI) {
+                pbc<true>(b, dx, dy, dz);
+            } else {
+                if (b.pbc[0]) dx = pbc_axis(dx, b.h[0], b.tn[0]);
+                if (b.pbc[1]) dy = pbc_axis(dy, b.h[4], b.tn[1]);
+                if (b.pbc[2]) dz = pbc_axis(dz, b.h[8], b.tn[2]);
+            }
             ok = ok && fabs(dx) <= reach && fabs(dy) <= reach && fabs(dz) <= reach; // (false for NaN)
             ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
         }
@@ -187,6 +192,7 @@ __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__rest
 // Held to 128 VGPRs (four waves per SIMD): the few spills that costs (the 14-neighbour branch) are cheaper than three waves;
 // at 96 VGPRs the pair tests spill and the kernel is a third slower.  (One kernel per list length — no spills at 128 — pays
 // a second pass over nn: measured 0.57 against 0.54 ms.)
+template <bool TRI>
 __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ x, const double *__restrict__ y,
                                                      const double *__restrict__ z, int64_t N, DBox b,
                                                      const int *__restrict__ verlet, int64_t M, const int *__restrict__ nn,
@@ -215,12 +221,12 @@ __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ 
         }
 #pragma unroll
         for (int a = 0; a < 12; ++a) ids[a] = safe_id(ids[a], i, N);
-        t = fcna_atom_f32<12>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
+        t = fcna_atom_f32<12, TRI>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
     } else if (n == 14 && M >= 14) {
         int ids[14];
 #pragma unroll
         for (int a = 0; a < 14; ++a) ids[a] = safe_id(row[a], i, N);
-        t = fcna_atom_f32<14>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
+        t = fcna_atom_f32<14, TRI>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
     }
     if (t > 0) pattern[i] = t;
     else if (t < 0) defer(todo, i);
@@ -264,6 +270,7 @@ __device__ __forceinline__ void pair_rows_f32(const float (&ux)[NV], const float
 // against a rounding bound of 2e-6 lc^2 for |u| <= 2 lc).  -1: the atom is finished by the GENERIC kernel — a pair inside the
 // band, a neighbour farther than 2 lc, a box edge shorter than 8 lc (the difference of two folded vectors would not be a
 // minimum image).
+template <bool TRI>
 __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restrict__ pos, int64_t i, const int *__restrict__ row,
                                              int label, int64_t N, unsigned short *lds_col)
 {
@@ -288,13 +295,15 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
         for (int v = 0; v < 7; ++v) {
             const int a = a0 + v;
             double dx = gx[v], dy = gy[v], dz = gz[v];
-            pbc<false>(b, dx, dy, dz);
+            pbc<TRI>(b, dx, dy, dz); // (triclinic: through fractional coordinates, once per neighbour; the pair tests are Cartesian)
             d2[a] = dx * dx + dy * dy + dz * dz;
             ux[a] = (float)dx; uy[a] = (float)dy; uz[a] = (float)dz;
             far2 = fmaxf(far2, fmaxf(fabsf(ux[a]), fmaxf(fabsf(uy[a]), fabsf(uz[a]))));
         }
     }
-    const double Lmin = fmin(b.pbc[0] ? b.h[0] : 1e300, fmin(b.pbc[1] ? b.h[4] : 1e300, b.pbc[2] ? b.h[8] : 1e300));
+    // shortest periodic extent: the edge of an orthogonal box, the perpendicular thickness along a vector of a triclinic one
+    const double Lmin = TRI ? fmin(b.pbc[0] ? b.thick[0] : 1e300, fmin(b.pbc[1] ? b.thick[1] : 1e300, b.pbc[2] ? b.thick[2] : 1e300))
+                            : fmin(b.pbc[0] ? b.h[0] : 1e300, fmin(b.pbc[1] ? b.h[4] : 1e300, b.pbc[2] ? b.h[8] : 1e300));
     const RowsLds L{lds_col, 256};
     // ---- 12 nearest neighbours: FCC / HCP / ICO (cna.cpp:309-370)
     {
@@ -346,6 +355,7 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
     return label;
 }
 
+template <bool TRI>
 __global__ __launch_bounds__(256, 4) void k_acna_f32(const Pos4 *__restrict__ pos, int64_t N, DBox b,
                                                      const int *__restrict__ verlet, int64_t M, int *__restrict__ pattern,
                                                      int *__restrict__ todo)
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256, 4) void k_acna_f32(const Pos4 *__restrict__ po
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    const int t = acna_atom_f32(b, pos, i, verlet + i * M, pattern[i], N, srows + threadIdx.x);
+    const int t = acna_atom_f32<TRI>(b, pos, i, verlet + i * M, pattern[i], N, srows + threadIdx.x);
     if (t >= 0) pattern[i] = t;
     else defer(todo, i);
 }
@@ -572,30 +582,33 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
                      int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done)
 {
     dim3 grid(grid_for(N, 256)), block(256);
-    if (b.tri) {
-        hipLaunchKernelGGL((k_fcna<true, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+    // single-precision pair tests where the neighbourhood of an atom cannot reach its own image (|u_c - u_a| <= 5 rc < L / 2;
+    // triclinic boxes: the perpendicular thickness along every periodic vector)
+    bool f32 = rc > 1e-12 && rc < 1e12 && g_fcna_variant == 0;
+    for (int d = 0; d < 3; ++d)
+        if (b.pbc[d] && !((b.tri ? b.thick[d] : b.h[d * 4]) >= 10.01 * rc)) f32 = false;
+    if (f32) {
+        // |e_f32 - (d2 - c)| <= 2.4e-6 rc^2 for |u| <= 2.5 rc (derivation at fcna_atom_f32); the band is four times that
+        const double rcsq = rc * rc, tol = 1e-5 * rcsq;
+        float c = (float)(rcsq - tol);
+        while ((double)c > rcsq - tol) c = std::nextafterf(c, -INFINITY);
+        const double want = (rcsq - (double)c) + tol;
+        float W = (float)want;
+        while ((double)W < want) W = std::nextafterf(W, INFINITY);
+        if (b.tri) hipLaunchKernelGGL(k_fcna_f32<true>, grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo);
+        else hipLaunchKernelGGL(k_fcna_f32<false>, grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo);
+    } else if (b.tri) {
+        hipLaunchKernelGGL((k_fcna<true, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo); // (defers nothing)
+        return;
     } else {
-        // single-precision pair tests where the neighbourhood of an atom cannot reach its own image (|u_c - u_a| <= 5 rc < L / 2)
-        bool f32 = rc > 1e-12 && rc < 1e12;
-        for (int d = 0; d < 3; ++d)
-            if (b.pbc[d] && !(b.h[d * 4] >= 10.01 * rc)) f32 = false;
-        if (f32 && g_fcna_variant == 0) {
-            // |e_f32 - (d2 - c)| <= 2.4e-6 rc^2 for |u| <= 2.5 rc (derivation at fcna_atom_f32); the band is four times that
-            const double rcsq = rc * rc, tol = 1e-5 * rcsq;
-            float c = (float)(rcsq - tol);
-            while ((double)c > rcsq - tol) c = std::nextafterf(c, -INFINITY);
-            const double want = (rcsq - (double)c) + tol;
-            float W = (float)want;
-            while ((double)W < want) W = std::nextafterf(W, INFINITY);
-            hipLaunchKernelGGL(k_fcna_f32, grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo);
-        } else {
-            hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
-        }
-        // the to-do list (length on the device, usually zero, a few per 10^4 atoms in a hot crystal) walked by a SMALL grid: the
-        // double-precision kernel holds 512 VGPRs and 7 KB of LDS per workgroup, and 2048 of them took 25 us to find an empty
-        // list at 10 M atoms (rocprofv3, round 4) where 256 take 5; a list of 10^5 atoms is two trips per thread
-        hipLaunchKernelGGL((k_fcna<false, true>), dim3(std::min<unsigned>(grid.x, 256u)), block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
+        hipLaunchKernelGGL((k_fcna<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
     }
+    // the to-do list (length on the device, usually zero, a few per 10^4 atoms in a hot crystal) walked by a SMALL grid: the
+    // double-precision kernel holds 512 VGPRs and 7 KB of LDS per workgroup, and 2048 of them took 25 us to find an empty
+    // list at 10 M atoms (rocprofv3, round 4) where 256 take 5; a list of 10^5 atoms is two trips per thread
+    const dim3 small(std::min<unsigned>(grid.x, 256u));
+    if (b.tri) hipLaunchKernelGGL((k_fcna<true, true>), small, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
+    else hipLaunchKernelGGL((k_fcna<false, true>), small, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
 }
 
 void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
@@ -666,7 +679,7 @@ int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const
     // (word 64) — are zero whenever it is idle (the list's last reader clears them): no hipMemsetAsync per call.  Triclinic
     // boxes (one kernel, nobody walks a list): plain scratch, cleared here.
     int *todo, *done = nullptr;
-    if (!b.tri && !g_track_counters) { // (tracking the length for bench.py: the plain list, whose count survives the call)
+    if (!g_track_counters) { // (tracking the length for bench.py: the plain list, whose count survives the call)
         done = static_cast<int *>(sc.alloc_kept(sizeof(int) * ((size_t)N + 1 + 64), Scope::KEEP_TODO));
         todo = done ? done + 64 : nullptr;
     } else {
@@ -704,17 +717,23 @@ int mdh_acna(const double *x, const double *y, const double *z, int64_t N, const
         return sc.error();
     MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
     dim3 grid(grid_for(N, 256)), block(256);
-    if (b.tri) {
+    const dim3 small(std::min<unsigned>(grid.x, 256u));
+    if (g_fcna_variant == 0) { // single-precision pair tests, the atoms inside the band (or too spread out) finished by the walker
+        const Pos4 *pos = pack_positions(sc, dx, dy, dz, N);
+        if (!pos)
+            return sc.error();
+        if (b.tri) {
+            hipLaunchKernelGGL(k_acna_f32<true>, grid, block, 0, st, pos, N, b, dv, M, dp, todo);
+            hipLaunchKernelGGL((k_acna<true, true>), small, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        } else {
+            hipLaunchKernelGGL(k_acna_f32<false>, grid, block, 0, st, pos, N, b, dv, M, dp, todo);
+            hipLaunchKernelGGL((k_acna<false, true>), small, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        }
+    } else if (b.tri) {
         hipLaunchKernelGGL((k_acna<true, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
     } else {
-        if (g_fcna_variant == 0) {
-            const Pos4 *pos = pack_positions(sc, dx, dy, dz, N);
-            if (!pos)
-                return sc.error();
-            hipLaunchKernelGGL(k_acna_f32, grid, block, 0, st, pos, N, b, dv, M, dp, todo);
-        }
-        else hipLaunchKernelGGL((k_acna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
-        hipLaunchKernelGGL((k_acna<false, true>), dim3(std::min<unsigned>(grid.x, 256u)), block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        hipLaunchKernelGGL((k_acna<false, false>), grid, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
+        hipLaunchKernelGGL((k_acna<false, true>), small, block, 0, st, dx, dy, dz, N, b, dv, M, dp, todo);
     }
     return sc.finish(space);
 }

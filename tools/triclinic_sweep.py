@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Every analysis on the same crystal in an orthogonal box, in a 10 % sheared periodic box and in the sheared box open along its
+second vector, through System: where a triclinic / open box falls off a fast path.  python tools/triclinic_sweep.py [cells=100]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import mdapy_amd as mp
+from mdapy_amd.build_lattice import lattice_positions
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+pos, box = lattice_positions("fcc", 3.615, cells, cells, cells)
+rng = np.random.default_rng(0)
+pos = pos + rng.normal(0.0, 0.05, pos.shape)
+L = 3.615 * cells
+sh = 0.1
+H = np.array([[L, 0, 0], [sh * L, L, 0], [0.5 * sh * L, sh * L, L]])
+tri = pos @ (H / L)
+ty = rng.integers(1, 3, len(pos)).astype(np.int32)
+CALLS = [("build_neighbor(0.854a, 16)", lambda s: s.build_neighbor(0.854 * 3.615, max_neigh=16)),
+         ("cna(0.854a)", lambda s: s.cal_common_neighbor_analysis(0.854 * 3.615)),
+         ("build_nearest_neighbor(18)", lambda s: s.build_nearest_neighbor(18)),
+         ("ptm", lambda s: s.cal_polyhedral_template_matching()),
+         ("csp(12)", lambda s: s.cal_centro_symmetry_parameter(12)),
+         ("adaptive cna", lambda s: s.cal_common_neighbor_analysis()),
+         ("steinhardt [4,6] nnn=12", lambda s: s.cal_steinhardt_bond_orientation([4, 6], nnn=12)),
+         ("steinhardt [6] rc", lambda s: s.cal_steinhardt_bond_orientation([6], rc=0.85 * 3.615)),
+         ("rdf(8, 200) streaming", lambda s: s.cal_radial_distribution_function(8.0, 200, streaming=True)),
+         ("wcp(3.6)", lambda s: s.cal_warren_cowley_parameter(3.6)),
+         ("aja", lambda s: s.cal_ackland_jones_analysis())]
+CASES = [("orthogonal", pos, mp.Box(box)), ("sheared", tri, mp.Box(H)), ("sheared, open b", tri, mp.Box(H, boundary=[1, 0, 1]))]
+res = {}
+for tag, p, bx in CASES:
+    for rep in range(2):
+        s = mp.System(pos=p, box=bx)
+        s.update_data(s.data.with_columns(type=ty))
+        for name, fn in CALLS:
+            torch.cuda.synchronize(); t0 = time.perf_counter(); fn(s); torch.cuda.synchronize()
+            res[(tag, name)] = (time.perf_counter() - t0) * 1e3
+print(f"N = {len(pos)}")
+for name, _ in CALLS:
+    a = res[("orthogonal", name)]
+    print(f"{name:32s} " + "   ".join(f"{tag} {res[(tag, name)]:8.2f} ms (x{res[(tag, name)] / a:5.2f})" for tag, _, _ in CASES))
