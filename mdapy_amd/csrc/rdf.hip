@@ -438,7 +438,7 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         const size_t tile_lds = (((size_t)hsize * 4 + 15) & ~(size_t)15) + 4 * sizeof(RdfWave);
         // the frame of 3x3x3 cells along the worst Cartesian axis, in units of the orthogonal kernel's 2.7 rc
         double tol_scale = 1.0;
-        const bool tri_tile = b.tri && b.pbc[0] && b.pbc[1] && b.pbc[2];
+        const bool tri_tile = b.tri != 0; // (periodic or open along any vector: the kernel wraps cell indices and atoms along the periodic ones only)
         if (tri_tile) {
             for (int c = 0; c < 3; ++c) {
                 double ext = 0;
