@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import mdapy_amd as mp
 from mdapy_amd.build_lattice import lattice_positions
-cells = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+cells = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
 pos, box = lattice_positions("fcc", 3.615, cells, cells, cells)
 rng = np.random.default_rng(0)
 pos = pos + rng.normal(0.0, 0.05, pos.shape)
@@ -28,6 +28,8 @@ CALLS = [("build_neighbor(0.854a, 16)", lambda s: s.build_neighbor(0.854 * 3.615
          ("wcp(3.6)", lambda s: s.cal_warren_cowley_parameter(3.6)),
          ("aja", lambda s: s.cal_ackland_jones_analysis())]
 CASES = [("orthogonal", pos, mp.Box(box)), ("sheared", tri, mp.Box(H)), ("sheared, open b", tri, mp.Box(H, boundary=[1, 0, 1]))]
+if "--open" in sys.argv:  # the orthogonal box periodic, as a slab (open z) and as a cluster (open everywhere)
+    CASES = [("orthogonal", pos, mp.Box(box)), ("slab (open z)", pos, mp.Box(box, boundary=[1, 1, 0])), ("cluster (open)", pos, mp.Box(box, boundary=[0, 0, 0]))]
 res = {}
 for tag, p, bx in CASES:
     for rep in range(2):
