@@ -154,7 +154,8 @@ with open(os.path.join(P, "r04_rc5_m50.md"), "w") as f:
         f.write(f"| {cur} | {n} | {ms:.2f} | {gbs:.0f} | {gbs / HBM:.3f} | {n / ms / 1e3:.0f} |\n")
 
 # ---- round 4: fixed cost per step
-for name in ("r04_launch_gap.txt", "r04_atomic_scope.txt", "r04_fast_path_holes.txt", "r04_step_vs_n.txt"):
+for name in ("r04_launch_gap.txt", "r04_atomic_scope.txt", "r04_fast_path_holes.txt", "r04_step_vs_n.txt", "r04_unwrapped_sweep.txt", "r04_triclinic_sweep.txt",
+             "r04_open_box_sweep.txt", "r04_disorder_sweep.txt", "r04_host_enqueue.txt", "r04_cold_rdf.txt", "r04_fcna_hot.txt"):
     if os.path.exists(os.path.join(G, name)):
         shutil.copy(os.path.join(G, name), os.path.join(P, name))
 svn = os.path.join(G, "r04_step_vs_n.txt")

@@ -48,3 +48,12 @@ for u in 0 1 3 13 20; do echo "unwrapped by up to $u box lengths: $(NB_UNWRAP=$u
 for pb in 111 101 010; do for var in 0 1; do echo "sheared box (10 %), pbc $pb, $( [ $var = 0 ] && echo 'tile kernel' || echo 'thread-per-atom kernel' ): $(NB_PBC=$pb NB_VARIANT=$var python tools/nb_probe.py 136 16 0.854 0.05 5 0.1 2>&1 | grep -v amdgpu.ids | tail -1)"; done; done
 } > $O/r04_fast_path_holes.txt 2>&1
 cat $O/r04_fast_path_holes.txt | cut -c1-200
+# ---- sweeps over input kinds (where a frame falls off a fast path), the host side of a small step, the first partial RDF, CNA on hot lattices
+python tools/unwrapped_sweep.py 100 2>&1 | grep -v amdgpu.ids > $O/r04_unwrapped_sweep.txt
+python tools/triclinic_sweep.py 100 2>&1 | grep -v amdgpu.ids > $O/r04_triclinic_sweep.txt
+python tools/triclinic_sweep.py 100 --open 2>&1 | grep -v amdgpu.ids > $O/r04_open_box_sweep.txt
+for c in 10 20 40; do python tools/host_enqueue.py $c 2>&1 | grep -v amdgpu.ids; done > $O/r04_host_enqueue.txt
+python tools/cold_rdf.py 2>&1 | grep -v amdgpu.ids | grep -v "^ \+[0-9]\+ " > $O/r04_cold_rdf.txt
+bash tools/measure_r04_t.sh 2>&1 | grep -v "^nn hist" > $O/r04_fcna_hot.txt
+tail -4 $O/r04_triclinic_sweep.txt | cut -c1-200
+python tools/triclinic_sweep.py 100 --disorder 2>&1 | grep -v amdgpu.ids > $O/r04_disorder_sweep.txt

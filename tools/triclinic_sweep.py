@@ -16,7 +16,7 @@ sh = 0.1
 H = np.array([[L, 0, 0], [sh * L, L, 0], [0.5 * sh * L, sh * L, L]])
 tri = pos @ (H / L)
 ty = rng.integers(1, 3, len(pos)).astype(np.int32)
-CALLS = [("build_neighbor(0.854a, 16)", lambda s: s.build_neighbor(0.854 * 3.615, max_neigh=16)),
+CALLS = [("build_neighbor(0.854a)", lambda s: s.build_neighbor(0.854 * 3.615, max_neigh=None if "--disorder" in sys.argv else 16)),
          ("cna(0.854a)", lambda s: s.cal_common_neighbor_analysis(0.854 * 3.615)),
          ("build_nearest_neighbor(18)", lambda s: s.build_nearest_neighbor(18)),
          ("ptm", lambda s: s.cal_polyhedral_template_matching()),
@@ -28,6 +28,9 @@ CALLS = [("build_neighbor(0.854a, 16)", lambda s: s.build_neighbor(0.854 * 3.615
          ("wcp(3.6)", lambda s: s.cal_warren_cowley_parameter(3.6)),
          ("aja", lambda s: s.cal_ackland_jones_analysis())]
 CASES = [("orthogonal", pos, mp.Box(box)), ("sheared", tri, mp.Box(H)), ("sheared, open b", tri, mp.Box(H, boundary=[1, 0, 1]))]
+if "--disorder" in sys.argv:  # the same lattice rattled more and more (sigma 0.05 / 0.20 / 0.50 A): hot crystal, liquid-like
+    base, _ = lattice_positions("fcc", 3.615, cells, cells, cells)
+    CASES = [(f"sigma {sg}", base + np.random.default_rng(1).normal(0.0, sg, base.shape), mp.Box(box)) for sg in (0.05, 0.20, 0.50)]
 if "--open" in sys.argv:  # the orthogonal box periodic, as a slab (open z) and as a cluster (open everywhere)
     CASES = [("orthogonal", pos, mp.Box(box)), ("slab (open z)", pos, mp.Box(box, boundary=[1, 1, 0])), ("cluster (open)", pos, mp.Box(box, boundary=[0, 0, 0]))]
 res = {}
@@ -40,5 +43,5 @@ for tag, p, bx in CASES:
             res[(tag, name)] = (time.perf_counter() - t0) * 1e3
 print(f"N = {len(pos)}")
 for name, _ in CALLS:
-    a = res[("orthogonal", name)]
+    a = res[(CASES[0][0], name)]
     print(f"{name:32s} " + "   ".join(f"{tag} {res[(tag, name)]:8.2f} ms (x{res[(tag, name)] / a:5.2f})" for tag, _, _ in CASES))
