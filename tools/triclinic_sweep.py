@@ -31,17 +31,22 @@ CASES = [("orthogonal", pos, mp.Box(box)), ("sheared", tri, mp.Box(H)), ("sheare
 if "--disorder" in sys.argv:  # the same lattice rattled more and more (sigma 0.05 / 0.20 / 0.50 A): hot crystal, liquid-like
     base, _ = lattice_positions("fcc", 3.615, cells, cells, cells)
     CASES = [(f"sigma {sg}", base + np.random.default_rng(1).normal(0.0, sg, base.shape), mp.Box(box)) for sg in (0.05, 0.20, 0.50)]
+if "--sizes" in sys.argv:  # the same crystal at 10^3, 20^3, 40^3 cells: what a call costs when the system is small (host overhead)
+    CASES = []
+    for n in (10, 20, 40):
+        pn, bn = lattice_positions("fcc", 3.615, n, n, n)
+        CASES.append((f"{len(pn)} atoms", pn + np.random.default_rng(2).normal(0.0, 0.05, pn.shape), mp.Box(bn)))
 if "--open" in sys.argv:  # the orthogonal box periodic, as a slab (open z) and as a cluster (open everywhere)
     CASES = [("orthogonal", pos, mp.Box(box)), ("slab (open z)", pos, mp.Box(box, boundary=[1, 1, 0])), ("cluster (open)", pos, mp.Box(box, boundary=[0, 0, 0]))]
 res = {}
 for tag, p, bx in CASES:
     for rep in range(2):
         s = mp.System(pos=p, box=bx)
-        s.update_data(s.data.with_columns(type=ty))
+        s.update_data(s.data.with_columns(type=ty[:len(p)]))
         for name, fn in CALLS:
             torch.cuda.synchronize(); t0 = time.perf_counter(); fn(s); torch.cuda.synchronize()
             res[(tag, name)] = (time.perf_counter() - t0) * 1e3
-print(f"N = {len(pos)}")
+print(f"N = {len(pos)}" if "--sizes" not in sys.argv else "sizes")
 for name, _ in CALLS:
     a = res[(CASES[0][0], name)]
     print(f"{name:32s} " + "   ".join(f"{tag} {res[(tag, name)]:8.2f} ms (x{res[(tag, name)] / a:5.2f})" for tag, _, _ in CASES))
