@@ -905,6 +905,40 @@ __global__ __launch_bounds__(256) void k_sort_rows_wide(int *__restrict__ verlet
     }
 }
 
+// whole rows of up to SORT_BLOCK_MAX entries, one workgroup per row: a bitonic network over (distance, index) keys in LDS
+// (the selection sort above is quadratic in the row length: a 36 000-wide row — surface atoms of a slab looking across
+// its vacuum — took minutes)
+constexpr int SORT_BLOCK_MAX = 8192;
+__global__ __launch_bounds__(256) void k_sort_rows_block(int *__restrict__ verlet, double *__restrict__ dist, int64_t M, int P)
+{
+    extern __shared__ double sort_block_lds[];
+    double *ld = sort_block_lds;
+    int *lv = (int *)(sort_block_lds + P);
+    const int64_t row = blockIdx.x;
+    const int t = threadIdx.x;
+    for (int c = t; c < P; c += 256) {
+        ld[c] = c < M ? dist[row * M + c] : 1.0e300;
+        lv[c] = c < M ? verlet[row * M + c] : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < (P >> 1); e += 256) {
+                const int lo = ((e & ~(stride - 1)) << 1) | (e & (stride - 1)), hi = lo | stride;
+                const bool up = (lo & size) == 0;
+                const double a = ld[lo], c = ld[hi];
+                const int va = lv[lo], vc = lv[hi];
+                const bool gt = a > c || (a == c && va > vc);
+                if (gt == up) { ld[lo] = c; ld[hi] = a; lv[lo] = vc; lv[hi] = va; }
+            }
+            __syncthreads();
+        }
+    for (int c = t; c < M; c += 256) {
+        dist[row * M + c] = ld[c];
+        verlet[row * M + c] = lv[c];
+    }
+}
+
 template <bool TRI>
 __global__ __launch_bounds__(256) void k_wrap(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
                                               int64_t N, DBox b)
@@ -1311,7 +1345,14 @@ int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M,
     const size_t lds = (size_t)M * SORT_ROWS * 12;
     if (lds <= 60 * 1024)
         hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(N, SORT_ROWS)), dim3(SORT_ROWS), lds, sc.stream(), dv, dd, N, M, k);
-    else
+    else if (k == M && M <= SORT_BLOCK_MAX) {
+        int P = 256;
+        while (P < M) P <<= 1;
+        const size_t bytes = (size_t)P * 12;
+        if (bytes > 48 * 1024)
+            MDH_HIP(hipFuncSetAttribute((const void *)k_sort_rows_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(k_sort_rows_block, dim3((unsigned)N), dim3(256), bytes, sc.stream(), dv, dd, M, P);
+    } else
         hipLaunchKernelGGL(k_sort_rows_wide, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, k);
     return sc.finish(space);
 }

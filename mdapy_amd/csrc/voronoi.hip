@@ -10,6 +10,9 @@
 //   radius   = 2 R_max                       (voro++ keeps cells doubled: sqrt(max_radius_squared()) is twice the
 //                                             farthest-vertex distance, and that is what the reference returns)
 #include "common.hpp"
+#include "grid.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include "voro_core.hpp"
 #include "../../include/mdapy_amd.h"
 
@@ -43,9 +46,13 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                                                         int *__restrict__ row_id, double *__restrict__ row_dist,
                                                         double *__restrict__ row_area, int W, double a_thr, double r_thr,
                                                         int64_t n_orig, int *__restrict__ max_faces, DBox b0,
-                                                        const unsigned char *__restrict__ dropped, CellOut co)
+                                                        const unsigned char *__restrict__ dropped, CellOut co,
+                                                        const int *__restrict__ subset, int *__restrict__ unfinished)
 {
-    const int64_t i = blockIdx.x;
+    // subset != nullptr: a refinement pass — workgroup r builds the cell of atom subset[r] from row r of (verlet, nn), which
+    // were made for the listed atoms only; unfinished: the atoms whose cell is still open are listed for the next pass
+    const int64_t row = blockIdx.x;
+    const int64_t i = subset ? subset[row] : row;
     const int lane = threadIdx.x;
     if (dropped && dropped[i % n_orig]) { // not in the reference's container (see k_mark_outside): no cell, no row
         if (lane == 0) {
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
     double *farea = dist + ncap;                                         // [ncap] area of face f (0: no face)
     const double xi = x[i], yi = y[i], zi = z[i];
     // rows are sorted by distance: a crowded atom uses its VORO_MAXC nearest neighbours and is complete within THEIR reach
-    const int n = min(min(nn[i], (int)M), VORO_MAXC);
+    const int n = min(min(nn[row], (int)M), VORO_MAXC);
     const double big = 4 * rc;
     // constraints 0..5: walls of open axes (orthogonal boxes), otherwise the bounding cube
     if (lane < 6) {
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
         dist[lane] = o;
     }
     for (int c = lane; c < n; c += VORO_LANES) {
-        const int j = verlet[i * M + c];
+        const int j = verlet[row * M + c];
         double dx = x[j] - xi, dy = y[j] - yi, dz = z[j] - zi;
         pbc<TRI>(b, dx, dy, dz);
         const double d2 = dx * dx + dy * dy + dz * dz;
@@ -167,11 +174,13 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
         volume[i] = vol;
         nfaces[i] = nf;
         radius[i] = 2.0 * rmax;
-        const double reach = nn[i] > VORO_MAXC ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
+        const double reach = nn[row] > VORO_MAXC ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
         // no face at all: nothing within the search radius cut the bounding cube (a lone atom of a tiny periodic cell) —
         // the cell is not known yet, whatever the vertex distances of an empty face list say
-        if (2.0 * rmax > reach || nn[i] > M || nf == 0)
-            atomicAdd(incomplete, 1);
+        if (2.0 * rmax > reach || nn[row] > M || nf == 0) {
+            const int slot = atomicAdd(incomplete, 1);
+            if (unfinished) unfinished[slot] = (int)i;
+        }
         if (max_faces && i < n_orig) atomicMax(max_faces, nf);
     }
     // Voronoi neighbour rows (src/voronoi.cpp:307-447): the faces shared with atoms — walls have no partner — whose area
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                 const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < W) {
                     const int64_t o = i * (int64_t)W + slot;
-                    const int64_t j = verlet[i * M + (f - 6)] % n_orig; // image of a replicated system -> original atom
+                    const int64_t j = verlet[row * M + (f - 6)] % n_orig; // image of a replicated system -> original atom
                     row_id[o] = (int)j;
                     // the reference reports the MINIMUM-IMAGE distance of the pair in the caller's box (src/voronoi.cpp:419-424,
                     // :277-282), also for a face that a thin box makes the cell share with a farther image of j
@@ -260,6 +269,68 @@ __global__ void k_replicate(const double *__restrict__ x, const double *__restri
     oz[t] = z[i] + a * h9[2] + bq * h9[5] + c * h9[8];
 }
 
+// Rows of the LISTED atoms only, for the refinement passes: one wavefront per listed atom walks the 27 cells of an rc-wide
+// grid in the reference's order (neighbor.cpp:147-151; inside a cell as the sorted arrays have it) and appends what lies
+// within rc — the same candidates, in the same order, with the same distance expression as mdh_build_neighbor gives that atom
+// (raw x[j] - wrapped x[i], minimum image, sqrt).  rows == nullptr: counts only.
+template <bool TRI>
+__global__ __launch_bounds__(64) void k_rows_of_listed(SortedView sv, const int *__restrict__ cell_start,
+                                                       const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ z, DBox b, Grid g, double rc,
+                                                       const int *__restrict__ listed, int *__restrict__ rows,
+                                                       double *__restrict__ dists, int *__restrict__ counts, int64_t M,
+                                                       int *__restrict__ max_count)
+{
+    const int64_t r = blockIdx.x;
+    const int i = listed[r];
+    const int lane = threadIdx.x;
+    double xi = x[i], yi = y[i], zi = z[i];
+    if (b.anypbc)
+        wrap<TRI>(b, xi, yi, zi); // neighbor.cpp:139-142
+    int c0, c1, c2;
+    cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+    const double rcsq = rc * rc;
+    int cnt = 0;
+    for (int a = c0 - 1; a <= c0 + 1; ++a)
+        for (int bb = c1 - 1; bb <= c1 + 1; ++bb)
+            for (int cc = c2 - 1; cc <= c2 + 1; ++cc) {
+                const int64_t cell = ((int64_t)pmod(a, g.nc[0]) * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2] + pmod(cc, g.nc[2]);
+                const int s = cell_start[cell], e = cell_start[cell + 1];
+                for (int q0 = s; q0 < e; q0 += 64) {
+                    const int q = q0 + lane;
+                    bool hit = false;
+                    int j = -1;
+                    double d2 = 0.0;
+                    if (q < e) {
+                        double xq, yq, zq;
+                        sv.get(q, xq, yq, zq, j);
+                        double dx = xq - xi, dy = yq - yi, dz = zq - zi;
+                        pbc<TRI>(b, dx, dy, dz);
+                        d2 = dx * dx + dy * dy + dz * dz;
+                        hit = j != i && d2 <= rcsq;
+                    }
+                    const unsigned long long m = __ballot(hit);
+                    if (hit && rows) {
+                        const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < M) {
+                            rows[r * M + slot] = j;
+                            dists[r * M + slot] = sqrt(d2);
+                        }
+                    }
+                    cnt += __popcll(m);
+                }
+            }
+    if (rows) // pads as mdh_build_neighbor(fill_pads) leaves them
+        for (int slot = cnt + lane; slot < M; slot += 64) {
+            rows[r * M + slot] = -1;
+            dists[r * M + slot] = rc + 1.0;
+        }
+    if (lane == 0) {
+        counts[r] = cnt;
+        if (max_count) atomicMax(max_count, cnt);
+    }
+}
+
 // cells of all `N` atoms of one (possibly replicated) system; 1 = some cells reach beyond half a period (caller replicates)
 static int voronoi_solve(void *stream, const double *dx, const double *dy, const double *dz, int64_t N, const double *box9,
                          const double *origin3, const int *boundary3, double *dvol, int *dnf, double *drad, int *dnn, int *dflag,
@@ -277,8 +348,13 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
     for (int a = 0; a < 3; ++a)
         if (b.pbc[a]) rc_cap = fmin(rc_cap, 0.5 * b.thick[a] * (1.0 - 1e-9));
     double rc = fmin(2.2 * cbrt(vol / (double)N), rc_cap);
+    Scope keep(stream);
+    int *lists[2] = {keep.alloc_n<int>((size_t)N), keep.alloc_n<int>((size_t)N)}; // atoms whose cell is still open, this pass / the next
+    if (keep.failed())
+        return keep.error();
     for (int attempt = 0; attempt < 16; ++attempt) {
         int maxc = 0;
+        if (std::getenv("MDH_VORO_DEBUG")) fprintf(stderr, "voronoi full pass: N %lld rc %g cap %g\n", (long long)N, rc, rc_cap);
         MDH_TRY(mdh_neighbor_count(dx, dy, dz, N, box9, origin3, boundary3, rc, dnn, &maxc, MDH_DEVICE, stream));
         const int64_t M = maxc > 0 ? maxc : 1;
         if ((double)N * (double)M > 4.0e8) { // 4.8 GB of rows: a homogeneous system needs ~60 entries per atom
@@ -298,9 +374,9 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
             ProfRange pr("k_voronoi", st);
             const size_t voro_lds_bytes = ((size_t)PolyLdsV::CAP * 2 * VORO_LANES + (size_t)((M < VORO_MAXC ? M : VORO_MAXC) + 6) * 6) * sizeof(double);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, (const int *)nullptr, lists[0]);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, (const int *)nullptr, lists[0]);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -312,6 +388,72 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
             return MDH_OK;
         }
         rc = fmin(rc * 1.4, rc_cap);
+        // A few open cells — the atoms of a surface, of a void's rim — do not send everybody to a wider search: while they are
+        // less than a quarter of the atoms, only THEY get rows at the wider radius (k_rows_of_listed) and their cells rebuilt,
+        // pass after pass, each pass listing who is still open.  (A slab of 256 k atoms took 47 ms against 9 for the periodic
+        // crystal, a free cluster 213 ms, and a triclinic slab — whose open direction is a vacuum three box lengths wide,
+        // voronoi.py — was refused for the size of everybody's rows.)
+        if (lists[0] && (int64_t)bad * 4 <= N) {
+            int cur = 0;
+            while (bad > 0) {
+                const int64_t nl = bad;
+                if (std::getenv("MDH_VORO_DEBUG")) fprintf(stderr, "voronoi subset pass: N %lld listed %lld rc %g cap %g\n", (long long)N, (long long)nl, rc, rc_cap);
+                CellGrid cg;
+                MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+                // (a listed atom looks at 27 cells of N / ncell atoms: surfaces facing a vacuum many cells wide — the widened open
+                // direction of a triclinic slab — would test 10^11 pairs before the row limit below stops them)
+                if ((double)nl * 27.0 * (double)N / (double)cg.g.ncell > 2.0e10) {
+                    set_error("mdh_voronoi_volume_number_radius: the search list would exceed 4e8 entries (extremely inhomogeneous system, e.g. a cluster in a periodic vacuum)");
+                    return MDH_ERR_ARG;
+                }
+                Scope inner(stream);
+                MDH_TRY(build_cell_grid(inner, dx, dy, dz, N, b, true, true, cg));
+                int *cnts = inner.alloc_n<int>((size_t)nl);
+                int *dmax = inner.alloc_n<int>(1);
+                if (inner.failed())
+                    return inner.error();
+                MDH_HIP(hipMemsetAsync(dmax, 0, sizeof(int), st));
+                const SortedView sv = view_of(cg);
+                if (b.tri) hipLaunchKernelGGL(k_rows_of_listed<true>, dim3((unsigned)nl), dim3(64), 0, st, sv, cg.cell_start, dx, dy, dz, b, cg.g, rc, lists[cur], (int *)nullptr, (double *)nullptr, cnts, (int64_t)0, dmax);
+                else hipLaunchKernelGGL(k_rows_of_listed<false>, dim3((unsigned)nl), dim3(64), 0, st, sv, cg.cell_start, dx, dy, dz, b, cg.g, rc, lists[cur], (int *)nullptr, (double *)nullptr, cnts, (int64_t)0, dmax);
+                int maxc = 0;
+                MDH_HIP(hipMemcpyAsync(&maxc, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
+                MDH_HIP(hipStreamSynchronize(st));
+                const int64_t M = maxc > 0 ? maxc : 1;
+                // (a row of 2048 candidates is a cell that reaches past five neighbour shells: the surface of a slab looking across a
+                // vacuum as wide as the slab, which only rows of 10^4..10^5 entries would close — seconds per pass; refused instead)
+                if ((double)nl * (double)M > 4.0e8 || M > 2048) {
+                    set_error("mdh_voronoi_volume_number_radius: the search list would exceed 4e8 entries (extremely inhomogeneous system, e.g. a cluster in a periodic vacuum)");
+                    return MDH_ERR_ARG;
+                }
+                int *dv = inner.alloc_n<int>((size_t)(nl * M));
+                double *dd = inner.alloc_n<double>((size_t)(nl * M));
+                if (inner.failed())
+                    return inner.error();
+                if (b.tri) hipLaunchKernelGGL(k_rows_of_listed<true>, dim3((unsigned)nl), dim3(64), 0, st, sv, cg.cell_start, dx, dy, dz, b, cg.g, rc, lists[cur], dv, dd, cnts, M, (int *)nullptr);
+                else hipLaunchKernelGGL(k_rows_of_listed<false>, dim3((unsigned)nl), dim3(64), 0, st, sv, cg.cell_start, dx, dy, dz, b, cg.g, rc, lists[cur], dv, dd, cnts, M, (int *)nullptr);
+                MDH_TRY(mdh_sort_verlet_by_distance(dv, dd, nl, M, (int)M, MDH_DEVICE, stream));
+                MDH_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
+                {
+                    ProfRange pr("k_voronoi", st);
+                    const size_t voro_lds_bytes = ((size_t)PolyLdsV::CAP * 2 * VORO_LANES + (size_t)((M < VORO_MAXC ? M : VORO_MAXC) + 6) * 6) * sizeof(double);
+                    if (b.tri)
+                        hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)nl), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, cnts, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, lists[cur], lists[1 - cur]);
+                    else
+                        hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)nl), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, cnts, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, lists[cur], lists[1 - cur]);
+                }
+                MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+                MDH_HIP(hipStreamSynchronize(st));
+                cur = 1 - cur;
+                if (bad == 0)
+                    return MDH_OK;
+                if (rc >= rc_cap) {
+                    *too_small = true;
+                    return MDH_OK;
+                }
+                rc = fmin(rc * 1.4, rc_cap);
+            }
+        }
     }
     set_error("mdh_voronoi_volume_number_radius: search radius did not converge");
     return MDH_ERR_ARG;

@@ -28,6 +28,14 @@ CALLS = [("build_neighbor(0.854a)", lambda s: s.build_neighbor(0.854 * 3.615, ma
          ("wcp(3.6)", lambda s: s.cal_warren_cowley_parameter(3.6)),
          ("aja", lambda s: s.cal_ackland_jones_analysis())]
 CASES = [("orthogonal", pos, mp.Box(box)), ("sheared", tri, mp.Box(H)), ("sheared, open b", tri, mp.Box(H, boundary=[1, 0, 1]))]
+if "--secondary" in sys.argv:  # the list consumers and Voronoi instead of the main analyses (run it on a smaller system: Voronoi is ~25 ns per atom)
+    CALLS = [("cnp(0.854a)", lambda s: s.cal_common_neighbor_parameter(0.854 * 3.615)),
+             ("structure entropy(5, 0.2)", lambda s: s.cal_structure_entropy(5.0, 0.2)),
+             ("cluster analysis(3.0)", lambda s: s.cal_cluster_analysis(3.0)),
+             ("identify diamond", lambda s: s.cal_identify_diamond_structure()),
+             ("voronoi volume", lambda s: s.cal_voronoi_volume()),
+             ("structure factor(debye, rc 10)", lambda s: s.cal_structure_factor(0.5, 10.0, 100, mode="debye", rc=10.0)),
+             ("average_by_neighbor(3.0, x)", lambda s: s.average_by_neighbor(3.0, "x"))]
 if "--disorder" in sys.argv:  # the same lattice rattled more and more (sigma 0.05 / 0.20 / 0.50 A): hot crystal, liquid-like
     base, _ = lattice_positions("fcc", 3.615, cells, cells, cells)
     CASES = [(f"sigma {sg}", base + np.random.default_rng(1).normal(0.0, sg, base.shape), mp.Box(box)) for sg in (0.05, 0.20, 0.50)]
