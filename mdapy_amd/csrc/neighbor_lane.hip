@@ -32,7 +32,7 @@
 // FOUR workgroups per CU): one-byte tickets (run << 5 | position in the run; run 8 is the last of the walk, so its tickets
 // are the last of the row and a count says which they are); the centre's own lane decodes them, recomputes the distances
 // in double precision and holds its whole row in registers; the four lanes of a quad exchange 16-byte pieces (quad_transpose)
-// and store 16 bytes each: a quad writes 64 contiguous bytes of every row array.  Wide (!TK8: dense cells, rows of up to 64
+// and store 16 bytes each: a quad writes 64 contiguous bytes of every row array.  Wide (!TK8: dense cells, rows of up to 128
 // slots, runs of up to 96 candidates as three masks): two-byte tickets, rows streamed four slots at a time, fewer rows per
 // wave (rw) where LDS is short.
 //
@@ -43,8 +43,8 @@
 // box on an open axis, a run longer than the instance's masks) is listed again for the thread-per-atom code
 // (k_neighbor_tiles).  Not taken at all (thread-per-atom kernel / round-1 tiled kernel, same results): fewer than 7 cells on
 // a periodic axis or 4 on an open one, atoms more than 14 box lengths outside an orthogonal periodic box (device flag; nearer
-// ones carry their image number in their record, grid.hpp img::), max_neigh > 64, grids where more than 5 % of the runs hold 89
-// atoms or more.
+// ones carry their image number in their record, grid.hpp img::), max_neigh > 128 (> 64 where a cell holds more than 19.5 atoms),
+// grids where more than 5 % of the runs hold 89 atoms or more.
 //
 // Measured (10 061 824-atom FCC Cu, rc = 0.854 a, M = 16; DESIGN.md 3a has the counters, the per-phase time stamps of the
 // MDH_STAMPS build and the tables of what moved the kernel and what was built and not kept): round-1 tiled kernel 1.78 ms,
@@ -1198,7 +1198,7 @@ static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw, int nw = 4)
 // reason (negative) the tile kernel cannot take a call with this box, grid and row width; 0: it can
 static int lane_refusal(const DBox &b, const Grid &g, int64_t M)
 {
-    if (g.mode != 0 || M <= 0 || M > 64) return -1;
+    if (g.mode != 0 || M <= 0 || M > 128) return -1;
     for (int d = 0; d < 3; ++d)
         if (g.nc[d] < (b.pbc[d] ? 7 : 4)) return -3; // image numbers from the cell pair need >= 7 cells; skipping the far side of an open axis >= 4
     return 0;
@@ -1253,6 +1253,11 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
     if (runs > 0 && (double)over96 > 0.05 * (double)runs) { g_last_plan[6] = -5; g_last_plan[5] = (int)over96; g_last_plan[4] = (int)runs; return p; }
     const int64_t occ = gs.v[0] > 0 ? gs.v[0] : g.ncell;
     const double pop = (double)N / (double)occ; // mean atoms per cell of the occupied region
+    // rows of 65 ... 128 slots: measured against the round-1 tiled kernel on 4 M atoms of rattled fcc Cu (tools/rc_sweep.py,
+    // profiles/r04_rc_sweep.txt) — ahead while a cell holds fewer than ~20 atoms (rc 5.6 / 5.8 / 6.0 A: 7.6 -> 5.5, ~8.3 -> 5.9,
+    // 8.8 -> 5.7 ms), behind beyond (rc 6.5 A, 24 atoms per cell: a third of the tiles hold a run of more than 96 candidates and
+    // go to the mop-up code, 10.9 -> 12.7 ms)
+    if (M > 64 && pop > 19.5) { g_last_plan[6] = -7; g_last_plan[5] = (int)(1000.0 * pop); return p; }
     static const int cap_env = [] { const char *e = std::getenv("MDH_LANE_CAP"); return e ? std::atoi(e) : 0; }();
     static const int wgs_env = [] { const char *e = std::getenv("MDH_LANE_WGS"); return e ? std::atoi(e) : 0; }(); // A/B: workgroups per CU the LDS is cut for
     // rows of at most 16 slots in cells of a few atoms: one-byte tickets, the lean LDS layout, rows written by the centre's lane;
@@ -1307,7 +1312,7 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
                 const double util = c / (passes * nthr);                   // lane utilisation of the scan
                 const double reuse = (double)ncc / (double)nh;             // centre cells per staged cell
                 const int wpc = wgs * nw;                                  // waves per CU
-                const double score = util * (0.35 + reuse) * (wpc == 16 ? 1.1 : (wpc == 12 ? 1.0 : (wpc == 8 ? 0.85 : 0.6)));
+                const double score = util * (0.35 + reuse) * (wpc == 16 ? 1.1 : (wpc == 12 ? 1.0 : (wpc == 8 ? 0.85 : (M > 64 ? 0.45 : 0.6))));
                 // the big tile must leave the chip full: at least four workgroups' worth of tiles per CU
                 if (nw == 8 && (double)occ / ncc < 4.0 * 256.0)
                     continue;

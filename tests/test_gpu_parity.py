@@ -228,6 +228,48 @@ def test_neighbor_dense_cells_take_the_wide_tile_kernel(kind):
     assert np.array_equal(n2, no) and np.array_equal(v2, vo) and np.array_equal(d2, do)
 
 
+@pytest.mark.parametrize("kind", ["fcc_rc6", "fcc_rc6_rattled_narrow", "gas_open", "triclinic"])
+def test_neighbor_rows_of_65_to_128_slots_take_the_wide_tile_kernel(kind):
+    """rc = 5.6 ... 6.5 A on fcc Cu (the structure-entropy and Steinhardt cutoffs): 78 ... 86 neighbours, ~18 atoms per cell,
+    3-cell runs of ~55 — rows of up to 128 slots on the wide instance of the tile kernel (three hit masks per run), bit for bit
+    vs the oracle, and the tile kernel did take the call."""
+    from mdapy_amd import _lib
+    rng = np.random.default_rng(78)
+    rc, M = 6.0, 96
+    org, bnd = ORG0, PBC
+    if kind == "fcc_rc6":
+        pos, box = _fcc(15)  # (9 cells of 6.025 A: 18.5 atoms per cell; beyond 19.5 the round-1 tiled kernel keeps the call)
+    elif kind == "fcc_rc6_rattled_narrow":
+        pos, box = _fcc(15, 0.1, 5)  # (9 cells of 6.025 A: 18.5 atoms per cell)
+        M = 68  # 78 neighbours: every row overflows
+    elif kind == "gas_open":
+        pos, box = rng.random((30000, 3)) * 70.0, np.eye(3) * 70.0  # ~17 atoms per cell, ~61 neighbours
+        bnd = np.array([1, 0, 1], np.int32)
+        rc, M = 5.5, 128
+    else:
+        box = np.array([[60.0, 0.0, 0.0], [7.0, 58.0, 0.0], [-4.0, 6.0, 61.0]])
+        pos = rng.random((11000, 3)) @ box  # (a gas: Poisson runs; denser, more than 5 % of them pass 88 candidates)
+        M = 112
+    x, y, z = _xyz(pos)
+    va = np.full((len(x), M), -1, np.int32); da = np.full((len(x), M), rc + 1.0); na = np.zeros(len(x), np.int32)
+    O.build_neighbor(x, y, z, box, org, bnd, rc, va, da, na, 4)
+    vb = np.empty((len(x), M), np.int32); db = np.empty((len(x), M)); nb = np.empty(len(x), np.int32)
+    for _ in range(2):  # (the second call plans from the first call's run-length statistics)
+        _neighbor.build_neighbor(x, y, z, box, org, bnd, rc, vb, db, nb, 1, fill_pads=True)
+    plan = np.zeros(8, np.int32)
+    _lib.lib().mdh_debug_neighbor_plan(plan.ctypes.data)
+    assert plan[0] > 0 and plan[7] == 1 and (plan[4] & 2) == 0, plan  # a tile plan was made, and it is the wide (two-byte) instance
+    assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+    if kind == "fcc_rc6":
+        assert (na == 78).all()
+    if kind == "fcc_rc6_rattled_narrow":
+        assert na.min() > M
+    v2, d2, n2 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1)
+    vo, do, no = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    assert v2.shape[1] > 64
+    assert np.array_equal(n2, no) and np.array_equal(v2, vo) and np.array_equal(d2, do)
+
+
 def test_fused_neighbor_fcna_equals_the_two_calls():
     """mdh_build_neighbor_fcna == mdh_build_neighbor then mdh_fcna, bit for bit (lists AND labels), on every kind of tile the
     kernel meets: interior, periodic seam, open faces, atoms handed in outside the box / unwrapped (the stand-by kernel

@@ -52,8 +52,13 @@ for tag, p, bx in CASES:
         s = mp.System(pos=p, box=bx)
         s.update_data(s.data.with_columns(type=ty[:len(p)]))
         for name, fn in CALLS:
-            torch.cuda.synchronize(); t0 = time.perf_counter(); fn(s); torch.cuda.synchronize()
-            res[(tag, name)] = (time.perf_counter() - t0) * 1e3
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            try:
+                fn(s); torch.cuda.synchronize()
+                res[(tag, name)] = (time.perf_counter() - t0) * 1e3
+            except ValueError as e:  # a refusal (printed as nan, with the time it took to refuse)
+                res[(tag, name)] = float("nan")
+                print(f"# {tag}: {name} refused after {(time.perf_counter() - t0) * 1e3:.0f} ms: {str(e)[:110]}")
 print(f"N = {len(pos)}" if "--sizes" not in sys.argv else "sizes")
 for name, _ in CALLS:
     a = res[(CASES[0][0], name)]
