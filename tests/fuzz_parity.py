@@ -112,13 +112,30 @@ def fused_check(s):
     assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da) and np.array_equal(pb, pa)
 
 
+def wide_rows_check(s):
+    """rows of 65 ... 128 slots (rc 5.4 ... 6.1 A on the big crystals): exact-width and fixed-width rows bit for bit vs the oracle"""
+    r = np.random.default_rng(s["seed"] + 41)
+    x, y, z = T._xyz(s["pos"])
+    n = len(x)
+    rc = float(r.uniform(5.4, 6.1))
+    v2, d2, n2 = T._neighbor.build_neighbor_without_max_neigh(x, y, z, s["box"], s["origin"], s["bnd"], rc, 1)
+    vo, do, no = T.O.build_neighbor_without_max_neigh(x, y, z, s["box"], s["origin"], s["bnd"], rc, 8)
+    assert np.array_equal(n2, no) and np.array_equal(v2, vo) and np.array_equal(d2, do)
+    M = int(r.choice([66, 80, 97, 128]))
+    va = np.full((n, M), -1, np.int32); da = np.full((n, M), rc + 1.0); na = np.zeros(n, np.int32)
+    T.O.build_neighbor(x, y, z, s["box"], s["origin"], s["bnd"], rc, va, da, na, 8)
+    vb = np.empty((n, M), np.int32); db = np.empty((n, M)); nb = np.empty(n, np.int32)
+    T._neighbor.build_neighbor(x, y, z, s["box"], s["origin"], s["bnd"], rc, vb, db, nb, 1, fill_pads=True)
+    assert np.array_equal(nb, na) and np.array_equal(vb, va) and np.array_equal(db, da)
+
+
 def checks(s):
     case = ("fuzz", s["pos"], s["box"], s["origin"], s["bnd"])
     if s["kind"] == "big":  # the tile kernels: neighbour rows bit for bit (fixed and exact width), pair counts
         rc_big = float(np.random.default_rng(s["seed"] + 7).uniform(2.8, 3.7))
         T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
         return [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc_big)), ("rdf_stream", lambda: rdf_stream_check(s)),
-                ("fused_cna", lambda: fused_check(s))]
+                ("fused_cna", lambda: fused_check(s))] + ([("wide_rows", lambda: wide_rows_check(s))] if s["seed"] % 3 == 0 else [])
     T._cases = lambda: [(n, ) + case[1:] for n in NAMES]
     rc = float(np.random.default_rng(s["seed"] + 7).uniform(2.6, 4.6))
     out = [("neighbor", lambda: T.test_neighbor_bit_exact_vs_oracle(case, rc)),
