@@ -104,7 +104,7 @@ int mdh_debug_set_fcna_variant(int variant);
  * {to-do atoms of the last tracked mdh_fcna or -1, tiles the previous neighbor build with the last plan's (N, grid) listed for
  * the one-cell-slice pass or -1, the "image codes not valid" flag of the last tracked neighbor build (1: an orthogonal box with atoms
  * more than 14 box lengths outside it — the thread-per-atom kernel took the call; 0: the tile kernel did where the box and the
- * grid allow one; -1: none tracked), 0}. */
+ * grid allow one; -1: none tracked), passes of the last Voronoi call that went over the atoms with a still-open cell only}. */
 int mdh_debug_track_counters(int on);
 int mdh_debug_counters(int64_t *out4);
 /* test hook: 0 = LDS-tile kernel for the streaming RDF where it applies (default), 1 = thread-per-atom kernel everywhere */

@@ -627,6 +627,7 @@ void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const do
 
 namespace mdh { int lane_last_listed(); } // neighbor_lane.hip
 namespace mdh { int moved_probe(int enable); } // neighbor.hip
+namespace mdh { int voro_listed_passes(); }     // voronoi.hip
 using namespace mdh;
 
 extern "C" {
@@ -656,7 +657,7 @@ int mdh_debug_counters(int64_t *out4)
     out4[0] = g_todo_probe ? (int64_t)*(volatile int *)g_todo_probe : -1;
     out4[1] = (int64_t)mdh::lane_last_listed();
     out4[2] = (int64_t)mdh::moved_probe(-1); // 1: the last tracked neighbor build found input it has no image codes for (thread-per-atom kernel)
-    out4[3] = 0;
+    out4[3] = (int64_t)mdh::voro_listed_passes(); // passes of the last Voronoi call over the atoms whose cell was still open
     return MDH_OK;
 }
 

@@ -18,7 +18,12 @@
 
 namespace mdh {
 
+static int g_listed_passes = 0; // passes of the last call that went over the atoms with open cells only (mdh_debug_counters out4[3])
+int voro_listed_passes() { return g_listed_passes; }
 static constexpr int VORO_MAXC = 250;  // neighbours one cell may consider
+// ... in a pass over the atoms whose cell is still open (few atoms, long rows: the surface of a void looks at 10^3 neighbours
+// before the far side closes its cell; 12 KB of polygons + 48 bytes per constraint = 108 KB of LDS, one wave per CU)
+static constexpr int VORO_MAXC_LISTED = 2048;
 static constexpr int VORO_LANES = 64;
 
 struct PolyLdsV { // vertex i, plane coordinate c (voro_core.hpp voronoi_face_2d) of lane l at [(i*2 + c) * 64 + l]
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                                                         double *__restrict__ row_area, int W, double a_thr, double r_thr,
                                                         int64_t n_orig, int *__restrict__ max_faces, DBox b0,
                                                         const unsigned char *__restrict__ dropped, CellOut co,
-                                                        const int *__restrict__ subset, int *__restrict__ unfinished)
+                                                        const int *__restrict__ subset, int *__restrict__ unfinished, int maxc)
 {
     // subset != nullptr: a refinement pass — workgroup r builds the cell of atom subset[r] from row r of (verlet, nn), which
     // were made for the listed atoms only; unfinished: the atoms whose cell is still open are listed for the next pass
@@ -73,14 +78,14 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
     // + 48 bytes per constraint — 16 KB and eight waves per CU at the usual 80-neighbour rows (36.9 KB and four waves with
     // 16-vertex polygons in space and tables for 256 constraints)
     extern __shared__ __attribute__((aligned(16))) double voro_lds[];
-    const int ncap = (int)(M < VORO_MAXC ? M : VORO_MAXC) + 6;
+    const int ncap = (int)(M < maxc ? M : maxc) + 6; // maxc: VORO_MAXC, or VORO_MAXC_LISTED in the passes over the open cells only
     double *poly_lds = voro_lds;                                         // [CAP * 2 * 64]
     double (*nrm)[3] = reinterpret_cast<double (*)[3]>(poly_lds + PolyLdsV::CAP * 2 * VORO_LANES); // [ncap][3]
     double *off = reinterpret_cast<double *>(nrm + ncap), *dist = off + ncap; // [ncap] each
     double *farea = dist + ncap;                                         // [ncap] area of face f (0: no face)
     const double xi = x[i], yi = y[i], zi = z[i];
     // rows are sorted by distance: a crowded atom uses its VORO_MAXC nearest neighbours and is complete within THEIR reach
-    const int n = min(min(nn[row], (int)M), VORO_MAXC);
+    const int n = min(min(nn[row], (int)M), maxc);
     const double big = 4 * rc;
     // constraints 0..5: walls of open axes (orthogonal boxes), otherwise the bounding cube
     if (lane < 6) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
         volume[i] = vol;
         nfaces[i] = nf;
         radius[i] = 2.0 * rmax;
-        const double reach = nn[row] > VORO_MAXC ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
+        const double reach = nn[row] > maxc ? 2.0 * dist[6 + n - 1] : rc; // every atom closer than `reach` has been seen
         // no face at all: nothing within the search radius cut the bounding cube (a lone atom of a tiny periodic cell) —
         // the cell is not known yet, whatever the vertex distances of an empty face list say
         if (2.0 * rmax > reach || nn[row] > M || nf == 0) {
@@ -374,9 +379,9 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
             ProfRange pr("k_voronoi", st);
             const size_t voro_lds_bytes = ((size_t)PolyLdsV::CAP * 2 * VORO_LANES + (size_t)((M < VORO_MAXC ? M : VORO_MAXC) + 6) * 6) * sizeof(double);
             if (b.tri)
-                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, (const int *)nullptr, lists[0]);
+                hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, (const int *)nullptr, lists[0], VORO_MAXC);
             else
-                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, (const int *)nullptr, lists[0]);
+                hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)N), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, dnn, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, (const int *)nullptr, lists[0], VORO_MAXC);
         }
         int bad = 0;
         MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -395,8 +400,10 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         // voronoi.py — was refused for the size of everybody's rows.)
         if (lists[0] && (int64_t)bad * 4 <= N) {
             int cur = 0;
+            bool stalled = false; // the previous listed pass closed no cell
             while (bad > 0) {
                 const int64_t nl = bad;
+                ++g_listed_passes;
                 if (std::getenv("MDH_VORO_DEBUG")) fprintf(stderr, "voronoi subset pass: N %lld listed %lld rc %g cap %g\n", (long long)N, (long long)nl, rc, rc_cap);
                 CellGrid cg;
                 MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
@@ -420,9 +427,11 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
                 MDH_HIP(hipMemcpyAsync(&maxc, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
                 MDH_HIP(hipStreamSynchronize(st));
                 const int64_t M = maxc > 0 ? maxc : 1;
-                // (a row of 2048 candidates is a cell that reaches past five neighbour shells: the surface of a slab looking across a
-                // vacuum as wide as the slab, which only rows of 10^4..10^5 entries would close — seconds per pass; refused instead)
-                if ((double)nl * (double)M > 4.0e8 || M > 2048) {
+                // (rows wider than the block sort takes are refused; so are rows of more than 2048 candidates — cells that reach past
+                // five neighbour shells — once a pass has closed none of its cells: the surface of a slab looking across a vacuum
+                // as wide as the slab, which only rows of 10^4..10^5 entries would close, seconds per pass.  A void in a crystal
+                // closes some cells with every pass and goes on)
+                if ((double)nl * (double)M > 4.0e8 || M > 8192 || (M > 2048 && stalled)) {
                     set_error("mdh_voronoi_volume_number_radius: the search list would exceed 4e8 entries (extremely inhomogeneous system, e.g. a cluster in a periodic vacuum)");
                     return MDH_ERR_ARG;
                 }
@@ -436,15 +445,18 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
                 MDH_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
                 {
                     ProfRange pr("k_voronoi", st);
-                    const size_t voro_lds_bytes = ((size_t)PolyLdsV::CAP * 2 * VORO_LANES + (size_t)((M < VORO_MAXC ? M : VORO_MAXC) + 6) * 6) * sizeof(double);
+                    const size_t voro_lds_bytes = ((size_t)PolyLdsV::CAP * 2 * VORO_LANES + (size_t)((M < VORO_MAXC_LISTED ? M : VORO_MAXC_LISTED) + 6) * 6) * sizeof(double);
+                    if (voro_lds_bytes > 48 * 1024)
+                        MDH_HIP(hipFuncSetAttribute(b.tri ? (const void *)k_voronoi<true> : (const void *)k_voronoi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)voro_lds_bytes));
                     if (b.tri)
-                        hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)nl), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, cnts, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, lists[cur], lists[1 - cur]);
+                        hipLaunchKernelGGL(k_voronoi<true>, dim3((unsigned)nl), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, cnts, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, lists[cur], lists[1 - cur], VORO_MAXC_LISTED);
                     else
-                        hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)nl), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, cnts, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, lists[cur], lists[1 - cur]);
+                        hipLaunchKernelGGL(k_voronoi<false>, dim3((unsigned)nl), dim3(VORO_LANES), voro_lds_bytes, st, dx, dy, dz, N, b, dv, cnts, M, rc, dvol, dnf, drad, dflag, row_id, row_dist, row_area, W, a_thr, r_thr, n_orig, dmaxf, b0, dropped, co, lists[cur], lists[1 - cur], VORO_MAXC_LISTED);
                 }
                 MDH_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
                 MDH_HIP(hipStreamSynchronize(st));
                 cur = 1 - cur;
+                stalled = bad == (int)nl;
                 if (bad == 0)
                     return MDH_OK;
                 if (rc >= rc_cap) {
@@ -470,6 +482,7 @@ static int voronoi_driver(const double *x, const double *y, const double *z, int
                           double *row_area, int W, double a_thr, double r_thr, int *max_faces_host, int space, void *stream,
                           const CellOut &co = CellOut())
 {
+    g_listed_passes = 0;
     if (N < 0 || N >= 2147483647LL) { set_error("mdh_voronoi_volume_number_radius: invalid N"); return MDH_ERR_ARG; }
     DBox b;
     MDH_TRY(make_box(b, box9, origin3, boundary3));

@@ -1596,6 +1596,42 @@ def test_voronoi_vs_reference_library(case):
 
 
 @needs_voro
+@pytest.mark.parametrize("kind", ["slab", "cluster", "void"])
+def test_voronoi_open_cells_take_the_listed_atom_passes(kind):
+    """After the first pass only the atoms whose cell is still open get rows at a wider radius (voronoi.hip k_rows_of_listed):
+    a slab, a free cluster and a crystal with a spherical void — volumes, cavity radii and face counts against voro++, the
+    neighbour rows too, and the listed-atom passes did run."""
+    from mdapy_amd import _lib
+    rng = np.random.default_rng(91)
+    pos, box = _fcc(10, 0.05, 3)
+    bd = {"slab": np.array([1, 1, 0], np.int32), "cluster": np.array([0, 0, 0], np.int32), "void": PBC}[kind]
+    bl = np.diag(box) if np.ndim(box) == 2 else np.asarray(box, float)
+    if kind == "void":
+        pos = pos[np.linalg.norm(pos - 0.5 * bl, axis=1) > 6.0]
+    pos = np.clip(pos, 1e-3, bl - 1e-3)  # inside the container along open axes
+    x, y, z = _xyz(pos)
+    N = len(pos)
+    v0, n0, r0 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
+    O.get_voronoi_volume_number_radius(x, y, z, box, ORG0, bd, v0, n0, r0)
+    v1, n1, r1 = np.zeros(N), np.zeros(N, np.int32), np.zeros(N)
+    _voronoi.get_voronoi_volume_number_radius(x, y, z, box, ORG0, bd, v1, n1, r1)
+    cnt = np.zeros(4, np.int64)
+    _lib.lib().mdh_debug_counters(cnt.ctypes.data)
+    assert cnt[3] >= 1, cnt
+    assert np.allclose(v1, v0, rtol=1e-9, atol=1e-9) and np.allclose(r1, r0, rtol=1e-9, atol=1e-9)
+    va, da, fa, ca = O.get_voronoi_neighbor(x, y, z, box, ORG0, bd, -1.0, -1.0)
+    vb, db, fb, cb = _voronoi.get_voronoi_neighbor(x, y, z, box, ORG0, bd, -1.0, -1.0)
+    real = lambda f, c: np.array([(f[r, :c[r]] >= 1e-10).sum() for r in range(len(c))])
+    assert np.array_equal(ca, n0) and np.array_equal(cb, n1) and np.array_equal(real(fa, ca), real(fb, cb))
+    for r in rng.choice(N, 200, replace=False):  # the same neighbour sets with the same face areas (rows are in different orders)
+        ka = {int(j): float(f) for j, f in zip(va[r, :ca[r]], fa[r, :ca[r]]) if f >= 1e-10}
+        kb = {int(j): float(f) for j, f in zip(vb[r, :cb[r]], fb[r, :cb[r]]) if f >= 1e-10}
+        assert ka.keys() == kb.keys() and all(abs(ka[j] - kb[j]) <= 1e-7 for j in ka)
+    if kind == "void":
+        assert abs(v1.sum() - float(np.prod(bl))) < 1e-6 * float(np.prod(bl))
+
+
+@needs_voro
 @pytest.mark.parametrize("case", ["fcc_rattled", "fcc_hot_shifted_origin", "random_gas", "slab_open_z"])
 def test_voronoi_neighbors_vs_reference_library(case):
     """neighbour SETS with their face areas and distances (the reference's row order is voro++'s internal face order)"""
