@@ -1345,17 +1345,33 @@ int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M,
     const size_t lds = (size_t)M * SORT_ROWS * 12;
     if (lds <= 60 * 1024)
         hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(N, SORT_ROWS)), dim3(SORT_ROWS), lds, sc.stream(), dv, dd, N, M, k);
-    else if (k == M && M <= SORT_BLOCK_MAX) {
-        int P = 256;
-        while (P < M) P <<= 1;
-        const size_t bytes = (size_t)P * 12;
-        if (bytes > 48 * 1024)
-            MDH_HIP(hipFuncSetAttribute((const void *)k_sort_rows_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(k_sort_rows_block, dim3((unsigned)N), dim3(256), bytes, sc.stream(), dv, dd, M, P);
-    } else
+    else // (the reference's selection sort, neighbor.cpp: its order among EQUAL distances — a perfect lattice — is part of the result)
         hipLaunchKernelGGL(k_sort_rows_wide, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, k);
     return sc.finish(space);
 }
+
+extern "C++" {
+namespace mdh {
+// Whole rows in HBM by ascending distance, equal distances by id — NOT the reference's order among equal distances (that is the
+// selection sort above, quadratic in the row length): for the Voronoi search lists, whose cells do not depend on the order of
+// equidistant planes.  Rows of 161 ... 8192 entries: one workgroup per row, a bitonic network in LDS.
+int sort_rows_any_tie_order(int *dv, double *dd, int64_t N, int64_t M, void *stream)
+{
+    if (N <= 0 || M <= 0)
+        return MDH_OK;
+    if ((size_t)M * SORT_ROWS * 12 <= 60 * 1024 || M > SORT_BLOCK_MAX)
+        return mdh_sort_verlet_by_distance(dv, dd, N, M, (int)M, MDH_DEVICE, stream);
+    int P = 256;
+    while (P < M) P <<= 1;
+    const size_t bytes = (size_t)P * 12;
+    if (bytes > 48 * 1024)
+        MDH_HIP(hipFuncSetAttribute((const void *)k_sort_rows_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(k_sort_rows_block, dim3((unsigned)N), dim3(256), bytes, static_cast<hipStream_t>(stream), dv, dd, M, P);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
+} // namespace mdh
+} // extern "C++"
 
 int mdh_wrap_positions(double *x, double *y, double *z, int64_t N, const double *box9, const double *origin3,
                        const int *boundary3, int space, void *stream)

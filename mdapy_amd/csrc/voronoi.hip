@@ -18,6 +18,7 @@
 
 namespace mdh {
 
+int sort_rows_any_tie_order(int *dv, double *dd, int64_t N, int64_t M, void *stream); // neighbor.hip
 static int g_listed_passes = 0; // passes of the last call that went over the atoms with open cells only (mdh_debug_counters out4[3])
 int voro_listed_passes() { return g_listed_passes; }
 static constexpr int VORO_MAXC = 250;  // neighbours one cell may consider
@@ -372,7 +373,7 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
         if (inner.failed())
             return inner.error();
         MDH_TRY(mdh_build_neighbor(dx, dy, dz, N, box9, origin3, boundary3, rc, dv, dd, dnn, M, 1, MDH_DEVICE, stream));
-        MDH_TRY(mdh_sort_verlet_by_distance(dv, dd, N, M, (int)M, MDH_DEVICE, stream));
+        MDH_TRY(sort_rows_any_tie_order(dv, dd, N, M, stream));
         MDH_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
         if (dmaxf) MDH_HIP(hipMemsetAsync(dmaxf, 0, sizeof(int), st));
         {
@@ -441,7 +442,7 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
                     return inner.error();
                 if (b.tri) hipLaunchKernelGGL(k_rows_of_listed<true>, dim3((unsigned)nl), dim3(64), 0, st, sv, cg.cell_start, dx, dy, dz, b, cg.g, rc, lists[cur], dv, dd, cnts, M, (int *)nullptr);
                 else hipLaunchKernelGGL(k_rows_of_listed<false>, dim3((unsigned)nl), dim3(64), 0, st, sv, cg.cell_start, dx, dy, dz, b, cg.g, rc, lists[cur], dv, dd, cnts, M, (int *)nullptr);
-                MDH_TRY(mdh_sort_verlet_by_distance(dv, dd, nl, M, (int)M, MDH_DEVICE, stream));
+                MDH_TRY(sort_rows_any_tie_order(dv, dd, nl, M, stream));
                 MDH_HIP(hipMemsetAsync(dflag, 0, sizeof(int), st));
                 {
                     ProfRange pr("k_voronoi", st);

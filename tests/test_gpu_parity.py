@@ -439,6 +439,20 @@ def test_sort_and_cna_vs_oracle(case):
     assert np.array_equal(vb, va) and np.array_equal(db, da)
 
 
+def test_sort_wide_rows_keeps_the_reference_order_among_equal_distances():
+    """rows of more than 160 slots (sorted in HBM) on a PERFECT lattice, whole rows and the first 20: the reference's selection
+    sort decides the order of the equidistant neighbours, and so must this one"""
+    pos, box = _fcc(6)
+    x, y, z = _xyz(pos)
+    v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, 8.2, 4)
+    assert v.shape[1] > 160
+    for k in (v.shape[1], 20):
+        va, da = v.copy(), d.copy(); vb, db = v.copy(), d.copy()
+        O.sort_verlet_by_distance(va, da, k, 4)
+        _neighbor.sort_verlet_by_distance(vb, db, k, 1)
+        assert np.array_equal(vb, va) and np.array_equal(db, da)
+
+
 def _fcna_cases():
     """boxes of >= 10 cutoffs per periodic edge: the single-precision pair tests of k_fcna_f32 apply"""
     rng = np.random.default_rng(5)
