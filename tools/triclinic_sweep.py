@@ -36,6 +36,17 @@ if "--secondary" in sys.argv:  # the list consumers and Voronoi instead of the m
              ("voronoi volume", lambda s: s.cal_voronoi_volume()),
              ("structure factor(debye, rc 10)", lambda s: s.cal_structure_factor(0.5, 10.0, 100, mode="debye", rc=10.0)),
              ("average_by_neighbor(3.0, x)", lambda s: s.average_by_neighbor(3.0, "x"))]
+if "--tertiary" in sys.argv:  # Voronoi neighbour rows and their consumer, the list form of the RDF, averaged Steinhardt, bookkeeping calls
+    CALLS = [("build_voronoi_neighbor", lambda s: s.build_voronoi_neighbor()),
+             ("steinhardt [6] use_voronoi", lambda s: s.cal_steinhardt_bond_orientation([6], use_voronoi=True)),
+             ("steinhardt [4,6] nnn=12 average", lambda s: s.cal_steinhardt_bond_orientation([4, 6], nnn=12, average=True)),
+             ("atomic temperature(5.0)", lambda s: s.cal_atomic_temperature(5.0)),
+             ("rdf(5, 200) from the list", lambda s: s.cal_radial_distribution_function(5.0, 200, streaming=False)),
+             ("structure factor(direct, 50 bins)", lambda s: s.cal_structure_factor(0.5, 5.0, 50, mode="direct")),
+             ("ptm(all)", lambda s: s.cal_polyhedral_template_matching("all")),
+             ("wrap_pos", lambda s: s.wrap_pos()),
+             ("replicate(2,2,1)", lambda s: s.replicate(2, 2, 1)),
+             ("delete_overlap(1.0)", lambda s: s.delete_overlap(1.0))]
 if "--disorder" in sys.argv:  # the same lattice rattled more and more (sigma 0.05 / 0.20 / 0.50 A): hot crystal, liquid-like
     base, _ = lattice_positions("fcc", 3.615, cells, cells, cells)
     CASES = [(f"sigma {sg}", base + np.random.default_rng(1).normal(0.0, sg, base.shape), mp.Box(box)) for sg in (0.05, 0.20, 0.50)]
@@ -51,12 +62,15 @@ for tag, p, bx in CASES:
     for rep in range(2):
         s = mp.System(pos=p, box=bx)
         s.update_data(s.data.with_columns(type=ty[:len(p)]))
+        if "--tertiary" in sys.argv:
+            vel = np.random.default_rng(3).normal(0.0, 0.01, (len(p), 3))
+            s.update_data(s.data.with_columns(vx=vel[:, 0], vy=vel[:, 1], vz=vel[:, 2], amass=np.full(len(p), 63.546)))
         for name, fn in CALLS:
             torch.cuda.synchronize(); t0 = time.perf_counter()
             try:
                 fn(s); torch.cuda.synchronize()
                 res[(tag, name)] = (time.perf_counter() - t0) * 1e3
-            except ValueError as e:  # a refusal (printed as nan, with the time it took to refuse)
+            except (ValueError, KeyError, TypeError, NotImplementedError) as e:  # a refusal (printed as nan, with the time it took to refuse)
                 res[(tag, name)] = float("nan")
                 print(f"# {tag}: {name} refused after {(time.perf_counter() - t0) * 1e3:.0f} ms: {str(e)[:110]}")
 print(f"N = {len(pos)}" if "--sizes" not in sys.argv else "sizes")
