@@ -433,7 +433,8 @@ static int voronoi_solve(void *stream, const double *dx, const double *dy, const
                 // as wide as the slab, which only rows of 10^4..10^5 entries would close, seconds per pass.  A void in a crystal
                 // closes some cells with every pass and goes on)
                 if ((double)nl * (double)M > 4.0e8 || M > 8192 || (M > 2048 && stalled)) {
-                    set_error("mdh_voronoi_volume_number_radius: the search list would exceed 4e8 entries (extremely inhomogeneous system, e.g. a cluster in a periodic vacuum)");
+                    set_error("mdh_voronoi_volume_number_radius: the search list would exceed 4e8 entries (extremely inhomogeneous system, e.g. a cluster in a periodic vacuum): " +
+                              std::to_string((long long)nl) + " cells still open at a search radius of " + std::to_string(rc) + " with rows of " + std::to_string((long long)M) + " candidates");
                     return MDH_ERR_ARG;
                 }
                 int *dv = inner.alloc_n<int>((size_t)(nl * M));
