@@ -264,6 +264,12 @@ def test_neighbor_rows_of_65_to_128_slots_take_the_wide_tile_kernel(kind):
         assert (na == 78).all()
     if kind == "fcc_rc6_rattled_narrow":
         assert na.min() > M
+    # the fused neighbor + CNA entry on rows this wide: the same lists, and the labels of the two-call path
+    pa = np.zeros(len(x), np.int32); pb = np.zeros(len(x), np.int32)
+    _cna.fcna(x, y, z, box, org, bnd, vb, nb, pa, rc, 1)
+    vf = np.empty((len(x), M), np.int32); df = np.empty((len(x), M)); nf = np.empty(len(x), np.int32)
+    _neighbor.build_neighbor_fcna(x, y, z, box, org, bnd, rc, vf, df, nf, pb, 1, fill_pads=True)
+    assert np.array_equal(nf, na) and np.array_equal(vf, va) and np.array_equal(df, da) and np.array_equal(pb, pa)
     v2, d2, n2 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1)
     vo, do, no = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
     assert v2.shape[1] > 64
