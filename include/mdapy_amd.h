@@ -418,6 +418,16 @@ int mdh_voronoi_neighbor(const double *x, const double *y, const double *z, int6
                          double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width, int space,
                          void *stream);
 
+/* mdh_voronoi_neighbor_count and mdh_voronoi_neighbor from ONE construction of the cells (the reference's function builds its
+ * container once, src/voronoi.cpp:307-447): rows are made `width` columns wide on the device; if no cell has more faces, verlet /
+ * distance / face_area (buffers of N * width entries) receive them as (N, *width_out_host) arrays, *width_out_host being the
+ * width mdh_voronoi_neighbor_count reports, and neighbor_number (N) the face counts; otherwise only *width_out_host (> width) is
+ * written: call again with that width. */
+int mdh_voronoi_neighbor_rows(const double *x, const double *y, const double *z, int64_t N, const double *box9_host,
+                              const double *origin3_host, const int *boundary3_host, double a_face_area_threshold,
+                              double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width,
+                              int *neighbor_number, int *width_out_host, int space, void *stream);
+
 /* geometry of _voronoi.get_cell_info                          src/voronoi.cpp:449-540: per cell, every face (walls of open axes
  * included) as a polygon.  face_nv (N,W) i32 vertices per face slot (0: none), face_area (N,W), face_vert (N,W,V,3) vertices
  * relative to the atom in polygon order, nfaces / volume / radius (N) as in mdh_voronoi_volume_number_radius.

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "mdh_voronoi_volume_number_radius": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, cint, vp],
     "mdh_voronoi_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, vp, vp, cint, vp],
     "mdh_voronoi_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, dbl, vp, vp, vp, cint, cint, vp],
+    "mdh_voronoi_neighbor_rows": [vp, vp, vp, i64, vp, vp, vp, dbl, dbl, vp, vp, vp, cint, vp, vp, cint, vp],
     "mdh_filter_overlap_atom_with_grain": [vp, vp, vp, vp, vp, i64, vp, vp, vp, dbl, dbl, dbl, vp, cint, vp],
     "mdh_transform_and_filter": [vp, vp, vp, i64, vp, vp, vp, vp, cint, vp, vp, cint, vp],
     "mdh_voronoi_cell_info": [vp, vp, vp, i64, vp, vp, vp, cint, cint, vp, vp, vp, vp, vp, vp, vp, cint, vp],

@@ -32,6 +32,9 @@ def get_voronoi_volume_number_radius_tri(x, y, z, box, origin, boundary, rotatio
                                      np.ones(3, i32), volume, neighbor_number, cavity_radius, num_t)
 
 
+_ROW_GUESS = 32  # columns of the device-side rows of get_voronoi_neighbor's first attempt (a test lowers it to reach the second)
+
+
 def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, r_face_area_threshold, num_t=1):
     """src/voronoi.cpp:307 -> (verlet (N,W) i32, distance (N,W) f64, face_area (N,W) f64, neighbor_number (N) i32).
     Rows list the faces shared with atoms, nearest first (the reference's rows follow voro++'s internal face order and
@@ -46,16 +49,20 @@ def get_voronoi_neighbor(x, y, z, box, origin, boundary, a_face_area_threshold, 
     if c.space != _lib.HOST:
         raise TypeError("get_voronoi_neighbor takes host (numpy) positions")
     L = _lib.lib()
-    _lib.check(L.mdh_voronoi_neighbor_count(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, nn.ctypes.data,
-                                            ctypes.byref(w), c.space, c.stream))
-    width = max(int(w.value), 1)
-    verlet = np.full((n, width), -1, i32)
-    dist = np.full((n, width), 10000.0)
-    area = np.zeros((n, width))
-    _lib.check(L.mdh_voronoi_neighbor(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, float(a_face_area_threshold),
-                                      float(r_face_area_threshold), verlet.ctypes.data, dist.ctypes.data, area.ctypes.data, width,
-                                      c.space, c.stream))
-    return verlet, dist, area, nn
+    # one construction of the cells (the reference builds its container once): rows 32 columns wide on the device — cells of
+    # crystals and liquids have 12 to ~26 faces — handed over at the width the face counts ask for; a cell with more faces: again
+    guess = _ROW_GUESS
+    while True:
+        verlet, dist, area = np.empty(n * guess, i32), np.empty(n * guess, f64), np.empty(n * guess, f64)
+        _lib.check(L.mdh_voronoi_neighbor_rows(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), n, pb, po, pp, float(a_face_area_threshold),
+                                               float(r_face_area_threshold), verlet.ctypes.data, dist.ctypes.data, area.ctypes.data,
+                                               guess, nn.ctypes.data, ctypes.byref(w), c.space, c.stream))
+        width = max(int(w.value), 1)
+        if width <= guess:
+            break
+        guess = width
+    cut = lambda a: a[:n * width].reshape(n, width)
+    return cut(verlet), cut(dist), cut(area), nn
 
 
 def get_voronoi_neighbor_tri(x, y, z, box, origin, boundary, rotation, need_rotation, a_face_area_threshold,

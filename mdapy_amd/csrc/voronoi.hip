@@ -634,6 +634,57 @@ extern "C" int mdh_voronoi_neighbor(const double *x, const double *y, const doub
 
 // replaces the geometry of _voronoi.get_cell_info (src/voronoi.cpp:449-540): for every cell its faces (walls of open axes
 // included) as polygons.  face_nv (N, W): vertices of face slot s (0: no face), face_area (N, W), face_vert (N, W, V, 3):
+// (rows of `from` columns -> rows of `to` <= from columns: the leading columns of every row)
+__global__ __launch_bounds__(256) void k_narrow_rows(const int *__restrict__ v, const double *__restrict__ d, const double *__restrict__ a,
+                                                     int64_t N, int from, int to, int *__restrict__ vo, double *__restrict__ d_out,
+                                                     double *__restrict__ ao)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * to)
+        return;
+    const int64_t r = e / to;
+    const int c = (int)(e - r * to);
+    vo[e] = v[r * from + c];
+    d_out[e] = d[r * from + c];
+    ao[e] = a[r * from + c];
+}
+
+// Both of the above from ONE construction of the cells: the rows are made `width` columns wide on the device; if no cell has
+// more faces than that, the caller's buffers receive them as (N, *width_out) arrays — *width_out = the width
+// mdh_voronoi_neighbor_count reports, the buffers must hold N * width entries — and neighbor_number the face counts; otherwise
+// nothing is written but *width_out (> width): call again with that width.
+extern "C" int mdh_voronoi_neighbor_rows(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                         const double *origin3, const int *boundary3, double a_face_area_threshold,
+                                         double r_face_area_threshold, int *verlet, double *distance, double *face_area, int width,
+                                         int *neighbor_number, int *width_out, int space, void *stream)
+{
+    if (N < 0 || width <= 0 || !width_out) { set_error("mdh_voronoi_neighbor_rows: invalid shape"); return MDH_ERR_ARG; }
+    *width_out = 0;
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    double *v = sc.alloc_n<double>((size_t)N), *r = sc.alloc_n<double>((size_t)N);
+    int *nf = sc.stage(neighbor_number, (size_t)N, space, false, true);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    int *wv = sc.alloc_n<int>((size_t)N * width);
+    double *wd = sc.alloc_n<double>((size_t)N * width), *wa = sc.alloc_n<double>((size_t)N * width);
+    if (sc.failed())
+        return sc.error();
+    int maxf = 0;
+    MDH_TRY(voronoi_driver(dx, dy, dz, N, box9, origin3, boundary3, v, nf, r, wv, wd, wa, width, a_face_area_threshold,
+                           r_face_area_threshold, &maxf, MDH_DEVICE, stream)); // (maxf is on the host when the driver returns)
+    const int w = maxf > 1 ? maxf : 1;
+    *width_out = w;
+    if (w > width)
+        return sc.finish(space);
+    int *ov = sc.stage(verlet, (size_t)N * w, space, false, true);
+    double *od = sc.stage(distance, (size_t)N * w, space, false, true), *oa = sc.stage(face_area, (size_t)N * w, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    hipLaunchKernelGGL(k_narrow_rows, dim3(grid_for(N * w, 256)), dim3(256), 0, sc.stream(), wv, wd, wa, N, width, w, ov, od, oa);
+    return sc.finish(space);
+}
+
 // polygon vertices RELATIVE TO THE ATOM in polygon order; W >= the width reported by mdh_voronoi_neighbor_count.
 // *need_v_host > V on return: some polygon has more vertices than V (call again with that V); volume / radius as in
 // mdh_voronoi_volume_number_radius.  Faces are listed walls first, then nearest neighbour first (voro++ lists them in the

@@ -1615,6 +1615,36 @@ def test_voronoi_vs_reference_library(case):
         assert abs(v1.sum() - vol) < 1e-6 * vol  # the cells tile the periodic box
 
 
+def test_voronoi_neighbor_rows_in_one_construction_equal_count_then_fill():
+    """get_voronoi_neighbor builds the cells once (mdh_voronoi_neighbor_rows: rows 32 columns wide on the device, handed over at the
+    width the face counts ask for); a cell with more faces than the first attempt's columns sends it round again — both against
+    mdh_voronoi_neighbor_count + mdh_voronoi_neighbor, the two-construction form, bit for bit."""
+    import ctypes
+    from mdapy_amd import _lib
+    rng = np.random.default_rng(93)
+    pos, box = rng.random((3000, 3)) * 28.0, np.eye(3) * 28.0  # a gas: 8 ... 30 faces per cell
+    x, y, z = _xyz(pos)
+    keep, (pb, po, pp) = _lib.host_box(box, ORG0, PBC)
+    n = len(x)
+    L = _lib.lib()
+    for a_thr, r_thr in ((-1.0, -1.0), (0.5, -1.0), (-1.0, 0.01)):
+        nn0 = np.zeros(n, np.int32); w = ctypes.c_int(0)
+        _lib.check(L.mdh_voronoi_neighbor_count(x.ctypes.data, y.ctypes.data, z.ctypes.data, n, pb, po, pp, nn0.ctypes.data, ctypes.byref(w), _lib.HOST, None))
+        W = int(w.value)
+        v0 = np.full((n, W), -1, np.int32); d0 = np.full((n, W), 10000.0); f0 = np.zeros((n, W))
+        _lib.check(L.mdh_voronoi_neighbor(x.ctypes.data, y.ctypes.data, z.ctypes.data, n, pb, po, pp, a_thr, r_thr, v0.ctypes.data, d0.ctypes.data, f0.ctypes.data, W, _lib.HOST, None))
+        assert W > 8
+        for guess in (32, 8):
+            old = _voronoi._ROW_GUESS
+            _voronoi._ROW_GUESS = guess
+            try:
+                v1, d1, f1, nn1 = _voronoi.get_voronoi_neighbor(x, y, z, box, ORG0, PBC, a_thr, r_thr)
+            finally:
+                _voronoi._ROW_GUESS = old
+            assert v1.shape == (n, W) and np.array_equal(nn1, nn0)
+            assert np.array_equal(v1, v0) and np.array_equal(d1, d0) and np.array_equal(f1, f0)
+
+
 @needs_voro
 @pytest.mark.parametrize("kind", ["slab", "cluster", "void"])
 def test_voronoi_open_cells_take_the_listed_atom_passes(kind):
