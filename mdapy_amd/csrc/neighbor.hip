@@ -400,11 +400,12 @@ __global__ __launch_bounds__(256) void k_sort_cells(const int *__restrict__ cell
 }
 
 // The same order for grids of many atoms per cell (N / ncell > 6: rc = 5 A in a metal, 11 atoms per cell): EIGHT lanes per cell.
-// The cell's ids are staged in LDS (40 per cell; a fuller cell is sorted by its first lane straight from HBM, as above), then lane l
+// The cell's ids are staged in LDS (64 per cell; a fuller cell is sorted by its first lane as above), then lane l
 // ranks the atoms l, l + 8, ... by counting the larger ids of its cell — n / 8 trips of n LDS reads instead of n * n dependent
 // global ones in a single lane (rc = 6 A, 18 atoms per cell, 4 M atoms: 240 us, as long as k_assign, k_scatter and k_gather together).
-constexpr int SORT_DENSE_CAP = 40;
-__global__ __launch_bounds__(256) void k_sort_cells_dense(const int *__restrict__ cell_start, int *__restrict__ order, int64_t ncell)
+constexpr int SORT_DENSE_CAP = 64;
+__global__ __launch_bounds__(256) void k_sort_cells_dense(const int *__restrict__ cell_start, int *__restrict__ order, int64_t ncell,
+                                                          int *__restrict__ tmp)
 {
     __shared__ int ids[32 * SORT_DENSE_CAP];
     const int sub = threadIdx.x & 7, lc = threadIdx.x >> 3;
@@ -414,10 +415,15 @@ __global__ __launch_bounds__(256) void k_sort_cells_dense(const int *__restrict_
         s = cell_start[c];
         n = cell_start[c + 1] - s;
     }
-    const bool staged = n > 1 && n <= SORT_DENSE_CAP;
+    const bool staged = n > 1 && n <= SORT_DENSE_CAP, big = n > SORT_DENSE_CAP;
     if (staged)
         for (int a = sub; a < n; a += 8) ids[lc * SORT_DENSE_CAP + a] = order[s + a];
-    __syncthreads();
+    // a fuller cell — the LAST cell of an axis takes the remainder of the box (neighbor.cpp:58-61) and is up to twice as wide: the
+    // corner cell of a 256 k-atom box at rc = 5 A holds 84 atoms where the mean is 12 — goes through the free `rank` array instead,
+    // still eight lanes to the cell (one lane, n * n loads: 330 us for that one cell, as long as the rest of the call)
+    if (big)
+        for (int a = sub; a < n; a += 8) tmp[s + a] = order[s + a];
+    __syncthreads(); // (workgroup scope: the copies in LDS and in HBM are visible to the cell's other lanes)
     if (staged) {
         for (int a = sub; a < n; a += 8) {
             const int mine = ids[lc * SORT_DENSE_CAP + a];
@@ -425,15 +431,12 @@ __global__ __launch_bounds__(256) void k_sort_cells_dense(const int *__restrict_
             for (int q = 0; q < n; ++q) larger += ids[lc * SORT_DENSE_CAP + q] > mine ? 1 : 0;
             order[s + larger] = mine; // (ids are distinct: every slot of the cell is written once)
         }
-    } else if (n > SORT_DENSE_CAP && sub == 0) {
-        for (int a = s + 1; a < s + n; ++a) { // insertion sort, descending
-            const int v = order[a];
-            int q = a - 1;
-            while (q >= s && order[q] < v) {
-                order[q + 1] = order[q];
-                --q;
-            }
-            order[q + 1] = v;
+    } else if (big) {
+        for (int a = sub; a < n; a += 8) {
+            const int mine = tmp[s + a];
+            int larger = 0;
+            for (int q = 0; q < n; ++q) larger += tmp[s + q] > mine ? 1 : 0;
+            order[s + larger] = mine;
         }
     }
 }
@@ -645,7 +648,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(N, 256)), dim3(256), 0, st, cell_id, rank, cg.cell_start, cg.order, N);
     if (sort_desc) {
         if (!windowed && !sort_key && (double)N > 6.0 * (double)g.ncell) {
-            hipLaunchKernelGGL(k_sort_cells_dense, dim3(grid_for(g.ncell, 32)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell);
+            hipLaunchKernelGGL(k_sort_cells_dense, dim3(grid_for(g.ncell, 32)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, rank);
         } else if (!windowed) {
             hipLaunchKernelGGL(k_sort_cells, dim3(grid_for(g.ncell, 256)), dim3(256), 0, st, cg.cell_start, cg.order, g.ncell, sort_key, rank);
         } else {
