@@ -736,6 +736,72 @@ __device__ __forceinline__ int neighbor_one(const SortedView &sv, const int *__r
     return cnt;
 }
 
+// The same walk by a whole wavefront for ONE atom: 64 candidates per trip, the hits' slots from a ballot (candidate order = row
+// order, as above).  For the listed tiles of the mop-up kernel: their atoms sit in the fat last cells of the box, a thread walks
+// 300 ... 1000 candidates there four at a time (80 ... 380 dependent trips), a wave 9 runs of one to three trips.
+template <bool TRI, int MODE>
+__device__ __forceinline__ int neighbor_one_wave(const SortedView &sv, const int *__restrict__ cell_start, const DBox &b,
+                                                 const Grid &g, double rc, int *__restrict__ verlet, double *__restrict__ dist,
+                                                 int *__restrict__ nn, int64_t M, int64_t p, double xi, double yi, double zi, int c0,
+                                                 int c1, int c2)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    int cnt = 0;
+    const int i = sv.id_of(p);
+    const double rcsq = rc * rc; // neighbor.cpp:127
+    const int64_t row = (int64_t)i * M;
+    const bool zrun = (c2 >= 1) && (c2 + 1 < g.nc[2]);
+    for (int a = c0 - 1; a <= c0 + 1; ++a) { // neighbor.cpp:147-151
+        const int ca = pmod(a, g.nc[0]);
+        for (int bb = c1 - 1; bb <= c1 + 1; ++bb) {
+            const int64_t base = ((int64_t)ca * g.nc[1] + pmod(bb, g.nc[1])) * g.nc[2];
+            for (int seg = 0; seg < (zrun ? 1 : 3); ++seg) {
+                int s, e;
+                if (zrun) {
+                    s = cell_start[base + c2 - 1];
+                    e = cell_start[base + c2 + 2];
+                } else {
+                    const int cc = pmod(c2 - 1 + seg, g.nc[2]);
+                    s = cell_start[base + cc];
+                    e = cell_start[base + cc + 1];
+                }
+                for (int q0 = s; q0 < e; q0 += 64) {
+                    const int q = q0 + lane;
+                    bool hit = false;
+                    int j = -1;
+                    double d2 = 0.0;
+                    if (q < e) {
+                        double xq, yq, zq;
+                        sv.get(q, xq, yq, zq, j);
+                        double dx = xq - xi, dy = yq - yi, dz = zq - zi; // raw x[j] - wrapped centre, :164-166
+                        pbc<TRI>(b, dx, dy, dz);
+                        d2 = dx * dx + dy * dy + dz * dz;
+                        hit = j != i && d2 <= rcsq;
+                    }
+                    const unsigned long long m = __ballot(hit);
+                    if (MODE != 0 && hit) {
+                        const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < M) {
+                            verlet[row + slot] = j;
+                            dist[row + slot] = sqrt(d2);
+                        }
+                    }
+                    cnt += __popcll(m);
+                }
+            }
+        }
+    }
+    if (lane == 0) nn[i] = cnt;
+    if (MODE == 2) {
+        const double pad = rc + 1.0;
+        for (int64_t n = cnt + lane; n < M; n += 64) {
+            verlet[row + n] = -1;
+            dist[row + n] = pad;
+        }
+    }
+    return cnt;
+}
+
 template <bool TRI, int MODE>
 __device__ __forceinline__ void neighbor_atoms_body(const SortedView &sv,
                                                   const int *__restrict__ cell_start, int64_t N, const DBox &b, const Grid &g,
@@ -801,29 +867,31 @@ __device__ __forceinline__ void neighbor_tiles_body(const SortedView &sv,
         return;
     const int nlist = min(*tf.any, tf.list_cap);
     int best = 0;
-    for (int q = blockIdx.x; q < nlist; q += gridDim.x) {
-        const int t = tf.list[q];
+    // a workgroup per (listed tile, column of the tile), a wavefront per atom of the column's z-run (neighbor_one_wave)
+    const int ncol = tf.tile * tf.tile;
+    const int wave = (int)(threadIdx.x >> 6), nwave = (int)(blockDim.x >> 6);
+    // (... and a column's atoms in MOP_CHUNKS interleaved shares, a workgroup each: the corner column of the box holds 84 atoms in
+    // one cell where the mean is 12 — 21 atoms per wave was the whole kernel's critical path, 440 us)
+    constexpr int MOP_CHUNKS = 8;
+    for (int64_t w8 = blockIdx.x; w8 < (int64_t)nlist * ncol * MOP_CHUNKS; w8 += gridDim.x) {
+        const int64_t w = w8 / MOP_CHUNKS;
+        const int chunk = (int)(w8 - w * MOP_CHUNKS);
+        const int t = tf.list[w / ncol], colq = (int)(w % ncol);
         const int t2 = t % tf.nt[2], t1 = (t / tf.nt[2]) % tf.nt[1], t0 = t / (tf.nt[2] * tf.nt[1]);
         const int z0 = t2 * tf.tile_z, z1 = min(z0 + tf.tile_z, g.nc[2]);
-        // the tile's (x, y) columns side by side: a group of threads per column, each thread its share of the column's atoms
-        const int ncol = tf.tile * tf.tile;
-        const int tpc = max(1, (int)blockDim.x / ncol); // threads per column: all of the workgroup's (28 x 9 of 256 for a 3 x 3 tile)
-        const int colq = (int)threadIdx.x / tpc, sub = (int)threadIdx.x % tpc;
-        if (colq < ncol) {
-            const int a = t0 * tf.tile + colq / tf.tile, c = t1 * tf.tile + colq % tf.tile;
-            if (a < g.nc[0] && c < g.nc[1]) {
-                const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
-                const int s = cell_start[col + z0], e = cell_start[col + z1]; // the z-run of a column is contiguous
-                for (int p = s + sub; p < e; p += tpc) {
-                    double xi, yi, zi;
-                    { int idp; sv.get(p, xi, yi, zi, idp); }
-                    if (b.anypbc)
-                        wrap<TRI>(b, xi, yi, zi);
-                    int c0, c1, c2;
-                    cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
-                    best = max(best, neighbor_one<TRI, MODE>(sv, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
-                    if (tf.cna_todo) defer(tf.cna_todo, sv.id_of(p));
-                }
+        const int a = t0 * tf.tile + colq / tf.tile, c = t1 * tf.tile + colq % tf.tile;
+        if (a < g.nc[0] && c < g.nc[1]) {
+            const int64_t col = ((int64_t)a * g.nc[1] + c) * g.nc[2];
+            const int s = cell_start[col + z0], e = cell_start[col + z1]; // the z-run of a column is contiguous
+            for (int p = s + chunk * nwave + wave; p < e; p += nwave * MOP_CHUNKS) {
+                double xi, yi, zi;
+                { int idp; sv.get(p, xi, yi, zi, idp); }
+                if (b.anypbc)
+                    wrap<TRI>(b, xi, yi, zi);
+                int c0, c1, c2;
+                cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+                best = max(best, neighbor_one_wave<TRI, MODE>(sv, cell_start, b, g, rc, verlet, dist, nn, M, p, xi, yi, zi, c0, c1, c2));
+                if (tf.cna_todo && (threadIdx.x & 63) == 0) defer(tf.cna_todo, sv.id_of(p));
             }
         }
     }
