@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 A_CU = 3.615
 RC = 0.854 * A_CU
+METRIC = "atoms/sec for neighbor+CNA on 10M-atom FCC Cu; 1/2/4/8-GPU scaling"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # the OpenMP port against the reference's own C++ on identical input and cores (1 000 188-atom FCC Cu, neighbor M = 16 + fixed
 # CNA, 8 threads, build container): port 0.315 s, reference 0.40 s
@@ -242,6 +243,79 @@ def live_traffic(args):
     return got["fetch"], got["write"]
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    the environment, rendezvous on 127.0.0.1 — what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would set),
+    pass rank 0's ONE JSON line through, and when any rank fails stop the others and print a JSON line with "error"."""
+    n = args.gpus
+    shared = os.environ.get("MDH_BENCH_SHARED_GPU", "") == "1"
+
+    def fail(msg, code=1):
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "atoms/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                          "error": msg}))
+        sys.stdout.flush()
+        raise SystemExit(code)
+
+    if not shared:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            fail(f"--gpus {n} on a box with {have} visible GPU(s) (MDH_BENCH_SHARED_GPU=1 runs the ranks on one GPU over gloo, for tests)")
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               MDH_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    errs = []
+    for r in range(n):
+        errs.append(tempfile.TemporaryFile(mode="w+"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[r], text=True))
+    bad = None
+    deadline = time.time() + float(os.environ.get("MDH_BENCH_LAUNCH_TIMEOUT", "1500"))
+    live = set(range(n))
+    while live and bad is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                bad = (r, rc)
+                break
+        if time.time() > deadline:
+            bad = (-1, "timeout")
+        if live and bad is None:
+            time.sleep(0.05)
+    if bad is not None:
+        for p in procs:  # exactly the processes started here, by handle
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        r = bad[0]
+        tail = ""
+        if r >= 0:
+            errs[r].seek(0)
+            tail = errs[r].read()[-1500:]
+        fail(f"rank {r} of {n} ended with {bad[1]}: {tail.strip()}" if r >= 0 else f"no result within the launch timeout ({n} ranks)")
+    out = procs[0].stdout.read()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        fail(f"rank 0 printed {len(lines)} JSON lines")
+    print(lines[0])
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
     if args.pmc_child:
@@ -251,12 +325,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # plain `python bench.py --gpus N`: this process starts the N ranks itself
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the two must agree")
     # MDH_BENCH_SHARED_GPU=1 (tests on a one-GPU box): every rank on cuda:0, gloo instead of RCCL — the same code path
     # above the transport, no claim about its speed
@@ -346,10 +420,31 @@ def main():
         _, _, prof_all = timed(step, min(args.steps, 10), 0, ranges=1)
         for name, rec in prof_all.items():
             prof.setdefault(name, rec)
+    multi = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # what the exchange alone costs (selection + packing + ring + append, nothing overlapped), after the timed region:
+        # max over ranks; and every rank's owned / ghost atom counts
+        dom_x = dec.exchange_halo(x, y, z, gid, RC, sort=False)  # (picks up the exchange the last timed step prefetched)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dom_x = dec.exchange_halo(x, y, z, gid, RC, sort=False)
+        sync()
+        n_ghost = int(dom_x.x.shape[0]) - n_local
+        mine = torch.zeros((world, 3), dtype=torch.float64, device="cpu" if shared else dev)
+        mine[rank, 0], mine[rank, 1], mine[rank, 2] = n_local, n_ghost, (time.perf_counter() - t0) / 5 * 1e3
+        dist.all_reduce(mine)
+        mine = mine.cpu()
+        multi = {"atoms_per_rank": [int(v) for v in mine[:, 0].tolist()], "ghosts_per_rank": [int(v) for v in mine[:, 1].tolist()],
+                 "exchange_ms": float(mine[:, 2].max()),
+                 # a ghost is x, y, z and its id, 8 bytes each; every rank receives its ghosts once per step
+                 "halo_bytes_per_step": int(mine[:, 1].sum().item()) * 32,
+                 "transport": "gloo, host-staged, ranks sharing one GPU (MDH_BENCH_SHARED_GPU=1): says nothing about xGMI" if shared
+                              else "RCCL (torch.distributed backend nccl), batch_isend_irecv ring, device buffers"}
+        del dom_x
 
     # correctness of what was timed: perfect FCC -> every owned atom has 12 neighbours and label 1
     nn_o, pat_o, dom = out
@@ -366,7 +461,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         n_rows = n_local if dom is None else int(dom.x.shape[0])  # rows the kernel actually processed on rank 0
         res = {
-            "metric": "atoms/sec for neighbor+CNA on 10M-atom FCC Cu; 1/2/4/8-GPU scaling",
+            "metric": METRIC,
             "value": n_total / (elapsed / args.steps),
             "unit": "atoms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -376,8 +471,14 @@ def main():
                                     if strong else f"FCC Cu a={A_CU}, {cells}^3 cells per GPU ({n_local} atoms/GPU, {n_total} total), ") +
                                    f"build_neighbor(rc=0.854a={RC:.5f}, max_neigh={M}) + fixed-cutoff CNA, positions resident in HBM",
                        "atoms_per_gpu": n_local, "rc": RC, "max_neigh": M, "sigma": args.sigma,
-                       "parallelism": f"slab{world}" if world > 1 else "single", "world_size_checked": world},
+                       "parallelism": f"slab{world}" if world > 1 else "single", "world_size_checked": world,
+                       "launched_by": "bench.py itself (one process per GPU)" if os.environ.get("MDH_BENCH_SELF_LAUNCHED") == "1"
+                                      else ("an external launcher" if world > 1 else "single process")},
         }
+        if multi is not None:
+            res["config"].update(multi)
+            res["config"]["exchange_note"] = ("exchange_ms: the halo exchange alone, nothing overlapped, max over ranks; inside the timed "
+                                              "steps the next step's exchange travels on a side stream under this step's kernels")
         if "k_neighbor" in prof:
             cnt, tot = prof["k_neighbor"]
             avg_ms = tot / cnt

@@ -508,10 +508,28 @@ static thread_local CellWindow g_window{0, 0.0, 0.0, false};
 static thread_local int *g_window_violations = nullptr; // pinned host word of the previous windowed build
 
 // out[a..b) = *v (a value that is on the device only)
+// (16-byte stores over the aligned middle — the region behind a slab's window is most of the global grid, 100 MB on eight ranks —
+// launched by fill_from() below)
 __global__ __launch_bounds__(256) void k_fill_from(int *__restrict__ out, int64_t a, int64_t b, const int *__restrict__ v)
 {
-    const int64_t i = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < b) out[i] = *v;
+    const int val = *v;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b - a < 8) {
+        if (a + i < b) out[a + i] = val;
+        return;
+    }
+    const int64_t a4 = (a + 3) & ~(int64_t)3, b4 = b & ~(int64_t)3; // a4 <= b4: out is 16-byte aligned at multiples of four
+    const int64_t q = a4 + 4 * i;
+    if (q + 4 <= b4) *reinterpret_cast<int4 *>(out + q) = make_int4(val, val, val, val);
+    if (i < 4) {
+        if (a + i < a4) out[a + i] = val;
+        if (b4 + i < b) out[b4 + i] = val;
+    }
+}
+static void fill_from(hipStream_t st, int *out, int64_t a, int64_t b, const int *v)
+{
+    if (b > a)
+        hipLaunchKernelGGL(k_fill_from, dim3(grid_for((b - a) / 4 + 8, 256)), dim3(256), 0, st, out, a, b, v);
 }
 
 // out[a..b) += *v  (v outside [a, b)); the entry `skip`, if in range, is left alone
@@ -584,7 +602,9 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     if (g_window.set) {
         const CellWindow w = g_window;
         g_window.set = false; // one build
-        if (w.axis == 0 && !b.tri && g.mode == 0 && g.nc[0] >= 16 && w.hi > w.lo && w.hi - w.lo < 0.75) {
+        // (only the neighbor builds — the callers of the packed record — know what a window leaves undone; a hint that meets
+        // any other grid build is dropped)
+        if (packed && w.axis == 0 && !b.tri && g.mode == 0 && g.nc[0] >= 16 && w.hi > w.lo && w.hi - w.lo < 0.75) {
             const double L = b.h[0];
             int lo = (int)std::floor(w.lo * L * g.rc_inv) - 1, hi = (int)std::ceil(w.hi * L * g.rc_inv) + 1; // one plane of margin
             if (hi - lo < g.nc[0] - 2) {
@@ -635,12 +655,15 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         scan_piece(a0, a1, gen, cg.flags);
         if (b1 > b0) {
             // second piece: offsets start at the first piece's total, which sits on the device in cell_start[a1]
-            hipLaunchKernelGGL(k_fill_from, dim3(grid_for(b0 - a1 - 1, 256) + 1), dim3(256), 0, st, cg.cell_start, a1 + 1, b0, cg.cell_start + a1);
+            fill_from(st, cg.cell_start, a1 + 1, b0, cg.cell_start + a1);
             scan_piece(b0, b1, next_scan_gen(), nullptr);
             hipLaunchKernelGGL(k_add_from, dim3(grid_for(b1 - b0 + 1, 256)), dim3(256), 0, st, cg.cell_start, b0, b1 + 1, cg.cell_start + a1, (int64_t)-1);
-            if (b1 < g.ncell) fill_const(b1 + 1, g.ncell + 1, (int)N);
+            // behind the window: the number of atoms BINNED (cell_start[b1], on the device) — N unless the promise was broken; with
+            // the constant N a cell behind a broken window spanned the records [n_binned, N), which k_scatter / k_gather never wrote
+            if (b1 < g.ncell)
+                fill_from(st, cg.cell_start, b1 + 1, g.ncell + 1, cg.cell_start + b1);
         } else if (a1 < g.ncell) {
-            fill_const(a1 + 1, g.ncell + 1, (int)N);
+            fill_from(st, cg.cell_start, a1 + 1, g.ncell + 1, cg.cell_start + a1);
         }
         MDH_HIP(fill_err);
     }
@@ -815,6 +838,9 @@ __device__ __forceinline__ void neighbor_atoms_body(const SortedView &sv,
     int cnt = 0;
     // the grid is capped (a stand-by launch then costs a few thousand workgroups that leave at once, not N / 256 of them):
     // a workgroup strides over the atoms
+    // (cell_start[ncell] = the atoms the grid holds: N, or fewer after a windowed build that dropped atoms outside its window —
+    // the records behind them were never written)
+    N = min(N, (int64_t)cell_start[g.ncell]);
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < N; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = base + threadIdx.x;
         bool mine = p < N;

@@ -76,7 +76,7 @@ def _from_ase(atoms):
 
 
 def _from_ovito(collection):
-    """frame, box and attributes of an OVITO ``DataCollection`` (load_save.py:413-505): the cell's 3x3 block transposed,
+    """frame, box and attributes of an OVITO ``DataCollection`` (load_save.py:413-505): the 3x4 cell transposed (vectors + origin),
     ``Position`` -> x y z, ``Particle Type`` -> type, ``Particle Identifier`` -> id, ``Velocity`` / ``Force`` -> three columns,
     ``Velocity Magnitude`` dropped, every other property under its name without blanks (vectors as name_0, name_1, ...);
     an ``element`` column when every particle type carries a name.  Duck-typed: ``.cell`` (array-like with ``.pbc``),
@@ -84,7 +84,8 @@ def _from_ovito(collection):
     for needed in ("cell", "particles", "attributes"):
         if not hasattr(collection, needed):
             raise TypeError("Only accept an Ovito DataCollection object")
-    cell = Box(np.array(collection.cell[...], dtype=np.float64)[:, :3].T, [1 if p else 0 for p in collection.cell.pbc])
+    # the whole 3x4 cell transposed: rows 0-2 the vectors, row 3 the origin (load_save.py:443-444)
+    cell = Box(np.array(collection.cell[...], dtype=np.float64).T, [1 if p else 0 for p in collection.cell.pbc])
     info = {key: value for key, value in collection.attributes.items()}
     three = {"Position": ("x", "y", "z"), "Velocity": ("vx", "vy", "vz"), "Force": ("fx", "fy", "fz")}
     one = {"Particle Type": "type", "Particle Identifier": "id"}

@@ -234,6 +234,44 @@ def test_bench_runs_its_multi_rank_path():
     assert res["config"]["atoms_per_gpu"] == 4 * 40 ** 3 and res["value"] > 0 and res["higher_is_better"] is True
     assert abs(res["value"] - 2 * res["config"]["atoms_per_gpu"] / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1 and "cpu_baseline" not in res
+    assert res["config"]["launched_by"] == "an external launcher" and len(res["config"]["atoms_per_rank"]) == 2
     wrong = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "20"], cwd=ROOT,
-                           capture_output=True, text=True, timeout=300)
-    assert wrong.returncode != 0 and "torch.distributed.run" in (wrong.stderr + wrong.stdout)
+                           env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert wrong.returncode != 0 and "must agree" in (wrong.stderr + wrong.stdout)
+
+
+def test_bench_starts_its_own_ranks():
+    """plain `python bench.py --gpus 2` — the driver's command form — with no launcher around it: bench.py starts one process
+    per rank itself, rank 0's ONE JSON line comes through, and a rank that fails turns into a JSON line with "error" and a
+    non-zero exit code.  (MDH_BENCH_SHARED_GPU=1: both ranks on this box's one GPU, gloo instead of RCCL.)"""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MDH_BENCH_SHARED_GPU"] = "1"
+    run = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cells", "40"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0 and "error" not in res
+    assert cfg["launched_by"].startswith("bench.py itself") and cfg["parallelism"] == "slab2"
+    assert cfg["atoms_per_rank"] == [4 * 40 ** 3] * 2 and all(g > 0 for g in cfg["ghosts_per_rank"])
+    assert cfg["halo_bytes_per_step"] == 32 * sum(cfg["ghosts_per_rank"]) and cfg["exchange_ms"] > 0
+    assert abs(res["value"] - 2 * cfg["atoms_per_gpu"] / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    # a failing rank: 20 cells do not split into 3 equal slabs
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--scaling", "strong", "--steps", "1", "--warmup", "0", "--cells", "20"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
+    lines = [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "do not split" in json.loads(lines[0])["error"]
+    # more ranks than GPUs without the test switch: refused with an error line, no rank started
+    env.pop("MDH_BENCH_SHARED_GPU")
+    import torch
+
+    many = torch.cuda.device_count() + 1
+    over = subprocess.run([sys.executable, "bench.py", "--gpus", str(many), "--steps", "1", "--warmup", "0", "--cells", "20"], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=300)
+    assert over.returncode != 0 and "visible GPU" in json.loads([ln for ln in over.stdout.splitlines() if ln.startswith("{")][0])["error"]

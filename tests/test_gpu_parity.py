@@ -1003,6 +1003,24 @@ def test_neighbor_cell_window_hint_same_rows_and_broken_promise_is_reported():
         build(None)      # ... and reported by the next build
     got = build((0.28, 0.54))  # the thread is usable again
     assert all(np.array_equal(a, b_) for a, b_ in zip(got, build(None)))
+    # a broken promise on the paths where the thread-per-atom kernel takes the whole call (rows wider than the tile kernel's 128
+    # slots): the records behind the atoms binned are never written, so no cell may span them and no centre may be read from
+    # them — every id written must be an atom's, and the atoms inside the window keep their full rows
+    Mw = 130
+    vw = torch.full((N, Mw), -7, dtype=torch.int32, device=dev); dw = torch.zeros((N, Mw), dtype=torch.float64, device=dev)
+    nw = torch.full((N,), -7, dtype=torch.int32, device=dev)
+    _neighbor.hint_cell_window(0, 0.40, 0.54)
+    _neighbor.build_neighbor(x, y, z, box, ORG0, PBC, rc, vw, dw, nw, 1, fill_pads=True)
+    torch.cuda.synchronize()
+    vw, nw = vw.cpu().numpy(), nw.cpu().numpy()
+    with pytest.raises(ValueError, match="outside the cell window"):
+        build(None)
+    ref_v, _, ref_n = build(None)
+    f = (pos[:, 0] / L) % 1.0
+    deep = (f >= 0.44) & (f < 0.50)  # atoms whose whole neighbourhood lies inside the promised planes
+    assert deep.sum() > 100 and np.array_equal(nw[deep], ref_n[deep])
+    assert np.array_equal(vw[deep][:, :M], ref_v[deep]) and (vw[deep][:, M:] == -1).all()
+    assert ((vw >= -1) | (vw == -7)).all() and (vw < N).all() and ((nw == -7) | ((nw >= 0) & (nw <= Mw))).all()
 
 
 from _ptm_cases import compare_ptm, ptm_cases

@@ -240,6 +240,7 @@ def test_system_from_ase_and_ovito_like_objects():
     c = Coll(); c.cell = _FakeCell(m34, (True, True, False)); c.particles = parts; c.attributes = {"Timestep": 100}
     s = mp.System(ovito_atom=c)
     assert s.N == 7 and np.array_equal(s.box.box, cell) and s.box.boundary.tolist() == [1, 1, 0]
+    assert s.box.origin.tolist() == [1.0, 2.0, 3.0]  # OVITO's origin column is part of the box (load_save.py:444)
     assert s.global_info == {"Timestep": 100}
     cols = set(s.data.columns)
     assert {"x", "y", "z", "type", "id", "vx", "vy", "vz", "PotentialEnergy", "StressTensor_0", "StressTensor_5", "element"} <= cols
