@@ -548,6 +548,17 @@ def main():
                 xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, sg)
                 extra[f"sigma_{sg:.2f}"] = other_input(xs, ys, zs, bx, n_local)
                 del xs, ys, zs
+            # (b0) atom ORDER: the headline lattice under one random permutation of its atoms (the reference's linked-list cell build
+            # does not care in which order atoms arrive, neighbor.cpp:64-100; these kernels' gathers and atomics do)
+            try:
+                gen = torch.Generator(device=dev); gen.manual_seed(11)
+                perm = torch.randperm(n_local, device=dev, generator=gen)
+                got = other_input(x[perm].contiguous(), y[perm].contiguous(), z[perm].contiguous(), bx, n_local)
+                extra["shuffled_ids"] = {k_: got[k_] for k_ in ("atoms", "ms_per_step", "atoms_per_s", "fcc_fraction", "kernels_ms")}
+                extra["shuffled_ids"]["ratio_to_ordered"] = got["ms_per_step"] / ms_per_step
+                del perm
+            except Exception as e:
+                extra["shuffled_ids"] = {"error": f"{type(e).__name__}: {e}"}
             # (b') the inputs that used to leave the tile kernel (round 4): an unwrapped trajectory frame — every atom a few whole box
             # lengths outside the box — and the same crystal in a sheared box open along its second vector; the build's device flag says
             # whether the thread-per-atom kernel had to take the call
@@ -581,8 +592,14 @@ def main():
                 pb = (poly.box.box, poly.box.origin, poly.box.boundary)
                 if n_poly < int(poly.N):  # (the buffers are the headline's: a box that came out fuller is cut to its first atoms, open along x)
                     pb = (poly.box.box, poly.box.origin, np.array([0, 1, 1], np.int32))
-                extra["polycrystal"] = dict(other_input(*cols, pb, n_poly), grains=grains, atoms_built=int(poly.N))
-                del cols, poly
+                extra["polycrystal"] = dict(other_input(*cols, pb, n_poly), grains=grains, atoms_built=int(poly.N),
+                                            order="the builder's: grain by grain, each in its rotated lattice's order")
+                gen = torch.Generator(device=dev); gen.manual_seed(12)
+                perm = torch.randperm(n_poly, device=dev, generator=gen)
+                got = other_input(*[c[perm].contiguous() for c in cols], pb, n_poly)
+                extra["polycrystal_shuffled"] = {k_: got[k_] for k_ in ("atoms", "ms_per_step", "atoms_per_s", "fcc_fraction", "kernels_ms")}
+                extra["polycrystal_shuffled"]["ratio_to_builder_order"] = got["ms_per_step"] / extra["polycrystal"]["ms_per_step"]
+                del cols, poly, perm
             except Exception as e:  # an extra, not the headline
                 extra["polycrystal"] = {"error": f"{type(e).__name__}: {e}"}
             # (d) strong scaling, one rank's share: the slab of rank 1 of 8 of the SAME box, exchange in loop-back on this GPU
