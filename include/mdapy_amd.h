@@ -215,6 +215,40 @@ int mdh_slab_halo_messages(const double *x, const double *y, const double *z, in
 int mdh_slab_append_ghosts(const double *msg_from_left, const double *msg_from_right, int64_t cap, int64_t nl, int64_t nr,
                            double *const *columns_host_array_of_device_pointers, int ncol, int64_t *gid, int64_t n_owned,
                            void *stream);
+/* The receiving side with NOTHING read by the host (the decomposed step's fast path): the ghost block behind the owned atoms has
+ * the fixed size 2 cap — the left message's atoms at n_owned + [0, cap), the right message's at n_owned + cap + [0, cap), their
+ * counts taken from the message headers on the device; the slots behind a message's atoms are marked ABSENT (x = NaN, y = z =
+ * extras = 0, id = -1).  An absent atom is given no cell by the cell-grid build of mdh_build_neighbor* (it appears in no row and
+ * its own row is not written: the caller zeroes the counts array).  A header above cap raises a flag that
+ * mdh_slab_overflow_check() reports (MDH_ERR_ARG, flag cleared) once that append has run on the device.  No reference
+ * counterpart (multi-GPU extension). */
+int mdh_slab_append_ghosts_static(const double *msg_from_left, const double *msg_from_right, int64_t cap,
+                                  double *const *columns_host_array_of_device_pointers, int ncol, int64_t *gid, int64_t n_owned,
+                                  void *stream);
+int mdh_slab_overflow_check(void);
+
+/* ---- atom order (csrc/order.hip).  The reference's linked-list cell build (src/neighbor.cpp:64-100) and its consumers are
+ * indifferent to the order in which atoms arrive; these kernels' gathers are not.  No reference counterpart: the host layer
+ * (mdapy_amd/system.py) uses the four entries to keep a cell-sorted copy of a system that was handed in in no spatial order.
+ *
+ * mdh_order_statistic: *far_fraction (host) = fraction of consecutive atoms (i, i+1) that do not lie in the same or in touching
+ * bins of a grid of ~64-atom bins.  ~0 for a lattice builder's order, a file written cell by cell or a sorted system, ~1 for a
+ * shuffled one.  Synchronises `stream`. */
+int mdh_order_statistic(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+                        const int *boundary3, double *far_fraction, int space, void *stream);
+/* mdh_spatial_sort: perm (N) i32 = the atoms in cell order (cells of 2.5 atoms on average, the walk of src/neighbor.cpp:18-62,
+ * descending index inside a cell), xs / ys / zs (N) f64 = the raw positions in that order.  *n_sorted (host) = N, or fewer when
+ * absent atoms (x = NaN) were handed in — perm is then no permutation.  Synchronises `stream`. */
+int mdh_spatial_sort(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+                     const int *boundary3, double *xs, double *ys, double *zs, int *perm, int64_t *n_sorted, int space, void *stream);
+/* mdh_permute: out[p] = in[perm[p]] (scatter == 0) or out[perm[p]] = in[p] (scatter != 0) for N elements of 4 or 8 bytes. */
+int mdh_permute(const void *in, const int *perm, int64_t N, int elem_bytes, int scatter, void *out, int space, void *stream);
+/* mdh_translate_rows: a list built on the sorted copy (row p = atom perm[p], entries = sorted indices) as the list of the
+ * original order: verlet[perm[p]][s] = perm[verlet_sorted[p][s]] (pads < 0 stay), dist and nn rows moved along (both NULL or both
+ * given, pairwise).  With rows built by mdh_build_neighbor_keyed(key = perm) the result is the list mdh_build_neighbor builds on
+ * the original order, bit for bit. */
+int mdh_translate_rows(const int *verlet_sorted, const double *dist_sorted, const int *nn_sorted, const int *perm, int64_t N,
+                       int64_t M, int *verlet, double *dist, int *nn, int space, void *stream);
 
 /*
  * first half of _neighbor.build_neighbor_without_max_neigh  src/neighbor.cpp:189-349:
@@ -241,6 +275,11 @@ typedef int (*mdh_alloc_rows_fn)(void *user, int64_t N, int64_t M, int **verlet,
 int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                              const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
                              mdh_alloc_rows_fn alloc, void *user, int space, void *stream);
+/* the same with an in-cell ordering key (N) i64 or NULL, as mdh_build_neighbor_keyed takes it (a sorted copy of a system: key = the
+ * original index, mdh_spatial_sort; a slab of a decomposed system: key = the global id) */
+int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                   const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
+                                   mdh_alloc_rows_fn alloc, void *user, const int64_t *key, int space, void *stream);
 
 /* replaces _neighbor.sort_verlet_by_distance               src/neighbor.cpp:745-775 */
 int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M, int sort_num, int space,

@@ -57,10 +57,17 @@ _SIGNATURES = {
     "mdh_cell_window_check": [vp],
     "mdh_slab_halo_messages": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, cint, vp, vp, i64, vp],
     "mdh_slab_append_ghosts": [vp, vp, i64, i64, i64, vp, cint, vp, i64, vp],
+    "mdh_order_statistic": [vp, vp, vp, i64, vp, vp, vp, vp, cint, vp],
+    "mdh_spatial_sort": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cint, vp],
+    "mdh_permute": [vp, vp, i64, cint, cint, vp, cint, vp],
+    "mdh_translate_rows": [vp, vp, vp, vp, i64, i64, vp, vp, vp, cint, vp],
+    "mdh_slab_append_ghosts_static": [vp, vp, i64, vp, cint, vp, i64, vp],
+    "mdh_slab_overflow_check": [],
     "mdh_build_neighbor_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, cint, vp],
     "mdh_build_neighbor_fcna": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, vp, vp, cint, vp],
     "mdh_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, cint, vp],
     "mdh_build_neighbor_exact": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, cint, vp],
+    "mdh_build_neighbor_exact_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, vp, cint, vp],
     "mdh_sort_verlet_by_distance": [vp, vp, i64, i64, cint, cint, vp],
     "mdh_wrap_positions": [vp, vp, vp, i64, vp, vp, vp, cint, vp],
     "mdh_average_by_neighbor": [dbl, vp, vp, vp, i64, i64, vp, vp, cint, cint, vp],

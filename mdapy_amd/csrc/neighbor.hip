@@ -43,7 +43,14 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false, outside = false, coded = false;
     int cell = -1 - (int)(threadIdx.x & 63); // lanes past the end: distinct negative values, no run, no atomic
-    if (i < N) {
+    // an atom whose x is NaN is ABSENT: it takes no cell, appears in nobody's row and gets no row of its own (the unused slots of a
+    // decomposed system's fixed-size ghost block, slab.hip k_slab_append_static; the reference has no meaning for such input)
+    const bool absent = i < N && x[i] != x[i];
+    if (absent) {
+        cell_id[i] = -1;
+        if (mv) mv[i] = (unsigned short)img::ATOM_NEUTRAL;
+    }
+    if (i < N && !absent) {
         const double xr = x[i], yr = y[i], zr = z[i];
         double xi = xr, yi = yr, zi = zr;
         int code = img::ATOM_NEUTRAL; // (m + 15) per axis: raw = wrapped + m*L
@@ -680,8 +687,8 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
                 hipLaunchKernelGGL(k_sort_cells, dim3(grid_for((p3 - p2) * plane, 256)), dim3(256), 0, st, cg.cell_start + p2 * plane, cg.order, (p3 - p2) * plane, sort_key, rank);
         }
     }
-    // (windowed: the atoms binned = the prefix behind the last piece, on the device; all N unless the promise was broken)
-    const int *n_binned = windowed ? cg.cell_start + (p3 > p2 ? p3 : p1) * plane : nullptr;
+    // (the atoms binned = the grid's total, on the device: all N unless absent atoms were handed in or a window's promise was broken)
+    const int *n_binned = cg.cell_start + g.ncell;
     hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4, n_binned);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
@@ -1379,6 +1386,14 @@ int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, 
                              const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
                              mdh_alloc_rows_fn alloc, void *user, int space, void *stream)
 {
+    return mdh_build_neighbor_exact_keyed(x, y, z, N, box9, origin3, boundary3, rc, nn, width, alloc, user, nullptr, space, stream);
+}
+
+// key (N) i64, or NULL: as in mdh_build_neighbor_keyed
+int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                   const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
+                                   mdh_alloc_rows_fn alloc, void *user, const int64_t *key, int space, void *stream)
+{
     if (N < 0 || N >= 2147483647LL || !(rc > 0) || !width || !alloc) { set_error("mdh_build_neighbor_exact: invalid N, rc, width or allocator"); return MDH_ERR_ARG; }
     DBox b;
     MDH_TRY(make_box(b, box9, origin3, boundary3));
@@ -1393,6 +1408,7 @@ int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, 
     const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
     int *dn = sc.stage(nn, (size_t)N, space, false, true);
     int *dmax = sc.alloc_n<int>(1);
+    const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
     if (sc.failed())
         return sc.error();
     hipStream_t st = sc.stream();
@@ -1401,7 +1417,7 @@ int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, 
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", st);
-        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, nullptr, true));
+        MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
     // Width hint: the largest count the previous call with the same (N, grid) found.  A sequence of calls on one system (a
     // trajectory, the same analysis repeated) almost always finds the same maximum again, so the rows are built at that

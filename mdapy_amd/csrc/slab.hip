@@ -93,10 +93,11 @@ __global__ __launch_bounds__(256) void k_slab_messages(const double *__restrict_
     if (is_down) put(msg_down, bd + __popcll(md & ((1ull << lane) - 1ull)));
 }
 
-__global__ void k_slab_headers(const int *__restrict__ counts, double *__restrict__ msg_up, double *__restrict__ msg_down)
+__global__ void k_slab_headers(int *__restrict__ counts, double *__restrict__ msg_up, double *__restrict__ msg_down)
 {
     msg_up[0] = (double)counts[0];
     msg_down[0] = (double)counts[1];
+    counts[0] = counts[1] = 0;
 }
 
 } // namespace mdh
@@ -116,16 +117,17 @@ extern "C" int mdh_slab_halo_messages(const double *x, const double *y, const do
     }
     Scope sc(stream);
     hipStream_t st = sc.stream();
-    int *dc = sc.alloc_n<int>(2);
+    // (two counters in a kept block that is zero whenever idle: k_slab_headers clears what it reads — no memset launch per exchange)
+    int *dc = static_cast<int *>(sc.alloc_kept(2 * sizeof(int), Scope::KEEP_ZERO));
     if (sc.failed())
         return sc.error();
-    MDH_HIP(hipMemsetAsync(dc, 0, 2 * sizeof(int), st));
     SlabExtras ex{{nullptr, nullptr, nullptr, nullptr}, nextra};
     for (int k = 0; k < nextra; ++k) ex.p[k] = extras[k];
     if (n > 0)
         hipLaunchKernelGGL(k_slab_messages, dim3(grid_for(n, 256)), dim3(256), 0, st, x, y, z, n, origin3[0], origin3[1], origin3[2],
                            hi3[0], hi3[1], hi3[2], up_from, down_below, dc, gid, ex, msg_up, msg_down, (int)cap);
     hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(1), 0, st, dc, msg_up, msg_down);
+    sc.keep_confirm(dc);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
@@ -148,6 +150,70 @@ __global__ __launch_bounds__(256) void k_slab_append(const double *__restrict__ 
     gid[n_owned + i] = (int64_t)m[1 + (int64_t)cols.n * cap + j];
 }
 } // namespace mdh
+
+// The same with NOTHING read by the host: the ghost block behind the owned atoms has the fixed size 2 cap — left message at
+// n_owned + [0, cap), right message at n_owned + cap + [0, cap) — the counts come from the message headers on the device, and the
+// slots behind them are marked absent (x = NaN: build_cell_grid gives such an atom no cell; y = z = extras = 0, id = -1).  A
+// header that announces more atoms than `cap` (the sender kept its first cap) sets a word of pinned host memory that
+// mdh_slab_overflow_check reads.
+namespace mdh {
+static thread_local int *g_slab_overflow = nullptr;
+__global__ __launch_bounds__(256) void k_slab_append_static(const double *__restrict__ msg_l, const double *__restrict__ msg_r, int64_t cap,
+                                                            SlabColumns cols, int64_t *__restrict__ gid, int64_t n_owned, int *__restrict__ overflow)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * cap)
+        return;
+    const bool left = i < cap;
+    const double *m = left ? msg_l : msg_r;
+    const int64_t j = left ? i : i - cap;
+    int64_t cnt = (int64_t)m[0];
+    if (cnt > cap) {
+        if (j == 0) *overflow = 1;
+        cnt = cap;
+    }
+    if (j < cnt) {
+        for (int k = 0; k < cols.n; ++k) cols.p[k][n_owned + i] = m[1 + (int64_t)k * cap + j];
+        gid[n_owned + i] = (int64_t)m[1 + (int64_t)cols.n * cap + j];
+    } else {
+        cols.p[0][n_owned + i] = __builtin_nan("");
+        for (int k = 1; k < cols.n; ++k) cols.p[k][n_owned + i] = 0.0;
+        gid[n_owned + i] = -1;
+    }
+}
+} // namespace mdh
+
+extern "C" int mdh_slab_append_ghosts_static(const double *msg_left, const double *msg_right, int64_t cap, double *const *columns, int ncol,
+                                             int64_t *gid, int64_t n_owned, void *stream)
+{
+    if (!msg_left || !msg_right || !columns || !gid || ncol < 3 || ncol > 7 || cap < 0 || n_owned < 0) {
+        set_error("mdh_slab_append_ghosts_static: bad arguments");
+        return MDH_ERR_ARG;
+    }
+    if (!g_slab_overflow) {
+        MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_slab_overflow), sizeof(int), hipHostMallocDefault));
+        *g_slab_overflow = 0;
+    }
+    SlabColumns c{{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ncol};
+    for (int k = 0; k < ncol; ++k) c.p[k] = columns[k];
+    if (cap > 0)
+        hipLaunchKernelGGL(k_slab_append_static, dim3(grid_for(2 * cap, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), msg_left, msg_right, cap, c,
+                           gid, n_owned, g_slab_overflow);
+    MDH_HIP(hipGetLastError());
+    return MDH_OK;
+}
+
+// MDH_ERR_ARG (and the flag cleared) if a halo message appended by this thread's mdh_slab_append_ghosts_static calls announced more
+// atoms than its capacity since the last check; sees the appends that have COMPLETED on the device (no synchronisation here)
+extern "C" int mdh_slab_overflow_check(void)
+{
+    if (g_slab_overflow && *(volatile int *)g_slab_overflow != 0) {
+        *g_slab_overflow = 0;
+        set_error("a halo message announced more atoms than the agreed capacity: the ghost block of that step was cut short");
+        return MDH_ERR_ARG;
+    }
+    return MDH_OK;
+}
 
 extern "C" int mdh_slab_append_ghosts(const double *msg_left, const double *msg_right, int64_t cap, int64_t nl, int64_t nr,
                                       double *const *columns, int ncol, int64_t *gid, int64_t n_owned, void *stream)

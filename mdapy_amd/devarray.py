@@ -242,6 +242,38 @@ class HArray:
     __hash__ = None
 
 
+class LazyHArray(HArray):
+    """An HArray whose HBM content is produced when somebody first touches it (``make()`` -> torch tensor): the rows of a list
+    that was built on the cell-sorted twin of a system, translated to the caller's atom order only if the caller reads them
+    (system.py).  Shape and dtype are known beforehand and answer without producing anything."""
+
+    __slots__ = ("_make", "_real", "_shape", "_np_dtype")
+
+    def __init__(self, make, shape, dtype):
+        self._make, self._real, self._host = make, None, None
+        self._shape, self._np_dtype = tuple(int(s) for s in shape), np.dtype(dtype)
+
+    @property
+    def _dev(self):
+        if self._real is None:
+            self._real = self._make()
+            self._make = None
+        return self._real
+
+    @_dev.setter
+    def _dev(self, value):
+        self._real, self._make = value, None
+
+    produced = property(lambda self: self._real is not None)
+    shape = property(lambda self: self._shape)
+    dtype = property(lambda self: self._np_dtype)
+    ndim = property(lambda self: len(self._shape))
+    size = property(lambda self: int(np.prod(self._shape)) if self._shape else 1)
+
+    def __len__(self):
+        return self._shape[0]
+
+
 def as_numpy(a):
     """host ndarray view of numpy / HArray / Column input"""
     if isinstance(a, np.ndarray):

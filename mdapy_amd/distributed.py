@@ -207,18 +207,30 @@ class SlabDecomposition:
             self._busy.discard(id(st["bufs"]))
         self._pending.clear()
 
-    def _exchange_fast(self, x, y, z, gid, cols, h, halo):
+    def _exchange_fast(self, x, y, z, gid, cols, h, halo, static=False):
         """device tensors, ghosts appended behind the owned atoms.  The layers are selected and packed into the two outgoing
         messages on the device (slab.hip), each message carries its atom count in its first word, and the host reads the four
         counts — sent and received — in ONE copy after the ring: no count round trip, no second synchronisation.  The message
-        size is agreed by all ranks (largest layer + 25 %) the first time a (halo, columns) pair is seen."""
+        size is agreed by all ranks (largest layer + 25 %) the first time a (halo, columns) pair is seen.
+
+        static=True (and room for two whole messages behind every column): the host reads NOTHING — the ghost block has the
+        fixed size 2 cap, the counts stay in the message headers on the device, unused slots are marked absent (x = NaN, id -1;
+        slab.hip k_slab_append_static) and a message that did not fit is reported by the next exchange (or check_halo())."""
         key = (x.data_ptr(), float(halo), len(cols))
         state = self._pending.pop(key, None)
         if state is None or state["n_owned"] != int(x.shape[0]):
-            state = self._fast_begin(x, y, z, gid, cols, h, halo, side=False)
-        return self._fast_end(state)
+            state = self._fast_begin(x, y, z, gid, cols, h, halo, side=False, heads=not static)
+        return self._fast_end(state, static)
 
-    def start_halo(self, x, y, z, gid, halo: float, extra=()):
+    def check_halo(self):
+        """raise if a halo message of an exchange with static=True that has run on the device did not fit its agreed size"""
+        from . import _lib
+
+        if _lib.lib().mdh_slab_overflow_check() != 0:
+            raise RuntimeError("a halo message did not fit the agreed size (" + _lib.last_error() + "): the system changed since the "
+                               "size was agreed — call reset_halo_capacity() on all ranks and repeat the step")
+
+    def start_halo(self, x, y, z, gid, halo: float, extra=(), static=False):
         """Begin the halo exchange of a frame — selection, packing, the ring, the read of the counts — on a side stream, and
         return at once: the kernels of the frame before keep the device busy meanwhile (frames of a trajectory do not depend
         on each other).  The exchange_halo(x, y, z, gid, halo, sort=False, extra=...) that follows with the SAME tensors picks
@@ -234,9 +246,10 @@ class SlabDecomposition:
             return
         if len(self._pending) > 2:
             self._drop_pending()
-        self._pending[key] = self._fast_begin(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, self.halo_fraction(halo), halo, side=True)
+        self._pending[key] = self._fast_begin(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, self.halo_fraction(halo), halo, side=True,
+                                              heads=not static)
 
-    def _fast_begin(self, x, y, z, gid, cols, h, halo, side):
+    def _fast_begin(self, x, y, z, gid, cols, h, halo, side, heads=True):
         import ctypes
 
         from . import _lib
@@ -272,7 +285,7 @@ class SlabDecomposition:
             bufs = tuple(t.empty(1 + width * cap, dtype=t.float64, device=dev) for _ in range(4)) + (t.empty(4, dtype=t.float64).pin_memory(),)
             pool.append(bufs)
         self._busy.add(id(bufs))
-        send_r, send_l, recv_l, recv_r, heads = bufs
+        send_r, send_l, recv_l, recv_r, heads_pinned = bufs
         o = np.ascontiguousarray(self.box.origin, dtype=np.float64)
         hi3 = np.ascontiguousarray(self.box.inverse_box[:, self.axis], dtype=np.float64)
         ex = [c.contiguous() for c in cols[3:]]
@@ -286,22 +299,31 @@ class SlabDecomposition:
             stream.wait_stream(main)  # the owned atoms are ready, and the previous frame's ghosts have been read out of the receive buffers
         else:
             stream = main
-        with t.cuda.stream(stream):
-            _lib.check(_lib.lib().mdh_slab_halo_messages(x.data_ptr(), y.data_ptr(), z.data_ptr(), n_owned, o.ctypes.data, hi3.ctypes.data,
-                                                         float(hi - h), float(lo + h), g.data_ptr(), exp, len(ex), send_r.data_ptr(),
-                                                         send_l.data_ptr(), cap, int(stream.cuda_stream)))
-            self._ring(send_r, send_l, recv_l, recv_r)
-            heads.copy_(t.stack([send_r[0], send_l[0], recv_l[0], recv_r[0]]), non_blocking=True)  # the one device-to-host read
-            done = t.cuda.Event()
-            done.record(stream)
-        return dict(cols=cols, gid=gid, ex=ex, g=g, n_owned=n_owned, cap=cap, sig=sig, bufs=bufs, done=done, side=side, dev=dev)
+        try:
+            with t.cuda.stream(stream):
+                _lib.check(_lib.lib().mdh_slab_halo_messages(x.data_ptr(), y.data_ptr(), z.data_ptr(), n_owned, o.ctypes.data, hi3.ctypes.data,
+                                                             float(hi - h), float(lo + h), g.data_ptr(), exp, len(ex), send_r.data_ptr(),
+                                                             send_l.data_ptr(), cap, int(stream.cuda_stream)))
+                self._ring(send_r, send_l, recv_l, recv_r)
+                if heads:  # the one device-to-host read (static exchanges leave the counts on the device)
+                    heads_pinned.copy_(t.stack([send_r[0], send_l[0], recv_l[0], recv_r[0]]), non_blocking=True)
+                done = t.cuda.Event()
+                done.record(stream)
+        except BaseException:
+            self._busy.discard(id(bufs))  # (an exchange that never got under way does not keep its buffer set)
+            raise
+        return dict(cols=cols, gid=gid, ex=ex, g=g, n_owned=n_owned, cap=cap, sig=sig, bufs=bufs, done=done, side=side, dev=dev, heads=heads)
 
-    def _fast_end(self, st):
+    def _fast_end(self, st, static=False):
         t = _torch()
+        if static and not st["heads"] and self._fast_end_static_ok(st):
+            return self._fast_end_static(st)
         st["done"].synchronize()  # (waits for the exchange only: kernels of the previous frame on the main stream keep running)
         if st["side"]:
             t.cuda.current_stream().wait_event(st["done"])
         send_r, send_l, recv_l, recv_r, heads_pinned = st["bufs"]
+        if not st["heads"]:  # begun as a static exchange, ended as a plain one: read the counts now
+            heads_pinned.copy_(t.stack([send_r[0], send_l[0], recv_l[0], recv_r[0]]))
         heads = heads_pinned.tolist()
         self._busy.discard(id(st["bufs"]))  # (what reads the receive buffers below is enqueued before any later exchange refills them)
         cap, dev, n_owned, cols, gid = st["cap"], st["dev"], st["n_owned"], st["cols"], st["gid"]
@@ -341,6 +363,34 @@ class SlabDecomposition:
             full.append(whole)
         return LocalDomain(full[0], full[1], full[2], full[-1], self._owned_mask(n_tot, n_owned, dev), n_owned, tuple(full[3:-1]))
 
+    def _fast_end_static_ok(self, st):
+        t = _torch()
+        cols, gid, cap = st["cols"], st["gid"], st["cap"]
+        return (all(self._room_behind(c) >= 2 * cap for c in list(cols) + [gid]) and all(c.dtype == t.float64 for c in cols)
+                and gid.dtype == t.int64 and len(cols) <= 7)
+
+    def _fast_end_static(self, st):
+        """no host read, no host wait: the ghost block is 2 cap slots, filled from the headers on the device"""
+        import ctypes
+
+        from . import _lib
+
+        t = _torch()
+        self.check_halo()  # (an overflow of an EARLIER step that has run by now)
+        if st["side"]:
+            t.cuda.current_stream().wait_event(st["done"])
+        send_r, send_l, recv_l, recv_r, _ = st["bufs"]
+        self._busy.discard(id(st["bufs"]))
+        cap, dev, n_owned, cols, gid = st["cap"], st["dev"], st["n_owned"], st["cols"], st["gid"]
+        ptrs = (ctypes.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+        _lib.check(_lib.lib().mdh_slab_append_ghosts_static(recv_l.data_ptr(), recv_r.data_ptr(), cap, ptrs, len(cols), gid.data_ptr(), n_owned,
+                                                            int(t.cuda.current_stream().cuda_stream)))
+        n_tot = n_owned + 2 * cap
+        full = [t.empty(0, dtype=c.dtype, device=dev).set_(c.untyped_storage(), c.storage_offset(), (n_tot,), (1,)) for c in list(cols) + [gid]]
+        dom = LocalDomain(full[0], full[1], full[2], full[-1], self._owned_mask(n_tot, n_owned, dev), n_owned, tuple(full[3:-1]))
+        dom.absent_slots = True  # rows [n_owned, n_tot) hold ghosts and absent atoms (x = NaN, gid = -1)
+        return dom
+
     def hint_window(self, halo: float, like=None):
         """tell the next neighbor build where this rank's atoms are (slab + halo along the decomposed axis): its passes over the
         cells of the GLOBAL grid then cover that window only"""
@@ -351,14 +401,17 @@ class SlabDecomposition:
             kernels.neighbor.hint_cell_window(self.axis, self.rank / self.world - h, (self.rank + 1) / self.world + h)
 
     # -- halo exchange --------------------------------------------------------
-    def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True, extra=()) -> LocalDomain:
+    def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True, extra=(), static: bool = False) -> LocalDomain:
         """x,y,z (f64) and gid (i64) of the OWNED atoms (1-D tensors on this rank's device).
 
         sort=True: the local order is ascending global id (what index-ordered kernels need to reproduce the undivided
         system's rows).  sort=False: owned atoms first, in the caller's order, then the ghosts — for kernels that take the
         ids as an ordering key (``build_neighbor(..., key=dom.gid)``); no pass over the owned atoms beyond the copy.
         extra: further per-owned-atom columns (numbers exact in f64, e.g. int32 types); they travel in the same message
-        as the positions and come back as ``dom.extra`` in local order."""
+        as the positions and come back as ``dom.extra`` in local order.
+        static (with sort=False, tensors from with_room() with room for two whole messages): nothing is read by the host; the
+        domain then has a ghost block of fixed size whose unused slots are ABSENT atoms (x = NaN, gid = -1, ``dom.absent_slots``)
+        — only kernels that skip them may take it (the neighbor build does: mdh_build_neighbor*, include/mdapy_amd.h)."""
         t = _torch()
         n_owned = int(x.shape[0])
         dev = x.device
@@ -371,7 +424,7 @@ class SlabDecomposition:
         h = self.halo_fraction(halo)
         lo, hi = self.rank / self.world, (self.rank + 1) / self.world
         if x.is_cuda and not sort and len(extra) <= 4 and self._single_message(h):
-            return self._exchange_fast(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, h, halo)
+            return self._exchange_fast(x.contiguous(), y.contiguous(), z.contiguous(), gid, cols, h, halo, static)
         if x.is_cuda:  # selection and packing in one fused pass (slab.hip); the torch expressions below are its definition
             up, down, rows_r, rows_l = self._select_device(x, y, z, hi - h, lo + h, gid)
             send_r, send_l = rows_r.t(), rows_l.t()  # rows x, y, z, id
@@ -463,10 +516,13 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     drifted across a face without re-partitioning); without it the build is still memory-safe and the NEXT build raises.
     """
     t = _torch()
-    dom = dec.exchange_halo(x, y, z, gid, rc, sort=False)
+    # static: the ghost count stays on the device (a ghost block of fixed size with absent slots) — nothing in this step waits
+    # for the device, the host runs ahead of it
+    static = bool(getattr(x, "is_cuda", False)) and dec.world > 1 and not getattr(dec, "_no_static", False)
+    dom = dec.exchange_halo(x, y, z, gid, rc, sort=False, static=static)
     if next_frame is not None and not getattr(dec, "_no_prefetch", False):
         try:
-            dec.start_halo(*next_frame, rc)
+            dec.start_halo(*next_frame, rc, static=static)
         except Exception as e:  # the overlap is an optimisation: without it the next call exchanges inside the step
             import sys
 
@@ -477,7 +533,8 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     b = dec.box
     verlet = t.empty((n, max_neigh), dtype=t.int32, device=dom.x.device)
     dist = t.empty((n, max_neigh), dtype=t.float64, device=dom.x.device)
-    nn = t.empty((n,), dtype=t.int32, device=dom.x.device)
+    # (absent slots get no row: their counts must read 0 for the CNA behind the build)
+    nn = (t.zeros if getattr(dom, "absent_slots", False) else t.empty)((n,), dtype=t.int32, device=dom.x.device)
     pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
     dec.hint_window(rc, dom.x)
     kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,

@@ -91,6 +91,50 @@ class Column:
         return f"Column({self.name!r}, {self._host!r})"
 
 
+class PermutedColumn(Column):
+    """column ``source`` read through a permutation: element p is source[perm[p]].  Nothing moves until somebody asks — then
+    in HBM (mdh_permute) when the permutation lives there, on the host otherwise.  (The per-atom columns of a system's
+    cell-sorted twin, system.py.)"""
+    __slots__ = ("_source", "_perm")
+
+    def __init__(self, source: Column, perm):
+        self.name = source.name
+        self._source, self._perm = source, perm
+        self._host_arr = None
+        self._dev = None
+
+    @property
+    def _host(self) -> np.ndarray:
+        if self._host_arr is None:
+            if self._dev is not None:
+                self._host_arr = self._dev.numpy()
+            else:
+                a = self._source.to_numpy()[np.asarray(self._perm)]
+                a.setflags(write=False)
+                self._host_arr = a
+        return self._host_arr
+
+    def device_array(self):
+        if self._dev is None:
+            kind = np.dtype(self._source.dtype)
+            if type(self._perm).__name__ in ("HArray", "LazyHArray") and kind.kind in "iuf" and kind.itemsize in (4, 8):
+                from . import kernels
+
+                self._dev = kernels.order.permute(self._source.device_array(), self._perm)
+            else:
+                from .devarray import HArray
+
+                self._dev = HArray.from_numpy(self._host)
+        return self._dev
+
+    @property
+    def dtype(self):
+        return self._source.dtype
+
+    def __len__(self):
+        return len(self._source)
+
+
 class Frame:
     def __init__(self, columns: Dict[str, Iterable] | None = None):
         self._cols: Dict[str, Column] = {}

@@ -13,6 +13,7 @@ from . import _csp as csp
 from . import _fast_knn as fast_knn
 from . import _fccpft as fccpft
 from . import _neighbor as neighbor
+from . import _order as order
 from . import _polycrystal as polycrystal
 from . import _ptm as ptm
 from . import _rdf as rdf
@@ -23,5 +24,5 @@ from . import _structure_entropy as structure_entropy
 from . import _voronoi as voronoi
 from . import _wcp as wcp
 
-NAMES = ("aja", "atomtemp", "cluster", "cna", "cnp", "csp", "fast_knn", "fccpft", "neighbor", "polycrystal", "ptm", "rdf",
+NAMES = ("aja", "atomtemp", "cluster", "cna", "cnp", "csp", "fast_knn", "fccpft", "neighbor", "order", "polycrystal", "ptm", "rdf",
          "repeat_cell", "sbo", "sfc", "structure_entropy", "voronoi", "wcp")

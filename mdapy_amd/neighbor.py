@@ -15,7 +15,10 @@ _NEEDS = ("x", "y", "z")
 
 
 class Neighbor:
-    def __init__(self, rc, box, data, max_neigh=None):
+    def __init__(self, rc, box, data, max_neigh=None, key=None):
+        # key (extension; int64 per atom): in-cell ordering key of the build — the original index of every atom of a cell-sorted
+        # copy (System's twin), so that its rows come out in the order the original system's rows have
+        self.key = key
         self.rc = float(rc)
         if not self.rc > 0:
             raise AssertionError(f"rc must be positive, got {self.rc}.")
@@ -36,8 +39,11 @@ class Neighbor:
         if grown:
             self._enlarge_data, self._enlarge_box = frame, cell
         where = (*policy.positions(frame), *policy.box_args(cell), self.rc)
+        if self.key is not None and grown:
+            raise AssertionError("an ordering key cannot follow a system into its replica")
+        self._key = {} if self.key is None else {"key": self.key}
         if self.max_neigh is None:
-            rows = kernels.neighbor.build_neighbor_without_max_neigh(*where, get_num_threads())
+            rows = kernels.neighbor.build_neighbor_without_max_neigh(*where, get_num_threads(), **self._key)
             self.verlet_list, self.distance_list, self.neighbor_number = rows
             return
         width, atoms = self.max_neigh, frame.shape[0]
@@ -61,6 +67,6 @@ class Neighbor:
             self.verlet_list[...] = -1
             self.distance_list[...] = self.rc + 1.0
             self.neighbor_number[...] = 0
-            kernels.neighbor.build_neighbor(*where, *out, get_num_threads())
+            kernels.neighbor.build_neighbor(*where, *out, get_num_threads(), **self._key)
         else:  # HBM buffers: the kernel writes the pads itself, no extra pass over 12 M bytes per atom
-            kernels.neighbor.build_neighbor(*where, *out, get_num_threads(), fill_pads=True)
+            kernels.neighbor.build_neighbor(*where, *out, get_num_threads(), fill_pads=True, **self._key)

@@ -42,6 +42,59 @@ _REPLICA = ("_enlarge_box", "_enlarge_data")
 _LIST = ("verlet_list", "neighbor_number", "distance_list", "rc", "_sorted_columns", "_list_cutoff") + _REPLICA
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# The cell-sorted twin.  The reference's kernels do not care in which order atoms arrive (a linked list per cell,
+# src/neighbor.cpp:64-100); a GPU's gathers do: on an id-sorted dump of a diffused system, or a shuffled one, a neighbour's
+# position is an HBM access instead of an L2 hit, and the fixed-cutoff CNA of 10 M such atoms took 6.7 ms instead of 0.54
+# (profiles/r05_order_sweep.txt).  A large system that was handed in in no spatial order therefore gets a TWIN: the same atoms
+# in cell order (csrc/order.hip), with every other column read through the permutation.  List builds and the analyses that do
+# not depend on atom numbering run on the twin — lists keyed by the original index, so rows come out in the reference's order
+# and every sum runs over the same numbers in the same order — and what the user reads is translated back: per-atom columns
+# by one scatter, the rows of a list only if somebody asks for them (devarray.LazyHArray).  MDAPY_SPATIAL_SORT = 0 (never),
+# 1 (always, whatever the order looks like; any size — tests), unset (systems of MDAPY_SORT_MIN_ATOMS atoms and more whose
+# order statistic says so).
+# ----------------------------------------------------------------------------------------------------------------------
+import functools
+import os
+
+SORT_MIN_ATOMS = int(os.environ.get("MDAPY_SORT_MIN_ATOMS", "200000"))
+SORT_FAR_FRACTION = 0.25  # of consecutive atoms in bins that do not touch (mdh_order_statistic): a lattice builder's order has < 0.01
+
+
+def _on_twin(method):
+    """run a System method on the cell-sorted twin when there is one (and the call's arguments allow it); copy back what it left"""
+    name = method.__name__
+
+    @functools.wraps(method)
+    def call(self, *args, **kwargs):
+        twin = self._twin_for(name, args, kwargs)
+        if twin is None:
+            return method(self, *args, **kwargs)
+        return self._run_on_twin(twin, name, args, kwargs)
+
+    return call
+
+
+def _dev_of(harray):
+    return harray.dev()
+
+
+# positional parameter names of the methods that may run on the twin (what _twin_for looks at)
+_ARGS = {
+    "build_neighbor": ("rc", "max_neigh"),
+    "build_nearest_neighbor": ("k",),
+    "cal_common_neighbor_analysis": ("rc", "max_neigh"),
+    "cal_common_neighbor_parameter": ("rc", "max_neigh"),
+    "cal_structure_entropy": ("rc", "sigma", "use_local_density", "average_rc", "max_neigh"),
+    "cal_atomic_temperature": ("rc", "factor", "max_neigh"),
+    "cal_steinhardt_bond_orientation": ("llist", "use_voronoi", "nnn", "rc", "average", "use_weight", "weight", "wl", "wlhat",
+                                        "a_face_area_threshold", "r_face_area_threshold", "identify_liquid"),
+    "cal_radial_distribution_function": ("rc", "nbin", "max_neigh", "streaming"),
+    "cal_warren_cowley_parameter": ("rc", "max_neigh"),
+    "average_by_neighbor": ("average_rc", "property_name"),
+}
+
+
 def _position_columns(xyz):
     """x, y, z columns of an (N, 3) array.  With a GPU the array crosses PCIe once, as it is, and is split into columns in HBM
     (the columns' host copies are made if somebody asks for them): the three strided host copies of the reference's
@@ -118,6 +171,7 @@ class System:
     def __init__(self, filename=None, data=None, pos=None, box=None, ase_atom=None, ovito_atom=None, format=None,
                  global_info=None):
         self._info = {}
+        self._sort_mode = os.environ.get("MDAPY_SPATIAL_SORT", "")  # (fixed when the system is made: see _spatial)
         if isinstance(filename, str):
             from .load_save import read_file
 
@@ -147,6 +201,153 @@ class System:
     def _forget(self, names):
         for name in names:
             self.__dict__.pop(name, None)
+        if "verlet_list" in names:  # the list is gone: the twin's too, and what mirrored it
+            state = self.__dict__.get("_twin_state")
+            if state is not None and state[1] is not None:
+                state[1]._forget(_LIST)
+            self.__dict__.pop("_mirror", None)
+
+    # ------------------------------------------------------- the cell-sorted twin (see the top of the module)
+    def _spatial(self):
+        """the twin, made on first use; None: this system is analysed in the order it has"""
+        if self.__dict__.get("_is_twin"):
+            return None
+        mode = self.__dict__.get("_sort_mode", "")
+        if mode == "0":
+            return None
+        cols = tuple(self._frame[c] for c in ("x", "y", "z"))
+        key = (id(cols[0]), id(cols[1]), id(cols[2]), id(self._cell))
+        state = self.__dict__.get("_twin_state")
+        if state is not None and state[0] == key:
+            return state[1]
+        twin = None
+        from .devarray import have_gpu
+        from . import kernels
+
+        big = self.N >= SORT_MIN_ATOMS or (mode == "1" and self.N >= 2)
+        if big and hasattr(kernels, "order") and (have_gpu() or mode == "1") and all(np.dtype(c.dtype) == np.float64 for c in cols) \
+                and policy.is_single(self._safe_repeat()):
+            where = (*cols, *policy.box_args(self.box))
+            if mode == "1" or kernels.order.order_statistic(*where) > SORT_FAR_FRACTION:
+                xs, ys, zs, perm, n = kernels.order.spatial_sort(*where)
+                if n == self.N:
+                    twin = System(data=Frame({"x": xs, "y": ys, "z": zs}), box=self.box)
+                    twin._is_twin = True
+                    twin._perm = perm
+                    # the in-cell ordering key of the twin's list builds: the ORIGINAL index, so that a row lists its atoms in the
+                    # order the reference would (descending index inside a cell, neighbor.cpp:97-98)
+                    twin._order_key = (HArray(perm.dev().long()) if isinstance(perm, HArray) else np.asarray(perm, np.int64))
+        self._twin_state = (key, twin)
+        self.__dict__.pop("_mirror", None)
+        self.__dict__.pop("_twin_cols", None)
+        return twin
+
+    def _twin_for(self, name, args, kwargs):
+        """the twin if method ``name`` may run on it with these arguments"""
+        twin = self._spatial()
+        if twin is None:
+            return None
+        # the list this system remembers must be the twin's (translated), or neither has one
+        mirror = self.__dict__.get("_mirror")
+        mine = self.__dict__.get("verlet_list")
+        if mine is not None and (mirror is None or mirror["rows"] is not mine):
+            return None
+        if mine is None and "verlet_list" in twin.__dict__:
+            twin._forget(_LIST)
+        bound = dict(zip(_ARGS.get(name, ()), args), **kwargs)
+        reach = bound.get("rc", bound.get("average_rc"))
+        if isinstance(reach, (int, float, np.integer, np.floating)) and reach > 0 and \
+                not policy.is_single(policy.axis_copies(self.box, 2.0 * float(reach))):
+            return None  # the build would search a replica: the ordering key cannot follow
+        if name == "cal_steinhardt_bond_orientation" and (bound.get("use_voronoi") or bound.get("identify_liquid")):
+            return None
+        return twin
+
+    def _run_on_twin(self, twin, name, args, kwargs):
+        from . import kernels
+        from .devarray import LazyHArray
+        from .frame import PermutedColumn
+
+        perm = twin._perm
+        # every column the twin does not have yet, read through the permutation (nothing moves before a kernel asks)
+        cache = self.__dict__.setdefault("_twin_cols", {})
+        cols = {}
+        for cname in twin._frame.columns[:3]:
+            cols[cname] = twin._frame[cname]
+        for cname in self._frame.columns:
+            if cname in ("x", "y", "z"):
+                continue
+            src = self._frame[cname]
+            hit = cache.get(cname)
+            if hit is None or hit[0] is not src:
+                hit = cache[cname] = (src, PermutedColumn(src, perm))
+            cols[cname] = hit[1]
+        twin._frame = Frame(cols)
+        before = {cname: twin._frame[cname] for cname in twin._frame.columns}
+        result = getattr(twin, name)(*args, **kwargs)
+        # per-atom results: columns the call added or replaced, back in this system's order
+        restored = {}
+        for cname in twin._frame.columns:
+            col = twin._frame[cname]
+            if before.get(cname) is col:
+                continue
+            kind = np.dtype(col.dtype)
+            if col._host_arr is None and kind.kind in "iuf" and kind.itemsize in (4, 8):
+                restored[cname] = kernels.order.permute(col.device_array(), perm, scatter=True)
+            else:
+                out = np.empty_like(col.to_numpy())
+                out[np.asarray(perm)] = col.to_numpy()
+                restored[cname] = out
+        if restored:
+            self.update_data(self._frame.with_columns(**restored))
+        for attr in ("cluster_number",):
+            if attr in twin.__dict__:
+                setattr(self, attr, twin.__dict__[attr])
+        # the list the twin remembers now, as this system's: translated when somebody reads it
+        self._mirror_lists(twin)
+        if "ptm_indices" in twin.__dict__ and name == "cal_polyhedral_template_matching":
+            src = twin.ptm_indices
+            self.ptm_indices = LazyHArray(lambda: _dev_of(kernels.order.translate_rows(src, None, None, perm)[0]), src.shape, np.int32) \
+                if isinstance(src, HArray) else kernels.order.translate_rows(np.asarray(src), None, None, np.asarray(perm))[0]
+        return result
+
+    def _mirror_lists(self, twin):
+        from . import kernels
+        from .devarray import LazyHArray
+
+        if "verlet_list" not in twin.__dict__:
+            for attr in _LIST:
+                self.__dict__.pop(attr, None)
+            self.__dict__.pop("_mirror", None)
+            return
+        rows, dist, counts = twin.verlet_list, twin.distance_list, twin.neighbor_number
+        state = (id(rows), id(dist), id(counts), twin.__dict__.get("_sorted_columns"))
+        mirror = self.__dict__.get("_mirror")
+        if mirror is None or mirror["state"] != state or self.__dict__.get("verlet_list") is not mirror["rows"]:
+            perm = twin._perm
+            done = {}
+
+            def translated(k):
+                if not done:
+                    done["v"], done["d"], done["n"] = kernels.order.translate_rows(rows, dist, counts, perm)
+                return done[k]
+
+            if isinstance(rows, HArray):
+                out = (LazyHArray(lambda: _dev_of(translated("v")), rows.shape, np.int32),
+                       LazyHArray(lambda: _dev_of(translated("d")), dist.shape, np.float64),
+                       LazyHArray(lambda: _dev_of(translated("n")), counts.shape, np.int32))
+            else:
+                out = (translated("v"), translated("d"), translated("n"))
+            mirror = self._mirror = {"state": state, "rows": out[0]}
+            self.verlet_list, self.distance_list, self.neighbor_number = out
+        for attr in ("rc", "_list_cutoff"):
+            if attr in twin.__dict__:
+                setattr(self, attr, twin.__dict__[attr])
+            else:
+                self.__dict__.pop(attr, None)
+        self._sorted_columns = (id(self.verlet_list), twin.__dict__.get("_sorted_columns", (None, 0))[1])
+        for attr in _REPLICA:
+            self.__dict__.pop(attr, None)
 
     @property
     def box(self):
@@ -292,8 +493,9 @@ class System:
             tool.sort_neighbor(self.verlet_list, self.distance_list, self.neighbor_number, k)
             self._sorted_columns = (id(self.verlet_list), k)
 
+    @_on_twin
     def build_neighbor(self, rc, max_neigh=None):
-        search = Neighbor(rc, self.box, self.data, max_neigh)
+        search = Neighbor(rc, self.box, self.data, max_neigh, key=self.__dict__.get("_order_key"))
         search.compute()
         self.rc = rc
         self._remember(search, search.verlet_list, search.distance_list, search.neighbor_number)
@@ -301,6 +503,7 @@ class System:
         # `rc` alone does not say so — like the reference's, it survives build_nearest_neighbor (system.py:1256-1263)
         self._list_cutoff = float(rc)
 
+    @_on_twin
     def build_nearest_neighbor(self, k):
         """k nearest neighbours as the current list (no ``rc``; every count is k)"""
         search = NearestNeighbor(self.data, self.box, k)
@@ -339,6 +542,7 @@ class System:
         return None
 
     # ------------------------------------------------------------- analyses
+    @_on_twin
     def cal_common_neighbor_analysis(self, rc=None, max_neigh=None):
         """column ``cna``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico; fixed cutoff ``rc`` or adaptive (None)"""
         rows = counts = None
@@ -362,6 +566,18 @@ class System:
                                          return_rmsd=False, return_atomic_distance=False, return_orientation=False,
                                          identify_fcc_planar_faults=False, identify_esf=True):
         """column ``ptm`` and, on request, ``ordering``, ``rmsd``, ``interatomic_distance``, ``qx qy qz qw``, ``pft``"""
+        twin = self._twin_for("cal_polyhedral_template_matching", (), {})
+        if twin is not None:
+            # the matching on the twin; the planar-fault sweep (its answer depends on the atom numbering: an index-ordered sweep,
+            # identify_fcc_planar_faults.cpp:139-180) here, on the translated labels and template-ordered neighbours
+            self._run_on_twin(twin, "cal_polyhedral_template_matching", (structure, rmsd_threshold, return_ordering, return_rmsd,
+                                                                        return_atomic_distance, return_orientation, False, identify_esf), {})
+            if identify_fcc_planar_faults:
+                shell = np.ascontiguousarray(as_numpy(self.ptm_indices)[:, 1:13])
+                faults = IdentifyFccPlanarFaults(np.array(self.data["ptm"].to_numpy(), np.int32), shell, identify_esf)
+                faults.compute()
+                self._store(pft=faults.fault_types)
+            return
         rows = self._borrow_nearest(18)
         cell, frame = self._get_compute_view()
         job = PolyhedralTemplateMatching(structure, frame, cell, rmsd_threshold, rows)
@@ -386,6 +602,7 @@ class System:
             found["pft"] = faults.fault_types
         self._store(**found)
 
+    @_on_twin
     def cal_common_neighbor_parameter(self, rc, max_neigh=None):
         """column ``cnp``"""
         self._require_cutoff_list(rc, max_neigh)
@@ -394,6 +611,7 @@ class System:
         job.compute()
         self._store(cnp=job.cnp)
 
+    @_on_twin
     def cal_ackland_jones_analysis(self):
         """column ``aja``: 0 other, 1 fcc, 2 hcp, 3 bcc, 4 ico"""
         depth = 14
@@ -406,6 +624,7 @@ class System:
         job.compute()
         self._store(aja=job.aja)
 
+    @_on_twin
     def cal_structure_entropy(self, rc, sigma, use_local_density=False, average_rc=0.0, max_neigh=None):
         """column ``entropy`` (and ``entropy_ave`` when average_rc > 0)"""
         self._require_cutoff_list(rc, max_neigh)
@@ -418,6 +637,7 @@ class System:
             found["entropy_ave"] = job.entropy_ave
         self._store(**found)
 
+    @_on_twin
     def cal_atomic_temperature(self, rc, factor=1.0, max_neigh=None):
         """column ``atomic_temp`` (K); velocities are A/fs times ``factor``"""
         self._require_cutoff_list(rc, max_neigh)
@@ -468,6 +688,7 @@ class System:
         volume, faces, radius = Voronoi(self.box, self.data).get_volume()
         self.update_data(self.data.with_columns(volume=volume, neighbor_number=faces, cavity_radius=radius))
 
+    @_on_twin
     def cal_centro_symmetry_parameter(self, N):
         """column ``csp`` from the N nearest neighbours (N even)"""
         if not (N > 0 and N % 2 == 0):
@@ -489,6 +710,7 @@ class System:
         job.compute()
         self._store(ids=job.pattern)
 
+    @_on_twin
     def cal_steinhardt_bond_orientation(self, llist, use_voronoi=False, nnn=0, rc=-1.0, average=False, use_weight=False,
                                         weight=None, wl=False, wlhat=False, a_face_area_threshold=-1,
                                         r_face_area_threshold=-1, identify_liquid=False, threshold=0.7, n_bond=7,
@@ -523,6 +745,7 @@ class System:
             found.update(solidliquid=job.solidliquid, nbond=job.nbond)
         self._store(**found)
 
+    @_on_twin
     def cal_radial_distribution_function(self, rc, nbin=100, max_neigh=None, streaming=None):
         """-> RadialDistributionFunction (``r``, ``g_total``, ``g_partial``).  ``streaming=None`` decides by itself: a cutoff
         of a third of the thinnest periodic direction or more is counted straight from the positions, without a list"""
@@ -544,6 +767,7 @@ class System:
         job.compute()
         return job
 
+    @_on_twin
     def cal_warren_cowley_parameter(self, rc, max_neigh=None):
         """-> WarrenCowleyParameter (``WCP`` matrix)"""
         self._require_cutoff_list(rc, max_neigh)
@@ -551,6 +775,7 @@ class System:
         job.compute()
         return job
 
+    @_on_twin
     def average_by_neighbor(self, average_rc, property_name, include_self=True, output_name=None, max_neigh=None):
         """column ``<property>_ave`` (or ``output_name``): neighbourhood mean of a column within ``average_rc``"""
         self._require_cutoff_list(average_rc, max_neigh)

@@ -19,17 +19,75 @@ def _mod(**fns):
     return types.SimpleNamespace(**fns)
 
 
-def _build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_pads=False):
+def _keyed(key, x, y, z):
+    """"descending key inside a cell" == the reference's "descending index" after sorting the atoms by key"""
+    perm = np.argsort(_np(key), kind="stable")
+    return perm, tuple(np.ascontiguousarray(_np(c)[perm]) for c in (x, y, z))
+
+
+def _unkey(perm, vs, ds, ns, v, d, nn):
+    v[perm] = np.where(vs >= 0, perm[np.clip(vs, 0, None)], -1)
+    d[perm] = ds
+    nn[perm] = ns
+
+
+def _build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_pads=False, key=None):
     if fill_pads:
         v.fill(-1)
         d.fill(rc + 1.0)
-    O.build_neighbor(_np(x), _np(y), _np(z), box, origin, boundary, rc, v, d, nn, NT)
+    if key is None:
+        O.build_neighbor(_np(x), _np(y), _np(z), box, origin, boundary, rc, v, d, nn, NT)
+        return
+    perm, (xs, ys, zs) = _keyed(key, x, y, z)
+    vs, ds, ns = v[perm].copy(), d[perm].copy(), nn[perm].copy()  # (the caller's pads travel with their rows)
+    O.build_neighbor(xs, ys, zs, box, origin, boundary, rc, vs, ds, ns, NT)
+    _unkey(perm, vs, ds, ns, v, d, nn)
 
 
+def _build_neighbor_exact(x, y, z, box, origin, boundary, rc, num_t=1, key=None):
+    if key is None:
+        return O.build_neighbor_without_max_neigh(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT)
+    perm, (xs, ys, zs) = _keyed(key, x, y, z)
+    vs, ds, ns = O.build_neighbor_without_max_neigh(xs, ys, zs, box, origin, boundary, rc, NT)
+    v, d, nn = np.empty_like(vs), np.empty_like(ds), np.empty_like(ns)
+    _unkey(perm, vs, ds, ns, v, d, nn)
+    return v, d, nn
+
+
+def _spatial_sort(x, y, z, box, origin, boundary):
+    """a stand-in for mdh_spatial_sort: ANY permutation serves the host logic that is tested with it — here cells of 3 A"""
+    pos = np.column_stack([_np(x), _np(y), _np(z)])
+    cells = np.floor((pos - pos.min(axis=0)) / 3.0).astype(np.int64)
+    perm = np.lexsort((-np.arange(len(pos)), cells[:, 2], cells[:, 1], cells[:, 0])).astype(np.int32)
+    return pos[perm, 0].copy(), pos[perm, 1].copy(), pos[perm, 2].copy(), perm, len(pos)
+
+
+def _permute(values, perm, scatter=False):
+    a, p = _np(values), _np(perm)
+    if not scatter:
+        return a[p]
+    out = np.empty_like(a)
+    out[p] = a
+    return out
+
+
+def _translate_rows(rows, dist, counts, perm):
+    rows, p = _np(rows), _np(perm)
+    v = np.empty_like(rows)
+    v[p] = np.where(rows >= 0, p[np.clip(rows, 0, None)], rows)
+    d = n = None
+    if dist is not None:
+        d = np.empty_like(_np(dist)); d[p] = _np(dist)
+    if counts is not None:
+        n = np.empty_like(_np(counts)); n[p] = _np(counts)
+    return v, d, n
+
+
+order = _mod(order_statistic=lambda x, y, z, box, origin, boundary: 1.0, spatial_sort=_spatial_sort, permute=_permute,
+             translate_rows=_translate_rows)
 neighbor = _mod(
     build_neighbor=_build_neighbor,
-    build_neighbor_without_max_neigh=lambda x, y, z, box, origin, boundary, rc, num_t=1:
-        O.build_neighbor_without_max_neigh(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT),
+    build_neighbor_without_max_neigh=_build_neighbor_exact,
     sort_verlet_by_distance=lambda v, d, k, num_t=1: O.sort_verlet_by_distance(v, d, k, NT),
     wrap_positions=lambda x, y, z, box, origin, boundary, num_t=1: O.wrap_positions(x, y, z, box, origin, boundary, NT),
     average_by_neighbor=lambda rc, v, d, nn, value, out, inc, num_t=1:
@@ -119,7 +177,7 @@ def install(monkeypatch):
 
     table = dict(neighbor=neighbor, polycrystal=polycrystal, repeat_cell=repeat_cell, fast_knn=fast_knn, cna=cna, csp=csp,
                  sbo=sbo, ptm=ptm, rdf=rdf, wcp=wcp, aja=aja, atomtemp=atomtemp, cluster=cluster, sfc=sfc, voronoi=voronoi,
-                 fccpft=fccpft, cnp=cnp, structure_entropy=structure_entropy)
+                 fccpft=fccpft, cnp=cnp, structure_entropy=structure_entropy, order=order)
     assert set(table) == set(K.NAMES), "an adapter per shim module"
     for name, adapter in table.items():
         monkeypatch.setattr(K, name, adapter)
