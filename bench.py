@@ -68,11 +68,11 @@ def parse():
     return p.parse_args()
 
 
-def slab_positions(torch, dev, cells, rank, sigma, cells_x=None):
+def slab_positions(torch, dev, cells, rank, sigma, cells_x=None, a=None):
     """FCC Cu slab of rank `rank`: cells ix in [cx*rank, cx*(rank+1)) x cells x cells (cx = cells unless cells_x is given: the
     slab of a box split along x), cell-major order, basis innermost — same expression as build_crystal / repeat_cell
     (basis@cell + (ix*a1 + iy*a2 + iz*a3))."""
-    a = A_CU
+    a = A_CU if a is None else a
     cx = cells if cells_x is None else cells_x
     basis = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]], dtype=torch.float64, device=dev) * a
     ix = torch.arange(cx * rank, cx * (rank + 1), dtype=torch.float64, device=dev) * a
@@ -90,6 +90,58 @@ def slab_positions(torch, dev, cells, rank, sigma, cells_x=None):
     n = cx * cells * cells * 4
     gid = torch.arange(n * rank, n * (rank + 1), dtype=torch.int64, device=dev)
     return out[0], out[1], out[2], gid
+
+
+def analyses_extra(torch, dev, mp, cells):
+    from mdapy_amd.devarray import HArray
+    from mdapy_amd.frame import Frame
+
+    def lap(n, alg_bytes, fn):
+        fn()  # (first call: sizes the scratch cache, loads code objects)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"ms": dt * 1e3, "atoms_per_s": n / dt, "alg_B_per_atom": alg_bytes, "frac_of_hbm_peak": alg_bytes * n / dt / 1e9 / HBM_PEAK_GBS}, out
+
+    found = {}
+    # ---- config 2
+    x, y, z, _ = slab_positions(torch, dev, cells, 0, 0.05)
+    n = int(x.shape[0])
+    s = mp.System(data=Frame({"x": HArray(x), "y": HArray(y), "z": HArray(z)}), box=mp.Box(np.diag([A_CU * cells] * 3)))
+    c2 = {"atoms": n, "input": f"{cells}^3-cell FCC Cu rattled by N(0, 0.05 A)"}
+    c2["knn18"], _ = lap(n, 24 + 18 * 12, lambda: s.build_nearest_neighbor(18))
+    c2["ptm_fcc_hcp_bcc"], _ = lap(n, 24 + 18 * 4 + 8 * 8 + 18 * 4, lambda: s.cal_polyhedral_template_matching("fcc-hcp-bcc", return_rmsd=True))
+    c2["steinhardt_q4_q6_nnn12"], _ = lap(n, 24 + 12 * 12 + 16, lambda: s.cal_steinhardt_bond_orientation([4, 6], nnn=12))
+    c2["csp12"], _ = lap(n, 24 + 12 * 4 + 8, lambda: s.cal_centro_symmetry_parameter(12))
+    c2["adaptive_cna"], _ = lap(n, 24 + 14 * 4 + 4, lambda: s.cal_common_neighbor_analysis())
+    lab = np.bincount(s.data["ptm"].to_numpy(), minlength=4).tolist()
+    c2["ptm_fcc_fraction"] = lab[1] / n
+    c2["total_ms_knn_ptm_steinhardt"] = c2["knn18"]["ms"] + c2["ptm_fcc_hcp_bcc"]["ms"] + c2["steinhardt_q4_q6_nnn12"]["ms"]
+    c2["dominant"] = "ptm_fcc_hcp_bcc"
+    found["config2"] = c2
+    del s, x, y, z
+    # ---- config 4
+    gc = cells - 1 if cells > 8 else cells
+    x, y, z, _ = slab_positions(torch, dev, gc, 0, 0.35, a=4.0)
+    n = int(x.shape[0])
+    gen = torch.Generator(device=dev); gen.manual_seed(42)
+    ty = (torch.rand(n, device=dev, generator=gen) < 0.36).to(torch.int32) + 1  # 1 = Cu (64 %), 2 = Zr (36 %)
+    s = mp.System(data=Frame({"x": HArray(x), "y": HArray(y), "z": HArray(z), "type": HArray(ty)}), box=mp.Box(np.diag([4.0 * gc] * 3)))
+    c4 = {"atoms": n, "input": f"{gc}^3 x 4 sites of fcc a = 4.0 A displaced by N(0, 0.35 A), Cu64Zr36 at random"}
+    c4["rdf_partial_rc8_200bins_streaming"], g = lap(n, 28, lambda: s.cal_radial_distribution_function(8.0, nbin=200, streaming=True))
+    c4["build_neighbor_rc3.6"], _ = lap(n, 28 + 12 * int(1), lambda: s.build_neighbor(3.6))
+    c4["build_neighbor_rc3.6"]["row_width"] = int(s.verlet_list.shape[1])
+    c4["build_neighbor_rc3.6"]["alg_B_per_atom"] = 28 + 12 * int(s.verlet_list.shape[1])
+    c4["build_neighbor_rc3.6"]["frac_of_hbm_peak"] = c4["build_neighbor_rc3.6"]["alg_B_per_atom"] * n / (c4["build_neighbor_rc3.6"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    c4["warren_cowley_rc3.6"], w = lap(n, 8 + 4 * int(s.verlet_list.shape[1]), lambda: s.cal_warren_cowley_parameter(3.6))
+    c4["g_total_tail"] = float(np.asarray(g.g_total)[-20:].mean())  # -> 1 for an uncorrelated frame
+    c4["wcp_max_abs"] = float(np.abs(np.asarray(w.WCP)).max())     # -> 0 for species placed at random
+    c4["total_ms_rdf_wcp"] = c4["rdf_partial_rc8_200bins_streaming"]["ms"] + c4["warren_cowley_rc3.6"]["ms"]
+    c4["dominant"] = "rdf_partial_rc8_200bins_streaming"
+    found["config4"] = c4
+    return found
 
 
 def cpu_baseline_child(args):
@@ -556,7 +608,32 @@ def main():
                 got = other_input(x[perm].contiguous(), y[perm].contiguous(), z[perm].contiguous(), bx, n_local)
                 extra["shuffled_ids"] = {k_: got[k_] for k_ in ("atoms", "ms_per_step", "atoms_per_s", "fcc_fraction", "kernels_ms")}
                 extra["shuffled_ids"]["ratio_to_ordered"] = got["ms_per_step"] / ms_per_step
-                del perm
+                extra["shuffled_ids"]["what"] = ("the two C-ABI calls of the headline step handed the shuffled columns as they are (what a binding "
+                                                 "that bypasses System gets)")
+                # the same frames through System — a NEW System per step, as a trajectory loop makes them: the shuffled one is
+                # analysed on its cell-sorted twin (order statistic + sort + keyed build + CNA + labels scattered back, all inside the step)
+                from mdapy_amd.devarray import HArray
+                from mdapy_amd.frame import Frame
+
+                def system_step(cols):
+                    def run():
+                        s_ = mp.System(data=Frame({"x": HArray(cols[0]), "y": HArray(cols[1]), "z": HArray(cols[2])}), box=box)
+                        s_.cal_common_neighbor_analysis(rc=RC, max_neigh=M)
+                        return s_
+                    return run
+
+                k = max(3, args.steps // 4)
+                shuf = (x[perm].contiguous(), y[perm].contiguous(), z[perm].contiguous())
+                res_sys = {}
+                for tag, cols in (("ordered", (x, y, z)), ("shuffled", shuf)):
+                    e_, s_, _ = timed(system_step(cols), k, 2, ranges=0)
+                    lab_ = s_.data["cna"].device_array().dev()
+                    res_sys[tag] = {"ms_per_step": e_ / k * 1e3, "all_fcc": bool((lab_ == 1).all().item()), "twin": s_._spatial() is not None}
+                    del s_, lab_
+                res_sys["ratio"] = res_sys["shuffled"]["ms_per_step"] / res_sys["ordered"]["ms_per_step"]
+                res_sys["ratio_to_the_headline_step"] = res_sys["shuffled"]["ms_per_step"] / ms_per_step
+                extra["shuffled_ids"]["system_path"] = res_sys
+                del perm, shuf
             except Exception as e:
                 extra["shuffled_ids"] = {"error": f"{type(e).__name__}: {e}"}
             # (b') the inputs that used to leave the tile kernel (round 4): an unwrapped trajectory frame — every atom a few whole box
@@ -625,6 +702,14 @@ def main():
                                             "transport": "loop-back on one GPU (device copy instead of RCCL): the wire is NOT measured"}
             except Exception as e:
                 extra["strong_1of8"] = {"error": f"{type(e).__name__}: {e}"}
+            # (e) BASELINE configs 2 and 4 at full size through the System API (wall time of each call, HBM-resident columns, the second
+            # of two calls): config 2 = the headline lattice rattled by 0.05 A: 18 nearest neighbours, PTM, Steinhardt q4 / q6;
+            # config 4 = a 9.84 M-atom Cu64Zr36 glass-like frame: streaming partial g_ab(r) to 8 A in 200 bins, Warren-Cowley at 3.6 A.
+            # alg_B_per_atom: compulsory unique traffic of the call (inputs read once + outputs written once), frac = that / time / 8 TB/s
+            try:
+                extra.update(analyses_extra(torch, dev, mp, cells))
+            except Exception as e:
+                extra["config2"] = {"error": f"{type(e).__name__}: {e}"}
             res["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args)

@@ -227,7 +227,7 @@ class SlabDecomposition:
         from . import _lib
 
         if _lib.lib().mdh_slab_overflow_check() != 0:
-            raise RuntimeError("a halo message did not fit the agreed size (" + _lib.last_error() + "): the system changed since the "
+            raise RuntimeError("a halo message did not fit the agreed size (" + _lib.lib().mdh_last_error().decode("utf-8", "replace") + "): the system changed since the "
                                "size was agreed — call reset_halo_capacity() on all ranks and repeat the step")
 
     def start_halo(self, x, y, z, gid, halo: float, extra=(), static=False):

@@ -112,6 +112,31 @@ def _run_rank(rank, world, torch, dist_ready=True):
         check_step(f"prefetched halo {it}: ", *D.neighbor_cna_step(dec, *own_args, rc, M, next_frame=own_args))
         check("an exchange is under way after the step", world < 2 or len(dec._pending) == 1)
     dec._drop_pending()
+    # ---- the same step on tensors with room behind them (with_room): the STATIC exchange — the ghost count never leaves the device,
+    # the ghost block has a fixed size and its unused slots are absent atoms (x = NaN, id -1) that the build gives no cell
+    roomy = tuple(dec.with_room(a, 0.6) for a in own_args)
+    for it in range(3):
+        out_s = D.neighbor_cna_step(dec, *roomy, rc, M, next_frame=roomy)
+        check(f"static exchange {it}: taken", world < 2 or getattr(out_s[0], "absent_slots", False))
+        check_step(f"static exchange {it}: ", *out_s)
+        if world > 1:
+            gx, gg = out_s[0].x.cpu().numpy(), out_s[0].gid.cpu().numpy()
+            check(f"static exchange {it}: absent slots", np.array_equal(np.isnan(gx), gg < 0) and np.isnan(gx).sum() > 0
+                  and not np.isnan(gx[:len(owned_ids)]).any())
+            check(f"static exchange {it}: absent atoms have no neighbours", int(out_s[3].cpu().numpy()[gg < 0].max()) == 0)
+    dec._drop_pending()
+    dec.check_halo()
+    if world > 1:  # a message that does not fit its agreed size is reported once the step has run
+        dec2 = D.SlabDecomposition(box, rank, world, axis=0)
+        dec2._msg_cap[(float(rc), 4)] = 8
+        roomy2 = tuple(dec2.with_room(a, 0.6) for a in own_args)
+        D.neighbor_cna_step(dec2, *roomy2, rc, M)
+        torch.cuda.synchronize()
+        try:
+            dec2.check_halo()
+            check("overflow of a static halo message is reported", False)
+        except RuntimeError:
+            pass
     # ---- a prefetched exchange keeps its own message buffers: frame B's halo is started, then ANOTHER exchange
     # with the same (halo, columns) runs for frame A on the main stream, then B's is picked up — and must hold B's ghosts
     yB = pos[:, 1] + 0.25

@@ -95,12 +95,14 @@ def test_shuffled_1M_atom_system_goes_through_the_twin_and_equals_the_oracle(sig
     assert np.array_equal(n, N_) and np.array_equal(v, V) and np.array_equal(d, D)
     # exact-width rows + CNA, through the System path
     rcna = 0.854 * 3.615
-    s.cal_common_neighbor_analysis(rc=rcna)
+    s = mp.System(pos=pos, box=box)
+    s.cal_common_neighbor_analysis(rc=rcna)  # (builds the exact-width list on the twin, keyed by the original index)
     Vc, Dc, Nc = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rcna, 64)
     P = np.zeros(len(x), np.int32)
     O.fcna(x, y, z, box, ORG0, PBC, Vc, Nc, P, rcna, 64)
     assert np.array_equal(s.data["cna"].to_numpy(), P)
     assert np.array_equal(np.asarray(s.verlet_list), Vc) and np.array_equal(np.asarray(s.distance_list), Dc)
+    assert np.array_equal(np.asarray(s.neighbor_number), Nc)
     # CSP on the twin against the oracle fed the k-nearest rows of the plain HIP search on the shuffled input
     I = np.zeros((len(x), 12), np.int32); Dk = np.zeros((len(x), 12))
     _fast_knn.knn(x, y, z, box, ORG0, PBC, 12, I, Dk, 1)

@@ -8,7 +8,7 @@ clean() { grep -v "^W2\|^E2\|amdgpu.ids\|^\[W\|^\[E"; }
 prof() { # prof <tag> <command...> : kernel trace + stats of a command, top kernels printed
   local tag=$1; shift
   mkdir -p $O/r05_$tag
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/r05_$tag -o s -- "$@" > $R/$O/r05_$tag/run.log 2>&1)
+  (cd /tmp && PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/r05_$tag -o s -- "$@" > $R/$O/r05_$tag/run.log 2>&1)
   clean < $O/r05_$tag/run.log | tail -2 | cut -c1-600
   python tools/kstats.py $O/r05_$tag 12
 }
@@ -16,10 +16,10 @@ for section in "$@"; do
 echo "=================== section $section"
 case $section in
 order)     # the headline step on the same atoms in five orders, per-kernel split of each
-  for o in lattice blocks shuffled poly poly_shuffled; do echo "--- order $o"; prof order_$o python tools/order_probe.py $o 136 10; done ;;
+  for o in lattice blocks shuffled poly poly_shuffled; do echo "--- order $o"; prof order_$o python $R/tools/order_probe.py $o 136 10; done ;;
 bench)     # the default bench line, then the same command under the kernel trace
   timeout 1200 python bench.py > $O/r05_bench.json 2> $O/r05_bench.err; tail -c 900 $O/r05_bench.json
-  prof bench python bench.py --no-extra --no-pmc --no-cpu-baseline ;;
+  prof bench python $R/bench.py --no-extra --no-pmc --no-cpu-baseline ;;
 bench_quick)
   timeout 900 python bench.py --no-cpu-baseline --no-pmc > $O/r05_bench_quick.json 2> $O/r05_bench_quick.err; python - <<P
 import json
@@ -29,6 +29,8 @@ for k, v in r.get("extra", {}).items():
     print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a in ("ms_per_step", "ratio", "ratio_prefetched", "ratio_to_ordered", "ratio_to_builder_order", "kernels_ms", "error")})
 P
   ;;
+tests_new)
+  timeout 1500 python -m pytest tests/test_gpu_order.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -15 ;;
 tests_dist)
   timeout 1500 python -m pytest tests/test_gpu_distributed.py tests/test_gpu_streams.py -x -q -m gpu 2>&1 | tail -5 ;;
 tests)
