@@ -180,7 +180,8 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g);
 //   sort_desc  : order every cell's atoms by descending id (reference row order); otherwise the
 //                order inside a cell is whatever the atomic counters produced
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
-                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key = nullptr, bool packed = false);
+                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key = nullptr, bool packed = false,
+                    bool scattered = false);
 
 // neighbor.hip: out[0..n] = exclusive prefix sums of in[0..n), out[n] = total
 int exclusive_scan_u32(Scope &sc, const unsigned *in, int *out, int64_t n);

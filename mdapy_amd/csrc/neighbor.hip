@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
                                                 unsigned *__restrict__ cell_count, unsigned *__restrict__ ctl, unsigned gen,
-                                                double slack, unsigned short *__restrict__ mv, CellPlanes win)
+                                                double slack, unsigned short *__restrict__ mv, CellPlanes win,
+                                                CellGrid::Packed *__restrict__ rec)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false, outside = false, coded = false;
@@ -74,6 +75,9 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
             }
         }
         if (mv) mv[i] = (unsigned short)code;
+        // scattered input (mdh_spatial_sort): the atom as ONE 32-byte record in input order — the gather then reads one random
+        // sector per atom instead of three (x, y, z) or four (the image code)
+        if (rec) rec[i] = CellGrid::Packed{xr, yr, zr, (int)i, code};
         coded = code != img::ATOM_NEUTRAL;
         int c0, c1, c2;
         cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
@@ -475,6 +479,16 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
     mvs[p] = m;
 }
 
+// the gather of scattered input: whole records (written in input order by k_assign), one random 32-byte read per atom
+__global__ __launch_bounds__(256) void k_gather_records(const CellGrid::Packed *__restrict__ rec, const int *__restrict__ order,
+                                                        CellGrid::Packed *__restrict__ pk, int64_t N, const int *__restrict__ n_binned)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N || p >= *n_binned)
+        return;
+    pk[p] = rec[order[p]];
+}
+
 __global__ __launch_bounds__(256) void k_unpack(const CellGrid::Packed *__restrict__ pk, int64_t N, double *__restrict__ xs,
                                                 double *__restrict__ ys, double *__restrict__ zs, unsigned short *__restrict__ mvs)
 {
@@ -568,7 +582,7 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
 }
 
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
-                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key, bool packed)
+                    bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key, bool packed, bool scattered)
 {
     const Grid &g = cg.g;
     hipStream_t st = sc.stream();
@@ -586,8 +600,11 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     cg.xs = cg.ys = cg.zs = nullptr;
     cg.mvs = nullptr;
     cg.pk = nullptr;
+    // scattered (with packed): the caller knows that the atoms come in no spatial order
+    CellGrid::Packed *rec = nullptr;
     if (packed) {
         cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
+        if (scattered) rec = sc.alloc_n<CellGrid::Packed>((size_t)N);
     } else {
         cg.xs = sc.alloc_n<double>((size_t)N);
         cg.ys = sc.alloc_n<double>((size_t)N);
@@ -639,9 +656,9 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     }
     const unsigned gen = next_scan_gen(); // stamps of this build's k_assign; the (first) scan below is launched with the same value
     if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec);
     else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win);
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec);
     auto scan_piece = [&](int64_t from, int64_t to, unsigned use_gen, int *flags) {
         launch_scan_gen(st, cell_count + from, cg.cell_start + from, to - from, ctl, use_gen, true, flags); // [to] = the piece's total
     };
@@ -689,7 +706,8 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     }
     // (the atoms binned = the grid's total, on the device: all N unless absent atoms were handed in or a window's promise was broken)
     const int *n_binned = cg.cell_start + g.ncell;
-    hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4, n_binned);
+    if (rec) hipLaunchKernelGGL(k_gather_records, dim3(grid_for(N, 256)), dim3(256), 0, st, rec, cg.order, cg.pk, N, n_binned);
+    else hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4, n_binned);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
