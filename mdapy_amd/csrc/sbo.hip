@@ -15,7 +15,7 @@
 
 namespace mdh {
 
-static int g_sq_variant = 0; // test hook: 1 = generic stage-1 kernel for every degree
+static int g_sq_variant = 0; // test hook: 1 = generic stage-1 kernel for every degree; 2 = sixteen lanes per atom for l = 4, 6 (measuring variant)
 static constexpr int SBO_MAXL = 16;  // entries of llist
 static constexpr int SBO_LMAX = 40;  // largest degree (3l+1 must index the 168-entry factorial table)
 static constexpr double MY_PI = 3.14159265358979323846;
@@ -235,6 +235,101 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
     }
 }
 
+// Stage 1 with SIXTEEN LANES PER ATOM (four atoms to a wavefront) — north_star's "one wavefront per atom" shape in the form that
+// wastes the fewest lanes on a 12-bond row: lane b of an atom's group takes the bonds b, b + 16, ... of the row (one bond each for
+// the rows of the k-nearest and first-shell lists), evaluates its bond's 2l+1 terms exactly as the lane-per-atom kernel does, and
+// the group adds the bonds up with four butterfly steps per component.  Sums run in the butterfly's order, not the list's: equal
+// to the lane-per-atom kernel to rounding (~1e-16 relative), not bit for bit.  A MEASURING variant (mdh_debug_set_sq_variant(2),
+// tools/sq_wave_ab.py -> profiles/r05_sq_wave.txt): the product path is k_sq_stage1_l.
+template <bool TRI, int L>
+__global__ __launch_bounds__(256) void k_sq_stage1_g16(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                       int64_t N, DBox b, const int *__restrict__ NL, const double *__restrict__ DL, int64_t M,
+                                                       const int *__restrict__ NN, const double *__restrict__ weight, int il, int stride, int nz,
+                                                       int lmax, int nnn, int use_voronoi, double rc, int use_weight,
+                                                       const double *__restrict__ norm, double *__restrict__ qlm_r, double *__restrict__ qlm_i,
+                                                       double *__restrict__ qn, int ncol, int lrt)
+{
+    constexpr int NM = 2 * L + 1;
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= N)
+        return; // (whole groups leave: the butterflies below stay inside a group of 16 lanes)
+    const int o = il * nz;
+    double ar[NM], ai[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { ar[m] = 0.0; ai[m] = 0.0; }
+    double nrm[L + 1];
+#pragma unroll
+    for (int m = 0; m <= L; ++m) nrm[m] = norm[il * (lmax + 1) + m];
+    const double EPS = 1e-15;
+    const double x1 = x[i], y1 = y[i], z1 = z[i];
+    int cnt = NN[i];
+    if (!use_voronoi && nnn > 0)
+        cnt = nnn;
+    double wsum = 0.0;
+    for (int jj = sub; jj < cnt; jj += 16) {
+        const int64_t idx = i * M + jj;
+        const int j = NL[idx];
+        const double r = DL[idx], w = use_weight ? weight[idx] : 1.0;
+        if ((unsigned)j >= (unsigned)N)
+            continue;
+        double dx = x[j] - x1, dy = y[j] - y1, dz = z[j] - z1;
+        pbc<TRI>(b, dx, dy, dz);
+        if (!((r > EPS) && (r <= rc)))
+            continue;
+        wsum += w;
+        const double rinv = 1.0 / r;
+        const double ct = dz * rinv;
+        double er = dx, ei = dy;
+        const double rxy2 = er * er + ei * ei;
+        if (rxy2 < EPS * EPS) { er = 1.0; ei = 0.0; }
+        else { const double sc = 1.0 / sqrt(rxy2); er *= sc; ei *= sc; }
+        ar[L] += w * (nrm[0] * assoc_legendre(L, 0, ct));
+        double mr = er, mi = ei;
+#pragma unroll
+        for (int m = 1; m < L + 1; ++m) {
+            const double pf = nrm[m] * assoc_legendre(L, m, ct);
+            const double cr = pf * mr, ci = pf * mi;
+            const double wr = w * cr, wi = w * ci;
+            ar[L + m] += wr;
+            ai[L + m] += wi;
+            if (m & 1) { ar[L - m] -= wr; ai[L - m] += wi; }
+            else { ar[L - m] += wr; ai[L - m] -= wi; }
+            const double tr = mr * er - mi * ei, ti = mr * ei + mi * er;
+            mr = tr; mi = ti;
+        }
+    }
+    // the group's bonds added up: four butterfly steps (every lane ends with the totals)
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        wsum += __shfl_xor(wsum, d, 16);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            ar[m] += __shfl_xor(ar[m], d, 16);
+            ai[m] += __shfl_xor(ai[m], d, 16);
+        }
+    }
+    const double f = 1.0 / wsum;
+    double mine_r = 0.0, mine_i = 0.0; // lane m of the group owns component m (NM <= 13 components for l <= 6)
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+        if (sub == m) { mine_r = ar[m]; mine_i = ai[m]; }
+    if (sub < NM) {
+        const int64_t at = i * stride + o + sub;
+        qlm_r[at] = (qlm_r[at] + mine_r) * f; // (onto the caller's pre-zeroed content, as the reference adds)
+        qlm_i[at] = (qlm_i[at] + mine_i) * f;
+    }
+    if (qn && sub == 0) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const double vr = ar[m] * f, vi = ai[m] * f;
+            sacc += vr * vr + vi * vi;
+        }
+        qn[i * ncol + il] = sqrt(4 * MY_PI / (2 * lrt + 1)) * sqrt(sacc);
+    }
+}
+
 template <bool TRI>
 static bool launch_stage1_l(int l, dim3 grid, hipStream_t st, const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b,
                             const int *dv, const double *dd, int64_t M, const int *dn, const double *dw, int il, int stride, int nz, int lmax,
@@ -245,6 +340,16 @@ static bool launch_stage1_l(int l, dim3 grid, hipStream_t st, const double *dx, 
         hipLaunchKernelGGL((k_sq_stage1_l<TRI, LL>), grid, dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, il, stride, nz, lmax, nnn, \
                            use_voronoi, rc, use_weight, dnorm, dqr, dqi, dqn, ncol, LL);                                                 \
         return true;
+    if (g_sq_variant == 2 && (l == 4 || l == 6)) { // measuring variant: sixteen lanes per atom
+        const dim3 g16(grid_for(N, 16));
+        if (l == 4)
+            hipLaunchKernelGGL((k_sq_stage1_g16<TRI, 4>), g16, dim3(256), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, il, stride, nz, lmax, nnn, use_voronoi, rc,
+                               use_weight, dnorm, dqr, dqi, dqn, ncol, 4);
+        else
+            hipLaunchKernelGGL((k_sq_stage1_g16<TRI, 6>), g16, dim3(256), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, il, stride, nz, lmax, nnn, use_voronoi, rc,
+                               use_weight, dnorm, dqr, dqi, dqn, ncol, 6);
+        return true;
+    }
     switch (l) {
         MDH_SQ_L(2) MDH_SQ_L(3) MDH_SQ_L(4) MDH_SQ_L(5) MDH_SQ_L(6) MDH_SQ_L(7) MDH_SQ_L(8) MDH_SQ_L(10) MDH_SQ_L(12)
     default:
@@ -556,7 +661,7 @@ int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, con
 
     // degrees with a compiled instantiation: one register-resident launch per entry of llist; any other degree in the list
     // sends the whole call through the generic kernel (LDS accumulators)
-    bool special = g_sq_variant == 0;
+    bool special = g_sq_variant != 1;
     for (int k = 0; k < nl && special; ++k) {
         const int l = ll.l[k];
         special = (l >= 2 && l <= 8) || l == 10 || l == 12;

@@ -29,6 +29,11 @@ for k, v in r.get("extra", {}).items():
     print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a in ("ms_per_step", "ratio", "ratio_prefetched", "ratio_to_ordered", "ratio_to_builder_order", "kernels_ms", "error")})
 P
   ;;
+order_sweep)
+  python tools/order_sweep.py 136 2>&1 | clean | tee $O/r05_order_sweep.txt ;;
+sq_wave)
+  prof sq_wave python $R/tools/sq_wave_ab.py 136
+  clean < $O/r05_sq_wave/run.log > $O/r05_sq_wave.txt; python tools/kstats.py $O/r05_sq_wave 8 | grep -i "sq_" >> $O/r05_sq_wave.txt; cat $O/r05_sq_wave.txt ;;
 tests_new)
   timeout 1500 python -m pytest tests/test_gpu_order.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -15 ;;
 tests_dist)
