@@ -15,7 +15,7 @@
 
 namespace mdh {
 
-static int g_sq_variant = 0; // test hook: 1 = generic stage-1 kernel for every degree; 2 = sixteen lanes per atom for l = 4, 6 (measuring variant)
+static int g_sq_variant = 0; // test hook: 1 = generic stage-1 kernel for every degree; 2 = sixteen lanes per atom for l = 4, 6 (measuring variant); 3 = one launch per degree even for the pair (4, 6)
 static constexpr int SBO_MAXL = 16;  // entries of llist
 static constexpr int SBO_LMAX = 40;  // largest degree (3l+1 must index the 168-entry factorial table)
 static constexpr double MY_PI = 3.14159265358979323846;
@@ -232,6 +232,161 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
         const int r = e / NM, m = e - r * NM;
         qlm_r[(row0 + r) * stride + o + m] = sr[m][r];
         qlm_i[(row0 + r) * stride + o + m] = si[m][r];
+    }
+}
+
+// Stage 1 for TWO degrees LA < LB in one launch (q4 and q6, the usual pair): the row, the neighbours' positions and the bond's
+// geometry are read and computed once, and the recurrence of assoc_legendre(LB, m, x) passes through P_LA^m on its way up — the same
+// operations in the same order as assoc_legendre(LA, m, x) performs, so both degrees' terms, and their sums bond by bond in list
+// order, are bit for bit those of two k_sq_stage1_l launches.  (Each of those took 2.8 ms at 10 M atoms whatever the degree: bound
+// by the gathers and the q_lm traffic, not by the harmonics.)
+template <int LA, int LB>
+__device__ __forceinline__ void legendre_pair(int m, double x, double sqx, double &pa, double &pb)
+{
+    double p = 1.0, pm1 = 0.0, pm2 = 0.0;
+    if (m != 0) {
+        for (int i = 1; i < m + 1; ++i)
+            p *= (2 * i - 1) * sqx;
+    }
+    pa = p; // (m == LA: the loop below does not reach LA)
+#pragma unroll
+    for (int i = m + 1; i < LB + 1; ++i) {
+        pm2 = pm1;
+        pm1 = p;
+        p = ((2 * i - 1) * x * pm1 - (i + m - 1) * pm2) / (i - m);
+        if (i == LA) pa = p;
+    }
+    pb = p;
+}
+template <bool TRI, int LA, int LB>
+__global__ __launch_bounds__(64) void k_sq_stage1_pair(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                       int64_t N, DBox b, const int *__restrict__ NL, const double *__restrict__ DL, int64_t M,
+                                                       const int *__restrict__ NN, const double *__restrict__ weight, int ila, int ilb, int stride,
+                                                       int nz, int lmax, int nnn, int use_voronoi, double rc, int use_weight,
+                                                       const double *__restrict__ norm, double *__restrict__ qlm_r, double *__restrict__ qlm_i,
+                                                       double *__restrict__ qn, int ncol)
+{
+    constexpr int NA = 2 * LA + 1, NB = 2 * LB + 1, NM = NA + NB;
+    __shared__ double sr[NM][65], si[NM][65];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + t;
+    const int rows = (int)(N - row0 < 64 ? N - row0 : 64);
+    const int oa = ila * nz, ob = ilb * nz;
+    for (int e = t; e < rows * NM; e += 64) {
+        const int r = e / NM, m = e - r * NM;
+        const int64_t at = (row0 + r) * stride + (m < NA ? oa + m : ob + (m - NA));
+        sr[m][r] = qlm_r[at]; // the caller's (pre-zeroed) content: the reference adds onto it
+        si[m][r] = qlm_i[at];
+    }
+    __syncthreads();
+    if (i < N) {
+        double ar[NM], ai[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { ar[m] = sr[m][t]; ai[m] = si[m][t]; }
+        double na[LA + 1], nb[LB + 1];
+#pragma unroll
+        for (int m = 0; m <= LA; ++m) na[m] = norm[ila * (lmax + 1) + m];
+#pragma unroll
+        for (int m = 0; m <= LB; ++m) nb[m] = norm[ilb * (lmax + 1) + m];
+        const double EPS = 1e-15;
+        const double x1 = x[i], y1 = y[i], z1 = z[i];
+        int cnt = NN[i];
+        if (!use_voronoi && nnn > 0)
+            cnt = nnn;
+        double wsum = 0.0;
+        int cj[4];
+        double cr_[4], cw[4], cx[4], cy[4], cz[4];
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int u = jj & 3;
+            if (u == 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t idx = i * M + min(jj + v, cnt - 1);
+                    cj[v] = NL[idx];
+                    cr_[v] = DL[idx];
+                    cw[v] = use_weight ? weight[idx] : 1.0;
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int js = (unsigned)cj[v] < (unsigned)N ? cj[v] : (int)i;
+                    cx[v] = x[js]; cy[v] = y[js]; cz[v] = z[js];
+                }
+            }
+            int j = cj[0];
+            double r = cr_[0], w = cw[0], xj = cx[0], yj = cy[0], zj = cz[0];
+#pragma unroll
+            for (int v = 1; v < 4; ++v)
+                if (u == v) { j = cj[v]; r = cr_[v]; w = cw[v]; xj = cx[v]; yj = cy[v]; zj = cz[v]; }
+            if ((unsigned)j >= (unsigned)N)
+                continue;
+            double dx = xj - x1, dy = yj - y1, dz = zj - z1;
+            pbc<TRI>(b, dx, dy, dz);
+            if (!((r > EPS) && (r <= rc)))
+                continue;
+            wsum += w;
+            const double rinv = 1.0 / r;
+            const double ct = dz * rinv;
+            double er = dx, ei = dy;
+            const double rxy2 = er * er + ei * ei;
+            if (rxy2 < EPS * EPS) { er = 1.0; ei = 0.0; }
+            else { const double sc = 1.0 / sqrt(rxy2); er *= sc; ei *= sc; }
+            const double sqx = sqrt(1.0 - ct * ct); // (assoc_legendre computes it for every m != 0: the same value)
+            double pa, pb;
+            legendre_pair<LA, LB>(0, ct, sqx, pa, pb);
+            ar[LA] += w * (na[0] * pa);
+            ar[NA + LB] += w * (nb[0] * pb);
+            double mr = er, mi = ei;
+#pragma unroll
+            for (int m = 1; m < LB + 1; ++m) {
+                legendre_pair<LA, LB>(m, ct, sqx, pa, pb);
+                if (m <= LA) {
+                    const double pf = na[m] * pa;
+                    const double cr = pf * mr, ci = pf * mi;
+                    const double wr = w * cr, wi = w * ci;
+                    ar[LA + m] += wr;
+                    ai[LA + m] += wi;
+                    if (m & 1) { ar[LA - m] -= wr; ai[LA - m] += wi; }
+                    else { ar[LA - m] += wr; ai[LA - m] -= wi; }
+                }
+                {
+                    const double pf = nb[m] * pb;
+                    const double cr = pf * mr, ci = pf * mi;
+                    const double wr = w * cr, wi = w * ci;
+                    ar[NA + LB + m] += wr;
+                    ai[NA + LB + m] += wi;
+                    if (m & 1) { ar[NA + LB - m] -= wr; ai[NA + LB - m] += wi; }
+                    else { ar[NA + LB - m] += wr; ai[NA + LB - m] -= wi; }
+                }
+                const double tr = mr * er - mi * ei, ti = mr * ei + mi * er;
+                mr = tr; mi = ti;
+            }
+        }
+        const double f = 1.0 / wsum;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { sr[m][t] = ar[m] * f; si[m][t] = ai[m] * f; }
+        if (qn) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < NA; ++m) {
+                const double vr = ar[m] * f, vi = ai[m] * f;
+                s1 += vr * vr + vi * vi;
+            }
+#pragma unroll
+            for (int m = NA; m < NM; ++m) {
+                const double vr = ar[m] * f, vi = ai[m] * f;
+                s2 += vr * vr + vi * vi;
+            }
+            const volatile int la_rt = LA, lb_rt = LB; // (the factor as the kernel of stage 3 computes it, from a degree known at run time)
+            qn[i * ncol + ila] = sqrt(4 * MY_PI / (2 * la_rt + 1)) * sqrt(s1);
+            qn[i * ncol + ilb] = sqrt(4 * MY_PI / (2 * lb_rt + 1)) * sqrt(s2);
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < rows * NM; e += 64) {
+        const int r = e / NM, m = e - r * NM;
+        const int64_t at = (row0 + r) * stride + (m < NA ? oa + m : ob + (m - NA));
+        qlm_r[at] = sr[m][r];
+        qlm_i[at] = si[m][r];
     }
 }
 
@@ -669,7 +824,15 @@ int mdh_get_sq(const double *x, const double *y, const double *z, int64_t N, con
     // no averaging, no w_l: q_l leaves the stage-1 kernels, stage 3 is not launched (2.1 of 8.2 ms for q4 + q6 of 10 M atoms)
     const bool fused_final = special && !average && !wl && !wlhat;
     double *fq = fused_final ? dqn : nullptr;
-    if (special) {
+    if (special && g_sq_variant == 0 && nl == 2 && ll.l[0] == 4 && ll.l[1] == 6) { // q4 and q6: both degrees in one launch
+        const dim3 grid(grid_for(N, 64));
+        if (b.tri)
+            hipLaunchKernelGGL((k_sq_stage1_pair<true, 4, 6>), grid, dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, 0, 1, (int)stride, 2 * lmax + 1, lmax, nnn,
+                               use_voronoi, rc, use_weight, dnorm, dqr, dqi, fq, ncol);
+        else
+            hipLaunchKernelGGL((k_sq_stage1_pair<false, 4, 6>), grid, dim3(64), 0, st, dx, dy, dz, N, b, dv, dd, M, dn, dw, 0, 1, (int)stride, 2 * lmax + 1, lmax, nnn,
+                               use_voronoi, rc, use_weight, dnorm, dqr, dqi, fq, ncol);
+    } else if (special) {
         const dim3 grid(grid_for(N, 64));
         for (int k = 0; k < nl; ++k) {
             if (b.tri)

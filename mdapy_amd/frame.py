@@ -106,6 +106,8 @@ class PermutedColumn(Column):
     @property
     def _host(self) -> np.ndarray:
         if self._host_arr is None:
+            if self._dev is None and self._in_hbm():
+                self.device_array()  # (10 M numbers: a gather in HBM and one copy down, not a host gather through 40 MB of indices)
             if self._dev is not None:
                 self._host_arr = self._dev.numpy()
             else:
@@ -114,10 +116,13 @@ class PermutedColumn(Column):
                 self._host_arr = a
         return self._host_arr
 
+    def _in_hbm(self):
+        kind = np.dtype(self._source.dtype)
+        return type(self._perm).__name__ in ("HArray", "LazyHArray") and kind.kind in "iuf" and kind.itemsize in (4, 8)
+
     def device_array(self):
         if self._dev is None:
-            kind = np.dtype(self._source.dtype)
-            if type(self._perm).__name__ in ("HArray", "LazyHArray") and kind.kind in "iuf" and kind.itemsize in (4, 8):
+            if self._in_hbm():
                 from . import kernels
 
                 self._dev = kernels.order.permute(self._source.device_array(), self._perm)

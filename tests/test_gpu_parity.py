@@ -669,7 +669,8 @@ def test_steinhardt_per_degree_kernels_equal_the_generic_one():
     N = len(x)
     v, d, n = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, 3.4, 4)
     w = np.random.default_rng(3).random(v.shape)
-    for ls, nnn, use_w in (([4, 6], 0, False), ([2, 3, 5, 7, 8, 10, 12], 0, True), ([6], 10, False), ([4, 9], 0, False)):
+    # ([4, 6]: both degrees in ONE launch, k_sq_stage1_pair — the recurrence to l = 6 passes through l = 4)
+    for ls, nnn, use_w in (([4, 6], 0, False), ([4, 6], 10, True), ([6, 4], 0, False), ([2, 3, 5, 7, 8, 10, 12], 0, True), ([6], 10, False), ([4, 9], 0, False)):
         ll = np.array(ls, np.int32)
         lmax = int(ll.max())
         # (w_l, w-hat_l, averaging) all on; all off: q_l then leaves the stage-1 kernels themselves and stage 3 is not launched
