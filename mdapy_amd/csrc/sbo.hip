@@ -267,6 +267,8 @@ __global__ __launch_bounds__(64) void k_sq_stage1_pair(const double *__restrict_
                                                        double *__restrict__ qn, int ncol)
 {
     constexpr int NA = 2 * LA + 1, NB = 2 * LB + 1, NM = NA + NB;
+    // (one staging buffer used twice — real parts, then imaginary ones: half the LDS, eleven instead of six wavefronts per CU — was
+    // measured SLOWER, 4.7 against 4.0 ms at 10 M atoms: the two extra barrier pairs cost more than the occupancy buys)
     __shared__ double sr[NM][65], si[NM][65];
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + t;
