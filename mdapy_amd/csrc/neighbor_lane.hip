@@ -55,6 +55,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -1275,6 +1276,8 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
 #else
     constexpr int nw_env = 0;
 #endif
+    // A/B (tools/measure_r05.sh lane_tiles): MDH_LANE_TILE="txy,tz" forces the tile shape where it fits
+    static const int tile_env = [] { const char *e = std::getenv("MDH_LANE_TILE"); int a = 0, c = 0; return (e && std::sscanf(e, "%d,%d", &a, &c) == 2) ? a * 100 + c : 0; }();
     Shape best{0, 0};
     int best_cap = 0, best_wgs = 0, best_rw = 64, best_nw = 4;
     double best_score = -1.0;
@@ -1295,6 +1298,8 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
             for (int tz = 1; tz <= 24; ++tz) {
                 const int nh = (txy + 2) * (txy + 2) * (tz + 2);
                 if (nh > nthr)
+                    continue;
+                if (tile_env && (txy != tile_env / 100 || tz != tile_env % 100))
                     continue;
                 const int ncc = txy * txy * tz;
                 const double c = ncc * pop;                                 // centre atoms per tile

@@ -34,6 +34,8 @@ order_sweep)
 sq_wave)
   prof sq_wave python $R/tools/sq_wave_ab.py 136
   clean < $O/r05_sq_wave/run.log > $O/r05_sq_wave.txt; python tools/kstats.py $O/r05_sq_wave 8 | grep -i "sq_" >> $O/r05_sq_wave.txt; cat $O/r05_sq_wave.txt ;;
+lane_tiles)  # the headline build with the tile shape forced (the planner picks 4x4x5): k_neighbor per shape
+  for t in "" 4,5 5,3 3,8 4,4 3,7 5,2 6,2; do echo "--- MDH_LANE_TILE=$t"; MDH_LANE_TILE=$t python tools/kbench.py 136 16 0.854 2>&1 | clean | grep -A1 "variant=0" | cut -c1-260; done | tee $O/r05_lane_tiles.txt ;;
 tests_new)
   timeout 1500 python -m pytest tests/test_gpu_order.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -15 ;;
 tests_dist)
