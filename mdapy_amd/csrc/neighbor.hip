@@ -547,6 +547,24 @@ __global__ __launch_bounds__(256) void k_fill_from(int *__restrict__ out, int64_
         if (b4 + i < b) out[b4 + i] = val;
     }
 }
+// a one-piece window [a0, a1] of the grid: zeros in front of it, *v (the atoms binned, cell_start[a1]) behind it — ONE launch behind
+// the window's scan instead of a memset in front of it and a fill behind (a memset is two 5 us nodes on the stream)
+__global__ __launch_bounds__(256) void k_fill_outside(int *__restrict__ out, int64_t a0, int64_t a1, int64_t n1, const int *__restrict__ v)
+{
+    const int val = *v;
+    const int64_t q = 4 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    const int64_t head4 = (a0 + 3) >> 2 << 2;               // the head [0, a0) rounded up to whole quads (the overshoot is fixed below)
+    const int64_t t0 = (a1 + 1 + 3) & ~(int64_t)3;          // first aligned index behind the window
+    if (q < head4) {
+        if (q + 4 <= a0) *reinterpret_cast<int4 *>(out + q) = make_int4(0, 0, 0, 0);
+        else for (int64_t i = q; i < a0; ++i) out[i] = 0;
+        return;
+    }
+    const int64_t r = q - head4 + t0;                       // quads behind the window
+    if (r == t0) for (int64_t i = a1 + 1; i < t0 && i < n1; ++i) out[i] = val;
+    if (r + 4 <= n1) *reinterpret_cast<int4 *>(out + r) = make_int4(val, val, val, val);
+    else for (int64_t i = r; i < n1; ++i) out[i] = val;
+}
 static void fill_from(hipStream_t st, int *out, int64_t a, int64_t b, const int *v)
 {
     if (b > a)
@@ -675,9 +693,12 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
             if (to > from && fill_err == hipSuccess)
                 fill_err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cg.cell_start + from), v, (size_t)(to - from), st);
         };
-        fill_const(0, a0, 0);
+        if (b1 > b0) fill_const(0, a0, 0);
         scan_piece(a0, a1, gen, cg.flags);
-        if (b1 > b0) {
+        if (b1 <= b0) { // one piece: everything outside it in one launch
+            const int64_t n1 = g.ncell + 1, quads = ((a0 + 3) >> 2) + ((n1 - std::min(n1, (a1 + 1 + 3) & ~(int64_t)3) + 3) >> 2) + 1;
+            hipLaunchKernelGGL(k_fill_outside, dim3(grid_for(quads, 256)), dim3(256), 0, st, cg.cell_start, a0, a1, n1, cg.cell_start + a1);
+        } else if (b1 > b0) {
             // second piece: offsets start at the first piece's total, which sits on the device in cell_start[a1]
             fill_from(st, cg.cell_start, a1 + 1, b0, cg.cell_start + a1);
             scan_piece(b0, b1, next_scan_gen(), nullptr);
@@ -686,8 +707,6 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
             // the constant N a cell behind a broken window spanned the records [n_binned, N), which k_scatter / k_gather never wrote
             if (b1 < g.ncell)
                 fill_from(st, cg.cell_start, b1 + 1, g.ncell + 1, cg.cell_start + b1);
-        } else if (a1 < g.ncell) {
-            fill_from(st, cg.cell_start, a1 + 1, g.ncell + 1, cg.cell_start + a1);
         }
         MDH_HIP(fill_err);
     }

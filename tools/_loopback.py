@@ -21,17 +21,24 @@ def install(dec, slab_length, n_owned):
     dec._host_staged = lambda: False
     dist.all_reduce = lambda tensor, op=None, group=None: tensor  # identical slabs: every rank's largest layer is this rank's
 
+    shifts = {}
+
     def fake_batch(ops):
         sends = [o for o in ops if o.op is dist.isend]
         recvs = [o for o in ops if o.op is dist.irecv]
         to_right, to_left = sends[0].tensor, sends[1].tensor      # order in _ring: sends = [to right, to left]
         from_left, from_right = recvs[0].tensor, recvs[1].tensor  # recvs = [from left, from right]
         if to_right.dim() == 1 and to_right.numel() > 16:  # the single-message exchange: [count, x row, y row, z row, (extra,) id row]
-            width = 4
-            cap = (to_right.numel() - 1) // width
-            a = to_right.clone(); a[1:1 + cap] -= slab_length; a[1 + 3 * cap:1 + 4 * cap] -= n_owned
-            b = to_left.clone(); b[1:1 + cap] += slab_length; b[1 + 3 * cap:1 + 4 * cap] += n_owned
-            from_left.copy_(a); from_right.copy_(b)
+            # ONE kernel per direction, as a P2P copy would be one: message + (the neighbour slab's offset in x and in the ids)
+            key = (to_right.numel(), str(to_right.device))
+            if key not in shifts:
+                width = 4
+                cap = (to_right.numel() - 1) // width
+                sh = torch.zeros_like(to_right)
+                sh[1:1 + cap] = slab_length; sh[1 + 3 * cap:1 + 4 * cap] = n_owned
+                shifts[key] = sh
+            torch.sub(to_right, shifts[key], out=from_left)
+            torch.add(to_left, shifts[key], out=from_right)
         elif to_right.dim() == 1:
             from_left.copy_(to_right); from_right.copy_(to_left)
         else:

@@ -36,6 +36,12 @@ sq_wave)
   clean < $O/r05_sq_wave/run.log > $O/r05_sq_wave.txt; python tools/kstats.py $O/r05_sq_wave 8 | grep -i "sq_" >> $O/r05_sq_wave.txt; cat $O/r05_sq_wave.txt ;;
 lane_tiles)  # the headline build with the tile shape forced (the planner picks 4x4x5): k_neighbor per shape
   for t in "" 4,5 5,3 3,8 4,4 3,7 5,2 6,2; do echo "--- MDH_LANE_TILE=$t"; MDH_LANE_TILE=$t python tools/kbench.py 136 16 0.854 2>&1 | clean | grep -A1 "variant=0" | cut -c1-260; done | tee $O/r05_lane_tiles.txt ;;
+strong)   # the 1-of-8 slab step: wall times, then the device timeline of one step
+  prof strong python $R/tools/strong_probe.py 136 20
+  clean < $O/r05_strong/run.log | grep slab > $O/r05_strong.txt
+  python tools/timeline.py $O/r05_strong k_slab_messages 2 >> $O/r05_strong.txt; cat $O/r05_strong.txt ;;
+halo)   # weak scaling: a 136^3-cell slab of 8 with its halo in loop-back against the undivided 136^3 box
+  python tools/halo_cost.py 136 8 2>&1 | clean | tee $O/r05_halo_cost.txt ;;
 tests_new)
   timeout 1500 python -m pytest tests/test_gpu_order.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -15 ;;
 tests_dist)
