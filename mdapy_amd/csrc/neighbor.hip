@@ -694,7 +694,10 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
                 fill_err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cg.cell_start + from), v, (size_t)(to - from), st);
         };
         if (b1 > b0) fill_const(0, a0, 0);
-        scan_piece(a0, a1, gen, cg.flags);
+        // (from a multiple of four cells on: the scan moves 16 bytes per access only from an aligned start — 66 against 26 us for the
+        // 3.6 M cells of a 10 M-atom slab; the up to three counters in front of the window are zero, and zero is what the cells in
+        // front of the window hold)
+        scan_piece(a0 & ~(int64_t)3, a1, gen, cg.flags);
         if (b1 <= b0) { // one piece: everything outside it in one launch
             const int64_t n1 = g.ncell + 1, quads = ((a0 + 3) >> 2) + ((n1 - std::min(n1, (a1 + 1 + 3) & ~(int64_t)3) + 3) >> 2) + 1;
             hipLaunchKernelGGL(k_fill_outside, dim3(grid_for(quads, 256)), dim3(256), 0, st, cg.cell_start, a0, a1, n1, cg.cell_start + a1);

@@ -40,6 +40,9 @@ strong)   # the 1-of-8 slab step: wall times, then the device timeline of one st
   prof strong python $R/tools/strong_probe.py 136 20
   clean < $O/r05_strong/run.log | grep slab > $O/r05_strong.txt
   python tools/timeline.py $O/r05_strong k_slab_messages 2 >> $O/r05_strong.txt; cat $O/r05_strong.txt ;;
+weak_trace)
+  prof weak python $R/tools/strong_probe.py 136 10 weak
+  python tools/timeline.py $O/r05_weak k_slab_messages 2 | tee $O/r05_weak.txt ;;
 halo)   # weak scaling: a 136^3-cell slab of 8 with its halo in loop-back against the undivided 136^3 box
   python tools/halo_cost.py 136 8 2>&1 | clean | tee $O/r05_halo_cost.txt ;;
 tests_new)

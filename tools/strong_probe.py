@@ -14,12 +14,13 @@ cells = int(sys.argv[1]) if len(sys.argv) > 1 else 136
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda", 0)
 w8, M = 8, 16
-cx = cells // w8
+weak = len(sys.argv) > 3 and sys.argv[3] == "weak"  # a whole cells^3 slab of an (8 cells) x cells x cells box instead of an eighth of the cells^3 box
+cx = cells if weak else cells // w8
 sx, sy, sz, sg = slab_positions(torch, dev, cells, 1, 0.0, cells_x=cx)
 n = int(sx.shape[0])
-dec = SlabDecomposition(mp.Box(np.diag([A_CU * cells] * 3)), 1, w8, axis=0)
+dec = SlabDecomposition(mp.Box(np.diag([A_CU * cx * w8, A_CU * cells, A_CU * cells])), 1, w8, axis=0)
 _loopback.install(dec, A_CU * cx, n)
-sx, sy, sz, sg = (dec.with_room(a, 0.25) for a in (sx, sy, sz, sg))
+sx, sy, sz, sg = (dec.with_room(a, 0.05 if weak else 0.25) for a in (sx, sy, sz, sg))
 for prefetch in (False, True):
     nf = (sx, sy, sz, sg) if prefetch else None
     for _ in range(3):
