@@ -230,7 +230,7 @@ def cpu_baseline(args):
     sweep = {int(k): v for k, v in got["sweep"].items()}
     best_threads = min(full, key=full.get)
     best = full[best_threads]
-    return {"value": N / best, "unit": "atoms/s", "cores": best_threads, "kind": "port",
+    return {"value": N / best, "unit": "atoms/s", "cores": cores, "threads": best_threads, "kind": "port",
             "sample": f"{N}-atom FCC Cu (the headline input), neighbor(rc={RC:.5f}, max_neigh={M}) + fixed CNA, OpenMP oracle port "
                       f"(oracle/mdapy_oracle.c), best of <= 3 runs at {sorted(full)} threads (picked by a sweep {sorted(sweep)} on "
                       f"{got['N_sweep']} atoms), {cores} host cores, {got.get('numa_nodes', 0)} NUMA node(s)",

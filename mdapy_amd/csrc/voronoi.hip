@@ -186,8 +186,11 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
         if (2.0 * rmax > reach || nn[row] > M || nf == 0) {
             const int slot = atomicAdd(incomplete, 1);
             if (unfinished) unfinished[slot] = (int)i;
+        } else if (max_faces && i < n_orig) {
+            // (only a cell that is COMPLETE in this pass counts: a cell still open has more faces now than it will have at a wider
+            // radius, and the width the rows are handed over at is max(neighbor_number) of the finished cells, voronoi.cpp:307-447)
+            atomicMax(max_faces, nf);
         }
-        if (max_faces && i < n_orig) atomicMax(max_faces, nf);
     }
     // Voronoi neighbour rows (src/voronoi.cpp:307-447): the faces shared with atoms — walls have no partner — whose area
     // exceeds max(a_thr, r_thr * total face area), nearest first, padded with -1 / 10000 / 0

@@ -128,6 +128,9 @@ def label_codes(labels, device_ok=False):
         return list(names), codes
     made = _label_codes_device(raw) if device_ok else None
     if made is not None:
+        if len(_population) > 8:  # (entries of arrays that are gone: a trajectory loop makes one per frame)
+            for k in [k for k, (ref, _) in _population.items() if ref() is None]:
+                del _population[k]
         _population[id(made[1])] = (weakref.ref(made[1]), made[2])
         return made[0], made[1]
     return _label_codes(raw)
