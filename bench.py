@@ -626,9 +626,11 @@ def main():
                 shuf = (x[perm].contiguous(), y[perm].contiguous(), z[perm].contiguous())
                 res_sys = {}
                 for tag, cols in (("ordered", (x, y, z)), ("shuffled", shuf)):
+                    a0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
                     e_, s_, _ = timed(system_step(cols), k, 2, ranges=0)
                     lab_ = s_.data["cna"].device_array().dev()
-                    res_sys[tag] = {"ms_per_step": e_ / k * 1e3, "all_fcc": bool((lab_ == 1).all().item()), "twin": s_._spatial() is not None}
+                    res_sys[tag] = {"ms_per_step": e_ / k * 1e3, "all_fcc": bool((lab_ == 1).all().item()), "twin": s_._spatial() is not None,
+                                    "hipMallocs_by_torch_during_the_loop": torch.cuda.memory_stats().get("num_device_alloc", 0) - a0}
                     del s_, lab_
                 res_sys["ratio"] = res_sys["shuffled"]["ms_per_step"] / res_sys["ordered"]["ms_per_step"]
                 res_sys["ratio_to_the_headline_step"] = res_sys["shuffled"]["ms_per_step"] / ms_per_step
