@@ -5,6 +5,8 @@ every per-atom column and every returned curve compared.
 
     python tests/fuzz_system.py [seconds] [first_seed]
 
+FUZZ_TWIN=1: the HIP side is analysed on System's cell-sorted twin (forced, whatever the size and order of the system).
+
 This exercises the policy layer above the C ABI as well (small-box replication, list reuse, triclinic alignment of
 the Voronoi calls, column naming).  Integer columns must be equal, floating ones agree to 1e-6.  Test infrastructure.
 """
@@ -120,6 +122,8 @@ def run_seed(seed, fails):
         fails.append((seed, "plan", repr(e)[:160]))
         return 0
     a, b = make_system(s), make_system(s)
+    if os.environ.get("FUZZ_TWIN") == "1":  # the HIP side analysed on its cell-sorted twin whatever its size and order, the oracle side as it is
+        a._sort_mode, b._sort_mode = "1", "0"
     for label, fn in calls:
         if os.environ.get("FUZZ_TRACE"):
             print("  call", label, flush=True)

@@ -35,3 +35,17 @@ def test_system_sweep_fixed_seeds():
         ran += F.run_seed(seed, fails)
     assert not fails, fails
     assert ran > 100
+
+
+def test_system_sweep_on_the_cell_sorted_twin(monkeypatch):
+    """the same sweep with the HIP side forced onto System's cell-sorted twin (mdapy_amd/system.py; csrc/order.hip): every
+    analysis of every drawn system — triclinic, open, unwrapped, thin (no twin then), with string and numeric columns — must
+    give what the oracle-routed classes give on the system as it is"""
+    import fuzz_system as F
+
+    monkeypatch.setenv("FUZZ_TWIN", "1")
+    fails, ran = [], 0
+    for seed in range(33000, 33040):
+        ran += F.run_seed(seed, fails)
+    assert not fails, fails
+    assert ran > 100
