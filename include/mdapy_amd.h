@@ -357,6 +357,12 @@ int mdh_wcp_counts(const int *verlet, const int *nn, const int *type, const unsi
 /* replaces _fast_knn.knn                                   src/fast_knn.cpp:846-916 */
 int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
             const int *boundary3, int k, int *indices, double *distances, int space, void *stream);
+/* the same with key (N) i64, a PERMUTATION of 0 .. N-1, or NULL: the number every atom has in another numbering of the same
+ * system (mdh_spatial_sort's perm for a cell-sorted copy).  Exact ties in distance are ordered by key instead of by index, so the
+ * rows are those mdh_knn gives for the system in the key's numbering, neighbour for neighbour — on a perfect lattice, where the
+ * k-th distance is a tie, WHICH neighbours are listed depends on it.  A key that is no permutation: memory-safe, rows meaningless. */
+int mdh_knn_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+                  const int *boundary3, int k, int *indices, double *distances, const int64_t *key, int space, void *stream);
 
 /* ---- _repeat_cell ----------------------------------------------------- */
 /* replaces _repeat_cell.repeat_cell                        src/repeat_cell.cpp:19-61; new_pos flat (n_old*nx*ny*nz*3) */

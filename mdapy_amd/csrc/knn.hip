@@ -74,12 +74,18 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
                                                   const double *__restrict__ zs, const int *__restrict__ order,
                                                   const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg, Grid g,
                                                   KnnGeom kg, int k, int *__restrict__ indices,
-                                                  double *__restrict__ distances, int *__restrict__ todo)
+                                                  double *__restrict__ distances, int *__restrict__ todo,
+                                                  const int *__restrict__ label, const int *__restrict__ unlabel)
 {
+    // label / unlabel (both NULL, or both given): candidates are told apart — the self test, the order under exact ties — by
+    // label[q] instead of their index order[q], and a listed label L is written as unlabel[L] (mdh_knn_keyed: the labels are the
+    // caller's key, a permutation of 0 .. N-1, so that ties fall as they would in the system the key numbers)
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N)
         return;
     const int i = order[p];
+    const int self = label ? label[p] : i;
+    const int *__restrict__ cand = label ? label : order;
     const double qx = xs[p], qy = ys[p], qz = zs[p]; // wrapped query == stored wrapped self (bitwise)
     int c0, c1, c2;
     cell_coords<TRI>(bg, g, qx, qy, qz, c0, c1, c2);
@@ -121,12 +127,12 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
                 for (int u = 0; u < 8; ++u) { // 32 loads in flight together
                     const int q = min(q0 + u, se - 1);
                     const double dx = xs[q] - w0, dy = ys[q] - w1, dz = zs[q] - w2;
-                    cj[u] = order[q];
+                    cj[u] = cand[q];
                     d2s[u] = dx * dx + dy * dy + dz * dz;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const bool live = q0 + u < se && !(cj[u] == i && d2s[u] == 0.0) && !(d2s[u] > bound) &&
+                    const bool live = q0 + u < se && !(cj[u] == self && d2s[u] == 0.0) && !(d2s[u] > bound) &&
                                       (d2s[u] < ld[K - 1] || (d2s[u] == ld[K - 1] && cj[u] < li[K - 1]));
                     todo_mask |= live ? 1u << u : 0u;
                 }
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
 #pragma unroll
     for (int e = 0; e < K; ++e)
         if (e < k) {
-            indices[(int64_t)i * k + e] = li[e];
+            indices[(int64_t)i * k + e] = unlabel ? unlabel[li[e]] : li[e];
             distances[(int64_t)i * k + e] = sqrt(ld[e]); // :883
         }
 }
@@ -175,7 +181,7 @@ template <bool TRI>
 __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
                       const int *__restrict__ order, const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg,
                       Grid g, KnnGeom kg, int k, int *__restrict__ indices, double *__restrict__ distances,
-                      const int *__restrict__ todo)
+                      const int *__restrict__ todo, const int *__restrict__ label, const int *__restrict__ unlabel)
 {
     extern __shared__ unsigned char smem[];
     const int bd = blockDim.x, t = threadIdx.x;
@@ -190,6 +196,8 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
         return;
     }
     const int i = order[p];
+    const int self = label ? label[p] : i; // (labels: as in k_knn_near)
+    const int *__restrict__ cand = label ? label : order;
     const double qx = xs[p], qy = ys[p], qz = zs[p]; // wrapped query == stored wrapped self (bitwise)
     int c0, c1, c2;
     cell_coords<TRI>(bg, g, qx, qy, qz, c0, c1, c2);
@@ -207,7 +215,7 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int q = min(q0 + u, se - 1);
-                cx[u] = xs[q]; cy[u] = ys[q]; cz[u] = zs[q]; cj[u] = order[q];
+                cx[u] = xs[q]; cy[u] = ys[q]; cz[u] = zs[q]; cj[u] = cand[q];
             }
             double d2s[8];
             unsigned todo = 0;
@@ -215,7 +223,7 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
             for (int u = 0; u < 8; ++u) {
                 const double dx = cx[u] - w0, dy = cy[u] - w1, dz = cz[u] - w2;
                 d2s[u] = dx * dx + dy * dy + dz * dz;
-                const bool live = q0 + u < se && !(cj[u] == i && d2s[u] == 0.0) && !(d2s[u] > bound);
+                const bool live = q0 + u < se && !(cj[u] == self && d2s[u] == 0.0) && !(d2s[u] > bound);
                 todo |= live ? 1u << u : 0u;
             }
             while (todo) {
@@ -332,7 +340,7 @@ __global__ void k_knn(const double *__restrict__ xs, const double *__restrict__ 
         }
     }
     for (int q = 0; q < n; ++q) {
-        indices[(int64_t)i * k + q] = ti[q * bd + t];
+        indices[(int64_t)i * k + q] = unlabel ? unlabel[ti[q * bd + t]] : ti[q * bd + t];
         distances[(int64_t)i * k + q] = sqrt(td[q * bd + t]); // :883
     }
     for (int q = n; q < k; ++q) { // :885-888
@@ -351,9 +359,36 @@ extern "C" int mdh_debug_set_knn_variant(int v)
     return MDH_OK;
 }
 
+namespace mdh {
+// label[q] = key[order[q]] for the cell-sorted atoms, unlabel[key[i]] = i
+__global__ __launch_bounds__(256) void k_knn_labels(const int *__restrict__ order, const int64_t *__restrict__ key, int64_t N,
+                                                    int *__restrict__ label, int *__restrict__ unlabel)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N)
+        return;
+    const int i = order[q];
+    const int64_t kv = key[i];
+    if (kv < 0 || kv >= N) { label[q] = 0; return; } // (not a permutation: memory-safe, rows meaningless)
+    label[q] = (int)kv;
+    unlabel[kv] = i;
+}
+} // namespace mdh
+
 extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                        const double *origin3, const int *boundary3, int k, int *indices, double *distances, int space,
                        void *stream)
+{
+    return mdh_knn_keyed(x, y, z, N, box9, origin3, boundary3, k, indices, distances, nullptr, space, stream);
+}
+
+// key (N) i64, a PERMUTATION of 0 .. N-1, or NULL: the number every atom has in another numbering of the same system (the
+// original index of every atom of a cell-sorted copy, mdh_spatial_sort).  Exact ties in distance are then ordered by key instead
+// of by index — the rows are the rows mdh_knn gives for the system in the key's numbering, listed neighbour for listed
+// neighbour (a perfect lattice is all ties: WHICH four of bcc's six second neighbours are among the twelve nearest depends on it).
+extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                             const double *origin3, const int *boundary3, int k, int *indices, double *distances,
+                             const int64_t *key, int space, void *stream)
 {
     if (N < 0 || N >= 2147483647LL || k <= 0 || k > 64) { set_error("mdh_knn: need 1 <= k <= 64"); return MDH_ERR_ARG; }
     DBox b;
@@ -421,6 +456,16 @@ extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_
     cg.g.rc_inv = 0.0;
     cg.g.mode = 1;
     MDH_TRY(build_cell_grid(sc, wx, wy, wz, N, bg, false, false, cg));
+    int *label = nullptr, *unlabel = nullptr;
+    if (key) {
+        const int64_t *dkey = sc.stage_in(key, (size_t)N, space);
+        label = sc.alloc_n<int>((size_t)N);
+        unlabel = sc.alloc_n<int>((size_t)N);
+        if (sc.failed())
+            return sc.error();
+        MDH_HIP(hipMemsetAsync(unlabel, 0, sizeof(int) * (size_t)N, st));
+        hipLaunchKernelGGL(k_knn_labels, dim3(grid_for(N, 256)), dim3(256), 0, st, cg.order, dkey, N, label, unlabel);
+    }
 
     // the near kernel (list in registers) where it applies, then the general kernel on what it listed; larger k: the general
     // kernel for every query
@@ -433,8 +478,8 @@ extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_
         const dim3 grid(grid_for(N, 256)), block(256);
 #define MDH_KNN_NEAR(K)                                                                                                                   \
     do {                                                                                                                                  \
-        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo); \
-        else hipLaunchKernelGGL((k_knn_near<false, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo); \
+        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel); \
+        else hipLaunchKernelGGL((k_knn_near<false, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel); \
     } while (0)
         if (k <= 12) MDH_KNN_NEAR(12);
         else if (k <= 14) MDH_KNN_NEAR(14);
@@ -446,9 +491,9 @@ extern "C" int mdh_knn(const double *x, const double *y, const double *z, int64_
     while (bd > 64 && (size_t)bd * k * 12 > 65536) bd -= 64;
     const size_t lds = (size_t)bd * k * 12;
     if (b.tri)
-        hipLaunchKernelGGL(k_knn<true>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo);
+        hipLaunchKernelGGL(k_knn<true>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel);
     else
-        hipLaunchKernelGGL(k_knn<false>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo);
+        hipLaunchKernelGGL(k_knn<false>, dim3(grid_for(N, bd)), dim3(bd), lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel);
     MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }

@@ -53,5 +53,9 @@ class NearestNeighbor:
         rows = frame.shape[0]
         self.indices_py = empty((rows, self.k), np.int32)
         self.distances_py = empty((rows, self.k), np.float64)
+        # a frame that is a cell-sorted copy of another (System's twin) carries the original index of its atoms: exact ties in
+        # distance are then ordered as they are in the original system (which neighbours of a perfect lattice are listed depends on it)
+        key = getattr(frame, "order_key", None) if frame is self.data else None
+        extra = {} if key is None else {"key": key}
         kernels.fast_knn.knn(*policy.positions(frame), *policy.box_args(cell), self.k, self.indices_py, self.distances_py,
-                             get_num_threads())
+                             get_num_threads(), **extra)

@@ -283,6 +283,7 @@ class System:
                 hit = cache[cname] = (src, PermutedColumn(src, perm))
             cols[cname] = hit[1]
         twin._frame = Frame(cols)
+        twin._frame.order_key = twin._order_key  # (what a k-nearest search on this frame breaks exact ties by: knn.py)
         before = {cname: twin._frame[cname] for cname in twin._frame.columns}
         result = getattr(twin, name)(*args, **kwargs)
         # per-atom results: columns the call added or replaced, back in this system's order

@@ -125,8 +125,19 @@ rdf = _mod(
         O._rdf_streaming(_np(x), _np(y), _np(z), _np(t), box, origin, boundary, g, rc, nbin, NT),
 )
 wcp = _mod(get_wcp=lambda v, nn, t, Nt, W, num_t=1: O.get_wcp(_np(v), _np(nn), _np(t), Nt, W, NT))
-fast_knn = _mod(knn=lambda x, y, z, box, origin, boundary, k, idx, dist, num_t=1:
-                O.knn(_np(x), _np(y), _np(z), box, origin, boundary, k, idx, dist, NT))
+def _knn(x, y, z, box, origin, boundary, k, idx, dist, num_t=1, key=None):
+    if key is None:
+        O.knn(_np(x), _np(y), _np(z), box, origin, boundary, k, idx, dist, NT)
+        return
+    # ties by key: the search in the key's numbering, rows and entries mapped back
+    perm, (xs, ys, zs) = _keyed(key, x, y, z)
+    ik, dk = np.empty_like(idx), np.empty_like(dist)
+    O.knn(xs, ys, zs, box, origin, boundary, k, ik, dk, NT)
+    idx[perm] = np.where(ik >= 0, perm[np.clip(ik, 0, None)], ik)
+    dist[perm] = dk
+
+
+fast_knn = _mod(knn=_knn)
 ptm = _mod(get_ptm=lambda st, x, y, z, box, origin, boundary, v, t, thr, out, ind, num_t=1:
            O.get_ptm(st, _np(x), _np(y), _np(z), box, origin, boundary, _np(v), _np(t), thr, out, ind, NT))
 aja = _mod(compute_aja=lambda x, y, z, box, origin, boundary, v, d, out, num_t=1:

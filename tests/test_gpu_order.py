@@ -128,3 +128,53 @@ def test_lattice_ordered_system_gets_no_twin():
     s = mp.System(pos=pos, box=box)
     s.cal_common_neighbor_analysis(rc=0.854 * 3.615)
     assert s._spatial() is None and int((s.data["cna"].to_numpy() == 1).sum()) == s.N
+
+
+@pytest.mark.parametrize("kind,k", [("bcc", 12), ("fcc", 18), ("bcc", 14), ("fcc", 8)])
+def test_keyed_knn_breaks_exact_ties_as_the_original_numbering_does(kind, k):
+    """a perfect lattice is all ties: WHICH of bcc's six second neighbours are among the twelve nearest, and in which order equal
+    distances are listed, is decided by atom number (knn.hip).  The search on a permuted copy with key = original number must
+    give the original system's rows, neighbour for neighbour (what the twin's k-nearest analyses rest on)."""
+    pos, box = lattice_positions(kind, 3.2, 9, 8, 7)
+    x, y, z = (np.ascontiguousarray(pos[:, c]) for c in range(3))
+    N = len(x)
+    ref_i, ref_d = np.zeros((N, k), np.int32), np.zeros((N, k))
+    _fast_knn.knn(x, y, z, np.asarray(box, float), ORG0, PBC, k, ref_i, ref_d, 1)
+    perm = np.random.default_rng(5).permutation(N)
+    xs, ys, zs = x[perm].copy(), y[perm].copy(), z[perm].copy()
+    for dev in (False, True):
+        got_i, got_d = np.zeros((N, k), np.int32), np.zeros((N, k))
+        args = [HArray.from_numpy(a) for a in (xs, ys, zs)] if dev else [xs, ys, zs]
+        key = HArray.from_numpy(perm.astype(np.int64)) if dev else perm.astype(np.int64)
+        out_i = HArray.from_numpy(got_i) if dev else got_i
+        out_d = HArray.from_numpy(got_d) if dev else got_d
+        _fast_knn.knn(*args, np.asarray(box, float), ORG0, PBC, k, out_i, out_d, 1, key=key)
+        rows, dist, _ = _order.translate_rows(as_numpy(out_i), as_numpy(out_d), None, perm.astype(np.int32))
+        assert np.array_equal(as_numpy(dist), ref_d)
+        assert np.array_equal(as_numpy(rows), ref_i)
+    # without the key the permuted copy lists other neighbours among the ties (that is what the key is for)
+    plain_i, plain_d = np.zeros((N, k), np.int32), np.zeros((N, k))
+    _fast_knn.knn(xs, ys, zs, np.asarray(box, float), ORG0, PBC, k, plain_i, plain_d, 1)
+    assert not np.array_equal(_order.translate_rows(plain_i, plain_d, None, perm.astype(np.int32))[0], ref_i)
+
+
+def test_perfect_lattice_through_the_twin_equals_the_plain_path():
+    pos, box = lattice_positions("bcc", 3.2, 12, 11, 10)
+    pos = pos[np.random.default_rng(9).permutation(len(pos))]
+    cols = {}
+    for mode in ("0", "1"):
+        os.environ["MDAPY_SPATIAL_SORT"] = mode
+        try:
+            s = mp.System(pos=pos, box=box)
+        finally:
+            del os.environ["MDAPY_SPATIAL_SORT"]
+        s.cal_steinhardt_bond_orientation([4, 6], nnn=12, wl=True)
+        s.cal_centro_symmetry_parameter(8)
+        s.cal_common_neighbor_analysis()
+        s.cal_ackland_jones_analysis()
+        s.cal_polyhedral_template_matching(return_rmsd=True)
+        cols[mode] = {c: s.data[c].to_numpy() for c in s.data.columns if c not in "xyz"}
+        cols[mode]["rows"] = np.asarray(s.verlet_list)
+        assert (s._spatial() is not None) == (mode == "1")
+    for c in cols["0"]:
+        assert np.array_equal(cols["0"][c], cols["1"][c], equal_nan=True), c

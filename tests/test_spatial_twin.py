@@ -116,3 +116,21 @@ def test_twin_follows_data_and_box_changes(oracle_backend, monkeypatch):
     # a list the user put there himself is not the twin's: the plain path takes over
     s.verlet_list = as_numpy(s.verlet_list).copy()
     assert s._twin_for("cal_common_neighbor_parameter", (3.2,), {}) is None
+
+
+def test_perfect_lattice_ties_fall_as_in_the_original_numbering(oracle_backend, monkeypatch):
+    """a perfect bcc lattice: the twelve nearest of an atom are its eight first neighbours and FOUR of its six second ones — which
+    four, the search decides by atom number; the twin's searches carry the original numbers as their tie-breaking key"""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MDAPY_SPATIAL_SORT", mode)
+        pos, box = lattice_positions("bcc", 3.2, 6, 5, 5)
+        pos = pos[np.random.default_rng(2).permutation(len(pos))]
+        s = mp.System(pos=pos, box=box)
+        s.cal_steinhardt_bond_orientation([4, 6], nnn=12)
+        s.cal_centro_symmetry_parameter(8)
+        s.build_nearest_neighbor(12)
+        out[mode] = (s, as_numpy(s.verlet_list).copy())
+    assert out["0"][0]._spatial() is None and out["1"][0]._spatial() is not None
+    assert np.array_equal(out["0"][1], out["1"][1])
+    _same_columns(out["0"][0], out["1"][0], ["ql4", "ql6", "csp"])
