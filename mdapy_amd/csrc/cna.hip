@@ -115,21 +115,36 @@ __global__ __launch_bounds__(256) void k_fcna(const double *__restrict__ x, cons
 // 2.5 rc from the first after the fold), goes to the to-do list and is finished by the GENERIC kernel with
 // the reference's expression — labels are the reference's, and no double-precision copy of the positions stays in registers
 // (36 instead of 72: the round-2 attempt kept both and lost to the register file).
-template <int NN, bool TRI = false>
+// position of atom j from the caller's three arrays, or from ONE 32-byte record (pos != nullptr: a neighbour is then two 16-byte
+// requests in one sector instead of three 8-byte ones in three — the difference between 0.55 and 6.7 ms on a frame whose atoms
+// come in no spatial order, where every gather is an HBM access)
+struct PosSource {
+    const double *__restrict__ x, *__restrict__ y, *__restrict__ z;
+    const Pos4 *__restrict__ pos; // nullptr: the three arrays
+    __device__ __forceinline__ void get(int j, double &a, double &b_, double &c) const
+    {
+        if (pos) { const Pos4 p = pos[j]; a = p.x; b_ = p.y; c = p.z; }
+        else { a = x[j]; b_ = y[j]; c = z[j]; }
+    }
+};
+template <int NN, bool TRI = false, bool REC = false>
 __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__restrict__ x, const double *__restrict__ y,
                                              const double *__restrict__ z, const int (&ids)[NN], float negc, float W, double reach,
-                                             unsigned short *lds_col)
+                                             unsigned short *lds_col, const Pos4 *__restrict__ pos = nullptr)
 {
     float ux[NN], uy[NN], uz[NN];
     const int j0 = ids[0];
-    const double x0 = x[j0], y0 = y[j0], z0 = z[j0];
+    const PosSource src{x, y, z, REC ? pos : nullptr};
+    double x0, y0, z0;
+    src.get(j0, x0, y0, z0);
     ux[0] = 0.f; uy[0] = 0.f; uz[0] = 0.f;
     // the plain differences first: away from the periodic faces (nearly every wavefront) nobody needs an image
     float big = 0.f;
 #pragma unroll
     for (int a = 1; a < NN; ++a) {
-        const int j = ids[a];
-        ux[a] = (float)(x[j] - x0); uy[a] = (float)(y[j] - y0); uz[a] = (float)(z[j] - z0);
+        double xa, ya, za;
+        src.get(ids[a], xa, ya, za);
+        ux[a] = (float)(xa - x0); uy[a] = (float)(ya - y0); uz[a] = (float)(za - z0);
         big = fmaxf(big, fmaxf(fabsf(ux[a]), fmaxf(fabsf(uy[a]), fabsf(uz[a]))));
     }
     const float reachf = (float)reach;
@@ -137,8 +152,9 @@ __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__rest
         bool ok = true;
 #pragma unroll
         for (int a = 1; a < NN; ++a) {
-            const int j = ids[a];
-            double dx = x[j] - x0, dy = y[j] - y0, dz = z[j] - z0;
+            double dx, dy, dz;
+            src.get(ids[a], dx, dy, dz);
+            dx -= x0; dy -= y0; dz -= z0;
             // (the reference's fold for ANY image number — pbc_axis: two exact thresholds for -1 / 0 / 1, the division beyond — so
             // that an unwrapped trajectory frame, every atom whole box lengths away from its neighbours' raw coordinates, stays in
             // this kernel: with the thresholds alone all 10 M atoms of such a frame went to the double-precision to-do kernel, 5.9 ms)
@@ -192,13 +208,15 @@ __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__rest
 // Held to 128 VGPRs (four waves per SIMD): the few spills that costs (the 14-neighbour branch) are cheaper than three waves;
 // at 96 VGPRs the pair tests spill and the kernel is a third slower.  (One kernel per list length — no spills at 128 — pays
 // a second pass over nn: measured 0.57 against 0.54 ms.)
-template <bool TRI>
+template <bool TRI, bool REC = false>
 __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ x, const double *__restrict__ y,
                                                      const double *__restrict__ z, int64_t N, DBox b,
                                                      const int *__restrict__ verlet, int64_t M, const int *__restrict__ nn,
                                                      int *__restrict__ pattern, float negc, float W, double reach,
-                                                     int *__restrict__ todo)
+                                                     int *__restrict__ todo, const Pos4 *__restrict__ pos = nullptr,
+                                                     const int *__restrict__ use_pos = nullptr)
 {
+    if (REC && use_pos && *use_pos == 0) pos = nullptr; // (the rows name neighbours close by in memory: the records were not packed)
     __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
@@ -221,12 +239,12 @@ __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ 
         }
 #pragma unroll
         for (int a = 0; a < 12; ++a) ids[a] = safe_id(ids[a], i, N);
-        t = fcna_atom_f32<12, TRI>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
+        t = fcna_atom_f32<12, TRI, REC>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x, pos);
     } else if (n == 14 && M >= 14) {
         int ids[14];
 #pragma unroll
         for (int a = 0; a < 14; ++a) ids[a] = safe_id(row[a], i, N);
-        t = fcna_atom_f32<14, TRI>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x);
+        t = fcna_atom_f32<14, TRI, REC>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x, pos);
     }
     if (t > 0) pattern[i] = t;
     else if (t < 0) defer(todo, i);
@@ -578,13 +596,51 @@ __global__ __launch_bounds__(256) void k_fill_int(int *__restrict__ p, int64_t n
     if (i < n) p[i] = v;
 }
 
+// Do the rows name neighbours that are far away in MEMORY (an id-sorted dump of a diffused system, a shuffled frame)?  One
+// workgroup samples 1 024 rows: a first neighbour more than N / 16 atoms away from its atom counts as far; more than a quarter far
+// -> *flag = 1: the CNA packs the positions into 32-byte records first (k_pack_positions_if) and gathers those — one HBM sector
+// per neighbour instead of three: 6.6 -> 2.3 ms at 10 M shuffled atoms; on a spatial order the records would cost 0.15 ms more
+// than they save and are not made (profiles/r05_fcna_records.txt).
+__global__ __launch_bounds__(1024) void k_rows_far_flag(const int *__restrict__ verlet, const int *__restrict__ nn, int64_t N, int64_t M,
+                                                        int *__restrict__ flag)
+{
+    // (one sample per thread: the two dependent loads of all 1 024 samples are in flight together — 16 samples per thread of a
+    // 256-thread workgroup took 25 us of the call)
+    __shared__ int s_far, s_seen;
+    if (threadIdx.x == 0) { s_far = 0; s_seen = 0; }
+    __syncthreads();
+    const int64_t step = N / 1024 > 0 ? N / 1024 : 1;
+    const int64_t i = (int64_t)threadIdx.x * step;
+    bool seen = false, far = false;
+    if (i < N && nn[i] > 0) {
+        const int64_t j = verlet[i * M];
+        if (j >= 0 && j < N) {
+            seen = true;
+            const int64_t d = j > i ? j - i : i - j;
+            far = d > N / 16 && N - d > N / 16; // (far either way round the index range: periodic neighbours of the last plane)
+        }
+    }
+    const unsigned long long ms = __ballot(seen), mf = __ballot(far);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_seen, __popcll(ms)); atomicAdd(&s_far, __popcll(mf)); }
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = (s_seen >= 64 && 4 * s_far > s_seen) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_pack_positions_if(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                           int64_t N, Pos4 *__restrict__ out, const int *__restrict__ flag)
+{
+    if (*flag == 0)
+        return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = Pos4{x[i], y[i], z[i], 0.0};
+}
+
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
-                     int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done)
+                     int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done, const Pos4 *pos, const int *use_pos)
 {
     dim3 grid(grid_for(N, 256)), block(256);
     // single-precision pair tests where the neighbourhood of an atom cannot reach its own image (|u_c - u_a| <= 5 rc < L / 2;
     // triclinic boxes: the perpendicular thickness along every periodic vector)
-    bool f32 = rc > 1e-12 && rc < 1e12 && g_fcna_variant == 0;
+    bool f32 = rc > 1e-12 && rc < 1e12 && (g_fcna_variant == 0 || g_fcna_variant == 2 || g_fcna_variant == 3);
     for (int d = 0; d < 3; ++d)
         if (b.pbc[d] && !((b.tri ? b.thick[d] : b.h[d * 4]) >= 10.01 * rc)) f32 = false;
     if (f32) {
@@ -595,8 +651,11 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
         const double want = (rcsq - (double)c) + tol;
         float W = (float)want;
         while ((double)W < want) W = std::nextafterf(W, INFINITY);
-        if (b.tri) hipLaunchKernelGGL(k_fcna_f32<true>, grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo);
-        else hipLaunchKernelGGL(k_fcna_f32<false>, grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo);
+        if (pos) {
+            if (b.tri) hipLaunchKernelGGL((k_fcna_f32<true, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo, pos, use_pos);
+            else hipLaunchKernelGGL((k_fcna_f32<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo, pos, use_pos);
+        } else if (b.tri) hipLaunchKernelGGL((k_fcna_f32<true, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo, pos);
+        else hipLaunchKernelGGL((k_fcna_f32<false, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, -c, W, 2.5 * rc, todo, pos);
     } else if (b.tri) {
         hipLaunchKernelGGL((k_fcna<true, false>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo); // (defers nothing)
         return;
@@ -691,7 +750,25 @@ int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const
     if (!done) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
     {
         ProfRange pr("k_fcna", st);
-        launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo, done);
+        // the neighbours' positions from 32-byte records when the rows say that neighbours are far away in memory (decided on the
+        // device, k_rows_far_flag; systems of 2^18 atoms and more: below that everything is an L2 hit anyway).  g_fcna_variant 2: always
+        // records, 3: never (A/B, tools/fcna_rec_ab.py)
+        const Pos4 *pos = nullptr;
+        int *use_pos = nullptr;
+        if (g_fcna_variant == 2) {
+            pos = pack_positions(sc, dx, dy, dz, N);
+        } else if (g_fcna_variant == 0 && N >= (int64_t(1) << 18)) {
+            Pos4 *rec = sc.alloc_n<Pos4>((size_t)N);
+            use_pos = sc.alloc_n<int>(1);
+            if (sc.failed())
+                return sc.error();
+            hipLaunchKernelGGL(k_rows_far_flag, dim3(1), dim3(1024), 0, st, dv, dn, N, M, use_pos);
+            hipLaunchKernelGGL(k_pack_positions_if, dim3(std::min<unsigned>(grid_for(N, 256), 4096u)), dim3(256), 0, st, dx, dy, dz, N, rec, use_pos); // (a small grid: it leaves at once when the flag is down)
+            pos = rec;
+        }
+        if (sc.failed())
+            return sc.error();
+        launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo, done, pos, use_pos);
     }
     if (done) sc.keep_confirm(done);
     if (g_track_counters && g_todo_probe)

@@ -123,7 +123,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
 // (todo[0] = count, device side) with the reference expression
 // done != nullptr: todo sits in a kept block (Scope::KEEP_TODO) — the kernel that walks the list clears its counters when it leaves
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
-                     int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done = nullptr);
+                     int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done = nullptr, const Pos4 *pos = nullptr, const int *use_pos = nullptr);
 void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
                         int64_t M, const int *nn, int *pattern, double rc, int *todo);
 
