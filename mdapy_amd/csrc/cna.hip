@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void k_fill_int(int *__restrict__ p, int64_t n
 
 // Do the rows name neighbours that are far away in MEMORY (an id-sorted dump of a diffused system, a shuffled frame)?  One
 // workgroup samples 1 024 rows: a first neighbour more than N / 16 atoms away from its atom counts as far; more than a quarter far
-// -> *flag = 1: the CNA packs the positions into 32-byte records first (k_pack_positions_if) and gathers those — one HBM sector
+// -> *flag = 1 (a word of pinned host memory, order_hint()): the NEXT calls with this (N, M) pack the positions into 32-byte records
+// first and gather those — one HBM sector
 // per neighbour instead of three: 6.6 -> 2.3 ms at 10 M shuffled atoms; on a spatial order the records would cost 0.15 ms more
 // than they save and are not made (profiles/r05_fcna_records.txt).
 __global__ __launch_bounds__(1024) void k_rows_far_flag(const int *__restrict__ verlet, const int *__restrict__ nn, int64_t N, int64_t M,
@@ -625,15 +626,6 @@ __global__ __launch_bounds__(1024) void k_rows_far_flag(const int *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) *flag = (s_seen >= 64 && 4 * s_far > s_seen) ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_pack_positions_if(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                                                           int64_t N, Pos4 *__restrict__ out, const int *__restrict__ flag)
-{
-    if (*flag == 0)
-        return;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = Pos4{x[i], y[i], z[i], 0.0};
-}
-
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
                      int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done, const Pos4 *pos, const int *use_pos)
 {
@@ -750,21 +742,19 @@ int mdh_fcna(const double *x, const double *y, const double *z, int64_t N, const
     if (!done) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
     {
         ProfRange pr("k_fcna", st);
-        // the neighbours' positions from 32-byte records when the rows say that neighbours are far away in memory (decided on the
-        // device, k_rows_far_flag; systems of 2^18 atoms and more: below that everything is an L2 hit anyway).  g_fcna_variant 2: always
-        // records, 3: never (A/B, tools/fcna_rec_ab.py)
+        // the neighbours' positions from 32-byte records when the rows say that neighbours are far away in memory (k_rows_far_flag;
+        // systems of 2^18 atoms and more: below that everything is an L2 hit anyway).  g_fcna_variant 2: always records, 3: never
+        // (A/B, tools/fcna_rec_ab.py)
         const Pos4 *pos = nullptr;
         int *use_pos = nullptr;
         if (g_fcna_variant == 2) {
             pos = pack_positions(sc, dx, dy, dz, N);
         } else if (g_fcna_variant == 0 && N >= (int64_t(1) << 18)) {
-            Pos4 *rec = sc.alloc_n<Pos4>((size_t)N);
-            use_pos = sc.alloc_n<int>(1);
-            if (sc.failed())
-                return sc.error();
-            hipLaunchKernelGGL(k_rows_far_flag, dim3(1), dim3(1024), 0, st, dv, dn, N, M, use_pos);
-            hipLaunchKernelGGL(k_pack_positions_if, dim3(std::min<unsigned>(grid_for(N, 256), 4096u)), dim3(256), 0, st, dx, dy, dz, N, rec, use_pos); // (a small grid: it leaves at once when the flag is down)
-            pos = rec;
+            // (the answer of the last sample of this (N, M) — a word of pinned host memory, read without waiting; sampled on the first
+            // and every eighth call: a call pays nothing for the question)
+            const OrderHint h = order_hint(2, N, M, dx); // (keyed by the positions: the order of the atoms is what the question is about)
+            if (h.word && *(volatile int *)h.word != 0) pos = pack_positions(sc, dx, dy, dz, N);
+            if (h.word && h.sample) hipLaunchKernelGGL(k_rows_far_flag, dim3(1), dim3(1024), 0, st, dv, dn, N, M, h.word);
         }
         if (sc.failed())
             return sc.error();

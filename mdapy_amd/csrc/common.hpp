@@ -188,6 +188,14 @@ class Scope {
 
 void reset_kept_blocks(int tag); // runtime.hip
 
+// A word of pinned host memory per (tag, a, b, array) signature — a shape and the device array the question is about — that a sampling
+// kernel of some call writes and the NEXT calls with the same signature read on the host without waiting for anything; a new array of a
+// known shape starts from the latest answer for that shape ("do this system's atoms come in a spatial order?", "do these rows name
+// neighbours far away in memory?").  A stale or missing answer costs speed, never correctness: both ways of doing the work give
+// the same result.  sample: true on the first and every eighth call of the signature — the caller launches its sampling kernel then.
+struct OrderHint { int *word; bool sample; };
+OrderHint order_hint(int tag, int64_t a, int64_t b, const void *array); // runtime.hip; word == nullptr if pinned memory could not be had
+
 // Positions as one 32-byte record per atom (x, y, z, unused): a neighbour's position is then two 16-byte requests instead of
 // three 8-byte ones — the list consumers that gather 12 - 18 neighbours per atom are bound by the number of lane requests their
 // gathers make (about two cycles each in the CU's address unit), not by bytes.  Packed into scratch at the start of a call:

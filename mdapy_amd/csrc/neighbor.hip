@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ x, co
     if (n_binned && p >= *n_binned) // a windowed build that dropped atoms outside its window: order[] ends at the atoms binned
         return;
     const int i = order[p];
+
     const double a = x[i], b = y[i], c = z[i];
     // the image codes are a fourth scattered read per atom (one byte each); k_assign says whether any of them is not neutral
     const unsigned short m = *any_code ? mv[i] : (unsigned short)img::ATOM_NEUTRAL;
@@ -599,6 +600,36 @@ int neighbor_grid_dims(const DBox &b, double rc, Grid &g)
     return MDH_OK;
 }
 
+// Do the atoms come in a spatial order?  One workgroup samples 1 024 pairs of consecutive atoms (i, i+1): far = more than two
+// bins of ~64 atoms apart along some axis (fractional coordinates, periodic axes wrapped); more than a quarter far -> *flag = 1 (a word
+// of pinned host memory, order_hint()): the NEXT builds of this (N, grid) move whole 32-byte records (k_assign writes them in input
+// order, the gather reads one random sector per atom instead of three or four: 598 -> ~250 us at 10 M shuffled atoms).  A lattice
+// builder's order, a file written cell by cell, a sorted copy: 0.  Launched on the first and every eighth build of a signature.
+__global__ __launch_bounds__(1024) void k_order_far_flag(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                         int64_t N, DBox b, double nb0, double nb1, double nb2, int *__restrict__ flag)
+{
+    __shared__ int s_far;
+    if (threadIdx.x == 0) s_far = 0;
+    __syncthreads();
+    const int64_t step = (N - 1) / 1024 > 0 ? (N - 1) / 1024 : 1;
+    const int64_t i = (int64_t)threadIdx.x * step;
+    bool far = false;
+    if (i + 1 < N) {
+        const double dx = x[i + 1] - x[i], dy = y[i + 1] - y[i], dz = z[i + 1] - z[i];
+        double f[3] = {dx * b.hi[0] + dy * b.hi[3] + dz * b.hi[6], dx * b.hi[1] + dy * b.hi[4] + dz * b.hi[7], dx * b.hi[2] + dy * b.hi[5] + dz * b.hi[8]};
+        const double nb[3] = {nb0, nb1, nb2};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (b.pbc[d]) f[d] -= rint(f[d]);
+            far = far || !(fabs(f[d]) * nb[d] <= 2.0); // (NaN counts as far)
+        }
+    }
+    const unsigned long long m = __ballot(far);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_far, __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = 4 * s_far > 1024 ? 1 : 0;
+}
+
 int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z, int64_t N, const DBox &b,
                     bool wrap_first, bool sort_desc, CellGrid &cg, const int64_t *sort_key, bool packed, bool scattered)
 {
@@ -620,8 +651,15 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     cg.pk = nullptr;
     // scattered (with packed): the caller knows that the atoms come in no spatial order
     CellGrid::Packed *rec = nullptr;
+    int *rec_flag = nullptr;
     if (packed) {
         cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
+        // records: always for a caller that knows (scattered); for a large system otherwise when the last sample of this (N, grid) said so
+        if (!scattered && N >= (int64_t(1) << 18)) {
+            const OrderHint h = order_hint(1, N, g.ncell, x);
+            scattered = h.word && *(volatile int *)h.word != 0;
+            if (h.word && h.sample) rec_flag = h.word;
+        }
         if (scattered) rec = sc.alloc_n<CellGrid::Packed>((size_t)N);
     } else {
         cg.xs = sc.alloc_n<double>((size_t)N);
@@ -671,6 +709,14 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         if (!g_window_violations) MDH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_window_violations), sizeof(int), hipHostMallocDefault));
         *g_window_violations = 0;
         win.bad = g_window_violations;
+    }
+    if (rec_flag) {
+        const double *h = b.h;
+        const double vol = std::fabs(h[0] * (h[4] * h[8] - h[5] * h[7]) - h[1] * (h[3] * h[8] - h[5] * h[6]) + h[2] * (h[3] * h[7] - h[4] * h[6]));
+        const double edge = std::cbrt(64.0 * vol / (double)N);
+        double nb[3];
+        for (int d = 0; d < 3; ++d) nb[d] = std::max(1.0, std::floor(b.thick[d] / edge));
+        hipLaunchKernelGGL(k_order_far_flag, dim3(1), dim3(1024), 0, st, x, y, z, N, b, nb[0], nb[1], nb[2], rec_flag);
     }
     const unsigned gen = next_scan_gen(); // stamps of this build's k_assign; the (first) scan below is launched with the same value
     if (b.tri)
