@@ -45,6 +45,10 @@ weak_trace)
   python tools/timeline.py $O/r05_weak k_slab_messages 2 | tee $O/r05_weak.txt ;;
 halo)   # weak scaling: a 136^3-cell slab of 8 with its halo in loop-back against the undivided 136^3 box
   python tools/halo_cost.py 136 8 2>&1 | clean | tee $O/r05_halo_cost.txt ;;
+analyses)   # configs 2 and 4 at full size through System under the kernel trace
+  prof analyses python $R/tools/profile_analyses.py c3 c5 ;;
+twin)
+  python tools/twin_probe.py 136 2>&1 | clean | tee $O/r05_twin_probe.txt ;;
 tests_new)
   timeout 1500 python -m pytest tests/test_gpu_order.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -15 ;;
 tests_dist)

@@ -57,7 +57,6 @@ for tag, cols in (("ordered", (x, y, z)), ("shuffled", (xs_, ys_, zs_))):
     print("   twin:", s._spatial() is not None, " fcc:", int((s.data["cna"].to_numpy() == 1).sum()) == n)
 
 # the bench's form of the same step: a NEW System per step from torch tensors, a few steps, after the C-ABI step on the same columns
-import cProfile, pstats
 v = torch.empty((n, M), dtype=torch.int32, device=dev); d = torch.empty((n, M), dtype=torch.float64, device=dev)
 nn = torch.empty((n,), dtype=torch.int32, device=dev); pat = torch.zeros((n,), dtype=torch.int32, device=dev)
 for _ in range(3):
@@ -70,12 +69,8 @@ def bench_like():
 for _ in range(2):
     out = bench_like()
 torch.cuda.synchronize()
-pr = cProfile.Profile()
 t0 = time.perf_counter()
-pr.enable()
 for _ in range(5):
     out = bench_like()
 torch.cuda.synchronize()
-pr.disable()
-print(f"bench-like shuffled System step: {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms")
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+print(f"a NEW System per step from the shuffled columns (the bench's extra.shuffled_ids.system_path): {(time.perf_counter() - t0) / 5 * 1e3:.3f} ms")
