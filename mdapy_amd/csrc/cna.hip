@@ -218,7 +218,12 @@ __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ 
 {
     if (REC && use_pos && *use_pos == 0) pos = nullptr; // (the rows name neighbours close by in memory: the records were not packed)
     __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware order of the workgroups (workgroup b runs on XCD b % 8): every XCD takes ONE contiguous eighth of the atoms, so that
+    // the neighbours its waves gather — a few atoms, rows and planes away in a spatial order — are lines its own L2 has just seen,
+    // not lines seven other L2s fetch as well (the grid is rounded up to a multiple of eight workgroups)
+    const int64_t per = gridDim.x >> 3;
+    const int64_t vb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int64_t i = vb * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
     const int n = nn[i];
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(1024) void k_rows_far_flag(const int *__restrict__ 
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
                      int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done, const Pos4 *pos, const int *use_pos)
 {
-    dim3 grid(grid_for(N, 256)), block(256);
+    dim3 grid((unsigned)((grid_for(N, 256) + 7) & ~7)), block(256); // (a multiple of eight: k_fcna_f32's XCD-aware workgroup order)
     // single-precision pair tests where the neighbourhood of an atom cannot reach its own image (|u_c - u_a| <= 5 rc < L / 2;
     // triclinic boxes: the perpendicular thickness along every periodic vector)
     bool f32 = rc > 1e-12 && rc < 1e12 && (g_fcna_variant == 0 || g_fcna_variant == 2 || g_fcna_variant == 3);
