@@ -20,10 +20,11 @@
 // list in registers; the queries it cannot prove go to k_knn through a to-do list.
 #include "common.hpp"
 #include "grid.hpp"
+#include <cstring>
 
 namespace mdh {
 
-int g_knn_variant = 0; // 0 = near kernel + general kernel, 1 = general kernel only (tests, A/B)
+int g_knn_variant = 0; // 0 = near kernel + general kernel, 1 = general kernel only (tests, A/B), 3 = counting kernel first (measuring variant)
 
 struct KnnGeom {
     int nim[3];    // images per axis (0 on open axes)
@@ -75,14 +76,20 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
                                                   const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg, Grid g,
                                                   KnnGeom kg, int k, int *__restrict__ indices,
                                                   double *__restrict__ distances, int *__restrict__ todo,
-                                                  const int *__restrict__ label, const int *__restrict__ unlabel)
+                                                  const int *__restrict__ label, const int *__restrict__ unlabel,
+                                                  const int *__restrict__ listed = nullptr)
 {
     // label / unlabel (both NULL, or both given): candidates are told apart — the self test, the order under exact ties — by
     // label[q] instead of their index order[q], and a listed label L is written as unlabel[L] (mdh_knn_keyed: the labels are the
     // caller's key, a permutation of 0 .. N-1, so that ties fall as they would in the system the key numbers)
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N)
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (listed) { // the queries k_knn_select could not finish (listed[0] of them, positions in the cell-sorted arrays)
+        if (p >= listed[0])
+            return;
+        p = listed[1 + p];
+    } else if (p >= N) {
         return;
+    }
     const int i = order[p];
     const int self = label ? label[p] : i;
     const int *__restrict__ cand = label ? label : order;
@@ -174,6 +181,164 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
             indices[(int64_t)i * k + e] = unlabel ? unlabel[li[e]] : li[e];
             distances[(int64_t)i * k + e] = sqrt(ld[e]); // :883
         }
+}
+
+// The same common case by COUNTING instead of streaming insertion (round 5) — A MEASURING VARIANT (mdh_debug_set_knn_variant(3),
+// tools/knn_ab.py -> profiles/r05_knn_counting.txt): rows identical to k_knn_near's, 1.05-1.3x SLOWER; not the product's path.  k_knn_near keeps a sorted list and inserts every
+// candidate that beats its k-th entry: ~14 instructions per list slot per insertion, and a wavefront runs as many insertion rounds per
+// batch of candidates as its busiest lane needs — 35 k wave-instructions per 64 queries at k = 18, 85 % of them insertions.  Here a
+// query walks its 27 cells twice.  Pass 1 counts the candidates inside NT trial radii around the radius a uniform system of this
+// density would need for k neighbours (volume steps of 15 %; none beyond one cell width, inside which the 27 cells are complete).  The
+// smallest radius that holds at least k — and at most KC — candidates is the query's; pass 2 appends exactly those to an unsorted
+// register list (three predicated moves per slot), and every entry finds its place in the row by counting the entries in front of it:
+// the row is written straight from the ranks, no sorted list is ever maintained.  Same candidates, same squared distances, same order
+// under ties (distance, then id or label) as k_knn_near: the rows are identical.  A query with fewer than k candidates inside one cell
+// width, or more than KC inside its radius (shells of a perfect lattice, a surface atom of a cluster whose global density says little),
+// is listed for k_knn_near, whose leftovers go on to k_knn as before.
+// Trial radii as BUCKETS of the squared distance, found without a comparison: the bits of a positive float grow with its value and are
+// a piecewise-linear log2, so bucket(d2) = clamp(mul_hi(bits((float)d2) - base, scale), 0, 7) is a monotone step function of d2 whose
+// steps are ~15 % apart in volume.  Monotone is all that is needed: "every candidate of bucket <= j" is a ball around the query for every j.
+constexpr int KNN_NT = 6; // buckets 0 .. 5 are counted; 6, 7: farther than any trial radius
+struct KnnTrial { int base; unsigned scale; float bound_f; };
+template <bool TRI, int KC>
+__global__ __launch_bounds__(128) void k_knn_select(const double *__restrict__ xs, const double *__restrict__ ys,
+                                                  const double *__restrict__ zs, const int *__restrict__ order,
+                                                  const int *__restrict__ cell_start, int64_t N, DBox b, DBox bg, Grid g,
+                                                  KnnGeom kg, int k, KnnTrial trial, int *__restrict__ indices,
+                                                  double *__restrict__ distances, int *__restrict__ failed,
+                                                  const int *__restrict__ label, const int *__restrict__ unlabel)
+{
+    // the query's list, UNSORTED, in a stripe of LDS (entry e of thread t at [e * 128 + t]: bank = lane): an append is two stores at a
+    // per-lane index, which registers cannot do without a predicated move per slot
+    __shared__ double s_d[KC * 128];
+    __shared__ int s_l[KC * 128];
+    const int t = threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + t;
+    if (p >= N)
+        return;
+    const int i = order[p];
+    const int self = label ? label[p] : i;
+    const int *__restrict__ cand = label ? label : order;
+    const double qx = xs[p], qy = ys[p], qz = zs[p];
+    int c0, c1, c2;
+    cell_coords<TRI>(bg, g, qx, qy, qz, c0, c1, c2);
+    auto fold_cell = [&](int d, int e, int &a, int &m) {
+        m = 0; a = e;
+        if (b.pbc[d]) { m = floordiv(e, g.nc[d]); a = e - m * g.nc[d]; return !(m > kg.nim[d] || m < -kg.nim[d]); }
+        return e >= 0 && e < g.nc[d];
+    };
+    auto bucket_of = [&](double d2, bool real) {
+        const float f = (float)d2;
+        int bk = (int)__umulhi((unsigned)max(__float_as_int(f) - trial.base, 0), trial.scale);
+        bk = min(bk, 7);
+        // beyond one cell width the 27 cells are not complete: such a candidate belongs to no trial radius
+        return (real && f < trial.bound_f) ? bk : 7;
+    };
+    // the walk of k_knn_near (nearest columns first), eight candidates per trip; visit(d2[8], label[8], bucket[8]).  The query itself
+    // (distance 0 in its own cell) is walked like everybody: it is counted, listed and left out when the row is written.
+    auto walk = [&](auto &&visit) {
+        for (int col9 = 0; col9 < 9; ++col9) {
+            const int da = (0x28161 >> (2 * col9) & 3) - 1, db = (0x22215 >> (2 * col9) & 3) - 1;
+            int a0, m0, a1, m1;
+            if (!fold_cell(0, c0 + da, a0, m0) || !fold_cell(1, c1 + db, a1, m1)) continue;
+            const int64_t col = ((int64_t)a0 * g.nc[1] + a1) * g.nc[2];
+            for (int e2 = c2 - 1; e2 <= c2 + 1;) {
+                int a2, m2;
+                if (!fold_cell(2, e2, a2, m2)) { ++e2; continue; }
+                int len = 1;
+                while (e2 + len <= c2 + 1 && a2 + len < g.nc[2]) ++len;
+                double s0, s1, s2;
+                if (TRI) {
+                    s0 = m0 * b.h[0] + m1 * b.h[3] + m2 * b.h[6];
+                    s1 = m0 * b.h[1] + m1 * b.h[4] + m2 * b.h[7];
+                    s2 = m0 * b.h[2] + m1 * b.h[5] + m2 * b.h[8];
+                } else {
+                    s0 = m0 * b.h[0]; s1 = m1 * b.h[4]; s2 = m2 * b.h[8];
+                }
+                const double w0 = qx - s0, w1 = qy - s1, w2 = qz - s2;
+                const int sb = cell_start[col + a2], se = cell_start[col + a2 + len];
+                for (int q0 = sb; q0 < se; q0 += 8) {
+                    double d2s[8];
+                    int cj[8], bk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int q = min(q0 + u, se - 1);
+                        const double dx = xs[q] - w0, dy = ys[q] - w1, dz = zs[q] - w2;
+                        cj[u] = cand[q];
+                        d2s[u] = dx * dx + dy * dy + dz * dz;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) bk[u] = bucket_of(d2s[u], q0 + u < se);
+                    visit(d2s, cj, bk);
+                }
+                e2 += len;
+            }
+        }
+    };
+    // ---- pass 1: candidates per bucket, eight bits each in one register (buckets 0 .. 3) and a second (4, 5; the rest is not counted)
+    unsigned acc0 = 0, acc1 = 0;
+    walk([&](const double (&)[8], const int (&)[8], const int (&bk)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned one = 1u << ((bk[u] & 3) << 3);
+            acc0 += one & (unsigned)((bk[u] - 4) >> 31);                              // bucket < 4
+            acc1 += one & (unsigned)(~((bk[u] - 4) >> 31) & ((bk[u] - 6) >> 31));      // bucket 4 or 5
+        }
+    });
+    // the smallest trial radius with k neighbours and the query itself inside
+    int sel = -1, want = 0, run = 0;
+#pragma unroll
+    for (int j = 0; j < KNN_NT; ++j) {
+        run += (int)(((j < 4 ? acc0 : acc1) >> ((j & 3) << 3)) & 255u);
+        if (sel < 0 && run >= k + 1) { sel = j; want = run; }
+    }
+    if (sel < 0 || want > KC) { // not k inside one cell width, or a shell too full for the list: the insertion kernel
+        failed[1 + atomicAdd(&failed[0], 1)] = (int)p;
+        return;
+    }
+    // ---- pass 2: exactly the candidates of the buckets up to the chosen one, appended as they come
+    int n = 0;
+    walk([&](const double (&d2s)[8], const int (&cj)[8], const int (&bk)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (bk[u] <= sel) {
+                s_d[n * 128 + t] = d2s[u];
+                s_l[n * 128 + t] = cj[u];
+                ++n;
+            }
+    });
+    // ---- every entry's place in the row: the entries in front of it by (squared distance, label); the query itself is taken out
+    double ld[KC];
+    int li[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const bool have = e < n;
+        ld[e] = have ? s_d[e * 128 + t] : __builtin_huge_val();
+        li[e] = have ? s_l[e * 128 + t] : 0x7fffffff;
+    }
+    int rank[KC];
+#pragma unroll
+    for (int e = 0; e < KC; ++e) rank[e] = 0;
+#pragma unroll
+    for (int e = 0; e < KC; ++e)
+#pragma unroll
+        for (int f = e + 1; f < KC; ++f) {
+            const bool f_first = ld[f] < ld[e] || (ld[f] == ld[e] && li[f] < li[e]);
+            rank[e] += f_first ? 1 : 0;
+            rank[f] += f_first ? 0 : 1;
+        }
+    int self_rank = 0x7fffffff; // the query's own entry: label `self` at distance 0 (fast_knn.cpp:641)
+#pragma unroll
+    for (int e = 0; e < KC; ++e)
+        if (e < n && li[e] == self && ld[e] == 0.0) self_rank = min(self_rank, rank[e]);
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const int r = rank[e] - (rank[e] > self_rank ? 1 : 0);
+        if (e < n && rank[e] != self_rank && r < k) {
+            indices[(int64_t)i * k + r] = unlabel ? unlabel[li[e]] : li[e];
+            distances[(int64_t)i * k + r] = sqrt(ld[e]); // :883
+        }
+    }
 }
 
 // top-k lists live in LDS: entry s of thread t at [s * blockDim + t]
@@ -470,16 +635,47 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
     // the near kernel (list in registers) where it applies, then the general kernel on what it listed; larger k: the general
     // kernel for every query
     int *todo = nullptr;
-    if (k <= 24 && kg.rmax >= 1 && g_knn_variant == 0) {
+    if (k <= 24 && kg.rmax >= 1 && (g_knn_variant == 0 || g_knn_variant == 3)) {
         todo = sc.alloc_n<int>((size_t)N + 1);
+        // g_knn_variant 3: the counting kernel first, its leftovers to the insertion kernel (a measuring variant)
+        int *failed = nullptr;
+        const bool select = g_knn_variant == 3 && N >= 32768 && k >= 4; // (measured slower than the insertion kernel alone: a measuring variant, tools/knn_ab.py)
+        if (select) failed = sc.alloc_n<int>((size_t)N + 1);
         if (sc.failed())
             return sc.error();
         MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
         const dim3 grid(grid_for(N, 256)), block(256);
+        const dim3 grid_sel(grid_for(N, 128)), block_sel(128);
+        if (select) {
+            MDH_HIP(hipMemsetAsync(failed, 0, sizeof(int), st));
+            // trial radii: buckets of the squared distance.  Bucket 0 ends at the radius that holds k + 1 atoms in a uniform system of this
+            // density; a step of the bucket number is 2^(0.1344) in d2 = 15 % in volume (float bits: 2^23 per octave)
+            KnnTrial trial;
+            const double r0 = std::cbrt(3.0 * (double)(k + 1) / (4.0 * 3.14159265358979323846 * ((double)N / vol)));
+            const float t0 = (float)(r0 * r0);
+            int t0_bits;
+            std::memcpy(&t0_bits, &t0, sizeof(int));
+            const double step = 0.1344 * 8388608.0; // float-bit units per bucket
+            trial.base = t0_bits - (int)step;       // bits below t0: bucket 0
+            trial.scale = (unsigned)(4294967296.0 / step);
+            const double one_cell = kg.wmin * (1.0 - 1e-9);
+            trial.bound_f = std::nextafterf((float)(one_cell * one_cell), 0.0f); // (below the double bound: "inside one cell width" for sure)
+#define MDH_KNN_SELECT(KC)                                                                                                                \
+    do {                                                                                                                                  \
+        if (b.tri) hipLaunchKernelGGL((k_knn_select<true, KC>), grid_sel, block_sel, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, trial, di, dd, failed, label, unlabel); \
+        else hipLaunchKernelGGL((k_knn_select<false, KC>), grid_sel, block_sel, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, trial, di, dd, failed, label, unlabel); \
+    } while (0)
+            if (k <= 12) MDH_KNN_SELECT(16);
+            else if (k <= 14) MDH_KNN_SELECT(20);
+            else if (k <= 18) MDH_KNN_SELECT(24);
+            else MDH_KNN_SELECT(32);
+#undef MDH_KNN_SELECT
+        }
+        const dim3 grid_near(grid.x); // (behind the counting kernel it walks a list, usually short: the other workgroups leave at once)
 #define MDH_KNN_NEAR(K)                                                                                                                   \
     do {                                                                                                                                  \
-        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel); \
-        else hipLaunchKernelGGL((k_knn_near<false, K>), grid, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel); \
+        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid_near, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel, failed); \
+        else hipLaunchKernelGGL((k_knn_near<false, K>), grid_near, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel, failed); \
     } while (0)
         if (k <= 12) MDH_KNN_NEAR(12);
         else if (k <= 14) MDH_KNN_NEAR(14);
