@@ -54,6 +54,6 @@ python tools/triclinic_sweep.py 100 2>&1 | grep -v amdgpu.ids > $O/r04_triclinic
 python tools/triclinic_sweep.py 100 --open 2>&1 | grep -v amdgpu.ids > $O/r04_open_box_sweep.txt
 for c in 10 20 40; do python tools/host_enqueue.py $c 2>&1 | grep -v amdgpu.ids; done > $O/r04_host_enqueue.txt
 python tools/cold_rdf.py 2>&1 | grep -v amdgpu.ids | grep -v "^ \+[0-9]\+ " > $O/r04_cold_rdf.txt
-bash tools/measure_r04_t.sh 2>&1 | grep -v "^nn hist" > $O/r04_fcna_hot.txt
+# (round 4 ran a one-off script here: fixed-cutoff CNA at sigma 0 / 0.2 / 0.5 under the kernel trace -> r04_fcna_hot.txt; round 5: tools/measure_r05.sh has sections instead)
 tail -4 $O/r04_triclinic_sweep.txt | cut -c1-200
 python tools/triclinic_sweep.py 100 --disorder 2>&1 | grep -v amdgpu.ids > $O/r04_disorder_sweep.txt
