@@ -49,6 +49,12 @@ analyses)   # configs 2 and 4 at full size through System under the kernel trace
   prof analyses python $R/tools/profile_analyses.py c3 c5 ;;
 twin)
   python tools/twin_probe.py 136 2>&1 | clean | tee $O/r05_twin_probe.txt ;;
+counters)   # SQ / traffic counters of the headline step's kernels, four separate --pmc passes (kernel trace only: gpurun's rule)
+  PROBE="python $R/tools/order_probe.py lattice 136 5"
+  tools/pmc_any.sh r05_sq1 "SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" $PROBE | tail -1
+  tools/pmc_any.sh r05_sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" $PROBE | tail -1
+  tools/pmc_any.sh r05_fetch "FETCH_SIZE" $PROBE | tail -1
+  tools/pmc_any.sh r05_write "WRITE_SIZE" $PROBE | tail -1 ;;
 tests_new)
   timeout 1500 python -m pytest tests/test_gpu_order.py tests/test_gpu_distributed.py -x -q -m gpu 2>&1 | tail -15 ;;
 tests_dist)
