@@ -216,9 +216,11 @@ class System:
         if mode == "0":
             return None
         cols = tuple(self._frame[c] for c in ("x", "y", "z"))
-        key = (id(cols[0]), id(cols[1]), id(cols[2]), id(self._cell))
+        # (the twin belongs to THESE column objects and THIS box: the state keeps them alive, so that "the same object" cannot be a
+        # new one at a recycled address)
+        key = (*cols, self._cell)
         state = self.__dict__.get("_twin_state")
-        if state is not None and state[0] == key:
+        if state is not None and len(state[0]) == len(key) and all(a is b for a, b in zip(state[0], key)):
             return state[1]
         twin = None
         from .devarray import have_gpu
@@ -322,9 +324,10 @@ class System:
             self.__dict__.pop("_mirror", None)
             return
         rows, dist, counts = twin.verlet_list, twin.distance_list, twin.neighbor_number
-        state = (id(rows), id(dist), id(counts), twin.__dict__.get("_sorted_columns"))
+        state = (rows, dist, counts, twin.__dict__.get("_sorted_columns", (None, 0))[1])  # (the objects themselves: see _spatial)
         mirror = self.__dict__.get("_mirror")
-        if mirror is None or mirror["state"] != state or self.__dict__.get("verlet_list") is not mirror["rows"]:
+        same = mirror is not None and all(a is b for a, b in zip(mirror["state"][:3], state[:3])) and mirror["state"][3] == state[3]
+        if not same or self.__dict__.get("verlet_list") is not mirror["rows"]:
             perm = twin._perm
             done = {}
 
