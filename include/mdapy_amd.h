@@ -161,7 +161,10 @@ int mdh_build_neighbor(const double *x, const double *y, const double *z, int64_
                        int64_t max_neigh, int fill_pads, int space, void *stream);
 /* The same with an ordering key (multi-GPU extension): inside a cell the atoms are listed by descending key[i]
  * (i64, N) instead of descending index — the reference's rule (neighbor.cpp:97-98) applied to the GLOBAL atom ids of a
- * slab's owned + ghost atoms, so that every row equals the row of the undivided system.  key == NULL: mdh_build_neighbor. */
+ * slab's owned + ghost atoms, so that every row equals the row of the undivided system.  key == NULL: mdh_build_neighbor.
+ * ABSENT atoms (extension, all mdh_build_neighbor* entries): an atom whose x is NaN takes no cell — it appears in nobody's row, and
+ * its own row and count are NOT written (the unused slots of a decomposed step's fixed-size ghost block,
+ * mdh_slab_append_ghosts_static; the reference has no meaning for NaN input). */
 int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                              const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                              int64_t max_neigh, int fill_pads, const int64_t *key, int space, void *stream);

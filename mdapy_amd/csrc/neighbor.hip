@@ -39,14 +39,16 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
                                                 unsigned *__restrict__ cell_count, unsigned *__restrict__ ctl, unsigned gen,
                                                 double slack, unsigned short *__restrict__ mv, CellPlanes win,
-                                                CellGrid::Packed *__restrict__ rec)
+                                                CellGrid::Packed *__restrict__ rec, int drop_absent)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool moved = false, outside = false, coded = false;
     int cell = -1 - (int)(threadIdx.x & 63); // lanes past the end: distinct negative values, no run, no atomic
     // an atom whose x is NaN is ABSENT: it takes no cell, appears in nobody's row and gets no row of its own (the unused slots of a
     // decomposed system's fixed-size ghost block, slab.hip k_slab_append_static; the reference has no meaning for such input)
-    const bool absent = i < N && x[i] != x[i];
+    // (only the neighbor builds — drop_absent — know what to do without such an atom: their kernels walk cells, and their per-atom
+    // passes end at the number of atoms binned; every other user of the grid bins a NaN as it always did, into cell 0)
+    const bool absent = drop_absent && i < N && x[i] != x[i];
     if (absent) {
         cell_id[i] = -1;
         if (mv) mv[i] = (unsigned short)img::ATOM_NEUTRAL;
@@ -720,9 +722,9 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     }
     const unsigned gen = next_scan_gen(); // stamps of this build's k_assign; the (first) scan below is launched with the same value
     if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec);
+        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec);
+        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0);
     auto scan_piece = [&](int64_t from, int64_t to, unsigned use_gen, int *flags) {
         launch_scan_gen(st, cell_count + from, cg.cell_start + from, to - from, ctl, use_gen, true, flags); // [to] = the piece's total
     };
