@@ -462,7 +462,9 @@ def main():
         def step():
             # every step: one halo exchange, one build, one CNA.  The exchange of the NEXT step (the next frame of a trajectory
             # does not depend on this one) is started on a side stream before this step's kernels are enqueued.
-            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M, next_frame=(x, y, z, gid))
+            # (the prefetch pays where the exchange's kernels are worth hiding: 2.01 -> 1.96 ms for a 10 M-atom slab; for a 1.26 M-atom
+            # slab the second stream costs more than it hides, 0.355 -> 0.377 ms — profiles/r05_strong.txt, r05_halo_cost.txt)
+            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M, next_frame=(x, y, z, gid) if n_local >= (1 << 22) else None)
             return nn_, pat_, dom
 
     # the timed region: K steps, the neighbour kernel's range timed live by HIP events on its launch stream; the other
