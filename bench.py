@@ -144,6 +144,63 @@ def analyses_extra(torch, dev, mp, cells):
     return found
 
 
+def notebook_calls(torch, dev, mp):
+    from mdapy_amd.devarray import HArray
+    from mdapy_amd.frame import Frame
+
+    def system(nx, ny, nz):
+        a = A_CU
+        basis = torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.5, 0.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5]], dtype=torch.float64, device=dev) * a
+        cols = []
+        for k, n in enumerate((nx, ny, nz)):
+            shape = [1, 1, 1, 1]
+            shape[k] = n
+            comp = basis[:, k].view(1, 1, 1, 4) + (torch.arange(n, dtype=torch.float64, device=dev) * a).view(shape)
+            cols.append(comp.expand(nx, ny, nz, 4).reshape(-1).contiguous())
+        return mp.System(data=Frame({"x": HArray(cols[0]), "y": HArray(cols[1]), "z": HArray(cols[2])}), box=mp.Box(np.diag([a * nx, a * ny, a * nz])))
+
+    def lap(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    out = {}
+    s = system(85, 100, 100)  # the largest system of the benchmark notebook: 3.4 M atoms
+    n = s.N
+    t = lap(lambda: s.build_neighbor(5.0, max_neigh=50))
+    out["build_neighbor(5.0, max_neigh=50), 3.4 M atoms"] = {"ms": t, "atoms_per_s": n / (t * 1e-3), "reference_published": "0.4 s per 10^6 atoms (1.36 s at this size)",
+                                                             "ratio_to_published": 0.4 * n / 1e6 / (t * 1e-3)}
+    t = lap(lambda: s.build_nearest_neighbor(12))
+    out["build_nearest_neighbor(12), 3.4 M atoms"] = {"ms": t, "atoms_per_s": n / (t * 1e-3), "reference_published": "0.2 s per 10^6 atoms (0.68 s at this size)",
+                                                      "ratio_to_published": 0.2 * n / 1e6 / (t * 1e-3)}
+    del s
+
+    def three(sysm):
+        sysm.cal_centro_symmetry_parameter(12)
+        sysm.cal_ackland_jones_analysis()
+        sysm.cal_structure_entropy(5.0, 0.2)
+
+    def fresh():
+        three(system(100, 100, 100))
+
+    t = lap(fresh)
+    out["4 M atoms: csp(12) + ackland_jones + structure_entropy(5.0, 0.2) on a new System"] = {
+        "ms": t, "reference_published": "8.72 s wall", "ratio_to_published": 8.72 / (t * 1e-3)}
+
+    def reuse():
+        sysm = system(100, 100, 100)
+        sysm.build_neighbor(rc=5.0, max_neigh=50)
+        three(sysm)
+
+    t = lap(reuse)
+    out["the same after build_neighbor(rc=5.0, max_neigh=50) (list reuse), build included"] = {
+        "ms": t, "reference_published": "6.39 s wall (build not included)", "ratio_to_published": 6.39 / (t * 1e-3)}
+    return out
+
+
 def cpu_baseline_child(args):
     """the timed sample itself (a process of its own: OpenMP reads its binding when the runtime starts, and the parent has
     long started one with torch): a thread sweep on a 1 M-atom lattice picks the thread count, the figure is then measured on
@@ -714,6 +771,12 @@ def main():
                 extra.update(analyses_extra(torch, dev, mp, cells))
             except Exception as e:
                 extra["config2"] = {"error": f"{type(e).__name__}: {e}"}
+            # (f) the reference's OWN published calls (doc/gettingstarted/benchmark.ipynb cells 4-10, use_mdapy_efficiently.ipynb
+            # cells 9-11; hardware not stated there) on the same systems, through System: wall time of the second of two calls
+            try:
+                extra["reference_notebook_calls"] = notebook_calls(torch, dev, mp)
+            except Exception as e:
+                extra["reference_notebook_calls"] = {"error": f"{type(e).__name__}: {e}"}
             res["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args)

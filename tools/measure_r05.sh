@@ -26,6 +26,10 @@ import json
 r = json.loads(open("$O/r05_bench_quick.json").read().strip().splitlines()[-1])
 print({k: r[k] for k in ("value", "ms_per_step")}, r["roofline"]["frac"], r["kernels_ms"])
 for k, v in r.get("extra", {}).items():
+    if k == "reference_notebook_calls":
+        for kk, vv in v.items():
+            print("  ", kk, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in vv.items()} if isinstance(vv, dict) else vv)
+        continue
     print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a in ("ms_per_step", "ratio", "ratio_prefetched", "ratio_to_ordered", "ratio_to_builder_order", "kernels_ms", "error")})
 P
   ;;
