@@ -114,6 +114,10 @@ int mdh_debug_set_rdf_variant(int variant);
 int mdh_debug_set_knn_variant(int variant);
 /* test hook: 0 = per-degree register-resident stage 1 of the Steinhardt parameters where compiled (default), 1 = generic kernel */
 int mdh_debug_set_sq_variant(int variant);
+/* test hook: structure entropy, 0 = the ladder kernel where it applies (<= 40 bins, rc^2 / 2 sigma^2 <= 640) with the lane count
+ * picked by the row width (default), 1 = the direct kernel (an exponential per term), 2 / 3 / 4 / 5 = the ladder with 1 / 2 / 4 / 8
+ * lanes to a row */
+int mdh_debug_set_entropy_variant(int variant);
 /* test hook: vertex capacity of the first pass of the PTM neighbour ordering (10 default, 15; 5 sends most atoms through
  * the second, 28-vertex pass, whose results must be the same) */
 int mdh_debug_set_ptm_order_cap(int cap);

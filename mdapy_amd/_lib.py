@@ -46,6 +46,7 @@ _SIGNATURES = {
     "mdh_debug_set_rdf_variant": [cint],
     "mdh_debug_set_knn_variant": [cint],
     "mdh_debug_set_sq_variant": [cint],
+    "mdh_debug_set_entropy_variant": [cint],
     "mdh_debug_set_ptm_order_cap": [cint],
     "mdh_debug_image_thresholds": [dbl, vp],
     "mdh_parse_table": [vp, i64, cint, i64, cint, vp, vp, vp, i64, vp, cint, vp],

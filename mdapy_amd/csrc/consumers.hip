@@ -205,6 +205,7 @@ __global__ __launch_bounds__(128) void k_cnp(const double *__restrict__ x, const
 }
 
 static constexpr int ENT_MAXBINS = 512;
+static int g_entropy_variant = 0;
 
 // the per-bin tables of the reference (:27-38: r_j = j*step, r_j^2, r_j^2*factor with entry 0 := entry 1) are single
 // IEEE multiplications, recomputed here with identical results
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64) void k_entropy(const double *__restrict__ dist,
     if (i >= N)
         return;
     const double PI = 3.14159265358979323846;
-    const double s2 = sigma * sigma, lvol = 4. / 3. * PI * rc * rc * rc;
+    const double c2 = -1.0 / (2.0 * sigma * sigma), lvol = 4. / 3. * PI * rc * rc * rc;
     const double *di = STAGED ? ent_rows + threadIdx.x : dist + i * M;
     const int stride = STAGED ? 65 : 1;
     const int n = STAGED ? min(nn[i], (int)M) : nn[i]; // (a count beyond the row width is the caller's error: the staged form stays inside the row)
@@ -246,18 +247,119 @@ __global__ __launch_bounds__(64) void k_entropy(const double *__restrict__ dist,
         double g = 0.0;
         const double r = j * step, r2 = r * r;
         const double p = j == 0 ? (step * step) * factor : r2 * factor;
-        for (int k = 0; k < n; ++k) {
+        for (int k = 0; k < n; ++k) { // (the reference divides every term by 2 sigma^2 and by p: one multiplication, one division of the sum)
             const double d = di[k * stride];
             if (d <= rc) {
                 const double dl = r - d;
-                g += exp(-(dl * dl) / (2.0 * s2)) / p;
+                g += exp((dl * dl) * c2);
             }
         }
+        g /= p;
         if (use_local) g *= fac;
         const double v = g >= 1e-10 ? (g * log(g) - g + 1.0) * r2 : r2;
         if (j > 0) sum += prev + v;
         prev = v;
     }
+    entropy[i] = -PI * density * sum * sigma;
+}
+
+
+// The same sums by a ladder.  The bins are equally spaced, so for one neighbour at distance d the terms of consecutive bins
+// are a Gaussian sampled on a grid: e_0 = exp(-d^2 / 2 sigma^2), e_{j+1} = e_j * rho_j, rho_{j+1} = rho_j * q with
+// rho_0 = exp((2 d step - step^2) / 2 sigma^2) and q = exp(-step^2 / sigma^2) — two exponentials per NEIGHBOUR and two
+// multiplications per term, where the direct form above spends an exponential and two divisions (~90 double-precision
+// instructions) on each of the nbins * n terms: 12.2 ms on 4 M atoms of the published workflow (rc 5.0, sigma 0.2: 26 bins,
+// 42 neighbours), the bulk of that call.  Rounding: e_j carries the argument error of e_0 (|arg| * 2^-53, at most 640 here)
+// and j steps of the ladder: <= 3e-13 relative on the sums (measured against the oracle: tests), the bar is 1e-6.  Used for
+// nbins <= ENT_LADDER_BINS and rc^2 / 2 sigma^2 <= 640 (e_0 stays a normal number); anything else takes the direct kernel.
+// Layout as k_sort_rows: one wave per workgroup, 64/L consecutive rows, L lanes to a row (each walks every L-th neighbour,
+// the partial sums meet by a butterfly), the rows read with 16-byte loads into LDS.
+static constexpr int ENT_LADDER_BINS = 40;
+struct EntBins { double inv_p[ENT_LADDER_BINS]; };
+
+template <int L, int NB>
+__global__ __launch_bounds__(64) void k_entropy_ladder(const double *__restrict__ dist, const int *__restrict__ nn, int64_t N, int M,
+                                                       unsigned inv_m, double rc, double sigma, int use_local, double gd, int nbins,
+                                                       double step, double q, EntBins bins, double *__restrict__ entropy)
+{
+    constexpr int ROWS = 64 / L;
+    extern __shared__ double ent_rows[]; // [M][ROWS]
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int rows = (int)((N - row0) < ROWS ? (N - row0) : ROWS);
+    const int total = rows * M;
+    const int t = threadIdx.x;
+    const double *__restrict__ gdist = dist + row0 * M;
+    auto slot = [&](int e) {
+        const int r = (int)__umulhi((unsigned)e, inv_m);
+        return (e - r * M) * ROWS + r;
+    };
+    if (rows == ROWS && (reinterpret_cast<uintptr_t>(dist) & 15) == 0) { // (ROWS * M is even)
+        const double2 *g2 = reinterpret_cast<const double2 *>(gdist);
+#pragma unroll 4
+        for (int p = t; p < (total >> 1); p += 64) {
+            const double2 v = g2[p];
+            ent_rows[slot(2 * p)] = v.x; ent_rows[slot(2 * p + 1)] = v.y;
+        }
+    } else {
+        for (int e = t; e < total; e += 64) ent_rows[slot(e)] = gdist[e];
+    }
+    __syncthreads();
+    const int r = t & (ROWS - 1), j = t / ROWS;
+    const bool live = r < rows;
+    const int64_t i = row0 + r;
+    const double PI = 3.14159265358979323846;
+    const double c2 = 1.0 / (2.0 * sigma * sigma), lvol = 4. / 3. * PI * rc * rc * rc;
+    const double *lr = ent_rows + r;
+    double G[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) G[b] = 0.0;
+    int nin = 0;
+    if (live) {
+        const int n = min(nn[i], M); // (a count beyond the row width is the caller's error: stay inside the row)
+        for (int k = j; k < n; k += L) {
+            const double d = lr[k * ROWS];
+            if (d <= rc) {
+                ++nin;
+                double e = exp(-(d * d) * c2);
+                double rho = exp((2.0 * d * step - step * step) * c2);
+#pragma unroll
+                for (int b8 = 0; b8 < NB; b8 += 8)
+                    if (b8 < nbins) { // (uniform: eight bins at a time)
+#pragma unroll
+                        for (int b = b8; b < b8 + 8; ++b) {
+                            G[b] += e;
+                            e *= rho;
+                            rho *= q;
+                        }
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = ROWS; w < 64; w <<= 1) {
+        nin += __shfl_xor(nin, w);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            G[b] += __shfl_xor(G[b], w);
+    }
+    if (!live || j != 0)
+        return;
+    double density = gd, fac = 1.0;
+    if (use_local) {
+        density = nin / lvol;
+        fac = gd / density;
+    }
+    double prev = 0.0, sum = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < nbins) {
+            const double rb = b * step, r2 = rb * rb;
+            double g = G[b] * bins.inv_p[b];
+            if (use_local) g *= fac;
+            const double v = g >= 1e-10 ? (g * log(g) - g + 1.0) * r2 : r2;
+            if (b > 0) sum += prev + v;
+            prev = v;
+        }
     entropy[i] = -PI * density * sum * sigma;
 }
 
@@ -341,6 +443,36 @@ extern "C" int mdh_structure_entropy(double rc, double sigma, int use_local_dens
     if (sc.failed())
         return sc.error();
     ProfRange pr("k_entropy", sc.stream());
+    if (g_entropy_variant != 1 && nbins <= ENT_LADDER_BINS && rc * rc / (2.0 * sigma * sigma) <= 640.0 && M >= 2 && M <= 1024) {
+        EntBins bins;
+        for (int b = 0; b < ENT_LADDER_BINS; ++b) { // :27-38: r_b^2 * factor, entry 0 := entry 1
+            const double rb = (b == 0 ? 1 : b) * step;
+            bins.inv_p[b] = 1.0 / ((rb * rb) * factor);
+        }
+        const double q = exp(-(step * step) / (sigma * sigma));
+        int L = 1; // lanes to a row: the fewest that keep the rows of a wave within ~13 KB of LDS
+        while (L < 8 && (size_t)(64 / L) * M * 8 > 13 * 1024) L <<= 1;
+        if (g_entropy_variant >= 2) L = g_entropy_variant == 2 ? 1 : g_entropy_variant == 3 ? 2 : g_entropy_variant == 4 ? 4 : 8;
+        const size_t lds = (size_t)(64 / L) * M * 8;
+        if (lds <= 64 * 1024) {
+            const unsigned inv_m = (unsigned)((0x100000000ull + (uint64_t)M - 1) / (uint64_t)M);
+            const dim3 grid(grid_for(N, 64 / L)), block(64);
+#define MDH_ENT_LAUNCH(LL, NB)                                                                                                        \
+    hipLaunchKernelGGL((k_entropy_ladder<LL, NB>), grid, block, lds, sc.stream(), dd, dn, N, (int)M, inv_m, rc, sigma,              \
+                       use_local_density ? 1 : 0, gd, nbins, step, q, bins, de)
+#define MDH_ENT_BINS(LL)                                                                                                              \
+    if (nbins <= 16) MDH_ENT_LAUNCH(LL, 16); else if (nbins <= 32) MDH_ENT_LAUNCH(LL, 32); else MDH_ENT_LAUNCH(LL, 40)
+            switch (L) {
+            case 1: MDH_ENT_BINS(1); break;
+            case 2: MDH_ENT_BINS(2); break;
+            case 4: MDH_ENT_BINS(4); break;
+            default: MDH_ENT_BINS(8); break;
+            }
+#undef MDH_ENT_BINS
+#undef MDH_ENT_LAUNCH
+            return sc.finish(space);
+        }
+    }
     const size_t lds = (size_t)M * 65 * sizeof(double);
     if (lds <= 48 * 1024) // (the reference reads nn[i] entries of a row of M: a count beyond M is its caller's error, here as there)
         hipLaunchKernelGGL(k_entropy<true>, dim3(grid_for(N, 64)), dim3(64), lds, sc.stream(), dd, dn, N, M, rc, sigma, use_local_density ? 1 : 0,
@@ -349,6 +481,12 @@ extern "C" int mdh_structure_entropy(double rc, double sigma, int use_local_dens
         hipLaunchKernelGGL(k_entropy<false>, dim3(grid_for(N, 64)), dim3(64), 0, sc.stream(), dd, dn, N, M, rc, sigma, use_local_density ? 1 : 0,
                            gd, nbins, step, factor, de);
     return sc.finish(space);
+}
+
+extern "C" int mdh_debug_set_entropy_variant(int v) // 0 automatic, 1 the direct kernel, 2/3/4/5 the ladder with 1/2/4/8 lanes to a row (A/B measurements, tests)
+{
+    g_entropy_variant = v;
+    return MDH_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1067,13 +1067,135 @@ static void launch_neighbor(hipStream_t st, const CellGrid &cg, int64_t N, const
 // small row-wise helpers
 // ----------------------------------------------------------------------------
 // neighbor.cpp:745-775: selection of the first k entries by strict '<' over all M columns.
-// 64 consecutive rows per workgroup: the rows are one contiguous piece of memory, loaded with coalesced reads into LDS
-// (element c of row t at [c * 64 + t]: conflict-free for the per-row walk), selected there, and only written back when
-// something moved — the rows of a k-nearest search arrive sorted, and every analysis that borrows them "sorts" them again
-// (the reference does the same); for those the kernel is one read of the list.
+// One wave per workgroup, 64/L consecutive rows of it, L lanes to a row (L = 1 ... 16, the smallest that keeps the LDS copy
+// of the rows near 10 KB: 12+ waves per CU, where 64 rows of 50 entries — build_neighbor(5.0, 50), the published workflow —
+// left one wave per SIMD and the list read at 0.8 TB/s).  The rows are one contiguous piece of memory: read with 16-byte
+// loads into LDS (element c of row r at [c * ROWS + r]; lane j * ROWS + r walks columns a+1+j, a+1+j+L, ...: consecutive
+// words, conflict-free), selected there — every lane starts from entry a and only takes a strictly smaller one, the L
+// partial results meet by (distance, column): the first of the smallest, as the serial loop has it — and only written back
+// when something moved: the rows of a k-nearest search arrive sorted, and every analysis that borrows them "sorts" them
+// again (the reference does the same); for those the kernel is one read of the list.
+template <int L>
+__global__ __launch_bounds__(64) void k_sort_rows(int *__restrict__ verlet, double *__restrict__ dist, int64_t N, int M, int k,
+                                                  unsigned inv_m)
+{
+    constexpr int ROWS = 64 / L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
+    double *ld = reinterpret_cast<double *>(sort_lds);        // [M][ROWS]
+    int *lv = reinterpret_cast<int *>(ld + (size_t)M * ROWS); // [M][ROWS]
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    const int rows = (int)((N - row0) < ROWS ? (N - row0) : ROWS);
+    const int total = rows * M;
+    const int t = threadIdx.x;
+    double *__restrict__ gd = dist + row0 * M;
+    int *__restrict__ gv = verlet + row0 * M;
+    // e -> (row, column): e < 2^16 and M < 2^16, so the high word of e * ceil(2^32 / M) is e / M exactly
+    auto slot = [&](int e) {
+        const int r = (int)__umulhi((unsigned)e, inv_m);
+        return (e - r * M) * ROWS + r;
+    };
+    const bool vec = rows == ROWS && ((reinterpret_cast<uintptr_t>(dist) | reinterpret_cast<uintptr_t>(verlet)) & 15) == 0; // (ROWS * M is a multiple of 4)
+    if (vec) {
+        {
+            const double2 *gd2 = reinterpret_cast<const double2 *>(gd);
+            const int4 *gv4 = reinterpret_cast<const int4 *>(gv);
+#pragma unroll 4
+            for (int p = t; p < (total >> 1); p += 64) {
+                const double2 v = gd2[p];
+                ld[slot(2 * p)] = v.x; ld[slot(2 * p + 1)] = v.y;
+            }
+#pragma unroll 4
+            for (int p = t; p < (total >> 2); p += 64) {
+                const int4 v = gv4[p];
+                lv[slot(4 * p)] = v.x; lv[slot(4 * p + 1)] = v.y; lv[slot(4 * p + 2)] = v.z; lv[slot(4 * p + 3)] = v.w;
+            }
+        }
+    } else {
+        for (int e = t; e < total; e += 64) { const int s = slot(e); ld[s] = gd[e]; lv[s] = gv[e]; }
+    }
+    __syncthreads();
+    const int r = t & (ROWS - 1), j = t / ROWS;
+    const bool live = r < rows;
+    const double *lr = ld + r;
+    // One walk first: entries 0 ... p-1 stay where they are if they ascend and nothing behind them is smaller — rows that
+    // arrive sorted (a k-nearest list; the same list sorted for the analysis before this one) are done after this walk,
+    // rows sorted to 12 and now wanted to 14 start at 12.  (s: the smallest entry behind a; '<' only, as the selection.)
+    int first = k;
+    if (live) {
+        double s = __builtin_inf();
+        for (int c = k + j; c < M; c += L) {
+            const double v = lr[c * ROWS];
+            if (v < s) s = v;
+        }
+#pragma unroll
+        for (int w = ROWS; w < 64; w <<= 1) {
+            const double o = __shfl_xor(s, w);
+            if (o < s) s = o;
+        }
+        for (int a = k - 1; a >= 0; --a) {
+            const double v = lr[a * ROWS];
+            if (s < v) first = a;
+            if (v < s) s = v;
+        }
+    }
+#pragma unroll
+    for (int w = 1; w < 64; w <<= 1) {
+        const int o = __shfl_xor(first, w);
+        first = o < first ? o : first;
+    }
+    bool moved = false;
+    for (int a = first; a < k; ++a) {
+        int best = a;
+        double db = live ? lr[a * ROWS] : 0.0;
+        if (live) {
+            int c = a + 1 + j;
+            for (; c + 3 * L < M; c += 4 * L) {
+                const double v0 = lr[c * ROWS], v1 = lr[(c + L) * ROWS], v2 = lr[(c + 2 * L) * ROWS], v3 = lr[(c + 3 * L) * ROWS];
+                if (v0 < db) { db = v0; best = c; }
+                if (v1 < db) { db = v1; best = c + L; }
+                if (v2 < db) { db = v2; best = c + 2 * L; }
+                if (v3 < db) { db = v3; best = c + 3 * L; }
+            }
+            for (; c < M; c += L) {
+                const double v = lr[c * ROWS];
+                if (v < db) { db = v; best = c; }
+            }
+        }
+#pragma unroll
+        for (int w = ROWS; w < 64; w <<= 1) { // the other lanes of this row are w, 2w, ... lanes away
+            const double od = __shfl_xor(db, w);
+            const int ob = __shfl_xor(best, w);
+            if (od < db || (od == db && ob < best)) { db = od; best = ob; }
+        }
+        if (live && j == 0 && best != a) {
+            const double td = ld[a * ROWS + r];
+            ld[a * ROWS + r] = db; ld[best * ROWS + r] = td;
+            const int tv = lv[a * ROWS + r];
+            lv[a * ROWS + r] = lv[best * ROWS + r]; lv[best * ROWS + r] = tv;
+            moved = true;
+        }
+        if (L > 1) __syncthreads(); // (one wave: the writes above are in LDS before the next column walk of the row's other lanes)
+    }
+    if (!__syncthreads_or(moved ? 1 : 0))
+        return;
+    if (vec) {
+        double2 *gd2 = reinterpret_cast<double2 *>(gd);
+        int4 *gv4 = reinterpret_cast<int4 *>(gv);
+#pragma unroll 4
+        for (int p = t; p < (total >> 1); p += 64)
+            gd2[p] = make_double2(ld[slot(2 * p)], ld[slot(2 * p + 1)]);
+#pragma unroll 4
+        for (int p = t; p < (total >> 2); p += 64)
+            gv4[p] = make_int4(lv[slot(4 * p)], lv[slot(4 * p + 1)], lv[slot(4 * p + 2)], lv[slot(4 * p + 3)]);
+    } else {
+        for (int e = t; e < total; e += 64) { const int s = slot(e); gd[e] = ld[s]; gv[e] = lv[s]; }
+    }
+}
+
+// the round-2 form of the same (64 rows per workgroup, a lane to a row): kept for A/B measurements (mdh_debug_set_neighbor_variant(3))
 constexpr int SORT_ROWS = 64;
-__global__ __launch_bounds__(SORT_ROWS) void k_sort_rows(int *__restrict__ verlet, double *__restrict__ dist, int64_t N,
-                                                         int64_t M, int k)
+__global__ __launch_bounds__(SORT_ROWS) void k_sort_rows_r2(int *__restrict__ verlet, double *__restrict__ dist, int64_t N,
+                                                            int64_t M, int k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
     double *ld = reinterpret_cast<double *>(sort_lds);            // [M][64]
@@ -1142,6 +1264,7 @@ __global__ __launch_bounds__(256) void k_sort_rows_wide(int *__restrict__ verlet
 // (the selection sort above is quadratic in the row length: a 36 000-wide row — surface atoms of a slab looking across
 // its vacuum — took minutes)
 constexpr int SORT_BLOCK_MAX = 8192;
+constexpr int SORT_LDS_WIDEST = 1024; // the selection kernel above with 16 lanes to a row: 4 rows of 1024 entries in 48 KB
 __global__ __launch_bounds__(256) void k_sort_rows_block(int *__restrict__ verlet, double *__restrict__ dist, int64_t M, int P)
 {
     extern __shared__ double sort_block_lds[];
@@ -1584,11 +1707,28 @@ int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M,
     if (sc.failed())
         return sc.error();
     const int k = (int)(sort_num < M ? sort_num : M);
-    const size_t lds = (size_t)M * SORT_ROWS * 12;
-    if (lds <= 60 * 1024)
-        hipLaunchKernelGGL(k_sort_rows, dim3(grid_for(N, SORT_ROWS)), dim3(SORT_ROWS), lds, sc.stream(), dv, dd, N, M, k);
-    else // (the reference's selection sort, neighbor.cpp: its order among EQUAL distances — a perfect lattice — is part of the result)
+    if (M == 1)
+        return sc.finish(space);
+    if (M > SORT_LDS_WIDEST) { // (the reference's selection sort, neighbor.cpp: its order among EQUAL distances — a perfect lattice — is part of the result)
         hipLaunchKernelGGL(k_sort_rows_wide, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, k);
+        return sc.finish(space);
+    }
+    if (g_neighbor_variant == 3 && (size_t)M * SORT_ROWS * 12 <= 60 * 1024) {
+        hipLaunchKernelGGL(k_sort_rows_r2, dim3(grid_for(N, SORT_ROWS)), dim3(SORT_ROWS), (size_t)M * SORT_ROWS * 12, sc.stream(), dv, dd, N, M, k);
+        return sc.finish(space);
+    }
+    int L = 1; // lanes to a row: the fewest that keep the rows of a wave within ~10 KB of LDS
+    while (L < 16 && (size_t)(64 / L) * M * 12 > 10 * 1024) L <<= 1;
+    const size_t lds = (size_t)(64 / L) * M * 12;
+    const unsigned inv_m = (unsigned)((0x100000000ull + (uint64_t)M - 1) / (uint64_t)M);
+    const dim3 grid(grid_for(N, 64 / L)), block(64);
+    switch (L) {
+    case 1: hipLaunchKernelGGL(k_sort_rows<1>, grid, block, lds, sc.stream(), dv, dd, N, (int)M, k, inv_m); break;
+    case 2: hipLaunchKernelGGL(k_sort_rows<2>, grid, block, lds, sc.stream(), dv, dd, N, (int)M, k, inv_m); break;
+    case 4: hipLaunchKernelGGL(k_sort_rows<4>, grid, block, lds, sc.stream(), dv, dd, N, (int)M, k, inv_m); break;
+    case 8: hipLaunchKernelGGL(k_sort_rows<8>, grid, block, lds, sc.stream(), dv, dd, N, (int)M, k, inv_m); break;
+    default: hipLaunchKernelGGL(k_sort_rows<16>, grid, block, lds, sc.stream(), dv, dd, N, (int)M, k, inv_m); break;
+    }
     return sc.finish(space);
 }
 
@@ -1601,7 +1741,7 @@ int sort_rows_any_tie_order(int *dv, double *dd, int64_t N, int64_t M, void *str
 {
     if (N <= 0 || M <= 0)
         return MDH_OK;
-    if ((size_t)M * SORT_ROWS * 12 <= 60 * 1024 || M > SORT_BLOCK_MAX)
+    if (M <= 80 || M > SORT_BLOCK_MAX) // (whole rows: the selection is quadratic in the row length, the network is not)
         return mdh_sort_verlet_by_distance(dv, dd, N, M, (int)M, MDH_DEVICE, stream);
     int P = 256;
     while (P < M) P <<= 1;

@@ -459,6 +459,24 @@ def test_sort_wide_rows_keeps_the_reference_order_among_equal_distances():
         assert np.array_equal(vb, va) and np.array_equal(db, da)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 13, 14, 16, 27, 50, 53, 100, 107, 171, 300, 681, 1024, 1025, 1100])
+def test_sort_every_row_width_vs_oracle(M):
+    """the selection kernel gives a row 1, 2, 4, 8 or 16 lanes by its width (and rows past 1024 entries are sorted in HBM):
+    rows full of EQUAL distances (a handful of distinct values), row counts that end inside a workgroup, sorted rows that must
+    be left alone — entry for entry the reference's selection (neighbor.cpp:745-775)"""
+    rng = np.random.default_rng(100 + M)
+    for N in (1, 67, 1000 if M < 200 else 130):
+        d = rng.integers(0, 5, (N, M)).astype(np.float64) * 0.25 + 2.0
+        d[N // 2:] += rng.random((N - N // 2, M)) * 1e-3  # half the rows without ties
+        d[::5] = np.sort(d[::5], axis=1)  # every fifth row arrives sorted
+        v = rng.integers(0, 1 << 30, (N, M)).astype(np.int32)
+        for k in sorted({1, min(12, M), min(14, M), M if M <= 171 else 20}):
+            va, da = v.copy(), d.copy(); vb, db = v.copy(), d.copy()
+            O.sort_verlet_by_distance(va, da, k, 4)
+            _neighbor.sort_verlet_by_distance(vb, db, k, 1)
+            assert np.array_equal(vb, va) and np.array_equal(db, da), (M, N, k)
+
+
 def _fcna_cases():
     """boxes of >= 10 cutoffs per periodic edge: the single-precision pair tests of k_fcna_f32 apply"""
     rng = np.random.default_rng(5)
@@ -1256,6 +1274,32 @@ def test_aja_cnp_entropy_vs_oracle(case):
         ok = np.isfinite(e0)
         assert np.array_equal(np.isfinite(e1), ok)
         assert np.allclose(e1[ok], e0[ok], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("sigma", [0.2, 0.5, 0.14, 0.1])
+def test_structure_entropy_ladder_and_direct_kernels_vs_oracle(sigma):
+    """rc 5.0 on rattled fcc (42 neighbours; rows of 50 and of the exact width): the ladder kernel (<= 40 bins; 26, 11 and 36 here)
+    with 1, 2, 4 and 8 lanes to a row and the direct kernel (sigma 0.1: 51 bins, the only one) against the oracle.  The bar is
+    rtol 1e-6; the ladder's rounding (DESIGN: <= 3e-13 on the sums) is checked at 1e-10."""
+    from mdapy_amd import _lib
+    pos, box = _fcc(9, 0.08, 77)
+    x, y, z = _xyz(pos)
+    N, rc = len(x), 5.0
+    vol = abs(np.linalg.det(np.diag(box) if np.ndim(box) == 1 else np.asarray(box, float)))
+    v, d, nn = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 4)
+    wide = np.full((N, 50), rc + 1.0); wide[:, :d.shape[1]] = d
+    try:
+        for dist in (d, wide, d[:67], wide[:1]):
+            n = np.ascontiguousarray(nn[:len(dist)])
+            for local in (False, True):
+                e0 = np.zeros(len(dist)); O.calculate_structure_entropy(rc, sigma, local, vol, dist, n, e0, 4)
+                for variant in (0, 1, 2, 3, 4, 5):
+                    _lib.check(_lib.lib().mdh_debug_set_entropy_variant(variant))
+                    e1 = np.full(len(dist), -1.0)
+                    _structure_entropy.calculate_structure_entropy(rc, sigma, local, vol, dist, n, e1, 1)
+                    assert np.allclose(e1, e0, rtol=1e-10, atol=1e-12), (sigma, dist.shape, local, variant, np.abs(e1 / e0 - 1).max())
+    finally:
+        _lib.check(_lib.lib().mdh_debug_set_entropy_variant(0))
 
 
 AJA_PATHS, CNP_PATHS = fixtures_with("aja"), fixtures_with("cnp")

@@ -51,6 +51,11 @@ halo)   # weak scaling: a 136^3-cell slab of 8 with its halo in loop-back agains
   python tools/halo_cost.py 136 8 2>&1 | clean | tee $O/r05_halo_cost.txt ;;
 analyses)   # configs 2 and 4 at full size through System under the kernel trace
   prof analyses python $R/tools/profile_analyses.py c3 c5 ;;
+notebook)   # the reference notebook's published workflow call by call, then the kernels behind the list-reuse form
+  python tools/notebook_probe.py both 3 2>&1 | clean | tee $O/r05_notebook.txt
+  prof notebook python $R/tools/notebook_probe.py reuse 2 | tee -a $O/r05_notebook.txt ;;
+sort)
+  python tools/sort_probe.py 2>&1 | clean | tee $O/r05_sort_rows.txt ;;
 twin)
   python tools/twin_probe.py 136 2>&1 | clean | tee $O/r05_twin_probe.txt ;;
 counters)   # SQ / traffic counters of the headline step's kernels, four separate --pmc passes (kernel trace only: gpurun's rule)
