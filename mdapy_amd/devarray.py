@@ -70,12 +70,13 @@ def _pinned_release(nbytes):
 class HArray:
     """An array that lives in HBM; the host copy is made on demand and is read-only."""
 
-    __slots__ = ("_dev", "_host", "__weakref__")
+    __slots__ = ("_dev", "_host", "_mm", "__weakref__")
     __array_priority__ = 100
 
     def __init__(self, dev):
         self._dev = dev
         self._host = None
+        self._mm = None  # (min, max) of an int32 array once somebody asked: dropped with the host copy (invalidate_host)
 
     # ---- construction
     @staticmethod
@@ -109,6 +110,7 @@ class HArray:
     def invalidate_host(self):
         """call after a kernel changed the HBM content"""
         self._host = None
+        self._mm = None
 
     # ---- host side
     def numpy(self) -> np.ndarray:
@@ -174,10 +176,12 @@ class HArray:
         its first call in a process loads torch's reduction code object (19 ms on an MI355X box, tools/cold_profile.py)"""
         import ctypes
 
-        d = self._dev if self._dev.is_contiguous() else self._dev.contiguous()
-        out = (ctypes.c_int * 2)()
-        _lib.check(_lib.lib().mdh_min_max_i32(int(d.data_ptr()), int(d.numel()), ctypes.addressof(out), _lib.DEVICE, current_stream_ptr()))
-        return int(out[0]), int(out[1])
+        if self._mm is None:  # (asked again and again for the counts of one list: every analysis checks the depth of the rows it borrows)
+            d = self._dev if self._dev.is_contiguous() else self._dev.contiguous()
+            out = (ctypes.c_int * 2)()
+            _lib.check(_lib.lib().mdh_min_max_i32(int(d.data_ptr()), int(d.numel()), ctypes.addressof(out), _lib.DEVICE, current_stream_ptr()))
+            self._mm = (int(out[0]), int(out[1]))
+        return self._mm
 
     def min(self, *a, **k):
         if not a and not k and self.size:
@@ -250,7 +254,7 @@ class LazyHArray(HArray):
     __slots__ = ("_make", "_real", "_shape", "_np_dtype")
 
     def __init__(self, make, shape, dtype):
-        self._make, self._real, self._host = make, None, None
+        self._make, self._real, self._host, self._mm = make, None, None, None
         self._shape, self._np_dtype = tuple(int(s) for s in shape), np.dtype(dtype)
 
     @property
