@@ -9,7 +9,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import kernels
-from .devarray import as_numpy, empty
+from .devarray import HArray, as_numpy, empty, have_gpu
 from .frame import Frame
 from .parallel import get_num_threads
 
@@ -28,6 +28,14 @@ STANDARD_ATOMIC_WEIGHT = {
 
 
 class AtomicTemperature:
+    def _scaled(self, name):
+        """the velocity column in m/s (A/fs x 1e3 x factor, the reference's two multiplications in its order), made where the column
+        lives: in HBM from the column's mirror — three host multiplications and 96 MB over PCIe per call at 4 M atoms otherwise"""
+        col = self.data[name]
+        if have_gpu() and col.dtype == np.float64:
+            return HArray((col.device_array().dev() * 1e3) * self.factor)
+        return np.ascontiguousarray(as_numpy(col.to_numpy()) * 1e3 * self.factor)
+
     def __init__(self, data: Frame, verlet_list, distance_list, rc: float, factor: float = 1.0) -> None:
         self.data = data
         self.verlet_list = verlet_list
@@ -50,6 +58,8 @@ class AtomicTemperature:
         else:
             raise ValueError("No atomic mass.")
         self.T = empty(self.data.shape[0], np.float64)
-        v = [np.ascontiguousarray(as_numpy(self.data[c].to_numpy()) * 1e3 * self.factor) for c in ("vx", "vy", "vz")]
+        v = [self._scaled(c) for c in ("vx", "vy", "vz")]
+        if "amass" in self.data.columns and self.data["amass"].dtype == np.float64 and have_gpu():
+            amass = self.data["amass"]  # (the column's HBM mirror: uploaded once, not with every call)
         kernels.atomtemp.compute_temp(self.verlet_list, self.distance_list, v[0], v[1], v[2], amass, self.T, self.rc,
                                get_num_threads())

@@ -216,6 +216,59 @@ __device__ __forceinline__ void load_row(const int *__restrict__ row, int (&ids)
 }
 const Pos4 *pack_positions(Scope &sc, const double *x, const double *y, const double *z, int64_t N);
 
+// Rows of a list for a thread-per-row kernel, ROW_CHUNK columns at a time through LDS.  A lane that walks its own row reads 4 or
+// 8 bytes at a time from an address M entries away from its neighbour's: every load instruction of the wave touches 64 cache
+// lines, and with rows of 40-50 entries the lines are gone from L1 and L2 before the lane comes back for their next entry — the
+// list is fetched 16-32 times (a 2 GB list walked by `k_cc_hook`, `k_average`, `k_atomic_temp`: 5-7 ms each at 4 M atoms).  Here
+// the 64 rows of a one-wave workgroup are read a chunk at a time in 16-byte requests (four lanes to a row's 16 ids, eight to
+// its 16 distances: whole 64- and 128-byte pieces), entry c of row t lands at [c * 64 + t], and lane t walks its row from there in
+// list order, as before.  Workgroups of 64 threads; `ids` and `dst` are ROW_CHUNK * 64 entries each.
+constexpr int ROW_CHUNK = 16;
+typedef double RowPair __attribute__((ext_vector_type(2), aligned(8)));
+template <bool WITH_DIST>
+__device__ __forceinline__ void stage_row_chunk(const int *__restrict__ verlet, const double *__restrict__ dist, int64_t N, int64_t M,
+                                                int64_t row0, int c0, int *__restrict__ ids, double *__restrict__ dst)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = t; e < 64 * (ROW_CHUNK / 4); e += 64) {
+        const int row = e / (ROW_CHUNK / 4), c = (e % (ROW_CHUNK / 4)) * 4;
+        const int64_t i = row0 + row;
+        if (i < N && c0 + c < M) {
+            const int *src = verlet + i * M + c0 + c;
+            if (c0 + c + 3 < M) {
+                const RowQuad v = *reinterpret_cast<const RowQuad *>(src);
+                ids[(c + 0) * 64 + row] = v.x; ids[(c + 1) * 64 + row] = v.y; ids[(c + 2) * 64 + row] = v.z; ids[(c + 3) * 64 + row] = v.w;
+            } else {
+                for (int k = 0; c0 + c + k < M; ++k) ids[(c + k) * 64 + row] = src[k];
+            }
+        }
+    }
+    if (WITH_DIST) {
+#pragma unroll
+        for (int e = t; e < 64 * (ROW_CHUNK / 2); e += 64) {
+            const int row = e / (ROW_CHUNK / 2), c = (e % (ROW_CHUNK / 2)) * 2;
+            const int64_t i = row0 + row;
+            if (i < N && c0 + c < M) {
+                const double *src = dist + i * M + c0 + c;
+                if (c0 + c + 1 < M) {
+                    const RowPair v = *reinterpret_cast<const RowPair *>(src);
+                    dst[(c + 0) * 64 + row] = v.x; dst[(c + 1) * 64 + row] = v.y;
+                } else {
+                    dst[c * 64 + row] = src[0];
+                }
+            }
+        }
+    }
+}
+// the largest of a per-lane count over the wave (how many chunks the workgroup has to stage)
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
 // An index taken from a caller's list, made safe to dereference: an entry outside [0, n) (a pad of a k-nearest list in a
 // system of fewer than k+1 atoms, a list that belongs to another system) reads atom `fallback` instead of faulting the
 // GPU.  The reference reads out of bounds there (undefined behaviour), so any defined result is as good as its.

@@ -497,48 +497,65 @@ extern "C" int mdh_debug_set_entropy_variant(int v) // 0 automatic, 1 the direct
 
 namespace mdh {
 
-__global__ __launch_bounds__(256) void k_atomic_temp(const int *__restrict__ verlet, const double *__restrict__ dist, int64_t N,
-                                                     int64_t M, const double *__restrict__ vx, const double *__restrict__ vy,
-                                                     const double *__restrict__ vz, const double *__restrict__ mass, double rc,
-                                                     double *__restrict__ T)
+// (velocity, mass) of an atom as one 32-byte record (x, y, z = velocity, w = mass): a neighbour is two 16-byte requests instead of
+// four 8-byte ones from four arrays.  Both sweeps gather every neighbour (42 at rc 5.0 in fcc Cu): 1.3 G requests per call at 4 M
+// atoms, each a 64-byte line from L2 whatever it carries — the kernel's bound (12.7 ms with four arrays)
+__global__ __launch_bounds__(256) void k_pack_velocity_mass(const double *__restrict__ vx, const double *__restrict__ vy,
+                                                            const double *__restrict__ vz, const double *__restrict__ mass, int64_t N,
+                                                            Pos4 *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
+    if (i < N) out[i] = Pos4{vx[i], vy[i], vz[i], mass[i]};
+}
+
+__global__ __launch_bounds__(64) void k_atomic_temp(const int *__restrict__ verlet, const double *__restrict__ dist, int64_t N,
+                                                    int64_t M, const Pos4 *__restrict__ vm, double rc, double *__restrict__ T)
+{
+    __shared__ int ids[ROW_CHUNK * 64];
+    __shared__ double dst[ROW_CHUNK * 64];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    const bool on = i < N;
     constexpr double kb = 1.380649e-23, dim = 3.0, afu = 6.022140857e23;
     constexpr double mass_factor = 1.0 / afu / 1000.0, vel_conv = 1e4;
-    const int *vi = verlet + i * M;
-    const double *di = dist + i * M;
-    const double mi = mass[i];
-    const double vxi = vx[i], vyi = vy[i], vzi = vz[i];
+    const Pos4 self = vm[on ? i : 0];
+    const double mi = self.w;
+    const double vxi = self.x, vyi = self.y, vzi = self.z;
     double sx = vxi * mi, sy = vyi * mi, sz = vzi * mi, ms = mi;
     int n = 1;
-    // Both sweeps read the row eight entries at a time — ids and distances, then the masses and velocities of the eight
-    // neighbours, each group of loads in flight together — and then take the entries in list order up to the first pad, as
-    // the entry-by-entry loop did (same sums, bit for bit): that loop paid two dependent memory latencies per neighbour.
+    // Both sweeps take the rows of the workgroup a chunk of 16 columns at a time through LDS (stage_row_chunk), then eight entries
+    // at a time: the (velocity, mass) records of the eight neighbours in flight together, the entries used in list order up to the
+    // first pad, as the reference's entry-by-entry loop does (same sums, bit for bit).
     auto sweep = [&](auto &&use) {
-        bool stop = false;
-        for (int q0 = 0; q0 < M && !stop; q0 += 8) {
-            int js[8];
-            double ds[8], mj[8], ux[8], uy[8], uz[8];
+        bool stop = !on;
+        for (int c0 = 0; c0 < M; c0 += ROW_CHUNK) {
+            if (!__syncthreads_or(stop ? 0 : 1)) // (also the barrier between the walk of one chunk and the staging of the next)
+                break;
+            stage_row_chunk<true>(verlet, dist, N, M, row0, c0, ids, dst);
+            __syncthreads();
+            for (int q0 = 0; q0 < ROW_CHUNK && c0 + q0 < M && !stop; q0 += 8) {
+                int js[8];
+                double ds[8], mj[8], ux[8], uy[8], uz[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int qq = min(q0 + u, (int)M - 1);
-                js[u] = vi[qq];
-                ds[u] = di[qq];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t jj = (unsigned)js[u] < (unsigned)N ? js[u] : i;
-                mj[u] = mass[jj]; ux[u] = vx[jj]; uy[u] = vy[jj]; uz[u] = vz[jj];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (!stop && q0 + u < M) {
-                    if ((unsigned)js[u] >= (unsigned)N) stop = true; // pad (-1) or an index of another system
-                    else if (js[u] != i && ds[u] <= rc) use(mj[u], ux[u], uy[u], uz[u]);
+                for (int u = 0; u < 8; ++u) {
+                    const int qq = min(q0 + u, min(ROW_CHUNK, (int)M - c0) - 1);
+                    js[u] = ids[qq * 64 + threadIdx.x];
+                    ds[u] = dst[qq * 64 + threadIdx.x];
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t jj = (unsigned)js[u] < (unsigned)N ? js[u] : i;
+                    const Pos4 r = vm[jj];
+                    mj[u] = r.w; ux[u] = r.x; uy[u] = r.y; uz[u] = r.z;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (!stop && c0 + q0 + u < M) {
+                        if ((unsigned)js[u] >= (unsigned)N) stop = true; // pad (-1) or an index of another system
+                        else if (js[u] != i && ds[u] <= rc) use(mj[u], ux[u], uy[u], uz[u]);
+                    }
+            }
         }
+        __syncthreads();
     };
     sweep([&](double mj, double ux, double uy, double uz) { // mass-weighted mean velocity of the neighbourhood (:44-62)
         sx += ux * mj; sy += uy * mj; sz += uz * mj;
@@ -553,7 +570,7 @@ __global__ __launch_bounds__(256) void k_atomic_temp(const int *__restrict__ ver
         dx = ux - mx; dy = uy - my; dz = uz - mz;
         ke += 0.5 * mj * mass_factor * (dx * dx + dy * dy + dz * dz) * vel_conv;
     });
-    T[i] = ke * 2.0 / (dim * n * kb);
+    if (on) T[i] = ke * 2.0 / (dim * n * kb);
 }
 
 // --- connected components: min-index hooking + pointer jumping -------------------------------------------------
@@ -570,32 +587,67 @@ __device__ __forceinline__ int cc_find(int *parent, int i)
 }
 
 // BY_BOND: an entry > -1 is a bond (get_cluster_by_bond :63); otherwise distance <= rc (get_cluster :32)
+// The list is symmetric when this runs (k_cc_fingerprint), so a bond is taken from its larger end only, and the root of the
+// atom's own tree is carried from bond to bond (one read confirms it) instead of walked again.  One pass joins every bond's two
+// trees — the loop does not leave a bond before both ends have one root or its hook went in, and trees only merge; what follows
+// the pass is a check of the labels (k_cc_verify), not a second pass (rounds 2-4 ran one: as long as the first).
 template <bool BY_BOND>
-__global__ __launch_bounds__(256) void k_cc_hook(const int *__restrict__ verlet, const double *__restrict__ dist,
-                                                 const int *__restrict__ nn, int64_t N, int64_t M, double rc,
-                                                 int *__restrict__ parent, int *__restrict__ changed)
+__global__ __launch_bounds__(64) void k_cc_hook(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                int *__restrict__ parent)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    const int n = nn[i];
-    bool any = false;
-    for (int q = 0; q < n; ++q) {
-        const int j = verlet[i * M + q];
-        const bool bond = BY_BOND ? (j > -1) : (dist[i * M + q] <= rc);
-        if (!bond || j < 0 || j >= N)
-            continue;
-        int a = cc_find(parent, (int)i), b = cc_find(parent, j);
-        while (a != b) { // hook the larger root under the smaller one
-            if (a < b) { const int t = a; a = b; b = t; }
-            const int old = atomicMin(&parent[a], b);
-            if (old == a) { any = true; break; }
-            a = cc_find(parent, old < a ? old : a);
-            b = cc_find(parent, b);
-            any = true;
+    __shared__ int ids[ROW_CHUNK * 64];
+    __shared__ double dst[BY_BOND ? 1 : ROW_CHUNK * 64];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    const int n = i < N ? min(nn[i], (int)M) : 0;
+    const int most = wave_max(n);
+    int mine = (int)i; // an ancestor of i: its root as of the last bond
+    for (int c0 = 0; c0 < most; c0 += ROW_CHUNK) {
+        __syncthreads();
+        stage_row_chunk<!BY_BOND>(verlet, dist, N, M, row0, c0, ids, dst);
+        __syncthreads();
+        for (int q = 0; q < ROW_CHUNK && c0 + q < n; ++q) {
+            const int j = ids[q * 64 + threadIdx.x];
+            const bool bond = BY_BOND ? (j > -1) : (dst[q * 64 + threadIdx.x] <= rc);
+            if (!bond || j < 0 || j >= i)
+                continue;
+            int a = cc_find(parent, mine), b = cc_find(parent, j);
+            while (a != b) { // hook the larger root under the smaller one
+                if (a < b) { const int t = a; a = b; b = t; }
+                const int old = atomicMin(&parent[a], b);
+                if (old == a) break;
+                a = cc_find(parent, old < a ? old : a);
+                b = cc_find(parent, b);
+            }
+            mine = a < b ? a : b; // where both trees hang now
         }
     }
-    if (any) *changed = 1;
+}
+
+// after the labels are written: do the two ends of every bond carry one label ?  (the flag stays 0; a 1 sends the caller round again)
+template <bool BY_BOND>
+__global__ __launch_bounds__(64) void k_cc_verify(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                  const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                  const int *__restrict__ cluster, int *__restrict__ flag)
+{
+    __shared__ int ids[ROW_CHUNK * 64];
+    __shared__ double dst[BY_BOND ? 1 : ROW_CHUNK * 64];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    const int n = i < N ? min(nn[i], (int)M) : 0;
+    const int most = wave_max(n);
+    const int ci = i < N ? cluster[i] : 0;
+    bool bad = false;
+    for (int c0 = 0; c0 < most; c0 += ROW_CHUNK) {
+        __syncthreads();
+        stage_row_chunk<!BY_BOND>(verlet, dist, N, M, row0, c0, ids, dst);
+        __syncthreads();
+        for (int q = 0; q < ROW_CHUNK && c0 + q < n; ++q) {
+            const int j = ids[q * 64 + threadIdx.x];
+            const bool bond = BY_BOND ? (j > -1) : (dst[q * 64 + threadIdx.x] <= rc);
+            if (bond && j >= 0 && j < i) bad = bad || cluster[j] != ci;
+        }
+    }
+    if (bad) *flag = 1;
 }
 
 // read-only walk to the root (the forest no longer changes once the hooking passes are over)
@@ -631,28 +683,52 @@ __global__ __launch_bounds__(256) void k_cc_label(const int *__restrict__ parent
 }
 
 // Is every bond i -> j also listed as j -> i?  (cutoff lists are; k-nearest lists and one-sided type filters are not)
-template <bool BY_BOND>
-__global__ __launch_bounds__(256) void k_cc_symmetric(const int *__restrict__ verlet, const double *__restrict__ dist,
-                                                      const int *__restrict__ nn, int64_t N, int64_t M, double rc,
-                                                      int *__restrict__ asym)
+// By a fingerprint: every directed bond adds a 128-bit hash of its unordered pair, with a plus sign from its smaller end and
+// a minus sign from its larger one; both sums are zero when the bonds listed upwards are the bonds listed downwards.  One
+// walk over the atom's own row — the test it replaces looked every bond up in the other atom's row (9.2 ms of the 22 ms of
+// a 4 M-atom cluster analysis).  A list that is not symmetric (or lists a bond twice in one direction only) leaves a
+// non-zero sum unless 128 bits collide, and takes the reference's literal sweep below, which is right for any list.
+__device__ __forceinline__ unsigned long long cc_mix(unsigned long long v)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
-    const int n = nn[i];
-    bool bad = false;
-    for (int q = 0; q < n && !bad; ++q) {
-        const int j = verlet[i * M + q];
-        const bool bond = BY_BOND ? (j > -1) : (dist[i * M + q] <= rc);
-        if (!bond || j < 0 || j >= N)
-            continue;
-        bool back = false;
-        const int nj = nn[j];
-        for (int p = 0; p < nj && !back; ++p)
-            back = verlet[(int64_t)j * M + p] == (int)i && (BY_BOND || dist[(int64_t)j * M + p] <= rc);
-        bad = !back;
+    v ^= v >> 30; v *= 0xbf58476d1ce4e5b9ull;
+    v ^= v >> 27; v *= 0x94d049bb133111ebull;
+    return v ^ (v >> 31);
+}
+template <bool BY_BOND>
+__global__ __launch_bounds__(64) void k_cc_fingerprint(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                       const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                       unsigned long long *__restrict__ sums)
+{
+    __shared__ int ids[ROW_CHUNK * 64];
+    __shared__ double dst[BY_BOND ? 1 : ROW_CHUNK * 64];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    const int n = i < N ? min(nn[i], (int)M) : 0;
+    const int most = wave_max(n);
+    unsigned long long s0 = 0, s1 = 0;
+    for (int c0 = 0; c0 < most; c0 += ROW_CHUNK) {
+        __syncthreads();
+        stage_row_chunk<!BY_BOND>(verlet, dist, N, M, row0, c0, ids, dst);
+        __syncthreads();
+        for (int q = 0; q < ROW_CHUNK && c0 + q < n; ++q) {
+            const int j = ids[q * 64 + threadIdx.x];
+            const bool bond = BY_BOND ? (j > -1) : (dst[q * 64 + threadIdx.x] <= rc);
+            if (!bond || j < 0 || j >= N || j == i)
+                continue;
+            const unsigned long long lo = j < i ? (unsigned long long)j : (unsigned long long)i, hi = j < i ? (unsigned long long)i : (unsigned long long)j;
+            const unsigned long long key = lo * (unsigned long long)N + hi;
+            const unsigned long long h0 = cc_mix(key + 0x9e3779b97f4a7c15ull), h1 = cc_mix(key ^ 0xd6e8feb86659fd93ull);
+            if (j > i) { s0 += h0; s1 += h1; } else { s0 -= h0; s1 -= h1; }
+        }
     }
-    if (bad) *asym = 1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    if (threadIdx.x == 0 && (s0 | s1)) {
+        atomicAdd(sums, s0);
+        atomicAdd(sums + 1, s1);
+    }
 }
 
 // The reference's sweep taken literally, for lists that are NOT symmetric (src/cluster.cpp:14-53, :56-93): seeds in index
@@ -769,8 +845,12 @@ extern "C" int mdh_atomic_temperature(const int *verlet, const double *dist, int
     double *dT = sc.stage(T, (size_t)N, space, false, true);
     if (sc.failed())
         return sc.error();
+    Pos4 *vm = sc.alloc_n<Pos4>((size_t)N);
+    if (!vm)
+        return sc.error();
     ProfRange pr("k_atomic_temp", sc.stream());
-    hipLaunchKernelGGL(k_atomic_temp, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dv, dd, N, M, dvx, dvy, dvz, dm, rc, dT);
+    hipLaunchKernelGGL(k_pack_velocity_mass, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), dvx, dvy, dvz, dm, N, vm);
+    hipLaunchKernelGGL(k_atomic_temp, dim3(grid_for(N, 64)), dim3(64), 0, sc.stream(), dv, dd, N, M, vm, rc, dT);
     return sc.finish(space);
 }
 
@@ -795,17 +875,20 @@ extern "C" int mdh_cluster(const int *verlet, const double *dist, const int *nn,
     int *flag = sc.alloc_n<int>(2);
     if (sc.failed())
         return sc.error();
-    const dim3 grid(grid_for(N, 256)), block(256);
+    const dim3 grid(grid_for(N, 256)), block(256), rgrid(grid_for(N, 64)), rblock(64); // (rgrid: the kernels that stage rows, one wave each)
     {   // directed lists get the reference's sweep itself; symmetric ones (every cutoff list) the union-find below
-        MDH_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+        unsigned long long *sums = sc.alloc_n<unsigned long long>(2);
+        if (!sums)
+            return sc.error();
+        MDH_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(unsigned long long), st));
         if (by_bond)
-            hipLaunchKernelGGL(k_cc_symmetric<true>, grid, block, 0, st, dv, dd, dn, N, M, rc, flag);
+            hipLaunchKernelGGL(k_cc_fingerprint<true>, rgrid, rblock, 0, st, dv, dd, dn, N, M, rc, sums);
         else
-            hipLaunchKernelGGL(k_cc_symmetric<false>, grid, block, 0, st, dv, dd, dn, N, M, rc, flag);
-        int asym = 0;
-        MDH_HIP(hipMemcpyAsync(&asym, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_cc_fingerprint<false>, rgrid, rblock, 0, st, dv, dd, dn, N, M, rc, sums);
+        unsigned long long got[2] = {0, 0};
+        MDH_HIP(hipMemcpyAsync(got, sums, sizeof(got), hipMemcpyDeviceToHost, st));
         MDH_HIP(hipStreamSynchronize(st));
-        if (asym) {
+        if (got[0] | got[1]) {
             int *qa = sc.alloc_n<int>((size_t)N + 1), *qb = sc.alloc_n<int>((size_t)N + 1);
             if (sc.failed())
                 return sc.error();
@@ -821,26 +904,30 @@ extern "C" int mdh_cluster(const int *verlet, const double *dist, const int *nn,
         }
     }
     hipLaunchKernelGGL(k_iota, grid, block, 0, st, parent, N);
-    // one hooking pass joins every bond's two trees (the loop inside retries until its pair is merged); a second pass
-    // only confirms that nothing is left to do.  The flag is read back once per pass: this analysis is not on a hot loop.
-    for (int pass = 0; pass < 64; ++pass) {
-        MDH_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+    // One hooking pass joins every bond's two trees; the labels are then checked bond by bond (k_cc_verify) and the pass is only
+    // repeated — on the forest as it stands — if a bond's ends disagree, which the hooking loop rules out (never seen).  The
+    // flags come back in one copy per round: this analysis is not on a hot loop.
+    int cnt = 0;
+    for (int round = 0; round < 64; ++round) {
+        MDH_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
         if (by_bond)
-            hipLaunchKernelGGL(k_cc_hook<true>, grid, block, 0, st, dv, dd, dn, N, M, rc, parent, flag);
+            hipLaunchKernelGGL(k_cc_hook<true>, rgrid, rblock, 0, st, dv, dd, dn, N, M, rc, parent);
         else
-            hipLaunchKernelGGL(k_cc_hook<false>, grid, block, 0, st, dv, dd, dn, N, M, rc, parent, flag);
-        int h = 0;
-        MDH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_cc_hook<false>, rgrid, rblock, 0, st, dv, dd, dn, N, M, rc, parent);
+        hipLaunchKernelGGL(k_cc_flatten, grid, block, 0, st, parent, N, is_root);
+        MDH_TRY(exclusive_scan_u32(sc, is_root, rank, N));
+        hipLaunchKernelGGL(k_cc_label, grid, block, 0, st, parent, rank, N, dc, flag + 1);
+        if (by_bond)
+            hipLaunchKernelGGL(k_cc_verify<true>, rgrid, rblock, 0, st, dv, dd, dn, N, M, rc, dc, flag);
+        else
+            hipLaunchKernelGGL(k_cc_verify<false>, rgrid, rblock, 0, st, dv, dd, dn, N, M, rc, dc, flag);
+        int back[2] = {0, 0};
+        MDH_HIP(hipMemcpyAsync(back, flag, sizeof(back), hipMemcpyDeviceToHost, st));
         MDH_HIP(hipStreamSynchronize(st));
-        if (!h)
+        cnt = back[1];
+        if (!back[0])
             break;
     }
-    hipLaunchKernelGGL(k_cc_flatten, grid, block, 0, st, parent, N, is_root);
-    MDH_TRY(exclusive_scan_u32(sc, is_root, rank, N));
-    hipLaunchKernelGGL(k_cc_label, grid, block, 0, st, parent, rank, N, dc, flag + 1);
-    int cnt = 0;
-    MDH_HIP(hipMemcpyAsync(&cnt, flag + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    MDH_HIP(hipStreamSynchronize(st));
     if (n_clusters_host) *n_clusters_host = cnt;
     return sc.finish(space);
 }

@@ -1307,21 +1307,35 @@ __global__ __launch_bounds__(256) void k_wrap(double *__restrict__ x, double *__
     x[i] = xi; y[i] = yi; z[i] = zi;
 }
 
-__global__ __launch_bounds__(256) void k_average(double rc, const int *__restrict__ verlet,
-                                                 const double *__restrict__ dist, const int *__restrict__ nn,
-                                                 int64_t N, int64_t M, const double *__restrict__ value,
-                                                 double *__restrict__ out, int include_self)
+// (the rows of the workgroup a chunk at a time through LDS: common.hpp stage_row_chunk)
+__global__ __launch_bounds__(64) void k_average(double rc, const int *__restrict__ verlet,
+                                                const double *__restrict__ dist, const int *__restrict__ nn,
+                                                int64_t N, int64_t M, const double *__restrict__ value,
+                                                double *__restrict__ out, int include_self)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N)
-        return;
+    __shared__ int ids[ROW_CHUNK * 64];
+    __shared__ double dst[ROW_CHUNK * 64];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    const bool on = i < N;
     double s = 0.0;
     int cnt = 0;
-    if (include_self) { s += value[i]; ++cnt; }
-    const int n = nn[i];
-    for (int j = 0; j < n; ++j) // neighbor.cpp:729-736 (sequential sum in list order)
-        if (dist[i * M + j] <= rc) { s += value[safe_id(verlet[i * M + j], i, N)]; ++cnt; }
-    out[i] = cnt > 0 ? s / cnt : 0.0;
+    if (on && include_self) { s += value[i]; ++cnt; }
+    const int n = on ? min(nn[i], (int)M) : 0;
+    const int most = wave_max(n);
+    for (int c0 = 0; c0 < most; c0 += ROW_CHUNK) {
+        __syncthreads();
+        stage_row_chunk<true>(verlet, dist, N, M, row0, c0, ids, dst);
+        __syncthreads();
+        // neighbor.cpp:729-736 (sequential sum in list order); the values of a chunk's entries requested together
+        double val[ROW_CHUNK];
+#pragma unroll
+        for (int q = 0; q < ROW_CHUNK; ++q)
+            val[q] = (c0 + q < n && dst[q * 64 + threadIdx.x] <= rc) ? value[safe_id(ids[q * 64 + threadIdx.x], i, N)] : 0.0;
+#pragma unroll
+        for (int q = 0; q < ROW_CHUNK; ++q)
+            if (c0 + q < n && dst[q * 64 + threadIdx.x] <= rc) { s += val[q]; ++cnt; }
+    }
+    if (on) out[i] = cnt > 0 ? s / cnt : 0.0;
 }
 
 // filter_overlap_atom (neighbor.cpp:390-486): keep[j] = 0 iff some atom i < j lies within rc of j.  The reference lets
@@ -1786,7 +1800,7 @@ int mdh_average_by_neighbor(double rc, const int *verlet, const double *dist, co
     double *dout = sc.stage(value_ave, (size_t)N, space, false, true);
     if (sc.failed())
         return sc.error();
-    hipLaunchKernelGGL(k_average, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), rc, dv, dd, dn, N, M, dval, dout, include_self);
+    hipLaunchKernelGGL(k_average, dim3(grid_for(N, 64)), dim3(64), 0, sc.stream(), rc, dv, dd, dn, N, M, dval, dout, include_self);
     return sc.finish(space);
 }
 }

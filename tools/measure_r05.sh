@@ -54,6 +54,9 @@ analyses)   # configs 2 and 4 at full size through System under the kernel trace
 notebook)   # the reference notebook's published workflow call by call, then the kernels behind the list-reuse form
   python tools/notebook_probe.py both 3 2>&1 | clean | tee $O/r05_notebook.txt
   prof notebook python $R/tools/notebook_probe.py reuse 2 | tee -a $O/r05_notebook.txt ;;
+consumers)   # the list consumers and secondary analyses at 4 M atoms through System: wall times, then the kernels behind them
+  python tools/consumer_times.py 2>&1 | clean | tee $O/r05_consumer_times.txt
+  prof consumers python $R/tools/consumer_times.py | tail -24 | tee -a $O/r05_consumer_times.txt ;;
 sort)
   python tools/sort_probe.py 2>&1 | clean | tee $O/r05_sort_rows.txt ;;
 twin)
