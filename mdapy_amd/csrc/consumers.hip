@@ -8,6 +8,7 @@
 // the arithmetic follows the reference's operation order, so AJA labels are exact and CNP / entropy agree to rounding
 // of exp/log (device libm vs glibc).
 #include "common.hpp"
+#include <cstring>
 
 namespace mdh {
 
@@ -202,6 +203,50 @@ __global__ __launch_bounds__(128) void k_cnp(const double *__restrict__ x, const
         acc += rx * rx + ry * ry + rz * rz;
     }
     cnp[i] = cnt > 0 ? acc / cnt : 1000.0;
+}
+
+// A wide list (more than 16 columns: the analysis borrowed a list built for a larger cutoff) is narrowed first: every row's
+// entries within rc, in their order, into a row of 16, and k_cnp then runs its register form on that.  The general form compared
+// the 42 x 42 entries of every pair's rows straight from memory: 418 ms for 4 M atoms of fcc Cu behind build_neighbor(5.0, 50),
+// against 8.5 ms on the list of the analysis' own cutoff.  What the narrowing must not change is which of an atom's entries a
+// common neighbour is matched to (the first one with that id decides, within rc or not, :83-120): that only differs when an id
+// sits twice in a row, i.e. in a box with a periodic width below twice the list's reach — flags[1] returns the largest listed
+// distance (as bits) for the caller to check that, flags[0] a row that did not fit; either sends the call down the general form.
+constexpr int CNP_NARROW = 16;
+__global__ __launch_bounds__(64) void k_cnp_narrow(const int *__restrict__ verlet, const double *__restrict__ dist,
+                                                   const int *__restrict__ nn, int64_t N, int64_t M, double rc,
+                                                   int *__restrict__ nv, double *__restrict__ nd, int *__restrict__ ncount,
+                                                   unsigned long long *__restrict__ flags)
+{
+    __shared__ int ids[ROW_CHUNK * 64];
+    __shared__ double dst[ROW_CHUNK * 64];
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + threadIdx.x;
+    const int n = i < N ? min(nn[i], (int)M) : 0;
+    const int most = wave_max(n);
+    int cnt = 0;
+    double far = 0.0;
+    for (int c0 = 0; c0 < most; c0 += ROW_CHUNK) {
+        __syncthreads();
+        stage_row_chunk<true>(verlet, dist, N, M, row0, c0, ids, dst);
+        __syncthreads();
+        for (int q = 0; q < ROW_CHUNK && c0 + q < n; ++q) {
+            const double d = dst[q * 64 + threadIdx.x];
+            far = d > far ? d : far;
+            if (d <= rc) {
+                if (cnt < CNP_NARROW) {
+                    nv[i * CNP_NARROW + cnt] = ids[q * 64 + threadIdx.x];
+                    nd[i * CNP_NARROW + cnt] = d;
+                }
+                ++cnt;
+            }
+        }
+    }
+    if (i < N) ncount[i] = min(cnt, CNP_NARROW);
+    const bool over = cnt > CNP_NARROW;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) far = fmax(far, __shfl_xor(far, s, 64));
+    if (__any(over) && threadIdx.x == 0) atomicMax(flags, 1ull);
+    if (threadIdx.x == 0) atomicMax(flags + 1, (unsigned long long)__double_as_longlong(far)); // (distances are >= 0: their bits order as they do)
 }
 
 static constexpr int ENT_MAXBINS = 512;
@@ -415,6 +460,30 @@ extern "C" int mdh_cnp(const double *x, const double *y, const double *z, int64_
     if (sc.failed())
         return sc.error();
     ProfRange pr("k_cnp", sc.stream());
+    if (M > CNP_NARROW) { // a wide list: narrowed to the entries within rc where that changes nothing (k_cnp_narrow)
+        int *nv = sc.alloc_n<int>((size_t)N * CNP_NARROW), *nc = sc.alloc_n<int>((size_t)N);
+        double *nd = sc.alloc_n<double>((size_t)N * CNP_NARROW);
+        unsigned long long *flags = sc.alloc_n<unsigned long long>(2);
+        if (sc.failed())
+            return sc.error();
+        MDH_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned long long), sc.stream()));
+        hipLaunchKernelGGL(k_cnp_narrow, dim3(grid_for(N, 64)), dim3(64), 0, sc.stream(), dv, dd, dn, N, M, rc, nv, nd, nc, flags);
+        unsigned long long back[2] = {0, 0};
+        MDH_HIP(hipMemcpyAsync(back, flags, sizeof(back), hipMemcpyDeviceToHost, sc.stream()));
+        MDH_HIP(hipStreamSynchronize(sc.stream()));
+        double reach;
+        memcpy(&reach, &back[1], sizeof(reach));
+        bool twice = false; // can one atom be listed twice in a row ?  Only through two images: a periodic width below twice the reach
+        for (int d = 0; d < 3; ++d)
+            twice = twice || (b.pbc[d] && b.thick[d] <= 2.0 * reach);
+        if (!back[0] && !twice) {
+            if (b.tri)
+                hipLaunchKernelGGL(k_cnp<true>, dim3(grid_for(N, 128)), dim3(128), 0, sc.stream(), dx, dy, dz, N, b, nv, nd, nc, (int64_t)CNP_NARROW, rc, dc);
+            else
+                hipLaunchKernelGGL(k_cnp<false>, dim3(grid_for(N, 128)), dim3(128), 0, sc.stream(), dx, dy, dz, N, b, nv, nd, nc, (int64_t)CNP_NARROW, rc, dc);
+            return sc.finish(space);
+        }
+    }
     if (b.tri)
         hipLaunchKernelGGL(k_cnp<true>, dim3(grid_for(N, 128)), dim3(128), 0, sc.stream(), dx, dy, dz, N, b, dv, dd, dn, M, rc, dc);
     else

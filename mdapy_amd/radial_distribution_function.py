@@ -30,7 +30,10 @@ class RadialDistributionFunction:
             self.verlet_list, self.distance_list, self.neighbor_number = verlet_list, distance_list, neighbor_number
             self.N = int(verlet_list.shape[0])
         labels = np.zeros(self.N, dtype=np.int32) if type_list is None else np.asarray(type_list)
-        self.elements, self.type_list = policy.label_codes(labels, device_ok=self.streaming)  # (streaming: the codes only ever go to the kernel)
+        # (the codes only go to the kernel — and to whoever reads `type_list`, for whom an array in HBM converts itself: streaming, or
+        # a list that lives in HBM; the host passes over a 4 M-label column are 19 ms of the first call on a new System)
+        in_hbm = self.streaming or type(verlet_list).__name__ in ("HArray", "LazyHArray")
+        self.elements, self.type_list = policy.label_codes(labels, device_ok=in_hbm)
         self.Ntype = len(self.elements)
 
     def _pair_counts(self):

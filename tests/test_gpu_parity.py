@@ -1302,6 +1302,43 @@ def test_structure_entropy_ladder_and_direct_kernels_vs_oracle(sigma):
         _lib.check(_lib.lib().mdh_debug_set_entropy_variant(0))
 
 
+@pytest.mark.parametrize("cells,sigma", [(9, 0.08), (2, 0.05), (7, 0.3)])
+def test_list_consumers_on_a_borrowed_wide_list_vs_oracle(cells, sigma):
+    """the reference's policy hands an analysis any held cutoff list that reaches far enough: here a list built for 5.0 A (42+ columns)
+    under analyses that want 3.1-3.3 A — common neighbour parameter (narrowed to 16 columns first; the 2-cell box is narrower than
+    twice the list's reach, where an atom could be listed twice in a row, and must take the general form; the hot 7-cell one has rows of more than 16 within rc), cluster analysis, neighbour
+    average, atomic temperature, list RDF"""
+    from mdapy_amd import _rdf
+    pos, box = _fcc(cells, sigma, 5)
+    x, y, z = _xyz(pos)
+    N = len(x)
+    rng = np.random.default_rng(3)
+    v, d, nn = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, 5.0, 4)
+    assert v.shape[1] > 16
+    for rc in (3.1, 3.3):
+        c0, c1 = np.zeros(N), np.full(N, -1.0)
+        O.compute_cnp(x, y, z, box, ORG0, PBC, v, d, nn, c0, rc, 4)
+        _cnp.compute_cnp(x, y, z, box, ORG0, PBC, v, d, nn, c1, rc, 1)
+        assert np.allclose(c1, c0, rtol=1e-9, atol=1e-12)
+        k0, k1 = np.full(N, -1, np.int32), np.full(N, -7, np.int32)
+        assert _cluster.get_cluster(v, d, nn, rc - 0.5, k1) == O.get_cluster(v, d, nn, rc - 0.5, k0) and np.array_equal(k1, k0)
+        val = rng.random(N)
+        a0, a1 = np.zeros(N), np.full(N, -1.0)
+        O.average_by_neighbor(rc, v, d, nn, val, a0, True)
+        _neighbor.average_by_neighbor(rc, v, d, nn, val, a1, True)
+        assert np.array_equal(a1, a0)
+    vel = rng.normal(0, 300.0, (N, 3)); mass = rng.choice([26.98, 63.546], N)
+    t0, t1 = np.zeros(N), np.full(N, -1.0)
+    O.compute_temp(v, d, vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy(), mass, t0, 4.2, 4)
+    _atomtemp.compute_temp(v, d, vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy(), mass, t1, 4.2, 1)
+    assert np.allclose(t1, t0, rtol=1e-12, atol=0)
+    ty = rng.integers(0, 2, N).astype(np.int32)
+    g0, g1 = np.zeros((2, 2, 50)), np.zeros((2, 2, 50))
+    O._rdf(v, d, nn, ty, g0, 4.5, 50)
+    _rdf._rdf(v, d, nn, ty, g1, 4.5, 50)
+    assert np.array_equal(g1, g0) and g0.sum() > 0
+
+
 AJA_PATHS, CNP_PATHS = fixtures_with("aja"), fixtures_with("cnp")
 
 
