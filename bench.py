@@ -3,14 +3,19 @@
 
 A "step" is one pass of the hot path over the whole (synthetic) system, positions already resident in HBM: cell-list
 neighbor build (rc = 0.854 a, max_neigh = 16: the `System.cal_common_neighbor_analysis(rc)` configuration the reference's
-own CNA tests and SURVEY.md 6 use) followed by fixed-cutoff CNA, all through the C ABI of libmdapy_amd.so with device
-pointers.  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling, the default) — or,
+own CNA tests and SURVEY.md 6 use) and fixed-cutoff CNA, through the C ABI of libmdapy_amd.so with device pointers — since
+round 5 as ONE call (mdh_build_neighbor_fcna: the lists as build_neighbor leaves them AND the labels as fcna leaves them, the
+label of a centre worked out inside the tile kernel while its neighbours are still staged in LDS; what
+`System.cal_common_neighbor_analysis(rc)` runs when the system has no list yet).  `extra.two_calls` times the same step as the
+two calls it was until then (mdh_build_neighbor, then mdh_fcna), with the plain neighbour kernel's own roofline figure.  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling, the default) — or,
 with --scaling strong, a 136/N-cell slab of the one 136^3 box — and exchanges a one-cutoff ghost halo with its two ring
 neighbours over RCCL each step.
 
 Prints ONE JSON line (rank 0):
-* `roofline` is for the dominant kernel of the step (the neighbor kernel, `k_neighbor` = everything between the cell grid
-  and the CNA of one build), timed with HIP events recorded inside the library on the launch stream.  `traffic` is the
+* `roofline` is for the dominant kernel of the step (the tile kernel, `k_neighbor` = everything between the cell grid
+  and the CNA's to-do kernel: it writes the lists AND the labels), timed with HIP events recorded inside the library on the
+  launch stream; its algorithmic bytes are what it must move — 24 B of position read, 4 B count, 12 M B of rows and the 4 B label
+  written per atom (SURVEY.md 8d counts the list a second time for a CNA that reads it back: 60 + 16 M; the fused kernel does not).  `traffic` is the
   HBM byte count of that kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) taken by THIS run when rocprofv3 is
   on PATH (`traffic_source: "live"`), else the committed measurement under profiles/ (`"committed"`); FETCH_SIZE is
   doubled as MI355X_MICROARCH.md prescribes for gfx950 (the raw sum is reported beside it).
@@ -314,8 +319,9 @@ def pmc_child(args):
     box = mp.Box(np.diag([A_CU * args.cells] * 3))
     verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty((n, M), dtype=torch.float64, device=dev)
     nn = torch.empty((n,), dtype=torch.int32, device=dev)
+    pat = torch.zeros((n,), dtype=torch.int32, device=dev)
     for _ in range(2):
-        _neighbor.build_neighbor(x, y, z, box.box, box.origin, box.boundary, RC, verlet, dist, nn, 1, fill_pads=True)
+        _neighbor.build_neighbor_fcna(x, y, z, box.box, box.origin, box.boundary, RC, verlet, dist, nn, pat, 1, fill_pads=True)
     torch.cuda.synchronize()
 
 
@@ -512,6 +518,11 @@ def main():
 
         def step():
             pattern.zero_()  # the kernels rely on the caller's pre-zeroing (common_neighbor_analysis.py:128)
+            _neighbor.build_neighbor_fcna(x, y, z, *bx, RC, verlet, distl, nn, pattern, 1, fill_pads=True)
+            return nn, pattern, None
+
+        def step_two_calls():  # the same step as the two reference calls one after the other (the headline until round 5)
+            pattern.zero_()
             _neighbor.build_neighbor(x, y, z, *bx, RC, verlet, distl, nn, 1, fill_pads=True)
             _cna.fcna(x, y, z, *bx, verlet, nn, pattern, RC, 1)
             return nn, pattern, None
@@ -593,7 +604,8 @@ def main():
         if "k_neighbor" in prof:
             cnt, tot = prof["k_neighbor"]
             avg_ms = tot / cnt
-            alg_bytes = (28 + 12 * M) * n_rows  # read x,y,z (24 B) + write nn (4 B) + rows (12 M B) per atom
+            # read x,y,z (24 B) + write nn (4 B) + rows (12 M B) per atom, and the label this kernel writes as well (4 B)
+            alg_bytes = (28 + 12 * M + 4) * n_rows
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic = traffic_raw = None
             source = None
@@ -607,7 +619,8 @@ def main():
                     with open(tpath) as fh:
                         t = json.load(fh)
                     traffic, traffic_raw, source = t["traffic_bytes_per_launch_fetch_x2"], t["traffic_bytes_per_launch_raw"], "committed"
-            res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor (k_neighbor_lane, the instance that also labels: lists + CNA in one pass)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw_fetch_plus_write": traffic_raw,
                                "traffic_source": source, "avg_kernel_ms": avg_ms, "launches": cnt,
                                "algorithmic_bytes_per_launch": alg_bytes}
@@ -616,11 +629,26 @@ def main():
                                       f"{min(args.steps, 10)} steps after them (an event pair costs ~8 us of stream time per range and step)")
         if world == 1 and not args.no_extra:
             extra = {}
-            # (a) the default API path: max_neigh=None -> exact-width rows, counting pass + build on one cell grid
+            # (0) the headline step as the two calls it was until round 5: mdh_build_neighbor, then mdh_fcna — with the plain neighbour
+            # kernel's own roofline figure ((28 + 12 M) B per atom), the number the earlier rounds' lines carry
+            try:
+                k = max(5, args.steps // 2)
+                e0, o0, p0 = timed(step_two_calls, k, 3)
+                ok0 = bool((o0[0] == 12).all().item()) and bool((o0[1] == 1).all().item()) if args.sigma == 0.0 else True
+                km = {k_: v_[1] / v_[0] for k_, v_ in p0.items()}
+                extra["two_calls"] = {"ms_per_step": e0 / k * 1e3, "atoms_per_s": n_local / (e0 / k), "kernels_ms": km, "result_ok": ok0,
+                                      "ratio_one_call_to_two": ms_per_step / (e0 / k * 1e3)}
+                if "k_neighbor" in km:
+                    a0 = (28 + 12 * M) * n_local / (km["k_neighbor"] * 1e-3) / 1e9
+                    extra["two_calls"]["plain_neighbor_kernel_roofline"] = {"achieved": a0, "frac": a0 / HBM_PEAK_GBS, "alg_B_per_atom": 28 + 12 * M}
+            except Exception as e:
+                extra["two_calls"] = {"error": f"{type(e).__name__}: {e}"}
+
+            # (a) the default API path: max_neigh=None -> exact-width rows, counting pass + build on one cell grid (and the labels
+            # in the pass that builds: mdh_build_neighbor_exact_fcna)
             def step_exact():
-                v_, d_, n_ = _neighbor.build_neighbor_without_max_neigh(x, y, z, *bx, RC, 1)
                 p_ = torch.zeros((n_local,), dtype=torch.int32, device=dev)
-                _cna.fcna(x, y, z, *bx, v_, n_, p_, RC, 1)
+                v_, d_, n_ = _neighbor.build_neighbor_without_max_neigh(x, y, z, *bx, RC, 1, pattern=p_)
                 return n_, p_, v_
 
             del verlet, distl
@@ -633,11 +661,16 @@ def main():
             v3 = torch.empty((n_local, M), dtype=torch.int32, device=dev); d3 = torch.empty((n_local, M), dtype=torch.float64, device=dev)
             cnt4 = (ctypes.c_int64 * 4)()
 
-            def other_input(xs, ys, zs, bxs, n_at):
+            def other_input(xs, ys, zs, bxs, n_at, both=False):
                 nn_, pat_ = nn[:n_at], pattern[:n_at]
                 v_, d_ = v3[:n_at], d3[:n_at]
 
-                def step_other():
+                def step_other():  # the one call of the headline step
+                    pat_.zero_()
+                    _neighbor.build_neighbor_fcna(xs, ys, zs, *bxs, RC, v_, d_, nn_, pat_, 1, fill_pads=True)
+                    return nn_, pat_, None
+
+                def step_other_two():  # the two calls it replaces
                     pat_.zero_()
                     _neighbor.build_neighbor(xs, ys, zs, *bxs, RC, v_, d_, nn_, 1, fill_pads=True)
                     _cna.fcna(xs, ys, zs, *bxs, v_, nn_, pat_, RC, 1)
@@ -645,19 +678,28 @@ def main():
 
                 k = max(3, args.steps // 4)
                 e_, o_, p_ = timed(step_other, k, 2)
-                L.mdh_debug_track_counters(1)
-                step_other(); step_other(); torch.cuda.synchronize()
+                lab = torch.bincount(o_[1], minlength=5).tolist()
+                mx = int(o_[0].max().item())
+                two = None
+                if both:
+                    e2_, o2_, p2_ = timed(step_other_two, k, 2)
+                    two = {"ms_per_step": e2_ / k * 1e3, "kernels_ms": {k_: v_[1] / v_[0] for k_, v_ in p2_.items()},
+                           "labels_equal": torch.bincount(o2_[1], minlength=5).tolist() == lab}
+                L.mdh_debug_track_counters(1)  # (the counters of the two-call form: the CNA's double-precision list, the slice pass of the build)
+                step_other_two(); step_other_two(); torch.cuda.synchronize()
                 L.mdh_debug_counters(cnt4)
                 L.mdh_debug_track_counters(0)
-                lab = torch.bincount(o_[1], minlength=5).tolist()
-                return {"atoms": n_at, "ms_per_step": e_ / k * 1e3, "atoms_per_s": n_at / (e_ / k), "fcc_fraction": lab[1] / n_at,
-                        "labels_other_fcc_hcp_bcc_ico": lab[:5], "max_neighbors": int(o_[0].max().item()),
-                        "todo_fraction": max(int(cnt4[0]), 0) / n_at, "cna_todo_atoms": int(cnt4[0]), "tiles_to_slice_pass": int(cnt4[1]),
-                        "kernels_ms": {k_: v_[1] / v_[0] for k_, v_ in p_.items()}}
+                got = {"atoms": n_at, "ms_per_step": e_ / k * 1e3, "atoms_per_s": n_at / (e_ / k), "fcc_fraction": lab[1] / n_at,
+                       "labels_other_fcc_hcp_bcc_ico": lab[:5], "max_neighbors": mx,
+                       "todo_fraction": max(int(cnt4[0]), 0) / n_at, "cna_todo_atoms": int(cnt4[0]), "tiles_to_slice_pass": int(cnt4[1]),
+                       "kernels_ms": {k_: v_[1] / v_[0] for k_, v_ in p_.items()}}
+                if two is not None:
+                    got["two_calls"] = two
+                return got
 
             for sg in (0.05, 0.20):
                 xs, ys, zs, _ = slab_positions(torch, dev, cells, 0, sg)
-                extra[f"sigma_{sg:.2f}"] = other_input(xs, ys, zs, bx, n_local)
+                extra[f"sigma_{sg:.2f}"] = other_input(xs, ys, zs, bx, n_local, both=True)
                 del xs, ys, zs
             # (b0) atom ORDER: the headline lattice under one random permutation of its atoms (the reference's linked-list cell build
             # does not care in which order atoms arrive, neighbor.cpp:64-100; these kernels' gathers and atomics do)

@@ -287,6 +287,13 @@ int mdh_build_neighbor_exact(const double *x, const double *y, const double *z, 
 int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                                    const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
                                    mdh_alloc_rows_fn alloc, void *user, const int64_t *key, int space, void *stream);
+/* the same, and the fixed-cutoff CNA labels of this cutoff in the same pass over the tiles (mdh_build_neighbor_fcna at the exact
+ * width): what System.cal_common_neighbor_analysis(rc) runs when it has no list yet — build_neighbor(rc, max_neigh=None), then
+ * fcna (src/neighbor.cpp:189-349, then src/cna.cpp:429-506).  pattern (N) i32, caller-initialised, as mdh_fcna leaves it; NULL:
+ * no labels (mdh_build_neighbor_exact_keyed).  key as above, or NULL. */
+int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                  const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
+                                  mdh_alloc_rows_fn alloc, void *user, int *pattern, const int64_t *key, int space, void *stream);
 
 /* replaces _neighbor.sort_verlet_by_distance               src/neighbor.cpp:745-775 */
 int mdh_sort_verlet_by_distance(int *verlet, double *dist, int64_t N, int64_t M, int sort_num, int space,

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "mdh_neighbor_count": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, cint, vp],
     "mdh_build_neighbor_exact": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, cint, vp],
     "mdh_build_neighbor_exact_keyed": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, vp, cint, vp],
+    "mdh_build_neighbor_exact_fcna": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, ALLOC_ROWS, vp, vp, vp, cint, vp],
     "mdh_sort_verlet_by_distance": [vp, vp, i64, i64, cint, cint, vp],
     "mdh_wrap_positions": [vp, vp, vp, i64, vp, vp, vp, cint, vp],
     "mdh_average_by_neighbor": [dbl, vp, vp, vp, i64, i64, vp, vp, cint, cint, vp],

@@ -60,12 +60,14 @@ def build_neighbor_fcna(x, y, z, box, origin, boundary, rc, verlet_list, distanc
     c.done(rc_)
 
 
-def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1, key=None):
+def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1, key=None, pattern=None):
     """src/neighbor.cpp:189: exact row width = max neighbour count (>= 1); returns (verlet, dist, nn).
     One library call (mdh_build_neighbor_exact): the cell grid is built once for the counting pass and the build; the rows
     are allocated between the two through a callback, as the reference allocates them inside the call (:312-317).
     The arrays are HBM resident when the inputs are (or when a GPU is present and inputs are frame columns).
-    ``key`` (i64, N): as in ``build_neighbor`` (mdh_build_neighbor_exact_keyed)."""
+    ``key`` (i64, N): as in ``build_neighbor`` (mdh_build_neighbor_exact_keyed).
+    ``pattern`` (i32, N, caller-initialised; extension): the fixed-cutoff CNA labels of this cutoff as ``_cna.fcna`` would leave
+    them on the finished lists, written in the same pass over the tiles (mdh_build_neighbor_exact_fcna)."""
     import ctypes
 
     keep, (pb, po, pp) = _lib.host_box(box, origin, boundary)
@@ -92,10 +94,11 @@ def build_neighbor_without_max_neigh(x, y, z, box, origin, boundary, rc, num_t=1
             return 1
 
     width = ctypes.c_int64(0)
-    c = Call(x, y, z, nn, key)
-    rc_ = _lib.lib().mdh_build_neighbor_exact_keyed(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
-                                                    c.out(nn, i32, upload=False), ctypes.addressof(width), alloc, None,
-                                                    c.inp(key, np.int64), c.space, c.stream)
+    c = Call(x, y, z, nn, key, pattern)
+    rc_ = _lib.lib().mdh_build_neighbor_exact_fcna(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), N, pb, po, pp, float(rc),
+                                                   c.out(nn, i32, upload=False), ctypes.addressof(width), alloc, None,
+                                                   c.out(pattern, i32) if pattern is not None else None,
+                                                   c.inp(key, np.int64), c.space, c.stream)
     c.done(rc_)
     return rows["v"], rows["d"], nn
 

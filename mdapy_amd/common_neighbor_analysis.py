@@ -29,15 +29,20 @@ class CommonNeighborAnalysis:
             return frame, cell, policy.nearest_rows(frame, cell, ADAPTIVE_DEPTH), None
         frame, cell, _ = policy.widened(frame, cell, 2.0 * self.rc)
         found = Neighbor(self.rc, cell, frame)
-        found.compute()
+        found.compute(label=True)  # (the labels in the pass that builds the list, where that applies)
+        self._labels = found.pattern
         return frame, cell, found.verlet_list, found.neighbor_number
 
     def compute(self):
         if policy.hopeless(self.box, self.data.shape[0], ADAPTIVE_DEPTH):
             self.pattern = np.zeros(self.data.shape[0], dtype=np.int32)
             return
+        self._labels = None
         if self.verlet_list is None:
             frame, cell, rows, counts = self._own_lists()
+            if self._labels is not None and self._labels.shape[0] == frame.shape[0]:
+                self.pattern = self._labels
+                return
         else:
             frame, cell, rows, counts = self.data, self.box, self.verlet_list, self.neighbor_number
             assert counts is not None or self.rc is None

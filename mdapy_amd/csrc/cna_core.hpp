@@ -47,6 +47,30 @@ __device__ __forceinline__ RowsLds spill_rows(const Rows &R, unsigned short *bas
     return RowsLds{base, stride};
 }
 
+// The rows where they are — NN registers — for a caller with no LDS to spare (the fused kernel of neighbor_lane.hip): a row fetched
+// by a computed index is a chain of NN - 1 selects; only the cluster walks of signature() fetch rows that way (six bonds on six
+// atoms, the (6,6,6) of bcc), cna_counts_words() decides everything else from the packed words.
+template <int NN>
+struct RowsReg {
+    unsigned v[NN]; // (a copy, every index a constant: stays in registers)
+    __device__ __forceinline__ explicit RowsReg(const unsigned (&adj)[NN])
+    {
+#pragma unroll
+        for (int k = 0; k < NN; ++k) v[k] = adj[k];
+    }
+    __device__ __forceinline__ unsigned row(int a) const
+    {
+        unsigned r = v[0];
+#pragma unroll
+        for (int k = 1; k < NN; ++k) {
+            unsigned t = v[k];
+            asm("" : "+v"(t)); // (opaque: left to itself the compiler turns the chain into an indexed array in scratch memory)
+            r = (a == k) ? t : r;
+        }
+        return r;
+    }
+};
+
 // (ncn, nb, chain) of the bond centre--neighbour ni.  Only neighbours in `limit_mask`
 // take part in the bond search (cna.cpp:69-92; the adaptive 12-neighbour pass hands 12, :344).
 template <class RT>
@@ -227,8 +251,8 @@ struct CnaCounts { int n421, n422, n555, n444, n666; };
 // past that number skips the rest of its bonds; the counts it returns are then incomplete, and every caller's label tests fail on
 // them as they would on the complete ones.  On a lattice nothing is skipped; in a liquid nearly every atom is decided by its
 // first bonds and a wave leaves once its last lane is (the general cluster walks below were most of the kernel's time there).
-template <int NN, int MAXO = NN>
-__device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN], const RowsLds &L)
+template <int NN, int MAXO = NN, class RT = RowsLds>
+__device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN], const RT &L)
 {
     constexpr int NW = (NN + 1) / 2;
     unsigned P[NW];
@@ -265,10 +289,10 @@ __device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN],
     }
     return CnaCounts{n421, n422, n555, n444, n666};
 }
-template <int NN>
-__device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RowsLds &L)
+template <int NN, class RT = RowsLds>
+__device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RT &L)
 {
-    const CnaCounts c = cna_counts_words<NN, NN - 12>(adj, L); // (12 neighbours: no stray bond; 14: two, n421 == 12 of 14)
+    const CnaCounts c = cna_counts_words<NN, NN - 12, RT>(adj, L); // (12 neighbours: no stray bond; 14: two, n421 == 12 of 14)
     if (c.n421 == 12) return 1; // cna.cpp:496-503
     if (c.n421 == 6 && c.n422 == 6) return 2;
     if (c.n555 == 12) return 4;

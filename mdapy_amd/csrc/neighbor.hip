@@ -33,7 +33,11 @@ int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kern
 // cell assignment: wrap, bin, take a slot from the cell's atomic counter
 // ----------------------------------------------------------------------------
 struct CellPlanes { int p0, p1, p2, p3; int *bad; }; // planes [p0, p1) and [p2, p3) of axis 0 hold every atom (bad == nullptr: not promised; else a pinned host word)
-template <bool TRI>
+// K atoms per lane: a wave takes 64 * K consecutive atoms as K slices of 64 (slice k: atom base + 64 k + lane, so adjacent lanes
+// still hold adjacent atoms and the runs below are found per slice).  The kernel is a chain of dependent memory trips — position
+// loads, the returning atomic, the stores — at full occupancy (26-34 VGPRs; 87 % of the wave-cycles waiting,
+// profiles/r05_step_counters.json): with K > 1 the loads of a lane's K atoms are in flight together, and so are its K atomics.
+template <bool TRI, int K>
 __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, int64_t N, DBox b, Grid g,
                                                 int wrap_first, int *__restrict__ cell_id, int *__restrict__ rank,
@@ -41,84 +45,103 @@ __global__ __launch_bounds__(256) void k_assign(const double *__restrict__ x, co
                                                 double slack, unsigned short *__restrict__ mv, CellPlanes win,
                                                 CellGrid::Packed *__restrict__ rec, int drop_absent)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 * K) + lane;
     bool moved = false, outside = false, coded = false;
-    int cell = -1 - (int)(threadIdx.x & 63); // lanes past the end: distinct negative values, no run, no atomic
-    // an atom whose x is NaN is ABSENT: it takes no cell, appears in nobody's row and gets no row of its own (the unused slots of a
-    // decomposed system's fixed-size ghost block, slab.hip k_slab_append_static; the reference has no meaning for such input)
-    // (only the neighbor builds — drop_absent — know what to do without such an atom: their kernels walk cells, and their per-atom
-    // passes end at the number of atoms binned; every other user of the grid bins a NaN as it always did, into cell 0)
-    const bool absent = drop_absent && i < N && x[i] != x[i];
-    if (absent) {
-        cell_id[i] = -1;
-        if (mv) mv[i] = (unsigned short)img::ATOM_NEUTRAL;
-    }
-    if (i < N && !absent) {
-        const double xr = x[i], yr = y[i], zr = z[i];
-        double xi = xr, yi = yr, zi = zr;
-        int code = img::ATOM_NEUTRAL; // (m + 15) per axis: raw = wrapped + m*L
-        if (wrap_first && b.anypbc) { // neighbor.cpp:88-91
-            wrap<TRI>(b, xi, yi, zi);
-            if (!TRI) {
-                // whole box lengths between the raw and the wrapped coordinate (an unwrapped trajectory: a few); more than
-                // img::MAX_M of them, or a coordinate that is not wrapped + m L to within `slack`, invalidates the image codes
-                // for this call (flags[0])
-                const double raw[3] = {xr, yr, zr}, wrp[3] = {xi, yi, zi};
-                code = 0;
+    double xr[K], yr[K], zr[K];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    double m = 0.0;
-                    if (b.pbc[d] && raw[d] != wrp[d]) { // already wrapped (the common case): m = 0, no division
-                        m = rint((raw[d] - wrp[d]) / b.h[d * 4]);
-                        if (!(fabs(m) <= (double)img::MAX_M) || !(fabs(raw[d] - m * b.h[d * 4] - wrp[d]) <= slack)) { moved = true; m = 0.0; }
+    for (int k = 0; k < K; ++k) { // (all loads of the lane first)
+        const int64_t i = i0 + 64 * k;
+        xr[k] = yr[k] = zr[k] = 0.0;
+        if (i < N) { xr[k] = x[i]; yr[k] = y[i]; zr[k] = z[i]; }
+    }
+    int cells[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t i = i0 + 64 * k;
+        int cell = -1 - lane; // lanes past the end: distinct negative values, no run, no atomic
+        // an atom whose x is NaN is ABSENT: it takes no cell, appears in nobody's row and gets no row of its own (the unused slots of a
+        // decomposed system's fixed-size ghost block, slab.hip k_slab_append_static; the reference has no meaning for such input)
+        // (only the neighbor builds — drop_absent — know what to do without such an atom: their kernels walk cells, and their per-atom
+        // passes end at the number of atoms binned; every other user of the grid bins a NaN as it always did, into cell 0)
+        const bool absent = drop_absent && i < N && xr[k] != xr[k];
+        if (absent) {
+            cell_id[i] = -1;
+            if (mv) mv[i] = (unsigned short)img::ATOM_NEUTRAL;
+        }
+        if (i < N && !absent) {
+            double xi = xr[k], yi = yr[k], zi = zr[k];
+            int code = img::ATOM_NEUTRAL; // (m + 15) per axis: raw = wrapped + m*L
+            if (wrap_first && b.anypbc) { // neighbor.cpp:88-91
+                wrap<TRI>(b, xi, yi, zi);
+                if (!TRI) {
+                    // whole box lengths between the raw and the wrapped coordinate (an unwrapped trajectory: a few); more than
+                    // img::MAX_M of them, or a coordinate that is not wrapped + m L to within `slack`, invalidates the image codes
+                    // for this call (flags[0])
+                    const double raw[3] = {xr[k], yr[k], zr[k]}, wrp[3] = {xi, yi, zi};
+                    code = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        double m = 0.0;
+                        if (b.pbc[d] && raw[d] != wrp[d]) { // already wrapped (the common case): m = 0, no division
+                            m = rint((raw[d] - wrp[d]) / b.h[d * 4]);
+                            if (!(fabs(m) <= (double)img::MAX_M) || !(fabs(raw[d] - m * b.h[d * 4] - wrp[d]) <= slack)) { moved = true; m = 0.0; }
+                        }
+                        code |= ((int)m + 15) << (5 * d);
                     }
-                    code |= ((int)m + 15) << (5 * d);
                 }
             }
+            if (mv) mv[i] = (unsigned short)code;
+            // scattered input (mdh_spatial_sort): the atom as ONE 32-byte record in input order — the gather then reads one random
+            // sector per atom instead of three (x, y, z) or four (the image code)
+            if (rec) rec[i] = CellGrid::Packed{xr[k], yr[k], zr[k], (int)i, code};
+            coded = coded || code != img::ATOM_NEUTRAL;
+            int c0, c1, c2;
+            cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
+            cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
+            if (win.bad && !((c0 >= win.p0 && c0 < win.p1) || (c0 >= win.p2 && c0 < win.p3))) {
+                // an atom outside the window of planes the caller promised (mdh_hint_cell_window): the counters out there were
+                // never zeroed — it takes no slot and is not scattered (cell -1); the build is reported broken (win.bad), its
+                // rows are not to be used, and nothing is written out of bounds
+                outside = true;
+                cell = -1 - lane;
+            }
+            cell_id[i] = cell;
         }
-        if (mv) mv[i] = (unsigned short)code;
-        // scattered input (mdh_spatial_sort): the atom as ONE 32-byte record in input order — the gather then reads one random
-        // sector per atom instead of three (x, y, z) or four (the image code)
-        if (rec) rec[i] = CellGrid::Packed{xr, yr, zr, (int)i, code};
-        coded = code != img::ATOM_NEUTRAL;
-        int c0, c1, c2;
-        cell_coords<TRI>(b, g, xi, yi, zi, c0, c1, c2);
-        cell = (c0 * g.nc[1] + c1) * g.nc[2] + c2; // neighbor.cpp:24-27 (ncell < 2^31 checked on the host)
-        if (win.bad && !((c0 >= win.p0 && c0 < win.p1) || (c0 >= win.p2 && c0 < win.p3))) {
-            // an atom outside the window of planes the caller promised (mdh_hint_cell_window): the counters out there were
-            // never zeroed — it takes no slot and is not scattered (cell -1); the build is reported broken (win.bad), its
-            // rows are not to be used, and nothing is written out of bounds
-            outside = true;
-            cell = -1 - (int)(threadIdx.x & 63);
-        }
-        cell_id[i] = cell;
+        cells[k] = cell;
     }
     // One returning atomic per RUN of adjacent lanes in the same cell instead of one per atom: atoms usually arrive in some
     // spatial order (a lattice builder, a file written cell by cell, a previous sort), so neighbouring lanes share cells;
     // the slot inside a cell is arbitrary anyway (k_sort_cells restores the reference's order).  Unordered input pays a
     // ballot and two shuffles.
-    {
-        const int lane = threadIdx.x & 63;
+    unsigned base[K];
+    int first[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { // (the K atomics of the lane in flight together)
+        const int cell = cells[k];
         const int prev = __shfl_up(cell, 1, 64);
         const bool head = lane == 0 || prev != cell || cell < 0;
         const unsigned long long heads = __ballot(head);
-        const int first = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));          // head of this lane's run
+        first[k] = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));                   // head of this lane's run
         const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
         const int last = later ? lane + __builtin_ctzll(later) : 63;                        // last lane of the run, as seen from its head
-        unsigned base = 0;
+        base[k] = 0;
         if (head && cell >= 0)
-            base = atomicAdd(&cell_count[cell], (unsigned)(last - lane + 1));
-        base = __shfl(base, first, 64);
-        if (cell >= 0)
-            rank[i] = (int)(base + (unsigned)(lane - first));
+            base[k] = atomicAdd(&cell_count[cell], (unsigned)(last - lane + 1));
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned bs = __shfl(base[k], first[k], 64);
+        if (cells[k] >= 0)
+            rank[i0 + 64 * k] = (int)(bs + (unsigned)(lane - first[k]));
     }
     // what this kernel finds out about the input goes into generation-stamped control words (no memset per build): the scan
     // that follows turns them into the build's flags[0] (unwrapped input) and flags[4] (image codes present)
-    if (__any(moved) && (threadIdx.x & 63) == 0)
+    if (__any(moved) && lane == 0)
         ctl[1] = gen;
-    if (__any(coded) && (threadIdx.x & 63) == 0)
+    if (__any(coded) && lane == 0)
         ctl[2] = gen; // some atom was handed in outside the box: the gather has to read the image codes (else they are all neutral)
-    if (__any(outside) && (threadIdx.x & 63) == 0)
+    if (__any(outside) && lane == 0)
         *win.bad = 1; // (pinned host memory: read by the next build of the thread / mdh_cell_window_check)
 }
 
@@ -721,10 +744,16 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         hipLaunchKernelGGL(k_order_far_flag, dim3(1), dim3(1024), 0, st, x, y, z, N, b, nb[0], nb[1], nb[2], rec_flag);
     }
     const unsigned gen = next_scan_gen(); // stamps of this build's k_assign; the (first) scan below is launched with the same value
-    if (b.tri)
-        hipLaunchKernelGGL(k_assign<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_assign<false>, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0);
+    // atoms per lane (A/B: MDH_ASSIGN_K = 1, 2, 4; small systems keep one atom per lane: they need the workgroups to fill the chip)
+    static const int assign_k_env = [] { const char *e = std::getenv("MDH_ASSIGN_K"); return e ? std::atoi(e) : 0; }();
+    const int assign_k = assign_k_env > 0 ? assign_k_env : (N >= (int64_t)1 << 20 ? 4 : 1);
+#define MDH_ASSIGN(TRI, K) hipLaunchKernelGGL((k_assign<TRI, K>), dim3(grid_for(N, 256 * K)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0)
+    if (b.tri) {
+        if (assign_k >= 4) MDH_ASSIGN(true, 4); else if (assign_k >= 2) MDH_ASSIGN(true, 2); else MDH_ASSIGN(true, 1);
+    } else {
+        if (assign_k >= 4) MDH_ASSIGN(false, 4); else if (assign_k >= 2) MDH_ASSIGN(false, 2); else MDH_ASSIGN(false, 1);
+    }
+#undef MDH_ASSIGN
     auto scan_piece = [&](int64_t from, int64_t to, unsigned use_gen, int *flags) {
         launch_scan_gen(st, cell_count + from, cg.cell_start + from, to - from, ctl, use_gen, true, flags); // [to] = the piece's total
     };
@@ -1619,6 +1648,14 @@ int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const doubl
                                    const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
                                    mdh_alloc_rows_fn alloc, void *user, const int64_t *key, int space, void *stream)
 {
+    return mdh_build_neighbor_exact_fcna(x, y, z, N, box9, origin3, boundary3, rc, nn, width, alloc, user, nullptr, key, space, stream);
+}
+
+// pattern (N) i32 or NULL: the fixed-cutoff CNA labels of the same cutoff as well (mdh_build_neighbor_fcna at the exact width)
+int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                  const double *origin3, const int *boundary3, double rc, int *nn, int64_t *width,
+                                  mdh_alloc_rows_fn alloc, void *user, int *pattern, const int64_t *key, int space, void *stream)
+{
     if (N < 0 || N >= 2147483647LL || !(rc > 0) || !width || !alloc) { set_error("mdh_build_neighbor_exact: invalid N, rc, width or allocator"); return MDH_ERR_ARG; }
     DBox b;
     MDH_TRY(make_box(b, box9, origin3, boundary3));
@@ -1634,6 +1671,8 @@ int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const doubl
     int *dn = sc.stage(nn, (size_t)N, space, false, true);
     int *dmax = sc.alloc_n<int>(1);
     const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
+    int *dp = pattern ? sc.stage(pattern, (size_t)N, space, true, true) : nullptr; // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
+    int *todo = pattern ? sc.alloc_n<int>((size_t)N + 1) : nullptr;
     if (sc.failed())
         return sc.error();
     hipStream_t st = sc.stream();
@@ -1644,6 +1683,15 @@ int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const doubl
         ProfRange pr("cell_grid", st);
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
+    // the labels of a build: inside the tile kernel where that ran (its leftovers listed in todo), from the finished rows otherwise
+    bool fused = false;
+    auto labels = [&](const int *dv, int64_t M) {
+        if (!dp)
+            return;
+        ProfRange pr("k_fcna", st);
+        if (fused) launch_fcna_listed(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
+        else launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
+    };
     // Width hint: the largest count the previous call with the same (N, grid) found.  A sequence of calls on one system (a
     // trajectory, the same analysis repeated) almost always finds the same maximum again, so the rows are built at that
     // width at once and the counts written by the build confirm it — the counting pass is skipped.  A wrong hint costs one
@@ -1659,10 +1707,15 @@ int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const doubl
             return sc.error();
         {
             ProfRange pr("k_neighbor", st);
-            MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, hint, 2, nullptr));
+            if (todo) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
+            MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, hint, 2, nullptr, dp, todo, &fused));
             hipLaunchKernelGGL(k_max_i32, dim3(1024), dim3(256), 0, st, dn, N, dmax);
             MDH_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
         }
+        // (enqueued before the width is known: with a confirmed hint — the usual case — the call has no idle gap; after a wrong one the
+        // second build labels again, and a label depends on the atom's neighbours only, not on the width of the rows: an atom the
+        // wasted pass labelled had its 12 or 14 neighbours listed in full, anything else it left to the list)
+        labels(dv, hint);
         MDH_HIP(hipStreamSynchronize(st));
         built = (hmax > 1 ? hmax : 1) == hint;
     } else {
@@ -1680,9 +1733,15 @@ int mdh_build_neighbor_exact_keyed(const double *x, const double *y, const doubl
         double *dd = sc.stage(dist, (size_t)(N * M), space, false, true);
         if (sc.failed())
             return sc.error();
-        ProfRange pr("k_neighbor", st);
-        MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, M, 2, nullptr));
+        {
+            ProfRange pr("k_neighbor", st);
+            if (todo) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
+            fused = false;
+            MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, M, 2, nullptr, dp, todo, &fused));
+        }
+        labels(dv, M);
     }
+    MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }
 

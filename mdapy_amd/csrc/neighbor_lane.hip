@@ -67,6 +67,9 @@ namespace lane {
 // A workgroup is NW waves (template parameter of the kernel): 4 — 256 threads, four workgroups per CU — or 8 for the big-tile
 // instance — 512 threads, two per CU.  A tile has at most one halo cell per thread.
 constexpr int cen_cap(int nw) { return 80 * nw; } // centre atoms a tile may hold
+// tickets of a row + the spare slot, rounded up (rows are read back four tickets at a time); cna_rows: the one-byte instance that
+// also labels keeps a centre's 12 or 14 bond rows (two bytes each) in its ticket row once the tickets are consumed: 28 bytes
+__host__ __device__ constexpr int ticket_row(int M, bool cna_rows) { return (cna_rows && ((M + 4) & ~3) < 28) ? 28 : ((M + 4) & ~3); }
 static constexpr int NEUTRAL = img::CELL_NEUTRAL;  // a halo cell's image code "no shift" (grid.hpp img::)
 static constexpr int NEUTRAL3 = img::NEUTRAL;      // combined code "no shift"
 
@@ -330,6 +333,60 @@ __device__ __forceinline__ int lane_fcna(const DBox &b, Index index_of, const do
     return fcna_label<NN>(R);
 }
 
+// The same label with the pair tests in SINGLE precision on the tile's staged coordinates (f4: relative to the tile's corner, every
+// staged atom already in the image the tile sees — a difference of two of them IS the minimum image while the box is at least
+// seven cells wide, which the tile kernel asks for anyway): no second read of the positions, 36 registers instead of 72, ten
+// register-only instructions per pair (cna.hip fcna_atom_f32).  The decision band is the scan's own: both tests compare a squared
+// distance of two staged atoms with rc^2 (neighbor.cpp:160 and cna.cpp:459-466 use the same `<=`), and the bound behind (negc, W)
+// holds for any two atoms of the 3 x 3 x 3 cells around a centre.  -1: a pair inside the band — the atom goes on the to-do list and
+// is finished by the double-precision kernel with the reference's expression (cna.hip k_fcna<TRI, true>), as mdh_fcna does it.
+// (the fused form had only ever been measured with the double-precision tests.)
+// rows != nullptr: 2 * NN bytes of LDS of this lane's own for the bond rows (the one-byte instance: its ticket row, once the
+// tickets have been read) — the cluster walks of a distorted neighbourhood fetch a row by a computed index with one ds_read_u16
+// instead of a chain of NN selects (a lattice rattled by 0.2 A: the tile kernel 2.03 -> see DESIGN 3a)
+template <int NN, class Index>
+__device__ __forceinline__ int lane_fcna_f32(Index index_of, const float4 *__restrict__ f4, float negc, float W, unsigned short *rows)
+{
+    float ux[NN], uy[NN], uz[NN];
+#pragma unroll
+    for (int a = 0; a < NN; ++a) {
+        const float4 c = f4[index_of(a)];
+        ux[a] = c.x; uy[a] = c.y; uz[a] = c.z;
+    }
+    unsigned adj[NN];
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+        adj[a] = 0;
+    unsigned w = 0x7f7fffffu; // bits of the smallest non-negative d2 - c seen
+#pragma unroll
+    for (int a = 0; a < NN; ++a)
+#pragma unroll
+        for (int c = a + 1; c < NN; ++c) {
+            float t0, t1, t2;
+            asm("v_sub_f32 %[t0], %[xc], %[xa]\n\t"
+                "v_sub_f32 %[t1], %[yc], %[ya]\n\t"
+                "v_sub_f32 %[t2], %[zc], %[za]\n\t"
+                "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"
+                "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
+                "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
+                "v_min_u32 %[w], %[w], %[t0]\n\t"
+                "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"
+                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w] "+v"(w), [ra] "+v"(adj[a]), [rc] "+v"(adj[c])
+                : [xc] "v"(ux[c]), [xa] "v"(ux[a]), [yc] "v"(uy[c]), [ya] "v"(uy[a]), [zc] "v"(uz[c]), [za] "v"(uz[a]),
+                  [negc] "v"(negc), [sc] "n"(c), [sa] "n"(a));
+        }
+    if (w <= __float_as_uint(W))
+        return -1;
+    if (rows) {
+#pragma unroll
+        for (int a = 0; a < NN; ++a) rows[a] = (unsigned short)adj[a];
+        return fcna_label_words<NN>(adj, RowsLds{rows, 1});
+    }
+    return fcna_label_words<NN, RowsReg<NN>>(adj, RowsReg<NN>(adj));
+}
+
 // 4 x 4 transpose of 16-byte pieces among the four lanes of a quad: lane u's piece v <-> lane v's piece u.  Two butterfly
 // stages (partner lane u^1, then u^2), each a bitwise select (v_bfi_b32 with a lane-parity mask in a VGPR), one quad_perm DPP
 // move and two selects per dword: 64 register-only instructions.  odd1 / odd2: all ones in lanes with bit 0 / bit 1 set.
@@ -382,7 +439,12 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
 // stages 2.5 halo cells per centre cell instead of 3.15, its per-wave front phases serve twice the centres, and its ~440 centres
 // fill seven chunks of 64 better than ~196 fill three or four
 template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8, int NW = 4>
-__global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neighbor_lane(
+#ifdef MDH_FCNA_F64
+#define MDH_FCNA_LEAN false // the double-precision pair tests of the fused label need ~175 VGPRs: three workgroups per CU
+#else
+#define MDH_FCNA_LEAN true  // the single-precision ones fit the 128 of the plain instance: four
+#endif
+__global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || MDH_FCNA_LEAN)) ? 16 / NW : 1) void k_neighbor_lane(
     const CellGrid::Packed *__restrict__ pk, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
@@ -411,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
     // halo cell: population — needed from the block scan's barrier to the run table only, so it lives in the ticket rows, cell t
     // in the rows of wave t / 64 (the wave that writes it: a wave walking a list of tiles may be a tile ahead of the others,
     // whose tickets it must not touch)
-    const int TKS = (M + 4) & ~3; // tickets of a row + the spare slot, rounded up: rows are read back four tickets at a time
+    const int TKS = ticket_row(M, FCNA && TK8 && MDH_FCNA_LEAN);
     const int wstride = max(rw * TKS, 256 / (int)sizeof(Ticket)); // tickets of one wave's rows (at least its 64 populations)
     auto hc = [&](int t) -> unsigned & { return reinterpret_cast<unsigned *>(tk + (size_t)(t >> 6) * wstride)[t & 63]; };
     __shared__ unsigned hr[NW * 64 + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
@@ -665,6 +727,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
             const int q = cbase + lane;
             const bool mine = lane < rw && q < ncentres; // this lane holds a centre
             int kept = 0, kept8 = 0, cb = 0, id = 0; // (lanes without a centre: no row)
+            unsigned tw_pre[4] = {0u, 0u, 0u, 0u};    // (the fused label of the one-byte instance: the row's tickets, read before its bond rows take their place)
             double xi = 0, yi = 0, zi = 0;
             Ticket *my = tkw + (size_t)lane * TKS;
             if (mine) {
@@ -807,8 +870,22 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                             return (int)(hr[run_cell(cb, r)] & 0xffffu) + (int)(t & ((1u << JB) - 1u));
                         };
                         int label = 0;
+#ifdef MDH_FCNA_F64 // measuring build (make fcna64): the pair tests in double precision on the raw coordinates, as until round 5
                         if (hits == 12 && M >= 12) label = lane_fcna<TRI, 12>(b, index_of, lxy, lz, !general_tile, rcsq);
                         else if (hits == 14 && M >= 14) label = lane_fcna<TRI, 14>(b, index_of, lxy, lz, !general_tile, rcsq);
+#else
+                        // (one-byte instance: the row's tickets go into registers first — the write-out below reads them from there —
+                        // and the 28 bytes of the ticket row hold the bond rows)
+                        unsigned short *rows = nullptr;
+                        if (TK8) {
+                            const unsigned *myw = reinterpret_cast<const unsigned *>(my);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) tw_pre[v] = (4 * v < M) ? myw[v] : 0u;
+                            rows = reinterpret_cast<unsigned short *>(my);
+                        }
+                        if (hits == 12 && M >= 12) label = lane_fcna_f32<12>(index_of, f4, negc, W, rows);
+                        else if (hits == 14 && M >= 14) label = lane_fcna_f32<14>(index_of, f4, negc, W, rows);
+#endif
                         if (label > 0) pattern[id] = label;
                         else if (label < 0) defer(cna_todo, id);
                     }
@@ -829,7 +906,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && !FCNA) ? 16 / NW : 1) void k_neigh
                 const unsigned *myw = reinterpret_cast<const unsigned *>(my);
                 unsigned tw[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) tw[v] = (4 * v < M) ? myw[v] : 0u;
+                for (int v = 0; v < 4; ++v) tw[v] = (FCNA && MDH_FCNA_LEAN) ? tw_pre[v] : ((4 * v < M) ? myw[v] : 0u);
                 int idv[16];
                 double dv[16];
                 // four slots at a time: their run-table reads go out together, then their twelve position reads, then four
@@ -1187,9 +1264,9 @@ int grid_stats_hint(Scope &sc, const CellGrid &cg, int64_t N, GridStats *out)
 namespace lane {
 
 // tk8: one-byte tickets, else two-byte ones; rows of (M + 1) tickets rounded up to a multiple of four; rw rows per wave
-static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw, int nw = 4)
+static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw, int nw = 4, bool fcna = false)
 {
-    const size_t wave = std::max<size_t>((size_t)rw * (size_t)((M + 4) & ~(int64_t)3) * (tk8 ? 1 : 2), 256); // (the kernel's wstride)
+    const size_t wave = std::max<size_t>((size_t)rw * (size_t)ticket_row((int)M, fcna && tk8 && MDH_FCNA_LEAN) * (tk8 ? 1 : 2), 256); // (the kernel's wstride)
     const size_t tk = (size_t)nw * wave;
     return (size_t)cap * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)cen_cap(nw) * 4 + (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }
@@ -1265,7 +1342,7 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
     // four workgroups per CU where the instance keeps to 128 VGPRs (not the fused CNA)
     static const int tk8_env = [] { const char *e = std::getenv("MDH_LANE_TK8"); return e ? std::atoi(e) : 1; }(); // A/B: 0 = the slot-per-lane write-out always
     const bool tk8 = (count && !long_runs) || (tk8_env && M <= 16 && !long_runs);
-    const int max_wgs = (tk8 && !fcna) ? 4 : 3;
+    const int max_wgs = (tk8 && (!fcna || MDH_FCNA_LEAN)) ? 4 : 3;
     // LDS budget: four workgroups per CU (the 128-VGPR instance only), else three, two, one, if the tile that allows is not
     // much worse than what fewer would get.  Rows of many slots in cells of many atoms (rc = 5 A, 50 slots: the reference's
     // own benchmark call) leave few centres per tile: the ticket rows are sized for them (rw rows per wave), not for 64.
@@ -1307,7 +1384,7 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
                     continue;
                 int rw = 64;
                 if (!tk8) rw = std::min(64, std::max(8, ((int)std::ceil(c * 1.15 / nw) + 3) & ~3)); // (a row is a multiple of eight bytes: any count keeps the waves' blocks aligned)
-                const long fixed = (long)lds_bytes(0, M, tk8, rw, nw);
+                const long fixed = (long)lds_bytes(0, M, tk8, rw, nw, fcna);
                 int cap = (int)((budget - fixed - 2) / 42);
                 if (cap_env > 0) cap = cap_env;
                 cap = std::min(cap, 2040); // (a centre's LDS index takes 11 bits of its table entry)
@@ -1377,7 +1454,7 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
     // per cent of empty blocks (the corner cell of a 100^3-cell fcc box holds no lattice site) cost a workgroup each that finds no
     // centre and leaves; the list costs three launches
     p.full = (double)occ >= 0.98 * (double)g.ncell;
-    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw, p.nw);
+    g_last_plan[0] = p.txy; g_last_plan[1] = p.tz; g_last_plan[2] = p.cap; g_last_plan[3] = (int)lds_bytes(p.cap, M, tk8, p.rw, p.nw, fcna);
     g_last_plan[4] = p.full | (p.tk8 ? 2 : 0) | (p.wgs << 2) | (p.nw == 8 ? 32 : 0); g_last_plan[5] = (int)(1000.0 * pop); g_last_plan[6] = (int)std::min<int64_t>(occ, 2147483647); g_last_plan[7] = 1;
     return p;
 }
@@ -1427,8 +1504,8 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         list_mode = 1;
     }
     const dim3 grid((unsigned)(per * 8));
-    const size_t lds1 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, plan.nw); // first pass (four or eight waves per workgroup)
-    const size_t lds2 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, 4);       // slice pass: always four
+    const size_t lds1 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, plan.nw, pattern != nullptr); // first pass (four or eight waves per workgroup)
+    const size_t lds2 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, 4, pattern != nullptr);       // slice pass: always four
     const int Mi = (int)M, wp = fill_pads ? 1 : 0;
     const float negc = -plan.mid;
     const int nt2b = nt[2] * nsub;

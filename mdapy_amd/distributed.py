@@ -545,11 +545,12 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     nn = (t.zeros if getattr(dom, "absent_slots", False) else t.empty)((n,), dtype=t.int32, device=dom.x.device)
     pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
     dec.hint_window(rc, dom.x)
-    kernels.neighbor.build_neighbor(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, 1, fill_pads=True,
-                             key=dom.gid if dec.world > 1 else None)
+    # lists and labels in ONE pass over the tiles (mdh_build_neighbor_fcna: a centre's 12 or 14 neighbours are still staged in LDS
+    # when its row is written) — bit for bit what build_neighbor followed by fcna leaves
+    kernels.neighbor.build_neighbor_fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, pattern, 1, fill_pads=True,
+                                         key=dom.gid if dec.world > 1 else None)
     if strict and dom.x.is_cuda and hasattr(kernels.neighbor, "cell_window_check"):
         kernels.neighbor.cell_window_check()
-    kernels.cna.fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, verlet, nn, pattern, rc, 1)
     return dom, verlet, dist, nn, pattern
 
 

@@ -8,7 +8,7 @@ count found (one library call, one cell grid for counting and building); with a 
 import numpy as np
 
 from . import kernels, policy
-from .devarray import empty
+from .devarray import empty, zeros
 from .parallel import get_num_threads
 
 _NEEDS = ("x", "y", "z")
@@ -33,7 +33,10 @@ class Neighbor:
         if self.N <= 0:
             raise AssertionError("data must contain at least one atom.")
 
-    def compute(self):
+    def compute(self, label=False):
+        """``label`` (extension): leave ``pattern`` as well — the fixed-cutoff common-neighbour labels of this cutoff, what
+        ``_cna.fcna`` makes of the finished lists (src/cna.cpp:429-506), written in the same pass over the tiles (a centre's 12
+        or 14 neighbours are still staged in LDS when its row is written).  ``None`` where the search ran on a replica."""
         # a periodic direction thinner than two cutoffs would make an atom its own neighbour's image: search a replica
         frame, cell, grown = policy.widened(self.data, self.box, 2.0 * self.rc, all_columns=True)
         if grown:
@@ -42,8 +45,10 @@ class Neighbor:
         if self.key is not None and grown:
             raise AssertionError("an ordering key cannot follow a system into its replica")
         self._key = {} if self.key is None else {"key": self.key}
+        self.pattern = zeros(frame.shape[0], np.int32) if (label and not grown) else None  # (the kernels only ever raise a label)
         if self.max_neigh is None:
-            rows = kernels.neighbor.build_neighbor_without_max_neigh(*where, get_num_threads(), **self._key)
+            extra = dict(self._key) if self.pattern is None else dict(self._key, pattern=self.pattern)
+            rows = kernels.neighbor.build_neighbor_without_max_neigh(*where, get_num_threads(), **extra)
             self.verlet_list, self.distance_list, self.neighbor_number = rows
             return
         width, atoms = self.max_neigh, frame.shape[0]
@@ -62,11 +67,17 @@ class Neighbor:
 
     def _search_fixed(self, where):
         out = (self.verlet_list, self.distance_list, self.neighbor_number)
+        if self.pattern is None:
+            build = kernels.neighbor.build_neighbor
+        else:
+            def build(*a, **kw):  # lists and labels in one pass (mdh_build_neighbor_fcna)
+                n = len(where) + len(out)
+                kernels.neighbor.build_neighbor_fcna(*a[:n], self.pattern, *a[n:], **kw)
         if isinstance(self.verlet_list, np.ndarray):
             # host buffers: the caller pre-fills the pads, as the reference's Python does (neighbor.py:125-129)
             self.verlet_list[...] = -1
             self.distance_list[...] = self.rc + 1.0
             self.neighbor_number[...] = 0
-            kernels.neighbor.build_neighbor(*where, *out, get_num_threads(), **self._key)
+            build(*where, *out, get_num_threads(), **self._key)
         else:  # HBM buffers: the kernel writes the pads itself, no extra pass over 12 M bytes per atom
-            kernels.neighbor.build_neighbor(*where, *out, get_num_threads(), fill_pads=True, **self._key)
+            build(*where, *out, get_num_threads(), fill_pads=True, **self._key)

@@ -312,6 +312,8 @@ class System:
             src = twin.ptm_indices
             self.ptm_indices = LazyHArray(lambda: _dev_of(kernels.order.translate_rows(src, None, None, perm)[0]), src.shape, np.int32) \
                 if isinstance(src, HArray) else kernels.order.translate_rows(np.asarray(src), None, None, np.asarray(perm))[0]
+        if name == "build_neighbor" and result is not None:  # the labels of build_neighbor(..., _label=True): per atom, the twin's order
+            result = kernels.order.permute(result, perm, scatter=True)
         return result
 
     def _mirror_lists(self, twin):
@@ -498,14 +500,16 @@ class System:
             self._sorted_columns = (id(self.verlet_list), k)
 
     @_on_twin
-    def build_neighbor(self, rc, max_neigh=None):
+    def build_neighbor(self, rc, max_neigh=None, _label=False):
+        # _label (internal): the fixed-cutoff common-neighbour labels of this cutoff in the same pass; returned, not stored
         search = Neighbor(rc, self.box, self.data, max_neigh, key=self.__dict__.get("_order_key"))
-        search.compute()
+        search.compute(label=_label)
         self.rc = rc
         self._remember(search, search.verlet_list, search.distance_list, search.neighbor_number)
         # provenance of the CURRENT list: a cutoff list of exactly this reach, complete (an overflow of max_neigh raises).
         # `rc` alone does not say so — like the reference's, it survives build_nearest_neighbor (system.py:1256-1263)
         self._list_cutoff = float(rc)
+        return search.pattern if _label else None
 
     @_on_twin
     def build_nearest_neighbor(self, k):
@@ -554,7 +558,12 @@ class System:
             if "rc" in self.__dict__:  # (only a cutoff list is lent to the adaptive variant)
                 rows = self._borrow_nearest(14)
         elif policy.is_single(self._safe_repeat()) and not ("rc" in self.__dict__ and self.rc >= rc):
-            self.build_neighbor(rc, max_neigh)
+            # no list that reaches: the reference builds one (it stays the system's list) and labels from it; here the labels
+            # are made in the pass that builds the list (mdh_build_neighbor_fcna / _exact_fcna), bit for bit the same
+            labels = self.build_neighbor(rc, max_neigh, _label=True)
+            if labels is not None:
+                self._store(cna=labels)
+                return
             rows, counts = self.verlet_list, self.neighbor_number
         elif policy.is_single(self._safe_repeat()) and self.__dict__.get("_list_cutoff") == float(rc):
             # the reference lends nothing here and the analysis builds a list of its own with this very cutoff: the same

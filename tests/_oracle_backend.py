@@ -44,14 +44,22 @@ def _build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t=1, fill_
     _unkey(perm, vs, ds, ns, v, d, nn)
 
 
-def _build_neighbor_exact(x, y, z, box, origin, boundary, rc, num_t=1, key=None):
+def _build_neighbor_exact(x, y, z, box, origin, boundary, rc, num_t=1, key=None, pattern=None):
     if key is None:
-        return O.build_neighbor_without_max_neigh(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT)
-    perm, (xs, ys, zs) = _keyed(key, x, y, z)
-    vs, ds, ns = O.build_neighbor_without_max_neigh(xs, ys, zs, box, origin, boundary, rc, NT)
-    v, d, nn = np.empty_like(vs), np.empty_like(ds), np.empty_like(ns)
-    _unkey(perm, vs, ds, ns, v, d, nn)
+        v, d, nn = O.build_neighbor_without_max_neigh(_np(x), _np(y), _np(z), box, origin, boundary, rc, NT)
+    else:
+        perm, (xs, ys, zs) = _keyed(key, x, y, z)
+        vs, ds, ns = O.build_neighbor_without_max_neigh(xs, ys, zs, box, origin, boundary, rc, NT)
+        v, d, nn = np.empty_like(vs), np.empty_like(ds), np.empty_like(ns)
+        _unkey(perm, vs, ds, ns, v, d, nn)
+    if pattern is not None:  # the fused call of the library = the two reference calls one after the other
+        O.fcna(_np(x), _np(y), _np(z), box, origin, boundary, v, nn, pattern, rc, NT)
     return v, d, nn
+
+
+def _build_neighbor_fcna(x, y, z, box, origin, boundary, rc, v, d, nn, pattern, num_t=1, fill_pads=False, key=None):
+    _build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t, fill_pads, key)
+    O.fcna(_np(x), _np(y), _np(z), box, origin, boundary, v, nn, pattern, rc, NT)
 
 
 def _spatial_sort(x, y, z, box, origin, boundary):
@@ -87,6 +95,7 @@ order = _mod(order_statistic=lambda x, y, z, box, origin, boundary: 1.0, spatial
              translate_rows=_translate_rows)
 neighbor = _mod(
     build_neighbor=_build_neighbor,
+    build_neighbor_fcna=_build_neighbor_fcna,
     build_neighbor_without_max_neigh=_build_neighbor_exact,
     sort_verlet_by_distance=lambda v, d, k, num_t=1: O.sort_verlet_by_distance(v, d, k, NT),
     wrap_positions=lambda x, y, z, box, origin, boundary, num_t=1: O.wrap_positions(x, y, z, box, origin, boundary, NT),
