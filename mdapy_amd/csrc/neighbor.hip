@@ -746,7 +746,9 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     const unsigned gen = next_scan_gen(); // stamps of this build's k_assign; the (first) scan below is launched with the same value
     // atoms per lane (A/B: MDH_ASSIGN_K = 1, 2, 4; small systems keep one atom per lane: they need the workgroups to fill the chip)
     static const int assign_k_env = [] { const char *e = std::getenv("MDH_ASSIGN_K"); return e ? std::atoi(e) : 0; }();
-    const int assign_k = assign_k_env > 0 ? assign_k_env : (N >= (int64_t)1 << 20 ? 4 : 1);
+    // (measured at 10 M atoms: 145 -> 120 us on a lattice, 162 -> 162 on a polycrystal — 10 M runs of one atom, the atomics' own
+    // throughput — 413 -> 440 on a shuffled frame, which therefore keeps one: profiles/r05_assign_k.txt)
+    const int assign_k = assign_k_env > 0 ? assign_k_env : ((N >= (int64_t)1 << 20 && !rec) ? 4 : 1);
 #define MDH_ASSIGN(TRI, K) hipLaunchKernelGGL((k_assign<TRI, K>), dim3(grid_for(N, 256 * K)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0)
     if (b.tri) {
         if (assign_k >= 4) MDH_ASSIGN(true, 4); else if (assign_k >= 2) MDH_ASSIGN(true, 2); else MDH_ASSIGN(true, 1);

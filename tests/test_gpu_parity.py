@@ -522,6 +522,52 @@ def test_fcna_single_precision_pair_tests_vs_oracle(case):
         assert (want > 0).mean() > 0.5  # the case does exercise labelled atoms
 
 
+@pytest.mark.parametrize("case", _fcna_cases(), ids=lambda c: c[0])
+def test_fused_labels_single_precision_pair_tests_vs_oracle(case):
+    """the labels made INSIDE the tile kernel (single-precision pair tests on the tile's staged coordinates, the scan's decision band,
+    pairs inside it finished in double precision from the to-do list) == the oracle's fcna on the oracle's lists: through
+    mdh_build_neighbor_fcna (fixed width) and mdh_build_neighbor_exact_fcna (max_neigh=None: host arrays, then HBM-resident twice — the
+    second call builds at the remembered width), lists included; the knife-edge case puts a pair of EVERY atom inside the band"""
+    import torch
+
+    name, pos, box, org, bnd, rc = case
+    x, y, z = _xyz(pos)
+    n = len(x)
+    v, d, c = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    want = np.zeros(n, np.int32)
+    O.fcna(x, y, z, box, org, bnd, v, c, want, rc, 4)
+    M = int(v.shape[1])
+    # fixed width = the exact one, and a wider one
+    for width in (M, M + 3):
+        vf = np.empty((n, width), np.int32); df = np.empty((n, width)); nf = np.empty(n, np.int32); pf = np.zeros(n, np.int32)
+        _neighbor.build_neighbor_fcna(x, y, z, box, org, bnd, rc, vf, df, nf, pf, 1, fill_pads=True)
+        assert np.array_equal(nf, c) and np.array_equal(vf[:, :M], v) and np.array_equal(df[:, :M], d), (name, width)
+        assert np.array_equal(pf, want), (name, width, int((pf != want).sum()))
+    # exact width, host arrays
+    pe = np.zeros(n, np.int32)
+    ve, de, ne = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1, pattern=pe)
+    assert np.array_equal(ne, c) and np.array_equal(ve, v) and np.array_equal(de, d) and np.array_equal(pe, want), name
+    # exact width, HBM-resident: twice (counting pass, then the remembered width), and once more after ANOTHER system of the same
+    # size and grid left a different width behind (a wrong hint: one wasted build, the labels of the second)
+    dev = torch.device("cuda", 0)
+    tx, ty, tz = (torch.from_numpy(a).to(dev) for a in (x, y, z))
+    for _ in range(2):
+        pt = torch.zeros(n, dtype=torch.int32, device=dev)
+        vt, dt, nt = _neighbor.build_neighbor_without_max_neigh(tx, ty, tz, box, org, bnd, rc, 1, pattern=pt)
+        assert np.array_equal(np.asarray(nt), c) and np.array_equal(np.asarray(vt), v) and np.array_equal(np.asarray(dt), d), name
+        assert np.array_equal(pt.cpu().numpy(), want), name
+    if name.startswith("fcc_rattled"):
+        sq = torch.from_numpy(np.ascontiguousarray(pos * np.array([1.0, 1.0, 0.97]))).to(dev)  # the same grid (cells absorb 3 %), denser along z
+        _neighbor.build_neighbor_without_max_neigh(sq[:, 0].contiguous(), sq[:, 1].contiguous(), sq[:, 2].contiguous(), box, org, bnd, rc, 1)
+        pt = torch.zeros(n, dtype=torch.int32, device=dev)
+        vt, dt, nt = _neighbor.build_neighbor_without_max_neigh(tx, ty, tz, box, org, bnd, rc, 1, pattern=pt)
+        assert np.array_equal(np.asarray(vt), v) and np.array_equal(pt.cpu().numpy(), want), name
+    if name == "fcc_second_shell_in_band":
+        assert (c == 12).all() and (want == 1).all()
+    if name[:3] in ("fcc", "bcc", "hcp"):
+        assert (want > 0).mean() > 0.5
+
+
 @pytest.mark.parametrize("case", [c for c in _fcna_cases() if c[0] != "fcc_second_shell_in_band"], ids=lambda c: c[0])
 def test_acna_single_precision_pair_tests_vs_oracle(case):
     """adaptive CNA on boxes large enough for the single-precision kernel (edges > 8 local cutoffs): labels == oracle == the
