@@ -258,13 +258,16 @@ __device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN],
     unsigned P[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) P[k] = adj[2 * k] | ((2 * k + 1 < NN) ? (adj[2 * k + 1] << 16) : 0u);
-    int n421 = 0, n422 = 0, n555 = 0, n444 = 0, n666 = 0, others = 0;
+    // the five counts and `others` as 4-bit fields of one word (each <= NN <= 14): a signature adds ONE constant picked by
+    // key = ncn + 32 nb — (4,2,x) 68, (5,5,5) 165, (4,4,4) 132, (6,6,6) 198 — instead of a chain of compared-and-branched
+    // increments (thirty instructions per bond, half of this function, before)
+    unsigned packed = 0;
 #pragma unroll
     for (int ni = 0; ni < NN; ++ni) {
-        if (MAXO < NN && others > MAXO)
+        if (MAXO < NN && (packed >> 20) > (unsigned)MAXO)
             continue;
         const unsigned common = adj[ni]; // cna.cpp:52-64
-        const int ncn = __popc(common);
+        const unsigned ncn = (unsigned)__popc(common);
         const unsigned c2 = common | (common << 16);
         unsigned twice = 0, touched = 0;
 #pragma unroll
@@ -275,19 +278,23 @@ __device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN],
             twice += __popc(xk);
             touched |= xk;
         }
-        const int nb = (int)(twice >> 1);
-        int ch;
-        if (nb <= 1) ch = nb;
-        else if (nb == 2) ch = (__popc((touched | (touched >> 16)) & 0xffffu) == 3) ? 2 : 1;
-        else if (nb == ncn && (ncn == 4 || ncn == 5)) ch = nb;
-        else { int a, c; signature(L, ni, (1u << NN) - 1u, a, c, ch); }
-        if (ncn == 4 && nb == 2) { n421 += (ch == 1); n422 += (ch == 2); }
-        else if (ncn == 5 && nb == 5 && ch == 5) ++n555;
-        else if (ncn == 4 && nb == 4 && ch == 4) ++n444;
-        else if (ncn == 6 && nb == 6 && ch == 6) ++n666;
-        else ++others;
+        // chain (cna.cpp:97-147) by the shortcuts of signature(): two bonds make a chain of 2 iff they share an atom (three atoms
+        // touched); k bonds on k = 4 or 5 atoms are one cluster.  Only (6,6,x) — bcc — has to walk, and only its answer is used:
+        // every other signature with three bonds or more counts as `other` whatever its chain is.
+        const unsigned key = ncn + (twice << 4); // (twice = 2 nb: the rows are symmetric; ncn < 16: no two signatures share a key)
+        const unsigned three = (__popc((touched | (touched >> 16)) & 0xffffu) == 3) ? 1u << 4 : 1u;
+        unsigned inc = 1u << 20;
+        inc = key == 68u ? three : inc;
+        inc = key == 165u ? 1u << 8 : inc;
+        inc = key == 132u ? 1u << 12 : inc;
+        if (key == 198u) {
+            int a, c, ch;
+            signature(L, ni, (1u << NN) - 1u, a, c, ch);
+            inc = ch == 6 ? 1u << 16 : 1u << 20;
+        }
+        packed += inc;
     }
-    return CnaCounts{n421, n422, n555, n444, n666};
+    return CnaCounts{(int)(packed & 15u), (int)((packed >> 4) & 15u), (int)((packed >> 8) & 15u), (int)((packed >> 12) & 15u), (int)((packed >> 16) & 15u)};
 }
 template <int NN, class RT = RowsLds>
 __device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const RT &L)
