@@ -59,7 +59,12 @@ def _worker(rank, world, port, q):
 
         import mdapy_amd.kernels as K  # the package's one door to the C ABI: swap the shims behind it
 
-        K.neighbor = type("M", (), {"build_neighbor": staticmethod(build_neighbor)})
+        def build_neighbor_fcna(x, y, z, box, origin, boundary, rc, v, d, nn, pat, num_t=1, fill_pads=False, key=None):
+            # the library's one-pass form = the two reference calls one after the other
+            build_neighbor(x, y, z, box, origin, boundary, rc, v, d, nn, num_t, fill_pads, key)
+            fcna(x, y, z, box, origin, boundary, v, nn, pat, rc, num_t)
+
+        K.neighbor = type("M", (), {"build_neighbor": staticmethod(build_neighbor), "build_neighbor_fcna": staticmethod(build_neighbor_fcna)})
         K.cna = type("M", (), {"fcna": staticmethod(fcna)})
         K.sbo = type("M", (), {"get_sq": staticmethod(get_sq)})
 
