@@ -173,16 +173,19 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
                              const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                              int64_t max_neigh, int fill_pads, const int64_t *key, int space, void *stream);
 
-/* Opt-in: mdh_build_neighbor followed by mdh_fcna(rc) — what System.cal_common_neighbor_analysis(rc, max_neigh) runs when it
- * has no list yet (neighbor.cpp:351 then cna.cpp:429-506) — as ONE pass over the LDS tiles: a centre's 12 or 14 neighbours are
- * still staged when its row is written, so the bond matrix is taken from LDS instead of 12-14 gathers per atom from HBM.
+/* mdh_build_neighbor followed by mdh_fcna(rc) — what System.cal_common_neighbor_analysis(rc, max_neigh) runs when it has no list
+ * yet (neighbor.cpp:351 then cna.cpp:429-506) — as ONE pass over the LDS tiles: a centre's 12 or 14 neighbours are still staged
+ * when its row is written, so the bond matrix is taken from LDS (single-precision pair tests on the tile's staged coordinates with
+ * the scan's own decision band; a pair inside the band sends the atom to a to-do list that the double-precision kernel of mdh_fcna
+ * finishes) instead of 12-14 gathers per atom from HBM and a second read of the rows.
  * verlet / dist / nn exactly as mdh_build_neighbor leaves them; pattern (N) i32 exactly as mdh_fcna leaves it
- * (caller-initialised; atoms without 12 or 14 neighbours keep their value).  key: as in mdh_build_neighbor_keyed, or NULL.
- * Where the tile kernel does not apply the two steps run one after the other inside the call.
- * MEASURED SLOWER than the two calls on MI355X (10 M atoms: tile kernels 2.15 ms against 1.19 + 0.81 ms,
- * profiles/r02_bench_fused_step.json): the analysis is bound by its ~1 700 double-precision instructions per atom, not by
- * its gathers, and inside the tile kernel it runs at 3 waves per SIMD with 77 % of the lanes holding a centre.  The package
- * therefore does not call it; it stays as the measured answer to "fuse CNA into the tile" (DESIGN.md 3a). */
+ * (caller-initialised; atoms without 12 or 14 neighbours keep their value) — bit for bit, tests/test_gpu_parity.py
+ * test_fused_*.  key: as in mdh_build_neighbor_keyed, or NULL.  Where the tile kernel does not apply the two steps run one after
+ * the other inside the call.
+ * Measured on MI355X (10 061 824-atom fcc Cu, M = 16, profiles/r05_fused_ab.txt): 1.51 ms against 1.71 ms for the two calls
+ * (0.88; 0.87 - 0.96 on lattices rattled by 0.05 - 0.3 A).  The form of rounds 2-4, with double-precision pair tests on the raw
+ * coordinates (175 VGPRs, three workgroups per CU, scratch memory), took 2.9 ms and was not used; this one keeps the 124 VGPRs and
+ * four workgroups per CU of the plain instance.  The package calls it wherever the reference would build a list and label from it. */
 int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                             const double *origin3, const int *boundary3, double rc, int *verlet, double *dist, int *nn,
                             int64_t max_neigh, int fill_pads, int *pattern, const int64_t *key, int space, void *stream);

@@ -245,6 +245,27 @@ __device__ __forceinline__ int fcna_label(const RT &R)
 // per word and the atoms those bonds touch are the OR of the masked words.  That decides every signature with at most two
 // bonds (two bonds share an atom <=> they touch three atoms) and those of the shortcuts of signature(); the rest — six bonds
 // on six atoms, the (6,6,6) of bcc — walks the clusters through the LDS copy of the rows.
+// six bonds among six common neighbours (the (6,6,x) of bcc): are they ONE cluster (x = 6)?  The cluster of the lowest atom that has
+// a bond is grown five times — a cluster on six atoms has no longer path — through the packed rows, the rows of the atoms reached so
+// far selected by masks as in cna_counts_words: no row is fetched by a computed index, so no caller needs its rows in LDS (the tile
+// kernel has none to spare: DESIGN 3a), and a lane that meets no such signature never comes here.
+template <int NW>
+__device__ __forceinline__ bool six_bonds_one_cluster(const unsigned (&P)[NW], unsigned common, unsigned bonded)
+{
+    unsigned reach = bonded & (0u - bonded); // bonded: the common neighbours that have a bond (16 bits)
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        unsigned acc = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const unsigned lo = (unsigned)(((int)(reach << (31 - 2 * k))) >> 31) & 0xffffu;
+            const unsigned hi = (unsigned)(((int)(reach << (30 - 2 * k))) >> 31) & 0xffff0000u;
+            acc |= P[k] & (lo | hi);
+        }
+        reach |= (acc | (acc >> 16)) & common & 0xffffu;
+    }
+    return (bonded & ~reach) == 0u;
+}
 struct CnaCounts { int n421, n422, n555, n444, n666; };
 // MAXO: signatures of none of the five kinds after which no label is possible any more — every label asks for 12 (14) bonds of
 // the listed kinds: one stray bond decides a 12-neighbour atom, three a 14-neighbour one (n421 == 12 needs 12 of the 14).  A lane
@@ -279,19 +300,17 @@ __device__ __forceinline__ CnaCounts cna_counts_words(const unsigned (&adj)[NN],
             touched |= xk;
         }
         // chain (cna.cpp:97-147) by the shortcuts of signature(): two bonds make a chain of 2 iff they share an atom (three atoms
-        // touched); k bonds on k = 4 or 5 atoms are one cluster.  Only (6,6,x) — bcc — has to walk, and only its answer is used:
-        // every other signature with three bonds or more counts as `other` whatever its chain is.
+        // touched); k bonds on k = 4 or 5 atoms are one cluster.  Only (6,6,x) — bcc — has to look at the clusters, and only its
+        // answer is used: every other signature with three bonds or more counts as `other` whatever its chain is.  (L, the rows
+        // for a fetch by a computed index, is not used any more: kept for the callers' sake.)
         const unsigned key = ncn + (twice << 4); // (twice = 2 nb: the rows are symmetric; ncn < 16: no two signatures share a key)
         const unsigned three = (__popc((touched | (touched >> 16)) & 0xffffu) == 3) ? 1u << 4 : 1u;
         unsigned inc = 1u << 20;
         inc = key == 68u ? three : inc;
         inc = key == 165u ? 1u << 8 : inc;
         inc = key == 132u ? 1u << 12 : inc;
-        if (key == 198u) {
-            int a, c, ch;
-            signature(L, ni, (1u << NN) - 1u, a, c, ch);
-            inc = ch == 6 ? 1u << 16 : 1u << 20;
-        }
+        if (key == 198u) // (6,6,x): x = 6 iff the six bonds are one cluster (cna.cpp:97-147)
+            inc = six_bonds_one_cluster<NW>(P, common, (touched | (touched >> 16)) & 0xffffu) ? 1u << 16 : 1u << 20;
         packed += inc;
     }
     return CnaCounts{(int)(packed & 15u), (int)((packed >> 4) & 15u), (int)((packed >> 8) & 15u), (int)((packed >> 12) & 15u), (int)((packed >> 16) & 15u)};

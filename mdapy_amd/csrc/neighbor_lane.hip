@@ -67,8 +67,9 @@ namespace lane {
 // A workgroup is NW waves (template parameter of the kernel): 4 — 256 threads, four workgroups per CU — or 8 for the big-tile
 // instance — 512 threads, two per CU.  A tile has at most one halo cell per thread.
 constexpr int cen_cap(int nw) { return 80 * nw; } // centre atoms a tile may hold
-// tickets of a row + the spare slot, rounded up (rows are read back four tickets at a time); cna_rows: the one-byte instance that
-// also labels keeps a centre's 12 or 14 bond rows (two bytes each) in its ticket row once the tickets are consumed: 28 bytes
+// tickets of a row + the spare slot, rounded up (rows are read back four tickets at a time).  (cna_rows: 28 bytes, room for a centre's
+// bond rows — built, and dropped: the 2 KB cost the headline tile 49 atoms of room, 169 of its 51 200 tiles went to the slice pass
+// (33 us), and since cna_counts_words fetches no row by a computed index nothing needs them)
 __host__ __device__ constexpr int ticket_row(int M, bool cna_rows) { return (cna_rows && ((M + 4) & ~3) < 28) ? 28 : ((M + 4) & ~3); }
 static constexpr int NEUTRAL = img::CELL_NEUTRAL;  // a halo cell's image code "no shift" (grid.hpp img::)
 static constexpr int NEUTRAL3 = img::NEUTRAL;      // combined code "no shift"
@@ -427,11 +428,8 @@ __device__ __forceinline__ void lane_pair_tests(const float (&ux)[NN], const flo
 // holds for any two atoms of the 3 x 3 x 3 cells around a centre.  -1: a pair inside the band — the atom goes on the to-do list and
 // is finished by the double-precision kernel with the reference's expression (cna.hip k_fcna<TRI, true>), as mdh_fcna does it.
 // (the fused form had only ever been measured with the double-precision tests.)
-// rows != nullptr: 2 * NN bytes of LDS of this lane's own for the bond rows (the one-byte instance: its ticket row, once the
-// tickets have been read) — the cluster walks of a distorted neighbourhood fetch a row by a computed index with one ds_read_u16
-// instead of a chain of NN selects (a lattice rattled by 0.2 A: the tile kernel 2.03 -> see DESIGN 3a)
 template <int NN, class Index>
-__device__ __forceinline__ int lane_fcna_f32(Index index_of, const float4 *__restrict__ f4, float negc, float W, unsigned short *rows)
+__device__ __forceinline__ int lane_fcna_f32(Index index_of, const float4 *__restrict__ f4, float negc, float W)
 {
     float ux[NN], uy[NN], uz[NN];
 #pragma unroll
@@ -447,12 +445,7 @@ __device__ __forceinline__ int lane_fcna_f32(Index index_of, const float4 *__res
     lane_pair_tests<NN, 0>(ux, uy, uz, negc, adj, w);
     if (w <= __float_as_uint(W))
         return -1;
-    if (rows) {
-#pragma unroll
-        for (int a = 0; a < NN; ++a) rows[a] = (unsigned short)adj[a];
-        return fcna_label_words<NN>(adj, RowsLds{rows, 1});
-    }
-    return fcna_label_words<NN, RowsReg<NN>>(adj, RowsReg<NN>(adj));
+    return fcna_label_words<NN, RowsReg<NN>>(adj, RowsReg<NN>(adj)); // (the label fetches no row by a computed index: cna_counts_words)
 }
 
 // 4 x 4 transpose of 16-byte pieces among the four lanes of a quad: lane u's piece v <-> lane v's piece u.  Two butterfly
@@ -512,7 +505,9 @@ template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8, int NW = 4>
 #else
 #define MDH_FCNA_LEAN true  // the single-precision ones fit the 128 of the plain instance: four
 #endif
-__global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || MDH_FCNA_LEAN)) ? 16 / NW : 1) void k_neighbor_lane(
+// (the walked instances that also label — the slice pass, a tile list longer than its launch: rare — take the registers they want:
+// held to 128 they spill a dozen to scratch memory, and a launch that reserves scratch is slower to start even when it finds no work)
+__global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP))) ? 16 / NW : 1) void k_neighbor_lane(
     const CellGrid::Packed *__restrict__ pk, const int *__restrict__ cell_start, DBox b,
     Grid g, double rc, float negc, float W, int *__restrict__ verlet, double *__restrict__ dist, int *__restrict__ nn,
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
@@ -541,7 +536,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || MDH_FCNA_LEAN)) ? 16 / N
     // halo cell: population — needed from the block scan's barrier to the run table only, so it lives in the ticket rows, cell t
     // in the rows of wave t / 64 (the wave that writes it: a wave walking a list of tiles may be a tile ahead of the others,
     // whose tickets it must not touch)
-    const int TKS = ticket_row(M, FCNA && TK8 && MDH_FCNA_LEAN);
+    const int TKS = ticket_row(M, false);
     const int wstride = max(rw * TKS, 256 / (int)sizeof(Ticket)); // tickets of one wave's rows (at least its 64 populations)
     auto hc = [&](int t) -> unsigned & { return reinterpret_cast<unsigned *>(tk + (size_t)(t >> 6) * wstride)[t & 63]; };
     __shared__ unsigned hr[NW * 64 + 2]; // 3-cell z-run centred on the cell: LDS offset | length << 16
@@ -795,7 +790,6 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || MDH_FCNA_LEAN)) ? 16 / N
             const int q = cbase + lane;
             const bool mine = lane < rw && q < ncentres; // this lane holds a centre
             int kept = 0, kept8 = 0, cb = 0, id = 0; // (lanes without a centre: no row)
-            unsigned tw_pre[4] = {0u, 0u, 0u, 0u};    // (the fused label of the one-byte instance: the row's tickets, read before its bond rows take their place)
             double xi = 0, yi = 0, zi = 0;
             Ticket *my = tkw + (size_t)lane * TKS;
             if (mine) {
@@ -942,17 +936,8 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || MDH_FCNA_LEAN)) ? 16 / N
                         if (hits == 12 && M >= 12) label = lane_fcna<TRI, 12>(b, index_of, lxy, lz, !general_tile, rcsq);
                         else if (hits == 14 && M >= 14) label = lane_fcna<TRI, 14>(b, index_of, lxy, lz, !general_tile, rcsq);
 #else
-                        // (one-byte instance: the row's tickets go into registers first — the write-out below reads them from there —
-                        // and the 28 bytes of the ticket row hold the bond rows)
-                        unsigned short *rows = nullptr;
-                        if (TK8) {
-                            const unsigned *myw = reinterpret_cast<const unsigned *>(my);
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) tw_pre[v] = (4 * v < M) ? myw[v] : 0u;
-                            rows = reinterpret_cast<unsigned short *>(my);
-                        }
-                        if (hits == 12 && M >= 12) label = lane_fcna_f32<12>(index_of, f4, negc, W, rows);
-                        else if (hits == 14 && M >= 14) label = lane_fcna_f32<14>(index_of, f4, negc, W, rows);
+                        if (hits == 12 && M >= 12) label = lane_fcna_f32<12>(index_of, f4, negc, W);
+                        else if (hits == 14 && M >= 14) label = lane_fcna_f32<14>(index_of, f4, negc, W);
 #endif
                         if (label > 0) pattern[id] = label;
                         else if (label < 0) defer(cna_todo, id);
@@ -974,7 +959,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || MDH_FCNA_LEAN)) ? 16 / N
                 const unsigned *myw = reinterpret_cast<const unsigned *>(my);
                 unsigned tw[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) tw[v] = (FCNA && MDH_FCNA_LEAN) ? tw_pre[v] : ((4 * v < M) ? myw[v] : 0u);
+                for (int v = 0; v < 4; ++v) tw[v] = (4 * v < M) ? myw[v] : 0u;
                 int idv[16];
                 double dv[16];
                 // four slots at a time: their run-table reads go out together, then their twelve position reads, then four
@@ -1334,7 +1319,7 @@ namespace lane {
 // tk8: one-byte tickets, else two-byte ones; rows of (M + 1) tickets rounded up to a multiple of four; rw rows per wave
 static size_t lds_bytes(int cap, int64_t M, bool tk8, int rw, int nw = 4, bool fcna = false)
 {
-    const size_t wave = std::max<size_t>((size_t)rw * (size_t)ticket_row((int)M, fcna && tk8 && MDH_FCNA_LEAN) * (tk8 ? 1 : 2), 256); // (the kernel's wstride)
+    const size_t wave = std::max<size_t>((size_t)rw * (size_t)ticket_row((int)M, false) * (tk8 ? 1 : 2), 256); // (the kernel's wstride)
     const size_t tk = (size_t)nw * wave;
     return (size_t)cap * 16 + (size_t)cap * 16 + (size_t)cap * 8 + (size_t)cen_cap(nw) * 4 + (size_t)(cap + (cap & 1)) * 2 + ((tk + 15) & ~(size_t)15);
 }

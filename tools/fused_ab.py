@@ -16,14 +16,27 @@ from bench import slab_positions, A_CU, RC
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 136
 sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+kind = sys.argv[4] if len(sys.argv) > 4 else "fcc"   # "bcc": a bcc Fe lattice of about the same size, rc = 1.2 a (14 neighbours: (6,6,6) and (4,4,4) bonds)
 M = 16
 dev = torch.device("cuda", 0)
 if os.environ.get("NB_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["NB_LIB"])
 L = _lib.lib()
-x, y, z, _ = slab_positions(torch, dev, cells, 0, sigma)
+if kind == "bcc":
+    from mdapy_amd.build_lattice import lattice_positions
+    a_fe = 2.87
+    nb = int(round(cells * (2.0 ** (1.0 / 3.0))))
+    pos, boxm = lattice_positions("bcc", a_fe, nb, nb, nb)
+    if sigma:
+        pos = pos + np.random.default_rng(3).normal(0.0, sigma, pos.shape)
+    x, y, z = (torch.from_numpy(np.ascontiguousarray(pos[:, k])).to(dev) for k in range(3))
+    b = mp.Box(boxm)
+    RC = 1.2 * a_fe
+    del pos
+else:
+    x, y, z, _ = slab_positions(torch, dev, cells, 0, sigma)
+    b = mp.Box(np.diag([A_CU * cells] * 3))
 n = int(x.shape[0])
-b = mp.Box(np.diag([A_CU * cells] * 3))
 bx = (b.box, b.origin, b.boundary)
 
 
@@ -74,7 +87,7 @@ for name, fn in (("two_calls", two_calls), ("fused", fused), ("two_calls", two_c
     L.mdh_prof_enable(0)
     r = report()
     res.setdefault(name, []).append(ms)
-    print(f"{name:10s} N={n} sigma={sigma}: {ms:.4f} ms per step; ranges {r}", flush=True)
+    print(f"{name:10s} {kind} N={n} sigma={sigma}: {ms:.4f} ms per step; ranges {r}", flush=True)
 same = bool(torch.equal(v1, v2) and torch.equal(d1, d2) and torch.equal(c1, c2) and torch.equal(p1, p2))
 print("lists and labels identical:", same, "labels", torch.bincount(p1).tolist())
 a, f = min(res["two_calls"]), min(res["fused"])

@@ -32,7 +32,7 @@ if os.path.exists(bj):
     json.dump({"source": "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) run by bench.py itself over the benchmarked step, this round's measurement pass",
                "traffic_bytes_per_launch_raw": rf["traffic_raw_fetch_plus_write"], "traffic_bytes_per_launch_fetch_x2": rf["traffic"],
                "traffic_source": rf["traffic_source"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
-               "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; kernel = k_neighbor_lane incl. its slice pass"},
+               "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; kernel = k_neighbor_lane (the instance that also labels: lists + CNA) incl. its slice pass"},
               open(os.path.join(P, "r05_traffic.json"), "w"), indent=1)
     bs, src = stats(os.path.join(G, "r05_bench"))
     if src:
@@ -43,7 +43,7 @@ if os.path.exists(bj):
                     f"events inside the library {rf['avg_kernel_ms']:.4f} ms -> {rf['achieved']:.0f} GB/s algorithmic = {rf['frac']:.4f} of 8 TB/s; PMC traffic "
                     f"{(rf['traffic'] or 0) / 1e9:.3f} GB per launch, FETCH doubled, vs {rf['algorithmic_bytes_per_launch'] / 1e9:.3f} GB algorithmic), then the same command "
                     "(`--no-extra --no-pmc --no-cpu-baseline`) under the kernel trace, whose table follows.\n\n"
-                    "The lane kernel is launched twice per build (all tiles, then the one-cell slices of the tiles whose halo overflowed LDS: an empty stand-by on this input).\n\n"
+                    "The tile kernel (the instance with the fused CNA: it writes the lists and the labels) is launched twice per build (all tiles, then the one-cell slices of the tiles whose halo overflowed LDS: an empty stand-by on this input).\n\n"
                     "| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n")
             for k, (c, a, mn, mx) in sorted(bs.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:16]:
                 f.write(f"| `{k}` | {c} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} |\n")
@@ -58,14 +58,34 @@ for o in ("lattice", "blocks", "shuffled", "poly", "poly_shuffled"):
         rows.append((o, log[-1].strip(), st))
 if rows:
     with open(os.path.join(P, "r05_order_probe.txt"), "w") as f:
-        f.write("# the headline step (two C-ABI calls) on the same atoms in five orders; tools/measure_r05.sh order = tools/order_probe.py under rocprofv3 --kernel-trace --stats\n"
+        f.write("# the headline step (ONE C-ABI call, mdh_build_neighbor_fcna: lists and labels in one pass over the tiles; the two-call form of the start of the round: r05a_order_probe.txt) on the same atoms in five orders; tools/measure_r05.sh order = tools/order_probe.py under rocprofv3 --kernel-trace --stats\n"
                 "# lattice: the builder's order; blocks: 4096-atom blocks dealt out at random; shuffled: one random permutation; poly: 9.87 M-atom polycrystal in its builder's\n"
                 "# order (grain by grain); poly_shuffled: the same permuted.  Kernel averages include the three warm-up steps (the first call with new positions still takes\n"
                 "# the spatial-order paths: the hints of csrc/runtime.hip order_hint are sampled on it)\n\n")
         for o, line, st in rows:
             f.write(line + "\n")
-            for k in ("k_assign<false>", "k_scan_onepass<true, 32>", "k_scatter", "k_sort_cells", "k_gather", "k_gather_records", "lane::k_neighbor_lane<false, false, false, false, true, 4>",
-                      "k_fcna_f32<false, false>", "k_fcna_f32<false, true>", "k_pack_positions"):
+            for k in ("k_assign<false, 4>", "k_assign<false, 1>", "k_scan_onepass<true, 32>", "k_scatter", "k_sort_cells", "k_gather", "k_gather_records",
+                      "lane::k_neighbor_lane<false, false, false, true, true, 4>", "lane::k_neighbor_lane<false, false, false, false, true, 4>",
+                      "k_fcna_f32<false, false>", "k_fcna_f32<false, true>", "k_fcna<false, true>", "k_pack_positions"):
+                if k in st:
+                    f.write(f"    {k:64s} calls {st[k][0]:4d}  avg {st[k][1] / 1e3:9.1f} us\n")
+            f.write("\n")
+
+# ---- the same step as two calls (lattice, shuffled): kernel split
+rows2 = []
+for o in ("lattice", "shuffled"):
+    d = os.path.join(G, f"r05_two_{o}")
+    log = [l for l in lines(os.path.join(d, "run.log")) if l.startswith("order=")]
+    st, _ = stats(d)
+    if log:
+        rows2.append((o, log[-1].strip(), st))
+if rows2:
+    with open(os.path.join(P, "r05_two_calls_probe.txt"), "w") as f:
+        f.write("# the headline step as the TWO calls it was until the labels moved into the tile kernel (PROBE_TWO_CALLS=1 tools/order_probe.py), same box and pass as r05_order_probe.txt\n\n")
+        for o, line, st in rows2:
+            f.write(line + "\n")
+            for k in ("k_assign<false, 4>", "k_assign<false, 1>", "k_scan_onepass<true, 32>", "k_scatter", "k_sort_cells", "k_gather", "k_gather_records",
+                      "lane::k_neighbor_lane<false, false, false, false, true, 4>", "k_fcna_f32<false, false>", "k_fcna_f32<false, true>", "k_fcna<false, true>", "k_pack_positions"):
                 if k in st:
                     f.write(f"    {k:64s} calls {st[k][0]:4d}  avg {st[k][1] / 1e3:9.1f} us\n")
             f.write("\n")
@@ -73,7 +93,7 @@ if rows:
 # ---- plain copies
 for src, dst in (("r05_order_sweep.txt", "r05_order_sweep.txt"), ("r05_strong.txt", "r05_strong.txt"), ("r05_halo_cost.txt", "r05_halo_cost.txt"),
                  ("r05_weak.txt", "r05_weak_timeline.txt"), ("r05_lane_tiles.txt", "r05_lane_tiles.txt"), ("r05_fuzz_parity.txt", "r05_fuzz_parity.txt"),
-                 ("r05_fuzz_system.txt", "r05_fuzz_system.txt"), ("r05_fuzz_twin.txt", "r05_fuzz_twin.txt"), ("r05_twin_probe.txt", "r05_twin_probe.txt")):
+                 ("r05_fuzz_system.txt", "r05_fuzz_system.txt"), ("r05_fuzz_twin.txt", "r05_fuzz_twin.txt"), ("r05_twin_probe.txt", "r05_twin_probe.txt"), ("r05_fused_ab.txt", "r05_fused_ab.txt")):
     if os.path.exists(os.path.join(G, src)):
         open(os.path.join(P, dst), "w").writelines(lines(os.path.join(G, src)))
 

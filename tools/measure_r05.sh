@@ -17,6 +17,10 @@ echo "=================== section $section"
 case $section in
 order)     # the headline step on the same atoms in five orders, per-kernel split of each
   for o in lattice blocks shuffled poly poly_shuffled; do echo "--- order $o"; prof order_$o python $R/tools/order_probe.py $o 136 10; done ;;
+two_calls)  # the same step as the two calls it was until the labels moved into the tile kernel: kernel split on the lattice and the shuffled frame
+  for o in lattice shuffled; do echo "--- order $o (two calls)"; PROBE_TWO_CALLS=1 prof two_$o python $R/tools/order_probe.py $o 136 10; done ;;
+fused_ab)   # one call against two on lattices rattled by 0 ... 0.3 A, and against the double-precision form (make fcna64)
+  WITH_F64=1 SIGMAS="0.0 0.05 0.1 0.2 0.3" bash tools/ab_fused.sh 2>&1 | tee $O/r05_fused_ab.txt ;;
 bench)     # the default bench line, then the same command under the kernel trace
   timeout 1200 python bench.py > $O/r05_bench.json 2> $O/r05_bench.err; tail -c 900 $O/r05_bench.json
   prof bench python $R/bench.py --no-extra --no-pmc --no-cpu-baseline ;;

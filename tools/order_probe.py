@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""The headline step (build_neighbor M = 16 + fixed CNA through the C ABI) on the SAME atoms handed in in different orders.
+"""The headline step (build_neighbor M = 16 + fixed CNA through the C ABI: ONE call, mdh_build_neighbor_fcna; PROBE_TWO_CALLS=1: the two calls
+it replaces) on the SAME atoms handed in in different orders.
 Usage: python tools/order_probe.py ORDER [cells] [steps]   ORDER in lattice | shuffled | blocks | poly | poly_shuffled
 (run one ORDER per process under `rocprofv3 --kernel-trace --stats` for the per-kernel split; tools/measure_r05.sh section order)"""
 import ctypes, os, sys, time
@@ -43,10 +44,16 @@ verlet = torch.empty((n, M), dtype=torch.int32, device=dev); dist = torch.empty(
 nn = torch.empty((n,), dtype=torch.int32, device=dev); pat = torch.zeros((n,), dtype=torch.int32, device=dev)
 
 
+two_calls = os.environ.get("PROBE_TWO_CALLS", "") == "1"  # the step as mdh_build_neighbor + mdh_fcna (the headline until the one-pass form)
+
+
 def step():
     pat.zero_()
-    _neighbor.build_neighbor(x, y, z, *bx, RC, verlet, dist, nn, 1, fill_pads=True)
-    _cna.fcna(x, y, z, *bx, verlet, nn, pat, RC, 1)
+    if two_calls:
+        _neighbor.build_neighbor(x, y, z, *bx, RC, verlet, dist, nn, 1, fill_pads=True)
+        _cna.fcna(x, y, z, *bx, verlet, nn, pat, RC, 1)
+    else:
+        _neighbor.build_neighbor_fcna(x, y, z, *bx, RC, verlet, dist, nn, pat, 1, fill_pads=True)
 
 
 for _ in range(3):
@@ -64,4 +71,4 @@ torch.cuda.synchronize()
 L.mdh_prof_enable(0)
 buf = ctypes.create_string_buffer(1 << 16); L.mdh_prof_report(buf, len(buf))
 k = {ln.split()[0]: round(float(ln.split()[2]) / int(ln.split()[1]), 4) for ln in buf.value.decode().strip().splitlines()}
-print(f"order={order} N={n} ms_per_step={ms:.4f} ranges_ms={k} fcc={int((pat == 1).sum())} nn_max={int(nn.max())}", flush=True)
+print(f"order={order} form={'two calls' if two_calls else 'one call'} N={n} ms_per_step={ms:.4f} ranges_ms={k} fcc={int((pat == 1).sum())} nn_max={int(nn.max())}", flush=True)
