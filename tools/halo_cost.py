@@ -71,10 +71,9 @@ ubox = mp.Box(np.diag([A_CU * cells] * 3))
 from mdapy_amd import _neighbor as _nb, _cna as _cn
 uv, ud = torch.empty((n, 16), dtype=torch.int32, device=dev), torch.empty((n, 16), dtype=torch.float64, device=dev)
 un, up = torch.empty((n,), dtype=torch.int32, device=dev), torch.zeros((n,), dtype=torch.int32, device=dev)
-def undivided():
+def undivided():  # (the headline step: lists and labels in one call, as the decomposed step makes them)
     up.zero_()
-    _nb.build_neighbor(xs, ys, zs, ubox.box, ubox.origin, ubox.boundary, RC, uv, ud, un, 1, fill_pads=True)
-    _cn.fcna(xs, ys, zs, ubox.box, ubox.origin, ubox.boundary, uv, un, up, RC, 1)
+    _nb.build_neighbor_fcna(xs, ys, zs, ubox.box, ubox.origin, ubox.boundary, RC, uv, ud, un, up, 1, fill_pads=True)
 ms_und, _ = timed(undivided, reps=20)
 print(f"undivided step of {n} atoms on the same box {ms_und:.2f} ms: loop-back slab step = {ms_step / ms_und:.3f}x, pipelined {ms_pipe / ms_und:.3f}x")
 
