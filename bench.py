@@ -614,7 +614,7 @@ def main():
                 if live is not None:
                     traffic, traffic_raw, source = 2.0 * live[0] + live[1], live[0] + live[1], "live"
             if traffic is None:
-                tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+                tpath = os.path.join(ROOT, "profiles", "r05_traffic.json")
                 if os.path.exists(tpath) and cells == 136 and M == 16 and world == 1 and args.sigma == 0.0:
                     with open(tpath) as fh:
                         t = json.load(fh)
