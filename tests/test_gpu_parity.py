@@ -568,6 +568,49 @@ def test_fused_labels_single_precision_pair_tests_vs_oracle(case):
         assert (want > 0).mean() > 0.5
 
 
+def test_fused_labels_where_the_tile_kernel_does_not_apply():
+    """boxes of fewer than seven cells per periodic axis, a thin slab that is replicated first, an empty and a one-atom system: the
+    one-call entries label from the finished rows (thread-per-atom build, then the analysis inside the call) — lists and labels as
+    the two reference calls leave them; System.cal_common_neighbor_analysis(rc) on the same inputs against the oracle-backed class"""
+    rng = np.random.default_rng(17)
+    a = 3.615
+    for n, sig, bnd in (((5, 5, 5), 0.05, PBC), ((6, 4, 3), 0.1, np.array([1, 0, 1], np.int32)), ((3, 3, 3), 0.02, PBC)):
+        pos, box = lattice_positions("fcc", a, *n)
+        pos = pos + rng.normal(0, sig, pos.shape)
+        x, y, z = _xyz(pos)
+        rc = 0.854 * a
+        if min(np.diag(box)[np.asarray(bnd) == 1]) < 2 * rc:
+            continue
+        v, d, c = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, bnd, rc, 4)
+        want = np.zeros(len(x), np.int32)
+        O.fcna(x, y, z, box, ORG0, bnd, v, c, want, rc, 4)
+        pe = np.zeros(len(x), np.int32)
+        ve, de, ne = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, ORG0, bnd, rc, 1, pattern=pe)
+        assert np.array_equal(ve, v) and np.array_equal(de, d) and np.array_equal(ne, c) and np.array_equal(pe, want), n
+        M = int(v.shape[1]) + 2
+        vf = np.empty((len(x), M), np.int32); df = np.empty((len(x), M)); nf = np.empty(len(x), np.int32); pf = np.zeros(len(x), np.int32)
+        _neighbor.build_neighbor_fcna(x, y, z, box, ORG0, bnd, rc, vf, df, nf, pf, 1, fill_pads=True)
+        assert np.array_equal(nf, c) and np.array_equal(vf[:, :M - 2], v) and np.array_equal(pf, want), n
+    # through System: a thin periodic slab (replicated: the labels come from the class, not from the one-call entry), and the 5 x 5 x 5 box
+    import mdapy_amd as mp
+    for n in ((5, 5, 5), (8, 8, 1)):
+        pos, box = lattice_positions("fcc", a, *n)
+        pos = pos + rng.normal(0, 0.04, pos.shape)
+        s = mp.System(pos=pos, box=box)
+        s.cal_common_neighbor_analysis(rc=0.854 * a)
+        got = np.asarray(s.data["cna"].to_numpy())
+        x, y, z = _xyz(pos)
+        # the oracle on a replica wide enough for the reference's own rule (15 A): labels of the first copy
+        reps = [int(np.ceil(15.0 / L)) if L < 15.0 else 1 for L in np.diag(box)]
+        big = np.concatenate([pos + np.array([i, j, k]) * np.diag(box) for i in range(reps[0]) for j in range(reps[1]) for k in range(reps[2])])
+        bb = box * np.array(reps)[:, None]
+        bx, by, bz = _xyz(big)
+        v, d, c = O.build_neighbor_without_max_neigh(bx, by, bz, bb, ORG0, PBC, 0.854 * a, 4)
+        want = np.zeros(len(bx), np.int32)
+        O.fcna(bx, by, bz, bb, ORG0, PBC, v, c, want, 0.854 * a, 4)
+        assert np.array_equal(got, want[:len(pos)]), n
+
+
 @pytest.mark.parametrize("case", [c for c in _fcna_cases() if c[0] != "fcc_second_shell_in_band"], ids=lambda c: c[0])
 def test_acna_single_precision_pair_tests_vs_oracle(case):
     """adaptive CNA on boxes large enough for the single-precision kernel (edges > 8 local cutoffs): labels == oracle == the
