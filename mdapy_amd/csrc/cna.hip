@@ -668,15 +668,15 @@ void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const doubl
 }
 
 void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
-                        int64_t M, const int *nn, int *pattern, double rc, int *todo)
+                        int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done)
 {
     // the list's length is on the device and usually zero: a grid that fills the chip once walks a long list, and an empty one
     // costs 5 us instead of the 17 us that N / 256 workgroups take to leave
     dim3 grid(std::min<unsigned>(grid_for(N, 256), 256u)), block(256);
     if (b.tri)
-        hipLaunchKernelGGL((k_fcna<true, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        hipLaunchKernelGGL((k_fcna<true, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
     else
-        hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo);
+        hipLaunchKernelGGL((k_fcna<false, true>), grid, block, 0, st, x, y, z, N, b, verlet, M, nn, pattern, rc, todo, done);
 }
 
 } // namespace mdh

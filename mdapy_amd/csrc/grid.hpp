@@ -125,7 +125,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
 void launch_fcna_all(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
                      int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done = nullptr, const Pos4 *pos = nullptr, const int *use_pos = nullptr);
 void launch_fcna_listed(hipStream_t st, const DBox &b, const double *x, const double *y, const double *z, int64_t N, const int *verlet,
-                        int64_t M, const int *nn, int *pattern, double rc, int *todo);
+                        int64_t M, const int *nn, int *pattern, double rc, int *todo, int *done = nullptr);
 
 __host__ __device__ __forceinline__ int pmod(int a, int n) // neighbor.cpp:18-22
 {

@@ -1560,11 +1560,13 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
     double *dd = sc.stage(dist, (size_t)(N * max_neigh), space, !fill_pads, true);
     int *dn = sc.stage(nn, (size_t)N, space, false, true);
     int *dp = sc.stage(pattern, (size_t)N, space, true, true); // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
-    int *todo = sc.alloc_n<int>((size_t)N + 1);
+    // the to-do list of the labels (count first) in a kept block whose two counters — workgroups done (word 0), length (word 64) — are
+    // zero whenever it is idle (the kernel that walks the list clears them when it leaves, cna.hip k_fcna): no memset per call
+    int *done = static_cast<int *>(sc.alloc_kept(sizeof(int) * ((size_t)N + 1 + 64), Scope::KEEP_TODO));
+    int *todo = done ? done + 64 : nullptr;
     const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
     if (sc.failed())
         return sc.error();
-    MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), sc.stream()));
     CellGrid cg;
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
@@ -1578,10 +1580,11 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
     }
     {
         ProfRange pr("k_fcna", sc.stream());
-        if (fused) launch_fcna_listed(sc.stream(), b, dx, dy, dz, N, dv, max_neigh, dn, dp, rc, todo);
-        else launch_fcna_all(sc.stream(), b, dx, dy, dz, N, dv, max_neigh, dn, dp, rc, todo);
+        if (fused) launch_fcna_listed(sc.stream(), b, dx, dy, dz, N, dv, max_neigh, dn, dp, rc, todo, done);
+        else launch_fcna_all(sc.stream(), b, dx, dy, dz, N, dv, max_neigh, dn, dp, rc, todo, done);
         MDH_HIP(hipGetLastError());
     }
+    sc.keep_confirm(done);
     return sc.finish(space);
 }
 
@@ -1674,7 +1677,8 @@ int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double
     int *dmax = sc.alloc_n<int>(1);
     const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
     int *dp = pattern ? sc.stage(pattern, (size_t)N, space, true, true) : nullptr; // atoms without 12 or 14 neighbours keep the caller's value (cna.cpp:456)
-    int *todo = pattern ? sc.alloc_n<int>((size_t)N + 1) : nullptr;
+    int *done = pattern ? static_cast<int *>(sc.alloc_kept(sizeof(int) * ((size_t)N + 1 + 64), Scope::KEEP_TODO)) : nullptr; // (as in mdh_build_neighbor_fcna)
+    int *todo = done ? done + 64 : nullptr;
     if (sc.failed())
         return sc.error();
     hipStream_t st = sc.stream();
@@ -1691,8 +1695,9 @@ int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double
         if (!dp)
             return;
         ProfRange pr("k_fcna", st);
-        if (fused) launch_fcna_listed(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
-        else launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo);
+        if (fused) launch_fcna_listed(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo, done);
+        else launch_fcna_all(st, b, dx, dy, dz, N, dv, M, dn, dp, rc, todo, done);
+        sc.keep_confirm(done); // (the list's walker leaves the counters zero)
     };
     // Width hint: the largest count the previous call with the same (N, grid) found.  A sequence of calls on one system (a
     // trajectory, the same analysis repeated) almost always finds the same maximum again, so the rows are built at that
@@ -1709,7 +1714,6 @@ int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double
             return sc.error();
         {
             ProfRange pr("k_neighbor", st);
-            if (todo) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
             MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, hint, 2, nullptr, dp, todo, &fused));
             hipLaunchKernelGGL(k_max_i32, dim3(1024), dim3(256), 0, st, dn, N, dmax);
             MDH_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1737,7 +1741,6 @@ int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double
             return sc.error();
         {
             ProfRange pr("k_neighbor", st);
-            if (todo) MDH_HIP(hipMemsetAsync(todo, 0, sizeof(int), st));
             fused = false;
             MDH_TRY(neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, M, 2, nullptr, dp, todo, &fused));
         }
