@@ -1037,6 +1037,22 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                 // of the CU, at about two cycles per request, was a quarter of the kernel's time.
                 {
                     const int rid = mine ? id : -1;
+#ifdef MDH_EXP_SCATTER // measuring build (make scatter): every lane stores its own row, 16 bytes at a time (64 line requests per store instruction)
+                    if (write_pads && (M & 3) == 0) {
+                        if (rid >= 0) {
+                            const uint64_t row = (uint64_t)(unsigned)id * (unsigned)M;
+#pragma unroll
+                            for (int pp = 0; pp < 4; ++pp)
+                                if (4 * pp < M)
+                                    *reinterpret_cast<Int4 *>(verlet + row + 4 * pp) = Int4{idv[4 * pp], idv[4 * pp + 1], idv[4 * pp + 2], idv[4 * pp + 3]};
+#pragma unroll
+                            for (int piece = 0; piece < 8; ++piece)
+                                if (2 * piece < M)
+                                    *reinterpret_cast<Int4 *>(dist + row + 2 * piece) = Int4{__double2loint(dv[2 * piece]), __double2hiint(dv[2 * piece]),
+                                                                                              __double2loint(dv[2 * piece + 1]), __double2hiint(dv[2 * piece + 1])};
+                        }
+                    } else
+#endif
                     if (write_pads && (M & 3) == 0) {
                         const int odd1 = -(lane & 1), odd2 = -((lane >> 1) & 1), u4 = lane & 3;
                         int P[4][4];
