@@ -153,6 +153,69 @@ def test_fixed_cutoff_cna_is_lent_a_remembered_list_of_the_same_cutoff(oracle_ba
     assert lent == [True, False] and np.array_equal(s.data["cna"].to_numpy(), want)
 
 
+def test_labels_made_in_the_pass_that_builds_the_list(oracle_backend, monkeypatch):
+    """a System without a list: cal_common_neighbor_analysis(rc[, max_neigh]) builds the list (it stays the system's, with its
+    provenance) and takes the labels from the SAME pass (Neighbor.compute(label=True) -> build_neighbor_fcna / the exact-width entry
+    with `pattern`) — no CommonNeighborAnalysis job, labels those of the class on explicit lists; the class without a list does the
+    same; a thin box (searched on a replica) falls back to the class"""
+    from mdapy_amd import kernels
+    from mdapy_amd import system as S
+    from mdapy_amd.build_lattice import lattice_positions
+    from mdapy_amd.common_neighbor_analysis import CommonNeighborAnalysis
+    from mdapy_amd.neighbor import Neighbor
+
+    pos, box = lattice_positions("fcc", 3.615, 6, 6, 6)
+    pos = pos + np.random.default_rng(7).normal(0, 0.06, pos.shape)
+    rc = 0.854 * 3.615
+    calls = {"fixed": 0, "exact": 0, "job": 0}
+    real_fixed, real_exact = kernels.neighbor.build_neighbor_fcna, kernels.neighbor.build_neighbor_without_max_neigh
+
+    def fixed(*a, **k):
+        calls["fixed"] += 1
+        return real_fixed(*a, **k)
+
+    def exact(*a, **k):
+        calls["exact"] += "pattern" in k
+        return real_exact(*a, **k)
+
+    monkeypatch.setattr(kernels.neighbor, "build_neighbor_fcna", fixed)
+    monkeypatch.setattr(kernels.neighbor, "build_neighbor_without_max_neigh", exact)
+    real_job = S.CommonNeighborAnalysis
+
+    def job(*a):
+        calls["job"] += 1
+        return real_job(*a)
+
+    monkeypatch.setattr(S, "CommonNeighborAnalysis", job)
+    # the reference's two steps, by hand
+    ref = Neighbor(rc, mp.Box(box), mp.System(pos=pos, box=mp.Box(box)).data)
+    ref.compute()
+    by_hand = CommonNeighborAnalysis(mp.System(pos=pos, box=mp.Box(box)).data, mp.Box(box), ref.verlet_list, ref.neighbor_number, rc)
+    by_hand.compute()
+    want = np.asarray(by_hand.pattern)
+    assert (want == 1).mean() > 0.9
+    for max_neigh, key in ((None, "exact"), (20, "fixed")):
+        s = mp.System(pos=pos, box=mp.Box(box))
+        s.cal_common_neighbor_analysis(rc, max_neigh)
+        assert calls[key] == 1 and calls["job"] == 0, (max_neigh, calls)
+        assert np.array_equal(s.data["cna"].to_numpy(), want)
+        assert s.rc == rc and s._list_cutoff == float(rc) and np.array_equal(np.asarray(s.neighbor_number), np.asarray(ref.neighbor_number))
+        width = 20 if max_neigh else int(np.asarray(ref.verlet_list).shape[1])
+        assert np.asarray(s.verlet_list).shape == (len(pos), width)
+        s.cal_common_neighbor_analysis(rc, max_neigh)  # now the remembered list is lent to the class
+        assert calls["job"] == 1 and np.array_equal(s.data["cna"].to_numpy(), want)
+        calls.update(fixed=0, exact=0, job=0)
+    # the class on its own (no list handed in)
+    alone = CommonNeighborAnalysis(mp.System(pos=pos, box=mp.Box(box)).data, mp.Box(box), rc=rc)
+    alone.compute()
+    assert calls["exact"] == 1 and np.array_equal(np.asarray(alone.pattern), want)
+    # Neighbor.compute(label=True) on a box thinner than two cutoffs: searched on a replica, no labels offered
+    thin_pos, thin_box = lattice_positions("fcc", 3.615, 6, 6, 1)
+    thin = Neighbor(rc, mp.Box(thin_box), mp.System(pos=thin_pos, box=mp.Box(thin_box)).data)
+    thin.compute(label=True)
+    assert thin.pattern is None and hasattr(thin, "_enlarge_data")
+
+
 def test_stale_rc_beside_a_k_nearest_list_lends_nothing(oracle_backend, monkeypatch):
     """build_neighbor(rc), build_nearest_neighbor(8), cal_common_neighbor_analysis(rc): `rc` survives the k-nearest search (as in
     the reference, src/mdapy/system.py:1256-1263) but the current list is a k-nearest list — the analysis must build its own
