@@ -177,32 +177,12 @@ __device__ __forceinline__ int fcna_atom_f32(const DBox &b, const double *__rest
     for (int a = 0; a < NN; ++a)
         adj[a] = 0;
     unsigned w = 0x7f7fffffu; // bits of the smallest non-negative d2 - c seen
-#pragma unroll
-    for (int a = 0; a < NN; ++a)
-#pragma unroll
-        for (int c = a + 1; c < NN; ++c) {
-            // (spelled out: left to itself the compiler pairs the tests into packed-f32 instructions, which issue at the
-            // double-precision rate, and shuffles operands into place with hundreds of moves)
-            float t0, t1, t2;
-            asm("v_sub_f32 %[t0], %[xc], %[xa]\n\t"
-                "v_sub_f32 %[t1], %[yc], %[ya]\n\t"
-                "v_sub_f32 %[t2], %[zc], %[za]\n\t"
-                "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"
-                "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
-                "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
-                "v_min_u32 %[w], %[w], %[t0]\n\t"
-                "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"
-                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
-                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]"
-                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w] "+v"(w), [ra] "+v"(adj[a]), [rc] "+v"(adj[c])
-                : [xc] "v"(ux[c]), [xa] "v"(ux[a]), [yc] "v"(uy[c]), [ya] "v"(uy[a]), [zc] "v"(uz[c]), [za] "v"(uz[a]),
-                  [negc] "v"(negc), [sc] "n"(c), [sa] "n"(a));
-        }
+    // (spelled out in cna_core.hpp: left to itself the compiler pairs the tests into packed-f32 instructions, which issue at the
+    // double-precision rate, and shuffles operands into place with hundreds of moves)
+    pair_tests_f32<NN, NN, 0>(ux, uy, uz, negc, adj, w);
     if (w <= __float_as_uint(W))
         return -1;
-#pragma unroll
-    for (int a = 0; a < NN; ++a) lds_col[a * 256] = (unsigned short)adj[a];
-    return fcna_label_words<NN>(adj, RowsLds{lds_col, 256});
+    return fcna_label_words<NN>(adj, RowsLds{lds_col, 256}); // (no row is fetched by a computed index any more: nothing is written to lds_col)
 }
 
 // Held to 128 VGPRs (four waves per SIMD): the few spills that costs (the 14-neighbour branch) are cheaper than three waves;
@@ -217,7 +197,6 @@ __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ 
                                                      const int *__restrict__ use_pos = nullptr)
 {
     if (REC && use_pos && *use_pos == 0) pos = nullptr; // (the rows name neighbours close by in memory: the records were not packed)
-    __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread
     // XCD-aware order of the workgroups (workgroup b runs on XCD b % 8): every XCD takes ONE contiguous eighth of the atoms, so that
     // the neighbours its waves gather — a few atoms, rows and planes away in a spatial order — are lines its own L2 has just seen,
     // not lines seven other L2s fetch as well (the grid is rounded up to a multiple of eight workgroups)
@@ -244,12 +223,12 @@ __global__ __launch_bounds__(256, 4) void k_fcna_f32(const double *__restrict__ 
         }
 #pragma unroll
         for (int a = 0; a < 12; ++a) ids[a] = safe_id(ids[a], i, N);
-        t = fcna_atom_f32<12, TRI, REC>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x, pos);
+        t = fcna_atom_f32<12, TRI, REC>(b, x, y, z, ids, negc, W, reach, nullptr, pos);
     } else if (n == 14 && M >= 14) {
         int ids[14];
 #pragma unroll
         for (int a = 0; a < 14; ++a) ids[a] = safe_id(row[a], i, N);
-        t = fcna_atom_f32<14, TRI, REC>(b, x, y, z, ids, negc, W, reach, srows + threadIdx.x, pos);
+        t = fcna_atom_f32<14, TRI, REC>(b, x, y, z, ids, negc, W, reach, nullptr, pos);
     }
     if (t > 0) pattern[i] = t;
     else if (t < 0) defer(todo, i);
@@ -265,25 +244,7 @@ __device__ __forceinline__ void pair_rows_f32(const float (&ux)[NV], const float
 #pragma unroll
     for (int a = 0; a < NN; ++a)
         adj[a] = 0;
-#pragma unroll
-    for (int a = 0; a < NN; ++a)
-#pragma unroll
-        for (int c = a + 1; c < NN; ++c) {
-            float t0, t1, t2;
-            asm("v_sub_f32 %[t0], %[xc], %[xa]\n\t"
-                "v_sub_f32 %[t1], %[yc], %[ya]\n\t"
-                "v_sub_f32 %[t2], %[zc], %[za]\n\t"
-                "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"
-                "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
-                "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
-                "v_min_u32 %[w], %[w], %[t0]\n\t"
-                "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"
-                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
-                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]"
-                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w] "+v"(w), [ra] "+v"(adj[a]), [rc] "+v"(adj[c])
-                : [xc] "v"(ux[c]), [xa] "v"(ux[a]), [yc] "v"(uy[c]), [ya] "v"(uy[a]), [zc] "v"(uz[c]), [za] "v"(uz[a]),
-                  [negc] "v"(negc), [sc] "n"(c), [sa] "n"(a));
-        }
+    pair_tests_f32<NN, NV, 0>(ux, uy, uz, negc, adj, w);
 }
 
 // The adaptive analysis with the pair tests of both passes in single precision.  The 14 neighbour vectors are evaluated once,
@@ -344,8 +305,6 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
         pair_rows_f32<12, 14>(ux, uy, uz, -cf, adj, w);
         if (w <= __float_as_uint(Wf))
             return -1;
-#pragma unroll
-        for (int a = 0; a < 12; ++a) lds_col[a * 256] = (unsigned short)adj[a];
         const CnaCounts c = cna_counts_words<12, 0>(adj, L); // (the reference's loop stops at the first signature of another kind;
         if (c.n421 == 12) label = 1;                      //  every label needs all twelve to be of the listed kinds: same result)
         else if (c.n421 == 6 && c.n422 == 6) label = 2;
@@ -370,8 +329,6 @@ __device__ __forceinline__ int acna_atom_f32(const DBox &b, const Pos4 *__restri
         pair_rows_f32<14, 14>(ux, uy, uz, -cf, adj, w);
         if (w <= __float_as_uint(Wf))
             return -1;
-#pragma unroll
-        for (int a = 0; a < 14; ++a) lds_col[a * 256] = (unsigned short)adj[a];
         const CnaCounts c = cna_counts_words<14, 0>(adj, L);
         if (c.n666 == 8 && c.n444 == 6) label = 3;
     }
@@ -383,11 +340,10 @@ __global__ __launch_bounds__(256, 4) void k_acna_f32(const Pos4 *__restrict__ po
                                                      const int *__restrict__ verlet, int64_t M, int *__restrict__ pattern,
                                                      int *__restrict__ todo)
 {
-    __shared__ unsigned short srows[14 * 256]; // bond rows, a column per thread
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N)
         return;
-    const int t = acna_atom_f32<TRI>(b, pos, i, verlet + i * M, pattern[i], N, srows + threadIdx.x);
+    const int t = acna_atom_f32<TRI>(b, pos, i, verlet + i * M, pattern[i], N, nullptr);
     if (t >= 0) pattern[i] = t;
     else defer(todo, i);
 }

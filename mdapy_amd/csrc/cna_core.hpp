@@ -326,6 +326,92 @@ __device__ __forceinline__ int fcna_label_words(const unsigned (&adj)[NN], const
     return 0;
 }
 
+// pair number p -> (a, c), a < c, in the order (0,1) (0,2) ... (NN-2,NN-1)
+template <int NN> constexpr int pair_a(int p) { int a = 0; while (p >= NN - 1 - a) { p -= NN - 1 - a; ++a; } return a; }
+template <int NN> constexpr int pair_c(int p) { int a = 0; while (p >= NN - 1 - a) { p -= NN - 1 - a; ++a; } return a + 1 + p; }
+// the NN (NN - 1) / 2 single-precision pair tests of the CNA kernels (the first NN of NV vectors), two pairs to a block: e = |u_c - u_a|^2 - c for both, ONE v_min3_u32
+// that tracks the smallest non-negative e seen, the sign of each e shifted into both bond rows — 9.5 register-only instructions per pair
+template <int NN, int NV, int P>
+__device__ __forceinline__ void pair_tests_f32(const float (&ux)[NV], const float (&uy)[NV], const float (&uz)[NV], float negc,
+                                               unsigned (&adj)[NN], unsigned &w)
+{
+    constexpr int NP = NN * (NN - 1) / 2;
+    if constexpr (P + 1 < NP) {
+        constexpr int a0 = pair_a<NN>(P), c0 = pair_c<NN>(P), a1 = pair_a<NN>(P + 1), c1 = pair_c<NN>(P + 1);
+        float t0, t1, t2, s0, s1, s2;
+        // (a row that both pairs touch — (a,c) (a,c+1), or (NN-3,NN-1) (NN-2,NN-1) — must be ONE operand of the block: bound twice it
+        // would be two registers, and one of the two bits would be lost)
+#define MDH_PAIR2_HEAD                                                                                                                 \
+            "v_sub_f32 %[t0], %[xc], %[xa]\n\t"                                                                                        \
+            "v_sub_f32 %[t1], %[yc], %[ya]\n\t"                                                                                        \
+            "v_sub_f32 %[t2], %[zc], %[za]\n\t"                                                                                        \
+            "v_sub_f32 %[s0], %[xd], %[xb]\n\t"                                                                                        \
+            "v_sub_f32 %[s1], %[yd], %[yb]\n\t"                                                                                        \
+            "v_sub_f32 %[s2], %[zd], %[zb]\n\t"                                                                                        \
+            "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"                                                                               \
+            "v_fma_f32 %[s0], %[s0], %[s0], %[negc]\n\t"                                                                               \
+            "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"                                                                                       \
+            "v_fmac_f32 %[s0], %[s1], %[s1]\n\t"                                                                                       \
+            "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"                                                                                       \
+            "v_fmac_f32 %[s0], %[s2], %[s2]\n\t"                                                                                       \
+            "v_min3_u32 %[w], %[w], %[t0], %[s0]\n\t"                                                                                  \
+            "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"                                                                                       \
+            "v_lshrrev_b32 %[s0], 31, %[s0]\n\t"
+#define MDH_PAIR2_IN                                                                                                                   \
+            [xc] "v"(ux[c0]), [xa] "v"(ux[a0]), [yc] "v"(uy[c0]), [ya] "v"(uy[a0]), [zc] "v"(uz[c0]), [za] "v"(uz[a0]),                 \
+            [xd] "v"(ux[c1]), [xb] "v"(ux[a1]), [yd] "v"(uy[c1]), [yb] "v"(uy[a1]), [zd] "v"(uz[c1]), [zb] "v"(uz[a1]),                 \
+            [negc] "v"(negc), [sc] "n"(c0), [sa] "n"(a0), [sd] "n"(c1), [sb] "n"(a1)
+        if constexpr (a0 == a1) {
+            asm(MDH_PAIR2_HEAD
+                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]\n\t"
+                "v_lshl_or_b32 %[ra], %[s0], %[sd], %[ra]\n\t"
+                "v_lshl_or_b32 %[rd], %[s0], %[sb], %[rd]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [w] "+v"(w),
+                  [ra] "+v"(adj[a0]), [rc] "+v"(adj[c0]), [rd] "+v"(adj[c1])
+                : MDH_PAIR2_IN);
+        } else if constexpr (c0 == c1) {
+            asm(MDH_PAIR2_HEAD
+                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]\n\t"
+                "v_lshl_or_b32 %[rb], %[s0], %[sd], %[rb]\n\t"
+                "v_lshl_or_b32 %[rc], %[s0], %[sb], %[rc]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [w] "+v"(w),
+                  [ra] "+v"(adj[a0]), [rc] "+v"(adj[c0]), [rb] "+v"(adj[a1])
+                : MDH_PAIR2_IN);
+        } else {
+            static_assert(a0 != c1 && c0 != a1, "two pairs of a block share a row that the block binds twice");
+            asm(MDH_PAIR2_HEAD
+                "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+                "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]\n\t"
+                "v_lshl_or_b32 %[rb], %[s0], %[sd], %[rb]\n\t"
+                "v_lshl_or_b32 %[rd], %[s0], %[sb], %[rd]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [w] "+v"(w),
+                  [ra] "+v"(adj[a0]), [rc] "+v"(adj[c0]), [rb] "+v"(adj[a1]), [rd] "+v"(adj[c1])
+                : MDH_PAIR2_IN);
+        }
+#undef MDH_PAIR2_HEAD
+#undef MDH_PAIR2_IN
+        pair_tests_f32<NN, NV, P + 2>(ux, uy, uz, negc, adj, w);
+    } else if constexpr (P < NP) {
+        constexpr int a = pair_a<NN>(P), c = pair_c<NN>(P);
+        float t0, t1, t2;
+        asm("v_sub_f32 %[t0], %[xc], %[xa]\n\t"
+            "v_sub_f32 %[t1], %[yc], %[ya]\n\t"
+            "v_sub_f32 %[t2], %[zc], %[za]\n\t"
+            "v_fma_f32 %[t0], %[t0], %[t0], %[negc]\n\t"
+            "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
+            "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
+            "v_min_u32 %[w], %[w], %[t0]\n\t"
+            "v_lshrrev_b32 %[t0], 31, %[t0]\n\t"
+            "v_lshl_or_b32 %[ra], %[t0], %[sc], %[ra]\n\t"
+            "v_lshl_or_b32 %[rc], %[t0], %[sa], %[rc]"
+            : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [w] "+v"(w), [ra] "+v"(adj[a]), [rc] "+v"(adj[c])
+            : [xc] "v"(ux[c]), [xa] "v"(ux[a]), [yc] "v"(uy[c]), [ya] "v"(uy[a]), [zc] "v"(uz[c]), [za] "v"(uz[a]), [negc] "v"(negc),
+              [sc] "n"(c), [sa] "n"(a));
+    }
+}
+
 // to-do list of atoms left to a later kernel: todo[0] = count, todo[1..] = atom ids
 __device__ __forceinline__ void defer(int *__restrict__ todo, int64_t i) { todo[1 + atomicAdd(&todo[0], 1)] = (int)i; }
 
