@@ -591,7 +591,7 @@ def main():
             "dtype": "f64 (CNA pair tests: f32 filter + f64 finish, labels exact)", "data": "synthetic",
             "config": {"workload": (f"FCC Cu a={A_CU}, ONE {cells}^3-cell box cut into {world} slabs along x ({n_local} atoms/GPU, {n_total} total), "
                                     if strong else f"FCC Cu a={A_CU}, {cells}^3 cells per GPU ({n_local} atoms/GPU, {n_total} total), ") +
-                                   f"build_neighbor(rc=0.854a={RC:.5f}, max_neigh={M}) + fixed-cutoff CNA, positions resident in HBM",
+                                   f"build_neighbor(rc=0.854a={RC:.5f}, max_neigh={M}) + fixed-cutoff CNA as one C-ABI call (mdh_build_neighbor_fcna: lists and labels), positions resident in HBM",
                        "atoms_per_gpu": n_local, "rc": RC, "max_neigh": M, "sigma": args.sigma,
                        "parallelism": f"slab{world}" if world > 1 else "single", "world_size_checked": world,
                        "launched_by": "bench.py itself (one process per GPU)" if os.environ.get("MDH_BENCH_SELF_LAUNCHED") == "1"
