@@ -568,6 +568,74 @@ def test_fused_labels_single_precision_pair_tests_vs_oracle(case):
         assert (want > 0).mean() > 0.5
 
 
+def _fcna_wide_and_sheared_cases():
+    """the instances of the fused tile kernel that `_fcna_cases` (orthogonal boxes, rows of <= 16 slots: TRI=0, TK8=1) does not reach:
+    a sheared box periodic along all three vectors and one open along b (TRI=1), and an orthogonal box whose dense region forces
+    the wide (two-byte ticket) instance on a call that also holds 12- and 14-neighbour atoms (TK8=0, FCNA=1)"""
+    rng = np.random.default_rng(61)
+    out = []
+    shear = np.array([[34.0, 0.0, 0.0], [3.4, 34.0, 0.0], [-1.7, 3.4, 34.0]])
+    p, _ = _fcc(10, 0.12, 31, a=3.4)
+    fr = p / 34.0
+    fr = fr + (rng.random(fr.shape) < 0.02) * rng.integers(-1, 2, fr.shape)  # some atoms a cell vector outside the box
+    org = np.array([2.0, -7.5, 11.0])
+    out.append(("sheared_periodic", fr @ shear + org, shear, org, PBC, 0.854 * 3.4, "tri"))
+    fo = p / 34.0
+    fo[:40] += rng.normal(0.0, 0.05, (40, 3)) * np.array([0, 1, 0])
+    out.append(("sheared_open_b", fo @ shear + org, shear, org, np.array([1, 0, 1], np.int32), 0.854 * 3.4, "tri"))
+    # fcc crystal with a ball of it replaced by a dense gas (~11 atoms per cell: 3-cell runs of 32 and more -> the wide instance for
+    # the whole call); the crystal around it keeps its 12 neighbours
+    a = 3.615
+    p, b = _fcc(14, 0.04, 32)
+    c = np.diag(b) / 2
+    keep = np.linalg.norm(p - c, axis=1) > 9.5
+    ball = rng.normal(size=(800, 3))
+    ball = ball / np.linalg.norm(ball, axis=1)[:, None] * (rng.random((800, 1)) ** (1 / 3)) * 8.0 + c
+    out.append(("fcc_with_dense_ball", np.concatenate([p[keep], ball]), b, ORG0, PBC, 0.854 * a, "wide"))
+    pb, bb = lattice_positions("bcc", 2.87, 16, 16, 16)
+    pb = pb + rng.normal(0, 0.03, pb.shape)
+    cb = np.diag(bb) / 2
+    keep = np.linalg.norm(pb - cb, axis=1) > 9.5
+    ballb = rng.normal(size=(580, 3))
+    ballb = ballb / np.linalg.norm(ballb, axis=1)[:, None] * (rng.random((580, 1)) ** (1 / 3)) * 8.0 + cb
+    out.append(("bcc_with_dense_ball", np.concatenate([pb[keep], ballb]), bb, ORG0, PBC, 1.2 * 2.87, "wide"))
+    return out
+
+
+@pytest.mark.parametrize("case", _fcna_wide_and_sheared_cases(), ids=lambda c: c[0])
+def test_fused_labels_sheared_and_wide_instances_vs_oracle(case):
+    """k_neighbor_lane<TRI=1, FCNA=1> and k_neighbor_lane<TK8=0, FCNA=1> DIRECTLY against the oracle: the labels and lists of
+    mdh_build_neighbor_fcna / mdh_build_neighbor_exact_fcna == O.fcna on O.build_neighbor_without_max_neigh (src/cna.cpp:429-506,
+    src/neighbor.cpp:189-388), with the instance that ran asserted through mdh_debug_neighbor_plan"""
+    from mdapy_amd import _lib
+
+    name, pos, box, org, bnd, rc, inst = case
+    x, y, z = _xyz(pos)
+    n = len(x)
+    v, d, c = O.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 4)
+    want = np.zeros(n, np.int32)
+    O.fcna(x, y, z, box, org, bnd, v, c, want, rc, 4)
+    M = int(v.shape[1])
+    assert ((c == 12) | (c == 14)).sum() > 1000 and (want > 0).sum() > 1000, name  # labelled atoms are there
+    plan = np.zeros(8, np.int32)
+    for width in (M, M + 5):
+        vf = np.empty((n, width), np.int32); df = np.empty((n, width)); nf = np.empty(n, np.int32); pf = np.zeros(n, np.int32)
+        for _ in range(2):  # (the second call plans from the first call's run-length statistics)
+            pf[:] = 0
+            _neighbor.build_neighbor_fcna(x, y, z, box, org, bnd, rc, vf, df, nf, pf, 1, fill_pads=True)
+        _lib.lib().mdh_debug_neighbor_plan(plan.ctypes.data)
+        assert plan[0] > 0 and plan[7] == 1, (name, plan)  # the tile kernel took the call
+        if inst == "wide":
+            assert (plan[4] & 2) == 0 and M > 16, (name, plan)  # ... as its wide (two-byte ticket) instance
+        else:
+            assert (plan[4] & 2) != 0, (name, plan)  # ... as its one-byte instance (rows of <= 16 slots), sheared
+        assert np.array_equal(nf, c) and np.array_equal(vf[:, :M], v) and np.array_equal(df[:, :M], d), (name, width)
+        assert np.array_equal(pf, want), (name, width, int((pf != want).sum()))
+    pe = np.zeros(n, np.int32)
+    ve, de, ne = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1, pattern=pe)
+    assert np.array_equal(ne, c) and np.array_equal(ve, v) and np.array_equal(de, d) and np.array_equal(pe, want), name
+
+
 def test_fused_labels_where_the_tile_kernel_does_not_apply():
     """boxes of fewer than seven cells per periodic axis, a thin slab that is replicated first, an empty and a one-atom system: the
     one-call entries label from the finished rows (thread-per-atom build, then the analysis inside the call) — lists and labels as
@@ -2058,6 +2126,17 @@ def test_config3_full_size_polycrystal_neighbor_cna_vs_oracle():
     assert np.array_equal(s.data["cna"].to_numpy(), p0)
     frac = np.bincount(p0, minlength=5) / n
     assert 0.85 < frac[1] < 0.95 and frac[2] < 0.01  # grain interiors fcc, boundaries not
+    # the ONE-CALL path (the kernel bench.py times): a fresh System has no list to lend, so cal_common_neighbor_analysis(rc) makes
+    # the labels inside the tile kernel (mdh_build_neighbor_exact_fcna) — against the oracle's labels, and its exact-width lists
+    # against the oracle's rows
+    del s
+    s2 = mp.System(pos=np.stack([x, y, z], axis=1), box=np.diag([L, L, L]))
+    s2.cal_common_neighbor_analysis(rc=rc)
+    assert "verlet_list" in s2.__dict__ and s2.rc == rc  # the list the labelling pass built stays the system's list
+    assert np.array_equal(s2.data["cna"].to_numpy(), p0)
+    w = int(np.asarray(s2.verlet_list).shape[1])
+    assert w == int(n0.max()) and np.array_equal(np.asarray(s2.neighbor_number), n0)
+    assert np.array_equal(np.asarray(s2.verlet_list), v0[:, :w]) and np.array_equal(np.asarray(s2.distance_list), d0[:, :w])
     print(f"config 3 full size: {n} atoms, builder {t_build:.1f} s, neighbor + CNA through System {t_gpu * 1e3:.0f} ms "
           f"({n / t_gpu / 1e6:.0f} M atoms/s, host arrays in, labels out), oracle on 64 threads {t_cpu:.1f} s ({n / t_cpu / 1e6:.1f} M atoms/s)")
 
