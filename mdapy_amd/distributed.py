@@ -226,12 +226,16 @@ class SlabDecomposition:
             state = self._fast_begin(x, y, z, gid, cols, h, halo, side=False, heads=not static)
         return self._fast_end(state, static)
 
-    def check_halo(self):
-        """raise if a halo message of an exchange with static=True that has run on the device did not fit its agreed size"""
+    def check_halo(self, whose="a"):
+        """raise if a halo message of an exchange with static=True that has RUN on the device did not fit its agreed size (its
+        ghost block was cut short: border atoms of that step have wrong rows and labels).  A static step cannot know this
+        about itself without waiting for the device, so the flag of step n is seen by step n + 1 — and the flag of the LAST
+        step of a run only by this call: synchronise the stream and call it once after the last step (neighbor_cna_step(...,
+        strict=True) does both)"""
         from . import _lib
 
         if _lib.lib().mdh_slab_overflow_check() != 0:
-            raise RuntimeError("a halo message did not fit the agreed size (" + _lib.lib().mdh_last_error().decode("utf-8", "replace") + "): the system changed since the "
+            raise RuntimeError(whose + " halo message did not fit the agreed size (" + _lib.lib().mdh_last_error().decode("utf-8", "replace") + "): the system changed since the "
                                "size was agreed — call reset_halo_capacity() on all ranks and repeat the step")
 
     def start_halo(self, x, y, z, gid, halo: float, extra=(), static=False):
@@ -384,11 +388,11 @@ class SlabDecomposition:
         from . import _lib
 
         t = _torch()
-        self.check_halo()  # (an overflow of an EARLIER step that has run by now)
+        self._busy.discard(id(st["bufs"]))  # (before anything can raise: a failed check must not keep the buffer set marked busy)
+        self.check_halo("an earlier step's")  # (an overflow of an EARLIER step that has run by now)
         if st["side"]:
             t.cuda.current_stream().wait_event(st["done"])
         send_r, send_l, recv_l, recv_r, _ = st["bufs"]
-        self._busy.discard(id(st["bufs"]))
         cap, dev, n_owned, cols, gid = st["cap"], st["dev"], st["n_owned"], st["cols"], st["gid"]
         ptrs = (ctypes.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
         _lib.check(_lib.lib().mdh_slab_append_ghosts_static(recv_l.data_ptr(), recv_r.data_ptr(), cap, ptrs, len(cols), gid.data_ptr(), n_owned,
@@ -521,7 +525,15 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     next_frame = (x, y, z, gid) of the frame the NEXT call will be given: its halo exchange is started on a side stream
     before this frame's kernels are enqueued and travels while they run (SlabDecomposition.start_halo).
     strict: wait for the build and raise if an atom lay outside the slab + halo window the build was promised (atoms that
-    drifted across a face without re-partitioning); without it the build is still memory-safe and the NEXT build raises.
+    drifted across a face without re-partitioning) or if THIS step's halo message did not fit its agreed size; without it
+    the build is still memory-safe, the NEXT step raises for this one, and the caller must end a run with
+    ``torch.cuda.synchronize(); dec.check_halo()`` (the last step has no successor to report it).
+
+    On more than one rank with HBM-resident tensors the exchange is *static*: the ghost count never leaves the device, so
+    the local arrays have ``n_owned + 2 * cap`` rows (``dom.absent_slots`` is True) of which the slots behind the ghosts
+    that arrived hold ABSENT atoms: ``x = NaN``, ``dom.gid = -1``, ``nn = 0``, a row of pads (-1 / rc + 1), label 0.  Index
+    with ``dom.owned`` (or ``dom.gid >= 0``) before scattering by ``dom.gid``.  ``dec._no_static = True`` switches back to
+    the exchange that reads the counts (one host wait per step, exact-size arrays).
     """
     t = _torch()
     # static: the ghost count stays on the device (a ghost block of fixed size with absent slots) — nothing in this step waits
@@ -544,6 +556,9 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     # (absent slots get no row: their counts must read 0 for the CNA behind the build)
     nn = (t.zeros if getattr(dom, "absent_slots", False) else t.empty)((n,), dtype=t.int32, device=dom.x.device)
     pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
+    if getattr(dom, "absent_slots", False):  # the build writes no row for an absent atom: pads, not what the allocator left
+        verlet[dom.n_owned:].fill_(-1)
+        dist[dom.n_owned:].fill_(rc + 1.0)
     dec.hint_window(rc, dom.x)
     # lists and labels in ONE pass over the tiles (mdh_build_neighbor_fcna: a centre's 12 or 14 neighbours are still staged in LDS
     # when its row is written) — bit for bit what build_neighbor followed by fcna leaves
@@ -551,6 +566,9 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
                                          key=dom.gid if dec.world > 1 else None)
     if strict and dom.x.is_cuda and hasattr(kernels.neighbor, "cell_window_check"):
         kernels.neighbor.cell_window_check()
+        if static:
+            t.cuda.current_stream().synchronize()
+            dec.check_halo("this step's")
     return dom, verlet, dist, nn, pattern
 
 

@@ -22,7 +22,7 @@ class Column:
 
     def __init__(self, name: str, values):
         self.name = name
-        if type(values).__name__ == "HArray":  # already in HBM (the file readers): the host copy is made on first use
+        if type(values).__name__ in ("HArray", "LazyHArray"):  # already in HBM (the file readers): the host copy is made on first use
             if values.ndim != 1:
                 raise ValueError(f"column {name!r} must be one-dimensional")
             self._host_arr = None
@@ -197,7 +197,7 @@ class Frame:
         cols = dict(self._cols)
         n = self.shape[0] if self._cols else None
         for name, v in new.items():
-            if type(v).__name__ == "HArray":
+            if type(v).__name__ in ("HArray", "LazyHArray"):
                 cols[name] = Column(name, v)
                 continue
             a = v.to_numpy() if isinstance(v, Column) else np.asarray(v)

@@ -54,7 +54,7 @@ class Neighbor:
         width, atoms = self.max_neigh, frame.shape[0]
         self.verlet_list = empty((atoms, width), np.int32)
         self.distance_list = empty((atoms, width), np.float64)
-        self.neighbor_number = empty((atoms,), np.int32)
+        self.neighbor_number = zeros((atoms,), np.int32)  # (an atom with a NaN coordinate takes no cell and gets no row: its count reads 0)
         self._search_fixed(where)
         longest = int(self.neighbor_number.max(initial=0))
         if longest > width:

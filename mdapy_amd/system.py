@@ -261,8 +261,9 @@ class System:
         if isinstance(reach, (int, float, np.integer, np.floating)) and reach > 0 and \
                 not policy.is_single(policy.axis_copies(self.box, 2.0 * float(reach))):
             return None  # the build would search a replica: the ordering key cannot follow
-        if name == "cal_steinhardt_bond_orientation" and (bound.get("use_voronoi") or bound.get("identify_liquid")):
-            return None
+        if name == "cal_steinhardt_bond_orientation" and (bound.get("use_voronoi") or bound.get("identify_liquid")
+                                                         or bound.get("weight") is not None):
+            return None  # (a caller's weight array lines up with THIS system's rows, not with the twin's permuted ones)
         return twin
 
     def _run_on_twin(self, twin, name, args, kwargs):
@@ -341,7 +342,8 @@ class System:
             if isinstance(rows, HArray):
                 out = (LazyHArray(lambda: _dev_of(translated("v")), rows.shape, np.int32),
                        LazyHArray(lambda: _dev_of(translated("d")), dist.shape, np.float64),
-                       LazyHArray(lambda: _dev_of(translated("n")), counts.shape, np.int32))
+                       # (the counts alone: `_deep_enough` and the overflow check read them; the N x M rows need not move for that)
+                       LazyHArray(lambda: _dev_of(done["n"] if done else kernels.order.permute(counts, perm, scatter=True)), counts.shape, np.int32))
             else:
                 out = (translated("v"), translated("d"), translated("n"))
             mirror = self._mirror = {"state": state, "rows": out[0]}

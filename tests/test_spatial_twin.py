@@ -89,6 +89,22 @@ def test_every_twin_analysis_equals_the_plain_one(oracle_backend, monkeypatch):
     assert np.array_equal(as_numpy(a.verlet_list), as_numpy(b.verlet_list))
 
 
+def test_user_weight_rows_keep_the_steinhardt_call_off_the_twin(oracle_backend, monkeypatch):
+    """cal_steinhardt_bond_orientation(use_weight=True, weight=<array>): the weight rows line up with THIS system's list rows,
+    which the twin holds permuted — the call must run in the system's own order: twin == plain bit for bit"""
+    out = {}
+    for mode in ("0", "1"):
+        s = _system(monkeypatch, mode)
+        s.build_neighbor(3.3, max_neigh=20)
+        rows = as_numpy(s.verlet_list)
+        w = np.where(rows >= 0, 1.0 + (rows % 7) * 0.25, 0.0)  # a weight that depends on the NEIGHBOUR's number: any row mix-up shows
+        assert s._twin_for("cal_steinhardt_bond_orientation", ([4, 6],), dict(rc=3.3, use_weight=True, weight=w)) is None
+        s.cal_steinhardt_bond_orientation([4, 6], rc=3.3, use_weight=True, weight=w)
+        out[mode] = s
+    _same_columns(out["0"], out["1"], ["ql4", "ql6"])
+    assert out["1"]._spatial() is not None
+
+
 def test_twin_follows_data_and_box_changes(oracle_backend, monkeypatch):
     s = _system(monkeypatch, "1", with_types=True)
     s.cal_centro_symmetry_parameter(12)
