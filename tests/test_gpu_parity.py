@@ -627,8 +627,8 @@ def test_fused_labels_sheared_and_wide_instances_vs_oracle(case):
         assert plan[0] > 0 and plan[7] == 1, (name, plan)  # the tile kernel took the call
         if inst == "wide":
             assert (plan[4] & 2) == 0 and M > 16, (name, plan)  # ... as its wide (two-byte ticket) instance
-        else:
-            assert (plan[4] & 2) != 0, (name, plan)  # ... as its one-byte instance (rows of <= 16 slots), sheared
+        else:  # sheared: the one-byte instance for rows of <= 16 slots (TRI=1, TK8=1), the wide one beyond (TRI=1, TK8=0) — both labelled here
+            assert ((plan[4] & 2) != 0) == (width <= 16), (name, width, plan)
         assert np.array_equal(nf, c) and np.array_equal(vf[:, :M], v) and np.array_equal(df[:, :M], d), (name, width)
         assert np.array_equal(pf, want), (name, width, int((pf != want).sum()))
     pe = np.zeros(n, np.int32)
