@@ -22,12 +22,13 @@ using ptmc::Tables;
 
 
 // staged pipeline for the single-shell structure types (ptm_stages.hip)
-void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc);
+size_t ptm_match_tables_bytes();
+void ptm_compose_match_tables(const ptmc::Tables &T, void *out);
 size_t ptm_stage_bytes(int64_t N);
 int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
                      int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st);
 int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int8_t *orders,
-                      const int *dtypes, const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol,
+                      const int *dtypes, const ptmc::Tables *dt, const void *dmatch, int flags, double rmsd_threshold, double *dout, int ncol,
                       int *dind, int nind, unsigned char *work, hipStream_t st);
 
 static Tables *g_host_tables = nullptr;
@@ -62,8 +63,8 @@ static int device_tables(const Tables **out, const int8_t **out_autc)
         MDH_HIP(hipMalloc(&p, sizeof(Tables)));
         MDH_HIP(hipMemcpy(p, host, sizeof(Tables), hipMemcpyHostToDevice));
         dev[d] = static_cast<const Tables *>(p);
-        std::vector<int8_t> autc((size_t)ptmc::MAX_AUTS * ptmc::MAX_PTS);
-        ptm_compose_automorphisms(*host, autc.data());
+        std::vector<int8_t> autc(ptm_match_tables_bytes());
+        ptm_compose_match_tables(*host, autc.data());
         MDH_HIP(hipMalloc(&p, autc.size()));
         MDH_HIP(hipMemcpy(p, autc.data(), autc.size(), hipMemcpyHostToDevice));
         dev_autc[d] = static_cast<const int8_t *>(p);

@@ -19,6 +19,9 @@
 #include "common.hpp"
 #include "ptm_core.hpp"
 #include <type_traits>
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace mdh {
 namespace ptms {
@@ -60,9 +63,149 @@ struct OrderShared { // per workgroup
 };
 template <int CAP, int DIM> constexpr size_t order_lds_bytes() { return sizeof(OrderShared) + (size_t)ORD_THREADS * CAP * DIM * 8; }
 
+// face_solid_angle_2d (ptm_core.hpp) with the polygon's vertices CACHED IN REGISTERS.  The plain form keeps the polygon in the
+// lane's LDS stripe only, so the counting pass of every clip — is vertex t beyond the plane? — is a run-time loop of one LDS round
+// trip and ~30 instructions (address arithmetic, loop and exec-mask bookkeeping around four multiplications) per vertex, and 13
+// of the 17 planes cut nothing.  Here the CAP vertex slots are a register array read with compile-time indices: the counting
+// pass is straight-line code, five instructions per slot, no memory access (unused slots hold NaN, which is never "beyond").
+// A cut — the only part with data-dependent indices — reads its four edge vertices from the stripe, writes the kept vertices
+// to their new slots FROM THE REGISTERS (no dependent read-modify-write chain, any order), then reloads the cache in one batch.
+// The outside run's start comes from the bit mask of the counting pass instead of a backward walk.  Per face the same
+// operations on the same operands as clip_poly2 / face_solid_angle_2d: the areas are bit for bit those of the host twin.
+template <class P> __device__ bool face_solid_angle_2d_regs(int i, int n, const double (*pts)[3], const double *nsq, double k, P &poly, double *out, int *peak)
+{
+    constexpr int CAP = P::CAP;
+    static_assert(CAP <= 31, "one bit per vertex slot");
+    *out = 0;
+    const double *p = pts[i];
+    if (!(nsq[i] > 0))
+        return true;
+    bool later_twin = false; // (face_solid_angle)
+    for (int j = i + 1; j < n; ++j)
+        if (nsq[j] == nsq[i])
+            later_twin = later_twin || (pts[j][0] == p[0] && pts[j][1] == p[1] && pts[j][2] == p[2]);
+    if (later_twin)
+        return true;
+    double u[3], v[3];
+    const double ax = fabs(p[0]), ay = fabs(p[1]), az = fabs(p[2]);
+    double e3[3] = {0, 0, 0};
+    if (ax <= ay && ax <= az) e3[0] = 1; else if (ay <= az) e3[1] = 1; else e3[2] = 1;
+    ptmc::cross3(p, e3, u);
+    const double iu = 1.0 / sqrt(ptmc::dot3(u, u));
+    u[0] *= iu; u[1] *= iu; u[2] *= iu;
+    ptmc::cross3(p, u, v);
+    const double iv = 1.0 / sqrt(ptmc::dot3(v, v));
+    v[0] *= iv; v[1] *= iv; v[2] *= iv;
+    const double c0[3] = {0.5 * p[0], 0.5 * p[1], 0.5 * p[2]};
+    const double R = 40 * k + 1;
+    const double QNAN = __builtin_nan("");
+    double va[CAP], vb[CAP]; // the polygon: slots [0, m) as in the stripe, the rest NaN (va)
+#pragma unroll
+    for (int t = 0; t < CAP; ++t) { va[t] = QNAN; vb[t] = 0; }
+    va[0] = R; vb[0] = R; va[1] = -R; vb[1] = R; va[2] = -R; vb[2] = -R; va[3] = R; vb[3] = -R;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { poly.set(t, 0, va[t]); poly.set(t, 1, vb[t]); }
+    int m = 4;
+    for (int j = 0; j < n && m >= 3; ++j) // nearest planes first (rows are distance-sorted): the square shrinks at once
+        if (j != i && !(nsq[j] == nsq[i] && pts[j][0] == p[0] && pts[j][1] == p[1] && pts[j][2] == p[2])) { // a twin's plane is this plane
+            const double la = ptmc::dot3(u, pts[j]), lb = ptmc::dot3(v, pts[j]), off = 0.5 * nsq[j] - ptmc::dot3(c0, pts[j]);
+            unsigned outmask = 0;
+#pragma unroll
+            for (int t = 0; t < CAP; ++t) outmask |= ((va[t] * la + vb[t] * lb) - off > 0) ? (1u << t) : 0u;
+            const int nout = __builtin_popcount(outmask);
+            if (nout == m) {
+                m = 0;
+            } else if (nout > 0) { // clip_cut2 (ptm_core.hpp)
+                const unsigned inside = ~outmask & ((1u << m) - 1u);
+                int s = (outmask & 1u) ? 32 - __builtin_clz(inside) : __builtin_ctz(outmask); // first vertex of the outside run (its predecessor is inside)
+                if (s == m) s = 0;
+                const int e = s + nout >= m ? s + nout - m : s + nout; // first inside vertex after the run
+                const int sp = s == 0 ? m - 1 : s - 1, ep = e == 0 ? m - 1 : e - 1;
+                double A[2], B[2];
+                {
+                    const double psp[2] = {poly.get(sp, 0), poly.get(sp, 1)}, ps[2] = {poly.get(s, 0), poly.get(s, 1)};
+                    const double pep[2] = {poly.get(ep, 0), poly.get(ep, 1)}, pe[2] = {poly.get(e, 0), poly.get(e, 1)};
+                    {
+                        const double d0 = (psp[0] * la + psp[1] * lb) - off, d1 = (ps[0] * la + ps[1] * lb) - off;
+                        const double t = d0 / (d0 - d1);
+                        for (int c = 0; c < 2; ++c) A[c] = psp[c] + t * (ps[c] - psp[c]);
+                    }
+                    {
+                        const double d0 = (pep[0] * la + pep[1] * lb) - off, d1 = (pe[0] * la + pe[1] * lb) - off;
+                        const double t = d0 / (d0 - d1);
+                        for (int c = 0; c < 2; ++c) B[c] = pep[c] + t * (pe[c] - pep[c]);
+                    }
+                }
+                const int mm = m - nout + 2;
+                if (mm > CAP) {
+                    m = -1;
+                } else {
+                    // kept vertex t goes to slot t + delta: the run inside the array (s < e): [0, s) stay, [e, m) move by s + 2 - e;
+                    // the run wraps or ends at m: [e, s) move down by e
+                    const bool mid = s < e;
+                    const int lo = e, hi = mid ? m : s, delta = mid ? s + 2 - e : -e;
+                    if (delta != 0) {
+#pragma unroll
+                        for (int t = 0; t < CAP; ++t)
+                            if (t >= lo && t < hi) { poly.set(t + delta, 0, va[t]); poly.set(t + delta, 1, vb[t]); }
+                    }
+                    const int at = mid ? s : s - e;
+                    poly.set(at, 0, A[0]); poly.set(at, 1, A[1]);
+                    poly.set(at + 1, 0, B[0]); poly.set(at + 1, 1, B[1]);
+                    m = mm;
+#pragma unroll
+                    for (int t = 0; t < CAP; ++t) {
+                        const double ra = poly.get(t, 0), rb = poly.get(t, 1);
+                        va[t] = t < m ? ra : QNAN;
+                        vb[t] = rb;
+                    }
+                }
+            }
+            if (peak && m > *peak) *peak = m;
+        }
+    bool inside_cube = m >= 3;
+    if (inside_cube) {
+#pragma unroll
+        for (int c = 0; c < CAP; ++c) { // (a NaN slot fails no test: the comparisons are written so that NaN counts as inside)
+            const double a = va[c], b = vb[c];
+            const bool outside = fabs(c0[0] + a * u[0] + b * v[0]) > k || fabs(c0[1] + a * u[1] + b * v[1]) > k || fabs(c0[2] + a * u[2] + b * v[2]) > k;
+            inside_cube = inside_cube && !outside;
+        }
+    }
+    for (int d = 0; d < 3 && m >= 3 && !inside_cube; ++d) { // the bounding cube  |x_d| <= k
+        m = ptmc::clip_poly2(poly, m, u[d], v[d], k - c0[d]);
+        if (m < 3) break;
+        m = ptmc::clip_poly2(poly, m, -u[d], -v[d], k + c0[d]);
+    }
+    if (m < 0)
+        return false;
+    if (m < 3)
+        return true;
+    double first[3], prev[3], cur[3];
+    double nfirst = 0, nprev = 0;
+    double sa = 0;
+    for (int c = 0; c < m; ++c) { // (face_solid_angle_2d: the fan of spherical triangles)
+        const double a = poly.get(c, 0), b = poly.get(c, 1);
+        cur[0] = c0[0] + a * u[0] + b * v[0]; cur[1] = c0[1] + a * u[1] + b * v[1]; cur[2] = c0[2] + a * u[2] + b * v[2];
+        const double ncur = sqrt(ptmc::dot3(cur, cur));
+        if (c == 0) { first[0] = cur[0]; first[1] = cur[1]; first[2] = cur[2]; nfirst = ncur; }
+        if (c >= 2) {
+            double cr[3];
+            ptmc::cross3(prev, cur, cr);
+            const double num = ptmc::dot3(first, cr);
+            const double den = nfirst * nprev * ncur + ptmc::dot3(first, prev) * ncur + ptmc::dot3(cur, first) * nprev + ptmc::dot3(prev, cur) * nfirst;
+            sa += fabs(2 * atan2(num, den));
+        }
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2]; nprev = ncur;
+    }
+    *out = sa < 2e-12 ? 0.0 : sa;
+    return true;
+}
+
 // REDO = second pass over the atoms whose polygons outgrew the first pass's storage (flag set), with room for 28 vertices
-template <bool TRI, int CAP, bool REDO, int DIM>
-__global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_faces(const double *__restrict__ x, const double *__restrict__ y,
+// ROUNDS (DIM 2; the name is historic): the polygon cached in registers, face_solid_angle_2d_regs
+template <bool TRI, int CAP, bool REDO, int DIM, bool ROUNDS = false>
+__global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? (ROUNDS ? 3 : 4) : (ROUNDS && CAP == 10 ? 3 : 1))) void k_ptm_order_faces(const double *__restrict__ x, const double *__restrict__ y,
                                                                  const double *__restrict__ z, int64_t N, DBox b,
                                                                  const int *__restrict__ verlet, int64_t M, int8_t *__restrict__ orders,
                                                                  int *__restrict__ nbr, unsigned char *__restrict__ redo,
@@ -128,8 +271,14 @@ __global__ __launch_bounds__(ORD_THREADS, (CAP == 8 ? 4 : 1)) void k_ptm_order_f
         const double k = 10 * sqrt(maxn);
         double a = 0;
         int peak = 0;
-        if (!(DIM == 2 ? ptmc::face_solid_angle_2d(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a, (CAP > 8 && !REDO) ? &peak : nullptr)
-                       : ptmc::face_solid_angle(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a)))
+        bool fits;
+        if constexpr (DIM == 2 && ROUNDS && CAP <= 15) // (the second pass's 28-vertex polygons stay in the stripe: 112 registers of cache)
+            fits = face_solid_angle_2d_regs(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a, (CAP > 8 && !REDO) ? &peak : nullptr);
+        else if constexpr (DIM == 2)
+            fits = ptmc::face_solid_angle_2d(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a, (CAP > 8 && !REDO) ? &peak : nullptr);
+        else
+            fits = ptmc::face_solid_angle(f, cnt, S.pts[slot], S.nsq[slot], k, poly, &a);
+        if (!fits)
             S.overflow[slot] = 1;
         if (CAP > 8 && !REDO && peak > 8) S.big[slot] = 1;
         S.area[slot][f] = a;
@@ -223,8 +372,11 @@ template <int NP> __device__ __forceinline__ void raw_normal(const HullMem<NP> &
     cross(u, v, N);
 }
 
-// new facet through (a,b,c), oriented away from `inside`; 0xFFFFFFFF when it duplicates one of the first nf facets
-template <int NP> __device__ uint32_t make_facet(const HullMem<NP> &m, int a, int b, int c, const double *inside, int nf)
+// new facet through (a,b,c), oriented away from `inside`; 0xFFFFFFFF when it duplicates one of the facets [first, nf).  (The
+// reference compares with every facet of the hull; a facet through the point being inserted can only equal a facet made
+// earlier in the SAME insertion — no older facet contains that point — so the caller passes the first facet of the insertion:
+// ~3 instead of ~20 dependent LDS reads per new facet.)
+template <int NP> __device__ uint32_t make_facet(const HullMem<NP> &m, int a, int b, int c, const double *inside, int nf, int first = 0)
 {
     double N[3], pa[3];
     raw_normal(m, a, b, c, N, pa);
@@ -239,7 +391,7 @@ template <int NP> __device__ uint32_t make_facet(const HullMem<NP> &m, int a, in
     constexpr int IB = HullMem<NP>::IB;
     const uint32_t w = (uint32_t)c0 | ((uint32_t)c1 << IB) | ((uint32_t)c2 << (2 * IB));
     bool dup = false;
-    for (int j = 0; j < nf; ++j)
+    for (int j = first; j < nf; ++j)
         dup = dup || ((uint32_t)m.F[j * BLK] & ((1u << (3 * IB)) - 1u)) == w;
     return dup ? 0xFFFFFFFFu : (w | ((uint32_t)r << (3 * IB)) | ((uint32_t)flip << (3 * IB + 2)));
 }
@@ -253,9 +405,16 @@ template <int NP> __device__ __forceinline__ bool facet_sees(const HullMem<NP> &
     const bool flip = (w >> (3 * IB + 2)) & 1;
     const int o0 = r == 0 ? c0 : r == 1 ? c2 : c1, o1 = r == 0 ? c1 : r == 1 ? c0 : c2, o2 = r == 0 ? c2 : r == 1 ? c1 : c0;
     const int a = flip ? o1 : o0, b = flip ? o0 : o1;
-    double N[3], pa[3], pp[3];
-    raw_normal(m, a, b, o2, N, pa);
-    m.pt(c0, pp);
+    double N[3], pa[3], pb[3], pc[3], pp[3];
+    m.pt(a, pa); m.pt(b, pb); m.pt(o2, pc);
+    {
+        const double u[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        const double v[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+        cross(u, v, N);
+    }
+    // the facet's first vertex c0 is one of the three just read: picked from registers, not read again (a fourth LDS latency per test)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pp[k] = c0 == a ? pa[k] : c0 == b ? pb[k] : pc[k];
     const double d[3] = {pp[0] - q[0], pp[1] - q[1], pp[2] - q[2]};
     return above_plane(N, d, flip, ptmc::HULL_TOL);
 }
@@ -390,11 +549,12 @@ template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullSt
             if (v && nadd < MAXF) { m.A[nadd * BLK] = (AW)(b | (c << IB)); ++nadd; }
             if (x && nadd < MAXF) { m.A[nadd * BLK] = (AW)(c | (a << IB)); ++nadd; }
         }
+        const int first_new = h.num_facets;
         for (int j = 0; j < nadd; ++j) {
             if (h.num_facets >= MAXF)
                 return -4;
             const int e = m.A[j * BLK];
-            const uint32_t w = make_facet(m, i, e & IM, (e >> IB) & IM, h.bary, h.num_facets);
+            const uint32_t w = make_facet(m, i, e & IM, (e >> IB) & IM, h.bary, h.num_facets, first_new);
             if (w == 0xFFFFFFFFu)
                 return -5;
             m.F[h.num_facets * BLK] = (FW)w;
@@ -953,14 +1113,38 @@ template <int NPM> struct MatchMem {
     static constexpr size_t BYTES = (size_t)BLK * (NP * 24 + NI * sizeof(IdT) + NV);
 };
 
+// what the match stage reads besides ptmc::Tables, made once on the host (ptm_compose_match_tables)
+struct MatchTables {
+    static constexpr int ROW = 32;                 // an automorphism's row: MAX_PTS bytes used, 32-byte aligned for wide loads
+    int8_t autc[ptmc::MAX_AUTS][ROW];              // autc[aut][i] = canon_of_its_graph[aut^-1[i]] (see ptm_compose_match_tables)
+    uint64_t sorted_hash[ptmc::MAX_GRAPHS];        // per type, its range [graph_begin, graph_begin + num_graphs) sorted by (hash, graph)
+    int16_t sorted_graph[ptmc::MAX_GRAPHS];        // ... the graph of that entry
+};
+
 struct GraphMap { // template point i -> cluster point V[autc[i]]
     const int8_t *V;
-    const int8_t *__restrict__ autc;
+    const int8_t *__restrict__ autc; // one row of MatchTables::autc: 32-byte aligned
     __device__ __forceinline__ int operator()(int i) const { return V[autc[i] * BLK]; }
+    // all NPX points at once: the row as two loads (one memory latency instead of one per point), then the NPX look-ups in V
+    // together (entries past the template's last point read row byte 0: a valid slot, never used)
+    template <int NPX> __device__ __forceinline__ void gather(int np, int *kk) const
+    {
+        static_assert(NPX <= 20, "five words of the row");
+        const uint4 lo = *reinterpret_cast<const uint4 *>(autc);
+        const uint32_t hi = *reinterpret_cast<const uint32_t *>(autc + 16);
+        const uint32_t w[5] = {lo.x, lo.y, lo.z, lo.w, hi};
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) kk[i] = V[(int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu) * BLK];
+    }
 };
 struct GrapheneMap { // the 2^3 assignments of each inner atom's two outer atoms: bit 2 swaps points 4,5, bit 1 6,7, bit 0 8,9
     int bits;
     __device__ __forceinline__ int operator()(int i) const { return i < 4 ? i : (((bits >> (2 - ((i - 4) >> 1))) & 1) ? (i ^ 1) : i); }
+    template <int NPX> __device__ __forceinline__ void gather(int np, int *kk) const
+    {
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) kk[i] = i < 10 ? (*this)(i) : 0;
+    }
 };
 
 // rmsd of template `s` onto the points  P[map(i)] - bary  (ptm_core.hpp calc_rmsd)
@@ -968,14 +1152,33 @@ template <class Mem, class Map>
 __device__ double stage_rmsd(const Mem &m, const ptmc::TypeInfo &s, int np, const Map &map, const double *bary, double G1, double G2, double E0,
                              double *q, double *p_scale)
 {
+    // The correspondence first, all points at once, then the points six at a time (their 18 LDS reads in flight together), the
+    // sums in the order i = 0, 1, ... of the plain loop (same bits).  One point per trip of a run-time loop was three DEPENDENT
+    // latencies per point — the automorphism's byte from memory, the look-up in V, the point — 13 x 3 per automorphism, 24
+    // automorphisms per fcc graph.
+    constexpr int NPX = Mem::NP;
+    int kk[NPX];
+    map.template gather<NPX>(np, kk);
     double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < np; ++i) {
-        const int k = map(i);
-        const double x1 = s.points[i][0], y1 = s.points[i][1], z1 = s.points[i][2];
-        const double x2 = m.P[(k * 3 + 0) * BLK] - bary[0], y2 = m.P[(k * 3 + 1) * BLK] - bary[1], z2 = m.P[(k * 3 + 2) * BLK] - bary[2];
-        A[0] += x1 * x2; A[1] += x1 * y2; A[2] += x1 * z2;
-        A[3] += y1 * x2; A[4] += y1 * y2; A[5] += y1 * z2;
-        A[6] += z1 * x2; A[7] += z1 * y2; A[8] += z1 * z2;
+#pragma unroll
+    for (int c = 0; c < NPX; c += 6) {
+        double px[6], py[6], pz[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (c + u < NPX) {
+                const int k = kk[c + u];
+                px[u] = m.P[(k * 3 + 0) * BLK]; py[u] = m.P[(k * 3 + 1) * BLK]; pz[u] = m.P[(k * 3 + 2) * BLK];
+            }
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (c + u < NPX && c + u < np) {
+                const int i = c + u;
+                const double x1 = s.points[i][0], y1 = s.points[i][1], z1 = s.points[i][2];
+                const double x2 = px[u] - bary[0], y2 = py[u] - bary[1], z2 = pz[u] - bary[2];
+                A[0] += x1 * x2; A[1] += x1 * y2; A[2] += x1 * z2;
+                A[3] += y1 * x2; A[4] += y1 * y2; A[5] += y1 * z2;
+                A[6] += z1 * x2; A[7] += z1 * y2; A[8] += z1 * z2;
+            }
     }
     double nrmsdsq, rot[9];
     ptmc::qcp_quaternion(A, E0, &nrmsdsq, q);
@@ -1016,29 +1219,48 @@ __device__ __forceinline__ double template_norm(const ptmc::TypeInfo &s, int np)
     return G1;
 }
 
-// every automorphism of every table graph of `type` with the atom's hash; the lanes of a wavefront walk their t-th
-// candidate together (ptm_core.hpp check_graphs)
+// every automorphism of every table graph of `type` with the atom's hash, in the order of the graphs; the lanes of a wavefront
+// walk their t-th candidate together (ptm_core.hpp check_graphs).  The graphs with the atom's hash are found in the type's
+// (hash, graph)-sorted list by bisection: the bcc template has 218 graphs, and a walk over them — one dependent memory latency
+// each, for every atom whose 15-point hull is a valid triangulation, i.e. nearly every atom of any crystal — was a third of the
+// kernel.  Entries of equal hash are in ascending graph order: candidates come in the order of the plain walk.
 template <class Mem>
-__device__ void try_graphs(const Mem &m, const Tables &T, const int8_t *__restrict__ autc, int type, int kind, int np, bool live, uint64_t hash,
+__device__ void try_graphs(const Mem &m, const Tables &T, const MatchTables &MT, int type, int kind, int np, bool live, uint64_t hash,
                            const double *bary, double G2, Best &best)
 {
     const ptmc::TypeInfo &s = T.types[type];
     const double G1 = template_norm(s, np);
     const double E0 = (G1 + G2) / 2;
-    int g = s.graph_begin, j = 0;
-    const int g_end = s.graph_begin + s.num_graphs;
-    while (true) {
-        bool has = false;
-        if (live) {
-            while (g < g_end && (T.graphs[g].hash != hash || j >= T.graphs[g].num_aut)) { ++g; j = 0; }
-            has = g < g_end;
+    const int e_end = s.graph_begin + s.num_graphs;
+    int e = e_end, j = 0, g = -1, naut = 0, abeg = 0; // entry of the sorted list, automorphism, its graph (-1: none left)
+    auto enter = [&]() {
+        g = -1;
+        if (e < e_end && MT.sorted_hash[e] == hash) {
+            g = MT.sorted_graph[e];
+            naut = T.graphs[g].num_aut;
+            abeg = T.graphs[g].aut_begin;
+            j = 0;
         }
+    };
+    if (live) {
+        int lo = s.graph_begin, hi = e_end;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (MT.sorted_hash[mid] < hash) lo = mid + 1; else hi = mid;
+        }
+        e = lo;
+        enter();
+    }
+    while (true) {
+        if (live)
+            while (g >= 0 && j >= naut) { ++e; enter(); }
+        const bool has = live && g >= 0;
         if (__ballot(has) == 0)
             break;
         if (has) {
-            const int aut = T.graphs[g].aut_begin + j;
+            const int aut = abeg + j;
             double q[4], scale = 0;
-            const GraphMap map{m.V, autc + (size_t)aut * ptmc::MAX_PTS};
+            const GraphMap map{m.V, MT.autc[aut]};
             const double rmsd = stage_rmsd(m, s, np, map, bary, G1, G2, E0, q, &scale);
             if (rmsd < best.rmsd) {
                 best.rmsd = rmsd; best.scale = scale; best.type = type; best.aut = aut; best.kind = kind;
@@ -1117,7 +1339,7 @@ template <class Mem> __device__ __forceinline__ void load_cluster(const Mem &m, 
 template <bool TRI, bool SHELL>
 __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                    int64_t N, DBox b, const int *__restrict__ nbr, const int *__restrict__ types,
-                                                   const Tables *__restrict__ tables, const int8_t *__restrict__ autc, int flags,
+                                                   const Tables *__restrict__ tables, const MatchTables *__restrict__ mtables, int flags,
                                                    MatchIn in, double rmsd_threshold, double *__restrict__ output, int ncol,
                                                    int *__restrict__ ptm_indices, int nind)
 {
@@ -1134,6 +1356,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
     // a stored identity -> atom id (MatchMem)
     auto id_of = [&](int v) { return !Mem::SLOTS ? v : v < 0 ? -1 : v == 0 ? (int)atom : nbr[(int64_t)(v - 1) * N + atom]; };
     const Tables &T = *tables;
+    const MatchTables &MT = *mtables;
     load_neighbourhood<TRI>(m, x, y, z, b, nbr, N, atom);
     Best best;
     best.type = ptmc::T_NONE; best.aut = -1; best.kind = -1;
@@ -1169,7 +1392,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
             const int bit = type == ptmc::T_SC ? ptmc::CHECK_SC : type == ptmc::T_BCC ? ptmc::CHECK_BCC : type == ptmc::T_FCC ? ptmc::CHECK_FCC
                           : type == ptmc::T_HCP ? ptmc::CHECK_HCP : ptmc::CHECK_ICO;
             if (flags & bit)
-                try_graphs(m, T, autc, type, kind, np, live, hash, bary, G2, best);
+                try_graphs(m, T, MT, type, kind, np, live, hash, bary, G2, best);
         }
     }
     if constexpr (SHELL) {
@@ -1184,8 +1407,8 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
                     for (int i = 0; i < 17; ++i) m.V[in.label[K_DC][(int64_t)i * N + atom] * BLK] = (int8_t)i;
                     barycentre(m, 17, bary, &G2);
                 }
-                if (flags & ptmc::CHECK_DCUB) try_graphs(m, T, autc, ptmc::T_DCUB, K_DC, 17, live, hash, bary, G2, best);
-                if (flags & ptmc::CHECK_DHEX) try_graphs(m, T, autc, ptmc::T_DHEX, K_DC, 17, live, hash, bary, G2, best);
+                if (flags & ptmc::CHECK_DCUB) try_graphs(m, T, MT, ptmc::T_DCUB, K_DC, 17, live, hash, bary, G2, best);
+                if (flags & ptmc::CHECK_DHEX) try_graphs(m, T, MT, ptmc::T_DHEX, K_DC, 17, live, hash, bary, G2, best);
             }
         }
         if (flags & ptmc::CHECK_GRAPHENE) { // 10 points, no graph: the eight assignments directly (ptm_core.hpp match_graphene)
@@ -1226,7 +1449,7 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
 #pragma unroll
             for (int i = 0; i < ptmc::MAX_PTS; ++i) pick[i] = (int8_t)(i < 10 ? map(i) : 0);
         } else {
-            const int8_t *ac = autc + (size_t)best.aut * ptmc::MAX_PTS;
+            const int8_t *ac = MT.autc[best.aut];
             {
                 const auto *lp = in.label[best.kind];
                 int lab[NP];
@@ -1337,10 +1560,13 @@ __global__ __launch_bounds__(BLK) void k_ptm_match(const double *__restrict__ x,
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 // autc[aut][i] = canon_of_its_graph[aut^-1[i]]: with it, template point i maps to V[autc[i]] (V = inverse of the atom's
-// canonical labelling) — ptm_core.hpp check_graphs builds the same mapping by scattering through `aut`.
-void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
+// canonical labelling) — ptm_core.hpp check_graphs builds the same mapping by scattering through `aut`.  And every type's graphs
+// sorted by (hash, graph) for the bisection of try_graphs.
+size_t ptm_match_tables_bytes() { return sizeof(ptms::MatchTables); }
+void ptm_compose_match_tables(const ptmc::Tables &T, void *out)
 {
-    for (int a = 0; a < ptmc::MAX_AUTS * ptmc::MAX_PTS; ++a) autc[a] = 0;
+    ptms::MatchTables &M = *static_cast<ptms::MatchTables *>(out);
+    std::memset(&M, 0, sizeof(M));
     for (int g = 0; g < T.num_graphs; ++g) {
         const ptmc::Graph &gr = T.graphs[g];
         int np = 0;
@@ -1348,15 +1574,24 @@ void ptm_compose_automorphisms(const ptmc::Tables &T, int8_t *autc)
             if (g >= T.types[t].graph_begin && g < T.types[t].graph_begin + T.types[t].num_graphs) np = T.types[t].num_nbrs + 1;
         for (int j = 0; j < gr.num_aut; ++j) {
             const int8_t *aut = T.auts[gr.aut_begin + j];
-            int8_t *dst = autc + (size_t)(gr.aut_begin + j) * ptmc::MAX_PTS;
+            int8_t *dst = M.autc[gr.aut_begin + j];
             for (int k = 0; k < np; ++k) dst[aut[k]] = gr.canon[k];
         }
+    }
+    for (int g = 0; g < ptmc::MAX_GRAPHS; ++g) { M.sorted_hash[g] = ~0ull; M.sorted_graph[g] = (int16_t)g; }
+    for (int t = 1; t < 9; ++t) {
+        const int g0 = T.types[t].graph_begin, n = T.types[t].num_graphs;
+        std::vector<int> idx(n);
+        for (int k = 0; k < n; ++k) idx[k] = g0 + k;
+        std::sort(idx.begin(), idx.end(), [&](int a, int b) { return T.graphs[a].hash != T.graphs[b].hash ? T.graphs[a].hash < T.graphs[b].hash : a < b; });
+        for (int k = 0; k < n; ++k) { M.sorted_hash[g0 + k] = T.graphs[idx[k]].hash; M.sorted_graph[g0 + k] = (int16_t)idx[k]; }
     }
 }
 
 static int g_order_cap = 10; // polygon vertices in the first pass (10: faces of up to ten corners — all of a crystal's — stay in it); larger faces take the second pass
 static int g_order_dim = 2;  // 2: polygons in the coordinates of their own plane; 3: in space (the form of rounds 1-2, kept for A/B)
 static bool g_order_auto = true;
+static bool g_order_rounds = true; // the polygon cached in registers (face_solid_angle_2d_regs); false: in the LDS stripe only (A/B, the areas are the same bits)
 // Automatic choice of the first pass: eight-vertex polygons run at four waves per SIMD (128 VGPRs, 22 KB of LDS) and are 5 %
 // faster on crystals, whose faces stay small; a gas or a glass sends half its atoms to the second pass with them (2.2x
 // slower).  Every call counts the atoms that had a face of more than eight vertices; the count of the previous call with the
@@ -1367,13 +1602,15 @@ static int64_t g_order_stat_n = -1; // ... which had this many atoms
 // test / measurement hook (mdh_debug_set_ptm_order_cap): 0 -> automatic; |cap| -> 5, 8, 10 or 15 vertices; a NEGATIVE value selects the 3-D polygons
 void ptm_debug_order_cap(int cap)
 {
+    g_order_rounds = !(cap >= 100); // 100 + cap: the plain clip loop (100 alone: plain loop, automatic cap)
+    if (cap >= 100) cap -= 100;
     g_order_auto = cap == 0;
     g_order_dim = cap < 0 ? 3 : 2;
     const int c = cap < 0 ? -cap : cap;
     g_order_cap = cap == 0 ? 10 : c <= 5 ? 5 : c <= 8 ? 8 : c <= 10 ? 10 : 15;
 }
 
-template <bool TRI, int CAP, int DIM>
+template <bool TRI, int CAP, int DIM, bool ROUNDS>
 static int launch_ptm_order_as(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *dv, int64_t M, int8_t *dord,
                                int *dnbr, unsigned char *redo, int *redo_count, hipStream_t st)
 {
@@ -1381,11 +1618,11 @@ static int launch_ptm_order_as(const double *dx, const double *dy, const double 
     const dim3 grid((unsigned)((N + ORD_APB - 1) / ORD_APB)), block(ORD_THREADS);
     const dim3 small(grid.x < 1024u ? grid.x : 1024u);
     // the second pass may ask for more than the 64 KB of dynamic LDS a launch gets by default
-    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<TRI, 28, true, DIM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    MDH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ptm_order_faces<TRI, 28, true, DIM, ROUNDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(order_lds_bytes<28, DIM>())));
     const size_t lds1 = order_lds_bytes<CAP, DIM>(), lds2 = order_lds_bytes<28, DIM>();
-    hipLaunchKernelGGL((k_ptm_order_faces<TRI, CAP, false, DIM>), grid, block, lds1, st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
-    hipLaunchKernelGGL((k_ptm_order_faces<TRI, 28, true, DIM>), small, block, lds2, st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    hipLaunchKernelGGL((k_ptm_order_faces<TRI, CAP, false, DIM, ROUNDS>), grid, block, lds1, st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
+    hipLaunchKernelGGL((k_ptm_order_faces<TRI, 28, true, DIM, ROUNDS>), small, block, lds2, st, dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
@@ -1406,7 +1643,11 @@ int launch_ptm_order(const double *dx, const double *dy, const double *dz, int64
         int *count; int cap; int64_t n; hipStream_t st;
         ~Note() { (void)hipMemcpyAsync(g_order_stat, cap > 8 ? count + 1 : count, sizeof(int), hipMemcpyDeviceToHost, st); g_order_stat_n = n; }
     } note{redo_count, ran_cap, N, st};
-#define MDH_ORD(TRI, CAP, DIM) return launch_ptm_order_as<TRI, CAP, DIM>(dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count, st)
+#define MDH_ORD(TRI, CAP, DIM)                                                                                                                  \
+    do {                                                                                                                                       \
+        if (DIM == 2 && g_order_rounds) return launch_ptm_order_as<TRI, CAP, DIM, (DIM == 2)>(dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count, st); \
+        return launch_ptm_order_as<TRI, CAP, DIM, false>(dx, dy, dz, N, b, dv, M, dord, dnbr, redo, redo_count, st);                          \
+    } while (0)
 #define MDH_ORD_CAP(TRI, DIM)                                                                                                                  \
     do {                                                                                                                                       \
         if (g_order_cap == 5) MDH_ORD(TRI, 5, DIM); /* test hook: a first pass so small that most atoms take the second one */                 \
@@ -1433,10 +1674,11 @@ size_t ptm_stage_bytes(int64_t N)
 }
 
 int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, const int *nbr, const int8_t *orders,
-                      const int *dtypes, const ptmc::Tables *dt, const int8_t *dautc, int flags, double rmsd_threshold, double *dout, int ncol,
+                      const int *dtypes, const ptmc::Tables *dt, const void *dmatch, int flags, double rmsd_threshold, double *dout, int ncol,
                       int *dind, int nind, unsigned char *work, hipStream_t st)
 {
     using namespace ptms;
+    const MatchTables *dmt = static_cast<const MatchTables *>(dmatch);
     const size_t n = (size_t)((N + 255) & ~int64_t(255));
     HullOut ho;
     uint16_t *facets[NCANON];
@@ -1510,7 +1752,7 @@ int launch_ptm_stages(const double *dx, const double *dy, const double *dz, int6
     {
         ProfRange pr("k_ptm_match", st);
 #define MDH_PTM_MATCH(TRI, SHELL)                                                                                                        \
-    hipLaunchKernelGGL((k_ptm_match<TRI, SHELL>), grid, block, MatchMem<SHELL ? 17 : 15>::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dautc, \
+    hipLaunchKernelGGL((k_ptm_match<TRI, SHELL>), grid, block, MatchMem<SHELL ? 17 : 15>::BYTES, st, dx, dy, dz, N, b, nbr, dtypes, dt, dmt, \
                        flags, mi, rmsd_threshold, dout, ncol, dind, nind)
         if (b.tri && shell) MDH_PTM_MATCH(true, true);
         else if (b.tri) MDH_PTM_MATCH(true, false);
