@@ -21,6 +21,7 @@
 #include <type_traits>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 namespace mdh {
