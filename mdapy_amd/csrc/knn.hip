@@ -21,8 +21,13 @@
 #include "common.hpp"
 #include "grid.hpp"
 #include <cstring>
+#include <type_traits>
+#include <cstdlib>
 
 namespace mdh {
+
+int neighbor_rows_device(Scope &sc, const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, double rc, int *dv,
+                         double *dd, int *dn, int64_t M, const int64_t *dkey, bool ids_only); // neighbor.hip
 
 int g_knn_variant = 0; // 0 = near kernel + general kernel, 1 = general kernel only (tests, A/B), 3 = counting kernel first (measuring variant)
 
@@ -63,6 +68,143 @@ __global__ __launch_bounds__(256) void k_knn_wrap(const double *__restrict__ x, 
 
 __device__ __forceinline__ int floordiv(int a, int n) { int q = a / n; return (a % n < 0) ? q - 1 : q; }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The k nearest from the rows of a CUTOFF build (round 6).  For a system of even density — a crystal, a glass, a liquid: what the
+// k-nearest analyses are run on — the k nearest of every atom lie inside a radius r a little beyond the one that holds k + 1 atoms at
+// the system's density, and the LDS-tile neighbour kernel (neighbor_lane.hip: single-precision scan of staged cells, ~1 ns per atom)
+// lists everything inside r three to four times faster than a thread can walk its 27 cells.  k_knn_rows then sees ~k + 6 candidates
+// per query instead of ~110: it recomputes every candidate's squared distance with the k-nearest search's OWN expression (the
+// reference wraps both atoms and shifts the query by whole box vectors, fast_knn.cpp:598-603, 759-770; the cutoff build folds the raw
+// separation, neighbor.cpp:139-177 — the two round differently across a periodic boundary) and keeps the k smallest by (squared
+// distance, index or key).  A query is finished here only if its row is complete (fewer entries than slots), holds k entries and its
+// k-th distance lies safely inside r — then nothing outside the row can be nearer; the others are flagged and go through the cell walk
+// (k_knn_near with `only`, then k_knn).  Rows are those of the plain search, bit for bit; r only decides who takes which path.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool TRI>
+__global__ __launch_bounds__(256) void k_knn_wrap4(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                   int64_t N, DBox b, Pos4 *__restrict__ w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    double px = x[i], py = y[i], pz = z[i]; // (k_knn_wrap)
+    if (TRI) {
+        const double r0 = px * b.hi[0] + py * b.hi[3] + pz * b.hi[6];
+        const double r1 = px * b.hi[1] + py * b.hi[4] + pz * b.hi[7];
+        const double r2 = px * b.hi[2] + py * b.hi[5] + pz * b.hi[8];
+        const double r[3] = {r0, r1, r2};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (b.pbc[d]) {
+                const double s = floor(r[d]);
+                if (s != 0.0) { px -= s * b.h[d * 3 + 0]; py -= s * b.h[d * 3 + 1]; pz -= s * b.h[d * 3 + 2]; }
+            }
+    } else {
+        if (b.pbc[0]) { const double s = floor((px - b.o[0]) * (1.0 / b.h[0])); if (s != 0.0) px -= s * b.h[0]; }
+        if (b.pbc[1]) { const double s = floor((py - b.o[1]) * (1.0 / b.h[4])); if (s != 0.0) py -= s * b.h[4]; }
+        if (b.pbc[2]) { const double s = floor((pz - b.o[2]) * (1.0 / b.h[8])); if (s != 0.0) pz -= s * b.h[8]; }
+    }
+    w[i] = Pos4{px, py, pz, 0.0};
+}
+
+// rows (N, M) of a cutoff build with radius r (counts nn keep running past M), K >= k list slots.  flag[i] = 1 and *nflag += 1 for a
+// query that must take the cell walk.  key: NULL, or the tie-breaking number of every atom (mdh_knn_keyed)
+template <bool TRI, int K, int MROW, bool KEYED>
+__global__ __launch_bounds__(256) void k_knn_rows(const Pos4 *__restrict__ w, int64_t N, DBox b, const int *__restrict__ rows, int M,
+                                                  const int *__restrict__ nn, double safe2, int k, const int64_t *__restrict__ key,
+                                                  int *__restrict__ indices, double *__restrict__ distances,
+                                                  unsigned char *__restrict__ flag, int *__restrict__ nflag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N)
+        return;
+    const int cnt = nn[i];
+    bool ok = cnt >= k && cnt <= M;
+    double ld[K]; // the K best so far, sorted by (squared distance, tie number); free slots hold +inf
+    int li[K];
+    typedef typename std::conditional<KEYED, int64_t, int>::type Tie; // (without a key the index itself breaks ties: no third array)
+    Tie lt[KEYED ? K : 1];
+#pragma unroll
+    for (int e = 0; e < K; ++e) { ld[e] = __builtin_huge_val(); li[e] = 0x7fffffff; if (KEYED) lt[e] = (Tie)0x7fffffffffffffffll; }
+    auto tie_at = [&](int e) -> Tie { if constexpr (KEYED) return lt[e]; else return (Tie)li[e]; };
+    if (ok) {
+        const Pos4 q = w[i];
+        // the whole row at once (MROW = M ids in 16-byte requests, back to back): a lane's row is one 128-byte line and a wavefront's
+        // rows are 64 of them — read four ids at a time as the loop goes, every step fetched all 64 lines again (they do not survive in
+        // the CU's 16 KB cache between steps with a dozen wavefronts resident: the kernel ran FASTER with fewer of them)
+        int rowv[MROW];
+        load_row<MROW>(rows + i * (int64_t)M, rowv);
+#pragma unroll
+        for (int e0 = 0; e0 < MROW; e0 += 4) {
+            if (e0 >= cnt)
+                break;
+            int cj[4];
+            Pos4 c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cj[u] = e0 + u < cnt ? rowv[e0 + u] : rowv[e0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = w[cj[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e0 + u >= cnt)
+                    continue;
+                // the image of the candidate nearest to the query: whole box vectors m between the wrapped positions (the box is at
+                // least seven cutoffs wide along every periodic vector — the tile kernel's condition, checked by the caller — so the
+                // fractional separation is far from +-1/2 and the rounding is not in doubt), then fast_knn.cpp's expression
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                const double ex = c[u].x - q.x, ey = c[u].y - q.y, ez = c[u].z - q.z;
+                if (TRI) {
+                    const double f0 = ex * b.hi[0] + ey * b.hi[3] + ez * b.hi[6];
+                    const double f1 = ex * b.hi[1] + ey * b.hi[4] + ez * b.hi[7];
+                    const double f2 = ex * b.hi[2] + ey * b.hi[5] + ez * b.hi[8];
+                    const int m0 = b.pbc[0] ? -(int)rint(f0) : 0, m1 = b.pbc[1] ? -(int)rint(f1) : 0, m2 = b.pbc[2] ? -(int)rint(f2) : 0;
+                    s0 = m0 * b.h[0] + m1 * b.h[3] + m2 * b.h[6];
+                    s1 = m0 * b.h[1] + m1 * b.h[4] + m2 * b.h[7];
+                    s2 = m0 * b.h[2] + m1 * b.h[5] + m2 * b.h[8];
+                } else {
+                    const int m0 = b.pbc[0] ? -(int)rint(ex * (1.0 / b.h[0])) : 0, m1 = b.pbc[1] ? -(int)rint(ey * (1.0 / b.h[4])) : 0,
+                              m2 = b.pbc[2] ? -(int)rint(ez * (1.0 / b.h[8])) : 0;
+                    s0 = m0 * b.h[0]; s1 = m1 * b.h[4]; s2 = m2 * b.h[8];
+                }
+                const double w0 = q.x - s0, w1 = q.y - s1, w2 = q.z - s2;
+                const double dx = c[u].x - w0, dy = c[u].y - w1, dz = c[u].z - w2;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                const int j = cj[u];
+                Tie tj;
+                if constexpr (KEYED) tj = key[j]; else tj = j;
+                if (!(d2 < ld[K - 1] || (d2 == ld[K - 1] && tj < tie_at(K - 1))))
+                    continue;
+                int pos = 0; // entries that stay in front of the new one
+#pragma unroll
+                for (int e = 0; e < K; ++e)
+                    pos += (ld[e] < d2 || (ld[e] == d2 && tie_at(e) < tj)) ? 1 : 0;
+#pragma unroll
+                for (int e = K - 1; e >= 1; --e) {
+                    if (e > pos) { ld[e] = ld[e - 1]; li[e] = li[e - 1]; if (KEYED) lt[e] = lt[e - 1]; }
+                    else if (e == pos) { ld[e] = d2; li[e] = j; if (KEYED) lt[e] = tj; }
+                }
+                if (pos == 0) { ld[0] = d2; li[0] = j; if (KEYED) lt[0] = tj; }
+            }
+        }
+        double kth = __builtin_huge_val();
+#pragma unroll
+        for (int e = 0; e < K; ++e)
+            if (e == k - 1) kth = ld[e];
+        ok = kth <= safe2; // (the k-th inside r with room to spare: an atom the cutoff build left out is farther than r (1 - 1e-12))
+    }
+    flag[i] = ok ? 0 : 1;
+    if (!ok) {
+        atomicAdd(nflag, 1);
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < K; ++e)
+        if (e < k) {
+            indices[i * (int64_t)k + e] = li[e];
+            distances[i * (int64_t)k + e] = sqrt(ld[e]); // :883
+        }
+}
+
 // The common case — the k nearest all lie within one cell width, in the 27 cells around the query — with the sorted list in
 // REGISTERS (K slots, K >= k a template constant): an insertion is a fully unrolled count of the entries that stay in front
 // (the position) and one predicated move per slot, ~14 instructions per slot and no memory access, where the list in LDS
@@ -77,8 +219,9 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
                                                   KnnGeom kg, int k, int *__restrict__ indices,
                                                   double *__restrict__ distances, int *__restrict__ todo,
                                                   const int *__restrict__ label, const int *__restrict__ unlabel,
-                                                  const int *__restrict__ listed = nullptr)
+                                                  const int *__restrict__ listed = nullptr, const unsigned char *__restrict__ only = nullptr)
 {
+    // only (N bytes by atom index, or NULL): the queries whose byte is set — the ones k_knn_rows could not finish
     // label / unlabel (both NULL, or both given): candidates are told apart — the self test, the order under exact ties — by
     // label[q] instead of their index order[q], and a listed label L is written as unlabel[L] (mdh_knn_keyed: the labels are the
     // caller's key, a permutation of 0 .. N-1, so that ties fall as they would in the system the key numbers)
@@ -91,6 +234,8 @@ __global__ __launch_bounds__(256, (K <= 18 ? 4 : 3)) void k_knn_near(const doubl
         return;
     }
     const int i = order[p];
+    if (only && !only[i])
+        return;
     const int self = label ? label[p] : i;
     const int *__restrict__ cand = label ? label : order;
     const double qx = xs[p], qy = ys[p], qz = zs[p]; // wrapped query == stored wrapped self (bitwise)
@@ -565,6 +710,73 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
     const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
     int *di = sc.stage(indices, (size_t)(N * k), space, false, true);
     double *dd = sc.stage(distances, (size_t)(N * k), space, false, true);
+    const double vol = std::fabs(b.tri ? (b.h[0] * (b.h[4] * b.h[8] - b.h[5] * b.h[7]) - b.h[1] * (b.h[3] * b.h[8] - b.h[5] * b.h[6]) + b.h[2] * (b.h[3] * b.h[7] - b.h[4] * b.h[6])) : b.h[0] * b.h[4] * b.h[8]);
+    const int64_t *dkey = key ? sc.stage_in(key, (size_t)N, space) : nullptr;
+    // ---- the k nearest from the rows of a cutoff build (k_knn_rows): large systems in boxes of at least 7.5 radii per periodic vector
+    // (the tile kernel's domain, and the nearest image of a listed neighbour is then beyond doubt); MDH_KNN_ROWS=0 or variant != 0: off
+    unsigned char *only = nullptr;
+    {
+        static const bool rows_env = [] { const char *e = std::getenv("MDH_KNN_ROWS"); return !e || std::atoi(e) != 0; }();
+        const double r = 1.15 * std::cbrt(3.0 * (double)(k + 1) / (4.0 * 3.14159265358979323846 * ((double)N / vol)));
+        bool fits = rows_env && g_knn_variant == 0 && k <= 18 && N >= 100000 && r > 0 && std::isfinite(r);
+        for (int d = 0; d < 3 && fits; ++d)
+            if (b.pbc[d] && !(std::fabs(b.thick[d]) >= 7.5 * r)) fits = false;
+        // a system of uneven density (a gas: Poisson counts; a cluster in vacuum) sends many queries on to the cell walk, and the rows
+        // were built for nothing: the share of the last search with this (N, k) decides — more than 0.5 %, and the next 15 searches
+        // of the signature walk the cells at once (then one more try)
+        struct Sig { int64_t N; int k; int left_pct, skip; };
+        static Sig sigs[16] = {};
+        Sig *sig = nullptr;
+        for (auto &e : sigs)
+            if (e.N == N && e.k == k) sig = &e;
+        if (!sig) {
+            static int next = 0;
+            sig = &sigs[next++ % 16];
+            *sig = Sig{N, k, 0, 0};
+        }
+        if (fits && sig->skip > 0) { --sig->skip; fits = false; }
+        if (fits) {
+            const int M = k <= 12 ? 24 : k <= 14 ? 28 : 32;
+            int *rows = sc.alloc_n<int>((size_t)N * M), *rnn = sc.alloc_n<int>((size_t)N), *nflag = sc.alloc_n<int>(4);
+            double *rdist = sc.alloc_n<double>((size_t)N * M);
+            Pos4 *w4 = sc.alloc_n<Pos4>((size_t)N);
+            only = sc.alloc_n<unsigned char>((size_t)N);
+            static int *pinned = nullptr; // the number of queries left for the cell walk: the one word this path reads back
+            if (!pinned && hipHostMalloc(reinterpret_cast<void **>(&pinned), sizeof(int), hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+            if (sc.failed() || !pinned)
+                return sc.failed() ? sc.error() : MDH_ERR_HIP;
+            MDH_HIP(hipMemsetAsync(nflag, 0, sizeof(int), st));
+            {
+                ProfRange pr("knn_rows_build", st);
+                MDH_TRY(neighbor_rows_device(sc, dx, dy, dz, N, b, r, rows, rdist, rnn, M, nullptr, true));
+            }
+            ProfRange pr("knn_rows_select", st);
+            const dim3 grid(grid_for(N, 256)), block(256);
+            const double safe2 = r * r * (1.0 - 1e-9);
+#define MDH_KNN_ROWS_AS(TRI, K, KEYED) hipLaunchKernelGGL((k_knn_rows<TRI, K, (K <= 12 ? 24 : K <= 14 ? 28 : 32), KEYED>), grid, block, 0, st, w4, N, b, rows, M, rnn, safe2, k, dkey, di, dd, only, nflag)
+#define MDH_KNN_ROWS(K)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (b.tri) {                                                                                                                      \
+            hipLaunchKernelGGL(k_knn_wrap4<true>, grid, block, 0, st, dx, dy, dz, N, b, w4);                                              \
+            if (dkey) MDH_KNN_ROWS_AS(true, K, true); else MDH_KNN_ROWS_AS(true, K, false);                                              \
+        } else {                                                                                                                          \
+            hipLaunchKernelGGL(k_knn_wrap4<false>, grid, block, 0, st, dx, dy, dz, N, b, w4);                                             \
+            if (dkey) MDH_KNN_ROWS_AS(false, K, true); else MDH_KNN_ROWS_AS(false, K, false);                                            \
+        }                                                                                                                                 \
+    } while (0)
+            if (k <= 12) MDH_KNN_ROWS(12);
+            else if (k <= 14) MDH_KNN_ROWS(14);
+            else MDH_KNN_ROWS(18);
+#undef MDH_KNN_ROWS
+#undef MDH_KNN_ROWS_AS
+            MDH_HIP(hipMemcpyAsync(pinned, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            MDH_HIP(hipStreamSynchronize(st));
+            sig->left_pct = (int)(100.0 * (double)*pinned / (double)N);
+            if ((double)*pinned > 0.005 * (double)N) sig->skip = 15; // (a wavefront of the cell walk runs whole if ONE of its queries is left: 2 % left cost as much as all)
+            if (*pinned == 0)
+                return sc.finish(space);
+        }
+    }
     double *wx = sc.alloc_n<double>((size_t)N), *wy = sc.alloc_n<double>((size_t)N), *wz = sc.alloc_n<double>((size_t)N);
     if (sc.failed())
         return sc.error();
@@ -588,7 +800,6 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
     DBox bg = b;
     if (b.tri) bg.o[0] = bg.o[1] = bg.o[2] = 0.0; // the triclinic wrap above is anchored at 0, not at the origin
     CellGrid cg;
-    const double vol = std::fabs(b.tri ? (b.h[0] * (b.h[4] * b.h[8] - b.h[5] * b.h[7]) - b.h[1] * (b.h[3] * b.h[8] - b.h[5] * b.h[6]) + b.h[2] * (b.h[3] * b.h[7] - b.h[4] * b.h[6])) : b.h[0] * b.h[4] * b.h[8]);
     const double per_cell = (double)k / 3.0 + 1.0;
     double wtarget = std::cbrt(vol * per_cell / (double)N);
     if (!(wtarget > 0) || !std::isfinite(wtarget)) wtarget = 1.0;
@@ -623,7 +834,6 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
     MDH_TRY(build_cell_grid(sc, wx, wy, wz, N, bg, false, false, cg));
     int *label = nullptr, *unlabel = nullptr;
     if (key) {
-        const int64_t *dkey = sc.stage_in(key, (size_t)N, space);
         label = sc.alloc_n<int>((size_t)N);
         unlabel = sc.alloc_n<int>((size_t)N);
         if (sc.failed())
@@ -674,8 +884,8 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
         const dim3 grid_near(grid.x); // (behind the counting kernel it walks a list, usually short: the other workgroups leave at once)
 #define MDH_KNN_NEAR(K)                                                                                                                   \
     do {                                                                                                                                  \
-        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid_near, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel, failed); \
-        else hipLaunchKernelGGL((k_knn_near<false, K>), grid_near, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel, failed); \
+        if (b.tri) hipLaunchKernelGGL((k_knn_near<true, K>), grid_near, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel, failed, only); \
+        else hipLaunchKernelGGL((k_knn_near<false, K>), grid_near, block, 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, N, b, bg, cg.g, kg, k, di, dd, todo, label, unlabel, failed, only); \
     } while (0)
         if (k <= 12) MDH_KNN_NEAR(12);
         else if (k <= 14) MDH_KNN_NEAR(14);

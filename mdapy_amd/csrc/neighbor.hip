@@ -1484,6 +1484,25 @@ static int neighbor_pass(Scope &sc, const CellGrid &cg, const DBox &b, int64_t N
     return MDH_OK;
 }
 
+// For other units of the library (knn.hip): the rows of a cutoff build on device arrays — its own cell grid, pads written (-1 / rc + 1),
+// counts that keep running past M — enqueued on the Scope's stream.  ids_only: the caller does not read the distances (dd must still
+// be a buffer of N x M: the kernels for rows of <= 16 slots and the mop-up code write them regardless).
+void lane_ids_only(bool on); // neighbor_lane.hip
+int neighbor_rows_device(Scope &sc, const double *dx, const double *dy, const double *dz, int64_t N, const DBox &b, double rc, int *dv,
+                         double *dd, int *dn, int64_t M, const int64_t *dkey, bool ids_only)
+{
+    CellGrid cg;
+    MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
+    // pads written (the tile kernel then stores whole 16-byte groups; leaving the pads out measured SLOWER: 2.96 against 2.54 ms
+    // at 10 M atoms, rc 3.8, 24 slots); distances wanted or not (rows of more than 16 slots: the wide instance skips them)
+    static const bool want_dist = [] { const char *e = std::getenv("MDH_KNN_ROWS_DIST"); return e && std::atoi(e) != 0; }(); // A/B
+    lane_ids_only(ids_only && !want_dist);
+    const int rcode = neighbor_pass(sc, cg, b, N, rc, dv, dd, dn, M, 2, nullptr);
+    lane_ids_only(false);
+    return rcode;
+}
+
 int moved_probe(int enable) // enable > 0: start tracking; 0: stop; < 0: the last value (-1: none)
 {
     if (enable > 0 && !g_moved_probe) {

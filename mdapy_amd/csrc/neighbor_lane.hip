@@ -1029,6 +1029,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                 for (int d = 32; d >= 1; d >>= 1) maxk = max(maxk, __shfl_xor(maxk, d, 64));
                 const uint64_t row = (uint64_t)(unsigned)id * (unsigned)M;
                 const int gend = write_pads ? M : min(M, maxk);
+                const bool ids_only = (write_pads & 2) != 0; // (uniform) lane_ids_only: no distance is computed or stored
                 for (int g0 = 0; g0 < gend; g0 += 4) {
                     int idv[4];
                     double dv[4];
@@ -1063,6 +1064,8 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                             sh[u] = (!TRI && general_tile) ? (int)lsh[k[u]] : 0;
                         }
                         bool slow = false;
+                        double rr[4] = {pad, pad, pad, pad}; // neighbor.cpp:174
+                        if (!ids_only) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (TRI) d2[u] = exact_d2<2>(b, cj[u].x, cj[u].y, zj[u], xi, yi, zi, 0);
@@ -1071,13 +1074,13 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                             d2[u] = h[u] ? d2[u] : 1.0;
                             slow = slow || !sqrt_fast_ok(d2[u]);
                         }
-                        double rr[4]; // neighbor.cpp:174
                         if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) == 0, 1)) {
 #pragma unroll
                             for (int u = 0; u < 4; ++u) rr[u] = sqrt_fast(d2[u]);
                         } else {
 #pragma unroll
                             for (int u = 0; u < 4; ++u) rr[u] = sqrt(d2[u]);
+                        }
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -1088,15 +1091,17 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                     if (mine) {
                         if (write_pads && g0 + 4 <= M) { // (any alignment: the hardware takes 16-byte stores at 4-byte addresses)
                             *reinterpret_cast<Int4 *>(verlet + row + g0) = Int4{idv[0], idv[1], idv[2], idv[3]};
-                            Int4 *dp = reinterpret_cast<Int4 *>(dist + row + g0);
-                            dp[0] = Int4{__double2loint(dv[0]), __double2hiint(dv[0]), __double2loint(dv[1]), __double2hiint(dv[1])};
-                            dp[1] = Int4{__double2loint(dv[2]), __double2hiint(dv[2]), __double2loint(dv[3]), __double2hiint(dv[3])};
+                            if (!ids_only) {
+                                Int4 *dp = reinterpret_cast<Int4 *>(dist + row + g0);
+                                dp[0] = Int4{__double2loint(dv[0]), __double2hiint(dv[0]), __double2loint(dv[1]), __double2hiint(dv[1])};
+                                dp[1] = Int4{__double2loint(dv[2]), __double2hiint(dv[2]), __double2loint(dv[3]), __double2hiint(dv[3])};
+                            }
                         } else {
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
                                 if (g0 + u < M && (g0 + u < kept || write_pads)) {
                                     verlet[row + g0 + u] = idv[u];
-                                    dist[row + g0 + u] = dv[u];
+                                    if (!ids_only) dist[row + g0 + u] = dv[u];
                                 }
                         }
                     }
@@ -1443,6 +1448,12 @@ static LanePlan plan_lane_fresh(const DBox &b, const Grid &g, int64_t N, int64_t
 }
 
 // count == true: nn and *max_count only (first pass of the exact-width variant); M is then 1
+// The next build's wide instance writes ids and counts only (knn.hip: the rows of a cutoff build as candidates of a k-nearest search;
+// the distances would be 8 M bytes per atom written and ~300 instructions per four slots computed for nobody).  The other kernels of
+// a build (rows of <= 16 slots, the mop-up code) write distances as always: the caller still passes a buffer.
+static thread_local bool g_lane_ids_only = false;
+void lane_ids_only(bool on) { g_lane_ids_only = on; }
+
 int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, int64_t N, const DBox &b, double rc,
                          int *verlet, double *dist, int *nn, int64_t M, bool fill_pads, bool count, int *max_count,
                          TileFilter &tf, int *pattern)
@@ -1489,7 +1500,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const dim3 grid((unsigned)(per * 8));
     const size_t lds1 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, plan.nw, pattern != nullptr); // first pass (four or eight waves per workgroup)
     const size_t lds2 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, 4, pattern != nullptr);       // slice pass: always four
-    const int Mi = (int)M, wp = fill_pads ? 1 : 0;
+    const int Mi = (int)M, wp = fill_pads ? (g_lane_ids_only ? 3 : 1) : 0; // bit 1: the wide instance neither computes nor stores the distances (lane_ids_only)
     const float negc = -plan.mid;
     const int nt2b = nt[2] * nsub;
     // second pass: workgroups walk the listed tiles' slices.  Nothing was listed by the previous build with this (N, grid)

@@ -14,8 +14,8 @@ for i, l in enumerate(lines):
 blocks, cur = [], {"label": "entry", "ins": []}
 order = {}
 for l in lines[start + 1:]:
-    if "s_endpgm" in l:
-        cur["ins"].append(l.strip()); break
+    if l.startswith(".Lfunc_end"):
+        break
     m = re.match(r"^(\.LBB\d+_\d+):", l)
     if m:
         blocks.append(cur); cur = {"label": m.group(1), "ins": []}; continue
