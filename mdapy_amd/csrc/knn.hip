@@ -718,21 +718,24 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
     {
         static const bool rows_env = [] { const char *e = std::getenv("MDH_KNN_ROWS"); return !e || std::atoi(e) != 0; }();
         const double r = 1.15 * std::cbrt(3.0 * (double)(k + 1) / (4.0 * 3.14159265358979323846 * ((double)N / vol)));
-        bool fits = rows_env && g_knn_variant == 0 && k <= 18 && N >= 100000 && r > 0 && std::isfinite(r);
+        const char *min_env = std::getenv("MDH_KNN_ROWS_MIN"); // (tests: the path on systems of a few thousand atoms)
+        const int64_t min_atoms = min_env ? std::atoll(min_env) : 100000;
+        bool fits = rows_env && g_knn_variant == 0 && k <= 18 && N >= min_atoms && r > 0 && std::isfinite(r);
         for (int d = 0; d < 3 && fits; ++d)
             if (b.pbc[d] && !(std::fabs(b.thick[d]) >= 7.5 * r)) fits = false;
         // a system of uneven density (a gas: Poisson counts; a cluster in vacuum) sends many queries on to the cell walk, and the rows
         // were built for nothing: the share of the last search with this (N, k) decides — more than 0.5 %, and the next 15 searches
         // of the signature walk the cells at once (then one more try)
-        struct Sig { int64_t N; int k; int left_pct, skip; };
+        struct Sig { int64_t N; int k, pbc; double vol; int left_pct, skip; };
         static Sig sigs[16] = {};
         Sig *sig = nullptr;
+        const int pbc_bits = (b.pbc[0] ? 1 : 0) | (b.pbc[1] ? 2 : 0) | (b.pbc[2] ? 4 : 0);
         for (auto &e : sigs)
-            if (e.N == N && e.k == k) sig = &e;
+            if (e.N == N && e.k == k && e.pbc == pbc_bits && e.vol == vol) sig = &e;
         if (!sig) {
             static int next = 0;
             sig = &sigs[next++ % 16];
-            *sig = Sig{N, k, 0, 0};
+            *sig = Sig{N, k, pbc_bits, vol, 0, 0};
         }
         if (fits && sig->skip > 0) { --sig->skip; fits = false; }
         if (fits) {

@@ -784,6 +784,70 @@ def test_knn_near_kernel_equals_general_kernel():
                 assert np.array_equal(out[0][1], q0), (name, k)
 
 
+def test_knn_from_cutoff_rows_vs_oracle(monkeypatch):
+    """The k nearest through the rows of a cutoff build (knn.hip k_knn_rows behind the tile kernel; large systems only, here let in
+    through MDH_KNN_ROWS_MIN): distances bit for bit and ids equal to the brute-force oracle's (src/fast_knn.cpp:846-916) on rattled
+    fcc / bcc, a sheared box, a slab open along z, atoms handed in box lengths away, a gas (most queries take the cell walk behind
+    it) and a perfect lattice (exact ties: distances equal, ids as the cell walk lists them); the event ranges say which path ran"""
+    import ctypes
+    from mdapy_amd import _lib
+
+    monkeypatch.setenv("MDH_KNN_ROWS_MIN", "1000")
+    L = _lib.lib()
+    rng = np.random.default_rng(41)
+    systems = []
+    p, b = _fcc(14, 0.06, 3)
+    systems.append(("fcc_rattled", p, b, ORG0, PBC, True))
+    pb, bb = lattice_positions("bcc", 2.87, 17, 17, 17)
+    systems.append(("bcc_rattled", pb + rng.normal(0, 0.05, pb.shape), bb, ORG0, PBC, True))
+    shear = np.array([[40.8, 0.0, 0.0], [4.1, 40.8, 0.0], [-2.0, 4.1, 40.8]])
+    pt, _ = _fcc(12, 0.06, 5, a=3.4)
+    org = np.array([2.0, -7.5, 11.0])
+    systems.append(("sheared", (pt / 40.8) @ shear + org, shear, org, PBC, True))
+    systems.append(("slab_open_z", p, b, ORG0, np.array([1, 1, 0], np.int32), True))
+    pu = p + rng.integers(-2, 3, p.shape) * np.diag(b)
+    systems.append(("fcc_unwrapped", pu, b, ORG0, PBC, True))
+    systems.append(("gas", rng.random((12000, 3)) * 52.0, np.eye(3) * 52.0, ORG0, PBC, True))
+    pp, bp = _fcc(13)
+    systems.append(("fcc_perfect", pp, bp, ORG0, PBC, False))
+    for name, pos, box, org, bnd, ids_too in systems:
+        x, y, z = _xyz(pos)
+        n = len(x)
+        for k in (5, 12, 14, 18):
+            i0 = np.zeros((n, k), np.int32); q0 = np.zeros((n, k)); i1 = np.zeros((n, k), np.int32); q1 = np.zeros((n, k))
+            O.knn(x, y, z, box, org, bnd, k, i0, q0, 8)
+            L.mdh_prof_reset(); L.mdh_prof_enable(1)
+            try:
+                _fast_knn.knn(x, y, z, box, org, bnd, k, i1, q1, 1)
+            finally:
+                L.mdh_prof_enable(0)
+            buf = ctypes.create_string_buffer(4096)
+            L.mdh_prof_report(buf, 4096)
+            assert b"knn_rows_build" in buf.value, (name, k, buf.value)  # the rows path did take the call
+            assert np.array_equal(q1, q0), (name, k)
+            if ids_too:
+                assert np.array_equal(i1, i0), (name, k)
+            else:  # exact ties: the same rows as the cell walk alone gives
+                monkeypatch.setenv("MDH_KNN_ROWS_MIN", "1000000000")
+                i2 = np.zeros((n, k), np.int32); q2 = np.zeros((n, k))
+                _fast_knn.knn(x, y, z, box, org, bnd, k, i2, q2, 1)
+                monkeypatch.setenv("MDH_KNN_ROWS_MIN", "1000")
+                assert np.array_equal(i1, i2) and np.array_equal(q1, q2), (name, k)
+    # keyed (the twin's searches): a perfect bcc lattice, permuted, key = the original number -> the original system's rows
+    from mdapy_amd import _order
+    pos, box = lattice_positions("bcc", 3.2, 14, 13, 12)
+    x, y, z = _xyz(pos)
+    n = len(x)
+    for k in (12, 14):
+        ref_i, ref_d = np.zeros((n, k), np.int32), np.zeros((n, k))
+        _fast_knn.knn(x, y, z, np.asarray(box, float), ORG0, PBC, k, ref_i, ref_d, 1)
+        perm = rng.permutation(n)
+        got_i, got_d = np.zeros((n, k), np.int32), np.zeros((n, k))
+        _fast_knn.knn(x[perm].copy(), y[perm].copy(), z[perm].copy(), np.asarray(box, float), ORG0, PBC, k, got_i, got_d, 1, key=perm.astype(np.int64))
+        rows, dist, _ = _order.translate_rows(got_i, got_d, None, perm.astype(np.int32))
+        assert np.array_equal(np.asarray(dist), ref_d) and np.array_equal(np.asarray(rows), ref_i), k
+
+
 @pytest.mark.parametrize("case", [CASES[0], CASES[5]], ids=[CASES[0][0], CASES[5][0]])
 @pytest.mark.parametrize("mode", ["rc", "nnn"])
 def test_steinhardt_vs_oracle(case, mode):
