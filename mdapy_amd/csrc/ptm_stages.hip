@@ -527,29 +527,68 @@ template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullSt
         m.pt(i, q);
         for (int a = 0; a < NP - 1; ++a) m.E[a * BLK] = 0;
         int nadd = 0;
-        for (int j = 0; j < h.num_facets; ++j) {
-            const uint32_t w = m.F[j * BLK];
-            const int a = w & IM, b = (w >> IB) & IM, c = (w >> (2 * IB)) & IM;
-            const bool vis = facet_sees(m, w, q);
-            const uint32_t side = vis ? 0u : 16u;
-            // the three marks are independent LDS read-modify-writes (ds_or_rtn): issued back to back
-            const int lo0 = min(a, b), hi0 = max(a, b), lo1 = min(b, c), hi1 = max(b, c), lo2 = min(c, a), hi2 = max(c, a);
-            const uint32_t b0 = 1u << (side + hi0 - 1), b1 = 1u << (side + hi1 - 1), b2 = 1u << (side + hi2 - 1);
-            const uint32_t e0 = __hip_atomic_fetch_or(&m.E[lo0 * BLK], b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b0;
-            const uint32_t e1 = __hip_atomic_fetch_or(&m.E[lo1 * BLK], b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b1;
-            const uint32_t e2 = __hip_atomic_fetch_or(&m.E[lo2 * BLK], b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b2;
-            const bool u = ((e0 >> (hi0 - 1)) & (e0 >> (16 + hi0 - 1)) & 1u) != 0;
-            const bool v = ((e1 >> (hi1 - 1)) & (e1 >> (16 + hi1 - 1)) & 1u) != 0;
-            const bool x = ((e2 >> (hi2 - 1)) & (e2 >> (16 + hi2 - 1)) & 1u) != 0;
-            if (vis) { // drop the facet: the last one takes its slot and is looked at next
-                m.F[j * BLK] = m.F[(h.num_facets - 1) * BLK];
-                --h.num_facets;
-                --j;
-            }
+        // The walk over the facets, software-pipelined (round 6).  A facet's turn was a CHAIN of LDS round trips — its word, its three
+        // vertices, the three returning marks, the word of the facet that takes a dropped one's slot — on a kernel that runs one wavefront
+        // per SIMD.  Now the word of the next slot and of the last facet are read a turn ahead, and the marks of a facet are looked at
+        // in the NEXT turn, behind the issue of that turn's vertex reads: per facet one exposed round trip (the vertices) instead of four.
+        // The LDS executes a wavefront's operations in order, so every mark returns what it returned in the plain loop; the horizon
+        // edges are appended in the same order (a facet's before the next facet's marks are even issued).
+        uint32_t pw = 0, pe0 = 0, pe1 = 0, pe2 = 0; // the facet whose marks are in flight: its word, what the three marks returned
+        bool pending = false;
+        auto settle = [&]() { // the horizon edges of the pending facet
+            const int a = pw & IM, b = (pw >> IB) & IM, c = (pw >> (2 * IB)) & IM;
+            const int hi0 = max(a, b), hi1 = max(b, c), hi2 = max(c, a);
+            const bool u = ((pe0 >> (hi0 - 1)) & (pe0 >> (16 + hi0 - 1)) & 1u) != 0;
+            const bool v = ((pe1 >> (hi1 - 1)) & (pe1 >> (16 + hi1 - 1)) & 1u) != 0;
+            const bool x = ((pe2 >> (hi2 - 1)) & (pe2 >> (16 + hi2 - 1)) & 1u) != 0;
             if (u && nadd < MAXF) { m.A[nadd * BLK] = (AW)(a | (b << IB)); ++nadd; }
             if (v && nadd < MAXF) { m.A[nadd * BLK] = (AW)(b | (c << IB)); ++nadd; }
             if (x && nadd < MAXF) { m.A[nadd * BLK] = (AW)(c | (a << IB)); ++nadd; }
+        };
+        int j = 0;
+        uint32_t w = h.num_facets > 0 ? (uint32_t)m.F[0] : 0u;                                  // the facet in slot j
+        uint32_t wlast = h.num_facets > 0 ? (uint32_t)m.F[(h.num_facets - 1) * BLK] : 0u;      // the facet in the last slot
+        while (j < h.num_facets) {
+            const uint32_t wnext = m.F[min(j + 1, MAXF - 1) * BLK]; // (used if this facet stays; a read past the end is never used)
+            const int a = w & IM, b = (w >> IB) & IM, c = (w >> (2 * IB)) & IM;
+            // facet_sees, its reads first
+            const int r = (w >> (3 * IB)) & 3;
+            const bool flip = (w >> (3 * IB + 2)) & 1;
+            const int o0 = r == 0 ? a : r == 1 ? c : b, o1 = r == 0 ? b : r == 1 ? a : c, o2 = r == 0 ? c : r == 1 ? b : a;
+            const int va = flip ? o1 : o0, vb = flip ? o0 : o1;
+            double pa[3], pb[3], pc[3];
+            m.pt(va, pa); m.pt(vb, pb); m.pt(o2, pc);
+            if (pending) settle(); // (behind the reads above, in front of their use)
+            bool vis;
+            {
+                double Nn[3], pp[3];
+                const double uu[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+                const double vv[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+                cross(uu, vv, Nn);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pp[k] = a == va ? pa[k] : a == vb ? pb[k] : pc[k]; // the facet's first vertex
+                const double d[3] = {pp[0] - q[0], pp[1] - q[1], pp[2] - q[2]};
+                vis = above_plane(Nn, d, flip, ptmc::HULL_TOL);
+            }
+            const uint32_t side = vis ? 0u : 16u;
+            const int lo0 = min(a, b), hi0 = max(a, b), lo1 = min(b, c), hi1 = max(b, c), lo2 = min(c, a), hi2 = max(c, a);
+            const uint32_t b0 = 1u << (side + hi0 - 1), b1 = 1u << (side + hi1 - 1), b2 = 1u << (side + hi2 - 1);
+            pe0 = __hip_atomic_fetch_or(&m.E[lo0 * BLK], b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b0;
+            pe1 = __hip_atomic_fetch_or(&m.E[lo1 * BLK], b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b1;
+            pe2 = __hip_atomic_fetch_or(&m.E[lo2 * BLK], b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) | b2;
+            pw = w;
+            pending = true;
+            if (vis) { // drop the facet: the last one takes its slot and is looked at next
+                m.F[j * BLK] = (FW)wlast;
+                --h.num_facets;
+                w = wlast;
+                wlast = m.F[max(h.num_facets - 1, 0) * BLK]; // (slot j itself when it is the last one left: just written)
+            } else {
+                ++j;
+                w = wnext;
+            }
         }
+        if (pending) settle();
         const int first_new = h.num_facets;
         for (int j = 0; j < nadd; ++j) {
             if (h.num_facets >= MAXF)
@@ -698,9 +737,8 @@ struct CanonOut {
     int8_t *ok;     // [N]
 };
 
-// (The facets themselves are not kept: they are read from the stage's lane-major input where a start edge is looked up — one
-// coalesced load per start edge — and the tables have NN rows, not 16: 212 instead of 280 bytes per lane for the 14-neighbour
-// kinds, twelve workgroups per CU instead of eight for a stage that runs a serial traversal per lane.)
+// (The facets are not kept in LDS — the kernel holds them in registers, two to a word — and the tables have NN rows, not 16: 212 instead
+// of 280 bytes per lane for the 14-neighbour kinds, twelve workgroups per CU instead of eight for a stage that runs a serial traversal per lane.)
 template <int NN> struct CanonMem {
     static constexpr int NF = 2 * NN - 4, NE = 3 * NN - 6;
     uint64_t *C; // [NN]: row a, nibble b = third vertex of the facet left of a->b
@@ -726,13 +764,31 @@ __global__ __launch_bounds__(BLK, (NN >= 12 && NN <= 14 ? 3 : 1)) void k_ptm_can
     m.C = reinterpret_cast<uint64_t *>(lds) + threadIdx.x;
     m.M = reinterpret_cast<uint16_t *>(lds + (size_t)BLK * NN * 8) + threadIdx.x;
     m.B = reinterpret_cast<int8_t *>(lds + (size_t)BLK * (NN * 8 + NN * 2)) + threadIdx.x;
-    auto facet = [&](int j) { return (int)facets[(int64_t)j * N + atom]; };
     bool good = status[atom] == NF;
+    // the NF facets once, two to a register (round 6): they are read three times below and once per start edge, and every read was a
+    // trip to memory inside a run-time loop — 3 NF dependent latencies per atom before the first traversal step.  A facet by a run-time
+    // number (the start edge's) is a chain of selects.
+    uint32_t fw[NF / 2];
+#pragma unroll
+    for (int j = 0; j < NF / 2; ++j) {
+        const uint32_t lo = good ? facets[(int64_t)(2 * j) * N + atom] : 0u, hi = good ? facets[(int64_t)(2 * j + 1) * N + atom] : 0u;
+        fw[j] = lo | (hi << 16);
+    }
+    static_assert(NF % 2 == 0, "facets in pairs");
+    auto facet_at = [&](int j) { return (int)((fw[j >> 1] >> (16 * (j & 1))) & 0xffffu); }; // compile-time j
+    auto facet = [&](int j) { // run-time j
+        uint32_t w = fw[0];
+#pragma unroll
+        for (int q = 1; q < NF / 2; ++q) w = (j >> 1) == q ? fw[q] : w;
+        return (int)((w >> (16 * (j & 1))) & 0xffffu);
+    };
     uint64_t deg = 0; // nibble v = degree of vertex v
     if (good) {
+#pragma unroll
         for (int a = 0; a < NN; ++a) { m.C[a * BLK] = 0; m.M[a * BLK] = 0; }
+#pragma unroll
         for (int j = 0; j < NF; ++j) {
-            const int w = facet(j);
+            const int w = facet_at(j);
             const int a = w & 31, b = (w >> 5) & 31, c = (w >> 10) & 31;
             deg += (1ull << (4 * a)) + (1ull << (4 * b)) + (1ull << (4 * c));
             // every directed edge may appear once (an oriented closed surface)
@@ -765,15 +821,17 @@ __global__ __launch_bounds__(BLK, (NN >= 12 && NN <= 14 ? 3 : 1)) void k_ptm_can
                 s_lo = 1;
             } else {
                 uint32_t bestd = 0;
+#pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const int w = facet(j);
+                    const int w = facet_at(j);
                     const uint32_t da = (uint32_t)((deg >> (4 * (w & 31))) & 15u), db = (uint32_t)((deg >> (4 * ((w >> 5) & 31))) & 15u),
                                    dc = (uint32_t)((deg >> (4 * ((w >> 10) & 31))) & 15u);
                     const uint32_t k0 = (da << 16) | (db << 8) | dc, k1 = da | (db << 16) | (dc << 8), k2 = (da << 8) | db | (dc << 16);
                     bestd = max(bestd, max(k0, max(k1, k2)));
                 }
+#pragma unroll
                 for (int j = 0; j < NF; ++j) {
-                    const int w = facet(j);
+                    const int w = facet_at(j);
                     const uint32_t da = (uint32_t)((deg >> (4 * (w & 31))) & 15u), db = (uint32_t)((deg >> (4 * ((w >> 5) & 31))) & 15u),
                                    dc = (uint32_t)((deg >> (4 * ((w >> 10) & 31))) & 15u);
                     const uint32_t k0 = (da << 16) | (db << 8) | dc, k1 = da | (db << 16) | (dc << 8), k2 = (da << 8) | db | (dc << 16);
