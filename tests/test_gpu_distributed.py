@@ -286,6 +286,10 @@ def test_bench_starts_its_own_ranks():
     assert cfg["atoms_per_rank"] == [4 * 40 ** 3] * 2 and all(g > 0 for g in cfg["ghosts_per_rank"])
     assert cfg["halo_bytes_per_step"] == 32 * sum(cfg["ghosts_per_rank"]) and cfg["exchange_ms"] > 0
     assert abs(res["value"] - 2 * cfg["atoms_per_gpu"] / (res["ms_per_step"] * 1e-3)) < 1e-6 * res["value"]
+    # the same run also times the metric's own box cut into the ranks' slabs (strong scaling), as config.strong
+    st = cfg["strong"]
+    assert st["result_ok"] and st["atoms_per_gpu"] == 4 * 40 ** 3 // 2 and st["value"] > 0 and st["ms_per_step"] > 0
+    assert abs(st["value"] - 4 * 40 ** 3 / (st["ms_per_step"] * 1e-3)) < 1e-6 * st["value"]
     # a failing rank: 20 cells do not split into 3 equal slabs
     bad = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--scaling", "strong", "--steps", "1", "--warmup", "0", "--cells", "20"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
