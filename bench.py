@@ -532,7 +532,8 @@ def main():
             # does not depend on this one) is started on a side stream before this step's kernels are enqueued.
             # (the prefetch pays where the exchange's kernels are worth hiding: 2.01 -> 1.96 ms for a 10 M-atom slab; for a 1.26 M-atom
             # slab the second stream costs more than it hides, 0.355 -> 0.377 ms — profiles/r05_strong.txt, r05_halo_cost.txt)
-            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M, next_frame=(x, y, z, gid) if n_local >= (1 << 22) else None)
+            dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec, x, y, z, gid, RC, M, next_frame=(x, y, z, gid) if n_local >= (1 << 22) else None,
+                                                       reuse_buffers=True)  # (the outputs allocated once, as the single-GPU step has them)
             return nn_, pat_, dom
 
     # the timed region: K steps, the neighbour kernel's range timed live by HIP events on its launch stream; the other
@@ -582,7 +583,7 @@ def main():
             xs_, ys_, zs_, gs_ = (dec_s.with_room(a, 0.25) for a in (xs_, ys_, zs_, gs_))
 
             def step_strong():
-                dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec_s, xs_, ys_, zs_, gs_, RC, M)
+                dom, v_, d_, nn_, pat_ = neighbor_cna_step(dec_s, xs_, ys_, zs_, gs_, RC, M, reuse_buffers=True)
                 return nn_, pat_, dom
 
             e_s, out_s, _ = timed(step_strong, args.steps, args.warmup, ranges=0)
@@ -831,7 +832,7 @@ def main():
                     _loopback.install(dec8, A_CU * cx, n_slab)
                     sx, sy, sz, sg_ = (dec8.with_room(a, 0.25) for a in (sx, sy, sz, sg_))
                     k = max(10, args.steps)
-                    e_a, o_a, _ = timed(lambda: neighbor_cna_step(dec8, sx, sy, sz, sg_, RC, M)[3:] + (None,), k, 3, ranges=0)
+                    e_a, o_a, _ = timed(lambda: neighbor_cna_step(dec8, sx, sy, sz, sg_, RC, M, reuse_buffers=True)[3:] + (None,), k, 3, ranges=0)
                     e_b, o_b, _ = timed(lambda: neighbor_cna_step(dec8, sx, sy, sz, sg_, RC, M, next_frame=(sx, sy, sz, sg_))[3:] + (None,), k, 3, ranges=0)
                     dec8._drop_pending(); torch.cuda.synchronize()
                     extra["strong_1of8"] = {"slab_atoms": n_slab, "slab_cells": f"{cx}x{cells}x{cells}", "ms_per_step": e_a / k * 1e3,

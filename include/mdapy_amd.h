@@ -197,6 +197,12 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
  * the window breaks the promise: detected on the device, the atom is left out of the grid (nothing is written out of bounds),
  * and the broken promise is reported as MDH_ERR_ARG by this thread's next build or by mdh_cell_window_check(). */
 int mdh_hint_cell_window(int axis, double frac_lo, double frac_hi);
+/* With a cell window: the stretch [frac_lo, frac_hi) of the same axis that holds the atoms whose rows the caller WANTS (a rank's own
+ * slab; the rest of the window is its ghost halo).  The next neighbor build of this thread lists the ghosts as neighbours but makes
+ * no rows for atoms binned outside the stretch's planes: their counts, rows and labels are left as the
+ * caller's buffers held them — pre-zero the counts.  The reference has no counterpart (src/mdapy/parallel.py:1-53 is OpenMP thread
+ * control); rows of the atoms inside the stretch are those of mdh_build_neighbor (src/neighbor.cpp:102-187).  Axis 0 of orthogonal boxes. */
+int mdh_hint_centre_window(int axis, double frac_lo, double frac_hi);
 /* Waits for `stream` and returns MDH_ERR_ARG if the last windowed build of this thread found atoms outside its window (the
  * build itself stays memory-safe: such atoms take no slot and are left out, so its rows are incomplete); MDH_OK otherwise.
  * For callers that want the CURRENT step to fail instead of the next build (one stream synchronisation). */

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "mdh_build_neighbor": [vp, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, i64, cint, cint, vp],
     "mdh_slab_halo_select": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, cint, vp],
     "mdh_hint_cell_window": [cint, dbl, dbl],
+    "mdh_hint_centre_window": [cint, dbl, dbl],
     "mdh_cell_window_check": [vp],
     "mdh_slab_halo_messages": [vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, cint, vp, vp, i64, vp],
     "mdh_slab_append_ghosts": [vp, vp, i64, i64, i64, vp, cint, vp, i64, vp],

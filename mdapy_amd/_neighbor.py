@@ -27,6 +27,12 @@ def build_neighbor(x, y, z, box, origin, boundary, rc, verlet_list, distance_lis
     c.done(rc_)
 
 
+def hint_centre_window(axis, frac_lo, frac_hi):
+    """with hint_cell_window: the stretch of the window that holds the atoms whose rows are wanted (a rank's own slab) — the next
+    build makes no rows for the ghosts around it (mdh_hint_centre_window); pre-zero the counts"""
+    _lib.check(_lib.lib().mdh_hint_centre_window(int(axis), float(frac_lo), float(frac_hi)))
+
+
 def hint_cell_window(axis, frac_lo, frac_hi):
     """promise to the next ``build_neighbor`` of this thread: every atom's wrapped fractional coordinate along ``axis`` lies in
     [frac_lo, frac_hi] (a rank's slab and halo in the global box): the passes over all cells of the global grid run over that

@@ -37,6 +37,7 @@ __host__ __device__ __forceinline__ int axis(int code, int d) { return ((code >>
 struct CellGrid {
     Grid g;
     int win_lo = 0, win_hi = 0; // planes [win_lo, win_hi) of axis 0 the grid was built over (a promised window, neighbor.hip); 0, 0: all
+    int cen_lo = 0, cen_hi = 0; // planes [cen_lo, cen_hi) of axis 0 whose atoms want rows (mdh_hint_centre_window: a slab's own atoms; the rest of the window is halo); 0, 0: all
     mutable bool flags_fresh = false; // flags[] were zeroed by build_cell_grid and nobody has used them yet (the first neighbor pass skips its own memset: every hipMemsetAsync is a 5 us launch)
     int *cell_start; // [ncell+1] exclusive prefix of the per-cell populations
     int *order;      // [N] atom ids, cell-major, DESCENDING id inside a cell

@@ -552,6 +552,9 @@ int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N)
 // ----------------------------------------------------------------------------
 struct CellWindow { int axis; double lo, hi; bool set; };
 static thread_local CellWindow g_window{0, 0.0, 0.0, false};
+// ... and inside the window the stretch that holds the atoms whose rows are wanted (mdh_hint_centre_window: a rank's OWN slab; what
+// lies between it and the window's ends are ghosts — candidates of the tile kernel, never its centres: their rows are not made)
+static thread_local CellWindow g_centre{0, 0.0, 0.0, false};
 static thread_local int *g_window_violations = nullptr; // pinned host word of the previous windowed build
 
 // out[a..b) = *v (a value that is on the device only)
@@ -724,6 +727,19 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     const int64_t plane = (int64_t)g.nc[1] * g.nc[2];
     cg.win_lo = cg.win_hi = 0;
     if (windowed && p3 <= p2) { cg.win_lo = p0; cg.win_hi = p1; } // one piece: the tile kernel runs over its range of tiles
+    cg.cen_lo = cg.cen_hi = 0;
+    if (g_centre.set) {
+        const CellWindow c = g_centre;
+        g_centre.set = false; // one build
+        if (packed && c.axis == 0 && !b.tri && g.mode == 0 && c.hi > c.lo && c.lo >= 0.0 && c.hi <= 1.0) {
+            // the planes an atom of fraction [lo, hi) can be binned into (cell_coords: floor((x - o) rc_inv), clamped); the ends moved
+            // out by 1e-9 of their value — far more than the roundings that separate the caller's fraction of an atom from the grid's
+            // (x - o) rc_inv, far less than a plane: an atom ON the slab's face is inside whichever way it was rounded
+            const double L = b.h[0];
+            cg.cen_lo = std::max(0, std::min(g.nc[0] - 1, (int)std::floor(c.lo * L * g.rc_inv * (1.0 - 1e-9) - 1e-9)));
+            cg.cen_hi = std::min(g.nc[0], (int)std::floor(c.hi * L * g.rc_inv * (1.0 + 1e-9) + 1e-9) + 1);
+        }
+    }
     cg.flags_fresh = true;
     // slack for the raw-vs-wrapped consistency flag: far above rounding, far below a cell width
     const double slack = 0.01 / (g.rc_inv > 0 ? g.rc_inv : 1.0);
@@ -1605,6 +1621,12 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
     }
     sc.keep_confirm(done);
     return sc.finish(space);
+}
+
+int mdh_hint_centre_window(int axis, double frac_lo, double frac_hi)
+{
+    g_centre = CellWindow{axis, frac_lo, frac_hi, true};
+    return MDH_OK;
 }
 
 int mdh_hint_cell_window(int axis, double frac_lo, double frac_hi)

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
     int M, int write_pads, int cap, int *__restrict__ flags, unsigned char *__restrict__ tile_flag, int nt0,
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
-    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw, int tile_base, int *__restrict__ listed_sink)
+    int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw, int tile_base, int *__restrict__ listed_sink,
+    int cen_lo, int cen_hi)
 {
     const int TXY = ts.txy, TZ = ts.tz;
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
@@ -517,7 +518,10 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                 h.img = (n0 + 1) | ((n1 + 1) << 2) | ((n2 + 1) << 4);
                 h.edge = (!b.pbc[0] && (a0 == 0 || a0 == g.nc[0] - 1)) || (!b.pbc[1] && (a1 == 0 || a1 == g.nc[1] - 1)) ||
                          (!b.pbc[2] && (a2 == 0 || a2 == g.nc[2] - 1));
-                h.centre = hx >= 1 && hx <= TXY && hy >= 1 && hy <= TXY && h.hz >= 1 && h.hz <= TZ && g0 < g.nc[0] && g1 < g.nc[1] && g2 < g.nc[2];
+                // (cen_lo, cen_hi: the planes of axis 0 whose atoms want rows — all of them, or the planes of a decomposed system's own slab:
+                // the ghost planes around it are staged as candidates, never scanned as centres)
+                h.centre = hx >= 1 && hx <= TXY && hy >= 1 && hy <= TXY && h.hz >= 1 && h.hz <= TZ && g0 < g.nc[0] && g1 < g.nc[1] && g2 < g.nc[2] &&
+                           g0 >= cen_lo && g0 < cen_hi;
             }
         }
         return h;
@@ -562,6 +566,8 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
         const int total = total2 & 0xffff, ncentres = total2 >> 16;
         const int off0 = off2 & 0xffff, coff = off2 >> 16;
         bool ok = !(total > cap || ncentres > CENC); // else: listed for the next pass
+        const bool no_centres = ncentres == 0;          // (uniform) a tile of ghost planes only: nothing to stage, nothing to list
+        if (no_centres) ok = false;
         STAMP(2);
         // the 3-cell run around every cell that can be a column entry of a centre's walk (cells tid-1, tid, tid+1 are adjacent in z
         // and in LDS)
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
         STAMP(3);
         if (ok && (s_flag[1] | s_flag[2]))
             ok = false;
-        if (!ok && tid == 0) { // list this tile for the next pass
+        if (!ok && !no_centres && tid == 0) { // list this tile for the next pass
             if (tile_flag) tile_flag[tile_id] = 1;
             flagged[atomicAdd(&flags[flag_slot], 1)] = tile_id;
         }
@@ -1484,7 +1490,9 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         // grid was built over it: the tiles that can hold atoms are ONE range of tile numbers (axis 0 is the slowest index) —
         // no list, no pass over the tiles of the global grid to make one
         tile_list = nullptr;
-        const int t_lo = cg.win_lo / ts.txy, t_hi = (cg.win_hi - 1) / ts.txy;
+        // (tiles of the planes that hold atoms wanting rows: the window, or the centre window inside it)
+        const int w_lo = cg.cen_hi > cg.cen_lo ? std::max(cg.win_lo, cg.cen_lo) : cg.win_lo, w_hi = cg.cen_hi > cg.cen_lo ? std::min(cg.win_hi, cg.cen_hi) : cg.win_hi;
+        const int t_lo = w_lo / ts.txy, t_hi = (std::max(w_hi, w_lo + 1) - 1) / ts.txy;
         tile_base = t_lo * nt[1] * nt[2];
         nt0_run = t_hi - t_lo + 1;
         per = (int)(((int64_t)nt0_run * nt[1] * nt[2] + 7) / 8);
@@ -1500,6 +1508,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     const dim3 grid((unsigned)(per * 8));
     const size_t lds1 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, plan.nw, pattern != nullptr); // first pass (four or eight waves per workgroup)
     const size_t lds2 = lds_bytes(plan.cap, count ? 1 : M, plan.tk8, plan.rw, 4, pattern != nullptr);       // slice pass: always four
+    const int cen_lo = cg.cen_hi > cg.cen_lo ? cg.cen_lo : 0, cen_hi = cg.cen_hi > cg.cen_lo ? cg.cen_hi : 0x7fffffff;
     const int Mi = (int)M, wp = fill_pads ? (g_lane_ids_only ? 3 : 1) : 0; // bit 1: the wide instance neither computes nor stores the distances (lane_ids_only)
     const float negc = -plan.mid;
     const int nt2b = nt[2] * nsub;
@@ -1514,7 +1523,8 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW>), GRID, dim3((NW) * 64), lds, st, cg.pk, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base, plan.listed_sink); \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base, plan.listed_sink, \
+                           cen_lo, cen_hi); \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once

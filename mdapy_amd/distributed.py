@@ -403,14 +403,17 @@ class SlabDecomposition:
         dom.absent_slots = True  # rows [n_owned, n_tot) hold ghosts and absent atoms (x = NaN, gid = -1)
         return dom
 
-    def hint_window(self, halo: float, like=None):
+    def hint_window(self, halo: float, like=None, own_rows_only: bool = False):
         """tell the next neighbor build where this rank's atoms are (slab + halo along the decomposed axis): its passes over the
-        cells of the GLOBAL grid then cover that window only"""
+        cells of the GLOBAL grid then cover that window only.  own_rows_only: the build makes no rows for the ghosts (they are listed
+        as neighbours of the owned atoms, which is what a step needs them for) — counts of ghost atoms stay as the caller zeroed them"""
         if self.world >= 2 and (like is None or getattr(like, "is_cuda", False)) and hasattr(kernels.neighbor, "hint_cell_window"):
             h = self.halo_fraction(halo)
             if not self._single_message(h):
                 return
             kernels.neighbor.hint_cell_window(self.axis, self.rank / self.world - h, (self.rank + 1) / self.world + h)
+            if own_rows_only and hasattr(kernels.neighbor, "hint_centre_window"):
+                kernels.neighbor.hint_centre_window(self.axis, self.rank / self.world, (self.rank + 1) / self.world)
 
     # -- halo exchange --------------------------------------------------------
     def exchange_halo(self, x, y, z, gid, halo: float, sort: bool = True, extra=(), static: bool = False) -> LocalDomain:
@@ -515,12 +518,16 @@ def partition_atoms(pos: np.ndarray, box: Box, world: int, axis: int = 0):
     return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
 
 
-def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh: int, next_frame=None, strict: bool = False):
+def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh: int, next_frame=None, strict: bool = False,
+                      reuse_buffers: bool = False):
     """One pass of the distributed hot path: halo exchange -> neighbor build -> fixed-cutoff CNA.
 
-    Returns (dom, verlet, dist, nn, pattern): neighbor arrays / labels for ALL local atoms in `dom`
-    order (rows of ghost atoms are incomplete; select with ``dom.owned``).  ``verlet`` holds local
-    indices; ``dom.gid[verlet]`` maps them to global ids.
+    Returns (dom, verlet, dist, nn, pattern): neighbor arrays / labels in `dom` order — the rows of the OWNED atoms
+    (``dom.owned``).  What the arrays hold for a GHOST is unspecified: ghosts are listed as neighbours, nobody needs THEIR
+    neighbours, and the tile kernel makes no rows for the cell planes that hold ghosts only (pads, count 0, label 0 there; a ghost
+    in a plane it shares with owned atoms gets its — by nature incomplete — row).  ``dec._ghost_rows = True`` makes all ghost rows as
+    earlier rounds did; on the CPU path they are always made.  ``verlet`` holds local indices; ``dom.gid[verlet]`` maps them to
+    global ids.
 
     next_frame = (x, y, z, gid) of the frame the NEXT call will be given: its halo exchange is started on a side stream
     before this frame's kernels are enqueued and travels while they run (SlabDecomposition.start_halo).
@@ -528,6 +535,11 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
     drifted across a face without re-partitioning) or if THIS step's halo message did not fit its agreed size; without it
     the build is still memory-safe, the NEXT step raises for this one, and the caller must end a run with
     ``torch.cuda.synchronize(); dec.check_halo()`` (the last step has no successor to report it).
+
+    reuse_buffers: the four result arrays are the SAME tensors from call to call (kept on `dec`, as a caller who allocates his
+    outputs once would have them — bench.py's single-GPU step does): a step then starts with one fill (the labels) instead of four —
+    the ghosts' pads and zero counts of the previous step are still there, no kernel writes those rows.  The previous step's results
+    are overwritten.
 
     On more than one rank with HBM-resident tensors the exchange is *static*: the ghost count never leaves the device, so
     the local arrays have ``n_owned + 2 * cap`` rows (``dom.absent_slots`` is True) of which the slots behind the ghosts
@@ -551,15 +563,25 @@ def neighbor_cna_step(dec: SlabDecomposition, x, y, z, gid, rc: float, max_neigh
             print(f"mdapy_amd.distributed: halo prefetch switched off on rank {dec.rank} ({type(e).__name__}: {e})", file=sys.stderr)
     n = int(dom.x.shape[0])
     b = dec.box
-    verlet = t.empty((n, max_neigh), dtype=t.int32, device=dom.x.device)
-    dist = t.empty((n, max_neigh), dtype=t.float64, device=dom.x.device)
     # (absent slots get no row: their counts must read 0 for the CNA behind the build)
-    nn = (t.zeros if getattr(dom, "absent_slots", False) else t.empty)((n,), dtype=t.int32, device=dom.x.device)
-    pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
-    if getattr(dom, "absent_slots", False):  # the build writes no row for an absent atom: pads, not what the allocator left
-        verlet[dom.n_owned:].fill_(-1)
-        dist[dom.n_owned:].fill_(rc + 1.0)
-    dec.hint_window(rc, dom.x)
+    ghost_rows = bool(getattr(dec, "_ghost_rows", False))  # (True: rows for the ghosts as well, as rounds 3-5 made them; incomplete by nature)
+    skip_ghosts = dec.world > 1 and not ghost_rows and bool(getattr(dom.x, "is_cuda", False))
+    kept = getattr(dec, "_step_buffers", None) if reuse_buffers else None
+    sig = (n, int(max_neigh), dom.n_owned, float(rc), str(dom.x.device), skip_ghosts)
+    if kept is not None and kept[0] == sig and skip_ghosts:
+        verlet, dist, nn, pattern = kept[1]
+        pattern.zero_()  # (the kernels only ever raise a label; the ghosts' pads and zero counts are the previous step's, untouched)
+    else:
+        verlet = t.empty((n, max_neigh), dtype=t.int32, device=dom.x.device)
+        dist = t.empty((n, max_neigh), dtype=t.float64, device=dom.x.device)
+        nn = (t.zeros if (getattr(dom, "absent_slots", False) or skip_ghosts) else t.empty)((n,), dtype=t.int32, device=dom.x.device)
+        pattern = t.zeros((n,), dtype=t.int32, device=dom.x.device)
+        if getattr(dom, "absent_slots", False) or skip_ghosts:  # the build writes no row for an absent atom or a ghost: pads, not what the allocator left
+            verlet[dom.n_owned:].fill_(-1)
+            dist[dom.n_owned:].fill_(rc + 1.0)
+        if reuse_buffers:
+            dec._step_buffers = (sig, (verlet, dist, nn, pattern))
+    dec.hint_window(rc, dom.x, own_rows_only=skip_ghosts)
     # lists and labels in ONE pass over the tiles (mdh_build_neighbor_fcna: a centre's 12 or 14 neighbours are still staged in LDS
     # when its row is written) — bit for bit what build_neighbor followed by fcna leaves
     kernels.neighbor.build_neighbor_fcna(dom.x, dom.y, dom.z, b.box, b.origin, b.boundary, rc, verlet, dist, nn, pattern, 1, fill_pads=True,

@@ -24,11 +24,11 @@ sx, sy, sz, sg = (dec.with_room(a, 0.05 if weak else 0.25) for a in (sx, sy, sz,
 for prefetch in (False, True):
     nf = (sx, sy, sz, sg) if prefetch else None
     for _ in range(3):
-        out = neighbor_cna_step(dec, sx, sy, sz, sg, RC, M, next_frame=nf)
+        out = neighbor_cna_step(dec, sx, sy, sz, sg, RC, M, next_frame=nf, reuse_buffers=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = neighbor_cna_step(dec, sx, sy, sz, sg, RC, M, next_frame=nf)
+        out = neighbor_cna_step(dec, sx, sy, sz, sg, RC, M, next_frame=nf, reuse_buffers=True)
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
