@@ -386,6 +386,18 @@ int mdh_knn(const double *x, const double *y, const double *z, int64_t N, const 
  * k-th distance is a tie, WHICH neighbours are listed depends on it.  A key that is no permutation: memory-safe, rows meaningless. */
 int mdh_knn_keyed(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
                   const int *boundary3, int k, int *indices, double *distances, const int64_t *key, int space, void *stream);
+/* mdh_knn_keyed (src/fast_knn.cpp:846-916) with the candidate rows of its cutoff build kept BY THE CALLER between searches of the
+ * same positions: a System that asks for its 12 nearest (centro-symmetry) and then for its 14 nearest (adaptive CNA) builds the rows
+ * once.  rows_io (N x M_io) i32 and counts_io (N) i32 are DEVICE buffers whatever `space` says; M_io a multiple of four,
+ * >= mdh_knn_rows_width(k) for a search that is to FILL them.  *radius (host): in — > 0: the buffers hold every atom's neighbours
+ * inside that radius for THESE positions in THIS box (the caller vouches for it), the build is skipped; 0: not yet — out: the radius
+ * of what the buffers hold now, 0 when they hold nothing usable (a small system, a box too thin, k > 18: the cell walk took the
+ * call).  Results are those of mdh_knn_keyed in every case; a query the rows cannot finish takes the cell walk. */
+int mdh_knn_keyed_rows(const double *x, const double *y, const double *z, int64_t N, const double *box9, const double *origin3,
+                       const int *boundary3, int k, int *indices, double *distances, const int64_t *key, int *rows_io, int *counts_io,
+                       int M_io, double *radius, int space, void *stream);
+/* slots per atom a search for k neighbours wants in rows_io (0: the rows path does not serve this k) */
+int mdh_knn_rows_width(int k);
 
 /* ---- _repeat_cell ----------------------------------------------------- */
 /* replaces _repeat_cell.repeat_cell                        src/repeat_cell.cpp:19-61; new_pos flat (n_old*nx*ny*nz*3) */

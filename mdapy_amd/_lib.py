@@ -89,6 +89,8 @@ _SIGNATURES = {
     "mdh_wcp_counts": [vp, vp, vp, vp, i64, i64, cint, vp, cint, vp],
     "mdh_knn": [vp, vp, vp, i64, vp, vp, vp, cint, vp, vp, cint, vp],
     "mdh_knn_keyed": [vp, vp, vp, i64, vp, vp, vp, cint, vp, vp, vp, cint, vp],
+    "mdh_knn_keyed_rows": [vp, vp, vp, i64, vp, vp, vp, cint, vp, vp, vp, vp, vp, cint, vp, cint, vp],
+    "mdh_knn_rows_width": [cint],
     "mdh_repeat_cell": [vp, vp, vp, i64, cint, cint, cint, cint, vp],
     "mdh_ptm": [C.c_char_p, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, dbl, vp, cint, vp, cint, cint, vp],
     "mdh_ptm_flags": [C.c_char_p],

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_knn_rows(const Pos4 *__restrict__ w, in
     if (i >= N)
         return;
     const int cnt = nn[i];
-    bool ok = cnt >= k && cnt <= M;
+    bool ok = cnt >= k && cnt <= M && cnt <= MROW; // (rows kept from a search with another k may be wider or narrower than MROW)
     double ld[K]; // the K best so far, sorted by (squared distance, tie number); free slots hold +inf
     int li[K];
     typedef typename std::conditional<KEYED, int64_t, int>::type Tie; // (without a key the index itself breaks ties: no third array)
@@ -133,7 +133,16 @@ __global__ __launch_bounds__(256) void k_knn_rows(const Pos4 *__restrict__ w, in
         // rows are 64 of them — read four ids at a time as the loop goes, every step fetched all 64 lines again (they do not survive in
         // the CU's 16 KB cache between steps with a dozen wavefronts resident: the kernel ran FASTER with fewer of them)
         int rowv[MROW];
-        load_row<MROW>(rows + i * (int64_t)M, rowv);
+        {
+            const int *__restrict__ row = rows + i * (int64_t)M;
+#pragma unroll
+            for (int q = 0; q < MROW / 4; ++q) {
+                RowQuad v = {-1, -1, -1, -1};
+                if (4 * q < M) v = *reinterpret_cast<const RowQuad *>(row + 4 * q); // (M: a multiple of four, uniform)
+                rowv[4 * q] = v.x; rowv[4 * q + 1] = v.y; rowv[4 * q + 2] = v.z; rowv[4 * q + 3] = v.w;
+            }
+        }
+        static_assert(MROW % 4 == 0, "rows in quads");
 #pragma unroll
         for (int e0 = 0; e0 < MROW; e0 += 4) {
             if (e0 >= cnt)
@@ -700,6 +709,22 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
                              const double *origin3, const int *boundary3, int k, int *indices, double *distances,
                              const int64_t *key, int space, void *stream)
 {
+    return mdh_knn_keyed_rows(x, y, z, N, box9, origin3, boundary3, k, indices, distances, key, nullptr, nullptr, 0, nullptr, space, stream);
+}
+
+extern "C" int mdh_knn_rows_width(int k) { return k <= 18 ? 32 : 0; } // (one width for every k: rows kept by the caller serve any of them)
+
+// mdh_knn_keyed with the candidate rows of the cutoff build kept BY THE CALLER between searches of the same positions (a System
+// that asks for its 12 nearest and then for its 14 nearest: the second search skips the build, half of its time).  rows (N x M i32)
+// and counts (N i32): DEVICE buffers (whatever `space` says about the other arguments), M >= mdh_knn_rows_width(k) or the path is
+// not taken; *radius (host): in — > 0: rows / counts hold the candidates inside that radius of THESE positions in THIS box (the
+// caller vouches for it); 0: build them — out: the radius of what the buffers hold now, 0 when they hold nothing usable.
+extern "C" int mdh_knn_keyed_rows(const double *x, const double *y, const double *z, int64_t N, const double *box9,
+                                  const double *origin3, const int *boundary3, int k, int *indices, double *distances,
+                                  const int64_t *key, int *rows_io, int *counts_io, int M_io, double *radius, int space, void *stream)
+{
+    const double radius_in = radius ? *radius : 0.0;
+    if (radius) *radius = 0.0;
     if (N < 0 || N >= 2147483647LL || k <= 0 || k > 64) { set_error("mdh_knn: need 1 <= k <= 64"); return MDH_ERR_ARG; }
     DBox b;
     MDH_TRY(make_box(b, box9, origin3, boundary3));
@@ -717,7 +742,13 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
     unsigned char *only = nullptr;
     {
         static const bool rows_env = [] { const char *e = std::getenv("MDH_KNN_ROWS"); return !e || std::atoi(e) != 0; }();
-        const double r = 1.15 * std::cbrt(3.0 * (double)(k + 1) / (4.0 * 3.14159265358979323846 * ((double)N / vol)));
+      // two attempts at most: with the caller's rows of an earlier search (any k) — and, when those leave more than a few queries
+      // unfinished (a radius sized for fewer neighbours), with rows of this k's own radius, built into the caller's buffers
+      const double r_own = 1.15 * std::cbrt(3.0 * (double)(k + 1) / (4.0 * 3.14159265358979323846 * ((double)N / vol)));
+      // (borrowed rows must reach at least nine tenths of this k's own radius: the rows of a 12-neighbour search serve 14, not 18)
+      for (int attempt = (rows_io && counts_io && radius_in >= 0.9 * r_own && M_io == mdh_knn_rows_width(k)) ? 0 : 1; attempt < 2; ++attempt) {
+        const bool reuse = attempt == 0;
+        const double r = reuse ? radius_in : r_own;
         const char *min_env = std::getenv("MDH_KNN_ROWS_MIN"); // (tests: the path on systems of a few thousand atoms)
         const int64_t min_atoms = min_env ? std::atoll(min_env) : 100000;
         bool fits = rows_env && g_knn_variant == 0 && k <= 18 && N >= min_atoms && r > 0 && std::isfinite(r);
@@ -739,9 +770,10 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
         }
         if (fits && sig->skip > 0) { --sig->skip; fits = false; }
         if (fits) {
-            const int M = k <= 12 ? 24 : k <= 14 ? 28 : 32;
-            int *rows = sc.alloc_n<int>((size_t)N * M), *rnn = sc.alloc_n<int>((size_t)N), *nflag = sc.alloc_n<int>(4);
-            double *rdist = sc.alloc_n<double>((size_t)N * M);
+            const bool kept = rows_io && counts_io && (reuse || M_io >= mdh_knn_rows_width(k)); // the rows live in the caller's buffers
+            const int M = reuse ? M_io : (kept ? M_io : mdh_knn_rows_width(k));
+            int *rows = kept ? rows_io : sc.alloc_n<int>((size_t)N * M), *rnn = kept ? counts_io : sc.alloc_n<int>((size_t)N), *nflag = sc.alloc_n<int>(4);
+            double *rdist = reuse ? nullptr : sc.alloc_n<double>((size_t)N * M);
             Pos4 *w4 = sc.alloc_n<Pos4>((size_t)N);
             only = sc.alloc_n<unsigned char>((size_t)N);
             static int *pinned = nullptr; // the number of queries left for the cell walk: the one word this path reads back
@@ -749,14 +781,15 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
             if (sc.failed() || !pinned)
                 return sc.failed() ? sc.error() : MDH_ERR_HIP;
             MDH_HIP(hipMemsetAsync(nflag, 0, sizeof(int), st));
-            {
+            if (!reuse) {
                 ProfRange pr("knn_rows_build", st);
                 MDH_TRY(neighbor_rows_device(sc, dx, dy, dz, N, b, r, rows, rdist, rnn, M, nullptr, true));
             }
+            if (kept && radius) *radius = r;
             ProfRange pr("knn_rows_select", st);
             const dim3 grid(grid_for(N, 256)), block(256);
             const double safe2 = r * r * (1.0 - 1e-9);
-#define MDH_KNN_ROWS_AS(TRI, K, KEYED) hipLaunchKernelGGL((k_knn_rows<TRI, K, (K <= 12 ? 24 : K <= 14 ? 28 : 32), KEYED>), grid, block, 0, st, w4, N, b, rows, M, rnn, safe2, k, dkey, di, dd, only, nflag)
+#define MDH_KNN_ROWS_AS(TRI, K, KEYED) hipLaunchKernelGGL((k_knn_rows<TRI, K, 32, KEYED>), grid, block, 0, st, w4, N, b, rows, M, rnn, safe2, k, dkey, di, dd, only, nflag)
 #define MDH_KNN_ROWS(K)                                                                                                                  \
     do {                                                                                                                                  \
         if (b.tri) {                                                                                                                      \
@@ -774,11 +807,18 @@ extern "C" int mdh_knn_keyed(const double *x, const double *y, const double *z, 
 #undef MDH_KNN_ROWS_AS
             MDH_HIP(hipMemcpyAsync(pinned, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
             MDH_HIP(hipStreamSynchronize(st));
-            sig->left_pct = (int)(100.0 * (double)*pinned / (double)N);
-            if ((double)*pinned > 0.005 * (double)N) sig->skip = 15; // (a wavefront of the cell walk runs whole if ONE of its queries is left: 2 % left cost as much as all)
             if (*pinned == 0)
                 return sc.finish(space);
+            if (reuse && (double)*pinned > 0.005 * (double)N) { // borrowed rows that do not reach: this k's own, then
+                if (radius) *radius = 0.0;
+                only = nullptr;
+                continue;
+            }
+            sig->left_pct = (int)(100.0 * (double)*pinned / (double)N);
+            if ((double)*pinned > 0.005 * (double)N) sig->skip = 15; // (a wavefront of the cell walk runs whole if ONE of its queries is left: 2 % left cost as much as all)
         }
+        break;
+      }
     }
     double *wx = sc.alloc_n<double>((size_t)N), *wy = sc.alloc_n<double>((size_t)N), *wz = sc.alloc_n<double>((size_t)N);
     if (sc.failed())

@@ -18,7 +18,7 @@ import numpy as np
 
 
 class Column:
-    __slots__ = ("name", "_host_arr", "_dev")
+    __slots__ = ("name", "_host_arr", "_dev", "__weakref__")  # (weakly referable: knn.py keeps candidate rows per position column)
 
     def __init__(self, name: str, values):
         self.name = name

@@ -11,6 +11,23 @@ from .parallel import get_num_threads
 
 MAX_K = 24  # the search keeps its candidates in a fixed-size list (src/mdapy/knn.py:14)
 
+import weakref
+
+_bags = weakref.WeakKeyDictionary()  # the x column of a frame -> (weak y column, weak z column, dict of candidate rows)
+
+
+def _candidates_of(frame):
+    """the dict that holds the candidate rows of searches over THESE position columns (column objects are immutable and shared by
+    the frames a System makes of them — a new per-atom column does not lose the rows; new positions are new columns)"""
+    try:
+        xc, yc, zc = frame["x"], frame["y"], frame["z"]
+        hit = _bags.get(xc)
+        if hit is None or hit[0]() is not yc or hit[1]() is not zc:
+            hit = _bags[xc] = (weakref.ref(yc), weakref.ref(zc), {})
+        return hit[2]
+    except TypeError:  # (a column type that cannot be weakly referenced: no sharing)
+        return None
+
 
 class NearestNeighbor:
     def __init__(self, data, box, k):
@@ -57,5 +74,11 @@ class NearestNeighbor:
         # distance are then ordered as they are in the original system (which neighbours of a perfect lattice are listed depends on it)
         key = getattr(frame, "order_key", None) if frame is self.data else None
         extra = {} if key is None else {"key": key}
+        # the candidate rows of the search's cutoff build stay with the FRAME (its columns never change, frame.py): the next
+        # search of the same frame in the same box — another k, another analysis — skips that build
+        if frame is self.data and getattr(kernels.fast_knn, "keeps_candidates", False):
+            bag = _candidates_of(frame)
+            if bag is not None:
+                extra["candidates"] = bag
         kernels.fast_knn.knn(*policy.positions(frame), *policy.box_args(cell), self.k, self.indices_py, self.distances_py,
                              get_num_threads(), **extra)

@@ -848,6 +848,49 @@ def test_knn_from_cutoff_rows_vs_oracle(monkeypatch):
         assert np.array_equal(np.asarray(dist), ref_d) and np.array_equal(np.asarray(rows), ref_i), k
 
 
+def test_knn_candidate_rows_are_shared_between_the_searches_of_a_system(monkeypatch):
+    """The searches of one System over the same positions — centro-symmetry (12 nearest), adaptive CNA (14), a k = 18 list — share
+    the candidate rows of the first search's cutoff build where they reach (knn.py keeps them with the position columns;
+    mdh_knn_keyed_rows): every result equals the one a fresh System computes alone, and the build ran for the first search and for
+    the one whose radius the kept rows do not reach, not for the others."""
+    import ctypes
+    from mdapy_amd import _lib
+    from mdapy_amd.devarray import as_numpy
+
+    monkeypatch.setenv("MDH_KNN_ROWS_MIN", "1000")
+    L = _lib.lib()
+    pos, box = _fcc(14, 0.06, 3)
+
+    def builds(fn):
+        L.mdh_prof_reset(); L.mdh_prof_enable(1)
+        try:
+            fn()
+        finally:
+            L.mdh_prof_enable(0)
+        buf = ctypes.create_string_buffer(4096)
+        L.mdh_prof_report(buf, 4096)
+        rec = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().strip().splitlines() if ln}
+        return rec.get("knn_rows_build", 0), rec.get("knn_rows_select", 0)
+
+    alone = {}
+    for name, fn in (("csp", lambda q: q.cal_centro_symmetry_parameter(12)), ("cna", lambda q: q.cal_common_neighbor_analysis()),
+                     ("knn", lambda q: q.build_nearest_neighbor(18))):
+        q = mp.System(pos=pos, box=box)
+        fn(q)
+        alone[name] = (q.data[name].to_numpy().copy() if name != "knn" else (as_numpy(q.verlet_list).copy(), as_numpy(q.distance_list).copy()))
+    s = mp.System(pos=pos, box=box)
+    assert builds(lambda: s.cal_centro_symmetry_parameter(12)) == (1, 1)
+    assert builds(lambda: s.cal_common_neighbor_analysis()) == (0, 1)   # the 14 nearest from the rows of the 12-nearest search
+    assert builds(lambda: s.build_nearest_neighbor(18)) == (1, 1)        # ... which do not reach the 18th neighbour: rows of its own
+    v18, d18 = as_numpy(s.verlet_list).copy(), as_numpy(s.distance_list).copy()
+    assert builds(lambda: s.cal_centro_symmetry_parameter(12)) == (0, 1)  # (the list is a k-nearest list: searched again, from the kept rows)
+    assert np.array_equal(s.data["csp"].to_numpy(), alone["csp"]) and np.array_equal(s.data["cna"].to_numpy(), alone["cna"])
+    assert np.array_equal(v18, alone["knn"][0]) and np.array_equal(d18, alone["knn"][1])
+    # new positions: new columns, nothing is borrowed
+    s2 = mp.System(pos=pos + 0.01, box=box)
+    assert builds(lambda: s2.cal_common_neighbor_analysis()) == (1, 1)
+
+
 @pytest.mark.parametrize("case", [CASES[0], CASES[5]], ids=[CASES[0][0], CASES[5][0]])
 @pytest.mark.parametrize("mode", ["rc", "nnn"])
 def test_steinhardt_vs_oracle(case, mode):
