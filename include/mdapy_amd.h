@@ -259,6 +259,10 @@ int mdh_spatial_sort(const double *x, const double *y, const double *z, int64_t 
                      const int *boundary3, double *xs, double *ys, double *zs, int *perm, int64_t *n_sorted, int space, void *stream);
 /* mdh_permute: out[p] = in[perm[p]] (scatter == 0) or out[perm[p]] = in[p] (scatter != 0) for N elements of 4 or 8 bytes. */
 int mdh_permute(const void *in, const int *perm, int64_t N, int elem_bytes, int scatter, void *out, int space, void *stream);
+/* xs[p] = x[perm[p]] (and y, z): the three position columns through one permutation in one pass — the next frame of a trajectory read
+ * through the previous frame's cell order (System's twin; no reference counterpart, see mdh_spatial_sort).  perm must hold indices in [0, N). */
+int mdh_gather_positions(const double *x, const double *y, const double *z, const int *perm, int64_t N, double *xs, double *ys, double *zs,
+                         int space, void *stream);
 /* mdh_translate_rows: a list built on the sorted copy (row p = atom perm[p], entries = sorted indices) as the list of the
  * original order: verlet[perm[p]][s] = perm[verlet_sorted[p][s]] (pads < 0 stay), dist and nn rows moved along (both NULL or both
  * given, pairwise).  With rows built by mdh_build_neighbor_keyed(key = perm) the result is the list mdh_build_neighbor builds on

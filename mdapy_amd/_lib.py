@@ -62,6 +62,7 @@ _SIGNATURES = {
     "mdh_order_statistic": [vp, vp, vp, i64, vp, vp, vp, vp, cint, vp],
     "mdh_spatial_sort": [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cint, vp],
     "mdh_permute": [vp, vp, i64, cint, cint, vp, cint, vp],
+    "mdh_gather_positions": [vp, vp, vp, vp, i64, vp, vp, vp, cint, vp],
     "mdh_translate_rows": [vp, vp, vp, vp, i64, i64, vp, vp, vp, cint, vp],
     "mdh_slab_append_ghosts_static": [vp, vp, i64, vp, cint, vp, i64, vp],
     "mdh_slab_overflow_check": [],

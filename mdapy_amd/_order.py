@@ -52,6 +52,18 @@ def permute(values, perm, scatter=False):
     return out
 
 
+def gather_positions(x, y, z, perm):
+    """(x[perm], y[perm], z[perm]) in one pass (mdh_gather_positions)"""
+    N = int(len(x))
+    on_dev = not all(isinstance(a, np.ndarray) for a in (x, y, z, perm))
+    mk = (lambda: HArray.empty((N,), f64)) if on_dev else (lambda: np.empty(N, f64))
+    xs, ys, zs = mk(), mk(), mk()
+    c = Call(x, y, z, perm, xs, ys, zs)
+    c.done(_lib.lib().mdh_gather_positions(c.inp(x, f64), c.inp(y, f64), c.inp(z, f64), c.inp(perm, i32), N, c.out(xs, f64, upload=False),
+                                           c.out(ys, f64, upload=False), c.out(zs, f64, upload=False), c.space, c.stream))
+    return xs, ys, zs
+
+
 def translate_rows(rows_sorted, dist_sorted, counts_sorted, perm):
     """a list built on the sorted copy -> the list of the original order (ids through perm, rows to their atoms' places);
     ``dist_sorted`` / ``counts_sorted`` may be None.  -> (rows, dist, counts)"""

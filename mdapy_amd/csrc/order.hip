@@ -87,6 +87,23 @@ __global__ __launch_bounds__(256) void k_permute(const T *__restrict__ in, const
     else out[p] = in[q];
 }
 
+// three f64 columns through one permutation, four atoms per thread: the permutation read once, twelve gathers in flight per thread
+__global__ __launch_bounds__(256) void k_gather3(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                 const int *__restrict__ perm, int64_t N, double *__restrict__ xs, double *__restrict__ ys,
+                                                 double *__restrict__ zs)
+{
+    const int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    int q[4];
+    double a[4], b[4], c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = p0 + u < N ? perm[p0 + u] : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = x[q[u]]; b[u] = y[q[u]]; c[u] = z[q[u]]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (p0 + u < N) { xs[p0 + u] = a[u]; ys[p0 + u] = b[u]; zs[p0 + u] = c[u]; }
+}
+
 // rows of a list built in sorted space -> the original index space: row p goes to row perm[p], its entries j >= 0 become perm[j]
 // (pads stay).  A thread per (row, four slots); rows of a multiple of four slots move in 16-byte pieces.
 typedef int RowPiece __attribute__((ext_vector_type(4), aligned(4)));
@@ -229,6 +246,23 @@ int mdh_permute(const void *in, const int *perm, int64_t N, int elem_bytes, int 
         if (scatter) hipLaunchKernelGGL((k_permute<unsigned long long, true>), grid, block, 0, st, di, dp, N, dout);
         else hipLaunchKernelGGL((k_permute<unsigned long long, false>), grid, block, 0, st, di, dp, N, dout);
     }
+    MDH_HIP(hipGetLastError());
+    return sc.finish(space);
+}
+
+int mdh_gather_positions(const double *x, const double *y, const double *z, const int *perm, int64_t N, double *xs, double *ys, double *zs,
+                         int space, void *stream)
+{
+    if (N < 0 || N >= 2147483647LL) { set_error("mdh_gather_positions: invalid N"); return MDH_ERR_ARG; }
+    if (N == 0)
+        return MDH_OK;
+    Scope sc(stream);
+    const double *dx = sc.stage_in(x, (size_t)N, space), *dy = sc.stage_in(y, (size_t)N, space), *dz = sc.stage_in(z, (size_t)N, space);
+    const int *dp = sc.stage_in(perm, (size_t)N, space);
+    double *ox = sc.stage(xs, (size_t)N, space, false, true), *oy = sc.stage(ys, (size_t)N, space, false, true), *oz = sc.stage(zs, (size_t)N, space, false, true);
+    if (sc.failed())
+        return sc.error();
+    hipLaunchKernelGGL(k_gather3, dim3(grid_for((N + 3) / 4, 256)), dim3(256), 0, sc.stream(), dx, dy, dz, dp, N, ox, oy, oz);
     MDH_HIP(hipGetLastError());
     return sc.finish(space);
 }

@@ -8,6 +8,7 @@
 // result is independent of the summation order and bit-identical to the
 // reference's "+= 1.0" on doubles (exact below 2^53).
 #include "common.hpp"
+#include <cstdlib>
 #include "grid.hpp"
 #include <algorithm>
 
@@ -144,8 +145,10 @@ template <bool TRI>
 __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs, const double *__restrict__ ys, const double *__restrict__ zs,
                                                   const int *__restrict__ order, const int *__restrict__ cell_start,
                                                   const int *__restrict__ type, DBox b, Grid g, double rc, int nbin, int ntype,
-                                                  unsigned long long *__restrict__ hist, float tol_scale)
+                                                  unsigned long long *__restrict__ hist, float tol_scale, int probe)
 {
+    // probe (a measuring switch, MDH_RDF_PROBE=1, tools/rdf_probe.py): 1 = no pair is ever "inside the cutoff" — the kernel walks
+    // and tests every pair as always and bins nothing: what the candidate walk and the distance tests cost by themselves
     extern __shared__ __attribute__((aligned(16))) unsigned char rdf_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t hsize = hsize_of(ntype, nbin);
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const int qi = __float_as_int(ce.w);
                     // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
-                    const bool hit = valid && r2 < rc2f * (1.0f + 1.0e-4f * tol_scale) && !(same_cell && qj <= qi);
+                    const bool hit = valid && r2 < rc2f * (1.0f + 1.0e-4f * tol_scale) && !(same_cell && qj <= qi) && probe == 0;
                     const unsigned long long hm = __ballot(hit);
                     if (hm == 0)
                         continue;
@@ -463,11 +466,13 @@ int mdh_rdf_streaming(const double *x, const double *y, const double *z, const i
         }
         if ((!b.tri || (tri_tile && tol_scale < 64.0)) && ntype <= 255 && hsize <= RDF_LDS_BINS && g_rdf_variant == 0) {
             ProfRange pr("k_rdf_tile", st);
+            const char *probe_env = std::getenv("MDH_RDF_PROBE");
+            const int rdf_probe = probe_env ? std::atoi(probe_env) : 0;
             const unsigned blocks = (unsigned)std::min<int64_t>((cg.g.ncell + 3) / 4, 256 * 8); // a wave per cell, four to a workgroup
             if (b.tri)
-                hipLaunchKernelGGL(k_rdf_tile<true>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, (float)tol_scale);
+                hipLaunchKernelGGL(k_rdf_tile<true>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, (float)tol_scale, rdf_probe);
             else
-                hipLaunchKernelGGL(k_rdf_tile<false>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, 1.0f);
+                hipLaunchKernelGGL(k_rdf_tile<false>, dim3(blocks), dim3(256), tile_lds, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, b, cg.g, rc, nbin, ntype, hist, 1.0f, rdf_probe);
         } else if (b.tri)
             hipLaunchKernelGGL(k_rdf_cells<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, cg.xs, cg.ys, cg.zs, cg.order, cg.cell_start, dt, N, b, cg.g, rc, nbin, ntype, hist);
         else

@@ -167,6 +167,41 @@ def _from_ovito(collection):
     return Frame(cols), cell, info
 
 
+# The frames of a trajectory share their atom numbering: when a System has just been sorted and the next one brings as many atoms in
+# the same box shape, its positions are first read through the LAST permutation — atoms move a fraction of a cell between frames, the
+# old cell order is still a spatial order — and the order statistic of the result decides whether that will do (three gathers and a
+# sampling pass instead of a sort: the sort is as long as the whole neighbor + CNA step of an ordered frame).
+_last_order = {}  # "perm": HArray / ndarray, "n": atoms, "pbc": tuple
+
+
+def _remember_order(perm, n, where):
+    _last_order.update(perm=perm, n=int(n), pbc=tuple(int(v) for v in np.asarray(where[5]).ravel()), host=isinstance(perm, np.ndarray))
+
+
+def _sorted_as_last_time(cols, where, n):
+    from . import kernels
+
+    perm = _last_order.get("perm")
+    if perm is None or _last_order.get("n") != int(n) or os.environ.get("MDAPY_REUSE_ORDER", "1") == "0":
+        return None
+    if _last_order.get("pbc") != tuple(int(v) for v in np.asarray(where[5]).ravel()):
+        return None
+    on_dev = any(c._host_arr is None or c._dev is not None for c in cols)
+    if on_dev == bool(_last_order.get("host")):
+        return None  # (the permutation lives in the other memory space)
+    try:
+        arrs = [c.device_array() if on_dev else c.to_numpy() for c in cols]
+        if hasattr(kernels.order, "gather_positions"):
+            moved = list(kernels.order.gather_positions(*arrs, perm))
+        else:
+            moved = [kernels.order.permute(a, perm) for a in arrs]
+        if kernels.order.order_statistic(*moved, *where[3:]) > SORT_FAR_FRACTION:
+            return None  # another numbering after all: sort
+    except Exception:
+        return None
+    return moved[0], moved[1], moved[2], perm, int(n)
+
+
 class System:
     def __init__(self, filename=None, data=None, pos=None, box=None, ase_atom=None, ovito_atom=None, format=None,
                  global_info=None):
@@ -231,8 +266,9 @@ class System:
                 and policy.is_single(self._safe_repeat()):
             where = (*cols, *policy.box_args(self.box))
             if mode == "1" or kernels.order.order_statistic(*where) > SORT_FAR_FRACTION:
-                xs, ys, zs, perm, n = kernels.order.spatial_sort(*where)
+                xs, ys, zs, perm, n = _sorted_as_last_time(cols, where, self.N) or kernels.order.spatial_sort(*where)
                 if n == self.N:
+                    _remember_order(perm, self.N, where)
                     twin = System(data=Frame({"x": xs, "y": ys, "z": zs}), box=self.box)
                     twin._is_twin = True
                     twin._perm = perm

@@ -178,3 +178,35 @@ def test_perfect_lattice_through_the_twin_equals_the_plain_path():
         assert (s._spatial() is not None) == (mode == "1")
     for c in cols["0"]:
         assert np.array_equal(cols["0"][c], cols["1"][c], equal_nan=True), c
+
+
+def test_next_frame_of_a_trajectory_is_read_through_the_last_permutation():
+    """frame 2 of a trajectory — the same numbering, every atom moved by a fraction of a cell — is not sorted again: its positions are
+    gathered through frame 1's permutation and found to be in a spatial order (system.py _sorted_as_last_time); lists and labels of
+    both frames against the oracle, and a frame in ANOTHER numbering is sorted afresh"""
+    from mdapy_amd import system as system_mod
+
+    pos, box = _lattice(40, 0.05, 11)  # 256 000 shuffled atoms
+    rng = np.random.default_rng(3)
+    rc = 0.854 * 3.615
+    perms = []
+    for frame in range(2):
+        p = pos + rng.normal(0, 0.04, pos.shape) * frame
+        s = mp.System(pos=p, box=box)
+        s.cal_common_neighbor_analysis(rc=rc)
+        twin = s._spatial()
+        assert twin is not None
+        perms.append(np.asarray(as_numpy(twin._perm)).copy())
+        x, y, z = (np.ascontiguousarray(p[:, k]) for k in range(3))
+        V, D, Nn = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 16)
+        P = np.zeros(len(x), np.int32)
+        O.fcna(x, y, z, box, ORG0, PBC, V, Nn, P, rc, 16)
+        assert np.array_equal(s.data["cna"].to_numpy(), P) and np.array_equal(np.asarray(s.verlet_list), V)
+        assert np.array_equal(np.asarray(s.distance_list), D)
+    assert np.array_equal(perms[0], perms[1]), "the second frame went through the first frame's permutation"
+    # another numbering of the same atoms: the old permutation leaves no spatial order, the frame is sorted
+    again = rng.permutation(len(pos))
+    s = mp.System(pos=pos[again], box=box)
+    s.cal_common_neighbor_analysis(rc=rc)
+    assert s._spatial() is not None and not np.array_equal(np.asarray(as_numpy(s._spatial()._perm)), perms[0])
+    assert int((s.data["cna"].to_numpy() == 1).sum()) > 0.9 * len(pos)
