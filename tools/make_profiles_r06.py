@@ -26,7 +26,7 @@ def pmc(tag):
     return {short(k)[:62]: v for k, v in json.load(open(p)).items()} if os.path.exists(p) else {}
 
 
-what = sys.argv[1:] or ["analyses"]
+what = sys.argv[1:] or ["analyses", "bench", "texts"]
 if "analyses" in what:
     src = os.path.join(G, "r06_analyses")
     shutil.copy(os.path.join(src, "s_kernel_stats.csv"), os.path.join(P, "r06_analyses_kernel_stats.csv"))
@@ -92,3 +92,68 @@ if "analyses" in what:
                 "`k_neighbor_lane` (ids only) + `k_knn_rows`.  What was tried and lost is in `r06_ptm_experiments.txt`.\n"
                 "None of these kernels is near the HBM roofline, and none should be: per atom they do 10^3 - 10^5 operations on a few hundred bytes.\n")
     print(open(os.path.join(P, "r06_analyses_roofline.md")).read()[:6000])
+
+
+def stats_dir(d):
+    import glob
+    hits = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    return (stats(hits[0]), hits[0]) if hits else ({}, None)
+
+
+if "bench" in what:
+    bj = os.path.join(G, "r06_bench.json")
+    if os.path.exists(bj):
+        bench = json.loads(open(bj).read().strip().splitlines()[-1])
+        json.dump(bench, open(os.path.join(P, "r06_bench_line.json"), "w"), indent=1)
+        rf = bench["roofline"]
+        json.dump({"source": "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) run by bench.py itself over the benchmarked step, this round's measurement pass",
+                   "traffic_bytes_per_launch_raw": rf["traffic_raw_fetch_plus_write"], "traffic_bytes_per_launch_fetch_x2": rf["traffic"],
+                   "traffic_source": rf["traffic_source"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                   "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; kernel = k_neighbor_lane (the instance that also labels: lists + CNA) incl. its slice pass"},
+                  open(os.path.join(P, "r06_traffic.json"), "w"), indent=1)
+        bs, src = stats_dir(os.path.join(G, "r06_bench"))
+        if src:
+            shutil.copy(src, os.path.join(P, "r06_bench_kernel_stats.csv"))
+            with open(os.path.join(P, "r06_bench_kernel_stats.md"), "w") as f:
+                f.write("# bench.py under `rocprofv3 --kernel-trace --stats` (round 6, one MI355X, 10 061 824-atom FCC Cu, M = 16)\n\n")
+                f.write(f"`tools/measure_r06.sh bench`: the default bench line first ({bench['ms_per_step']:.3f} ms/step = {bench['value'] / 1e9:.2f} G atoms/s; `k_neighbor` range by HIP "
+                        f"events inside the library {rf['avg_kernel_ms']:.4f} ms -> {rf['achieved']:.0f} GB/s algorithmic = {rf['frac']:.4f} of 8 TB/s; PMC traffic "
+                        f"{(rf['traffic'] or 0) / 1e9:.3f} GB per launch, FETCH doubled, vs {rf['algorithmic_bytes_per_launch'] / 1e9:.3f} GB algorithmic), then the same command "
+                        "(`--no-extra --no-pmc --no-cpu-baseline`) under the kernel trace, whose table follows.\n\n"
+                        "The tile kernel (the instance with the fused CNA: it writes the lists and the labels) is launched twice per build (all tiles, then the one-cell slices of the "
+                        "tiles whose halo overflowed LDS: an empty stand-by on this input).  The headline step's kernels did not change in round 6 (the round went into configs 2 "
+                        "and 4, the k-nearest search and the decomposed step).\n\n| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n")
+                for k, (c, a, mn, mx) in sorted(bs.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:16]:
+                    f.write(f"| `{k}` | {c} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} |\n")
+    merged = {}
+    for tag in ("r06_sq1", "r06_sq2", "r06_fetch", "r06_write"):
+        pth = os.path.join(G, f"pmc_{tag}.json")
+        if os.path.exists(pth):
+            for k, v in json.load(open(pth)).items():
+                merged.setdefault(short(k), {}).update({c: val for c, val in v.items()})
+    merged = {k: v for k, v in merged.items() if not k.startswith("k_warm_")}
+    bs, _ = stats_dir(os.path.join(G, "r06_bench"))
+    for k, v in merged.items():
+        d = {}
+        if "SQ_INSTS_VALU" in v and v.get("SQ_WAVES"):
+            d["valu_instr_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+        if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES"):
+            d["wave_cycles_waiting_fraction"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+        if k in bs and "SQ_ACTIVE_INST_VALU" in v:
+            d["kernel_us_under_the_bench_trace"] = bs[k][1] / 1e3
+            d["valu_busy_fraction_per_simd"] = v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (bs[k][1] * 1e-9 * 2.4e9)
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            d["hbm_bytes_fetch_x2_plus_write"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        v["_derived"] = d
+    if merged:
+        merged["_note"] = ("per dispatch of every kernel of the headline step (tools/order_probe.py lattice 136 5 under four separate rocprofv3 --pmc passes, "
+                           "tools/measure_r06.sh counters); SQ_* summed over the chip; FETCH_SIZE / WRITE_SIZE in KB (FETCH undoubled)")
+        json.dump(merged, open(os.path.join(P, "r06_step_counters.json"), "w"), indent=1)
+
+if "texts" in what:
+    for src, dst in (("r06_knn_split.txt", "r06_knn_split.txt"), ("r06_knn_rows.txt", "r06_knn_rows.txt"), ("r06_notebook.txt", "r06_notebook.txt"),
+                     ("r06_ptm_bench.txt", "r06_ptm_bench.txt"), ("r06_rc_sweep.txt", "r06_rc_sweep.txt")):
+        pth = os.path.join(G, src)
+        if os.path.exists(pth):
+            keep = [l for l in open(pth) if not re.match(r"^[WE]\d{8}", l) and "amdgpu.ids" not in l]
+            open(os.path.join(P, dst), "w").writelines(keep)
