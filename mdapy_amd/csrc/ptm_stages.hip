@@ -364,6 +364,15 @@ __device__ __forceinline__ bool above_plane(const double *N, const double *d, bo
     return n[0] * d[0] + n[1] * d[1] + n[2] * d[2] > tol;
 }
 
+// the reference's normalised expression alone (the tail of above_plane)
+__device__ __forceinline__ bool above_plane_exact(const double *N, const double *d, bool neg, double tol)
+{
+    const double nr = sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+    double n[3] = {N[0] / nr, N[1] / nr, N[2] / nr};
+    if (neg) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    return n[0] * d[0] + n[1] * d[1] + n[2] * d[2] > tol;
+}
+
 template <int NP> __device__ __forceinline__ void raw_normal(const HullMem<NP> &m, int a, int b, int c, double *N, double *pa)
 {
     double pb[3], pc[3];
@@ -565,10 +574,23 @@ template <int NP> __device__ int hull_grow(const HullMem<NP> &m, int num, HullSt
                 const double uu[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
                 const double vv[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
                 cross(uu, vv, Nn);
+                // The quick decision from vertex `va` (already in registers): any vertex of the facet gives the same product up to
+                // rounding, 1e-16 |N| |p|, and the band S = 1e-9 |N| is seven orders wider — a product outside the band has the sign
+                // the reference's expression (from the facet's FIRST vertex, HULL_TOL = 1e-12) has.  Inside the band: that expression.
+                const double da[3] = {pa[0] - q[0], pa[1] - q[1], pa[2] - q[2]};
+                const double s0 = Nn[0] * da[0] + Nn[1] * da[1] + Nn[2] * da[2];
+                const double sg = flip ? -s0 : s0;
+                const double S = 1e-9 * (fabs(Nn[0]) + fabs(Nn[1]) + fabs(Nn[2]));
+                if (sg > S) {
+                    vis = true;
+                } else if (sg < -S) {
+                    vis = false;
+                } else {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) pp[k] = a == va ? pa[k] : a == vb ? pb[k] : pc[k]; // the facet's first vertex
-                const double d[3] = {pp[0] - q[0], pp[1] - q[1], pp[2] - q[2]};
-                vis = above_plane(Nn, d, flip, ptmc::HULL_TOL);
+                    for (int k = 0; k < 3; ++k) pp[k] = a == va ? pa[k] : a == vb ? pb[k] : pc[k]; // the facet's first vertex
+                    const double d[3] = {pp[0] - q[0], pp[1] - q[1], pp[2] - q[2]};
+                    vis = above_plane_exact(Nn, d, flip, ptmc::HULL_TOL);
+                }
             }
             const uint32_t side = vis ? 0u : 16u;
             const int lo0 = min(a, b), hi0 = max(a, b), lo1 = min(b, c), hi1 = max(b, c), lo2 = min(c, a), hi2 = max(c, a);
