@@ -140,10 +140,24 @@ __global__ __launch_bounds__(64) void k_sq_stage1_l(const double *__restrict__ x
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + t;
     const int rows = (int)(N - row0 < 64 ? N - row0 : 64);
     const int o = il * nz; // this degree's segment of a row: components o .. o + 2l
-    for (int e = t; e < rows * NM; e += 64) {
-        const int r = e / NM, m = e - r * NM;
-        sr[m][r] = qlm_r[(row0 + r) * stride + o + m]; // the caller's (pre-zeroed) content: the reference adds onto it
-        si[m][r] = qlm_i[(row0 + r) * stride + o + m];
+    // (NM trips at most, unrolled: as a run-time loop every trip waited for its two loads before the next were issued — NM dependent
+    // memory latencies in front of every workgroup's work; now the 2 NM loads are in flight together)
+    {
+        double gr[NM], gi[NM];
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int e = t + 64 * q;
+            const int r = e / NM, m = e - r * NM;
+            const bool in = e < rows * NM;
+            gr[q] = in ? qlm_r[(row0 + r) * stride + o + m] : 0.0; // the caller's (pre-zeroed) content: the reference adds onto it
+            gi[q] = in ? qlm_i[(row0 + r) * stride + o + m] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int e = t + 64 * q;
+            const int r = e / NM, m = e - r * NM;
+            if (e < rows * NM) { sr[m][r] = gr[q]; si[m][r] = gi[q]; }
+        }
     }
     __syncthreads();
     if (i < N) {
@@ -274,11 +288,23 @@ __global__ __launch_bounds__(64) void k_sq_stage1_pair(const double *__restrict_
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + t;
     const int rows = (int)(N - row0 < 64 ? N - row0 : 64);
     const int oa = ila * nz, ob = ilb * nz;
-    for (int e = t; e < rows * NM; e += 64) {
-        const int r = e / NM, m = e - r * NM;
-        const int64_t at = (row0 + r) * stride + (m < NA ? oa + m : ob + (m - NA));
-        sr[m][r] = qlm_r[at]; // the caller's (pre-zeroed) content: the reference adds onto it
-        si[m][r] = qlm_i[at];
+    { // (unrolled: the 2 NM loads in flight together instead of NM dependent latencies, see k_sq_stage1_l)
+        double gr[NM], gi[NM];
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int e = t + 64 * q;
+            const int r = e / NM, m = e - r * NM;
+            const int64_t at = (row0 + r) * stride + (m < NA ? oa + m : ob + (m - NA));
+            const bool in = e < rows * NM;
+            gr[q] = in ? qlm_r[at] : 0.0; // the caller's (pre-zeroed) content: the reference adds onto it
+            gi[q] = in ? qlm_i[at] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int e = t + 64 * q;
+            const int r = e / NM, m = e - r * NM;
+            if (e < rows * NM) { sr[m][r] = gr[q]; si[m][r] = gi[q]; }
+        }
     }
     __syncthreads();
     if (i < N) {
