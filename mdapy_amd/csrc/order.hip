@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_gather3(const double *__restrict__ x, c
     int q[4];
     double a[4], b[4], c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) q[u] = p0 + u < N ? perm[p0 + u] : 0;
+    for (int u = 0; u < 4; ++u) q[u] = perm[p0 + u < N ? p0 + u : N - 1]; // (unconditional: a branch around a load is followed by a wait for it)
 #pragma unroll
     for (int u = 0; u < 4; ++u) { a[u] = x[q[u]]; b[u] = y[q[u]]; c[u] = z[q[u]]; }
 #pragma unroll
