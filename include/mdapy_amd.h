@@ -90,6 +90,10 @@ int mdh_prof_report(char *buf, int buflen);
 /* A/B switch for measurements and tests: 0 = automatic kernel choice (default), 1 = force the
  * thread-per-atom neighbor kernel, 2 = force the round-1 LDS-tiled kernel where it applies.  Results are identical. */
 int mdh_debug_set_neighbor_variant(int variant);
+/* A/B switch for measurements and tests: 1 (default; MDH_INDIRECT in the environment) = a neighbor build of input that comes in
+ * some spatial order keeps no cell-sorted copy of the atoms, its kernels read them through the cell-sorted id list;
+ * 0 = the cell-sorted 32-byte records always (what unordered input gets either way).  Returns the previous value.  Results are identical. */
+int mdh_debug_set_indirect(int on);
 /* test hook: the tile plan of the last neighbor build that took the LDS-tile kernel (neighbor_lane.hip):
  * plan8 = {tile cells in x/y, in z, halo atoms per tile, LDS bytes, box full of atoms, 1000 * atoms per cell,
  * cells of the occupied region, 1 if a plan was made since the last query}. */

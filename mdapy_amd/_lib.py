@@ -39,6 +39,7 @@ _SIGNATURES = {
     "mdh_prof_reset": [],
     "mdh_prof_report": [vp, cint],
     "mdh_debug_set_neighbor_variant": [cint],
+    "mdh_debug_set_indirect": [cint],
     "mdh_debug_neighbor_plan": [vp],
     "mdh_debug_set_fcna_variant": [cint],
     "mdh_debug_track_counters": [cint],

@@ -52,20 +52,32 @@ struct CellGrid {
     // 16-byte requests instead of five small ones
     struct Packed { double x, y, z; int id, code; };
     Packed *pk; // when set, xs / ys / zs / mvs are NOT filled (ensure_unpacked() does that for the kernels that want them)
+    // INDIRECT (neighbor builds of input that comes in some spatial order): no sorted copy of the atoms at all — atom q of the cell
+    // order is atom order[q] of the CALLER's arrays (ix, iy, iz; image code imv[order[q]] when flags[4] says that any atom has
+    // one).  pk, xs, ys, zs, mvs are all null; the kernels read through `order` (the tile kernel stages a cell's atoms with four
+    // small gathers per atom where the record took two 16-byte reads — and the grid build is one pass over 56 B per atom shorter)
+    const double *ix = nullptr, *iy = nullptr, *iz = nullptr;
+    const unsigned short *imv = nullptr;
 };
 // a cell-sorted atom, from either representation
 struct SortedView {
     const double *xs, *ys, *zs;
     const int *order;
     const CellGrid::Packed *pk;
+    bool indirect; // xs, ys, zs are the caller's arrays, read at order[q] (CellGrid::ix)
     __device__ __forceinline__ void get(int64_t q, double &x, double &y, double &z, int &id) const
     {
         if (pk) { const CellGrid::Packed r = pk[q]; x = r.x; y = r.y; z = r.z; id = r.id; }
+        else if (indirect) { id = order[q]; x = xs[id]; y = ys[id]; z = zs[id]; }
         else { x = xs[q]; y = ys[q]; z = zs[q]; id = order[q]; }
     }
     __device__ __forceinline__ int id_of(int64_t q) const { return pk ? pk[q].id : order[q]; }
 };
-inline SortedView view_of(const CellGrid &cg) { return SortedView{cg.xs, cg.ys, cg.zs, cg.order, cg.pk}; }
+inline SortedView view_of(const CellGrid &cg)
+{
+    if (!cg.pk && !cg.xs && cg.ix) return SortedView{cg.ix, cg.iy, cg.iz, cg.order, nullptr, true};
+    return SortedView{cg.xs, cg.ys, cg.zs, cg.order, cg.pk, false};
+}
 int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N); // xs, ys, zs, mvs from pk (no-op when they exist)
 
 // neighbor_tiled.hip: the round-1 LDS-tiled kernel (double-precision scan, any run length); serves the cells too full for neighbor_lane.hip

@@ -27,6 +27,8 @@
 namespace mdh {
 
 static int *g_moved_probe = nullptr; // pinned: flags[0] of the last tracked neighbor pass (mdh_debug_track_counters)
+// 1: neighbor builds of input in spatial order keep no sorted copy of the atoms (CellGrid::ix); 0: the 32-byte records always
+static std::atomic<int> g_indirect{[] { const char *e = std::getenv("MDH_INDIRECT"); return e ? std::atoi(e) : 1; }()};
 int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel, 2 = force the round-1 LDS-tiled kernel (A/B measurements, tests)
 
 // ----------------------------------------------------------------------------
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void k_unpack(const CellGrid::Packed *__restri
 
 int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N)
 {
-    if (!cg.pk || cg.xs)
+    if ((!cg.pk && !cg.ix) || cg.xs)
         return MDH_OK;
     cg.xs = sc.alloc_n<double>((size_t)N);
     cg.ys = sc.alloc_n<double>((size_t)N);
@@ -535,7 +537,11 @@ int ensure_unpacked(Scope &sc, CellGrid &cg, int64_t N)
     cg.mvs = sc.alloc_n<unsigned short>((size_t)N);
     if (sc.failed())
         return sc.error();
-    hipLaunchKernelGGL(k_unpack, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.pk, N, cg.xs, cg.ys, cg.zs, cg.mvs);
+    if (cg.pk) // from the records
+        hipLaunchKernelGGL(k_unpack, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.pk, N, cg.xs, cg.ys, cg.zs, cg.mvs);
+    else // an indirect grid: the gather its build left out
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, sc.stream(), cg.ix, cg.iy, cg.iz, cg.order, cg.xs, cg.ys, cg.zs, N, cg.imv,
+                           cg.mvs, (CellGrid::Packed *)nullptr, cg.flags + 4, cg.cell_start + cg.g.ncell);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
 }
@@ -680,14 +686,21 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     // scattered (with packed): the caller knows that the atoms come in no spatial order
     CellGrid::Packed *rec = nullptr;
     int *rec_flag = nullptr;
+    cg.ix = cg.iy = cg.iz = nullptr;
+    cg.imv = nullptr;
     if (packed) {
-        cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
         // records: always for a caller that knows (scattered); for a large system otherwise when the last sample of this (N, grid) said so
         if (!scattered && N >= (int64_t(1) << 18)) {
             const OrderHint h = order_hint(1, N, g.ncell, x);
             scattered = h.word && *(volatile int *)h.word != 0;
             if (h.word && h.sample) rec_flag = h.word;
         }
+        // input in some spatial order: no sorted copy, the kernels read through `order` (CellGrid::ix); MDH_INDIRECT=0 /
+        // mdh_debug_set_indirect(0): the records always — an A/B switch, and how the tests reach both paths on one input
+        // (not for dense cells — six atoms and more, the wide instance's ground: two workgroups per CU hide the staging's
+        // dependent gathers badly, build_neighbor(5.0, 50) at 10 M atoms 4.48 -> 4.60 ms; profiles/r06_cell_grid_ab.txt)
+        const bool indirect = g_indirect.load(std::memory_order_relaxed) != 0 && !scattered && (double)N <= 6.0 * (double)g.ncell;
+        if (!indirect) cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
         if (scattered) rec = sc.alloc_n<CellGrid::Packed>((size_t)N);
     } else {
         cg.xs = sc.alloc_n<double>((size_t)N);
@@ -764,7 +777,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     static const int assign_k_env = [] { const char *e = std::getenv("MDH_ASSIGN_K"); return e ? std::atoi(e) : 0; }();
     // (measured at 10 M atoms: 145 -> 120 us on a lattice, 162 -> 162 on a polycrystal — 10 M runs of one atom, the atomics' own
     // throughput — 413 -> 440 on a shuffled frame, which therefore keeps one: profiles/r05_assign_k.txt)
-    const int assign_k = assign_k_env > 0 ? assign_k_env : ((N >= (int64_t)1 << 20 && !rec) ? 4 : 1);
+    const int assign_k = assign_k_env > 0 ? assign_k_env : ((N >= (int64_t)1 << 20 && !scattered) ? 4 : 1);
 #define MDH_ASSIGN(TRI, K) hipLaunchKernelGGL((k_assign<TRI, K>), dim3(grid_for(N, 256 * K)), dim3(256), 0, st, x, y, z, N, b, g, (int)wrap_first, cell_id, rank, cell_count, ctl, gen, slack, mv, win, rec, packed ? 1 : 0)
     if (b.tri) {
         if (assign_k >= 4) MDH_ASSIGN(true, 4); else if (assign_k >= 2) MDH_ASSIGN(true, 2); else MDH_ASSIGN(true, 1);
@@ -823,7 +836,8 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     }
     // (the atoms binned = the grid's total, on the device: all N unless absent atoms were handed in or a window's promise was broken)
     const int *n_binned = cg.cell_start + g.ncell;
-    if (rec) hipLaunchKernelGGL(k_gather_records, dim3(grid_for(N, 256)), dim3(256), 0, st, rec, cg.order, cg.pk, N, n_binned);
+    if (packed && !cg.pk) { cg.ix = x; cg.iy = y; cg.iz = z; cg.imv = mv; } // indirect: nothing is gathered
+    else if (rec) hipLaunchKernelGGL(k_gather_records, dim3(grid_for(N, 256)), dim3(256), 0, st, rec, cg.order, cg.pk, N, n_binned);
     else hipLaunchKernelGGL(k_gather, dim3(grid_for(N, 256)), dim3(256), 0, st, x, y, z, cg.order, cg.xs, cg.ys, cg.zs, N, mv, cg.mvs, cg.pk, cg.flags + 4, n_binned);
     MDH_HIP(hipGetLastError());
     return MDH_OK;
@@ -1653,6 +1667,8 @@ int mdh_debug_set_neighbor_variant(int v)
     g_neighbor_variant = v;
     return MDH_OK;
 }
+
+int mdh_debug_set_indirect(int on) { return g_indirect.exchange(on ? 1 : 0); }
 
 int mdh_neighbor_count(const double *x, const double *y, const double *z, int64_t N, const double *box9,
                        const double *origin3, const int *boundary3, double rc, int *nn, int *max_count, int space,

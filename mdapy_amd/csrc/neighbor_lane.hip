@@ -393,6 +393,23 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
         }
 }
 
+// Where a tile's atoms come from.  Records (pk): the cell-sorted 32-byte records of k_gather / k_gather_records — two 16-byte
+// reads per atom.  IND (CellGrid::ix, input that comes in some spatial order): no sorted copy exists; atom q of the cell order is
+// atom order[q] of the caller's arrays — the id, then x, y, z (and the image code, where any atom has one) of that atom.  The
+// staging pays four small gathers per atom, three tiles stage every atom (0.05-0.09 ms at 10 M atoms); the grid build is
+// k_gather shorter (0.13 ms, 623 MB written and read back): profiles/r06_cell_grid_ab.txt.
+struct IndirectSrc { const double *x, *y, *z; const unsigned short *mv; const int *order; };
+template <bool IND>
+__device__ __forceinline__ CellGrid::Packed load_record(const CellGrid::Packed *__restrict__ pk, const IndirectSrc &src, int q, int coded)
+{
+    if (!IND)
+        return pk[q];
+    const int id = src.order[q];
+    // (unconditional: a branch around a load is followed by a wait for it; without image codes every lane reads mv[0])
+    const int code = src.mv[coded ? id : 0];
+    return CellGrid::Packed{src.x[id], src.y[id], src.z[id], id, coded ? code : (int)img::ATOM_NEUTRAL};
+}
+
 // COUNT: nn and the largest count only (first pass of the exact-width variant)
 // parent != nullptr: second pass over the tiles the first pass listed (halo over the LDS budget): the same tiling cut into
 // nsub slices along z (this launch's TZ = parent's TZ / nsub); what still does not fit goes to `flagged` (counter
@@ -413,7 +430,8 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
 // only): tiles of up to 512 halo cells, two workgroups per CU — the same sixteen waves per CU, but a tile of 6 x 6 x 5 cells
 // stages 2.5 halo cells per centre cell instead of 3.15, its per-wave front phases serve twice the centres, and its ~440 centres
 // fill seven chunks of 64 better than ~196 fill three or four
-template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8, int NW = 4>
+// IND: the atoms are read through the cell-sorted id list from the caller's arrays (load_record)
+template <bool COUNT, bool TRI, bool LOOP, bool FCNA, bool TK8, int NW = 4, bool IND = false>
 #ifdef MDH_FCNA_F64
 #define MDH_FCNA_LEAN false // the double-precision pair tests of the fused label need ~175 VGPRs: three workgroups per CU
 #else
@@ -428,9 +446,10 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
     int nt1, int nt2, Shape ts, const int *__restrict__ tile_list, const int *__restrict__ n_live, int list_mode,
     int *__restrict__ max_count, int *__restrict__ flagged, const int *__restrict__ parent, int parent_nt2, int nsub,
     int flag_slot, int *__restrict__ pattern, int *__restrict__ cna_todo, int jt0, int rw, int tile_base, int *__restrict__ listed_sink,
-    int cen_lo, int cen_hi)
+    int cen_lo, int cen_hi, IndirectSrc isrc)
 {
     const int TXY = ts.txy, TZ = ts.tz;
+    const int coded = IND ? flags[4] : 0; // (uniform) some atom was handed in outside the box: the image codes are read as well
     const int HXY = TXY + 2, HZ = TZ + 2, NH = HXY * HXY * HZ;
     constexpr int CENC = cen_cap(NW);
 
@@ -535,7 +554,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int q = h.cnt > 0 ? h.src + min(v, h.cnt - 1) : 0;
-            const CellGrid::Packed a = pk[q];
+            const CellGrid::Packed a = load_record<IND>(pk, isrc, q, coded);
             ra[v] = a.x; rb[v] = a.y; rc4[v] = a.z; rd[v] = a.id; rm[v] = a.code;
         }
     };
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
                         if (k == 0) { a[v] = pa[v]; bb[v] = pb[v]; c[v] = pc[v]; d[v] = pd[v]; m[v] = pm[v]; }
                         else {
                             const int q = src + min(k + v, cnt - 1);
-                            const CellGrid::Packed r = pk[q];
+                            const CellGrid::Packed r = load_record<IND>(pk, isrc, q, coded);
                             a[v] = r.x; bb[v] = r.y; c[v] = r.z; d[v] = r.id; m[v] = r.code;
                         }
                     }
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { // (unconditional: past the cell's end the last atom again, never staged)
                         const int q = src + min(k + 4 + v, cnt - 1);
-                        const CellGrid::Packed r = pk[q];
+                        const CellGrid::Packed r = load_record<IND>(pk, isrc, q, coded);
                         na[v] = r.x; nb[v] = r.y; nc[v] = r.z; nd[v] = r.id; nm[v] = r.code;
                     }
                     stage4(k, a, bb, c, d, m);
@@ -1517,14 +1536,21 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
     // every build went into 1024 workgroups that found an empty list
     const dim3 grid2(plan.last_listed == 0 ? 64u : 1024u);
     const Shape ts2 = make_shape(ts.txy, 1, nt[1], nt2b);
+    const bool indirect = !cg.pk; // CellGrid::ix
+    const lane::IndirectSrc isrc{cg.ix, cg.iy, cg.iz, cg.imv, cg.order};
+#define MDH_LANE_PASS_I(COUNT, TRI, LOOP, FCNA, TK8, NW, IND, GRID, JT0, ...)                                                             \
+    do {                                                                                                                                  \
+        if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW, IND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW, IND>), GRID, dim3((NW) * 64), lds, st, cg.pk, cg.cell_start, b, \
+                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base, plan.listed_sink, \
+                           cen_lo, cen_hi, isrc); \
+    } while (0)
 #define MDH_LANE_PASS(COUNT, TRI, LOOP, FCNA, TK8, NW, GRID, JT0, ...)                                                                         \
     do {                                                                                                                                  \
         const size_t lds = (NW) == 8 ? lds1 : lds2;                                                                                       \
-        if (lds > 60 * 1024) /* above the default dynamic-LDS limit: raise it for the instance about to run */                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_neighbor_lane<COUNT, TRI, LOOP, FCNA, TK8, NW>), GRID, dim3((NW) * 64), lds, st, cg.pk, cg.cell_start, b, \
-                           cg.g, rc, negc, plan.T, verlet, dist, nn, Mi, wp, plan.cap, cg.flags, nullptr, __VA_ARGS__, pattern, tf.cna_todo, JT0, plan.rw, tile_base, plan.listed_sink, \
-                           cen_lo, cen_hi); \
+        if (indirect) MDH_LANE_PASS_I(COUNT, TRI, LOOP, FCNA, TK8, NW, true, GRID, JT0, __VA_ARGS__);                                     \
+        else MDH_LANE_PASS_I(COUNT, TRI, LOOP, FCNA, TK8, NW, false, GRID, JT0, __VA_ARGS__);                                             \
     } while (0)
     // first pass: one tile per workgroup — all tiles, or the list of live ones, whose length only the device knows: the grid
     // is cut for the expected number and a walked launch stands by for what a longer list leaves over (it leaves at once
@@ -1558,6 +1584,7 @@ int launch_neighbor_lane(Scope &sc, const CellGrid &cg, const LanePlan &plan, in
         else { if (b.tri) MDH_LANE_LAUNCH(false, true, false, false); else MDH_LANE_LAUNCH(false, false, false, false); }
     }
 #undef MDH_LANE_PASS
+#undef MDH_LANE_PASS_I
 #undef MDH_LANE_LAUNCH
 #undef MDH_LANE_LAUNCH_NW
     MDH_HIP(hipGetLastError());

@@ -6,6 +6,7 @@ Bars: bit-exact for integer outputs (neighbor ids, counts, labels, histogram cou
 arithmetic is IEEE-exact — for distances; 1e-6 relative for floating-point outputs (CSP, q_l, g(r)).
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -634,6 +635,48 @@ def test_fused_labels_sheared_and_wide_instances_vs_oracle(case):
     pe = np.zeros(n, np.int32)
     ve, de, ne = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, org, bnd, rc, 1, pattern=pe)
     assert np.array_equal(ne, c) and np.array_equal(ve, v) and np.array_equal(de, d) and np.array_equal(pe, want), name
+
+
+def test_neighbor_builds_from_the_cell_sorted_records_vs_oracle():
+    """A neighbor build of input that comes in some spatial order keeps no cell-sorted copy of the atoms (CellGrid::ix: its kernels
+    read them through the cell-sorted id list) — the default, asserted here, and so what every other test of this file runs.  With
+    mdh_debug_set_indirect(0) the same calls go through the 32-byte records of k_gather, the path unordered input takes: the rows
+    (and fused labels) of both are the oracle's bit for bit — periodic and open, orthogonal and sheared boxes, atoms handed in
+    outside the box (image codes), unwrapped trajectories, dense cells (the wide instance), the mop-up kernels
+    (src/neighbor.cpp:64-187)."""
+    from mdapy_amd import _lib
+
+    L = _lib.lib()
+    prev = L.mdh_debug_set_indirect(0)
+    try:
+        assert prev == 1 or os.environ.get("MDH_INDIRECT") == "0"
+        for case in CASES:
+            for rc in (3.0, 4.4):
+                test_neighbor_bit_exact_vs_oracle(case, rc)
+        test_unwrapped_input_takes_the_tile_kernel()
+        test_neighbor_tile_overflow_and_variants()
+        for kind in ("fcc_rattled_shifted", "gas", "triclinic"):
+            test_neighbor_dense_cells_take_the_wide_tile_kernel(kind)
+        test_neighbor_rows_of_65_to_128_slots_take_the_wide_tile_kernel("fcc_rc6_rattled_narrow")
+        test_fused_neighbor_fcna_equals_the_two_calls()
+        for case in _fcna_cases():
+            test_fused_labels_single_precision_pair_tests_vs_oracle(case)
+        for case in _fcna_wide_and_sheared_cases():
+            test_fused_labels_sheared_and_wide_instances_vs_oracle(case)
+        test_neighbor_cell_window_hint_same_rows_and_broken_promise_is_reported()
+    finally:
+        L.mdh_debug_set_indirect(prev)
+    # and one system large enough for the build's own order sample (>= 2^18 atoms): in lattice order (indirect) and shuffled
+    # (the sample sends the NEXT build of this (N, grid) to the records), both against the oracle
+    pos, box = _fcc(42, 0.05, 11)  # 296 352 atoms
+    rc = 3.3
+    for shuffled in (False, True):
+        p = pos[np.random.default_rng(5).permutation(len(pos))] if shuffled else pos
+        x, y, z = _xyz(p)
+        v0, d0, n0 = O.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 8)
+        for _ in range(3):
+            v1, d1, n1 = _neighbor.build_neighbor_without_max_neigh(x, y, z, box, ORG0, PBC, rc, 1)
+            assert np.array_equal(n1, n0) and np.array_equal(v1, v0) and np.array_equal(d1, d0), shuffled
 
 
 def test_fused_labels_where_the_tile_kernel_does_not_apply():

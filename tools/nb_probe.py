@@ -49,6 +49,10 @@ buf = ctypes.create_string_buffer(1 << 16); L.mdh_prof_report(buf, len(buf))
 print("plan txy,tz,cap,lds,full|tk8<<1|wgs<<2,pop*1000,occ,fresh:", list(plan))
 print(buf.value.decode().strip(), "N", n, "env", {k: v for k, v in os.environ.items() if k.startswith("MDH_")}, flush=True)
 
+if os.environ.get("NB_SUM"):  # a fingerprint of the rows: two builds of the library (NB_LIB) must print the same three numbers
+    w = torch.arange(1, M + 1, device=dev, dtype=torch.int64)[None, :]
+    print("rows fingerprint:", int((verlet.long() * w).sum()), int(nn.long().sum()), float((dist * w).sum()), flush=True)
+
 if hasattr(L, "mdh_debug_lane_stamps"):  # experiment builds only (-DMDH_STAMPS): phase stamps of the first 51200 tiles
     nt = 51200
     st = np.zeros(nt * 8, dtype=np.uint64)
