@@ -7,7 +7,9 @@ own CNA tests and SURVEY.md 6 use) and fixed-cutoff CNA, through the C ABI of li
 round 5 as ONE call (mdh_build_neighbor_fcna: the lists as build_neighbor leaves them AND the labels as fcna leaves them, the
 label of a centre worked out inside the tile kernel while its neighbours are still staged in LDS; what
 `System.cal_common_neighbor_analysis(rc)` runs when the system has no list yet).  `extra.two_calls` times the same step as the
-two calls it was until then (mdh_build_neighbor, then mdh_fcna), with the plain neighbour kernel's own roofline figure.  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling, the default) — or,
+two calls it was until then (mdh_build_neighbor, then mdh_fcna), with the plain neighbour kernel's own roofline figure; `extra.records_path`
+the one call with the atoms gathered into cell-sorted records first (rounds 1-5; from round 6 on a build of spatially ordered input keeps no
+sorted copy and the tile kernel reads the atoms through the cell-sorted id list: a faster step, a slower tile kernel).  At N GPUs every rank owns a 136^3-cell slab of a (136 N) x 136 x 136-cell box (weak scaling, the default) — or,
 with --scaling strong, a 136/N-cell slab of the one 136^3 box — and exchanges a one-cutoff ghost halo with its two ring
 neighbours over RCCL each step.
 
@@ -659,12 +661,13 @@ def main():
                 if live is not None:
                     traffic, traffic_raw, source = 2.0 * live[0] + live[1], live[0] + live[1], "live"
             if traffic is None:
-                tpath = os.path.join(ROOT, "profiles", "r05_traffic.json")
+                tpath = os.path.join(ROOT, "profiles", "r06_traffic.json")
                 if os.path.exists(tpath) and cells == 136 and M == 16 and world == 1 and args.sigma == 0.0:
                     with open(tpath) as fh:
                         t = json.load(fh)
                     traffic, traffic_raw, source = t["traffic_bytes_per_launch_fetch_x2"], t["traffic_bytes_per_launch_raw"], "committed"
-            res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor (k_neighbor_lane, the instance that also labels: lists + CNA in one pass)",
+            res["roofline"] = {"bound": "hbm", "kernel": "k_neighbor (k_neighbor_lane, the instance that also labels: lists + CNA in one pass; from round 6 it also gathers "
+                                                           "the atoms through the cell-sorted id list — k_gather's work, on unchanged algorithmic bytes: extra.records_path has the kernel of rounds 1-5)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw_fetch_plus_write": traffic_raw,
                                "traffic_source": source, "avg_kernel_ms": avg_ms, "launches": cnt,
@@ -688,6 +691,27 @@ def main():
                     extra["two_calls"]["plain_neighbor_kernel_roofline"] = {"achieved": a0, "frac": a0 / HBM_PEAK_GBS, "alg_B_per_atom": 28 + 12 * M}
             except Exception as e:
                 extra["two_calls"] = {"error": f"{type(e).__name__}: {e}"}
+
+            # (0') the same one call with the atoms gathered into cell-sorted 32-byte records first (mdh_debug_set_indirect(0): the path
+            # of rounds 1-5, and what unordered input still takes).  From round 6 on a build of spatially ordered input keeps no sorted
+            # copy: k_gather is gone from the cell grid and the tile kernel reads the atoms through the cell-sorted id list — a faster
+            # step, and a slower tile kernel on the same algorithmic bytes (the roofline object above is that kernel's)
+            try:
+                from mdapy_amd import _lib as _l
+                k = max(5, args.steps // 2)
+                prev = _l.lib().mdh_debug_set_indirect(0)
+                try:
+                    e1, o1, p1 = timed(step, k, 3)
+                finally:
+                    _l.lib().mdh_debug_set_indirect(prev)
+                km1 = {k_: v_[1] / v_[0] for k_, v_ in p1.items()}
+                extra["records_path"] = {"ms_per_step": e1 / k * 1e3, "kernels_ms": km1, "ratio_default_to_records": ms_per_step / (e1 / k * 1e3),
+                                         "what": "mdh_debug_set_indirect(0): cell grid incl. k_gather (32-byte records), tile kernel staging from the records"}
+                if "k_neighbor" in km1:
+                    a1 = (28 + 12 * M + 4) * n_local / (km1["k_neighbor"] * 1e-3) / 1e9
+                    extra["records_path"]["tile_kernel_roofline"] = {"achieved": a1, "frac": a1 / HBM_PEAK_GBS, "alg_B_per_atom": 28 + 12 * M + 4}
+            except Exception as e:
+                extra["records_path"] = {"error": f"{type(e).__name__}: {e}"}
 
             # (a) the default API path: max_neigh=None -> exact-width rows, counting pass + build on one cell grid (and the labels
             # in the pass that builds: mdh_build_neighbor_exact_fcna)

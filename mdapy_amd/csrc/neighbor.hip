@@ -699,7 +699,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         // mdh_debug_set_indirect(0): the records always — an A/B switch, and how the tests reach both paths on one input
         // (not for dense cells — six atoms and more, the wide instance's ground: two workgroups per CU hide the staging's
         // dependent gathers badly, build_neighbor(5.0, 50) at 10 M atoms 4.48 -> 4.60 ms; profiles/r06_cell_grid_ab.txt)
-        const bool indirect = g_indirect.load(std::memory_order_relaxed) != 0 && !scattered && (double)N <= 6.0 * (double)g.ncell;
+        const bool indirect = g_indirect.load(std::memory_order_relaxed) != 0 && !scattered && sort_desc && (double)N <= 6.0 * (double)g.ncell;
         if (!indirect) cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
         if (scattered) rec = sc.alloc_n<CellGrid::Packed>((size_t)N);
     } else {

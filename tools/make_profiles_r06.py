@@ -121,8 +121,8 @@ if "bench" in what:
                         f"{(rf['traffic'] or 0) / 1e9:.3f} GB per launch, FETCH doubled, vs {rf['algorithmic_bytes_per_launch'] / 1e9:.3f} GB algorithmic), then the same command "
                         "(`--no-extra --no-pmc --no-cpu-baseline`) under the kernel trace, whose table follows.\n\n"
                         "The tile kernel (the instance with the fused CNA: it writes the lists and the labels) is launched twice per build (all tiles, then the one-cell slices of the "
-                        "tiles whose halo overflowed LDS: an empty stand-by on this input).  The headline step's kernels did not change in round 6 (the round went into configs 2 "
-                        "and 4, the k-nearest search and the decomposed step).\n\n| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n")
+                        "tiles whose halo overflowed LDS: an empty stand-by on this input).  Round 6: `k_gather` is gone from the cell grid (a build of spatially ordered input keeps no cell-sorted copy of the atoms); "
+                        "the tile kernel — the `..., true>` instance — reads them through the cell-sorted id list instead and is 0.06-0.09 ms slower for it (`r06_cell_grid_ab.txt`).\n\n| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n")
                 for k, (c, a, mn, mx) in sorted(bs.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:16]:
                     f.write(f"| `{k}` | {c} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} |\n")
     merged = {}
