@@ -138,6 +138,8 @@ struct RdfWave { // LDS of one wave
     int start[RDF_NB + 2], src[RDF_NB];
     unsigned nq, pad;
     unsigned char etype[64];
+    float4 cbuf[128];        // candidates that can reach a centre, waiting for a full wave of them: ux, uy, uz, bits of the position
+    unsigned cinfo[128];     // their type | (1 << 8 when they belong to the centre cell itself)
 };
 static_assert(sizeof(RdfWave) % 16 == 0, "RdfWave keeps float4 alignment");
 
@@ -246,27 +248,41 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                 W.etype[lane] = (unsigned char)type[order[q]];
             }
             wsync();
-            for (int gbase = 0; gbase < ncand_all; gbase += 64) {
-                const int gv = gbase + lane; // this lane's candidate: atom gv of the 14 cells laid end to end
-                const bool valid = gv < ncand_all;
-                int k = 0;
-                if (valid)
-                    while (gv >= W.start[k + 1]) ++k;
-                const int qj = valid ? W.src[k] + (gv - W.start[k]) : W.src[0];
-                double xj = xs[qj], yj = ys[qj], zj = zs[qj];
-                if (b.anypbc)
-                    wrap<TRI>(b, xj, yj, zj);
-                const float ux = (float)(xj - W.lo[k][0]) + W.shift[k][0], uy = (float)(yj - W.lo[k][1]) + W.shift[k][1],
-                            uz = (float)(zj - W.lo[k][2]) + W.shift[k][2];
-                const unsigned tj = (unsigned)type[order[qj]];
-                const bool same_cell = k == 0;
+            // The centres' bounding box (in the centre cell's frame; an atom clamped into an edge cell from outside an open box may lie
+            // outside the cell): a candidate farther than the cutoff from the BOX reaches no centre — 24 % of the atoms of the 14
+            // cells of rc-wide cells (the cells' corners and edges beyond the rounded box of volume 20.6 rc^3 of 27).  Its distance to
+            // the box is worked out per axis with the subtraction of the pair test, squared and summed as the pair test does: rounding
+            // is monotone, so the bound is never above the r2 the pair test would find and no pair is lost.  The candidates that
+            // pass are gathered into full waves (ballot, mbcnt, LDS), and the centre loop runs once per FULL wave of them.
+            float blo[3], bhi[3];
+            {
+                const float4 ce = W.cen[lane < ncen ? lane : 0];
+                blo[0] = bhi[0] = ce.x; blo[1] = bhi[1] = ce.y; blo[2] = bhi[2] = ce.z;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        blo[c] = fminf(blo[c], __shfl_xor(blo[c], d, 64));
+                        bhi[c] = fmaxf(bhi[c], __shfl_xor(bhi[c], d, 64));
+                    }
+            }
+            const float reach2 = rc2f * (1.0f + 1.0e-4f * tol_scale);
+            int nbuf = 0; // candidates waiting in W.cbuf (the same number in every lane)
+            auto pair_up = [&](int nact) { // the first nact (<= 64) waiting candidates against every centre of the chunk
+                const bool valid = lane < nact;
+                const float4 cb = W.cbuf[lane];
+                const unsigned info = W.cinfo[lane];
+                const float ux = cb.x, uy = cb.y, uz = cb.z;
+                const int qj = __float_as_int(cb.w);
+                const unsigned tj = info & 255u;
+                const bool same_cell = (info >> 8) != 0u;
                 for (int c = 0; c < ncen; ++c) {
                     const float4 ce = W.cen[c]; // one address for the whole wavefront: a broadcast read
                     const float dx = ux - ce.x, dy = uy - ce.y, dz = uz - ce.z;
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const int qi = __float_as_int(ce.w);
                     // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
-                    const bool hit = valid && r2 < rc2f * (1.0f + 1.0e-4f * tol_scale) && !(same_cell && qj <= qi) && probe == 0;
+                    const bool hit = valid && r2 < reach2 && !(same_cell && qj <= qi) && probe != 1;
                     const unsigned long long hm = __ballot(hit);
                     if (hm == 0)
                         continue;
@@ -286,7 +302,46 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                         nhit = rest;
                     }
                 }
+            };
+            for (int gbase = 0; gbase < ncand_all; gbase += 64) {
+                const int gv = gbase + lane; // this lane's candidate: atom gv of the 14 cells laid end to end
+                const bool valid = gv < ncand_all;
+                int k = 0;
+                if (valid)
+                    while (gv >= W.start[k + 1]) ++k;
+                const int qj = valid ? W.src[k] + (gv - W.start[k]) : W.src[0];
+                double xj = xs[qj], yj = ys[qj], zj = zs[qj];
+                if (b.anypbc)
+                    wrap<TRI>(b, xj, yj, zj);
+                const float ux = (float)(xj - W.lo[k][0]) + W.shift[k][0], uy = (float)(yj - W.lo[k][1]) + W.shift[k][1],
+                            uz = (float)(zj - W.lo[k][2]) + W.shift[k][2];
+                const unsigned tj = (unsigned)type[order[qj]];
+                // distance to the centres' box, axis by axis as the pair test subtracts (candidate minus centre): never above a pair's
+                const float ex = fmaxf(fmaxf(ux - bhi[0], blo[0] - ux), 0.0f), ey = fmaxf(fmaxf(uy - bhi[1], blo[1] - uy), 0.0f),
+                            ez = fmaxf(fmaxf(uz - bhi[2], blo[2] - uz), 0.0f);
+                const float box2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                const bool keep = valid && (box2 < reach2 || probe == 2); // (probe 2, a measuring switch: nobody is left out)
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const int at = nbuf + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u));
+                    W.cbuf[at] = make_float4(ux, uy, uz, __int_as_float(qj));
+                    W.cinfo[at] = tj | (k == 0 ? 256u : 0u);
+                }
+                nbuf += __popcll(km);
+                if (nbuf >= 64) { // a full wave of candidates
+                    wsync();
+                    pair_up(64);
+                    const int rest = nbuf - 64;
+                    float4 mv = W.cbuf[lane];
+                    unsigned mi = W.cinfo[lane];
+                    if (lane < rest) { mv = W.cbuf[64 + lane]; mi = W.cinfo[64 + lane]; }
+                    wsync();
+                    if (lane < rest) { W.cbuf[lane] = mv; W.cinfo[lane] = mi; }
+                    nbuf = rest;
+                }
             }
+            wsync();
+            if (nbuf > 0) pair_up(nbuf); // what is left
         }
         wsync(); // what is left on the wave's list
         if (lane < nhit) bin_hit(W.hitq[lane]);

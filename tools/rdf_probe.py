@@ -16,7 +16,7 @@ ty = np.repeat([1, 2], [int(round(0.64 * n)), n - int(round(0.64 * n))]).astype(
 np.random.default_rng(42).shuffle(ty)
 s = mp.System(pos=pos, box=box); s.update_data(s.data.with_columns(type=ty))
 L = _lib.lib()
-for probe in ("0", "1", "0", "1"):
+for probe in (os.environ.get("RDF_PROBES", "0,1,0,1").split(",")):
     os.environ["MDH_RDF_PROBE"] = probe
     s.cal_radial_distribution_function(8.0, nbin=200, streaming=True)
     L.mdh_prof_reset(); L.mdh_prof_enable(1)
