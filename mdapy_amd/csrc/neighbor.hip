@@ -29,6 +29,10 @@ namespace mdh {
 static int *g_moved_probe = nullptr; // pinned: flags[0] of the last tracked neighbor pass (mdh_debug_track_counters)
 // 1: neighbor builds of input in spatial order keep no sorted copy of the atoms (CellGrid::ix); 0: the 32-byte records always
 static std::atomic<int> g_indirect{[] { const char *e = std::getenv("MDH_INDIRECT"); return e ? std::atoi(e) : 1; }()};
+// Row width of the build the NEXT packed cell grid of this thread is for (0: not known).  Rows of more than 16 slots go to the tile
+// kernel's wide instance, which hides the indirect staging's gathers badly (two or three workgroups per CU): such a build keeps
+// the records (the 12-nearest search's cutoff build, 4.7 atoms per cell, rows of 24: 2.15 ms with records, 2.22 without)
+static thread_local int g_next_rows = 0;
 int g_neighbor_variant = 0; // 0 = automatic, 1 = force the thread-per-atom kernel, 2 = force the round-1 LDS-tiled kernel (A/B measurements, tests)
 
 // ----------------------------------------------------------------------------
@@ -699,7 +703,8 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
         // mdh_debug_set_indirect(0): the records always — an A/B switch, and how the tests reach both paths on one input
         // (not for dense cells — six atoms and more, the wide instance's ground: two workgroups per CU hide the staging's
         // dependent gathers badly, build_neighbor(5.0, 50) at 10 M atoms 4.48 -> 4.60 ms; profiles/r06_cell_grid_ab.txt)
-        const bool indirect = g_indirect.load(std::memory_order_relaxed) != 0 && !scattered && sort_desc && (double)N <= 6.0 * (double)g.ncell;
+        const bool indirect = g_indirect.load(std::memory_order_relaxed) != 0 && !scattered && sort_desc && (double)N <= 6.0 * (double)g.ncell && g_next_rows <= 16;
+        g_next_rows = 0;
         if (!indirect) cg.pk = sc.alloc_n<CellGrid::Packed>((size_t)N);
         if (scattered) rec = sc.alloc_n<CellGrid::Packed>((size_t)N);
     } else {
@@ -1523,6 +1528,7 @@ int neighbor_rows_device(Scope &sc, const double *dx, const double *dy, const do
 {
     CellGrid cg;
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
+    g_next_rows = (int)std::min<int64_t>(M, 1 << 20);
     MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     // pads written (the tile kernel then stores whole 16-byte groups; leaving the pads out measured SLOWER: 2.96 against 2.54 ms
     // at 10 M atoms, rc 3.8, 24 slots); distances wanted or not (rows of more than 16 slots: the wide instance skips them)
@@ -1584,6 +1590,7 @@ int mdh_build_neighbor_keyed(const double *x, const double *y, const double *z, 
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", sc.stream());
+        g_next_rows = (int)std::min<int64_t>(max_neigh, 1 << 20);
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
     {
@@ -1620,6 +1627,7 @@ int mdh_build_neighbor_fcna(const double *x, const double *y, const double *z, i
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", sc.stream());
+        g_next_rows = (int)std::min<int64_t>(max_neigh, 1 << 20);
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
     bool fused = false;
@@ -1744,6 +1752,7 @@ int mdh_build_neighbor_exact_fcna(const double *x, const double *y, const double
     MDH_TRY(neighbor_grid_dims(b, rc, cg.g));
     {
         ProfRange pr("cell_grid", st);
+        g_next_rows = width_hint(N, cg.g.ncell, -1); // the width the last build of this (N, grid) found (0: none yet)
         MDH_TRY(build_cell_grid(sc, dx, dy, dz, N, b, true, true, cg, dkey, true));
     }
     // the labels of a build: inside the tile kernel where that ran (its leftovers listed in todo), from the finished rows otherwise
