@@ -276,21 +276,22 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
                 const int qj = __float_as_int(cb.w);
                 const unsigned tj = info & 255u;
                 const bool same_cell = (info >> 8) != 0u;
-                for (int c = 0; c < ncen; ++c) {
+                const int ncen_u = __builtin_amdgcn_readfirstlane(ncen); // (the same in every lane: a scalar trip count, no exec-mask loop)
+                for (int c = 0; c < ncen_u; ++c) {
                     const float4 ce = W.cen[c]; // one address for the whole wavefront: a broadcast read
                     const float dx = ux - ce.x, dy = uy - ce.y, dz = uz - ce.z;
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const int qi = __float_as_int(ce.w);
                     // pairs inside the cell once: candidate after centre (and never the atom itself, :240)
                     const bool hit = valid && r2 < reach2 && !(same_cell && qj <= qi) && probe != 1;
-                    const unsigned long long hm = __ballot(hit);
+                    const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
                     if (hm == 0)
                         continue;
                     if (hit) {
                         const int at = nhit + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
                         W.hitq[at] = RdfHit{r2, (unsigned)qi, (unsigned)qj, (unsigned)W.etype[c] | (tj << 8)};
                     }
-                    nhit += __popcll(hm);
+                    nhit = __builtin_amdgcn_readfirstlane(nhit + (int)__popcll(hm)); // (kept in a scalar register: the test below is a scalar branch)
                     if (nhit >= 64) { // a full wave of hits: bin them, move the rest down
                         wsync();
                         bin_hit(W.hitq[lane]);
