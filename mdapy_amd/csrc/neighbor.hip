@@ -682,7 +682,7 @@ int build_cell_grid(Scope &sc, const double *x, const double *y, const double *z
     cg.cell_start = sc.alloc_n<int>((size_t)g.ncell + 1);
     int *cell_id = sc.alloc_n<int>((size_t)N);
     int *rank = sc.alloc_n<int>((size_t)N);
-    cg.order = sc.alloc_n<int>((size_t)N);
+    cg.order = sc.alloc_n<int>((size_t)N + 4); // (four spare entries: the tile kernel reads a cell's first four ids as one 16-byte request)
     unsigned short *mv = sc.alloc_n<unsigned short>((size_t)N);
     cg.xs = cg.ys = cg.zs = nullptr;
     cg.mvs = nullptr;

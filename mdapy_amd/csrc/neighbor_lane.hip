@@ -399,15 +399,21 @@ __device__ __forceinline__ void quad_transpose(int (&P)[4][4], int odd1, int odd
 // staging pays four small gathers per atom, three tiles stage every atom (0.05-0.09 ms at 10 M atoms); the grid build is
 // k_gather shorter (0.13 ms, 623 MB written and read back): profiles/r06_cell_grid_ab.txt.
 struct IndirectSrc { const double *x, *y, *z; const unsigned short *mv; const int *order; };
+__device__ __forceinline__ CellGrid::Packed load_atom(const IndirectSrc &src, int id, int coded)
+{
+    // the image code only where some atom of the call has one (`coded` is the same in every lane, and nearly always 0: the branch
+    // is jumped over, the wait the compiler puts behind a guarded load is never reached)
+    int code = (int)img::ATOM_NEUTRAL;
+    if (coded) code = src.mv[id];
+    return CellGrid::Packed{src.x[id], src.y[id], src.z[id], id, code};
+}
+struct __attribute__((packed, aligned(4))) Ids4 { int v[4]; }; // four consecutive ids of the cell order as ONE 16-byte request (any 4-byte address)
 template <bool IND>
 __device__ __forceinline__ CellGrid::Packed load_record(const CellGrid::Packed *__restrict__ pk, const IndirectSrc &src, int q, int coded)
 {
     if (!IND)
         return pk[q];
-    const int id = src.order[q];
-    // (unconditional: a branch around a load is followed by a wait for it; without image codes every lane reads mv[0])
-    const int code = src.mv[coded ? id : 0];
-    return CellGrid::Packed{src.x[id], src.y[id], src.z[id], id, coded ? code : (int)img::ATOM_NEUTRAL};
+    return load_atom(src, src.order[q], coded);
 }
 
 // COUNT: nn and the largest count only (first pass of the exact-width variant)
@@ -551,10 +557,13 @@ __global__ __launch_bounds__(NW * 64, (TK8 && (!FCNA || (MDH_FCNA_LEAN && !LOOP)
     // copy registers behind an s_waitcnt right after the loads, and the latency is paid before the scan after all; a thread
     // without atoms loads record 0 and never looks at it)
     auto request = [&](const Halo &h, double (&ra)[4], double (&rb)[4], double (&rc4)[4], int (&rd)[4], int (&rm)[4]) {
+        Ids4 ids{};
+        if (IND) ids = *reinterpret_cast<const Ids4 *>(isrc.order + h.src); // (order[] has four spare entries behind its last atom)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int q = h.cnt > 0 ? h.src + min(v, h.cnt - 1) : 0;
-            const CellGrid::Packed a = load_record<IND>(pk, isrc, q, coded);
+            // (IND: a slot past the cell's end repeats its first atom; a cell without atoms reads atom 0)
+            const CellGrid::Packed a = IND ? load_atom(isrc, v < h.cnt ? ids.v[v] : (h.cnt > 0 ? ids.v[0] : 0), coded) : load_record<false>(pk, isrc, q, coded);
             ra[v] = a.x; rb[v] = a.y; rc4[v] = a.z; rd[v] = a.id; rm[v] = a.code;
         }
     };
