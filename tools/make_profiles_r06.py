@@ -37,7 +37,7 @@ if "analyses" in what:
     N3, N5 = 10061824, 9841500
     # (kernel, atoms, algorithmic bytes per atom, what the bytes are)
     ALG = [
-        ("lane::k_neighbor_lane<false, false, false, false, false, 4>", N3, 24 + 4 + 4 * 24, "the cutoff build behind the k-nearest searches (and the rc = 0.85 a / rc = 3.6 lists): positions in, count + ids out (ids only for the searches; 24-32 slots)"),
+        ("lane::k_neighbor_lane<false, false, false, false, false, 4, false>", N3, 24 + 4 + 4 * 24, "the cutoff build behind the k-nearest searches (and the rc = 0.85 a / rc = 3.6 lists): positions in, count + ids out (ids only for the searches; 24-32 slots)"),
         ("k_knn_rows<false, 18, 32, false>", N3, 24 + 4 + 4 * 32 + 12 * 18, "k = 18: wrapped positions, count, row of 32 ids in; ids 4k + distances 8k out"),
         ("k_knn_rows<false, 12, 24, false>", N3, 24 + 4 + 4 * 24 + 12 * 12, "k = 12"),
         ("k_knn_rows<false, 14, 28, false>", N3, 24 + 4 + 4 * 28 + 12 * 14, "k = 14"),
