@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_rdf_tile(const double *__restrict__ xs,
 {
     // probe (a measuring switch, MDH_RDF_PROBE=1, tools/rdf_probe.py): 1 = no pair is ever "inside the cutoff" — the kernel walks
     // and tests every pair as always and bins nothing: what the candidate walk and the distance tests cost by themselves
+    // 2 = no candidate is dropped by the bounding-box test below (what the cull is worth; same counts)
     extern __shared__ __attribute__((aligned(16))) unsigned char rdf_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t hsize = hsize_of(ntype, nbin);
