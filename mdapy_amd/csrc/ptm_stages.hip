@@ -199,7 +199,7 @@ template <class P> __device__ bool face_solid_angle_2d_regs(int i, int n, const 
         }
         prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2]; nprev = ncur;
     }
-    *out = sa < 2e-12 ? 0.0 : sa;
+    *out = (sa < ptmc::SLIVER_SR && ptmc::poly_width2(poly, m) < ptmc::SLIVER_WIDTH) ? 0.0 : sa; // (ptm_core.hpp: a needle where a plane grazes the cell is no face)
     return true;
 }
 
