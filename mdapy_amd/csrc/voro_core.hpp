@@ -178,7 +178,19 @@ PTM_HDN FaceResult2 voronoi_face_2d(P &poly, int f, int nc, const double (*nrm)[
     return r;
 }
 
-// faces smaller than this fraction of the squared plane distance are rounding debris of a plane that only touches the cell
-constexpr double AREA_TOL = 1e-14;
+// Does voro++ have this face?  A plane that only touches the cell — through an edge or a vertex of a perfect lattice's cell — makes
+// no face there (its vertex tolerance snaps the contact onto the plane) where exact clipping leaves a needle; a plane that really
+// cuts a corner off makes one however small.  Until round 6 the rule was an area (below 1e-14 d^2 = debris), which miscounts the
+// faces of 5 % of the atoms of a lattice rattled by 1e-6 A and now and then one of an ordinary system (profiles/r06_fuzz.txt);
+// the two kinds differ in WIDTH by five orders of magnitude (ptm_core.hpp SLIVER_WIDTH), not in area.
+constexpr double SLIVER_WIDTH = 1e-11; // (needles <= 2.2e-15 A, kept slivers >= 2.8e-10 A: tools/voro_sliver_scan.py)
+template <class P> PTM_HD bool face_exists(const FaceResult2 &r, const P &poly, double d)
+{
+    if (!(r.area > 0.0) || r.nv < 3)
+        return false;
+    if (r.area >= 1e-8 * d * d)
+        return true;
+    return ptmc::poly_width2(poly, r.nv) >= SLIVER_WIDTH;
+}
 
 } // namespace voroc

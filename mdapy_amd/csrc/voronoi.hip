@@ -133,7 +133,7 @@ __global__ __launch_bounds__(VORO_LANES) void k_voronoi(const double *__restrict
                     r = voroc::voronoi_face_2d(slow, f, nc, nrm, off, dist, 6, big);
                     in_slow = true;
                 }
-                if (!r.overflow && r.area > voroc::AREA_TOL * dist[f] * dist[f]) {
+                if (!r.overflow && (in_slow ? voroc::face_exists(r, slow, dist[f]) : voroc::face_exists(r, fast, dist[f]))) {
                     vol += r.area * dist[f] / 3.0;
                     ++nf;
                     mr2 = fmax(mr2, r.maxr2);

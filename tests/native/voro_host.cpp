@@ -42,7 +42,7 @@ extern "C" int voroh_run(const double *x, const double *y, const double *z, int6
             ptmc::PolyLocal poly;
             FaceResult2 r = voronoi_face_2d(poly, f, nc, (const double(*)[3])nrm.data(), off.data(), dist.data(), first_sorted, big); // the form the device runs
             if (r.overflow) return -2;
-            if (r.area > AREA_TOL * dist[f] * dist[f]) { vol += r.area * dist[f] / 3.0; ++nf; mr2 = std::max(mr2, r.maxr2); }
+            if (face_exists(r, poly, dist[f])) { vol += r.area * dist[f] / 3.0; ++nf; mr2 = std::max(mr2, r.maxr2); }
         }
         volume[i] = vol; nfaces[i] = nf; radius[i] = std::sqrt(mr2);
         if (2 * radius[i] > rc) ++*incomplete;
